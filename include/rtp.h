@@ -1,0 +1,211 @@
+/* rtp.h -- C ABI of librtp_hip.so, the MI355X (gfx950) kernel library behind rt_pose_amd.
+ *
+ * Drop-in boundary.  The reference reaches its arithmetic through two doors:
+ *   (1) torch.nn modules (Conv3d / GroupNorm / interpolate / losses) built by the det3d registry
+ *       -- det3d/models/backbones/hr_util/common.py:40,57, hr_util/hr3d.py:83-90,147-224,
+ *          det3d/models/pose_heads/center_head.py:86-93,240-360, det3d/models/losses/centernet_loss.py:17-54.
+ *       Those have no native ABI in the reference; the entry points in section A/B/C below are what the
+ *       Python host mirror (rt_pose_amd/modules.py, registered under the same registry names) binds.
+ *   (2) the pybind module `deform_conv_cuda` (det3d/ops/dcn/src/deform_conv_cuda.cpp:687-701), five
+ *       functions taking at::Tensor.  Section D declares their C-ABI replacements one for one.
+ *
+ * Conventions: plain pointers + sizes, no torch types; every pointer is DEVICE memory unless
+ * marked host; the callee never allocates, never synchronises, launches on `stream` (hipStream_t
+ * passed as void*), is re-entrant, and returns 0 or a negative RTP_ERR_* code (no exceptions
+ * cross the boundary).  Activations are bf16, channels-last: [N][D][H][W][C] with an optional
+ * channel stride/offset so a kernel can read or write a channel slice of a wider buffer.
+ */
+#ifndef RTP_H_
+#define RTP_H_
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RTP_OK 0
+#define RTP_ERR_SHAPE (-1)       /* inconsistent or unsupported geometry */
+#define RTP_ERR_UNSUPPORTED (-2) /* channel count / kernel size this build has no kernel for */
+#define RTP_ERR_LAUNCH (-3)      /* hipGetLastError() after the launch */
+#define RTP_ERR_ALIGN (-4)       /* pointer or channel offset not 16-byte aligned */
+
+#define RTP_MAX_TERMS 6
+
+/* A channels-last activation (or gradient) tensor view. */
+typedef struct RtpAct {
+  void* ptr;   /* bf16 unless a kernel says fp32 */
+  int cs;      /* channel stride: elements per voxel in the underlying buffer */
+  int co;      /* first channel of the view */
+  int c;       /* channels in the view */
+} RtpAct;
+
+/* Geometry of one convolution (forward orientation). */
+typedef struct RtpConvGeom {
+  int n;
+  int di, hi, wi; /* input  spatial dims */
+  int dov, ho, wo; /* output spatial dims */
+  int ci, co;     /* logical channels (ci multiple of 32 after padding; co padded to 16) */
+  int ks;         /* 1 or 3 (cubic) */
+  int stride;     /* 1 or 2 */
+  int pad;        /* 0 (ks=1) or 1 (ks=3) */
+  int w_ci_total; /* the fp32 weight tensor is [co][w_ci_total][ks^3]; this conv uses input channels   */
+  int w_ci_off;   /* [w_ci_off, w_ci_off+ci_real) of it (0,0 = the whole tensor; final_conv chunks)   */
+} RtpConvGeom;
+
+/* ---------------------------------------------------------------- A. convolution family --- */
+
+/* Per-channel sums for GroupNorm statistics and for the GN backward reductions.
+ *   b == NULL : out[n][s][c][0] = sum_v a, [1] = sum_v a*a
+ *   b != NULL : out[n][s][c][0] = sum_v a, [1] = sum_v a*b
+ * out: fp32 [n][nsplit][c][2]; deterministic (fixed voxel->split assignment, no atomics).
+ * Replaces the statistics half of torch.nn.GroupNorm (hr_util/common.py:57). */
+int rtp_chan_stats(const RtpAct* a, const RtpAct* b, int n, long vox, int nsplit, float* out, void* stream);
+
+/* Fold GroupNorm into per-sample conv weights (+ boundary-class bias table) and emit mean/rstd.
+ *   w      fp32 [co][ci][ks^3]  (reference nn.Conv3d layout), bias fp32 [co] or NULL
+ *   gamma/beta fp32 [ci] or NULL (no norm); stats = rtp_chan_stats output of the conv INPUT or NULL
+ *   wf     bf16 [nw][ks^3][co_pad][ci_pad]   nw = n with norm, 1 without
+ *   btab   fp32 [nw][64][co_pad]  bias for each boundary class of an output voxel
+ *   mr     fp32 [n][groups][2]  (mean, rstd) saved for backward, or NULL
+ * Replaces GroupNorm-apply + weight layout of common.py:25-71 / hr3d.py:147-155. */
+int rtp_fold_fwd(const float* w, const float* bias, const float* gamma, const float* beta, const float* stats,
+                 int nsplit, int groups, float eps, const RtpConvGeom* g, int ci_real, int co_real, void* wf,
+                 float* btab, float* mr, void* stream);
+
+/* Pack weights for the data-gradient conv: wd bf16 [ks^3][ci_pad][cok] with cok = co rounded up to 32. */
+int rtp_pack_dgrad_w(const float* w, const RtpConvGeom* g, int ci_real, int co_real, void* wd, void* stream);
+
+/* Implicit-GEMM convolution on MFMA (v_mfma_f32_16x16x32_bf16).
+ *   transposed == 0 : y = conv(x; wf) + btab[class] (+ res) (ReLU)
+ *   transposed == 1 : y = conv_transpose(x; wf) i.e. the data gradient of a forward conv with geometry g
+ *                     (x is then the output-side gradient, y the input-side gradient; no bias)
+ * y_fp32: store fp32 instead of bf16 (head logits).  Replaces nn.Conv3d forward/backward-data
+ * (common.py:40, hr3d.py:149-197, center_head.py:86-93). */
+int rtp_conv_igemm(const RtpAct* x, const void* wf, int w_per_sample, const float* btab, const RtpAct* res,
+                   const RtpAct* y, const RtpConvGeom* g, int relu, int transposed, int y_fp32, void* stream);
+
+/* Weight-gradient correlation: gp[n][s][tap][co32][ci_pad] (fp32 partial slabs, s = voxel split) =
+ * sum over the split's output voxels of gy[v][co] * x[v*stride + tap - pad][ci].  Replaces
+ * nn.Conv3d backward-weight. */
+int rtp_wgrad(const RtpAct* gy, const RtpAct* x, const RtpConvGeom* g, int nsplit, float* gp, void* stream);
+
+/* Per boundary-class channel sums of an output-side gradient: out fp32 [n][nsplit][64][c]. */
+int rtp_class_sums(const RtpAct* gy, int n, int d, int h, int w, int nsplit, float* out, void* stream);
+
+/* Finish the weight gradient: reduce slabs, undo the GroupNorm fold, write reference-layout fp32 grads.
+ *   dw[co][ci][tap] (+)= sum_n scale[n][ci] * sum_s gp + shift[n][ci] * sum_{classes where tap in-bounds} csum
+ *   dbias[co] (+)= sum of csum over all classes (if dbias != NULL) */
+int rtp_wgrad_fold(const float* gp, int nsplit, const float* csum, int csplit, const float* mr, const float* gamma,
+                   const float* beta, int groups, const RtpConvGeom* g, int ci_real, int co_real, float* dw,
+                   float* dbias, int accumulate, void* stream);
+
+/* GroupNorm backward coefficients from pq = rtp_chan_stats(dxhat, x):
+ *   coeff[n][c] = (A, B, C) with  dx = A*dxhat + B*x + C ;  dgamma/dbeta (+)= per-channel param grads. */
+int rtp_gn_bwd_coeffs(const float* pq, int nsplit, const float* mr, const float* gamma, int n, int c, int groups,
+                      long vox, float* coeff, float* dgamma, float* dbeta, int accumulate, void* stream);
+
+/* ---------------------------------------------------------------- B. point-wise family --- */
+
+typedef struct RtpTerm {
+  RtpAct t;          /* DIRECT: the addend.  GN: dxhat */
+  const float* coeff; /* NULL = DIRECT term, else GN-backward coefficients [n][c][3] */
+  int d, h, w;       /* spatial dims of the term (fuse_sum: low-res terms are upsampled) */
+} RtpTerm;
+
+/* out = mask(relu_src > 0) * sum_k term_k ; GN terms evaluate A*dxhat + B*x + C.  All same resolution. */
+int rtp_grad_combine(const RtpTerm* terms /*host*/, int nterms, const RtpAct* x, const RtpAct* relu_src,
+                     const RtpAct* out, int n, long vox, void* stream);
+
+/* out = (relu) sum_k up(term_k): trilinear align_corners=True upsample for terms whose dims differ
+ * (hr3d.py:205-229, hrnet3d.py:37-39). bias fp32 [c] or NULL. */
+int rtp_fuse_sum(const RtpTerm* terms /*host*/, int nterms, const float* bias, const RtpAct* out, int n, int d, int h,
+                 int w, int relu, void* stream);
+
+/* Adjoint of the trilinear upsample: glow[n][dl][hl][wl][c] = up^T(ghi). */
+int rtp_upsample_bwd(const RtpAct* ghi, int d, int h, int w, const RtpAct* glow, int dl, int hl, int wl, int n,
+                     void* stream);
+
+/* layer1.conv1 when Cin == 1 (common.py:111-113): y[v][c] = x[v]*w[c] + b[c]; x fp32 [n][vox]. */
+int rtp_stem_fwd(const float* x, const float* w, const float* b, const RtpAct* y, int n, long vox, void* stream);
+/* dw[c] (+)= sum x*g, db[c] (+)= sum g ; scratch fp32 [nblk][c][2] with nblk = rtp_stem_bwd_blocks(). */
+int rtp_stem_bwd(const float* x, const RtpAct* gy, int n, long vox, float* scratch, float* dw, float* db,
+                 int accumulate, void* stream);
+int rtp_stem_bwd_blocks(void);
+
+/* NCDHW fp32 -> channels-last bf16 (network input with Cin in {32,64}) and back (feature export). */
+int rtp_pack_ncdhw(const float* x, const RtpAct* y, int n, int c, long vox, void* stream);
+int rtp_unpack_ncdhw(const RtpAct* x, float* y, int n, int c, long vox, void* stream);
+
+/* ---------------------------------------------------------------- C. head: loss / decode / optimiser --- */
+
+/* FastFocalLoss forward+backward (centernet_loss.py:34-54, center_head.py:240-242).
+ *   logits fp32 [n][vox][cpad]; target fp32 NCDHW [n][ncls][vox]; ind/cat int64 [n][m]; mask uint8 [n][m]
+ *   scratch fp32 [rtp_focal_blocks()]; out_loss[0] = hm_loss (fp32, device); ghm bf16 view: d(gscale*hm_loss)/dlogits */
+int rtp_focal_loss(const float* logits, int cpad, const float* target, const long long* ind, const unsigned char* mask,
+                   const long long* cat, int n, int ncls, long vox, int m, float gscale, float* scratch,
+                   float* out_loss, const RtpAct* ghm, void* stream);
+int rtp_focal_blocks(void);
+
+/* RegLoss forward+backward (centernet_loss.py:17-24, center_head.py:252-258).
+ *   reg fp32 [n][vox][cpad]; target fp32 [n][m][nreg]; code_w fp32 [nreg]
+ *   out[0..nreg) = per-channel loss, out[nreg] = loc_loss; greg (bf16, pre-zeroed by this call) gets
+ *   gscale * weight * d loc_loss / d reg. */
+int rtp_reg_loss(const float* reg, int cpad, const float* target, const long long* ind, const unsigned char* mask,
+                 const float* code_w, int n, int nreg, long vox, int m, float gscale, float* out,
+                 const RtpAct* greg, void* stream);
+
+/* sigmoid -> per-channel first-index argmax -> offset decode (center_head.py:272-360).
+ *   scale_xyz / origin_xyz: HOST fp32[3] = (out_size_factor*voxel_size, pc_range) per x,y,z
+ *   scratch fp32 [rtp_decode_scratch_floats(n,ncls)]
+ *   out fp32 [n][ncls][2 + nreg] = (argmax voxel index, score, x0,y0,z0, x1,...) */
+int rtp_decode(const float* logits, int hm_cpad, const float* reg, int reg_cpad, int n, int ncls, int nreg, int d,
+               int h, int w, const float* scale_xyz, const float* origin_xyz, float* scratch, float* out,
+               void* stream);
+int rtp_decode_scratch_floats(int n, int ncls);
+
+/* Global grad-norm partials and the fused clip + decoupled-weight-decay + Adam step over a flat fp32
+ * parameter buffer (fastai_optim.py:154-172, hooks/optimizer.py:14-24, torch.optim.Adam).
+ *   hyper (device fp32[10]) = {lr, beta1, beta2, eps, wd, max_norm, 1-beta1^t, 1-beta2^t, grad_scale, -}
+ *   mode 0: clip+decay+Adam;  mode 1: decay only (parameters that received no gradient);
+ *   norm_out (device, optional) receives the pre-clip global L2 norm. */
+int rtp_sqnorm(const float* g, long n, const float* hyper, float* partial /*[rtp_sqnorm_blocks()]*/, void* stream);
+int rtp_sqnorm_blocks(void);
+int rtp_adam_step(float* p, const float* g, float* m, float* v, long n, const float* hyper,
+                  const float* sqnorm_partial, int mode, float* norm_out, void* stream);
+
+/* ---------------------------------------------------------------- D. deformable convolution --- */
+/* One-for-one replacements of deform_conv_cuda.cpp:152-157, 262-268, 376-381, 490-496, 571-578.
+ * Tensors are contiguous NCHW fp32 as in the reference; `columns`/`ones` scratch is replaced by
+ * an explicit workspace (size from rtp_dcn_workspace_bytes).  Argument order keeps the reference's
+ * (kW,kH,dW,dH,padW,padH,dilW,dilH) W-before-H convention. */
+long rtp_dcn_workspace_bytes(int n, int c, int h, int w, int co, int kh, int kw, int ho, int wo);
+int rtp_deform_conv_forward(const float* input, const float* weight, const float* offset, float* output, void* ws,
+                            int n, int c, int h, int w, int co, int kW, int kH, int dW, int dH, int padW, int padH,
+                            int dilW, int dilH, int group, int deformable_group, int im2col_step, void* stream);
+int rtp_deform_conv_backward_input(const float* input, const float* offset, const float* gradOutput, float* gradInput,
+                                   float* gradOffset, const float* weight, void* ws, int n, int c, int h, int w,
+                                   int co, int kW, int kH, int dW, int dH, int padW, int padH, int dilW, int dilH,
+                                   int group, int deformable_group, int im2col_step, void* stream);
+int rtp_deform_conv_backward_parameters(const float* input, const float* offset, const float* gradOutput,
+                                        float* gradWeight, void* ws, int n, int c, int h, int w, int co, int kW, int kH,
+                                        int dW, int dH, int padW, int padH, int dilW, int dilH, int group,
+                                        int deformable_group, float scale, int im2col_step, void* stream);
+int rtp_modulated_deform_conv_forward(const float* input, const float* weight, const float* bias, const float* offset,
+                                      const float* mask, float* output, void* ws, int n, int c, int h, int w, int co,
+                                      int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw, int group,
+                                      int deformable_group, int with_bias, void* stream);
+int rtp_modulated_deform_conv_backward(const float* input, const float* weight, const float* bias, const float* offset,
+                                       const float* mask, float* grad_input, float* grad_weight, float* grad_bias,
+                                       float* grad_offset, float* grad_mask, const float* grad_output, void* ws, int n,
+                                       int c, int h, int w, int co, int kh, int kw, int sh, int sw, int ph, int pw,
+                                       int dh, int dw, int group, int deformable_group, int with_bias, void* stream);
+
+/* ---------------------------------------------------------------- E. diagnostics --- */
+/* Per-kernel-family HIP-event timing on the launch stream (bench.py roofline leg). */
+int rtp_prof_enable(int family, int on);
+int rtp_prof_collect(int family, float* total_ms, int* launches); /* synchronises the recorded events */
+const char* rtp_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTP_H_ */

@@ -1,0 +1,102 @@
+"""ctypes binding of librtp_hip.so (the C ABI declared in include/rtp.h).
+
+Fails loudly: a missing library raises at import of the symbols, a non-zero return code raises RtpError.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "librtp_hip.so")
+
+RTP_MAX_TERMS = 6
+
+# kernel families for rtp_prof_* (csrc/rtp_prof.h)
+FAM_CONV, FAM_CONV_TILED, FAM_WGRAD, FAM_POINTWISE, FAM_NORM, FAM_LOSS, FAM_OPTIM, FAM_DCN = range(8)
+
+_ERR = {-1: "RTP_ERR_SHAPE", -2: "RTP_ERR_UNSUPPORTED", -3: "RTP_ERR_LAUNCH", -4: "RTP_ERR_ALIGN"}
+
+
+class RtpError(RuntimeError):
+    pass
+
+
+class RtpAct(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("cs", C.c_int), ("co", C.c_int), ("c", C.c_int)]
+
+
+class RtpConvGeom(C.Structure):
+    _fields_ = [("n", C.c_int), ("di", C.c_int), ("hi", C.c_int), ("wi", C.c_int), ("dov", C.c_int), ("ho", C.c_int),
+                ("wo", C.c_int), ("ci", C.c_int), ("co", C.c_int), ("ks", C.c_int), ("stride", C.c_int),
+                ("pad", C.c_int), ("w_ci_total", C.c_int), ("w_ci_off", C.c_int)]
+
+
+class RtpTerm(C.Structure):
+    _fields_ = [("t", RtpAct), ("coeff", C.c_void_p), ("d", C.c_int), ("h", C.c_int), ("w", C.c_int)]
+
+
+_P = C.c_void_p
+_I = C.c_int
+_L = C.c_long
+_F = C.c_float
+_A = C.POINTER(RtpAct)
+_G = C.POINTER(RtpConvGeom)
+_T = C.POINTER(RtpTerm)
+
+# name -> argtypes (restype int unless listed in _RESTYPE)
+PROTOTYPES = {
+    "rtp_chan_stats": [_A, _A, _I, _L, _I, _P, _P],
+    "rtp_fold_fwd": [_P, _P, _P, _P, _P, _I, _I, _F, _G, _I, _I, _P, _P, _P, _P],
+    "rtp_pack_dgrad_w": [_P, _G, _I, _I, _P, _P],
+    "rtp_conv_igemm": [_A, _P, _I, _P, _A, _A, _G, _I, _I, _I, _P],
+    "rtp_wgrad": [_A, _A, _G, _I, _P, _P],
+    "rtp_class_sums": [_A, _I, _I, _I, _I, _I, _P, _P],
+    "rtp_wgrad_fold": [_P, _I, _P, _I, _P, _P, _P, _I, _G, _I, _I, _P, _P, _I, _P],
+    "rtp_gn_bwd_coeffs": [_P, _I, _P, _P, _I, _I, _I, _L, _P, _P, _P, _I, _P],
+    "rtp_grad_combine": [_T, _I, _A, _A, _A, _I, _L, _P],
+    "rtp_fuse_sum": [_T, _I, _P, _A, _I, _I, _I, _I, _I, _P],
+    "rtp_upsample_bwd": [_A, _I, _I, _I, _A, _I, _I, _I, _I, _P],
+    "rtp_stem_fwd": [_P, _P, _P, _A, _I, _L, _P],
+    "rtp_stem_bwd": [_P, _A, _I, _L, _P, _P, _P, _I, _P],
+    "rtp_stem_bwd_blocks": [],
+    "rtp_pack_ncdhw": [_P, _A, _I, _I, _L, _P],
+    "rtp_unpack_ncdhw": [_A, _P, _I, _I, _L, _P],
+    "rtp_focal_loss": [_P, _I, _P, _P, _P, _P, _I, _I, _L, _I, _F, _P, _P, _A, _P],
+    "rtp_focal_blocks": [],
+    "rtp_reg_loss": [_P, _I, _P, _P, _P, _P, _I, _I, _L, _I, _F, _P, _A, _P],
+    "rtp_decode": [_P, _I, _P, _I, _I, _I, _I, _I, _I, _I, C.POINTER(_F), C.POINTER(_F), _P, _P, _P],
+    "rtp_decode_scratch_floats": [_I, _I],
+    "rtp_sqnorm": [_P, _L, _P, _P, _P],
+    "rtp_sqnorm_blocks": [],
+    "rtp_adam_step": [_P, _P, _P, _P, _L, _P, _P, _I, _P, _P],
+    "rtp_prof_enable": [_I, _I],
+    "rtp_prof_collect": [_I, C.POINTER(_F), C.POINTER(_I)],
+    "rtp_version": [],
+}
+_RESTYPE = {"rtp_version": C.c_char_p}
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once).  Raises if it has not been built -- there is no fallback path."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RtpError("%s not found: run `python -m rt_pose_amd.build` (hipcc, gfx950). "
+                           "rt_pose_amd has no CPU fallback." % LIB_PATH)
+        lib = C.CDLL(LIB_PATH)
+        for name, argtypes in PROTOTYPES.items():
+            fn = getattr(lib, name)  # AttributeError if the symbol is missing
+            fn.argtypes = argtypes
+            fn.restype = _RESTYPE.get(name, C.c_int)
+        _lib = lib
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RtpError("%s failed: %s (%d)" % (what, _ERR.get(rc, "?"), rc))
+
+
+def act(ptr, cs, co, c):
+    return RtpAct(ptr, cs, co, c)

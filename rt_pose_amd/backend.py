@@ -1,0 +1,215 @@
+"""HipBackend: binds the graph's kernel calls to librtp_hip.so through ctypes.
+
+PyTorch is used only for device memory (torch.zeros / torch.empty on cuda:N) and for the stream handle; every
+method marshals its arguments ONCE and returns a closure f(stream_ptr) that performs the launch.
+There is deliberately no CPU path here: constructing the backend without a GPU or without the built library
+raises.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import RtpAct, RtpConvGeom, RtpTerm, check
+
+_DT = {"bf16": torch.bfloat16, "f32": torch.float32, "i64": torch.int64, "u8": torch.uint8}
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _act(v):
+    if v is None:
+        return None
+    return RtpAct(v.buf.data_ptr(), v.cs, v.co, v.c)
+
+
+def _geom(g):
+    return RtpConvGeom(g.n, g.di, g.hi, g.wi, g.do, g.ho, g.wo, g.ci, g.co, g.ks, g.stride, g.pad, g.w_ci_total,
+                       g.w_ci_off)
+
+
+class HipBackend:
+    name = "hip"
+
+    def __init__(self, device=None):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise _lib.RtpError("rt_pose_amd needs an MI355X (no GPU visible) -- there is no CPU fallback")
+        self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
+        self.bytes = 0
+
+    # -------------------------------------------------------------- memory (plumbing)
+    def alloc(self, shape, dtype):
+        t = torch.zeros(shape, dtype=_DT[dtype], device=self.device)
+        self.bytes += t.numel() * t.element_size()
+        return t
+
+    def stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def stem_bwd_blocks(self):
+        return self.lib.rtp_stem_bwd_blocks()
+
+    # -------------------------------------------------------------- conv family
+    def chan_stats(self, a, b, nsplit, out):
+        fn, aa, bb, o = self.lib.rtp_chan_stats, _act(a), _act(b), _ptr(out)
+        n, vox = a.n, a.vox
+        keep = (a, b, out)
+        return lambda s: check(fn(aa, bb, n, vox, nsplit, o, s), "rtp_chan_stats") or keep and None
+
+    def fold_fwd(self, w, bias, gamma, beta, stats, nsplit, groups, eps, geom, ci_real, co_real, wf, btab, mr):
+        fn, g = self.lib.rtp_fold_fwd, _geom(geom)
+        args = (_ptr(w), _ptr(bias), _ptr(gamma), _ptr(beta), _ptr(stats), nsplit, groups, eps, g, ci_real, co_real,
+                _ptr(wf), _ptr(btab), _ptr(mr))
+        keep = (w, bias, gamma, beta, stats, wf, btab, mr)
+        return lambda s: check(fn(*args, s), "rtp_fold_fwd") or keep and None
+
+    def pack_dgrad_w(self, w, geom, ci_real, co_real, wd):
+        fn, g = self.lib.rtp_pack_dgrad_w, _geom(geom)
+        args = (_ptr(w), g, ci_real, co_real, _ptr(wd))
+        keep = (w, wd)
+        return lambda s: check(fn(*args, s), "rtp_pack_dgrad_w") or keep and None
+
+    def conv(self, x, wf, per_sample, btab, res, y, geom, relu, transposed, y_fp32):
+        fn, g = self.lib.rtp_conv_igemm, _geom(geom)
+        args = (_act(x), _ptr(wf), int(per_sample), _ptr(btab), _act(res), _act(y), g, int(relu), int(transposed),
+                int(y_fp32))
+        keep = (x, wf, btab, res, y)
+        return lambda s: check(fn(*args, s), "rtp_conv_igemm") or keep and None
+
+    def wgrad(self, gy, x, geom, nsplit, gp):
+        fn, g = self.lib.rtp_wgrad, _geom(geom)
+        args = (_act(gy), _act(x), g, nsplit, _ptr(gp))
+        keep = (gy, x, gp)
+        return lambda s: check(fn(*args, s), "rtp_wgrad") or keep and None
+
+    def class_sums(self, gy, nsplit, out):
+        fn = self.lib.rtp_class_sums
+        args = (_act(gy), gy.n, gy.d, gy.h, gy.w, nsplit, _ptr(out))
+        keep = (gy, out)
+        return lambda s: check(fn(*args, s), "rtp_class_sums") or keep and None
+
+    def wgrad_fold(self, gp, nsplit, csum, csplit, mr, gamma, beta, groups, geom, ci_real, co_real, dw, dbias, acc):
+        fn, g = self.lib.rtp_wgrad_fold, _geom(geom)
+        args = (_ptr(gp), nsplit, _ptr(csum), csplit, _ptr(mr), _ptr(gamma), _ptr(beta), groups, g, ci_real, co_real,
+                _ptr(dw), _ptr(dbias), int(acc))
+        keep = (gp, csum, mr, gamma, beta, dw, dbias)
+        return lambda s: check(fn(*args, s), "rtp_wgrad_fold") or keep and None
+
+    def gn_bwd_coeffs(self, pq, nsplit, mr, gamma, n, c, groups, vox, coeff, dgamma, dbeta, acc):
+        fn = self.lib.rtp_gn_bwd_coeffs
+        args = (_ptr(pq), nsplit, _ptr(mr), _ptr(gamma), n, c, groups, vox, _ptr(coeff), _ptr(dgamma), _ptr(dbeta),
+                int(acc))
+        keep = (pq, mr, gamma, coeff, dgamma, dbeta)
+        return lambda s: check(fn(*args, s), "rtp_gn_bwd_coeffs") or keep and None
+
+    # -------------------------------------------------------------- point-wise family
+    @staticmethod
+    def _terms(terms, with_dims):
+        arr = (RtpTerm * len(terms))()
+        for i, t in enumerate(terms):
+            v, coeff = t if isinstance(t, tuple) else (t, None)
+            arr[i].t = _act(v)
+            arr[i].coeff = coeff.data_ptr() if coeff is not None else None
+            arr[i].d, arr[i].h, arr[i].w = (v.d, v.h, v.w) if with_dims else (0, 0, 0)
+        return arr
+
+    def grad_combine(self, terms, x, relu_src, out):
+        fn, arr = self.lib.rtp_grad_combine, self._terms(terms, False)
+        args = (arr, len(terms), _act(x), _act(relu_src), _act(out), out.n, out.vox)
+        keep = (terms, x, relu_src, out)
+        return lambda s: check(fn(*args, s), "rtp_grad_combine") or keep and None
+
+    def fuse_sum(self, terms, bias, out, relu):
+        fn, arr = self.lib.rtp_fuse_sum, self._terms(terms, True)
+        args = (arr, len(terms), _ptr(bias), _act(out), out.n, out.d, out.h, out.w, int(relu))
+        keep = (terms, bias, out)
+        return lambda s: check(fn(*args, s), "rtp_fuse_sum") or keep and None
+
+    def upsample_bwd(self, ghi, glow):
+        fn = self.lib.rtp_upsample_bwd
+        args = (_act(ghi), ghi.d, ghi.h, ghi.w, _act(glow), glow.d, glow.h, glow.w, ghi.n)
+        keep = (ghi, glow)
+        return lambda s: check(fn(*args, s), "rtp_upsample_bwd") or keep and None
+
+    def stem_fwd(self, x, w, b, y):
+        fn = self.lib.rtp_stem_fwd
+        args = (_ptr(x), _ptr(w), _ptr(b), _act(y), y.n, y.vox)
+        keep = (x, w, b, y)
+        return lambda s: check(fn(*args, s), "rtp_stem_fwd") or keep and None
+
+    def stem_bwd(self, x, gy, scratch, dw, db, acc):
+        fn = self.lib.rtp_stem_bwd
+        args = (_ptr(x), _act(gy), gy.n, gy.vox, _ptr(scratch), _ptr(dw), _ptr(db), int(acc))
+        keep = (x, gy, scratch, dw, db)
+        return lambda s: check(fn(*args, s), "rtp_stem_bwd") or keep and None
+
+    def pack_ncdhw(self, x, y, c):
+        fn = self.lib.rtp_pack_ncdhw
+        args = (_ptr(x), _act(y), y.n, c, y.vox)
+        keep = (x, y)
+        return lambda s: check(fn(*args, s), "rtp_pack_ncdhw") or keep and None
+
+    def unpack_ncdhw(self, x, y, c):
+        fn = self.lib.rtp_unpack_ncdhw
+        args = (_act(x), _ptr(y), x.n, c, x.vox)
+        keep = (x, y)
+        return lambda s: check(fn(*args, s), "rtp_unpack_ncdhw") or keep and None
+
+    # -------------------------------------------------------------- head: loss / decode / optimiser
+    def focal_scratch(self, n):
+        return self.alloc((n * self.lib.rtp_focal_blocks() * 2,), "f32")
+
+    def focal_loss(self, logits, target, ind, mask, cat, ncls, gscale, scratch, out_loss, ghm):
+        fn = self.lib.rtp_focal_loss
+        n, vox, m = logits.n, logits.vox, ind.shape[1]
+        args = (_ptr(logits.buf), logits.cs, _ptr(target), _ptr(ind), _ptr(mask), _ptr(cat), n, ncls, vox, m,
+                float(gscale), _ptr(scratch), _ptr(out_loss), _act(ghm))
+        keep = (logits, target, ind, mask, cat, scratch, out_loss, ghm)
+        return lambda s: check(fn(*args, s), "rtp_focal_loss") or keep and None
+
+    def reg_loss(self, reg, target, ind, mask, code_w, nreg, gscale, out, greg):
+        fn = self.lib.rtp_reg_loss
+        n, vox, m = reg.n, reg.vox, ind.shape[1]
+        args = (_ptr(reg.buf), reg.cs, _ptr(target), _ptr(ind), _ptr(mask), _ptr(code_w), n, nreg, vox, m,
+                float(gscale), _ptr(out), _act(greg))
+        keep = (reg, target, ind, mask, code_w, out, greg)
+        return lambda s: check(fn(*args, s), "rtp_reg_loss") or keep and None
+
+    def decode_scratch(self, n, ncls):
+        return self.alloc((self.lib.rtp_decode_scratch_floats(n, ncls),), "f32")
+
+    def decode(self, hm, reg, ncls, nreg, scale_xyz, origin_xyz, scratch, out):
+        fn = self.lib.rtp_decode
+        sc = (C.c_float * 3)(*scale_xyz)
+        og = (C.c_float * 3)(*origin_xyz)
+        args = (_ptr(hm.buf), hm.cs, _ptr(reg.buf), reg.cs, hm.n, ncls, nreg, hm.d, hm.h, hm.w, sc, og, _ptr(scratch),
+                _ptr(out))
+        keep = (hm, reg, scratch, out, sc, og)
+        return lambda s: check(fn(*args, s), "rtp_decode") or keep and None
+
+    def sqnorm_blocks(self):
+        return self.lib.rtp_sqnorm_blocks()
+
+    def sqnorm(self, g, n, hyper, partial):
+        fn = self.lib.rtp_sqnorm
+        args = (_ptr(g), n, _ptr(hyper), _ptr(partial))
+        keep = (g, hyper, partial)
+        return lambda s: check(fn(*args, s), "rtp_sqnorm") or keep and None
+
+    def adam_step(self, p, g, m, v, n, hyper, partial, mode, norm_out):
+        fn = self.lib.rtp_adam_step
+        args = (_ptr(p), _ptr(g), _ptr(m), _ptr(v), n, _ptr(hyper), _ptr(partial), mode, _ptr(norm_out))
+        keep = (p, g, m, v, hyper, partial, norm_out)
+        return lambda s: check(fn(*args, s), "rtp_adam_step") or keep and None
+
+    # -------------------------------------------------------------- diagnostics
+    def prof_enable(self, family, on=True):
+        check(self.lib.rtp_prof_enable(family, int(on)), "rtp_prof_enable")
+
+    def prof_collect(self, family):
+        ms, cnt = C.c_float(0), C.c_int(0)
+        check(self.lib.rtp_prof_collect(family, C.byref(ms), C.byref(cnt)), "rtp_prof_collect")
+        return ms.value, cnt.value

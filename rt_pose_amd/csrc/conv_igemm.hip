@@ -1,0 +1,183 @@
+// Implicit-GEMM 3-D convolution on MFMA for channels-last bf16 activations (gfx950).
+//
+// GEMM view: M = output voxels, N = Cout, K = taps * Cin.  One v_mfma_f32_16x16x32_bf16
+// contracts the 32 channels of one tap:  A = weights [16 cout][32 cin],  B = activations [32 cin][16 voxels]
+// so the accumulator holds, per lane, 4 consecutive output channels of one voxel (an 8-byte bf16 store).
+//
+// This file holds the GENERIC kernel: any Cin multiple of 32, Cout multiple of 16, ks in {1,3}, stride in
+// {1,2}, normal or transposed (data-gradient) indexing; the B operand is gathered straight from global/L2.
+// The LDS-tiled kernel for the full-resolution 32->32 layers lives in conv_tiled.hip.
+#include "rtp_common.h"
+#include "rtp_prof.h"
+
+struct ConvParams {
+  const bf16_t* x;
+  const bf16_t* w;
+  const float* btab;
+  const bf16_t* res;
+  void* y;
+  int N, Di, Hi, Wi, Do, Ho, Wo;
+  int Ci, Co;  // padded: Ci % 32 == 0, Co % 16 == 0
+  int ks, stride, pad, transposed;
+  int x_cs, x_co, y_cs, y_co, r_cs, r_co;
+  int relu, y_fp32;
+  long w_sample_stride;  // elements between per-sample weight sets (0 = shared)
+  int Vo;                // Do*Ho*Wo
+  int blocks_per_sample;
+};
+
+// NT = number of 16-wide Cout tiles handled by one wave; MT voxel tiles of 16.
+template <int NT, int MT>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int n = blockIdx.x / p.blocks_per_sample;
+  const int blk = blockIdx.x - n * p.blocks_per_sample;
+  const int co_base = blockIdx.y * (NT * 16);
+  const int vbase = (blk * 4 + wave) * (MT * 16);
+  if (vbase >= p.Vo) return;  // wave-uniform
+  const int lv = lane & 15;   // voxel within tile (B column) / cout within tile (A row)
+  const int q = lane >> 4;    // k sub-chunk (8 channels)
+
+  int oz[MT], oy[MT], ox[MT];
+  bool vok[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    int v = vbase + mt * 16 + lv;
+    vok[mt] = v < p.Vo;
+    vox_decode(vok[mt] ? v : 0, p.Ho, p.Wo, oz[mt], oy[mt], ox[mt]);
+  }
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const bf16_t* wbase = p.w + (long)n * p.w_sample_stride;
+  const long x_n = (long)n * p.Di * p.Hi * p.Wi;
+  const int ntap = p.ks * p.ks * p.ks;
+  const int kchunks = p.Ci >> 5;
+
+  for (int tap = 0; tap < ntap; ++tap) {
+    const int kz = tap / (p.ks * p.ks);
+    const int ky = (tap / p.ks) % p.ks;
+    const int kx = tap % p.ks;
+    long xoff[MT];
+    bool ok[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      int iz, iy, ix;
+      bool v = vok[mt];
+      if (!p.transposed) {
+        iz = oz[mt] * p.stride + kz - p.pad;
+        iy = oy[mt] * p.stride + ky - p.pad;
+        ix = ox[mt] * p.stride + kx - p.pad;
+      } else {
+        int tz = oz[mt] + p.pad - kz, ty = oy[mt] + p.pad - ky, tx = ox[mt] + p.pad - kx;
+        v = v && tz >= 0 && ty >= 0 && tx >= 0;
+        if (p.stride == 2) {
+          v = v && !((tz | ty | tx) & 1);
+          tz >>= 1; ty >>= 1; tx >>= 1;
+        }
+        iz = tz; iy = ty; ix = tx;
+      }
+      v = v && (unsigned)iz < (unsigned)p.Di && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+      ok[mt] = v;
+      xoff[mt] = (x_n + ((long)iz * p.Hi + iy) * p.Wi + ix) * p.x_cs + p.x_co + q * 8;
+    }
+    const bf16_t* wt = wbase + ((long)tap * p.Co + co_base + lv) * p.Ci + q * 8;
+    for (int kc = 0; kc < kchunks; ++kc) {
+      bf16x8 a[NT], b[MT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) a[nt] = ld_bf16x8(wt + (long)nt * 16 * p.Ci + kc * 32);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) b[mt] = ok[mt] ? ld_bf16x8(p.x + xoff[mt] + kc * 32) : zero_bf16x8();
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[nt], b[mt], acc[mt][nt], 0, 0, 0);
+    }
+  }
+
+  // epilogue: lane holds couts co_base + nt*16 + 4q .. +3 of voxel (mt, lv)
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    if (!vok[mt]) continue;
+    const long vo = (long)n * p.Vo + vbase + mt * 16 + lv;
+    int cls = 0;
+    if (p.btab) cls = vox_class(oz[mt], oy[mt], ox[mt], p.Do, p.Ho, p.Wo);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int c0 = co_base + nt * 16 + q * 4;
+      f32x4 v = acc[mt][nt];
+      if (p.btab) {
+        const f32x4 bb = *reinterpret_cast<const f32x4*>(p.btab + ((long)(p.w_sample_stride ? n : 0) * 64 + cls) * p.Co + c0);
+        v += bb;
+      }
+      if (p.res) {
+        const bf16x4 r = *reinterpret_cast<const bf16x4*>(p.res + vo * p.r_cs + p.r_co + c0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] += bf2f(r[j]);
+      }
+      if (p.relu) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : 0.f;
+      }
+      if (p.y_fp32) {
+        *reinterpret_cast<f32x4*>((float*)p.y + vo * p.y_cs + p.y_co + c0) = v;
+      } else {
+        bf16x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = f2bf(v[j]);
+        *reinterpret_cast<bf16x4*>((bf16_t*)p.y + vo * p.y_cs + p.y_co + c0) = o;
+      }
+    }
+  }
+}
+
+extern "C" int rtp_conv_igemm(const RtpAct* x, const void* wf, int w_per_sample, const float* btab, const RtpAct* res,
+                              const RtpAct* y, const RtpConvGeom* g, int relu, int transposed, int y_fp32,
+                              void* stream) {
+  if (!x || !y || !wf || !g) return RTP_ERR_SHAPE;
+  if (g->ks != 1 && g->ks != 3) return RTP_ERR_UNSUPPORTED;
+  if (g->stride != 1 && g->stride != 2) return RTP_ERR_UNSUPPORTED;
+  ConvParams p;
+  p.x = (const bf16_t*)x->ptr;
+  p.w = (const bf16_t*)wf;
+  p.btab = btab;
+  p.res = res ? (const bf16_t*)res->ptr : nullptr;
+  p.y = y->ptr;
+  p.N = g->n;
+  p.ks = g->ks; p.stride = g->stride; p.pad = g->pad; p.transposed = transposed;
+  if (!transposed) {
+    p.Di = g->di; p.Hi = g->hi; p.Wi = g->wi; p.Do = g->dov; p.Ho = g->ho; p.Wo = g->wo;
+    p.Ci = g->ci; p.Co = g->co;
+  } else {  // gradient flows output-side -> input-side; contraction over the forward conv's (padded) Cout
+    p.Di = g->dov; p.Hi = g->ho; p.Wi = g->wo; p.Do = g->di; p.Ho = g->hi; p.Wo = g->wi;
+    p.Ci = (g->co + 31) / 32 * 32; p.Co = g->ci;
+  }
+  if (p.Ci % 32 || p.Co % 16) return RTP_ERR_UNSUPPORTED;
+  if (x->c < p.Ci || y->c < p.Co) return RTP_ERR_SHAPE;
+  if ((x->co % 8) || (x->cs % 8) || (y->co % 4) || (y->cs % 4)) return RTP_ERR_ALIGN;
+  if (res && ((res->co % 4) || (res->cs % 4))) return RTP_ERR_ALIGN;
+  p.x_cs = x->cs; p.x_co = x->co; p.y_cs = y->cs; p.y_co = y->co;
+  p.r_cs = res ? res->cs : 0; p.r_co = res ? res->co : 0;
+  p.relu = relu; p.y_fp32 = y_fp32;
+  const int ntap = p.ks * p.ks * p.ks;
+  p.w_sample_stride = w_per_sample ? (long)ntap * p.Co * p.Ci : 0;
+  p.Vo = p.Do * p.Ho * p.Wo;
+  constexpr int MT = 4;
+  p.blocks_per_sample = rtp_div_up(p.Vo, 4 * MT * 16);
+  hipStream_t s = (hipStream_t)stream;
+  int nt = (p.Co % 32 == 0) ? 2 : 1;
+  dim3 grid(p.N * p.blocks_per_sample, p.Co / (16 * nt));
+  RtpProfScope prof(RTP_FAM_CONV, s);
+  if (nt == 2)
+    hipLaunchKernelGGL((conv_igemm_kernel<2, MT>), grid, dim3(256), 0, s, p);
+  else
+    hipLaunchKernelGGL((conv_igemm_kernel<1, MT>), grid, dim3(256), 0, s, p);
+  RTP_CHECK_LAUNCH();
+  return RTP_OK;
+}

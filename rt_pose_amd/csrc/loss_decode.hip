@@ -1,0 +1,248 @@
+// CenterHead losses (forward + backward in one pass) and the argmax decode.
+//   FastFocalLoss  det3d/models/losses/centernet_loss.py:34-54 (+ _sigmoid clamp, pose_heads/center_head.py:240-242)
+//   RegLoss        centernet_loss.py:17-24 (+ code weights, center_head.py:252-258)
+//   predict        center_head.py:272-360
+// Head logits are fp32 channels-last [n][vox][cpad]; heat-map targets arrive as the dataset makes them
+// (fp32 NCDHW); gradients are written as bf16 channels-last with the channel count padded to 32/64 so the
+// data-gradient conv contracts a full MFMA K step.
+#include "rtp_common.h"
+#include "rtp_prof.h"
+
+#define FOCAL_BPS 64  // blocks per sample
+extern "C" int rtp_focal_blocks(void) { return FOCAL_BPS; }
+
+struct FocalParams {
+  const float* logits; int cpad; const float* target; const long long* ind; const unsigned char* mask;
+  const long long* cat; int n, ncls, m; long vox; float gscale; float* scratch; bf16_t* g; int g_cs, g_co, g_c;
+};
+
+__global__ __launch_bounds__(256) void focal_kernel(FocalParams p) {
+  __shared__ long long s_ind[64];
+  __shared__ int s_cat[64];
+  __shared__ float s_msk[64];
+  __shared__ float s_npos;
+  __shared__ float red[256 * 2];
+  const int n = blockIdx.y, tid = threadIdx.x;
+  if (tid < p.m) {
+    s_ind[tid] = p.ind[(long)n * p.m + tid];
+    s_cat[tid] = (int)p.cat[(long)n * p.m + tid];
+    s_msk[tid] = p.mask[(long)n * p.m + tid] ? 1.f : 0.f;
+  }
+  if (tid == 0) {
+    float np = 0.f;
+    for (int i = 0; i < p.n * p.m; ++i) np += p.mask[i] ? 1.f : 0.f;
+    s_npos = np;
+  }
+  __syncthreads();
+  const float denom = s_npos > 0.f ? s_npos : 1.f;
+  const float gs = -p.gscale / denom;
+  const long vps = (p.vox + gridDim.x - 1) / gridDim.x;
+  const long v0 = blockIdx.x * vps, v1 = (v0 + vps < p.vox) ? v0 + vps : p.vox;
+  float negsum = 0.f, possum = 0.f;
+  for (long v = v0 + tid; v < v1; v += 256) {
+    const float* lg = p.logits + ((long)n * p.vox + v) * p.cpad;
+    bf16_t* gout = p.g + ((long)n * p.vox + v) * p.g_cs + p.g_co;
+    for (int c = 0; c < p.g_c; ++c) {
+      float grad = 0.f;
+      if (c < p.ncls) {
+        const float zl = lg[c];
+        const float praw = 1.f / (1.f + expf(-zl));
+        const bool inside = (praw >= 1e-4f) && (praw <= 1.f - 1e-4f);
+        const float pc = fminf(fmaxf(praw, 1e-4f), 1.f - 1e-4f);
+        const float gt = p.target[((long)n * p.ncls + c) * p.vox + v];
+        float w = 1.f - gt; w = w * w; w = w * w;
+        const float l1p = logf(1.f - pc);
+        negsum += l1p * pc * pc * w;
+        float dldp = (-pc * pc / (1.f - pc) + 2.f * pc * l1p) * w;
+        for (int k = 0; k < p.m; ++k)
+          if (s_ind[k] == v && s_cat[k] == c) {
+            const float lp = logf(pc), omp = 1.f - pc;
+            possum += lp * omp * omp * s_msk[k];
+            dldp += (omp * omp / pc - 2.f * omp * lp) * s_msk[k];
+          }
+        grad = inside ? gs * dldp * praw * (1.f - praw) : 0.f;
+      }
+      gout[c] = f2bf(grad);
+    }
+  }
+  red[tid] = negsum; red[256 + tid] = possum;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o) { red[tid] += red[tid + o]; red[256 + tid] += red[256 + tid + o]; }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    float* sc = p.scratch + ((long)n * gridDim.x + blockIdx.x) * 2;
+    sc[0] = red[0]; sc[1] = red[256];
+  }
+}
+
+__global__ void focal_final(const float* scratch, int nparts, const unsigned char* mask, int nm, float* out) {
+  if (threadIdx.x != 0) return;
+  float neg = 0.f, pos = 0.f, np = 0.f;
+  for (int i = 0; i < nparts; ++i) { neg += scratch[2 * i]; pos += scratch[2 * i + 1]; }
+  for (int i = 0; i < nm; ++i) np += mask[i] ? 1.f : 0.f;
+  out[0] = (np == 0.f) ? -neg : -(pos + neg) / np;
+}
+
+extern "C" int rtp_focal_loss(const float* logits, int cpad, const float* target, const long long* ind,
+                              const unsigned char* mask, const long long* cat, int n, int ncls, long vox, int m,
+                              float gscale, float* scratch, float* out_loss, const RtpAct* ghm, void* stream) {
+  if (!logits || !target || !ghm || m > 64 || ncls > cpad || ncls > ghm->c) return RTP_ERR_SHAPE;
+  FocalParams p{logits, cpad, target, ind, mask, cat, n, ncls, m, vox, gscale, scratch,
+                (bf16_t*)ghm->ptr, ghm->cs, ghm->co, ghm->c};
+  hipStream_t s = (hipStream_t)stream;
+  RtpProfScope prof(RTP_FAM_LOSS, s);
+  hipLaunchKernelGGL(focal_kernel, dim3(FOCAL_BPS, n), dim3(256), 0, s, p);
+  hipLaunchKernelGGL(focal_final, dim3(1), dim3(64), 0, s, scratch, n * FOCAL_BPS, mask, n * m, out_loss);
+  RTP_CHECK_LAUNCH();
+  return RTP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// RegLoss: single block; (n*m) rows are few
+// ------------------------------------------------------------------------------------------------
+struct RegParams {
+  const float* reg; int cpad; const float* target; const long long* ind; const unsigned char* mask; const float* cw;
+  int n, nreg, m; long vox; float gscale; float* out; bf16_t* g; int g_cs, g_co;
+};
+
+__global__ __launch_bounds__(256) void reg_loss_kernel(RegParams p) {
+  __shared__ float s_msum;
+  __shared__ float s_loss[64];
+  const int tid = threadIdx.x;
+  if (tid == 0) {
+    float ms = 0.f;
+    for (int i = 0; i < p.n * p.m; ++i) ms += p.mask[i] ? 1.f : 0.f;
+    s_msum = ms;
+  }
+  __syncthreads();
+  const float inv = 1.f / (s_msum + 1e-4f);
+  // per-channel loss: thread per channel (nreg <= 64)
+  if (tid < p.nreg) {
+    float acc = 0.f;
+    for (int r = 0; r < p.n * p.m; ++r) {
+      const int n = r / p.m;
+      const float mk = p.mask[r] ? 1.f : 0.f;
+      const float pred = p.reg[((long)n * p.vox + p.ind[r]) * p.cpad + tid];
+      acc += fabsf(pred * mk - p.target[(long)r * p.nreg + tid] * mk) * inv;
+    }
+    s_loss[tid] = acc;
+    p.out[tid] = acc;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    float loc = 0.f;
+    for (int c = 0; c < p.nreg; ++c) loc += s_loss[c] * p.cw[c];
+    p.out[p.nreg] = loc;
+  }
+  // gradient scatter: the first row of each (sample, voxel) group sums its duplicates
+  for (int i = tid; i < p.n * p.m * p.nreg; i += 256) {
+    const int c = i % p.nreg, r = i / p.nreg, n = r / p.m;
+    bool first = true;
+    for (int r2 = n * p.m; r2 < r; ++r2) first = first && (p.ind[r2] != p.ind[r]);
+    if (!first) continue;
+    float gsum = 0.f;
+    for (int r2 = r; r2 < (n + 1) * p.m; ++r2) {
+      if (p.ind[r2] != p.ind[r]) continue;
+      const float mk = p.mask[r2] ? 1.f : 0.f;
+      const float pred = p.reg[((long)n * p.vox + p.ind[r2]) * p.cpad + c];
+      const float d = pred * mk - p.target[(long)r2 * p.nreg + c] * mk;
+      const float sg = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+      gsum += sg * mk;
+    }
+    p.g[((long)n * p.vox + p.ind[r]) * p.g_cs + p.g_co + c] = f2bf(p.gscale * p.cw[c] * inv * gsum);
+  }
+}
+
+extern "C" int rtp_reg_loss(const float* reg, int cpad, const float* target, const long long* ind,
+                            const unsigned char* mask, const float* code_w, int n, int nreg, long vox, int m,
+                            float gscale, float* out, const RtpAct* greg, void* stream) {
+  if (!reg || !target || !greg || nreg > 64 || nreg > cpad || nreg > greg->c) return RTP_ERR_SHAPE;
+  if (greg->co != 0 || greg->cs != greg->c) return RTP_ERR_SHAPE;  // zero-filled as one contiguous buffer
+  hipStream_t s = (hipStream_t)stream;
+  RtpProfScope prof(RTP_FAM_LOSS, s);
+  if (hipMemsetAsync(greg->ptr, 0, (size_t)n * vox * greg->cs * sizeof(bf16_t), s) != hipSuccess) return RTP_ERR_LAUNCH;
+  RegParams p{reg, cpad, target, ind, mask, code_w, n, nreg, m, vox, gscale, out, (bf16_t*)greg->ptr, greg->cs, greg->co};
+  hipLaunchKernelGGL(reg_loss_kernel, dim3(1), dim3(256), 0, s, p);
+  RTP_CHECK_LAUNCH();
+  return RTP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// decode: per (sample, class) first-index argmax of sigmoid(logit), then offset decode
+// ------------------------------------------------------------------------------------------------
+#define DEC_BPS 64
+struct DecParams {
+  const float* logits; int hm_cpad; const float* reg; int reg_cpad; int n, ncls, nreg, d, h, w;
+  float sx, sy, sz, ox, oy, oz; float* part; float* out;
+};
+
+__global__ __launch_bounds__(256) void decode_scan(DecParams p) {
+  __shared__ float s_val[256];
+  __shared__ int s_idx[256];
+  const int n = blockIdx.y, tid = threadIdx.x;
+  const long vox = (long)p.d * p.h * p.w;
+  const long vps = (vox + gridDim.x - 1) / gridDim.x;
+  const long v0 = blockIdx.x * vps, v1 = (v0 + vps < vox) ? v0 + vps : vox;
+  for (int c = 0; c < p.ncls; ++c) {
+    float best = -1.f; int bi = 0x7fffffff;
+    for (long v = v0 + tid; v < v1; v += 256) {
+      const float sg = 1.f / (1.f + expf(-p.logits[((long)n * vox + v) * p.hm_cpad + c]));
+      if (sg > best) { best = sg; bi = (int)v; }
+    }
+    s_val[tid] = best; s_idx[tid] = bi;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if (tid < o) {
+        const float ov = s_val[tid + o]; const int oi = s_idx[tid + o];
+        if (ov > s_val[tid] || (ov == s_val[tid] && oi < s_idx[tid])) { s_val[tid] = ov; s_idx[tid] = oi; }
+      }
+      __syncthreads();
+    }
+    if (tid == 0) {
+      float* o = p.part + (((long)n * p.ncls + c) * gridDim.x + blockIdx.x) * 2;
+      o[0] = s_val[0]; o[1] = __int_as_float(s_idx[0]);
+    }
+    __syncthreads();
+  }
+}
+
+__global__ void decode_final(DecParams p, int nparts) {
+  const int n = blockIdx.x / p.ncls, c = blockIdx.x % p.ncls;
+  if (threadIdx.x != 0) return;
+  const long vox = (long)p.d * p.h * p.w;
+  float best = -1.f; int bi = 0x7fffffff;
+  for (int i = 0; i < nparts; ++i) {
+    const float* q = p.part + (((long)n * p.ncls + c) * nparts + i) * 2;
+    const float v = q[0]; const int idx = __float_as_int(q[1]);
+    if (v > best || (v == best && idx < bi)) { best = v; bi = idx; }
+  }
+  int z, y, x;
+  vox_decode(bi, p.h, p.w, z, y, x);
+  const int nk = p.nreg / 3;
+  float* o = p.out + ((long)n * p.ncls + c) * (2 + p.nreg);
+  o[0] = (float)bi; o[1] = best;
+  const float* r = p.reg + ((long)n * vox + bi) * p.reg_cpad;
+  for (int k = 0; k < nk; ++k) {
+    o[2 + 3 * k + 0] = ((float)x + r[3 * k + 0]) * p.sx + p.ox;
+    o[2 + 3 * k + 1] = ((float)y + r[3 * k + 1]) * p.sy + p.oy;
+    o[2 + 3 * k + 2] = ((float)z + r[3 * k + 2]) * p.sz + p.oz;
+  }
+}
+
+extern "C" int rtp_decode_scratch_floats(int n, int ncls) { return n * ncls * DEC_BPS * 2; }
+
+extern "C" int rtp_decode(const float* logits, int hm_cpad, const float* reg, int reg_cpad, int n, int ncls, int nreg,
+                          int d, int h, int w, const float* scale_xyz /*host*/, const float* origin_xyz /*host*/,
+                          float* scratch, float* out, void* stream) {
+  if (!logits || !reg || !out || !scratch || nreg % 3) return RTP_ERR_SHAPE;
+  DecParams p{logits, hm_cpad, reg, reg_cpad, n, ncls, nreg, d, h, w,
+              scale_xyz[0], scale_xyz[1], scale_xyz[2], origin_xyz[0], origin_xyz[1], origin_xyz[2], scratch, out};
+  hipStream_t s = (hipStream_t)stream;
+  RtpProfScope prof(RTP_FAM_LOSS, s);
+  hipLaunchKernelGGL(decode_scan, dim3(DEC_BPS, n), dim3(256), 0, s, p);
+  hipLaunchKernelGGL(decode_final, dim3(n * ncls), dim3(64), 0, s, p, DEC_BPS);
+  RTP_CHECK_LAUNCH();
+  return RTP_OK;
+}

@@ -1,0 +1,404 @@
+// HBM-bound point-wise kernels of the HRRadarPose path: gradient combine (ReLU mask + GroupNorm backward
+// apply + residual fan-in), fuse-row sums with on-the-fly trilinear upsampling, the upsample adjoint, the
+// Cin=1 stem conv, and NCDHW<->channels-last packing.  All move 16 bytes (8 bf16 channels) per lane.
+#include "rtp_common.h"
+#include "rtp_prof.h"
+
+// ------------------------------------------------------------------------------------------------
+// rtp_grad_combine
+// ------------------------------------------------------------------------------------------------
+struct CombTerm { const bf16_t* t; int cs, co; const float* coeff; };
+struct CombParams {
+  CombTerm terms[RTP_MAX_TERMS]; int nterms;
+  const bf16_t* x; int x_cs, x_co;
+  const bf16_t* relu; int r_cs, r_co;
+  bf16_t* out; int o_cs, o_co;
+  int c, n; long vox;
+};
+
+__global__ __launch_bounds__(256) void grad_combine_kernel(CombParams p) {
+  const int cpv = p.c >> 3;
+  const long total = (long)p.n * p.vox * cpv;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int ck = (int)(i % cpv);
+    const long vv = i / cpv;
+    const int n = (int)(vv / p.vox);
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    bf16x8 xv = zero_bf16x8();
+    bool have_x = false;
+#pragma unroll
+    for (int k = 0; k < RTP_MAX_TERMS; ++k) {
+      if (k >= p.nterms) break;
+      const CombTerm& t = p.terms[k];
+      bf16x8 tv = ld_bf16x8(t.t + vv * t.cs + t.co + ck * 8);
+      if (t.coeff) {
+        if (!have_x) { xv = ld_bf16x8(p.x + vv * p.x_cs + p.x_co + ck * 8); have_x = true; }
+        const float* cf = t.coeff + ((long)n * p.c + ck * 8) * 3;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += cf[j * 3] * bf2f(tv[j]) + cf[j * 3 + 1] * bf2f(xv[j]) + cf[j * 3 + 2];
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += bf2f(tv[j]);
+      }
+    }
+    if (p.relu) {
+      bf16x8 rv = ld_bf16x8(p.relu + vv * p.r_cs + p.r_co + ck * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] = bf2f(rv[j]) > 0.f ? acc[j] : 0.f;
+    }
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = f2bf(acc[j]);
+    st_bf16x8(p.out + vv * p.o_cs + p.o_co + ck * 8, o);
+  }
+}
+
+static inline int grid_for(long items) {
+  long b = (items + 255) / 256;
+  return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
+}
+
+extern "C" int rtp_grad_combine(const RtpTerm* terms, int nterms, const RtpAct* x, const RtpAct* relu_src,
+                                const RtpAct* out, int n, long vox, void* stream) {
+  if (!terms || nterms < 1 || nterms > RTP_MAX_TERMS || !out) return RTP_ERR_SHAPE;
+  CombParams p;
+  p.nterms = nterms;
+  p.c = out->c;
+  if (p.c % 8 || (out->cs % 8) || (out->co % 8)) return RTP_ERR_ALIGN;
+  bool need_x = false;
+  for (int k = 0; k < nterms; ++k) {
+    if (terms[k].t.c != p.c || (terms[k].t.cs % 8) || (terms[k].t.co % 8)) return RTP_ERR_ALIGN;
+    p.terms[k] = CombTerm{(const bf16_t*)terms[k].t.ptr, terms[k].t.cs, terms[k].t.co, terms[k].coeff};
+    need_x |= terms[k].coeff != nullptr;
+  }
+  if (need_x && (!x || (x->cs % 8) || (x->co % 8))) return RTP_ERR_SHAPE;
+  p.x = x ? (const bf16_t*)x->ptr : nullptr; p.x_cs = x ? x->cs : 0; p.x_co = x ? x->co : 0;
+  p.relu = relu_src ? (const bf16_t*)relu_src->ptr : nullptr;
+  p.r_cs = relu_src ? relu_src->cs : 0; p.r_co = relu_src ? relu_src->co : 0;
+  p.out = (bf16_t*)out->ptr; p.o_cs = out->cs; p.o_co = out->co;
+  p.n = n; p.vox = vox;
+  hipStream_t s = (hipStream_t)stream;
+  RtpProfScope prof(RTP_FAM_POINTWISE, s);
+  hipLaunchKernelGGL(grad_combine_kernel, dim3(grid_for((long)n * vox * (p.c / 8))), dim3(256), 0, s, p);
+  RTP_CHECK_LAUNCH();
+  return RTP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// rtp_fuse_sum : trilinear align_corners=True, PyTorch index rule (upsample_trilinear3d)
+// ------------------------------------------------------------------------------------------------
+struct FuseTerm { const bf16_t* t; int cs, co, d, h, w; };
+struct FuseParams {
+  FuseTerm terms[RTP_MAX_TERMS]; int nterms;
+  const float* bias; bf16_t* out; int o_cs, o_co;
+  int c, n, d, h, w, relu;
+};
+
+__device__ __forceinline__ void src_index(int o, int I, int O, int& i0, int& i1, float& l0, float& l1) {
+  if (I == O) { i0 = i1 = o; l0 = 1.f; l1 = 0.f; return; }
+  const float scale = (O > 1) ? (float)(I - 1) / (float)(O - 1) : 0.f;
+  const float src = scale * (float)o;
+  i0 = (int)src;
+  i1 = i0 + ((i0 < I - 1) ? 1 : 0);
+  l1 = src - (float)i0;
+  l0 = 1.f - l1;
+}
+
+__global__ __launch_bounds__(256) void fuse_sum_kernel(FuseParams p) {
+  const int cpv = p.c >> 3;
+  const long vox = (long)p.d * p.h * p.w;
+  const long total = (long)p.n * vox * cpv;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int ck = (int)(i % cpv);
+    const long vv = i / cpv;
+    const int n = (int)(vv / vox);
+    int z, y, x;
+    vox_decode((int)(vv - (long)n * vox), p.h, p.w, z, y, x);
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = p.bias ? p.bias[ck * 8 + j] : 0.f;
+#pragma unroll
+    for (int k = 0; k < RTP_MAX_TERMS; ++k) {
+      if (k >= p.nterms) break;
+      const FuseTerm& t = p.terms[k];
+      if (t.d == p.d && t.h == p.h && t.w == p.w) {
+        bf16x8 tv = ld_bf16x8(t.t + vv * t.cs + t.co + ck * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += bf2f(tv[j]);
+      } else {
+        int z0, z1, y0, y1, x0, x1;
+        float lz0, lz1, ly0, ly1, lx0, lx1;
+        src_index(z, t.d, p.d, z0, z1, lz0, lz1);
+        src_index(y, t.h, p.h, y0, y1, ly0, ly1);
+        src_index(x, t.w, p.w, x0, x1, lx0, lx1);
+        const long base = (long)n * t.d * t.h * t.w;
+        float up[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) up[j] = 0.f;
+#pragma unroll
+        for (int cz = 0; cz < 2; ++cz)
+#pragma unroll
+          for (int cy = 0; cy < 2; ++cy)
+#pragma unroll
+            for (int cx = 0; cx < 2; ++cx) {
+              const float wgt = (cz ? lz1 : lz0) * (cy ? ly1 : ly0) * (cx ? lx1 : lx0);
+              const long sv = base + ((long)(cz ? z1 : z0) * t.h + (cy ? y1 : y0)) * t.w + (cx ? x1 : x0);
+              bf16x8 tv = ld_bf16x8(t.t + sv * t.cs + t.co + ck * 8);
+#pragma unroll
+              for (int j = 0; j < 8; ++j) up[j] += wgt * bf2f(tv[j]);
+            }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += up[j];
+      }
+    }
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = f2bf(p.relu ? (acc[j] > 0.f ? acc[j] : 0.f) : acc[j]);
+    st_bf16x8(p.out + vv * p.o_cs + p.o_co + ck * 8, o);
+  }
+}
+
+extern "C" int rtp_fuse_sum(const RtpTerm* terms, int nterms, const float* bias, const RtpAct* out, int n, int d, int h,
+                            int w, int relu, void* stream) {
+  if (!terms || nterms < 1 || nterms > RTP_MAX_TERMS || !out) return RTP_ERR_SHAPE;
+  FuseParams p;
+  p.nterms = nterms; p.c = out->c;
+  if (p.c % 8 || (out->cs % 8) || (out->co % 8)) return RTP_ERR_ALIGN;
+  for (int k = 0; k < nterms; ++k) {
+    if (terms[k].t.c != p.c || (terms[k].t.cs % 8) || (terms[k].t.co % 8)) return RTP_ERR_ALIGN;
+    p.terms[k] = FuseTerm{(const bf16_t*)terms[k].t.ptr, terms[k].t.cs, terms[k].t.co, terms[k].d, terms[k].h, terms[k].w};
+  }
+  p.bias = bias; p.out = (bf16_t*)out->ptr; p.o_cs = out->cs; p.o_co = out->co;
+  p.n = n; p.d = d; p.h = h; p.w = w; p.relu = relu;
+  hipStream_t s = (hipStream_t)stream;
+  RtpProfScope prof(RTP_FAM_POINTWISE, s);
+  hipLaunchKernelGGL(fuse_sum_kernel, dim3(grid_for((long)n * d * h * w * (p.c / 8))), dim3(256), 0, s, p);
+  RTP_CHECK_LAUNCH();
+  return RTP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// rtp_upsample_bwd : one wave per low-res voxel gathers its whole support
+// ------------------------------------------------------------------------------------------------
+#define UPB_MAXS 256
+struct UpbParams {
+  const bf16_t* g; int g_cs, g_co; bf16_t* out; int o_cs, o_co;
+  int c, n, d, h, w, dl, hl, wl;
+};
+
+// weight of high-res position o on low-res index il along one dim
+__device__ __forceinline__ float adj_w(int o, int il, int I, int O) {
+  int i0, i1; float l0, l1;
+  src_index(o, I, O, i0, i1, l0, l1);
+  return (i0 == il ? l0 : 0.f) + (i1 == il ? l1 : 0.f);
+}
+
+__device__ __forceinline__ void support(int il, int I, int O, int& lo, int& hi) {
+  if (I == O) { lo = hi = il; return; }
+  if (I == 1 || O == 1) { lo = 0; hi = O - 1; return; }
+  const float inv = (float)(O - 1) / (float)(I - 1);
+  lo = (int)floorf((float)(il - 1) * inv) - 1;
+  hi = (int)ceilf((float)(il + 1) * inv) + 1;
+  if (lo < 0) lo = 0;
+  if (hi > O - 1) hi = O - 1;
+}
+
+__global__ __launch_bounds__(64) void upsample_bwd_kernel(UpbParams p) {
+  __shared__ float wz[UPB_MAXS], wy[UPB_MAXS], wx[UPB_MAXS];
+  __shared__ float red[64 * 65];
+  const int lane = threadIdx.x;
+  const long lvox = (long)p.dl * p.hl * p.wl;
+  const int n = blockIdx.x / lvox;
+  const int lv = blockIdx.x - n * lvox;
+  int zl, yl, xl;
+  vox_decode(lv, p.hl, p.wl, zl, yl, xl);
+  int z_lo, z_hi, y_lo, y_hi, x_lo, x_hi;
+  support(zl, p.dl, p.d, z_lo, z_hi);
+  support(yl, p.hl, p.h, y_lo, y_hi);
+  support(xl, p.wl, p.w, x_lo, x_hi);
+  const int nz = z_hi - z_lo + 1, ny = y_hi - y_lo + 1, nx = x_hi - x_lo + 1;
+  for (int i = lane; i < nz; i += 64) wz[i] = adj_w(z_lo + i, zl, p.dl, p.d);
+  for (int i = lane; i < ny; i += 64) wy[i] = adj_w(y_lo + i, yl, p.hl, p.h);
+  for (int i = lane; i < nx; i += 64) wx[i] = adj_w(x_lo + i, xl, p.wl, p.w);
+  __syncthreads();
+  const long hbase = (long)n * p.d * p.h * p.w;
+  const int tot = nz * ny * nx;
+  for (int cb = 0; cb < p.c; cb += 64) {
+    const int cw = (p.c - cb < 64) ? p.c - cb : 64;  // channels in this block (multiple of 8)
+    float acc[64];
+#pragma unroll
+    for (int j = 0; j < 64; ++j) acc[j] = 0.f;
+    for (int s = lane; s < tot; s += 64) {
+      const int ix = s % nx, iy = (s / nx) % ny, iz = s / (nx * ny);
+      const float wgt = wz[iz] * wy[iy] * wx[ix];
+      if (wgt == 0.f) continue;
+      const long hv = hbase + ((long)(z_lo + iz) * p.h + (y_lo + iy)) * p.w + (x_lo + ix);
+      const bf16_t* src = p.g + hv * p.g_cs + p.g_co + cb;
+#pragma unroll
+      for (int ck = 0; ck < 8; ++ck) {
+        if (ck * 8 < cw) {
+          bf16x8 tv = ld_bf16x8(src + ck * 8);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc[ck * 8 + j] += wgt * bf2f(tv[j]);
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 64; ++j) red[lane * 65 + j] = acc[j];
+    __syncthreads();
+    if (lane < cw) {
+      float sum = 0.f;
+      for (int l = 0; l < 64; ++l) sum += red[l * 65 + lane];
+      p.out[((long)n * lvox + lv) * p.o_cs + p.o_co + cb + lane] = f2bf(sum);
+    }
+  }
+}
+
+extern "C" int rtp_upsample_bwd(const RtpAct* ghi, int d, int h, int w, const RtpAct* glow, int dl, int hl, int wl,
+                                int n, void* stream) {
+  if (!ghi || !glow) return RTP_ERR_SHAPE;
+  if (ghi->c != glow->c || ghi->c % 8 || (ghi->cs % 8) || (ghi->co % 8)) return RTP_ERR_ALIGN;
+  if (d > UPB_MAXS || h > UPB_MAXS || w > UPB_MAXS) return RTP_ERR_UNSUPPORTED;
+  UpbParams p{(const bf16_t*)ghi->ptr, ghi->cs, ghi->co, (bf16_t*)glow->ptr, glow->cs, glow->co,
+              ghi->c, n, d, h, w, dl, hl, wl};
+  hipStream_t s = (hipStream_t)stream;
+  RtpProfScope prof(RTP_FAM_POINTWISE, s);
+  hipLaunchKernelGGL(upsample_bwd_kernel, dim3(n * dl * hl * wl), dim3(64), 0, s, p);
+  RTP_CHECK_LAUNCH();
+  return RTP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Cin == 1 stem (layer1.conv1, hr_util/common.py:111-113)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void stem_fwd_kernel(const float* x, const float* w, const float* b, bf16_t* y,
+                                                       int y_cs, int y_co, int c, long total_vox) {
+  const int cpv = c >> 3;
+  const long total = total_vox * cpv;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int ck = (int)(i % cpv);
+    const long vv = i / cpv;
+    const float xv = x[vv];
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = f2bf(xv * w[ck * 8 + j] + b[ck * 8 + j]);
+    st_bf16x8(y + vv * y_cs + y_co + ck * 8, o);
+  }
+}
+
+extern "C" int rtp_stem_fwd(const float* x, const float* w, const float* b, const RtpAct* y, int n, long vox,
+                            void* stream) {
+  if (!x || !w || !b || !y || y->c % 8 || (y->cs % 8) || (y->co % 8)) return RTP_ERR_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  RtpProfScope prof(RTP_FAM_POINTWISE, s);
+  hipLaunchKernelGGL(stem_fwd_kernel, dim3(grid_for((long)n * vox * (y->c / 8))), dim3(256), 0, s, x, w, b,
+                     (bf16_t*)y->ptr, y->cs, y->co, y->c, (long)n * vox);
+  RTP_CHECK_LAUNCH();
+  return RTP_OK;
+}
+
+#define STEM_BWD_BLOCKS 256
+extern "C" int rtp_stem_bwd_blocks(void) { return STEM_BWD_BLOCKS; }
+
+__global__ __launch_bounds__(256) void stem_bwd_partial(const float* x, const bf16_t* g, int g_cs, int g_co, int c,
+                                                        long total_vox, float* scratch) {
+  __shared__ float red[256 * 17];
+  const int cpv = c >> 3, tid = threadIdx.x;
+  const int ck = tid % cpv, vsub = tid / cpv, vper = 256 / cpv;
+  float sw[8], sb[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) sw[j] = sb[j] = 0.f;
+  if (vsub < vper)
+    for (long v = (long)blockIdx.x * vper + vsub; v < total_vox; v += (long)gridDim.x * vper) {
+      const float xv = x[v];
+      bf16x8 gv = ld_bf16x8(g + v * g_cs + g_co + ck * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float gf = bf2f(gv[j]); sw[j] += xv * gf; sb[j] += gf; }
+    }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { red[tid * 17 + j] = sw[j]; red[tid * 17 + 8 + j] = sb[j]; }
+  __syncthreads();
+  for (int t = tid; t < 2 * c; t += 256) {
+    const int ch = t >> 1, which = t & 1;
+    float acc = 0.f;
+    for (int vs = 0; vs < vper; ++vs) acc += red[(vs * cpv + (ch >> 3)) * 17 + which * 8 + (ch & 7)];
+    scratch[((long)blockIdx.x * c + ch) * 2 + which] = acc;
+  }
+}
+
+__global__ void stem_bwd_final(const float* scratch, int nblk, int c, float* dw, float* db, int accumulate) {
+  const int t = threadIdx.x;
+  if (t >= 2 * c) return;
+  const int ch = t >> 1, which = t & 1;
+  float acc = 0.f;
+  for (int b = 0; b < nblk; ++b) acc += scratch[((long)b * c + ch) * 2 + which];
+  float* o = which ? db + ch : dw + ch;
+  if (accumulate) *o += acc; else *o = acc;
+}
+
+extern "C" int rtp_stem_bwd(const float* x, const RtpAct* gy, int n, long vox, float* scratch, float* dw, float* db,
+                            int accumulate, void* stream) {
+  if (!x || !gy || !scratch || gy->c % 8 || gy->c > 128 || (256 % (gy->c / 8))) return RTP_ERR_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  RtpProfScope prof(RTP_FAM_POINTWISE, s);
+  hipLaunchKernelGGL(stem_bwd_partial, dim3(STEM_BWD_BLOCKS), dim3(256), 0, s, x, (const bf16_t*)gy->ptr, gy->cs,
+                     gy->co, gy->c, (long)n * vox, scratch);
+  hipLaunchKernelGGL(stem_bwd_final, dim3(1), dim3(256), 0, s, scratch, STEM_BWD_BLOCKS, gy->c, dw, db, accumulate);
+  RTP_CHECK_LAUNCH();
+  return RTP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// NCDHW fp32 <-> channels-last bf16
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pack_kernel(const float* x, bf16_t* y, int y_cs, int y_co, int n, int c,
+                                                   int cpad, long vox) {
+  const int cpv = cpad >> 3;
+  const long total = (long)n * vox * cpv;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long v = i % vox;  // voxel fastest across threads -> coalesced per channel plane
+    const int ck = (int)((i / vox) % cpv);
+    const int nn = (int)(i / (vox * cpv));
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int ch = ck * 8 + j;
+      o[j] = f2bf(ch < c ? x[((long)nn * c + ch) * vox + v] : 0.f);
+    }
+    st_bf16x8(y + ((long)nn * vox + v) * y_cs + y_co + ck * 8, o);
+  }
+}
+
+extern "C" int rtp_pack_ncdhw(const float* x, const RtpAct* y, int n, int c, long vox, void* stream) {
+  if (!x || !y || y->c % 8 || c > y->c || (y->cs % 8) || (y->co % 8)) return RTP_ERR_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  RtpProfScope prof(RTP_FAM_POINTWISE, s);
+  hipLaunchKernelGGL(pack_kernel, dim3(grid_for((long)n * vox * (y->c / 8))), dim3(256), 0, s, x, (bf16_t*)y->ptr,
+                     y->cs, y->co, n, c, y->c, vox);
+  RTP_CHECK_LAUNCH();
+  return RTP_OK;
+}
+
+__global__ __launch_bounds__(256) void unpack_kernel(const bf16_t* x, int x_cs, int x_co, float* y, int n, int c,
+                                                     long vox) {
+  const long total = (long)n * c * vox;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long v = i % vox;
+    const int ch = (int)((i / vox) % c);
+    const int nn = (int)(i / (vox * c));
+    y[i] = bf2f(x[((long)nn * vox + v) * x_cs + x_co + ch]);
+  }
+}
+
+extern "C" int rtp_unpack_ncdhw(const RtpAct* x, float* y, int n, int c, long vox, void* stream) {
+  if (!x || !y || c > x->c) return RTP_ERR_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  RtpProfScope prof(RTP_FAM_POINTWISE, s);
+  hipLaunchKernelGGL(unpack_kernel, dim3(grid_for((long)n * vox * c)), dim3(256), 0, s, (const bf16_t*)x->ptr, x->cs,
+                     x->co, y, n, c, vox);
+  RTP_CHECK_LAUNCH();
+  return RTP_OK;
+}

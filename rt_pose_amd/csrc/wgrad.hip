@@ -1,0 +1,148 @@
+// Weight-gradient correlation on MFMA (gfx950):  G[co][tap][ci] = sum_v gy[v][co] * x[v*s + tap - pad][ci].
+//
+// The contraction runs over VOXELS, but activations are channels-last (channel contiguous), so both MFMA
+// operands need a transpose: tiles are staged voxel-major in LDS and read with ds_read_b64_tr_b16, which
+// hands each lane 4 consecutive voxels of one channel (cdna_hip_programming.md T10).
+//   A = gy^T  [16 co ][32 voxels]   B = x_tap [32 voxels][16 ci]   D[co][ci] (fp32, 4 regs)
+// Block = 4 waves; the 27 taps are dealt round-robin to the waves (<= 7 each, 16 acc regs per tap), every
+// wave gathers its own shifted x chunk for the tap it is working on.  Output: fp32 partial slabs per
+// (sample, voxel split) -- reduced deterministically by rtp_wgrad_fold (no atomics).
+#include "rtp_common.h"
+#include "rtp_prof.h"
+
+#define WG_VB 256  // voxels per staged chunk
+
+struct WgradParams {
+  const bf16_t* gy; const bf16_t* x; float* gp;
+  int N, Di, Hi, Wi, Do, Ho, Wo, ks, stride, pad;
+  int g_cs, g_co, x_cs, x_co;
+  int ci_pad, co32, ntap, nsplit, citiles;
+  int Vo; int vps;
+};
+
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+__device__ __forceinline__ bf16x8 tr_frag(const bf16_t* tile /*[vox][32]*/, int kstep, int sub, int lane) {
+  const int q = lane >> 4, i = lane & 15, a = i >> 2, pp = i & 3;
+  const bf16_t* p0 = tile + ((kstep * 32 + q * 8 + a) * 32 + sub * 16 + pp * 4);
+  s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p0));
+  s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p0 + 4 * 32));
+  s16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8, r);
+}
+
+__global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
+  __shared__ __attribute__((aligned(16))) bf16_t gyL[WG_VB * 32];
+  __shared__ __attribute__((aligned(16))) bf16_t xL[4][WG_VB * 32];
+  __shared__ int coordL[WG_VB];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int s = blockIdx.x, n = blockIdx.y;
+  const int cot = blockIdx.z / p.citiles, cit = blockIdx.z % p.citiles;
+  const int v_begin = s * p.vps;
+  const int v_end = (v_begin + p.vps < p.Vo) ? v_begin + p.vps : p.Vo;
+
+  f32x4 acc[7][2][2];
+#pragma unroll
+  for (int t = 0; t < 7; ++t)
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) acc[t][a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const long g_n = (long)n * p.Vo;
+  const long x_n = (long)n * p.Di * p.Hi * p.Wi;
+
+  for (int vc = v_begin; vc < v_end; vc += WG_VB) {
+    __syncthreads();  // previous chunk fully consumed
+    {
+      const int v = vc + tid;
+      int z = 0, y = 0, x = 0;
+      if (v < v_end) vox_decode(v, p.Ho, p.Wo, z, y, x);
+      coordL[tid] = (v < v_end) ? ((z << 20) | (y << 10) | x) : -1;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int item = tid + 256 * r, vox = item >> 2, ck = item & 3;
+        bf16x8 val = zero_bf16x8();
+        if (vc + vox < v_end) val = ld_bf16x8(p.gy + (g_n + vc + vox) * p.g_cs + p.g_co + cot * 32 + ck * 8);
+        st_bf16x8(&gyL[vox * 32 + ck * 8], val);
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 7; ++t) {
+      const int tap = wave + 4 * t;
+      const bool live = tap < p.ntap;  // wave-uniform
+      if (live) {
+        const int kz = tap / (p.ks * p.ks), ky = (tap / p.ks) % p.ks, kx = tap % p.ks;
+#pragma unroll 4
+        for (int r = 0; r < 16; ++r) {
+          const int item = lane + 64 * r, vox = item >> 2, ck = item & 3;
+          const int cd = coordL[vox];
+          bf16x8 val = zero_bf16x8();
+          if (cd >= 0) {
+            const int iz = (cd >> 20) * p.stride + kz - p.pad;
+            const int iy = ((cd >> 10) & 1023) * p.stride + ky - p.pad;
+            const int ix = (cd & 1023) * p.stride + kx - p.pad;
+            if ((unsigned)iz < (unsigned)p.Di && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi)
+              val = ld_bf16x8(p.x + (x_n + ((long)iz * p.Hi + iy) * p.Wi + ix) * p.x_cs + p.x_co + cit * 32 + ck * 8);
+          }
+          st_bf16x8(&xL[wave][vox * 32 + ck * 8], val);
+        }
+      }
+      __syncthreads();
+      if (live) {
+#pragma unroll 2
+        for (int ks = 0; ks < WG_VB / 32; ++ks) {
+          bf16x8 a0 = tr_frag(gyL, ks, 0, lane), a1 = tr_frag(gyL, ks, 1, lane);
+          bf16x8 b0 = tr_frag(xL[wave], ks, 0, lane), b1 = tr_frag(xL[wave], ks, 1, lane);
+          acc[t][0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b0, acc[t][0][0], 0, 0, 0);
+          acc[t][0][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b1, acc[t][0][1], 0, 0, 0);
+          acc[t][1][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b0, acc[t][1][0], 0, 0, 0);
+          acc[t][1][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1, acc[t][1][1], 0, 0, 0);
+        }
+      }
+      __syncthreads();
+    }
+  }
+
+  // D[row = co][col = ci]: lane holds rows 4q..4q+3, column lane&15
+  const int q = lane >> 4, i = lane & 15;
+  float* out = p.gp + ((long)n * p.nsplit + s) * p.ntap * p.co32 * p.ci_pad;
+#pragma unroll
+  for (int t = 0; t < 7; ++t) {
+    const int tap = wave + 4 * t;
+    if (tap >= p.ntap) continue;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          out[((long)tap * p.co32 + cot * 32 + a * 16 + q * 4 + r) * p.ci_pad + cit * 32 + b * 16 + i] = acc[t][a][b][r];
+  }
+}
+
+extern "C" int rtp_wgrad(const RtpAct* gy, const RtpAct* x, const RtpConvGeom* g, int nsplit, float* gp,
+                         void* stream) {
+  if (!gy || !x || !g || !gp || nsplit < 1) return RTP_ERR_SHAPE;
+  if (g->ks != 1 && g->ks != 3) return RTP_ERR_UNSUPPORTED;
+  WgradParams p;
+  p.gy = (const bf16_t*)gy->ptr; p.x = (const bf16_t*)x->ptr; p.gp = gp;
+  p.N = g->n; p.Di = g->di; p.Hi = g->hi; p.Wi = g->wi; p.Do = g->dov; p.Ho = g->ho; p.Wo = g->wo;
+  p.ks = g->ks; p.stride = g->stride; p.pad = g->pad;
+  p.g_cs = gy->cs; p.g_co = gy->co; p.x_cs = x->cs; p.x_co = x->co;
+  p.ci_pad = g->ci; p.co32 = (g->co + 31) / 32 * 32; p.ntap = g->ks * g->ks * g->ks; p.nsplit = nsplit;
+  if (p.ci_pad % 32) return RTP_ERR_UNSUPPORTED;
+  if (gy->c < p.co32 || x->c < p.ci_pad) return RTP_ERR_SHAPE;
+  if ((gy->cs % 8) || (gy->co % 8) || (x->cs % 8) || (x->co % 8)) return RTP_ERR_ALIGN;
+  if (p.Ho >= 1024 || p.Wo >= 1024 || p.Do >= 2048) return RTP_ERR_UNSUPPORTED;
+  p.citiles = p.ci_pad / 32;
+  p.Vo = p.Do * p.Ho * p.Wo;
+  p.vps = rtp_div_up(rtp_div_up(p.Vo, nsplit), WG_VB) * WG_VB;
+  hipStream_t s = (hipStream_t)stream;
+  RtpProfScope prof(RTP_FAM_WGRAD, s);
+  dim3 grid(nsplit, p.N, (p.co32 / 32) * p.citiles);
+  hipLaunchKernelGGL(wgrad_kernel, grid, dim3(256), 0, s, p);
+  RTP_CHECK_LAUNCH();
+  return RTP_OK;
+}

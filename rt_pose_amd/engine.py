@@ -1,0 +1,233 @@
+"""Whole-model execution engine: forward, losses, backward and the optimiser step as one static launch plan.
+
+Mirrors the reference's train step semantics:
+  Trainer.train -> batch_processor_inline -> RadarPoseNet.forward(return_loss=True)
+      det3d/torchie/trainer/trainer.py:399-434, det3d/models/detectors/radar_pose_net.py:36-46
+  CenterHead.loss                      det3d/models/pose_heads/center_head.py:244-270
+  OptimizerHook.after_train_iter       det3d/torchie/trainer/hooks/optimizer.py:14-24  (clip 35)
+  OptimWrapper.step (true_wd) + Adam   det3d/solver/fastai_optim.py:154-172
+  OneCycle                             det3d/solver/learning_schedules_fastai.py:53-95
+Data parallel: one process per GPU, batch sharded by rank, ONE all-reduce of the flat fp32 gradient buffer
+(replaces DDP buckets + the reference's redundant second all-reduce, core/utils/dist_utils.py:45-57).
+"""
+import math
+from collections import OrderedDict
+
+import torch
+
+from . import net
+from .graph import Graph, View, pad_to
+
+
+def one_cycle(step, total_step, lr_max, moms=(0.95, 0.85), div_factor=10.0, pct_start=0.4):
+    """(lr, beta1) at `step` -- learning_schedules_fastai.py:53-95 (cosine up over pct_start, then down to lr_max/div/1e4)."""
+    def cos(start, end, pct):
+        return end + (start - end) / 2 * (math.cos(math.pi * pct) + 1)
+
+    a1 = int(total_step * pct_start)
+    low = lr_max / div_factor
+    if step >= a1:
+        pct = (step - a1) / max(1, total_step - a1)
+        return cos(lr_max, low / 1e4, pct), cos(moms[1], moms[0], pct)
+    pct = step / max(1, a1)
+    return cos(low, lr_max, pct), cos(moms[0], moms[1], pct)
+
+
+class FlatParams:
+    """All parameters (reference state_dict names/shapes, fp32) as views of ONE flat buffer, plus flat grad/m/v."""
+
+    def __init__(self, shapes: OrderedDict, alloc):
+        self.shapes = OrderedDict((k, tuple(v)) for k, v in shapes.items())
+        self.offsets, off = OrderedDict(), 0
+        for k, s in self.shapes.items():
+            self.offsets[k] = off
+            off += int(torch.Size(s).numel())
+        self.numel = off
+        self.p = alloc((off,), "f32")
+        self.g = alloc((off,), "f32")
+        self.m = alloc((off,), "f32")
+        self.v = alloc((off,), "f32")
+        self.values = OrderedDict((k, self._view(self.p, k)) for k in self.shapes)
+        self.grads = OrderedDict((k, self._view(self.g, k)) for k in self.shapes)
+
+    def _view(self, flat, k):
+        o = self.offsets[k]
+        return flat[o:o + int(torch.Size(self.shapes[k]).numel())].view(self.shapes[k])
+
+    def load_state_dict(self, sd):
+        for k, v in self.values.items():
+            v.copy_(sd[k].to(v.dtype))
+
+    def state_dict(self):
+        return OrderedDict((k, v.detach().clone()) for k, v in self.values.items())
+
+    def runs(self, live_names):
+        """Maximal contiguous [start, end, live] element ranges in buffer order."""
+        out = []
+        for k in self.shapes:
+            o, n = self.offsets[k], int(torch.Size(self.shapes[k]).numel())
+            live = k in live_names
+            if out and out[-1][2] == live and out[-1][1] == o:
+                out[-1][1] = o + n
+            else:
+                out.append([o, o + n, live])
+        return [tuple(r) for r in out]
+
+
+class PoseEngine:
+    """HRRadarPose for a fixed (batch, Cin, dims): buffers + launch lists built once, replayed every step."""
+
+    def __init__(self, backend, params, arch, final_fuse, heads, loss_weight, code_weights, batch, dims, train=True,
+                 pgrads=None, test_cfg=None, max_objs=None):
+        self.be, self.n, self.dims, self.train = backend, batch, tuple(dims), train
+        self.heads = OrderedDict(heads)
+        self.nreg, self.ncls = self.heads["reg"], self.heads["hm"]
+        self.loss_weight = float(loss_weight)
+        cin = net.ARCH_TABLES[arch]["inplanes"]
+        be = backend
+        g = self.graph = Graph(be, batch, params, train=train, pgrads=pgrads)
+        self.x_in = g.input_f32("rdr", cin, dims)
+        self.feats = net.build_hrnet3d(g, self.x_in, arch, dims, final_fuse)
+        self.outs = net.build_head(g, self.feats, list(self.heads))
+        self.fwd = list(g.fwd)
+        d, h, w = dims
+        self.m = max_objs or self.ncls  # max_poses(1) * 15 key-points for hr3d, 1 for the one-heat-map variant
+        # ---- decode (inference)
+        self.dec_out = be.alloc((batch, self.ncls, 2 + self.nreg), "f32")
+        self.dec = None
+        if test_cfg is not None:
+            self.set_test_cfg(test_cfg)
+        # ---- losses + backward (training)
+        self.loss_launches, self.bwd = [], []
+        if train:
+            self.tgt_hm = be.alloc((batch, self.ncls, d, h, w), "f32")
+            self.tgt_ind = be.alloc((batch, self.m), "i64")
+            self.tgt_mask = be.alloc((batch, self.m), "u8")
+            self.tgt_cat = be.alloc((batch, self.m), "i64")
+            self.tgt_pose = be.alloc((batch, self.m, self.nreg), "f32")
+            self.code_w = be.alloc((self.nreg,), "f32")
+            self.code_w.copy_(torch.tensor(list(code_weights), dtype=torch.float32))
+            self.loss_hm = be.alloc((1,), "f32")
+            self.loss_reg = be.alloc((self.nreg + 1,), "f32")
+            hm, reg = self.outs["hm"], self.outs["reg"]
+            ghm_c, greg_c = pad_to(pad_to(self.ncls, 16), 32), pad_to(pad_to(self.nreg, 16), 32)
+            self.ghm = View(be.alloc((batch, d, h, w, ghm_c), "bf16"), batch, d, h, w, ghm_c, 0, ghm_c)
+            self.greg = View(be.alloc((batch, d, h, w, greg_c), "bf16"), batch, d, h, w, greg_c, 0, greg_c)
+            scratch = be.focal_scratch(batch)
+            self.loss_launches.append(be.focal_loss(hm, self.tgt_hm, self.tgt_ind, self.tgt_mask, self.tgt_cat,
+                                                    self.ncls, 1.0, scratch, self.loss_hm, self.ghm))
+            self.loss_launches.append(be.reg_loss(reg, self.tgt_pose, self.tgt_ind, self.tgt_mask, self.code_w,
+                                                  self.nreg, self.loss_weight, self.loss_reg, self.greg))
+            g.seed_grad(hm, self.ghm)
+            g.seed_grad(reg, self.greg)
+            g.build_backward()
+            self.bwd = list(g.bwd)
+        self.live_params = set(g.used_params)
+
+    # ------------------------------------------------------------------ data in (plumbing copies)
+    def load_input(self, rdr_tensor):
+        self.x_in.copy_(rdr_tensor.reshape(self.x_in.shape), non_blocking=True)
+
+    def load_targets(self, ex):
+        """ex: the reference's example['rdr'] dict with per-task lists (cruw_pose.py:225-275)."""
+        self.tgt_hm.copy_(ex["hm"][0], non_blocking=True)
+        self.tgt_ind.copy_(ex["ind"][0], non_blocking=True)
+        self.tgt_mask.copy_(ex["mask"][0], non_blocking=True)
+        self.tgt_cat.copy_(ex["cat"][0], non_blocking=True)
+        self.tgt_pose.copy_(ex["anno_pose"][0].reshape(self.tgt_pose.shape), non_blocking=True)
+
+    # ------------------------------------------------------------------ launch lists
+    def run_forward(self, stream=None):
+        s = stream if stream is not None else self.be.stream()
+        for f in self.fwd:
+            f(s)
+
+    def run_loss_backward(self, stream=None):
+        s = stream if stream is not None else self.be.stream()
+        for f in self.loss_launches:
+            f(s)
+        for f in self.bwd:
+            f(s)
+
+    def losses(self):
+        """The reference's loss dict (center_head.py:260): device scalars, no host sync here."""
+        hm_loss = self.loss_hm[0]
+        loc = self.loss_reg[self.nreg]
+        return OrderedDict(loss=hm_loss + self.loss_weight * loc, hm_loss=hm_loss, loc_loss=loc,
+                           loc_loss_elem=self.loss_reg[:self.nreg], num_positive=self.tgt_mask.float().sum())
+
+    # ------------------------------------------------------------------ inference
+    def set_test_cfg(self, test_cfg):
+        osf, vs, pr = test_cfg["out_size_factor"], test_cfg["voxel_size"], test_cfg["pc_range"]
+        scale = (osf[2] * vs[0], osf[1] * vs[1], osf[0] * vs[2])
+        self.score_threshold = float(test_cfg.get("score_threshold", 0.0))
+        scratch = self.be.decode_scratch(self.n, self.ncls)
+        self.dec = self.be.decode(self.outs["hm"], self.outs["reg"], self.ncls, self.nreg, scale, tuple(pr[:3]),
+                                  scratch, self.dec_out)
+
+    def run_decode(self, stream=None):
+        self.dec(stream if stream is not None else self.be.stream())
+
+    def keypoints(self, metas=None):
+        """Format like CenterHead.post_processing (center_head.py:332-360): list of dicts per frame."""
+        out = self.dec_out.detach().cpu()
+        rets = []
+        for b in range(self.n):
+            kps = []
+            if self.nreg == 3:
+                for c in range(self.ncls):
+                    score = float(out[b, c, 1])
+                    if score > self.score_threshold:
+                        kps.append((c, *[float(v) for v in out[b, c, 2:5]], score))
+            else:
+                score = float(out[b, 0, 1])
+                pose = [float(v) for v in out[b, 0, 2:2 + self.nreg]]
+                if score > self.score_threshold:
+                    kps.append((0, *pose[:3], score))
+                for i in range(1, self.nreg // 3):
+                    kps.append((i, *pose[3 * i:3 * i + 3], score))
+            rets.append({"keypoints": kps, "metadata": None if metas is None else metas[b]})
+        return rets
+
+    # ------------------------------------------------------------------ exported tensors (logical NCDHW views)
+    def output(self, name):
+        a = self.outs[name]
+        return a.buf[..., :self.heads[name]].permute(0, 4, 1, 2, 3)
+
+    def features(self):
+        a = self.feats
+        return a.buf[..., :a.c_real].permute(0, 4, 1, 2, 3)
+
+
+class FlatAdam:
+    """Clip + decoupled weight decay + Adam over FlatParams in (at most a few) fused launches."""
+
+    def __init__(self, backend, flat: FlatParams, live_names, wd=0.01, beta2=0.99, eps=1e-8, max_norm=35.0):
+        self.be, self.flat = backend, flat
+        self.wd, self.beta2, self.eps, self.max_norm = wd, beta2, eps, max_norm
+        self.hyper = backend.alloc((10,), "f32")
+        self.hyper_host = torch.zeros(10, dtype=torch.float32)
+        if self.hyper.is_cuda:
+            self.hyper_host = self.hyper_host.pin_memory()
+        self.partial = backend.alloc((max(256, backend.sqnorm_blocks()),), "f32")
+        self.norm = backend.alloc((1,), "f32")
+        self.t = 0
+        self.launches = [backend.sqnorm(flat.g, flat.numel, self.hyper, self.partial)]
+        for (a, b, live) in flat.runs(live_names):
+            self.launches.append(backend.adam_step(flat.p[a:b], flat.g[a:b] if live else None,
+                                                   flat.m[a:b] if live else None, flat.v[a:b] if live else None,
+                                                   b - a, self.hyper, self.partial, 0 if live else 1,
+                                                   self.norm if live else None))
+
+    def set_hyper(self, lr, beta1, grad_scale=1.0):
+        """Host-side scalars for the NEXT step (uploaded asynchronously; graph-capture safe)."""
+        self.t += 1
+        h = self.hyper_host
+        h[0], h[1], h[2], h[3], h[4], h[5] = lr, beta1, self.beta2, self.eps, self.wd, self.max_norm
+        h[6], h[7], h[8] = 1.0 - beta1 ** self.t, 1.0 - self.beta2 ** self.t, grad_scale
+        self.hyper.copy_(h, non_blocking=True)
+
+    def run(self, stream=None):
+        s = stream if stream is not None else self.be.stream()
+        for f in self.launches:
+            f(s)

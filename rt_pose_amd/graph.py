@@ -1,0 +1,312 @@
+"""Static execution plan for the HRRadarPose hot path.
+
+The network is a fixed DAG, so instead of a tracing compiler the host builds, once per input shape, two flat
+lists of kernel launches (forward, backward) over statically allocated HBM buffers; a step replays the lists
+(and can be captured into a HIP graph).  Nodes are the fused macro-ops the HIP kernels implement:
+
+  stem / pack            network input -> bf16 channels-last
+  conv                   [GroupNorm folded] Conv3d k in {1,3}, stride in {1,2} [+bias] [+residual] [ReLU]
+  fuse                   sum of same-resolution terms and trilinear-upsampled low-resolution terms [ReLU]
+
+Backward is emitted mechanically in reverse creation order.  Every activation collects "contributions" from
+its consumers (plain addends, or GroupNorm-backward terms A*dxhat + B*x + C); one grad_combine launch per
+activation sums them and applies the activation's own ReLU mask, so no gradient tensor is written twice.
+
+The `backend` supplies the kernels (rt_pose_amd.backend.HipBackend in the product; tests inject a torch-CPU
+emulation of each kernel to check this file's plan logic without a GPU).  Every backend method returns a
+closure f(stream) so argument marshalling happens once, at build time.
+"""
+from dataclasses import dataclass, field
+from typing import List, Optional
+
+GROUPS = 8      # nn.GroupNorm(num_groups=8, ...) everywhere on the path (hr_util/common.py:57, hr3d.py:147)
+GN_EPS = 1e-5
+
+
+def pad_to(v, m):
+    return (v + m - 1) // m * m
+
+
+@dataclass
+class Geom:
+    n: int
+    di: int
+    hi: int
+    wi: int
+    do: int
+    ho: int
+    wo: int
+    ci: int          # padded to 32
+    co: int          # padded to 16
+    ks: int
+    stride: int
+    pad: int
+    w_ci_total: int = 0
+    w_ci_off: int = 0
+
+
+class View:
+    """A channels-last tensor view handed to kernels: buf [n,d,h,w,cs], channels [co, co+c)."""
+
+    def __init__(self, buf, n, d, h, w, cs, co, c):
+        self.buf, self.n, self.d, self.h, self.w, self.cs, self.co, self.c = buf, n, d, h, w, cs, co, c
+
+    @property
+    def vox(self):
+        return self.d * self.h * self.w
+
+    @property
+    def dims(self):
+        return (self.d, self.h, self.w)
+
+
+class Act(View):
+    """An activation node: its buffer, whether it went through a ReLU, and its gradient bookkeeping."""
+
+    def __init__(self, g, name, c_real, dims, c=None, dtype="bf16", relu=False, needs_grad=True, buf=None):
+        c = c or c_real
+        d, h, w = dims
+        if buf is None:
+            buf = g.be.alloc((g.n, d, h, w, c), dtype)
+        super().__init__(buf, g.n, d, h, w, c, 0, c)
+        self.g, self.name, self.c_real, self.dtype, self.relu = g, name, c_real, dtype, relu
+        self.needs_grad = needs_grad
+        self.stats = None          # chan_stats partials [n, S, c, 2]
+        self.stats_split = 0
+        self.contribs = []         # list of (View, coeff tensor | None)
+        self.grad: Optional[View] = None
+        self.producer = None
+
+
+def stats_split(vox):
+    return max(1, min(64, (vox + 1023) // 1024))
+
+
+def wgrad_split(vox):
+    return max(1, min(64, (vox + 511) // 512))
+
+
+class Graph:
+    def __init__(self, backend, n, params, train=True, pgrads=None):
+        """params: dict name -> fp32 tensor (reference state_dict names/shapes).
+        pgrads: optional dict name -> fp32 tensor the backward plan writes parameter gradients into
+        (views of a flat buffer); allocated per parameter when absent."""
+        self.be, self.n, self.params, self.train = backend, n, params, train
+        self._pgrads_ext = pgrads
+        self.fwd: List = []
+        self.bwd: List = []
+        self.ops: List = []
+        self.acts: List[Act] = []
+        self.pgrad = {}            # name -> fp32 grad tensor written by the backward plan
+        self.used_params = []      # creation order
+        self.bytes = 0
+
+    # ------------------------------------------------------------------ helpers
+    def act(self, *a, **k):
+        t = Act(self, *a, **k)
+        self.acts.append(t)
+        return t
+
+    def param(self, name):
+        p = self.params[name]
+        if name not in self.pgrad:
+            self.used_params.append(name)
+            if not self.train:
+                self.pgrad[name] = None
+            elif self._pgrads_ext is not None:
+                self.pgrad[name] = self._pgrads_ext[name]
+            else:
+                self.pgrad[name] = self.be.alloc(tuple(p.shape), "f32")
+        return p
+
+    def ensure_stats(self, x: Act):
+        if x.stats is None:
+            x.stats_split = stats_split(x.vox)
+            x.stats = self.be.alloc((self.n, x.stats_split, x.c, 2), "f32")
+            self.fwd.append(self.be.chan_stats(x, None, x.stats_split, x.stats))
+        return x.stats
+
+    # ------------------------------------------------------------------ forward node constructors
+    def input_f32(self, name, c, dims):
+        d, h, w = dims
+        buf = self.be.alloc((self.n, c, d, h, w), "f32")
+        return buf
+
+    def stem(self, name, x_f32, dims, wname, bname):
+        """layer1.conv1 with Cin == 1 (hr_util/common.py:111-113)."""
+        w, b = self.param(wname), self.param(bname)
+        y = self.act(name, w.shape[0], dims)
+        op = StemOp(self, x_f32, y, wname, bname)
+        y.producer = op
+        self.ops.append(op)
+        self.fwd.append(self.be.stem_fwd(x_f32, w, b, y))
+        return y
+
+    def pack(self, name, x_f32, c, dims):
+        y = self.act(name, c, dims, c=pad_to(c, 32), needs_grad=False)
+        self.fwd.append(self.be.pack_ncdhw(x_f32, y, c))
+        return y
+
+    def conv(self, name, x: Act, wname, bname=None, gn=None, ks=3, stride=1, relu=False, residual=None,
+             out_fp32=False, w_ci_total=0, w_ci_off=0, ci_real=None):
+        w = self.param(wname)
+        co_real = w.shape[0]
+        ci_real = ci_real if ci_real is not None else w.shape[1]
+        pad = ks // 2
+        do, ho, wo = [(s + 2 * pad - ks) // stride + 1 for s in x.dims]
+        co_pad = pad_to(co_real, 16)
+        geom = Geom(self.n, x.d, x.h, x.w, do, ho, wo, pad_to(ci_real, 32), co_pad, ks, stride, pad,
+                    w_ci_total, w_ci_off)
+        assert x.c >= geom.ci, (name, x.c, geom.ci)
+        y = self.act(name, co_real, (do, ho, wo), c=co_pad if out_fp32 else pad_to(co_real, 32) if co_real % 16 else co_real,
+                     dtype="f32" if out_fp32 else "bf16", relu=relu)
+        op = ConvOp(self, name, x, y, geom, wname, bname, gn, relu, residual, out_fp32, ci_real, co_real)
+        y.producer = op
+        self.ops.append(op)
+        op.emit_forward()
+        return y
+
+    def fuse(self, name, terms: List[Act], relu=True):
+        """HighResolutionModule fuse row (hr3d.py:213-228): terms at other resolutions are upsampled."""
+        hi = max(terms, key=lambda t: t.vox)
+        y = self.act(name, hi.c_real, hi.dims, c=hi.c, relu=relu)
+        op = FuseOp(self, terms, y)
+        y.producer = op
+        self.ops.append(op)
+        self.fwd.append(self.be.fuse_sum(terms, None, y, relu))
+        return y
+
+    # ------------------------------------------------------------------ backward
+    def seed_grad(self, y: Act, gview: View):
+        """Declare the gradient of a graph output (already scaled; written by a loss kernel or by autograd)."""
+        y.contribs.append((gview, None))
+
+    def finalize_grad(self, t: Act):
+        if not t.contribs:
+            return None
+        if len(t.contribs) == 1 and t.contribs[0][1] is None and not t.relu:
+            t.grad = t.contribs[0][0]
+            return t.grad
+        c = t.contribs[0][0].c
+        gbuf = self.be.alloc((self.n, t.d, t.h, t.w, c), "bf16")
+        t.grad = View(gbuf, self.n, t.d, t.h, t.w, c, 0, c)
+        need_x = any(cf is not None for _, cf in t.contribs)
+        # at most RTP_MAX_TERMS terms per launch; chain if a node ever has more
+        terms = list(t.contribs)
+        first = True
+        while terms:
+            chunk, terms = terms[:5 if not first else 6], terms[5 if not first else 6:]
+            if not first:
+                chunk = [(t.grad, None)] + chunk
+            last = not terms
+            self.bwd.append(self.be.grad_combine(chunk, t if need_x else None, t if (t.relu and last) else None, t.grad))
+            first = False
+        return t.grad
+
+    def build_backward(self):
+        assert self.train
+        for op in reversed(self.ops):
+            gy = self.finalize_grad(op.y)
+            if gy is None:
+                continue
+            op.emit_backward(gy)
+
+
+class StemOp:
+    def __init__(self, g, x_f32, y, wname, bname):
+        self.g, self.x, self.y, self.wname, self.bname = g, x_f32, y, wname, bname
+
+    def emit_backward(self, gy):
+        g = self.g
+        scratch = g.be.alloc((g.be.stem_bwd_blocks(), self.y.c, 2), "f32")
+        g.bwd.append(g.be.stem_bwd(self.x, gy, scratch, g.pgrad[self.wname], g.pgrad[self.bname], 0))
+
+
+class ConvOp:
+    def __init__(self, g, name, x, y, geom, wname, bname, gn, relu, residual, out_fp32, ci_real, co_real):
+        self.g, self.name, self.x, self.y, self.geom = g, name, x, y, geom
+        self.wname, self.bname, self.gn, self.relu, self.residual, self.out_fp32 = wname, bname, gn, relu, residual, out_fp32
+        self.ci_real, self.co_real = ci_real, co_real
+        self.mr = None
+
+    def emit_forward(self):
+        g, be, ge = self.g, self.g.be, self.geom
+        w = g.param(self.wname)
+        bias = g.param(self.bname) if self.bname else None
+        ntap = ge.ks ** 3
+        if self.gn:
+            gamma, beta = g.param(self.gn[0]), g.param(self.gn[1])
+            assert self.x.c == self.ci_real, (self.name, self.x.c, self.ci_real)
+            stats = g.ensure_stats(self.x)
+            nw = g.n
+            self.mr = be.alloc((g.n, GROUPS if self.ci_real >= GROUPS else 1, 2), "f32")
+        else:
+            gamma = beta = stats = None
+            nw = 1
+        self.groups = GROUPS if self.ci_real >= GROUPS else 1
+        self.wf = be.alloc((nw, ntap, ge.co, ge.ci), "bf16")
+        need_btab = bool(self.gn) or bias is not None
+        self.btab = be.alloc((nw, 64, ge.co), "f32") if need_btab else None
+        g.fwd.append(be.fold_fwd(w, bias, gamma, beta, stats, self.x.stats_split if self.gn else 0, self.groups, GN_EPS,
+                                 ge, self.ci_real, self.co_real, self.wf, self.btab, self.mr))
+        g.fwd.append(be.conv(self.x, self.wf, nw > 1, self.btab, self.residual, self.y, ge, self.relu, False,
+                             self.out_fp32))
+
+    def emit_backward(self, gy: View):
+        g, be, ge, x = self.g, self.g.be, self.geom, self.x
+        if self.residual is not None and self.residual.needs_grad:
+            self.residual.contribs.append((gy, None))
+        w = g.params[self.wname]
+        # ---- data gradient (and GroupNorm backward terms)
+        if x.needs_grad or self.gn:
+            cok = pad_to(ge.co, 32)
+            assert gy.c >= cok, (self.name, gy.c, cok)
+            wd = be.alloc((ge.ks ** 3, ge.ci, cok), "bf16")
+            g.bwd.append(be.pack_dgrad_w(w, ge, self.ci_real, self.co_real, wd))
+            dxh_buf = be.alloc((g.n, x.d, x.h, x.w, ge.ci), "bf16")
+            dxh = View(dxh_buf, g.n, x.d, x.h, x.w, ge.ci, 0, ge.ci)
+            g.bwd.append(be.conv(gy, wd, False, None, None, dxh, ge, False, True, False))
+            if self.gn:
+                S = x.stats_split
+                pq = be.alloc((g.n, S, ge.ci, 2), "f32")
+                g.bwd.append(be.chan_stats(dxh, x, S, pq))
+                coeff = be.alloc((g.n, ge.ci, 3), "f32")
+                g.bwd.append(be.gn_bwd_coeffs(pq, S, self.mr, g.params[self.gn[0]], g.n, self.ci_real, self.groups,
+                                              x.vox, coeff, g.pgrad[self.gn[0]], g.pgrad[self.gn[1]], 0))
+                if x.needs_grad:
+                    x.contribs.append((dxh, coeff))
+            elif x.needs_grad:
+                x.contribs.append((dxh, None))
+        # ---- weight gradient
+        S = wgrad_split(gy.vox)
+        co32 = pad_to(ge.co, 32)
+        assert gy.c == co32, (self.name, gy.c, co32)
+        gp = be.alloc((g.n, S, ge.ks ** 3, co32, ge.ci), "f32")
+        g.bwd.append(be.wgrad(gy, x, ge, S, gp))
+        csum, cs_split = None, 0
+        if self.gn or self.bname:
+            cs_split = stats_split(gy.vox)
+            csum = be.alloc((g.n, cs_split, 64, gy.c), "f32")
+            g.bwd.append(be.class_sums(gy, cs_split, csum))
+        g.bwd.append(be.wgrad_fold(gp, S, csum, cs_split, self.mr, g.params[self.gn[0]] if self.gn else None,
+                                   g.params[self.gn[1]] if self.gn else None, self.groups, ge, self.ci_real,
+                                   self.co_real, g.pgrad[self.wname],
+                                   g.pgrad[self.bname] if self.bname else None, 0))
+
+
+class FuseOp:
+    def __init__(self, g, terms, y):
+        self.g, self.terms, self.y = g, terms, y
+
+    def emit_backward(self, gy: View):
+        g, be = self.g, self.g.be
+        for t in self.terms:
+            if not t.needs_grad:
+                continue
+            if t.dims == self.y.dims:
+                t.contribs.append((gy, None))
+            else:
+                glow_buf = be.alloc((g.n, t.d, t.h, t.w, t.c), "bf16")
+                glow = View(glow_buf, g.n, t.d, t.h, t.w, t.c, 0, t.c)
+                g.bwd.append(be.upsample_bwd(gy, glow))
+                t.contribs.append((glow, None))

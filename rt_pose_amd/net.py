@@ -1,0 +1,112 @@
+"""HRRadarPose as a static graph: mirrors the reference module tree op for op.
+
+  HighResolution3DNet.forward   det3d/models/backbones/hr_util/hr3d.py:373-399 (transitions :286-331)
+  HighResolutionModule.forward  hr3d.py:205-229 (fuse layers :135-200)
+  ResNetBlock.forward           hr_util/common.py:138-148
+  HRNet3D.forward               det3d/models/backbones/hrnet3d.py:29-43
+  CenterHead / SepHead          det3d/models/pose_heads/center_head.py:66-109, 232-238
+
+Parameter names are the reference state_dict keys (so reference checkpoints load unchanged).
+"""
+from .graph import Graph
+
+# det3d/models/backbones/hrnet3D_config.py:85-187 -- tables selected by configs/cruw_pose/*.py
+ARCH_TABLES = {
+    "hr_tiny_feat32_zyx_l4": dict(inplanes=1, channels=(32, 32, 64, 64)),
+    "hr_tiny_feat32_zyx_l4_in32": dict(inplanes=32, channels=(32, 32, 64, 64)),
+    "hr_tiny_feat64_zyx_l4_in64": dict(inplanes=64, channels=(64, 64, 128, 128)),
+}
+
+
+def down_dims(dims):
+    return tuple((s + 2 - 3) // 2 + 1 for s in dims)
+
+
+def _resblock(g: Graph, p, x, tag):
+    """GN->conv3->ReLU, GN->conv3, +x, ReLU   (conv1 is Identity here: Cin == Cout)."""
+    t = g.conv(tag + ".c2", x, p + ".conv2.conv.weight", gn=(p + ".conv2.groupnorm.weight", p + ".conv2.groupnorm.bias"),
+               relu=True)
+    return g.conv(tag + ".c3", t, p + ".conv3.conv.weight", gn=(p + ".conv3.groupnorm.weight", p + ".conv3.groupnorm.bias"),
+                  relu=True, residual=x)
+
+
+def _seq(g: Graph, p, x, tag, ks, stride, relu):
+    """nn.Sequential(GroupNorm, Conv3d(bias=False)[, ReLU])."""
+    return g.conv(tag, x, p + ".1.weight", gn=(p + ".0.weight", p + ".0.bias"), ks=ks, stride=stride, relu=relu)
+
+
+def build_backbone(g: Graph, x_f32, arch, dims, prefix="backbone.backbone", live_rows_last=None):
+    """Returns the list of stage-4 outputs.  live_rows_last: how many fuse rows of the LAST stage to compute
+    (final_fuse='top' only consumes row 0; rows 1..3 of stage4 are dead code in the reference)."""
+    a = ARCH_TABLES[arch]
+    ch = a["channels"]
+    p = prefix + ".layer1"
+    if a["inplanes"] == 1:
+        t0 = g.stem("l1.c1", x_f32, dims, p + ".conv1.weight", p + ".conv1.bias")
+    else:
+        xin = g.pack("l1.in", x_f32, a["inplanes"], dims)
+        if a["inplanes"] != ch[0] or (p + ".conv1.weight") in g.params:
+            t0 = g.conv("l1.c1", xin, p + ".conv1.weight", bname=p + ".conv1.bias", ks=1)
+        else:
+            t0 = xin
+    ys = [_resblock(g, p, t0, "l1")]
+    for stage in (2, 3, 4):
+        nb = stage
+        new = _seq(g, "%s.transition%d.%d.0" % (prefix, stage - 1, stage - 1), ys[-1], "t%d" % (stage - 1), 3, 2, True)
+        xs = ys + [new]
+        sp = "%s.stage%d.0" % (prefix, stage)
+        xs = [_resblock(g, "%s.branches.%d.0" % (sp, i), xs[i], "s%d.b%d" % (stage, i)) for i in range(nb)]
+        rows = nb if (stage < 4 or live_rows_last is None) else live_rows_last
+        ys = []
+        for i in range(rows):
+            terms = []
+            for j in range(nb):
+                if j == i:
+                    terms.append(xs[j])
+                elif j > i:
+                    terms.append(_seq(g, "%s.fuse_layers.%d.%d" % (sp, i, j), xs[j], "s%d.f%d%d" % (stage, i, j), 1, 1, False))
+                else:
+                    t = xs[j]
+                    for k in range(i - j):
+                        t = _seq(g, "%s.fuse_layers.%d.%d.%d" % (sp, i, j, k), t, "s%d.f%d%d.%d" % (stage, i, j, k), 3, 2,
+                                 relu=(k != i - j - 1))
+                    terms.append(t)
+            ys.append(g.fuse("s%d.row%d" % (stage, i), terms, relu=True))
+    return ys
+
+
+def build_hrnet3d(g: Graph, x_f32, arch, dims, final_fuse, prefix="backbone"):
+    ch = ARCH_TABLES[arch]["channels"]
+    has_final = (prefix + ".final_conv.weight") in g.params
+    if final_fuse == "top":
+        ys = build_backbone(g, x_f32, arch, dims, prefix + ".backbone", live_rows_last=1)
+        f = ys[0]
+        if has_final:
+            f = g.conv("final", f, prefix + ".final_conv.weight", bname=prefix + ".final_conv.bias", ks=1)
+        return f
+    ys = build_backbone(g, x_f32, arch, dims, prefix + ".backbone")
+    if final_fuse != "conat_conv" or not has_final:
+        raise NotImplementedError("final_fuse=%r without final_conv (plain concat) is not used by any shipped config" % final_fuse)
+    # cat(x0, up(x1), up(x2), up(x3)) -> 1x1x1 conv  ==  sum_j up(conv1x1_j(x_j))   (both ops are linear and
+    # the upsample acts per channel), so the 192-channel concat is never materialised.
+    total = sum(ch)
+    off, terms = 0, []
+    for j, y in enumerate(ys):
+        terms.append(g.conv("final.%d" % j, y, prefix + ".final_conv.weight",
+                            bname=(prefix + ".final_conv.bias") if j == 0 else None, ks=1,
+                            w_ci_total=total, w_ci_off=off, ci_real=ch[j]))
+        off += ch[j]
+    return g.fuse("final.sum", terms, relu=False)
+
+
+def build_head(g: Graph, feats, heads, prefix="pose_head"):
+    """SepHead with head_conv=32, final_kernel=3 (center_head.py:223): Conv3d(C,32,3)+ReLU -> Conv3d(32,classes,3)."""
+    if (prefix + ".shared_conv.1.weight") in g.params:
+        feats = g.conv("shared", feats, prefix + ".shared_conv.1.weight",
+                       gn=(prefix + ".shared_conv.0.weight", prefix + ".shared_conv.0.bias"), relu=True)
+    out = {}
+    for name in heads:
+        p = "%s.tasks.0.%s" % (prefix, name)
+        t = g.conv("head.%s.0" % name, feats, p + ".0.weight", bname=p + ".0.bias", relu=True)
+        out[name] = g.conv("head.%s.2" % name, t, p + ".2.weight", bname=p + ".2.bias", out_fp32=True)
+    return out

@@ -1,0 +1,411 @@
+"""Torch-CPU emulation of every kernel in include/rtp.h -- a TEST DOUBLE, never shipped or used by the product.
+
+Two jobs:
+  * `-m "not gpu"` tests inject it into rt_pose_amd.graph.Graph to check the plan logic (fold algebra,
+    backward emission, grad routing) against the oracle's autograd without a GPU;
+  * `-m gpu` tests run the same closure on CPU copies of the same buffers and compare with what the HIP
+    kernel wrote (per-kernel parity).
+It mirrors the kernels' buffer layouts and rounding points (bf16 stores, fp32 accumulation).
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+_DT = {"bf16": torch.bfloat16, "f32": torch.float32, "i64": torch.int64, "u8": torch.uint8}
+
+
+def _sl(v):
+    """float32 [n,d,h,w,c] copy of a view"""
+    return v.buf[..., v.co:v.co + v.c].float()
+
+
+def _store(v, val):
+    v.buf[..., v.co:v.co + val.shape[-1]] = val.to(v.buf.dtype)
+
+
+def _ncdhw(t):
+    return t.permute(0, 4, 1, 2, 3).contiguous()
+
+
+def _ndhwc(t):
+    return t.permute(0, 2, 3, 4, 1).contiguous()
+
+
+def _classes(d, h, w):
+    z = torch.arange(d).view(d, 1, 1)
+    y = torch.arange(h).view(1, h, 1)
+    x = torch.arange(w).view(1, 1, w)
+    return ((z == 0).long() | ((z == d - 1).long() << 1) | ((y == 0).long() << 2) | ((y == h - 1).long() << 3)
+            | ((x == 0).long() << 4) | ((x == w - 1).long() << 5))
+
+
+def _tap_inb_1d(k, first, last, O, I, s, pad):
+    if first and not (0 <= k - pad < I):
+        return False
+    if last and not (0 <= (O - 1) * s + k - pad < I):
+        return False
+    return True
+
+
+def _tap_inb(tap, cls, g):
+    ks = g.ks
+    kz, ky, kx = tap // (ks * ks), (tap // ks) % ks, tap % ks
+    return (_tap_inb_1d(kz, cls & 1, (cls >> 1) & 1, g.do, g.di, g.stride, g.pad)
+            and _tap_inb_1d(ky, (cls >> 2) & 1, (cls >> 3) & 1, g.ho, g.hi, g.stride, g.pad)
+            and _tap_inb_1d(kx, (cls >> 4) & 1, (cls >> 5) & 1, g.wo, g.wi, g.stride, g.pad))
+
+
+def _split_ranges(vox, nsplit, mult=1):
+    vps = (vox + nsplit - 1) // nsplit
+    vps = (vps + mult - 1) // mult * mult
+    return [(min(s * vps, vox), min((s + 1) * vps, vox)) for s in range(nsplit)]
+
+
+class EmuBackend:
+    name = "emu"
+
+    def __init__(self, exact=False):
+        """exact=True keeps every 'bf16' buffer in fp32: isolates plan-logic errors from rounding."""
+        self.bytes = 0
+        self.exact = exact
+
+    def alloc(self, shape, dtype):
+        if self.exact and dtype == "bf16":
+            dtype = "f32"
+        return torch.zeros(shape, dtype=_DT[dtype])
+
+    def stream(self):
+        return None
+
+    def stem_bwd_blocks(self):
+        return 1
+
+    # ---------------------------------------------------------------- conv family
+    def chan_stats(self, a, b, nsplit, out):
+        def run(s):
+            x = _sl(a).reshape(a.n, a.vox, a.c)
+            y = _sl(b).reshape(a.n, a.vox, a.c) if b is not None else x
+            for i, (v0, v1) in enumerate(_split_ranges(a.vox, nsplit)):
+                out[:, i, :, 0] = x[:, v0:v1].sum(1)
+                out[:, i, :, 1] = (x[:, v0:v1] * y[:, v0:v1]).sum(1)
+        return run
+
+    def fold_fwd(self, w, bias, gamma, beta, stats, nsplit, groups, eps, geom, ci_real, co_real, wf, btab, mr):
+        def run(s):
+            g = geom
+            ntap = g.ks ** 3
+            cit = g.w_ci_total or ci_real
+            W = w.detach().reshape(co_real, cit, ntap)[:, g.w_ci_off:g.w_ci_off + ci_real].float()
+            nw = wf.shape[0]
+            for n in range(nw):
+                if stats is not None:
+                    st = stats[n].double().sum(0)  # [c,2]
+                    cg = ci_real // groups
+                    cnt = cg * g.di * g.hi * g.wi
+                    sg = st.reshape(groups, cg, 2).sum(1)
+                    mean = sg[:, 0] / cnt
+                    var = (sg[:, 1] / cnt - mean * mean).clamp_min(0)
+                    rstd = (1.0 / torch.sqrt(var + eps)).float()
+                    if mr is not None:
+                        mr[n, :, 0] = mean.float()
+                        mr[n, :, 1] = rstd
+                    scale = rstd.repeat_interleave(cg) * gamma.detach().float()
+                    shift = beta.detach().float() - mean.float().repeat_interleave(cg) * scale
+                else:
+                    scale = torch.ones(ci_real)
+                    shift = torch.zeros(ci_real)
+                full = torch.zeros(ntap, g.co, g.ci)
+                full[:, :co_real, :ci_real] = (W * scale.view(1, -1, 1)).permute(2, 0, 1)
+                wf[n] = full.to(wf.dtype)
+                if btab is not None:
+                    T = torch.einsum("oct,c->ot", W, shift)  # [co,tap]
+                    bt = torch.zeros(64, g.co)
+                    if bias is not None:
+                        bt[:, :co_real] += bias.detach().float()
+                    if stats is not None:
+                        for cls in range(64):
+                            inb = torch.tensor([_tap_inb(t, cls, g) for t in range(ntap)])
+                            bt[cls, :co_real] += T[:, inb].sum(1)
+                    btab[n] = bt
+        return run
+
+    def pack_dgrad_w(self, w, geom, ci_real, co_real, wd):
+        def run(s):
+            g = geom
+            ntap = g.ks ** 3
+            cit = g.w_ci_total or ci_real
+            W = w.detach().reshape(co_real, cit, ntap)[:, g.w_ci_off:g.w_ci_off + ci_real].float()
+            full = torch.zeros(ntap, g.ci, wd.shape[2])
+            full[:, :ci_real, :co_real] = W.permute(2, 1, 0)
+            wd.copy_(full.to(wd.dtype))
+        return run
+
+    def conv(self, x, wf, per_sample, btab, res, y, geom, relu, transposed, y_fp32):
+        def run(s):
+            g = geom
+            k = g.ks
+            if not transposed:
+                ci, co = g.ci, g.co
+                xin = _ncdhw(x.buf[..., x.co:x.co + ci].float())
+                outs = []
+                for n in range(g.n):
+                    wn = wf[n if per_sample else 0].float().reshape(k, k, k, co, ci).permute(3, 4, 0, 1, 2)
+                    outs.append(F.conv3d(xin[n:n + 1], wn, None, g.stride, g.pad))
+                out = _ndhwc(torch.cat(outs))
+                if btab is not None:
+                    cls = _classes(g.do, g.ho, g.wo)
+                    out = out + torch.stack([btab[n if per_sample else 0][cls] for n in range(g.n)])
+            else:
+                cok = (g.co + 31) // 32 * 32
+                xin = _ncdhw(x.buf[..., x.co:x.co + cok].float())
+                wt = wf.float().reshape(k, k, k, g.ci, cok).permute(4, 3, 0, 1, 2)  # [cok(in), ci(out), k,k,k]
+                op = [i - ((o - 1) * g.stride - 2 * g.pad + k) for i, o in
+                      zip((g.di, g.hi, g.wi), (g.do, g.ho, g.wo))]
+                out = _ndhwc(F.conv_transpose3d(xin, wt, None, g.stride, g.pad, output_padding=tuple(op)))
+            if res is not None:
+                out = out + _sl(res)[..., :out.shape[-1]]
+            if relu:
+                out = out.clamp_min(0)
+            _store(y, out)
+        return run
+
+    def wgrad(self, gy, x, geom, nsplit, gp):
+        def run(s):
+            g = geom
+            k = g.ks
+            co32 = gp.shape[3]
+            gyf = gy.buf[..., gy.co:gy.co + co32].float().reshape(g.n, -1, co32)
+            xin = _ncdhw(x.buf[..., x.co:x.co + g.ci].float())
+            vo = g.do * g.ho * g.wo
+            for i, (v0, v1) in enumerate(_split_ranges(vo, nsplit, 256)):
+                if v1 <= v0:
+                    gp[:, i] = 0
+                    continue
+                m = torch.zeros(g.n, vo, co32)
+                m[:, v0:v1] = gyf[:, v0:v1]
+                go = _ncdhw(m.reshape(g.n, g.do, g.ho, g.wo, co32))
+                for n in range(g.n):
+                    dw = torch.nn.grad.conv3d_weight(xin[n:n + 1], (co32, g.ci, k, k, k), go[n:n + 1], g.stride, g.pad)
+                    gp[n, i] = dw.reshape(co32, g.ci, k ** 3).permute(2, 0, 1)
+        return run
+
+    def class_sums(self, gy, nsplit, out):
+        def run(s):
+            cls = _classes(gy.d, gy.h, gy.w).reshape(-1)
+            gf = _sl(gy).reshape(gy.n, gy.vox, gy.c)
+            out.zero_()
+            for i, (v0, v1) in enumerate(_split_ranges(gy.vox, nsplit)):
+                if v1 > v0:
+                    out[:, i].index_add_(1, cls[v0:v1], gf[:, v0:v1])
+        return run
+
+    def wgrad_fold(self, gp, nsplit, csum, csplit, mr, gamma, beta, groups, geom, ci_real, co_real, dw, dbias, acc):
+        def run(s):
+            g = geom
+            ntap = g.ks ** 3
+            G = gp.sum(1)[:, :, :co_real, :ci_real]  # [n,tap,co,ci]
+            if mr is not None:
+                cg = ci_real // groups
+                scale = mr[:, :, 1].repeat_interleave(cg, 1) * gamma.detach().float()  # [n,ci]
+                shift = beta.detach().float() - mr[:, :, 0].repeat_interleave(cg, 1) * scale
+                cs = csum.sum(1)[:, :, :co_real]  # [n,64,co]
+                sdy = torch.zeros(g.n, co_real, ntap)
+                for t in range(ntap):
+                    inb = torch.tensor([_tap_inb(t, c, g) for c in range(64)])
+                    sdy[:, :, t] = cs[:, inb].sum(1)
+                val = torch.einsum("ntoc,nc->oct", G, scale) + torch.einsum("not,nc->oct", sdy, shift)
+            else:
+                val = G.sum(0).permute(1, 2, 0)
+            cit = g.w_ci_total or ci_real
+            dwv = dw.view(co_real, cit, ntap)[:, g.w_ci_off:g.w_ci_off + ci_real]
+            if acc:
+                dwv.add_(val)
+            else:
+                dwv.copy_(val)
+            if dbias is not None:
+                b = csum.sum((0, 1, 2))[:co_real]
+                if acc:
+                    dbias.add_(b)
+                else:
+                    dbias.copy_(b)
+        return run
+
+    def gn_bwd_coeffs(self, pq, nsplit, mr, gamma, n, c, groups, vox, coeff, dgamma, dbeta, acc):
+        def run(s):
+            cg = c // groups
+            P = pq.sum(1)[:, :c, 0]
+            Q = pq.sum(1)[:, :c, 1]
+            mu = mr[:, :, 0].repeat_interleave(cg, 1)
+            r = mr[:, :, 1].repeat_interleave(cg, 1)
+            gam = gamma.detach().float()
+            m = float(cg * vox)
+            s1 = (gam * P).reshape(n, groups, cg).sum(2).repeat_interleave(cg, 1)
+            s2 = (gam * r * (Q - mu * P)).reshape(n, groups, cg).sum(2).repeat_interleave(cg, 1)
+            coeff[:, :c, 0] = r * gam
+            coeff[:, :c, 1] = -r * r * s2 / m
+            coeff[:, :c, 2] = -r * s1 / m + r * r * mu * s2 / m
+            dg = (r * (Q - mu * P)).sum(0)
+            db = P.sum(0)
+            if acc:
+                dgamma.add_(dg)
+                dbeta.add_(db)
+            else:
+                dgamma.copy_(dg)
+                dbeta.copy_(db)
+        return run
+
+    # ---------------------------------------------------------------- point-wise family
+    def grad_combine(self, terms, x, relu_src, out):
+        def run(s):
+            acc = torch.zeros(out.n, out.d, out.h, out.w, out.c)
+            for v, cf in terms:
+                if cf is None:
+                    acc += _sl(v)
+                else:
+                    c = cf.view(out.n, 1, 1, 1, -1, 3)[..., :out.c, :]
+                    acc += c[..., 0] * _sl(v) + c[..., 1] * _sl(x)[..., :out.c] + c[..., 2]
+            if relu_src is not None:
+                acc = torch.where(_sl(relu_src)[..., :out.c] > 0, acc, torch.zeros(()))
+            _store(out, acc)
+        return run
+
+    def fuse_sum(self, terms, bias, out, relu):
+        def run(s):
+            acc = torch.zeros(out.n, out.d, out.h, out.w, out.c)
+            if bias is not None:
+                acc += bias.detach().float()
+            for t in terms:
+                v = _sl(t)
+                if (t.d, t.h, t.w) != (out.d, out.h, out.w):
+                    v = _ndhwc(F.interpolate(_ncdhw(v), size=(out.d, out.h, out.w), mode="trilinear", align_corners=True))
+                acc += v
+            if relu:
+                acc = acc.clamp_min(0)
+            _store(out, acc)
+        return run
+
+    def upsample_bwd(self, ghi, glow):
+        def run(s):
+            z = torch.zeros(glow.n, glow.c, glow.d, glow.h, glow.w, requires_grad=True)
+            up = F.interpolate(z, size=(ghi.d, ghi.h, ghi.w), mode="trilinear", align_corners=True)
+            up.backward(_ncdhw(_sl(ghi)))
+            _store(glow, _ndhwc(z.grad))
+        return run
+
+    def stem_fwd(self, x, w, b, y):
+        def run(s):
+            out = x.reshape(y.n, y.d, y.h, y.w, 1).float() * w.detach().reshape(-1).float() + b.detach().float()
+            _store(y, out)
+        return run
+
+    def stem_bwd(self, x, gy, scratch, dw, db, acc):
+        def run(s):
+            gf = _sl(gy)
+            xf = x.reshape(gy.n, gy.d, gy.h, gy.w, 1).float()
+            vw = (gf * xf).sum((0, 1, 2, 3))[:dw.numel()]
+            vb = gf.sum((0, 1, 2, 3))[:db.numel()]
+            if acc:
+                dw.view(-1).add_(vw)
+                db.add_(vb)
+            else:
+                dw.view(-1).copy_(vw)
+                db.copy_(vb)
+        return run
+
+    def pack_ncdhw(self, x, y, c):
+        def run(s):
+            out = torch.zeros(y.n, y.d, y.h, y.w, y.c)
+            out[..., :c] = _ndhwc(x.float())
+            _store(y, out)
+        return run
+
+    def unpack_ncdhw(self, x, y, c):
+        def run(s):
+            y.copy_(_ncdhw(_sl(x)[..., :c]))
+        return run
+
+    # ---------------------------------------------------------------- head
+    def focal_scratch(self, n):
+        return torch.zeros(2)
+
+    def focal_loss(self, logits, target, ind, mask, cat, ncls, gscale, scratch, out_loss, ghm):
+        def run(s):
+            z = logits.buf[..., :ncls].detach().clone().requires_grad_(True)  # [n,d,h,w,ncls]
+            p = torch.clamp(torch.sigmoid(z), 1e-4, 1 - 1e-4)
+            pn = p.permute(0, 4, 1, 2, 3)
+            mk = mask.float()
+            neg = (torch.log(1 - pn) * pn.pow(2) * (1 - target).pow(4)).sum()
+            n = z.shape[0]
+            flat = p.reshape(n, -1, ncls)
+            pos_pred = flat.gather(1, ind.unsqueeze(2).expand(n, ind.shape[1], ncls)).gather(2, cat.unsqueeze(2))
+            pos = (torch.log(pos_pred) * (1 - pos_pred).pow(2) * mk.unsqueeze(2)).sum()
+            num_pos = mk.sum()
+            loss = -neg if num_pos == 0 else -(pos + neg) / num_pos
+            (loss * gscale).backward()
+            out_loss[0] = loss.detach()
+            g = torch.zeros(ghm.n, ghm.d, ghm.h, ghm.w, ghm.c)
+            g[..., :ncls] = z.grad
+            _store(ghm, g)
+        return run
+
+    def reg_loss(self, reg, target, ind, mask, code_w, nreg, gscale, out, greg):
+        def run(s):
+            r = reg.buf[..., :nreg].detach().clone().requires_grad_(True)
+            n = r.shape[0]
+            pred = r.reshape(n, -1, nreg).gather(1, ind.unsqueeze(2).expand(n, ind.shape[1], nreg))
+            mk = mask.float().unsqueeze(2)
+            loss = F.l1_loss(pred * mk, target * mk, reduction="none") / (mk.sum() + 1e-4)
+            loss = loss.transpose(2, 0).sum(dim=2).sum(dim=1)
+            loc = (loss * code_w).sum()
+            (loc * gscale).backward()
+            out[:nreg] = loss.detach()
+            out[nreg] = loc.detach()
+            g = torch.zeros(greg.n, greg.d, greg.h, greg.w, greg.c)
+            g[..., :nreg] = r.grad
+            greg.buf.copy_(g.to(greg.buf.dtype))
+        return run
+
+    def decode_scratch(self, n, ncls):
+        return torch.zeros(1)
+
+    def decode(self, hm, reg, ncls, nreg, scale_xyz, origin_xyz, scratch, out):
+        def run(s):
+            n = hm.n
+            sg = torch.sigmoid(hm.buf[..., :ncls]).reshape(n, -1, ncls)
+            rg = reg.buf[..., :nreg].reshape(n, -1, nreg)
+            for b in range(n):
+                for c in range(ncls):
+                    idx = int(torch.argmax(sg[b, :, c]))
+                    z, rem = divmod(idx, hm.h * hm.w)
+                    y, x = divmod(rem, hm.w)
+                    out[b, c, 0] = float(idx)
+                    out[b, c, 1] = sg[b, idx, c]
+                    for k in range(nreg // 3):
+                        out[b, c, 2 + 3 * k] = (x + rg[b, idx, 3 * k]) * scale_xyz[0] + origin_xyz[0]
+                        out[b, c, 3 + 3 * k] = (y + rg[b, idx, 3 * k + 1]) * scale_xyz[1] + origin_xyz[1]
+                        out[b, c, 4 + 3 * k] = (z + rg[b, idx, 3 * k + 2]) * scale_xyz[2] + origin_xyz[2]
+        return run
+
+    def sqnorm_blocks(self):
+        return 1
+
+    def sqnorm(self, g, n, hyper, partial):
+        def run(s):
+            partial.zero_()
+            partial[0] = ((g[:n] * hyper[8]) ** 2).sum()
+        return run
+
+    def adam_step(self, p, g, m, v, n, hyper, partial, mode, norm_out):
+        def run(s):
+            lr, b1, b2, eps, wd, max_norm, bc1, bc2, gs = [float(hyper[i]) for i in range(9)]
+            p[:n].mul_(1 - wd * lr)
+            if mode == 0:
+                total = float(partial.sum().sqrt())
+                coef = min(max_norm / (total + 1e-6), 1.0)
+                if norm_out is not None:
+                    norm_out[0] = total
+                gv = g[:n] * gs * coef
+                m[:n].mul_(b1).add_(gv, alpha=1 - b1)
+                v[:n].mul_(b2).addcmul_(gv, gv, value=1 - b2)
+                p[:n].sub_((lr / bc1) * m[:n] / (v[:n].sqrt() / np.sqrt(bc2) + eps))
+        return run
