@@ -1,0 +1,349 @@
+"""Per-kernel parity on a real MI355X: every C-ABI entry point (through rt_pose_amd.backend.HipBackend) against the
+torch-CPU emulation of the same kernel on identical seeded buffers, including the edge cases the shapes of the
+path produce (stride 2, 1x1x1, depth-1 volumes, channel-padded heads, channel-slice views, ragged voxel counts).
+
+Tolerances: bf16 outputs -- norm-wise 4e-3 (one bf16 ulp is 2^-8 relative; fp32 accumulation order differs);
+fp32 outputs -- norm-wise 2e-4.
+"""
+import numpy as np
+import pytest
+import torch
+
+from rt_pose_amd.graph import Geom, View, pad_to
+from tests.emu_backend import EmuBackend
+from tests.util import rel_err
+
+pytestmark = pytest.mark.gpu
+
+BF, F32 = 4e-3, 2e-4
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from rt_pose_amd.backend import HipBackend
+    return HipBackend("cuda:0")
+
+
+EMU = EmuBackend()
+
+
+class Pair:
+    """The same tensor on both backends."""
+
+    def __init__(self, hip, t):
+        self.c = t.clone()
+        self.g = t.to(hip.device)
+
+    def sync_back(self):
+        return self.g.detach().cpu()
+
+
+def rnd(shape, seed, dtype=torch.bfloat16, scale=1.0, relu=False):
+    g = torch.Generator().manual_seed(seed)
+    t = torch.randn(*shape, generator=g) * scale
+    if relu:
+        t = torch.relu(t + 0.1)
+    return t.to(dtype)
+
+
+def views(hip, t, n, d, h, w, co=0, c=None):
+    p = Pair(hip, t)
+    cs = t.shape[-1]
+    c = c or cs - co
+    return p, View(p.c, n, d, h, w, cs, co, c), View(p.g, n, d, h, w, cs, co, c)
+
+
+def run(hip, fc, fg):
+    fc(None)
+    fg(hip.stream())
+    torch.cuda.synchronize()
+
+
+def check(pair, tol, what=""):
+    got, ref = pair.sync_back().float(), pair.c.float()
+    assert torch.isfinite(got).all(), what
+    e = rel_err(got, ref)
+    assert e < tol, (what, e)
+
+
+CONV_CASES = [
+    # n, dims, ci, co_real, ks, stride, per_sample, res, relu, fp32
+    (2, (4, 8, 16), 32, 32, 3, 1, True, True, True, False),
+    (2, (4, 8, 16), 32, 64, 3, 2, True, False, True, False),
+    (1, (2, 4, 20), 64, 32, 1, 1, True, False, False, False),
+    (2, (4, 8, 8), 32, 15, 3, 1, False, False, False, True),
+    (1, (1, 2, 4), 64, 64, 3, 2, True, False, True, False),   # depth-1 volume: first AND last flags together
+    (1, (3, 5, 7), 128, 128, 3, 1, True, True, False, False),  # ragged voxel count (105)
+    (2, (4, 8, 8), 32, 45, 3, 1, False, False, False, True),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_forward(hip, case):
+    n, dims, ci, co_real, ks, stride, per_sample, has_res, relu, fp32 = case
+    d, h, w = dims
+    pad = ks // 2
+    do, ho, wo = [(s + 2 * pad - ks) // stride + 1 for s in dims]
+    co = pad_to(co_real, 16)
+    geom = Geom(n, d, h, w, do, ho, wo, ci, co, ks, stride, pad)
+    xp, xc, xg = views(hip, rnd((n, d, h, w, ci), 1, relu=True), n, d, h, w)
+    nw = n if per_sample else 1
+    wf = Pair(hip, rnd((nw, ks ** 3, co, ci), 2, scale=0.05))
+    bt = Pair(hip, rnd((nw, 64, co), 3, torch.float32))
+    yc_ch = co if fp32 else (co if co_real % 16 == 0 else pad_to(co_real, 32))
+    yp, yc, yg = views(hip, torch.zeros(n, do, ho, wo, yc_ch, dtype=torch.float32 if fp32 else torch.bfloat16), n, do, ho, wo)
+    rc = rg = None
+    if has_res:
+        rp, rc, rg = views(hip, rnd((n, do, ho, wo, co), 4), n, do, ho, wo)
+    run(hip, EMU.conv(xc, wf.c, per_sample, bt.c, rc, yc, geom, relu, False, fp32),
+        hip.conv(xg, wf.g, per_sample, bt.g, rg, yg, geom, relu, False, fp32))
+    check(yp, F32 if fp32 else BF, "conv fwd %r" % (case,))
+
+
+@pytest.mark.parametrize("case", [
+    (2, (4, 8, 16), 32, 32, 3, 1), (2, (4, 8, 16), 32, 64, 3, 2), (1, (2, 4, 20), 64, 32, 1, 1),
+    (2, (4, 8, 8), 32, 15, 3, 1), (1, (1, 2, 4), 64, 64, 3, 2), (1, (5, 6, 7), 32, 32, 3, 2)])
+def test_conv_transposed_is_data_gradient(hip, case):
+    n, dims, ci, co_real, ks, stride = case
+    d, h, w = dims
+    pad = ks // 2
+    do, ho, wo = [(s + 2 * pad - ks) // stride + 1 for s in dims]
+    co = pad_to(co_real, 16)
+    cok = pad_to(co, 32)
+    geom = Geom(n, d, h, w, do, ho, wo, ci, co, ks, stride, pad)
+    gt = rnd((n, do, ho, wo, cok), 5)
+    gt[..., co_real:] = 0
+    gp_, gc, gg = views(hip, gt, n, do, ho, wo)
+    w32 = Pair(hip, rnd((co_real, ci, ks, ks, ks), 6, torch.float32, 0.05))
+    wd = Pair(hip, torch.zeros(ks ** 3, ci, cok, dtype=torch.bfloat16))
+    run(hip, EMU.pack_dgrad_w(w32.c, geom, ci, co_real, wd.c), hip.pack_dgrad_w(w32.g, geom, ci, co_real, wd.g))
+    assert torch.equal(wd.sync_back(), wd.c)
+    yp, yc, yg = views(hip, torch.zeros(n, d, h, w, ci, dtype=torch.bfloat16), n, d, h, w)
+    run(hip, EMU.conv(gc, wd.c, False, None, None, yc, geom, False, True, False),
+        hip.conv(gg, wd.g, False, None, None, yg, geom, False, True, False))
+    check(yp, BF, "dgrad %r" % (case,))
+    # and it IS the autograd data gradient of F.conv3d
+    x = torch.zeros(n, ci, d, h, w, requires_grad=True)
+    wq = w32.c.to(torch.bfloat16).float()
+    y = torch.nn.functional.conv3d(x, wq, None, stride, pad)
+    y.backward(gt[..., :co_real].float().permute(0, 4, 1, 2, 3))
+    assert rel_err(yp.sync_back().float().permute(0, 4, 1, 2, 3), x.grad) < BF
+
+
+@pytest.mark.parametrize("case", [
+    (2, (4, 8, 16), 32, 32, 3, 1, 4), (2, (8, 8, 16), 32, 64, 3, 2, 2), (1, (2, 4, 20), 64, 32, 1, 1, 1),
+    (2, (4, 8, 8), 32, 15, 3, 1, 3), (1, (3, 5, 7), 128, 128, 3, 1, 1), (1, (1, 2, 4), 64, 64, 3, 2, 1)])
+def test_wgrad(hip, case):
+    n, dims, ci, co_real, ks, stride, nsplit = case
+    d, h, w = dims
+    pad = ks // 2
+    do, ho, wo = [(s + 2 * pad - ks) // stride + 1 for s in dims]
+    co = pad_to(co_real, 16)
+    co32 = pad_to(co, 32)
+    geom = Geom(n, d, h, w, do, ho, wo, ci, co, ks, stride, pad)
+    gt = rnd((n, do, ho, wo, co32), 7)
+    gt[..., co_real:] = 0
+    _, gc, gg = views(hip, gt, n, do, ho, wo)
+    _, xc, xg = views(hip, rnd((n, d, h, w, ci), 8, relu=True), n, d, h, w)
+    gp = Pair(hip, torch.full((n, nsplit, ks ** 3, co32, ci), 7.0))
+    run(hip, EMU.wgrad(gc, xc, geom, nsplit, gp.c), hip.wgrad(gg, xg, geom, nsplit, gp.g))
+    check(gp, F32 * 5, "wgrad %r" % (case,))
+    # slabs sum to the autograd weight gradient
+    x = xc.buf.float().permute(0, 4, 1, 2, 3)
+    wz = torch.zeros(co_real, ci, ks, ks, ks, requires_grad=True)
+    torch.nn.functional.conv3d(x, wz, None, stride, pad).backward(gt[..., :co_real].float().permute(0, 4, 1, 2, 3))
+    got = gp.sync_back().sum((0, 1))[:, :co_real].permute(1, 2, 0).reshape(wz.shape)
+    assert rel_err(got, wz.grad) < 1e-3
+
+
+@pytest.mark.parametrize("c,vox,nsplit,with_b", [(32, 1000, 3, False), (64, 333, 1, True), (128, 2048, 7, True), (32, 64, 4, False)])
+def test_chan_stats(hip, c, vox, nsplit, with_b):
+    n = 2
+    _, ac, ag = views(hip, rnd((n, 1, 1, vox, c), 9, relu=True), n, 1, 1, vox)
+    bc = bg = None
+    if with_b:
+        _, bc, bg = views(hip, rnd((n, 1, 1, vox, c), 10), n, 1, 1, vox)
+    out = Pair(hip, torch.zeros(n, nsplit, c, 2))
+    run(hip, EMU.chan_stats(ac, bc, nsplit, out.c), hip.chan_stats(ag, bg, nsplit, out.g))
+    check(out, F32, "chan_stats")
+
+
+@pytest.mark.parametrize("ci,co_real,ks,stride,norm,bias,dims,slc", [
+    (32, 32, 3, 1, True, False, (4, 8, 8), None), (32, 64, 3, 2, True, False, (4, 8, 8), None),
+    (64, 32, 1, 1, True, False, (2, 4, 4), None), (32, 15, 3, 1, False, True, (4, 4, 4), None),
+    (64, 128, 1, 1, False, True, (2, 2, 2), (192, 64)), (32, 32, 3, 2, True, False, (1, 2, 4), None)])
+def test_fold_and_wgrad_fold(hip, ci, co_real, ks, stride, norm, bias, dims, slc):
+    n, groups = 2, 8
+    d, h, w = dims
+    pad = ks // 2
+    do, ho, wo = [(s + 2 * pad - ks) // stride + 1 for s in dims]
+    co = pad_to(co_real, 16)
+    cit, cio = slc if slc else (0, 0)
+    geom = Geom(n, d, h, w, do, ho, wo, ci, co, ks, stride, pad, cit, cio)
+    ntap = ks ** 3
+    w32 = Pair(hip, rnd((co_real, cit or ci, ks, ks, ks), 11, torch.float32, 0.1))
+    b32 = Pair(hip, rnd((co_real,), 12, torch.float32)) if bias else None
+    gam = Pair(hip, 1 + 0.2 * rnd((ci,), 13, torch.float32)) if norm else None
+    bet = Pair(hip, 0.2 * rnd((ci,), 14, torch.float32)) if norm else None
+    nsplit = 3
+    stats = None
+    if norm:
+        x = torch.relu(rnd((n, d * h * w, ci), 15, torch.float32) + 0.3)
+        st = torch.zeros(n, nsplit, ci, 2)
+        st[:, 0, :, 0] = x.sum(1)
+        st[:, 0, :, 1] = (x * x).sum(1)
+        stats = Pair(hip, st)
+    nw = n if norm else 1
+    wf = Pair(hip, torch.zeros(nw, ntap, co, ci, dtype=torch.bfloat16))
+    bt = Pair(hip, torch.zeros(nw, 64, co))
+    mr = Pair(hip, torch.zeros(n, groups, 2)) if norm else None
+
+    def g_(p, side):
+        return None if p is None else getattr(p, side)
+    run(hip,
+        EMU.fold_fwd(w32.c, g_(b32, "c"), g_(gam, "c"), g_(bet, "c"), g_(stats, "c"), nsplit, groups, 1e-5, geom, ci, co_real, wf.c, bt.c, g_(mr, "c")),
+        hip.fold_fwd(w32.g, g_(b32, "g"), g_(gam, "g"), g_(bet, "g"), g_(stats, "g"), nsplit, groups, 1e-5, geom, ci, co_real, wf.g, bt.g, g_(mr, "g")))
+    check(wf, BF, "fold wf")
+    check(bt, F32 * 5, "fold btab")
+    if norm:
+        check(mr, F32, "fold mr")
+    # backward fold
+    co32 = pad_to(co, 32)
+    gp = Pair(hip, rnd((n, 2, ntap, co32, ci), 16, torch.float32))
+    cs = Pair(hip, rnd((n, 2, 64, co32), 17, torch.float32))
+    dw = Pair(hip, rnd((co_real, cit or ci, ks, ks, ks), 18, torch.float32))
+    db = Pair(hip, rnd((co_real,), 19, torch.float32)) if bias else None
+    for acc in (0, 1):
+        run(hip,
+            EMU.wgrad_fold(gp.c, 2, cs.c, 2, g_(mr, "c"), g_(gam, "c"), g_(bet, "c"), groups, geom, ci, co_real, dw.c, g_(db, "c"), acc),
+            hip.wgrad_fold(gp.g, 2, cs.g, 2, g_(mr, "g"), g_(gam, "g"), g_(bet, "g"), groups, geom, ci, co_real, dw.g, g_(db, "g"), acc))
+        check(dw, F32 * 5, "wgrad_fold dw acc=%d" % acc)
+        if bias:
+            check(db, F32 * 5, "wgrad_fold db")
+
+
+def test_gn_bwd_coeffs_and_class_sums(hip):
+    n, c, groups, vox, nsplit = 3, 64, 8, 5000, 4
+    pq = Pair(hip, rnd((n, nsplit, c, 2), 20, torch.float32))
+    mr = Pair(hip, torch.rand(n, groups, 2, generator=torch.Generator().manual_seed(1)) + 0.5)
+    gam = Pair(hip, 1 + 0.2 * rnd((c,), 21, torch.float32))
+    co = Pair(hip, torch.zeros(n, c, 3))
+    dg, db = Pair(hip, rnd((c,), 22, torch.float32)), Pair(hip, rnd((c,), 23, torch.float32))
+    for acc in (0, 1):
+        run(hip, EMU.gn_bwd_coeffs(pq.c, nsplit, mr.c, gam.c, n, c, groups, vox, co.c, dg.c, db.c, acc),
+            hip.gn_bwd_coeffs(pq.g, nsplit, mr.g, gam.g, n, c, groups, vox, co.g, dg.g, db.g, acc))
+        check(co, F32, "coeff")
+        check(dg, F32, "dgamma")
+        check(db, F32, "dbeta")
+    for dims, ch in (((4, 6, 10), 32), ((1, 2, 4), 64), ((2, 1, 3), 128)):
+        d, h, w = dims
+        _, gc, gg = views(hip, rnd((2, d, h, w, ch), 24), 2, d, h, w)
+        out = Pair(hip, torch.ones(2, 3, 64, ch))
+        run(hip, EMU.class_sums(gc, 3, out.c), hip.class_sums(gg, 3, out.g))
+        check(out, F32 * 5, "class_sums %r" % (dims,))
+
+
+def test_grad_combine_fuse_upsample(hip):
+    n, d, h, w, c = 2, 4, 8, 16, 32
+    _, xc, xg = views(hip, rnd((n, d, h, w, c), 30, relu=True), n, d, h, w)
+    _, t1c, t1g = views(hip, rnd((n, d, h, w, c), 31), n, d, h, w)
+    _, t2c, t2g = views(hip, rnd((n, d, h, w, 2 * c), 32), n, d, h, w, co=c, c=c)  # channel-slice view
+    cf = Pair(hip, rnd((n, c, 3), 33, torch.float32))
+    op, oc, og = views(hip, torch.zeros(n, d, h, w, c, dtype=torch.bfloat16), n, d, h, w)
+    run(hip, EMU.grad_combine([(t1c, None), (t2c, cf.c)], xc, xc, oc), hip.grad_combine([(t1g, None), (t2g, cf.g)], xg, xg, og))
+    check(op, BF, "grad_combine")
+    # fuse rows: same-res + three lower resolutions (the stage-4 row-0 pattern)
+    lows = [((2, 4, 8), 35), ((1, 2, 4), 36), ((1, 1, 2), 37)]
+    tc, tg = [t1c], [t1g]
+    for (ld, lh, lw), seed in lows:
+        _, lc, lg = views(hip, rnd((n, ld, lh, lw, c), seed), n, ld, lh, lw)
+        tc.append(lc)
+        tg.append(lg)
+    for relu in (True, False):
+        run(hip, EMU.fuse_sum(tc, None, oc, relu), hip.fuse_sum(tg, None, og, relu))
+        check(op, BF, "fuse_sum relu=%s" % relu)
+    # upsample adjoint for x2, x4, x8 and a non-integer ratio
+    for (ld, lh, lw), ch in (((2, 4, 8), 32), ((1, 2, 4), 64), ((1, 1, 2), 128), ((3, 5, 7), 32)):
+        _, gc, gg = views(hip, rnd((n, d, h, w, ch), 38), n, d, h, w)
+        lp, lc, lg = views(hip, torch.zeros(n, ld, lh, lw, ch, dtype=torch.bfloat16), n, ld, lh, lw)
+        run(hip, EMU.upsample_bwd(gc, lc), hip.upsample_bwd(gg, lg))
+        check(lp, BF, "upsample_bwd %r" % ((ld, lh, lw),))
+
+
+def test_stem_and_pack(hip):
+    n, d, h, w = 2, 4, 8, 16
+    x = Pair(hip, torch.relu(rnd((n, 1, d, h, w), 40, torch.float32)))
+    wt, b = Pair(hip, rnd((32, 1, 1, 1, 1), 41, torch.float32)), Pair(hip, rnd((32,), 42, torch.float32))
+    yp, yc, yg = views(hip, torch.zeros(n, d, h, w, 32, dtype=torch.bfloat16), n, d, h, w)
+    run(hip, EMU.stem_fwd(x.c, wt.c, b.c, yc), hip.stem_fwd(x.g, wt.g, b.g, yg))
+    check(yp, BF, "stem_fwd")
+    _, gc, gg = views(hip, rnd((n, d, h, w, 32), 43), n, d, h, w)
+    dw, db = Pair(hip, torch.zeros(32, 1, 1, 1, 1)), Pair(hip, torch.zeros(32))
+    sc = hip.alloc((hip.stem_bwd_blocks(), 32, 2), "f32")
+    run(hip, EMU.stem_bwd(x.c, gc, None, dw.c, db.c, 0), hip.stem_bwd(x.g, gg, sc, dw.g, db.g, 0))
+    check(dw, F32 * 5, "stem dw")
+    check(db, F32 * 5, "stem db")
+    x32 = Pair(hip, rnd((n, 32, d, h, w), 44, torch.float32))
+    pp, pc, pg = views(hip, torch.zeros(n, d, h, w, 32, dtype=torch.bfloat16), n, d, h, w)
+    run(hip, EMU.pack_ncdhw(x32.c, pc, 32), hip.pack_ncdhw(x32.g, pg, 32))
+    assert torch.equal(pp.sync_back(), pp.c)
+    back = Pair(hip, torch.zeros(n, 32, d, h, w))
+    run(hip, EMU.unpack_ncdhw(pc, back.c, 32), hip.unpack_ncdhw(pg, back.g, 32))
+    assert torch.equal(back.sync_back(), back.c)
+
+
+@pytest.mark.parametrize("ncls,nreg", [(15, 3), (1, 45)])
+def test_losses_and_decode(hip, ncls, nreg):
+    from oracle import hrradarpose_ref as O
+    n, dims = 2, (4, 8, 16)
+    d, h, w = dims
+    ex = O.synth_example(n, 1, dims, seed=5, one_hm=ncls == 1)["rdr"]
+    m = ex["ind"][0].shape[1]
+    hm_c, rg_c = pad_to(ncls, 16), pad_to(nreg, 16)
+    hp, hc, hg = views(hip, rnd((n, d, h, w, hm_c), 50, torch.float32, 2.0) - 2.0, n, d, h, w)
+    rp, rc, rg = views(hip, rnd((n, d, h, w, rg_c), 51, torch.float32), n, d, h, w)
+    # duplicate a positive voxel (two joints in one voxel) and mask one out
+    if m > 2:
+        ex["ind"][0][0, 1] = ex["ind"][0][0, 0]
+        ex["mask"][0][1, 2] = 0
+    tgt, ind, mask, cat = Pair(hip, ex["hm"][0]), Pair(hip, ex["ind"][0]), Pair(hip, ex["mask"][0]), Pair(hip, ex["cat"][0])
+    pose = Pair(hip, ex["anno_pose"][0].reshape(n, m, nreg).contiguous())
+    cw = Pair(hip, torch.linspace(1, 2, nreg))
+    gh_c, gr_c = pad_to(hm_c, 32), pad_to(rg_c, 32)
+    ghp, ghc, ghg = views(hip, torch.ones(n, d, h, w, gh_c, dtype=torch.bfloat16), n, d, h, w)
+    grp, grc, grg = views(hip, torch.ones(n, d, h, w, gr_c, dtype=torch.bfloat16), n, d, h, w)
+    lh, lr = Pair(hip, torch.zeros(1)), Pair(hip, torch.zeros(nreg + 1))
+    run(hip, EMU.focal_loss(hc, tgt.c, ind.c, mask.c, cat.c, ncls, 1.0, None, lh.c, ghc),
+        hip.focal_loss(hg, tgt.g, ind.g, mask.g, cat.g, ncls, 1.0, hip.focal_scratch(n), lh.g, ghg))
+    check(lh, 1e-4, "focal loss value")
+    check(ghp, BF, "focal grad")
+    run(hip, EMU.reg_loss(rc, pose.c, ind.c, mask.c, cw.c, nreg, 0.2, lr.c, grc),
+        hip.reg_loss(rg, pose.g, ind.g, mask.g, cw.g, nreg, 0.2, lr.g, grg))
+    check(lr, 1e-4, "reg loss values")
+    check(grp, BF, "reg grad")
+    out = Pair(hip, torch.zeros(n, ncls, 2 + nreg))
+    sc, og = (0.05, 0.15, 0.36), (0.77, -5.0, -1.1)
+    run(hip, EMU.decode(hc, rc, ncls, nreg, sc, og, None, out.c),
+        hip.decode(hg, rg, ncls, nreg, sc, og, hip.decode_scratch(n, ncls), out.g))
+    got, ref = out.sync_back(), out.c
+    assert torch.equal(got[..., 0], ref[..., 0]), "argmax indices"
+    np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=1e-5, atol=1e-5)
+
+
+def test_adam_and_sqnorm(hip):
+    nel = 100003
+    p, g = Pair(hip, rnd((nel,), 60, torch.float32)), Pair(hip, rnd((nel,), 61, torch.float32, 3.0))
+    m, v = Pair(hip, rnd((nel,), 62, torch.float32, 0.1)), Pair(hip, rnd((nel,), 63, torch.float32).abs() * 0.01)
+    hyper = Pair(hip, torch.tensor([1e-3, 0.9, 0.99, 1e-8, 0.01, 35.0, 1 - 0.9 ** 3, 1 - 0.99 ** 3, 0.5, 0.0]))
+    pc, pg = torch.zeros(1), hip.alloc((256,), "f32")
+    nc, ng = torch.zeros(1), hip.alloc((1,), "f32")
+    run(hip, EMU.sqnorm(g.c, nel, hyper.c, pc), hip.sqnorm(g.g, nel, hyper.g, pg))
+    assert abs(float(pg.sum()) - float(pc.sum())) < 1e-4 * float(pc.sum())
+    run(hip, EMU.adam_step(p.c, g.c, m.c, v.c, nel, hyper.c, pc, 0, nc), hip.adam_step(p.g, g.g, m.g, v.g, nel, hyper.g, pg, 0, ng))
+    assert float(nc) > 35.0  # the clip engaged
+    assert abs(float(ng.cpu()) - float(nc)) < 1e-4 * float(nc)
+    check(p, 1e-5, "adam p")
+    check(m, 1e-5, "adam m")
+    check(v, 1e-5, "adam v")
+    run(hip, EMU.adam_step(p.c, None, None, None, nel, hyper.c, pc, 1, None), hip.adam_step(p.g, None, None, None, nel, hyper.g, pg, 1, None))
+    check(p, 1e-6, "decay only")
