@@ -1,0 +1,163 @@
+#!/usr/bin/env python
+"""HRRadarPose training throughput on MI355X (radar frames/s), BASELINE.json's metric.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--model hr3d] [--batch 8]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A step = forward + losses + backward + gradient all-reduce + clip/Adam on one batch of synthetic radar tensors of
+the dataset-native shape [B,Cin,16,64,160] per GPU (weak scaling), inputs resident in HBM.  Rank 0 prints ONE JSON
+line.  At N=1 the line also carries:
+  roofline     -- the dominant kernel family's algorithmic FLOP/s (HIP events around every launch of that family,
+                  on the launch stream, over K eagerly launched steps right after the timed region) vs the dense
+                  bf16 MFMA peak;
+  cpu_baseline -- the oracle (oracle/hrradarpose_ref.py, PyTorch CPU fp32) timed on this host on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA, MI355X_MICROARCH.md chip table
+
+
+def cpu_baseline(name, seconds_budget=30.0):
+    """Oracle train step (fwd + loss + bwd + clip + Adam) on the host cores; reported, never the target."""
+    import torch
+    from oracle import hrradarpose_ref as O
+    arch, fin, fout, fuse, heads, weight, cw = O.MODEL_CONFIGS[name]
+    shapes = O.param_shapes(arch, fin, fout, fout, heads)
+    sd = {k: v.requires_grad_(True) for k, v in O.seeded_state_dict(shapes, seed=1).items()}
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    opt = O.AdamTrueWD(list(sd.values()))
+    batch, dims = 1, (16, 64, 160)
+    ex = O.synth_example(batch, O.ARCHS[arch]["inplanes"], dims, seed=1234, one_hm=heads["hm"] == 1)
+    t0 = time.perf_counter()
+    steps = 0
+    while True:
+        for p in sd.values():
+            p.grad = None
+        O.radar_pose_net(sd, ex, fuse, weight, cw)["loss"][0].backward()
+        opt.step(1e-4, 0.95)
+        steps += 1
+        el = time.perf_counter() - t0
+        if el > seconds_budget * 0.5 or steps >= 3:
+            break
+    return dict(value=round(batch * steps / el, 4), unit="frames/s", cores=cores, kind="port",
+                sample="%d train step(s) of batch %d at [B,%d,16,64,160], fp32, oracle/hrradarpose_ref.py, %d threads"
+                       % (steps, batch, O.ARCHS[arch]["inplanes"], cores))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--model", default="hr3d")
+    ap.add_argument("--batch", type=int, default=8, help="frames per GPU")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+        torch.cuda.set_device(0)
+    dev = "cuda:%d" % local
+
+    from rt_pose_amd import _lib, configs, synth
+    from rt_pose_amd.trainer import DataParallelTrainer
+
+    spec = configs.spec(args.model)
+    tr = DataParallelTrainer(args.model, args.batch, configs.NATIVE_DIMS, total_steps=max(100, args.steps + args.warmup),
+                             device=dev, rank=rank, world_size=world, use_graph=not args.no_graph)
+    ex = synth.make_batch(args.batch, spec["cin"], configs.NATIVE_DIMS, seed=1234, one_hm=spec["heads"]["hm"] == 1, rank=rank)
+    tr.load(ex)  # inputs resident in HBM before the timed region
+    torch.cuda.synchronize()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        tr.step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        tr.step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+    loss = float(tr.losses()["loss"])
+    frames = world * args.batch * args.steps
+    g = tr.engine.graph
+    train_flops_per_frame = (g.flops["conv_fwd"] + g.flops["conv_dgrad"] + g.flops["wgrad"]) / args.batch
+
+    line = {
+        "metric": "radar frames/sec (train) HRRadarPose", "value": round(frames / elapsed, 3), "unit": "frames/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": "%s train step (fwd+loss+bwd+allreduce+clip+Adam), %d frames/GPU of [%d,16,64,160], "
+                               "random-init weights" % (args.model, args.batch, spec["cin"]),
+                   "global_batch": world * args.batch, "parallelism": "dp%d" % world, "hip_graph": not args.no_graph},
+        "final_loss": round(loss, 5),
+        "train_gflop_per_frame": round(train_flops_per_frame / 1e9, 2),
+        "mfma_frac_whole_step": round(frames / elapsed * train_flops_per_frame / (world * PEAK_BF16_TFLOPS * 1e12), 4),
+    }
+
+    if world == 1 and not args.no_roofline:
+        be = tr.be
+        fams = {"conv_igemm (fwd+dgrad)": (_lib.FAM_CONV, g.flops["conv_fwd"] + g.flops["conv_dgrad"]),
+                "wgrad": (_lib.FAM_WGRAD, g.flops["wgrad"])}
+        tr.use_graph = False
+        for fam, _ in fams.values():
+            be.prof_enable(fam, True)
+        ksteps = min(args.steps, 5)
+        for _ in range(ksteps):
+            tr.step()
+        torch.cuda.synchronize()
+        best = None
+        detail = {}
+        for kname, (fam, flops) in fams.items():
+            ms, cnt = be.prof_collect(fam)
+            be.prof_enable(fam, False)
+            if cnt == 0:
+                continue
+            tf = flops * ksteps / (ms * 1e-3) / 1e12
+            detail[kname] = {"launches_per_step": cnt // ksteps, "ms_per_step": round(ms / ksteps, 3),
+                             "avg_us_per_launch": round(1e3 * ms / cnt, 2), "tflops": round(tf, 2)}
+            if best is None or ms > best[1]:
+                best = (kname, ms, tf)
+        line["roofline"] = {"bound": "mfma", "kernel": best[0], "achieved": round(best[2], 2), "peak": PEAK_BF16_TFLOPS,
+                            "unit": "TFLOP/s", "frac": round(best[2] / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                            "families": detail}
+    if world == 1 and rank == 0 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(args.model)
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

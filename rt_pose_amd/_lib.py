@@ -81,6 +81,9 @@ def load():
     """Load the shared library (once).  Raises if it has not been built -- there is no fallback path."""
     global _lib
     if _lib is None:
+        # PyTorch-ROCm ships its own libamdhip64; it must be in the process before this library is dlopen'ed so
+        # both resolve to ONE HIP runtime (streams and device pointers are shared with torch).
+        import torch  # noqa: F401
         if not os.path.exists(LIB_PATH):
             raise RtpError("%s not found: run `python -m rt_pose_amd.build` (hipcc, gfx950). "
                            "rt_pose_amd has no CPU fallback." % LIB_PATH)

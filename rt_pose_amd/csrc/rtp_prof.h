@@ -23,6 +23,10 @@ struct RtpProfScope {
   hipStream_t s;
   bool on;
   RtpProfScope(int f, hipStream_t st) : fam(f), s(st), on(g_rtp_prof_on[f] != 0) {
+    // Every entry point constructs one of these right before its launches: clear any stale "last error" left by
+    // other HIP users in the process (PyTorch's event queries leave hipErrorNotReady behind) so that
+    // RTP_CHECK_LAUNCH reports only this call's launches.
+    (void)hipGetLastError();
     if (on) rtp_prof_begin(fam, s);
   }
   ~RtpProfScope() {

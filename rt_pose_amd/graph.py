@@ -100,6 +100,8 @@ class Graph:
         self.pgrad = {}            # name -> fp32 grad tensor written by the backward plan
         self.used_params = []      # creation order
         self.bytes = 0
+        # algorithmic FLOPs (2*MACs of real channels) per kernel family, per replay of the lists
+        self.flops = {"conv_fwd": 0, "conv_dgrad": 0, "wgrad": 0}
 
     # ------------------------------------------------------------------ helpers
     def act(self, *a, **k):
@@ -251,6 +253,8 @@ class ConvOp:
                                  ge, self.ci_real, self.co_real, self.wf, self.btab, self.mr))
         g.fwd.append(be.conv(self.x, self.wf, nw > 1, self.btab, self.residual, self.y, ge, self.relu, False,
                              self.out_fp32))
+        self.alg_flops = 2 * g.n * ge.do * ge.ho * ge.wo * self.co_real * self.ci_real * ntap
+        g.flops["conv_fwd"] += self.alg_flops
 
     def emit_backward(self, gy: View):
         g, be, ge, x = self.g, self.g.be, self.geom, self.x
@@ -266,6 +270,7 @@ class ConvOp:
             dxh_buf = be.alloc((g.n, x.d, x.h, x.w, ge.ci), "bf16")
             dxh = View(dxh_buf, g.n, x.d, x.h, x.w, ge.ci, 0, ge.ci)
             g.bwd.append(be.conv(gy, wd, False, None, None, dxh, ge, False, True, False))
+            g.flops["conv_dgrad"] += self.alg_flops
             if self.gn:
                 S = x.stats_split
                 pq = be.alloc((g.n, S, ge.ci, 2), "f32")
@@ -283,6 +288,7 @@ class ConvOp:
         assert gy.c == co32, (self.name, gy.c, co32)
         gp = be.alloc((g.n, S, ge.ks ** 3, co32, ge.ci), "f32")
         g.bwd.append(be.wgrad(gy, x, ge, S, gp))
+        g.flops["wgrad"] += self.alg_flops
         csum, cs_split = None, 0
         if self.gn or self.bname:
             cs_split = stats_split(gy.vox)
