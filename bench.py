@@ -32,7 +32,11 @@ def cpu_baseline(name, seconds_budget=30.0):
     arch, fin, fout, fuse, heads, weight, cw = O.MODEL_CONFIGS[name]
     shapes = O.param_shapes(arch, fin, fout, fout, heads)
     sd = {k: v.requires_grad_(True) for k, v in O.seeded_state_dict(shapes, seed=1).items()}
-    cores = os.cpu_count() or 1
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, 32))  # PyTorch CPU conv stops scaling (and oversubscribes) far below a 256-thread host
     torch.set_num_threads(cores)
     opt = O.AdamTrueWD(list(sd.values()))
     batch, dims = 1, (16, 64, 160)
@@ -127,7 +131,8 @@ def main():
 
     if world == 1 and not args.no_roofline:
         be = tr.be
-        fams = {"conv_igemm (fwd+dgrad)": (_lib.FAM_CONV, g.flops["conv_fwd"] + g.flops["conv_dgrad"]),
+        fams = {"conv_tiled (fwd+dgrad, 32ch full-res)": (_lib.FAM_CONV_TILED, g.flops["conv_tiled"]),
+                "conv_igemm generic (fwd+dgrad)": (_lib.FAM_CONV, g.flops["conv_generic"]),
                 "wgrad": (_lib.FAM_WGRAD, g.flops["wgrad"])}
         tr.use_graph = False
         for fam, _ in fams.values():

@@ -88,18 +88,20 @@ int rtp_conv_igemm(const RtpAct* x, const void* wf, int w_per_sample, const floa
  * nn.Conv3d backward-weight. */
 int rtp_wgrad(const RtpAct* gy, const RtpAct* x, const RtpConvGeom* g, int nsplit, float* gp, void* stream);
 
-/* Per boundary-class channel sums of an output-side gradient: out fp32 [n][nsplit][64][c]. */
-int rtp_class_sums(const RtpAct* gy, int n, int d, int h, int w, int nsplit, float* out, void* stream);
+/* Per boundary-class channel sums of an output-side gradient: out fp32 [n][64][c];
+ * scratch fp32 [n][nsplit][64][c] (row-split partials, reduced in fixed order). */
+int rtp_class_sums(const RtpAct* gy, int n, int d, int h, int w, int nsplit, float* scratch, float* out, void* stream);
 
 /* Finish the weight gradient: reduce slabs, undo the GroupNorm fold, write reference-layout fp32 grads.
- *   dw[co][ci][tap] (+)= sum_n scale[n][ci] * sum_s gp + shift[n][ci] * sum_{classes where tap in-bounds} csum
+ *   dw[co][ci][tap] (+)= sum_n scale[n][ci] * sum_s gp + shift[n][ci] * sum_{classes where tap in-bounds} csum[n][cls][co]
  *   dbias[co] (+)= sum of csum over all classes (if dbias != NULL) */
-int rtp_wgrad_fold(const float* gp, int nsplit, const float* csum, int csplit, const float* mr, const float* gamma,
+int rtp_wgrad_fold(const float* gp, int nsplit, const float* csum, const float* mr, const float* gamma,
                    const float* beta, int groups, const RtpConvGeom* g, int ci_real, int co_real, float* dw,
                    float* dbias, int accumulate, void* stream);
 
 /* GroupNorm backward coefficients from pq = rtp_chan_stats(dxhat, x):
- *   coeff[n][c] = (A, B, C) with  dx = A*dxhat + B*x + C ;  dgamma/dbeta (+)= per-channel param grads. */
+ *   coeff[n][c] = (A, B, C) with  dx = A*dxhat + B*x + C ;  dgamma/dbeta (+)= per-channel param grads.
+ *   The coeff buffer must hold n*c*5 floats (n*c*3 coefficients followed by n*c*2 of scratch). */
 int rtp_gn_bwd_coeffs(const float* pq, int nsplit, const float* mr, const float* gamma, int n, int c, int groups,
                       long vox, float* coeff, float* dgamma, float* dbeta, int accumulate, void* stream);
 

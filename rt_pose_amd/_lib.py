@@ -49,8 +49,8 @@ PROTOTYPES = {
     "rtp_pack_dgrad_w": [_P, _G, _I, _I, _P, _P],
     "rtp_conv_igemm": [_A, _P, _I, _P, _A, _A, _G, _I, _I, _I, _P],
     "rtp_wgrad": [_A, _A, _G, _I, _P, _P],
-    "rtp_class_sums": [_A, _I, _I, _I, _I, _I, _P, _P],
-    "rtp_wgrad_fold": [_P, _I, _P, _I, _P, _P, _P, _I, _G, _I, _I, _P, _P, _I, _P],
+    "rtp_class_sums": [_A, _I, _I, _I, _I, _I, _P, _P, _P],
+    "rtp_wgrad_fold": [_P, _I, _P, _P, _P, _P, _I, _G, _I, _I, _P, _P, _I, _P],
     "rtp_gn_bwd_coeffs": [_P, _I, _P, _P, _I, _I, _I, _L, _P, _P, _P, _I, _P],
     "rtp_grad_combine": [_T, _I, _A, _A, _A, _I, _L, _P],
     "rtp_fuse_sum": [_T, _I, _P, _A, _I, _I, _I, _I, _I, _P],

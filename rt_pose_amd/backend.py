@@ -85,15 +85,15 @@ class HipBackend:
         keep = (gy, x, gp)
         return lambda s: check(fn(*args, s), "rtp_wgrad") or keep and None
 
-    def class_sums(self, gy, nsplit, out):
+    def class_sums(self, gy, nsplit, scratch, out):
         fn = self.lib.rtp_class_sums
-        args = (_act(gy), gy.n, gy.d, gy.h, gy.w, nsplit, _ptr(out))
-        keep = (gy, out)
+        args = (_act(gy), gy.n, gy.d, gy.h, gy.w, nsplit, _ptr(scratch), _ptr(out))
+        keep = (gy, scratch, out)
         return lambda s: check(fn(*args, s), "rtp_class_sums") or keep and None
 
-    def wgrad_fold(self, gp, nsplit, csum, csplit, mr, gamma, beta, groups, geom, ci_real, co_real, dw, dbias, acc):
+    def wgrad_fold(self, gp, nsplit, csum, mr, gamma, beta, groups, geom, ci_real, co_real, dw, dbias, acc):
         fn, g = self.lib.rtp_wgrad_fold, _geom(geom)
-        args = (_ptr(gp), nsplit, _ptr(csum), csplit, _ptr(mr), _ptr(gamma), _ptr(beta), groups, g, ci_real, co_real,
+        args = (_ptr(gp), nsplit, _ptr(csum), _ptr(mr), _ptr(gamma), _ptr(beta), groups, g, ci_real, co_real,
                 _ptr(dw), _ptr(dbias), int(acc))
         keep = (gp, csum, mr, gamma, beta, dw, dbias)
         return lambda s: check(fn(*args, s), "rtp_wgrad_fold") or keep and None

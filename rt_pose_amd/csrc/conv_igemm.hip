@@ -137,12 +137,21 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
   }
 }
 
+int rtp_conv_tiled_try(const RtpAct* x, const void* wf, int w_per_sample, const float* btab, const RtpAct* res,
+                       const RtpAct* y, const RtpConvGeom* g, int relu, int transposed, int y_fp32, hipStream_t s);
+
 extern "C" int rtp_conv_igemm(const RtpAct* x, const void* wf, int w_per_sample, const float* btab, const RtpAct* res,
                               const RtpAct* y, const RtpConvGeom* g, int relu, int transposed, int y_fp32,
                               void* stream) {
   if (!x || !y || !wf || !g) return RTP_ERR_SHAPE;
   if (g->ks != 1 && g->ks != 3) return RTP_ERR_UNSUPPORTED;
   if (g->stride != 1 && g->stride != 2) return RTP_ERR_UNSUPPORTED;
+  if ((x->co % 8) || (x->cs % 8) || (y->co % 4) || (y->cs % 4)) return RTP_ERR_ALIGN;
+  if (res && ((res->co % 4) || (res->cs % 4))) return RTP_ERR_ALIGN;
+  {
+    const int rc = rtp_conv_tiled_try(x, wf, w_per_sample, btab, res, y, g, relu, transposed, y_fp32, (hipStream_t)stream);
+    if (rc <= 0) return rc;  // handled (or failed) by the LDS-tiled kernel
+  }
   ConvParams p;
   p.x = (const bf16_t*)x->ptr;
   p.w = (const bf16_t*)wf;

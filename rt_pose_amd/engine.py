@@ -206,7 +206,8 @@ class FlatAdam:
         self.be, self.flat = backend, flat
         self.wd, self.beta2, self.eps, self.max_norm = wd, beta2, eps, max_norm
         self.hyper = backend.alloc((10,), "f32")
-        self.hyper_host = torch.zeros(10, dtype=torch.float32)
+        # ring of pinned host slots: the async upload of step k must not see step k+1's values when the host runs ahead
+        self.hyper_host = torch.zeros(256, 10, dtype=torch.float32)
         if self.hyper.is_cuda:
             self.hyper_host = self.hyper_host.pin_memory()
         self.partial = backend.alloc((max(256, backend.sqnorm_blocks()),), "f32")
@@ -222,7 +223,7 @@ class FlatAdam:
     def set_hyper(self, lr, beta1, grad_scale=1.0):
         """Host-side scalars for the NEXT step (uploaded asynchronously; graph-capture safe)."""
         self.t += 1
-        h = self.hyper_host
+        h = self.hyper_host[self.t % 256]
         h[0], h[1], h[2], h[3], h[4], h[5] = lr, beta1, self.beta2, self.eps, self.wd, self.max_norm
         h[6], h[7], h[8] = 1.0 - beta1 ** self.t, 1.0 - self.beta2 ** self.t, grad_scale
         self.hyper.copy_(h, non_blocking=True)

@@ -101,7 +101,7 @@ class Graph:
         self.used_params = []      # creation order
         self.bytes = 0
         # algorithmic FLOPs (2*MACs of real channels) per kernel family, per replay of the lists
-        self.flops = {"conv_fwd": 0, "conv_dgrad": 0, "wgrad": 0}
+        self.flops = {"conv_fwd": 0, "conv_dgrad": 0, "wgrad": 0, "conv_tiled": 0, "conv_generic": 0}
 
     # ------------------------------------------------------------------ helpers
     def act(self, *a, **k):
@@ -255,6 +255,11 @@ class ConvOp:
                              self.out_fp32))
         self.alg_flops = 2 * g.n * ge.do * ge.ho * ge.wo * self.co_real * self.ci_real * ntap
         g.flops["conv_fwd"] += self.alg_flops
+        # mirrors the dispatch predicate of rtp_conv_tiled_try (csrc/conv_tiled.hip)
+        brick = ge.ks == 3 and ge.stride == 1 and ge.di % 2 == 0 and ge.hi % 8 == 0 and ge.wi % 32 == 0
+        self.tiled_fwd = brick and ge.ci == 32 and ge.co in (16, 32) and self.x.cs == 32
+        self.tiled_bwd = brick and ge.ci == 32 and pad_to(ge.co, 32) == 32
+        g.flops["conv_tiled" if self.tiled_fwd else "conv_generic"] += self.alg_flops
 
     def emit_backward(self, gy: View):
         g, be, ge, x = self.g, self.g.be, self.geom, self.x
@@ -271,11 +276,12 @@ class ConvOp:
             dxh = View(dxh_buf, g.n, x.d, x.h, x.w, ge.ci, 0, ge.ci)
             g.bwd.append(be.conv(gy, wd, False, None, None, dxh, ge, False, True, False))
             g.flops["conv_dgrad"] += self.alg_flops
+            g.flops["conv_tiled" if self.tiled_bwd else "conv_generic"] += self.alg_flops
             if self.gn:
                 S = x.stats_split
                 pq = be.alloc((g.n, S, ge.ci, 2), "f32")
                 g.bwd.append(be.chan_stats(dxh, x, S, pq))
-                coeff = be.alloc((g.n, ge.ci, 3), "f32")
+                coeff = be.alloc((g.n * ge.ci * 5,), "f32")  # [n][c][3] coefficients + [n][c][2] scratch
                 g.bwd.append(be.gn_bwd_coeffs(pq, S, self.mr, g.params[self.gn[0]], g.n, self.ci_real, self.groups,
                                               x.vox, coeff, g.pgrad[self.gn[0]], g.pgrad[self.gn[1]], 0))
                 if x.needs_grad:
@@ -289,12 +295,13 @@ class ConvOp:
         gp = be.alloc((g.n, S, ge.ks ** 3, co32, ge.ci), "f32")
         g.bwd.append(be.wgrad(gy, x, ge, S, gp))
         g.flops["wgrad"] += self.alg_flops
-        csum, cs_split = None, 0
+        csum = None
         if self.gn or self.bname:
-            cs_split = stats_split(gy.vox)
-            csum = be.alloc((g.n, cs_split, 64, gy.c), "f32")
-            g.bwd.append(be.class_sums(gy, cs_split, csum))
-        g.bwd.append(be.wgrad_fold(gp, S, csum, cs_split, self.mr, g.params[self.gn[0]] if self.gn else None,
+            cs_split = max(1, min(64, (gy.d * gy.h + 3) // 4))
+            csum = be.alloc((g.n, 64, gy.c), "f32")
+            cs_scratch = be.alloc((g.n, cs_split, 64, gy.c), "f32")
+            g.bwd.append(be.class_sums(gy, cs_split, cs_scratch, csum))
+        g.bwd.append(be.wgrad_fold(gp, S, csum, self.mr, g.params[self.gn[0]] if self.gn else None,
                                    g.params[self.gn[1]] if self.gn else None, self.groups, ge, self.ci_real,
                                    self.co_real, g.pgrad[self.wname],
                                    g.pgrad[self.bname] if self.bname else None, 0))

@@ -68,26 +68,30 @@ class DataParallelTrainer:
         self.pg = process_group
         self.use_graph = use_graph and self.be.name == "hip"
         self._graph = None
+        # All work of a step goes to ONE explicit (non-default) HIP stream: a graph launched on the legacy NULL stream
+        # was observed NOT to be ordered against the optimiser kernels queued behind it on ROCm 7.x.
+        self.stream = torch.cuda.Stream(self.be.device) if self.be.name == "hip" else None
 
     # ------------------------------------------------------------------ one step
+    def _on_stream(self):
+        import contextlib
+        return torch.cuda.stream(self.stream) if self.stream is not None else contextlib.nullcontext()
+
     def load(self, example):
-        self.engine.load_input(example["rdr"]["rdr_tensor"])
-        self.engine.load_targets(example["rdr"])
+        with self._on_stream():
+            self.engine.load_input(example["rdr"]["rdr_tensor"])
+            self.engine.load_targets(example["rdr"])
 
     def _fwd_bwd(self):
         self.engine.run_forward()
         self.engine.run_loss_backward()
 
     def _capture(self):
-        # warm the lazily-initialised pieces outside capture, then record the fwd+loss+bwd lists once
-        side = torch.cuda.Stream(self.be.device)
-        side.wait_stream(torch.cuda.current_stream(self.be.device))
-        with torch.cuda.stream(side):
-            self._fwd_bwd()
-        torch.cuda.current_stream(self.be.device).wait_stream(side)
+        # run once eagerly (lazy initialisation happens outside capture), then record the fwd+loss+bwd lists
+        self._fwd_bwd()
         torch.cuda.synchronize(self.be.device)
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        with torch.cuda.graph(g, stream=self.stream):
             self._fwd_bwd()
         self._graph = g
 
@@ -95,6 +99,10 @@ class DataParallelTrainer:
         """forward + loss + backward + gradient all-reduce + optimiser step on the currently loaded batch."""
         if example is not None:
             self.load(example)
+        with self._on_stream():
+            self._step()
+
+    def _step(self):
         if self.use_graph:
             if self._graph is None:
                 self._capture()
@@ -115,4 +123,5 @@ class DataParallelTrainer:
         return self.engine.losses()
 
     def forward_only(self):
-        self.engine.run_forward()
+        with self._on_stream():
+            self.engine.run_forward()

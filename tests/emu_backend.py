@@ -189,17 +189,15 @@ class EmuBackend:
                     gp[n, i] = dw.reshape(co32, g.ci, k ** 3).permute(2, 0, 1)
         return run
 
-    def class_sums(self, gy, nsplit, out):
+    def class_sums(self, gy, nsplit, scratch, out):
         def run(s):
             cls = _classes(gy.d, gy.h, gy.w).reshape(-1)
             gf = _sl(gy).reshape(gy.n, gy.vox, gy.c)
             out.zero_()
-            for i, (v0, v1) in enumerate(_split_ranges(gy.vox, nsplit)):
-                if v1 > v0:
-                    out[:, i].index_add_(1, cls[v0:v1], gf[:, v0:v1])
+            out.index_add_(1, cls, gf)
         return run
 
-    def wgrad_fold(self, gp, nsplit, csum, csplit, mr, gamma, beta, groups, geom, ci_real, co_real, dw, dbias, acc):
+    def wgrad_fold(self, gp, nsplit, csum, mr, gamma, beta, groups, geom, ci_real, co_real, dw, dbias, acc):
         def run(s):
             g = geom
             ntap = g.ks ** 3
@@ -208,7 +206,7 @@ class EmuBackend:
                 cg = ci_real // groups
                 scale = mr[:, :, 1].repeat_interleave(cg, 1) * gamma.detach().float()  # [n,ci]
                 shift = beta.detach().float() - mr[:, :, 0].repeat_interleave(cg, 1) * scale
-                cs = csum.sum(1)[:, :, :co_real]  # [n,64,co]
+                cs = csum[:, :, :co_real]  # [n,64,co]
                 sdy = torch.zeros(g.n, co_real, ntap)
                 for t in range(ntap):
                     inb = torch.tensor([_tap_inb(t, c, g) for c in range(64)])
@@ -223,7 +221,7 @@ class EmuBackend:
             else:
                 dwv.copy_(val)
             if dbias is not None:
-                b = csum.sum((0, 1, 2))[:co_real]
+                b = csum.sum((0, 1))[:co_real]
                 if acc:
                     dbias.add_(b)
                 else:
@@ -241,9 +239,10 @@ class EmuBackend:
             m = float(cg * vox)
             s1 = (gam * P).reshape(n, groups, cg).sum(2).repeat_interleave(cg, 1)
             s2 = (gam * r * (Q - mu * P)).reshape(n, groups, cg).sum(2).repeat_interleave(cg, 1)
-            coeff[:, :c, 0] = r * gam
-            coeff[:, :c, 1] = -r * r * s2 / m
-            coeff[:, :c, 2] = -r * s1 / m + r * r * mu * s2 / m
+            cf = coeff[:n * c * 3].view(n, c, 3)
+            cf[:, :, 0] = r * gam
+            cf[:, :, 1] = -r * r * s2 / m
+            cf[:, :, 2] = -r * s1 / m + r * r * mu * s2 / m
             dg = (r * (Q - mu * P)).sum(0)
             db = P.sum(0)
             if acc:
@@ -262,7 +261,7 @@ class EmuBackend:
                 if cf is None:
                     acc += _sl(v)
                 else:
-                    c = cf.view(out.n, 1, 1, 1, -1, 3)[..., :out.c, :]
+                    c = cf[:out.n * out.c * 3].view(out.n, 1, 1, 1, out.c, 3)
                     acc += c[..., 0] * _sl(v) + c[..., 1] * _sl(x)[..., :out.c] + c[..., 2]
             if relu_src is not None:
                 acc = torch.where(_sl(relu_src)[..., :out.c] > 0, acc, torch.zeros(()))
