@@ -133,7 +133,8 @@ def main():
         be = tr.be
         fams = {"conv_tiled (fwd+dgrad, 32ch full-res)": (_lib.FAM_CONV_TILED, g.flops["conv_tiled"]),
                 "conv_igemm generic (fwd+dgrad)": (_lib.FAM_CONV, g.flops["conv_generic"]),
-                "wgrad": (_lib.FAM_WGRAD, g.flops["wgrad"])}
+                "wgrad_tiled (32ch full-res)": (_lib.FAM_WGRAD_TILED, g.flops["wgrad_tiled"]),
+                "wgrad generic": (_lib.FAM_WGRAD, g.flops["wgrad_generic"])}
         tr.use_graph = False
         for fam, _ in fams.values():
             be.prof_enable(fam, True)

@@ -87,6 +87,9 @@ int rtp_conv_igemm(const RtpAct* x, const void* wf, int w_per_sample, const floa
  * sum over the split's output voxels of gy[v][co] * x[v*stride + tap - pad][ci].  Replaces
  * nn.Conv3d backward-weight. */
 int rtp_wgrad(const RtpAct* gy, const RtpAct* x, const RtpConvGeom* g, int nsplit, float* gp, void* stream);
+/* Slab count the LDS-tiled weight-gradient kernel wants for this geometry (one slab per workgroup); 0 = the generic
+ * kernel will run and any nsplit >= 1 is accepted. */
+int rtp_wgrad_nsplit(const RtpConvGeom* g);
 
 /* Per boundary-class channel sums of an output-side gradient: out fp32 [n][64][c];
  * scratch fp32 [n][nsplit][64][c] (row-split partials, reduced in fixed order). */

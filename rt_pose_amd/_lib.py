@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(HERE, "lib", "librtp_hip.so")
 RTP_MAX_TERMS = 6
 
 # kernel families for rtp_prof_* (csrc/rtp_prof.h)
-FAM_CONV, FAM_CONV_TILED, FAM_WGRAD, FAM_POINTWISE, FAM_NORM, FAM_LOSS, FAM_OPTIM, FAM_DCN = range(8)
+FAM_CONV, FAM_CONV_TILED, FAM_WGRAD, FAM_POINTWISE, FAM_NORM, FAM_LOSS, FAM_OPTIM, FAM_DCN, FAM_WGRAD_TILED = range(9)
 
 _ERR = {-1: "RTP_ERR_SHAPE", -2: "RTP_ERR_UNSUPPORTED", -3: "RTP_ERR_LAUNCH", -4: "RTP_ERR_ALIGN"}
 
@@ -49,6 +49,7 @@ PROTOTYPES = {
     "rtp_pack_dgrad_w": [_P, _G, _I, _I, _P, _P],
     "rtp_conv_igemm": [_A, _P, _I, _P, _A, _A, _G, _I, _I, _I, _P],
     "rtp_wgrad": [_A, _A, _G, _I, _P, _P],
+    "rtp_wgrad_nsplit": [_G],
     "rtp_class_sums": [_A, _I, _I, _I, _I, _I, _P, _P, _P],
     "rtp_wgrad_fold": [_P, _I, _P, _P, _P, _P, _I, _G, _I, _I, _P, _P, _I, _P],
     "rtp_gn_bwd_coeffs": [_P, _I, _P, _P, _I, _I, _I, _L, _P, _P, _P, _I, _P],

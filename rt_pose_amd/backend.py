@@ -85,6 +85,9 @@ class HipBackend:
         keep = (gy, x, gp)
         return lambda s: check(fn(*args, s), "rtp_wgrad") or keep and None
 
+    def wgrad_nsplit(self, geom):
+        return self.lib.rtp_wgrad_nsplit(_geom(geom))
+
     def class_sums(self, gy, nsplit, scratch, out):
         fn = self.lib.rtp_class_sums
         args = (_act(gy), gy.n, gy.d, gy.h, gy.w, nsplit, _ptr(scratch), _ptr(out))

@@ -11,7 +11,8 @@ enum RtpFamily {
   RTP_FAM_LOSS = 5,
   RTP_FAM_OPTIM = 6,
   RTP_FAM_DCN = 7,
-  RTP_FAM_COUNT = 8
+  RTP_FAM_WGRAD_TILED = 8,
+  RTP_FAM_COUNT = 9
 };
 
 void rtp_prof_begin(int fam, hipStream_t s);

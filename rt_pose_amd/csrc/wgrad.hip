@@ -122,10 +122,18 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
   }
 }
 
+int rtp_wgrad_tiled_try(const RtpAct* gy, const RtpAct* x, const RtpConvGeom* g, int nsplit, float* gp, hipStream_t s);
+
 extern "C" int rtp_wgrad(const RtpAct* gy, const RtpAct* x, const RtpConvGeom* g, int nsplit, float* gp,
                          void* stream) {
   if (!gy || !x || !g || !gp || nsplit < 1) return RTP_ERR_SHAPE;
   if (g->ks != 1 && g->ks != 3) return RTP_ERR_UNSUPPORTED;
+  if ((gy->cs % 8) || (gy->co % 8) || (x->cs % 8) || (x->co % 8)) return RTP_ERR_ALIGN;
+  if (gy->c < (g->co + 31) / 32 * 32 || x->c < g->ci) return RTP_ERR_SHAPE;
+  {
+    const int rc = rtp_wgrad_tiled_try(gy, x, g, nsplit, gp, (hipStream_t)stream);
+    if (rc <= 0) return rc;
+  }
   WgradParams p;
   p.gy = (const bf16_t*)gy->ptr; p.x = (const bf16_t*)x->ptr; p.gp = gp;
   p.N = g->n; p.Di = g->di; p.Hi = g->hi; p.Wi = g->wi; p.Do = g->dov; p.Ho = g->ho; p.Wo = g->wo;

@@ -1,0 +1,258 @@
+// LDS-tiled weight-gradient correlation for the full-resolution 32-channel 3x3x3 stride-1 layers (the same layer set
+// as conv_tiled.hip):  G[tap][co][ci] = sum_v gy[v][co] * x[v + tap - 1][ci].
+//
+// Same workgroup shape as the forward kernel: 8 waves = two teams of 4 that ping-pong between staging a brick
+// (2z x 4y x 32x output voxels: gy brick 16 KB + haloed x brick 52 KB per team) and running MFMAs on it.
+// The contraction runs over voxels, so both operands are read TRANSPOSED from the voxel-major LDS images with
+// ds_read_b64_tr_b16; one k-step = one 32-voxel x-row of the brick, and a tap shift is just a different halo address.
+// The 27 taps are dealt round-robin to the team's 4 waves (<= 7 taps x 4 accumulator tiles each); every wave keeps its
+// accumulators in registers across ALL bricks of the team, so a workgroup emits ONE fp32 slab [27][32][32]
+// (team 1's accumulators are folded into team 0's through LDS at the end).
+// LDS images rotate the 16-B chunk index by (x>>2) -- conflict-free for the tr-read lane groups (voxels v and v+8).
+#include "rtp_common.h"
+#include "rtp_prof.h"
+
+#define TZ 2
+#define TY 4
+#define TX 32
+#define HZ (TZ + 2)
+#define HY (TY + 2)
+#define HX (TX + 2)
+#define HALO_VOX (HZ * HY * HX)   // 816
+#define BRICK_VOX (TZ * TY * TX)  // 256
+#define X_ITEMS (HALO_VOX * 4)
+#define G_ITEMS (BRICK_VOX * 4)
+#define STAGE_ITERS 17            // 17 * 256 = 4352 >= 3264 + 1024 sixteen-byte items per team brick
+
+struct WgTiledParams {
+  const bf16_t* gy; const bf16_t* x; float* gp;
+  int N, D, H, W, g_cs, g_co;
+  int tiles_y, tiles_x, tiles_per_sample, wgs_per_sample;
+};
+
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+__device__ __attribute__((aligned(16))) bf16_t g_zero_line[8];  // zero-initialised: source of padding voxels
+
+__device__ __forceinline__ int rot(int chunk, int xi) { return ((chunk + (xi >> 2)) & 3) << 3; }  // bf16 elements
+
+// Transposed fragment = two ds_read_b64_tr_b16 (voxels xq..xq+3 and xq+4..xq+7 of one x-row, 16 channels): lane gets
+// channel (sub*16 + lane&15).  `lo`/`hi` are per-lane byte addresses that already contain the lane's voxel, chunk
+// rotation and tap x-shift; OFF is a compile-time row offset, so it folds into the instruction's immediate field and
+// ALL rows/taps share 12 (+4) address registers.
+template <int OFF>
+__device__ __forceinline__ bf16x8 tr_pair(unsigned lo, unsigned hi) {
+  s16x4 l = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lo + OFF));
+  s16x4 h = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(hi + OFF));
+  s16x8 r = {l[0], l[1], l[2], l[3], h[0], h[1], h[2], h[3]};
+  return __builtin_bit_cast(bf16x8, r);
+}
+
+struct LaneAddr {          // 32-bit LDS byte addresses
+  unsigned x[3][2][2];     // [dx][ci sub-tile][lo/hi]  into the haloed x brick
+  unsigned g[2][2];        // [co sub-tile][lo/hi]      into the gy brick
+};
+
+template <int TW, int R, int T>
+__device__ __forceinline__ void wg_tap(const LaneAddr& la, const bf16x8& a0, const bf16x8& a1, f32x4 (&acc)[7][2][2]) {
+  constexpr int tap = TW + 4 * T;
+  if constexpr (tap < 27) {
+    constexpr int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
+    constexpr int rz = R / TY, ry = R % TY;
+    constexpr int off = ((rz + dz) * HY + (ry + dy)) * HX * 64;  // bytes (< 64 KB): folds into the ds_read immediate
+    const bf16x8 b0 = tr_pair<off>(la.x[dx][0][0], la.x[dx][0][1]);
+    const bf16x8 b1 = tr_pair<off>(la.x[dx][1][0], la.x[dx][1][1]);
+    acc[T][0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b0, acc[T][0][0], 0, 0, 0);
+    acc[T][0][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b1, acc[T][0][1], 0, 0, 0);
+    acc[T][1][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b0, acc[T][1][0], 0, 0, 0);
+    acc[T][1][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1, acc[T][1][1], 0, 0, 0);
+  }
+}
+
+template <int TW, int R>
+__device__ __forceinline__ void wg_row(const LaneAddr& la, f32x4 (&acc)[7][2][2]) {
+  constexpr int goff = R * TX * 64;
+  const bf16x8 a0 = tr_pair<goff>(la.g[0][0], la.g[0][1]);
+  const bf16x8 a1 = tr_pair<goff>(la.g[1][0], la.g[1][1]);
+  wg_tap<TW, R, 0>(la, a0, a1, acc); wg_tap<TW, R, 1>(la, a0, a1, acc); wg_tap<TW, R, 2>(la, a0, a1, acc);
+  wg_tap<TW, R, 3>(la, a0, a1, acc); wg_tap<TW, R, 4>(la, a0, a1, acc); wg_tap<TW, R, 5>(la, a0, a1, acc);
+  wg_tap<TW, R, 6>(la, a0, a1, acc);
+}
+
+// Issue-order plan for the whole (fully unrolled, branch-free) brick: a software pipeline with the LDS reads of
+// stage s+2 issued before the MFMAs of stage s (stage = one tap of one x-row: 4 transposing reads [+4 for the row's
+// gy fragments] then 4 MFMAs).  Without it the scheduler front-loads hundreds of reads and spills.
+template <int S, int K, int TOTAL>
+__device__ __forceinline__ void wg_sched() {
+  if constexpr (S < TOTAL) {
+    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                    // MFMA x4  (stage S)
+    if constexpr (S + 2 < TOTAL)
+      __builtin_amdgcn_sched_group_barrier(0x100, ((S + 2) % K == 0) ? 8 : 4, 0);         // DS_READ  (stage S+2)
+    wg_sched<S + 1, K, TOTAL>();
+  }
+}
+
+template <int TW>
+__device__ __forceinline__ void wg_brick(const LaneAddr& la0, unsigned boff, f32x4 (&acc)[7][2][2]) {
+  LaneAddr la;  // this brick's buffer: 16 adds per brick buy immediate offsets for every read below
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      la.g[a][b] = la0.g[a][b] + boff;
+#pragma unroll
+      for (int d = 0; d < 3; ++d) la.x[d][a][b] = la0.x[d][a][b] + boff;
+    }
+  wg_row<TW, 0>(la, acc); wg_row<TW, 1>(la, acc); wg_row<TW, 2>(la, acc); wg_row<TW, 3>(la, acc);
+  wg_row<TW, 4>(la, acc); wg_row<TW, 5>(la, acc); wg_row<TW, 6>(la, acc); wg_row<TW, 7>(la, acc);
+  constexpr int K = (TW == 3) ? 6 : 7;
+  __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+  __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+  wg_sched<0, K, 8 * K>();
+}
+
+__global__ __launch_bounds__(512, 2) void wgrad_tiled_kernel(WgTiledParams p) {
+  extern __shared__ __attribute__((aligned(16))) bf16_t lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool loader = __builtin_amdgcn_readfirstlane(wave >> 2) == 1;  // waves 4-7 stage, waves 0-3 run the MFMAs
+  const int tw = __builtin_amdgcn_readfirstlane(wave & 3);
+  const int ttid = tid & 255;
+  const int n = blockIdx.x / p.wgs_per_sample;
+  const int wg = blockIdx.x - n * p.wgs_per_sample;
+  const long vox_n = (long)n * p.D * p.H * p.W;
+  const int my_tiles = (p.tiles_per_sample - wg + p.wgs_per_sample - 1) / p.wgs_per_sample;
+  constexpr int BUF = (HALO_VOX + BRICK_VOX) * 32;  // elements per staged brick (x halo + gy)
+
+  if (loader) {
+    // ---- producer: brick k -> buffer k&1, one brick ahead of the consumers
+    for (int k = 0; k <= my_tiles; ++k) {
+      if (k < my_tiles) {
+        bf16_t* xL = lds + (k & 1) * BUF;
+        const int tile = wg + k * p.wgs_per_sample;
+        const int tx = tile % p.tiles_x, ty = (tile / p.tiles_x) % p.tiles_y, tz = tile / (p.tiles_x * p.tiles_y);
+        const int z0 = tz * TZ, y0 = ty * TY, x0 = tx * TX;
+        // LDS-DMA (global_load_lds, 16 B per lane): a wave-instruction's LDS destination is linear (wave base +
+        // lane*16), so the chunk rotation is applied on the SOURCE side -- the lane whose slot holds rotated chunk
+        // (i&3) fetches logical chunk (i&3) - (x>>2).  Out-of-volume halo voxels fetch a zero line.
+#pragma unroll
+        for (int it = 0; it < STAGE_ITERS; ++it) {
+          int i = ttid + it * 256;
+          asm volatile("" : "+v"(i));  // keep the per-item decode inside the brick loop (LICM would hoist and spill it)
+          if (it * 256 + (ttid & ~63) < X_ITEMS + G_ITEMS) {  // wave-uniform: region sizes are multiples of 64 items
+            const bf16_t* src = g_zero_line;
+            if (i < X_ITEMS) {
+              const int cp = i & 3, hv = i >> 2;
+              const int hx = hv % HX, hy = (hv / HX) % HY, hz = hv / (HX * HY);
+              const int gz = z0 + hz - 1, gy_ = y0 + hy - 1, gx = x0 + hx - 1;
+              const int ck = (cp - (hx >> 2)) & 3;
+              if ((unsigned)gz < (unsigned)p.D && (unsigned)gy_ < (unsigned)p.H && (unsigned)gx < (unsigned)p.W)
+                src = p.x + (vox_n + ((long)gz * p.H + gy_) * p.W + gx) * 32 + ck * 8;
+            } else {
+              const int j = i - X_ITEMS;
+              const int cp = j & 3, bv = j >> 2;
+              const int bx = bv % TX, by = (bv / TX) % TY, bz = bv / (TX * TY);
+              const int ck = (cp - (bx >> 2)) & 3;
+              src = p.gy + (vox_n + ((long)(z0 + bz) * p.H + (y0 + by)) * p.W + (x0 + bx)) * p.g_cs + p.g_co + ck * 8;
+            }
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(xL + (i - lane) * 8), 16, 0, 0);
+          }
+        }
+      }
+      __syncthreads();  // (drains the DMA: hipcc emits vmcnt(0) before the barrier)
+    }
+    return;
+  }
+
+  // ---- consumers: per-lane fragment addresses for both buffers, accumulators live for the whole kernel
+  f32x4 acc[7][2][2];
+#pragma unroll
+  for (int t = 0; t < 7; ++t)
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) acc[t][a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  LaneAddr la;
+  {
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) bf16_t*)lds;
+    const int q = lane >> 4, i = lane & 15, a = i >> 2, pp = i & 3;
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+      const int chunk = 2 * sub + (pp >> 1), within = (pp & 1) * 4;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int xg = 8 * q + a + 4 * h;
+        la.g[sub][h] = lds_base + 2u * (HALO_VOX * 32 + xg * 32 + rot(chunk, xg) + within);
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+          const int xa = xg + dx;
+          la.x[dx][sub][h] = lds_base + 2u * (xa * 32 + rot(chunk, xa) + within);
+        }
+      }
+    }
+  }
+  __syncthreads();  // brick 0 staged
+  for (int k = 0; k < my_tiles; ++k) {
+    const unsigned boff = (k & 1) ? 2u * BUF : 0u;
+    switch (tw) {  // scalar selector: uniform branch, EXEC stays all-ones for the transposing reads
+      case 0: wg_brick<0>(la, boff, acc); break;
+      case 1: wg_brick<1>(la, boff, acc); break;
+      case 2: wg_brick<2>(la, boff, acc); break;
+      default: wg_brick<3>(la, boff, acc); break;
+    }
+    __syncthreads();  // brick k consumed, brick k+1 staged
+  }
+
+  // ---- one fp32 slab [27][32][32] per workgroup; D[row = co][col = ci]: lane holds rows 4q..4q+3, column lane&15
+  const int q = lane >> 4, i = lane & 15;
+  float* out = p.gp + ((long)n * p.wgs_per_sample + wg) * 27 * 32 * 32;
+#pragma unroll
+  for (int t = 0; t < 7; ++t) {
+    const int tap = tw + 4 * t;
+    if (tap < 27)
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            out[(tap * 32 + a * 16 + q * 4 + r) * 32 + b * 16 + i] = acc[t][a][b][r];
+  }
+}
+
+static bool wg_tiled_applicable(const RtpConvGeom* g) {
+  static const bool disabled = getenv("RTP_DISABLE_TILED") != nullptr;
+  if (disabled) return false;
+  return g->ks == 3 && g->stride == 1 && g->pad == 1 && g->ci == 32 && (g->co + 31) / 32 * 32 == 32 &&
+         g->di % TZ == 0 && g->hi % TY == 0 && g->wi % TX == 0;
+}
+
+static int wg_tiled_wgs(const RtpConvGeom* g) {
+  const int tiles = (g->di / TZ) * (g->hi / TY) * (g->wi / TX);
+  int wgs = 256 / g->n;
+  if (wgs < 1) wgs = 1;
+  if (wgs > tiles) wgs = tiles;
+  return wgs;
+}
+
+// Number of slabs rtp_wgrad will write per sample for this geometry if the caller lets it choose (0 = generic kernel,
+// any nsplit accepted).
+extern "C" int rtp_wgrad_nsplit(const RtpConvGeom* g) { return (g && wg_tiled_applicable(g)) ? wg_tiled_wgs(g) : 0; }
+
+int rtp_wgrad_tiled_try(const RtpAct* gy, const RtpAct* x, const RtpConvGeom* g, int nsplit, float* gp, hipStream_t s) {
+  if (!wg_tiled_applicable(g)) return 1;
+  if (x->cs != 32 || x->co != 0 || nsplit != wg_tiled_wgs(g)) return 1;
+  WgTiledParams p;
+  p.gy = (const bf16_t*)gy->ptr; p.x = (const bf16_t*)x->ptr; p.gp = gp;
+  p.N = g->n; p.D = g->di; p.H = g->hi; p.W = g->wi; p.g_cs = gy->cs; p.g_co = gy->co;
+  p.tiles_y = p.H / TY; p.tiles_x = p.W / TX;
+  p.tiles_per_sample = (p.D / TZ) * p.tiles_y * p.tiles_x;
+  p.wgs_per_sample = nsplit;
+  const size_t shm = sizeof(bf16_t) * 2 * (size_t)(HALO_VOX + BRICK_VOX) * 32;
+  RtpProfScope prof(RTP_FAM_WGRAD_TILED, s);
+  static bool attr = false;
+  if (!attr) { (void)hipFuncSetAttribute((const void*)wgrad_tiled_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); attr = true; }
+  hipLaunchKernelGGL(wgrad_tiled_kernel, dim3(p.N * nsplit), dim3(512), shm, s, p);
+  RTP_CHECK_LAUNCH();
+  return RTP_OK;
+}

@@ -101,7 +101,8 @@ class Graph:
         self.used_params = []      # creation order
         self.bytes = 0
         # algorithmic FLOPs (2*MACs of real channels) per kernel family, per replay of the lists
-        self.flops = {"conv_fwd": 0, "conv_dgrad": 0, "wgrad": 0, "conv_tiled": 0, "conv_generic": 0}
+        self.flops = {"conv_fwd": 0, "conv_dgrad": 0, "wgrad": 0, "conv_tiled": 0, "conv_generic": 0,
+                      "wgrad_tiled": 0, "wgrad_generic": 0}
 
     # ------------------------------------------------------------------ helpers
     def act(self, *a, **k):
@@ -289,12 +290,15 @@ class ConvOp:
             elif x.needs_grad:
                 x.contribs.append((dxh, None))
         # ---- weight gradient
-        S = wgrad_split(gy.vox)
+        S = be.wgrad_nsplit(ge) if x.cs == 32 and x.co == 0 else 0
+        self.tiled_wgrad = S > 0
+        S = S or wgrad_split(gy.vox)
         co32 = pad_to(ge.co, 32)
         assert gy.c == co32, (self.name, gy.c, co32)
         gp = be.alloc((g.n, S, ge.ks ** 3, co32, ge.ci), "f32")
         g.bwd.append(be.wgrad(gy, x, ge, S, gp))
         g.flops["wgrad"] += self.alg_flops
+        g.flops["wgrad_tiled" if self.tiled_wgrad else "wgrad_generic"] += self.alg_flops
         csum = None
         if self.gn or self.bname:
             cs_split = max(1, min(64, (gy.d * gy.h + 3) // 4))

@@ -189,6 +189,9 @@ class EmuBackend:
                     gp[n, i] = dw.reshape(co32, g.ci, k ** 3).permute(2, 0, 1)
         return run
 
+    def wgrad_nsplit(self, geom):
+        return 0
+
     def class_sums(self, gy, nsplit, scratch, out):
         def run(s):
             cls = _classes(gy.d, gy.h, gy.w).reshape(-1)
