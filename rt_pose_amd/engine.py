@@ -149,6 +149,17 @@ class PoseEngine:
         for f in self.bwd:
             f(s)
 
+    def run_losses_only(self, stream=None):
+        """Loss values (and the loss kernels' logit gradients) without the backward sweep."""
+        s = stream if stream is not None else self.be.stream()
+        for f in self.loss_launches:
+            f(s)
+
+    def run_backward_only(self, stream=None):
+        s = stream if stream is not None else self.be.stream()
+        for f in self.bwd:
+            f(s)
+
     def losses(self):
         """The reference's loss dict (center_head.py:260): device scalars, no host sync here."""
         hm_loss = self.loss_hm[0]

@@ -1,0 +1,330 @@
+"""Host-side mirror of the reference's module interface, registered under the same registry names:
+
+    RadarFeatureNet   det3d/models/readers/radar_encoder.py:7-17
+    HRNet3D           det3d/models/backbones/hrnet3d.py:8-56           (backbone_cfg, final_conv_in/out, final_fuse, ds_factor)
+    CenterHead        det3d/models/pose_heads/center_head.py:166-360   (tasks, in_channels, share_conv_channel, weight, ...)
+    RadarPoseNet      det3d/models/detectors/radar_pose_net.py:9-46    (reader, backbone, neck, pose_head, ...)
+
+Each class is an nn.Module whose parameters carry the reference's state_dict names and shapes (so reference
+checkpoints load with load_state_dict), but whose arithmetic is the static HIP launch plan of rt_pose_amd.engine:
+RadarPoseNet.forward(example, return_loss=True) returns the reference's loss dict with `loss` attached to autograd
+(loss.backward() replays the backward launch list and fills p.grad), return_loss=False returns the reference's
+key-point list.  There is no eager-PyTorch or CPU path: without the built library / a GPU the first forward raises.
+"""
+from collections import OrderedDict, defaultdict
+
+import torch
+import torch.nn as nn
+
+from . import net
+from .engine import FlatParams, PoseEngine
+from .registry import BACKBONES, DETECTORS, HEADS, READERS, build_backbone, build_head, build_neck, build_reader
+
+
+def _default_backend(device):
+    from .backend import HipBackend
+    return HipBackend(device)
+
+
+_backend_factory = _default_backend
+
+
+def set_backend_factory(fn):
+    """Test hook: CPU tests inject the emulated kernels (tests/emu_backend.py) to check the module plumbing without a
+    GPU.  The product never calls this; the default factory is HipBackend, which raises without a GPU."""
+    global _backend_factory
+    _backend_factory = fn if fn is not None else _default_backend
+
+
+class ParamTree(nn.Module):
+    """Parameters addressed by dotted reference names ('stage2.0.branches.1.0.conv2.conv.weight')."""
+
+    def add(self, dotted, tensor):
+        parts = dotted.split(".")
+        mod = self
+        for p in parts[:-1]:
+            if p not in mod._modules:
+                mod.add_module(p, ParamTree())
+            mod = mod._modules[p]
+        mod.register_parameter(parts[-1], nn.Parameter(tensor))
+
+
+def _build_params(shapes, seed=0):
+    from .trainer import init_state_dict
+    return init_state_dict(shapes, seed)
+
+
+def _backbone_shapes(arch, final_in, final_out):
+    from . import configs
+    for k, v in configs._TABLE.items():
+        if v[0] == arch and v[2] == final_in and v[3] == final_out:
+            sd = configs.param_shapes(k)
+            return OrderedDict((n, s) for n, s in sd.items() if n.startswith("backbone."))
+    raise NotImplementedError("HRNet3D(%s, final_conv %d->%d) is not one of the shipped configurations" % (arch, final_in, final_out))
+
+
+@READERS.register_module
+class RadarFeatureNet(nn.Module):
+    def __init__(self, name="RadarFeatureNet"):
+        super().__init__()
+        self.name = name
+
+    def forward(self, rdr_cube):
+        return rdr_cube
+
+
+@BACKBONES.register_module
+class HRNet3D(nn.Module):
+    def __init__(self, backbone_cfg="hr_tiny_feat32_zyx_l4", feat_transform=None, **kwargs):
+        super().__init__()
+        if feat_transform is not None:
+            raise NotImplementedError("feat_transform is unreachable from the shipped configs (polar_to_cart.py is unregistered)")
+        if backbone_cfg not in net.ARCH_TABLES:
+            raise KeyError("backbone_cfg %r: only the tables used by configs/cruw_pose/*.py are built (%s)"
+                           % (backbone_cfg, ", ".join(net.ARCH_TABLES)))
+        self.backbone_cfg = backbone_cfg
+        self.final_fuse = kwargs["final_fuse"]
+        self.final_conv_in, self.final_conv_out = kwargs["final_conv_in"], kwargs["final_conv_out"]
+        shapes = _backbone_shapes(backbone_cfg, self.final_conv_in, self.final_conv_out)
+        init = _build_params(shapes)
+        self.backbone = ParamTree()
+        self.final_conv = ParamTree() if self.final_conv_in != self.final_conv_out else nn.Identity()
+        for k, t in init.items():
+            if k.startswith("backbone.backbone."):
+                self.backbone.add(k[len("backbone.backbone."):], t)
+            else:
+                self.final_conv.add(k[len("backbone.final_conv."):], t)
+        self._engines = {}
+
+    def forward(self, x_):
+        """Inference-only when used stand-alone (training goes through RadarPoseNet's fused plan)."""
+        eng = _standalone_engine(self, x_, "backbone")
+        eng.load_input(x_.float())
+        eng.run_forward()
+        return eng.features()
+
+
+@HEADS.register_module
+class CenterHead(nn.Module):
+    def __init__(self, in_channels=128, tasks=[], dataset="cruw_pose", common_heads=dict(), logger=None, init_bias=-2.19,
+                 share_conv_channel=64, num_hm_conv=2, weight=0.1, code_weights=[], dcn_head=False):
+        super().__init__()
+        if dcn_head:
+            raise NotImplementedError("dcn_head=True cannot run in the reference either (center_head.py:152 passes bn= into "
+                                      "nn.Module.__init__); the deformable operator is available as rt_pose_amd.dcn")
+        if in_channels != share_conv_channel:
+            raise NotImplementedError("shared_conv (in_channels != share_conv_channel) is not used by any shipped config")
+        if len(tasks) != 1 or num_hm_conv != 2:
+            raise NotImplementedError("one task with two convs per head, as in every shipped config")
+        self.class_names = [t["class_names"] for t in tasks]
+        self.num_classes = [len(t["class_names"]) for t in tasks]
+        self.weight, self.code_weights, self.dataset = weight, list(code_weights), dataset
+        self.in_channels = in_channels
+        self.heads = OrderedDict((k, v[0]) for k, v in dict(common_heads).items())
+        self.heads["hm"] = self.num_classes[0]
+        shapes = OrderedDict()
+        for hname, ncls in self.heads.items():
+            p = "pose_head.tasks.0.%s" % hname
+            shapes[p + ".0.weight"] = (32, share_conv_channel, 3, 3, 3)
+            shapes[p + ".0.bias"] = (32,)
+            shapes[p + ".2.weight"] = (ncls, 32, 3, 3, 3)
+            shapes[p + ".2.bias"] = (ncls,)
+        init = _build_params(shapes)
+        if init_bias != -2.19:
+            init["pose_head.tasks.0.hm.2.bias"].fill_(init_bias)
+        self.shared_conv = nn.Identity()
+        self.tasks = ParamTree()
+        for k, t in init.items():
+            self.tasks.add(k[len("pose_head.tasks."):], t)
+        self._engines = {}
+        self._last = None
+
+    def forward(self, x, *kwargs):
+        eng = _standalone_engine(self, x, "head")
+        eng.load_features(x)
+        eng.run_forward()
+        self._last = eng
+        return [OrderedDict((k, eng.output(k)) for k in self.heads)], x
+
+    def loss(self, example, preds_dicts, test_cfg, **kwargs):
+        raise NotImplementedError("stand-alone CenterHead.loss: training runs through RadarPoseNet's fused plan "
+                                  "(RadarPoseNet.forward(example, return_loss=True))")
+
+    @torch.no_grad()
+    def predict(self, example, preds_dicts, test_cfg, **kwargs):
+        eng = self._last
+        if eng is None:
+            raise RuntimeError("CenterHead.predict: call forward() first")
+        eng.set_test_cfg(_plain(test_cfg))
+        eng.run_decode()
+        return eng.keypoints(example.get("meta") if isinstance(example, dict) else None)
+
+
+def _plain(cfg):
+    return {k: cfg[k] for k in ("out_size_factor", "voxel_size", "pc_range", "score_threshold") if k in cfg}
+
+
+def _loss_dict(eng, loss_tensor=None):
+    l = eng.losses()
+    rets = defaultdict(list)
+    rets["loss"].append(loss_tensor if loss_tensor is not None else l["loss"])
+    rets["hm_loss"].append(l["hm_loss"].detach().cpu())
+    rets["loc_loss"].append(l["loc_loss"])
+    rets["loc_loss_elem"].append(l["loc_loss_elem"].detach().cpu())
+    rets["num_positive"].append(l["num_positive"])
+    return rets
+
+
+def _standalone_engine(mod, x, kind):
+    """Inference plans for a backbone or a head used on its own."""
+    from .graph import Graph
+    key = (tuple(x.shape), str(x.device), kind)
+    eng = mod._engines.get(key)
+    if eng is None:
+        eng = _StandaloneEngine(mod, x, kind)
+        mod._engines[key] = eng
+    return eng
+
+
+class _StandaloneEngine:
+    def __init__(self, mod, x, kind):
+        from .graph import Graph, Act
+        be = _backend_factory(x.device)
+        self.be, self.kind, self.train = be, kind, False
+        b, c, d, h, w = x.shape
+        self.n, self.dims = b, (d, h, w)
+        prefix = "backbone." if kind == "backbone" else "pose_head."
+        params = OrderedDict((prefix + k, p.data) for k, p in mod.named_parameters())
+        g = self.graph = Graph(be, b, params, train=False)
+        if kind == "backbone":
+            self.x_in = g.input_f32("rdr", c, self.dims)
+            self.feats = net.build_hrnet3d(g, self.x_in, mod.backbone_cfg, self.dims, mod.final_fuse)
+        else:
+            self.heads = mod.heads
+            self.f32_in = be.alloc((b, c, d, h, w), "f32")
+            self.feats = g.act("feats", c, self.dims, needs_grad=False)
+            g.fwd.append(be.pack_ncdhw(self.f32_in, self.feats, c))
+            self.outs = net.build_head(g, self.feats, list(mod.heads))
+            self.ncls, self.nreg = mod.heads["hm"], mod.heads["reg"]
+            self.dec_out = be.alloc((b, self.ncls, 2 + self.nreg), "f32")
+            self.dec = None
+        self.fwd = list(g.fwd)
+
+    def load_input(self, x):
+        self.x_in.copy_(x.reshape(self.x_in.shape))
+
+    def load_features(self, x):
+        self.f32_in.copy_(x.float())
+
+    def run_forward(self):
+        s = self.be.stream()
+        for f in self.fwd:
+            f(s)
+
+    def features(self):
+        a = self.feats
+        return a.buf[..., :a.c_real].permute(0, 4, 1, 2, 3)
+
+    def output(self, name):
+        return self.outs[name].buf[..., :self.heads[name]].permute(0, 4, 1, 2, 3)
+
+    set_test_cfg = PoseEngine.set_test_cfg
+    run_decode = PoseEngine.run_decode
+    keypoints = PoseEngine.keypoints
+
+
+class _PlanLoss(torch.autograd.Function):
+    """Attaches the plan's scalar loss to autograd: backward replays the backward launch list, which writes the
+    parameter gradients straight into the flat gradient buffer the parameters' .grad tensors view."""
+
+    @staticmethod
+    def forward(ctx, holder, *params):
+        ctx.holder = holder
+        return holder.engine.losses()["loss"].detach().clone()
+
+    @staticmethod
+    def backward(ctx, go):
+        h = ctx.holder
+        h.engine.run_backward_only()
+        grads = []
+        unit = float(go) == 1.0
+        for name, p in h.named:
+            if name in h.engine.live_params:
+                g = h.flat.grads[name]
+                grads.append(g.clone() if unit else g * go)
+            else:
+                grads.append(None)
+        return (None, *grads)
+
+
+@DETECTORS.register_module
+class RadarPoseNet(nn.Module):
+    def __init__(self, reader, backbone, neck, pose_head, sensor_type="rdr", train_cfg=None, test_cfg=None, pretrained=None):
+        super().__init__()
+        self.reader = build_reader(reader)
+        self.backbone = build_backbone(backbone)
+        if neck is not None:
+            raise NotImplementedError("every shipped config has neck=None (configs/cruw_pose/hr3d.py:81)")
+        self.pose_head = build_head(pose_head)
+        self.train_cfg, self.test_cfg, self.sensor_type = train_cfg, test_cfg, sensor_type
+        self._plans = {}
+        self.flat = None
+        if pretrained is not None:
+            self.load_state_dict(torch.load(pretrained, map_location="cpu").get("state_dict", {}), strict=False)
+
+    @property
+    def with_neck(self):
+        return False
+
+    # ------------------------------------------------------------------ plan management
+    def _flatten(self, device, be):
+        """Re-point every parameter at a view of one flat fp32 buffer (values preserved) so the optimiser step and the
+        gradient all-reduce are single launches; p.grad views the flat gradient buffer."""
+        named = list(self.named_parameters())
+        shapes = OrderedDict((n, tuple(p.shape)) for n, p in named)
+        flat = FlatParams(shapes, be.alloc)
+        for n, p in named:
+            flat.values[n].copy_(p.data)
+            p.data = flat.values[n]
+        self.flat, self._named = flat, named
+
+    def _plan(self, x, train):
+        key = (tuple(x.shape), str(x.device), bool(train))
+        plan = self._plans.get(key)
+        if plan is None:
+            be = _backend_factory(x.device)
+            if self.flat is None or self.flat.p.device != x.device:
+                self._flatten(x.device, be)
+            bb, hd = self.backbone, self.pose_head
+            eng = PoseEngine(be, self.flat.values, bb.backbone_cfg, bb.final_fuse, hd.heads, hd.weight, hd.code_weights,
+                             x.shape[0], tuple(x.shape[2:]), train=train, pgrads=self.flat.grads if train else None,
+                             test_cfg=_plain(self.test_cfg) if self.test_cfg else None)
+            plan = type("Plan", (), {})()
+            plan.engine, plan.flat, plan.named = eng, self.flat, self._named
+            self._plans[key] = plan
+        return plan
+
+    # ------------------------------------------------------------------ reference call convention
+    def extract_feat(self, data):
+        plan = self._plan(data["rdr_tensor"], False)
+        plan.engine.load_input(data["rdr_tensor"].float())
+        plan.engine.run_forward()
+        return plan.engine.features()
+
+    def forward(self, example, return_loss=True, **kwargs):
+        ex = dict(example[self.sensor_type])
+        ex["meta"] = example.get("meta")
+        x = ex["rdr_tensor"]
+        plan = self._plan(x, bool(return_loss))
+        eng = plan.engine
+        eng.load_input(x.float())
+        if return_loss:
+            eng.load_targets(ex)
+            eng.run_forward()
+            eng.run_losses_only()
+            params = [p for _, p in plan.named]
+            loss = _PlanLoss.apply(plan, *params)
+            return _loss_dict(eng, loss)
+        eng.run_forward()
+        eng.run_decode()
+        return eng.keypoints(ex["meta"])

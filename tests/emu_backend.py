@@ -287,6 +287,7 @@ class EmuBackend:
         return run
 
     def upsample_bwd(self, ghi, glow):
+        @torch.enable_grad()  # this emulation differentiates F.interpolate; it may be called inside an autograd backward
         def run(s):
             z = torch.zeros(glow.n, glow.c, glow.d, glow.h, glow.w, requires_grad=True)
             up = F.interpolate(z, size=(ghi.d, ghi.h, ghi.w), mode="trilinear", align_corners=True)
@@ -331,6 +332,7 @@ class EmuBackend:
         return torch.zeros(2)
 
     def focal_loss(self, logits, target, ind, mask, cat, ncls, gscale, scratch, out_loss, ghm):
+        @torch.enable_grad()
         def run(s):
             z = logits.buf[..., :ncls].detach().clone().requires_grad_(True)  # [n,d,h,w,ncls]
             p = torch.clamp(torch.sigmoid(z), 1e-4, 1 - 1e-4)
@@ -351,6 +353,7 @@ class EmuBackend:
         return run
 
     def reg_loss(self, reg, target, ind, mask, code_w, nreg, gscale, out, greg):
+        @torch.enable_grad()
         def run(s):
             r = reg.buf[..., :nreg].detach().clone().requires_grad_(True)
             n = r.shape[0]
