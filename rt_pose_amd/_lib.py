@@ -69,11 +69,17 @@ PROTOTYPES = {
     "rtp_sqnorm": [_P, _L, _P, _P, _P],
     "rtp_sqnorm_blocks": [],
     "rtp_adam_step": [_P, _P, _P, _P, _L, _P, _P, _I, _P, _P],
+    "rtp_dcn_workspace_bytes": [_I] * 9,
+    "rtp_deform_conv_forward": [_P, _P, _P, _P, _P] + [_I] * 16 + [_P],
+    "rtp_deform_conv_backward_input": [_P, _P, _P, _P, _P, _P, _P] + [_I] * 16 + [_P],
+    "rtp_deform_conv_backward_parameters": [_P, _P, _P, _P, _P] + [_I] * 15 + [_F, _I, _P],
+    "rtp_modulated_deform_conv_forward": [_P, _P, _P, _P, _P, _P, _P] + [_I] * 16 + [_P],
+    "rtp_modulated_deform_conv_backward": [_P] * 12 + [_I] * 16 + [_P],
     "rtp_prof_enable": [_I, _I],
     "rtp_prof_collect": [_I, C.POINTER(_F), C.POINTER(_I)],
     "rtp_version": [],
 }
-_RESTYPE = {"rtp_version": C.c_char_p}
+_RESTYPE = {"rtp_version": C.c_char_p, "rtp_dcn_workspace_bytes": C.c_long}
 
 _lib = None
 

@@ -1,0 +1,411 @@
+// Deformable convolution (DCNv1 + modulated DCNv2) for gfx950 -- C-ABI replacements of the five entry points of the
+// reference's pybind module deform_conv_cuda (det3d/ops/dcn/src/deform_conv_cuda.cpp:152-157, 262-268, 376-381,
+// 490-496, 571-578).  Contiguous NCHW fp32 tensors as in the reference; offsets [N, dg*2*kh*kw, Ho, Wo] ordered
+// (dh, dw) per tap; mask [N, dg*kh*kw, Ho, Wo].
+//
+// Structure (what each reference kernel became):
+//   deformable_im2col (+modulated)      -> dcn_im2col_kernel: one thread per (channel, image, ho, wo), wo fastest so the
+//                                          column matrix is written fully coalesced; the 4-corner gather is the
+//                                          irregular HBM/L2 access of the operator
+//   addmm_ per group (cuBLAS)            -> sgemm_kernel: LDS-tiled 64x64x16 fp32 GEMM with strided "matrix views", so
+//                                          the [Co][step*P] -> [N][Co][P] output transpose of the reference
+//                                          (cpp:243-246) is folded into the store
+//   deformable_col2im (atomicAdd)        -> dcn_col2im_kernel (hardware fp32 global atomics, 4 live corners instead of
+//                                          the reference's 5x5 scan)
+//   deformable_col2im_coord              -> dcn_col2im_coord_kernel (also emits the mask gradient for v2)
+// The `columns`/`ones` scratch tensors of the reference become one caller-provided workspace.
+#include "rtp_common.h"
+#include "rtp_prof.h"
+
+struct DcnGeom {
+  int n, c, h, w, co, kh, kw, sh, sw, ph, pw, dh, dw, group, dg, ho, wo;
+};
+
+static inline void dcn_out_size(DcnGeom& g) {
+  g.ho = (g.h + 2 * g.ph - (g.dh * (g.kh - 1) + 1)) / g.sh + 1;
+  g.wo = (g.w + 2 * g.pw - (g.dw * (g.kw - 1) + 1)) / g.sw + 1;
+}
+
+__device__ __forceinline__ float dcn_bilinear(const float* im, int H, int W, float h, float w) {
+  const int h_low = (int)floorf(h), w_low = (int)floorf(w);
+  const int h_high = h_low + 1, w_high = w_low + 1;
+  const float lh = h - h_low, lw = w - w_low, hh = 1.f - lh, hw = 1.f - lw;
+  float v1 = 0.f, v2 = 0.f, v3 = 0.f, v4 = 0.f;
+  if (h_low >= 0 && w_low >= 0) v1 = im[h_low * W + w_low];
+  if (h_low >= 0 && w_high <= W - 1) v2 = im[h_low * W + w_high];
+  if (h_high <= H - 1 && w_low >= 0) v3 = im[h_high * W + w_low];
+  if (h_high <= H - 1 && w_high <= W - 1) v4 = im[h_high * W + w_high];
+  return hh * hw * v1 + hh * lw * v2 + lh * hw * v3 + lh * lw * v4;
+}
+
+// columns[(c*K + tap)][bl*P + p]   for images b0 .. b0+step-1
+__global__ __launch_bounds__(256) void dcn_im2col_kernel(const float* x, const float* offset, const float* mask,
+                                                         float* col, DcnGeom g, int b0, int step) {
+  const int P = g.ho * g.wo, K = g.kh * g.kw;
+  const long total = (long)g.c * step * P;
+  const int cpg = g.c / g.dg;
+  for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int p = (int)(idx % P);
+    const int bl = (int)((idx / P) % step);
+    const int c = (int)(idx / ((long)P * step));
+    const int wo = p % g.wo, ho = p / g.wo;
+    const int b = b0 + bl, dgi = c / cpg;
+    const float* im = x + ((long)b * g.c + c) * g.h * g.w;
+    const float* off = offset + ((long)b * g.dg + dgi) * 2 * K * P;
+    const float* mk = mask ? mask + ((long)b * g.dg + dgi) * K * P : nullptr;
+    const int h_in = ho * g.sh - g.ph, w_in = wo * g.sw - g.pw;
+    float* dst = col + ((long)c * K * step + bl) * P + p;
+    for (int t = 0; t < K; ++t) {
+      const int i = t / g.kw, j = t - i * g.kw;
+      const float hi = h_in + i * g.dh + off[(2 * t) * P + p];
+      const float wi = w_in + j * g.dw + off[(2 * t + 1) * P + p];
+      float v = 0.f;
+      if (hi > -1.f && wi > -1.f && hi < g.h && wi < g.w) v = dcn_bilinear(im, g.h, g.w, hi, wi);
+      if (mk) v *= mk[t * P + p];
+      dst[(long)t * step * P] = v;
+    }
+  }
+}
+
+// grad_im[b][c] += bilinear-adjoint of columns-gradient (atomic scatter to the 4 live corners)
+__global__ __launch_bounds__(256) void dcn_col2im_kernel(const float* col, const float* offset, const float* mask,
+                                                         float* grad_im, DcnGeom g, int b0, int step) {
+  const int P = g.ho * g.wo, K = g.kh * g.kw;
+  const long total = (long)g.c * K * step * P;
+  const int cpg = g.c / g.dg;
+  for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int p = (int)(idx % P);
+    const int bl = (int)((idx / P) % step);
+    const int t = (int)((idx / ((long)P * step)) % K);
+    const int c = (int)(idx / ((long)P * step * K));
+    const int wo = p % g.wo, ho = p / g.wo;
+    const int b = b0 + bl, dgi = c / cpg;
+    const int i = t / g.kw, j = t - i * g.kw;
+    const float* off = offset + ((long)b * g.dg + dgi) * 2 * K * P;
+    const float hi = ho * g.sh - g.ph + i * g.dh + off[(2 * t) * P + p];
+    const float wi = wo * g.sw - g.pw + j * g.dw + off[(2 * t + 1) * P + p];
+    if (!(hi > -1.f && wi > -1.f && hi < g.h && wi < g.w)) continue;
+    float top = col[idx];
+    if (mask) top *= mask[((long)b * g.dg + dgi) * K * P + t * P + p];
+    const int h_low = (int)floorf(hi), w_low = (int)floorf(wi);
+    const float lh = hi - h_low, lw = wi - w_low;
+    float* gim = grad_im + ((long)b * g.c + c) * g.h * g.w;
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 2; ++dx) {
+        const int yy = h_low + dy, xx = w_low + dx;
+        if (yy >= 0 && yy <= g.h - 1 && xx >= 0 && xx <= g.w - 1) {
+          const float wgt = (dy ? lh : 1.f - lh) * (dx ? lw : 1.f - lw);
+          if (wgt != 0.f) atomicAdd(gim + yy * g.w + xx, wgt * top);
+        }
+      }
+  }
+}
+
+__device__ __forceinline__ float dcn_coord_weight(const float* im, int H, int W, float h, float w, int dir) {
+  // d bilinear / d h (dir 0) or / d w (dir 1), per-corner bounds as the forward (kernel.cu:145-188)
+  const int h_low = (int)floorf(h), w_low = (int)floorf(w);
+  const int h_high = h_low + 1, w_high = w_low + 1;
+  const float lh = h - h_low, lw = w - w_low;
+  float v1 = 0.f, v2 = 0.f, v3 = 0.f, v4 = 0.f;
+  if (h_low >= 0 && w_low >= 0) v1 = im[h_low * W + w_low];
+  if (h_low >= 0 && w_high <= W - 1) v2 = im[h_low * W + w_high];
+  if (h_high <= H - 1 && w_low >= 0) v3 = im[h_high * W + w_low];
+  if (h_high <= H - 1 && w_high <= W - 1) v4 = im[h_high * W + w_high];
+  if (dir == 0) return -(1.f - lw) * v1 - lw * v2 + (1.f - lw) * v3 + lw * v4;
+  return -(1.f - lh) * v1 + (1.f - lh) * v2 - lh * v3 + lh * v4;
+}
+
+// grad_offset[b][dg*2K + 2t + dir][p] = sum_{c in dg} col[c,t] * (mask) * d bilinear/d coord ; grad_mask likewise
+__global__ __launch_bounds__(256) void dcn_col2im_coord_kernel(const float* col, const float* x, const float* offset,
+                                                               const float* mask, float* grad_offset, float* grad_mask,
+                                                               DcnGeom g, int b0, int step) {
+  const int P = g.ho * g.wo, K = g.kh * g.kw;
+  const long total = (long)step * g.dg * K * P;
+  const int cpg = g.c / g.dg;
+  for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int p = (int)(idx % P);
+    const int t = (int)((idx / P) % K);
+    const int dgi = (int)((idx / ((long)P * K)) % g.dg);
+    const int bl = (int)(idx / ((long)P * K * g.dg));
+    const int b = b0 + bl;
+    const int wo = p % g.wo, ho = p / g.wo;
+    const int i = t / g.kw, j = t - i * g.kw;
+    const float* off = offset + ((long)b * g.dg + dgi) * 2 * K * P;
+    const float hi = ho * g.sh - g.ph + i * g.dh + off[(2 * t) * P + p];
+    const float wi = wo * g.sw - g.pw + j * g.dw + off[(2 * t + 1) * P + p];
+    const bool inside = hi > -1.f && wi > -1.f && hi < g.h && wi < g.w;
+    const float mk = mask ? mask[((long)b * g.dg + dgi) * K * P + t * P + p] : 1.f;
+    float gh = 0.f, gw = 0.f, gm = 0.f;
+    if (inside) {
+      for (int cc = 0; cc < cpg; ++cc) {
+        const int c = dgi * cpg + cc;
+        const float cv = col[(((long)c * K + t) * step + bl) * P + p];
+        const float* im = x + ((long)b * g.c + c) * g.h * g.w;
+        gh += cv * mk * dcn_coord_weight(im, g.h, g.w, hi, wi, 0);
+        gw += cv * mk * dcn_coord_weight(im, g.h, g.w, hi, wi, 1);
+        if (grad_mask) gm += cv * dcn_bilinear(im, g.h, g.w, hi, wi);
+      }
+    }
+    float* go = grad_offset + ((long)b * g.dg + dgi) * 2 * K * P;
+    go[(2 * t) * P + p] = gh;
+    go[(2 * t + 1) * P + p] = gw;
+    if (grad_mask) grad_mask[((long)b * g.dg + dgi) * K * P + t * P + p] = gm;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ SGEMM
+struct MatView {
+  float* p; long s_row, s_col; int split; long s_outer;  // column index n -> (n / split) * s_outer + (n % split) * s_col
+  __device__ __forceinline__ long at(int r, int cidx) const {
+    return (long)r * s_row + (long)(cidx / split) * s_outer + (long)(cidx % split) * s_col;
+  }
+};
+
+// C[M][N] = alpha * A[M][K] * B[K][N] + beta * C
+__global__ __launch_bounds__(256) void sgemm_kernel(MatView A, MatView B, MatView C, int M, int N, int K, float alpha,
+                                                    float beta) {
+  __shared__ float As[16][64 + 4];
+  __shared__ float Bs[16][64 + 4];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+  float acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+  for (int k0 = 0; k0 < K; k0 += 16) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int e = threadIdx.x + r * 256;  // 1024 elements per tile
+      {
+        const int kk = e & 15, mm = e >> 4;  // A tile: 64 rows x 16 k
+        const int m = m0 + mm, k = k0 + kk;
+        As[kk][mm] = (m < M && k < K) ? A.p[A.at(m, k)] : 0.f;
+      }
+      {
+        const int nn = e & 63, kk = e >> 6;  // B tile: 16 k x 64 cols
+        const int n = n0 + nn, k = k0 + kk;
+        Bs[kk][nn] = (n < N && k < K) ? B.p[B.at(k, n)] : 0.f;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+      float a[4], b[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = As[kk][ty * 4 + i];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[j] = Bs[kk][tx * 4 + j];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] += a[i] * b[j];
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int m = m0 + ty * 4 + i, n = n0 + tx * 4 + j;
+      if (m < M && n < N) {
+        float* dst = C.p + C.at(m, n);
+        *dst = alpha * acc[i][j] + (beta != 0.f ? beta * *dst : 0.f);
+      }
+    }
+}
+
+static void sgemm(hipStream_t s, MatView A, MatView B, MatView C, int M, int N, int K, float alpha, float beta) {
+  dim3 grid((N + 63) / 64, (M + 63) / 64);
+  hipLaunchKernelGGL(sgemm_kernel, grid, dim3(256), 0, s, A, B, C, M, N, K, alpha, beta);
+}
+
+static inline MatView mv(const float* p, long s_row, long s_col, int split = 1 << 30, long s_outer = 0) {
+  return MatView{const_cast<float*>(p), s_row, s_col, split, s_outer};
+}
+
+static inline int grid1d(long n) {
+  long b = (n + 255) / 256;
+  return (int)(b > 8192 ? 8192 : (b < 1 ? 1 : b));
+}
+
+__global__ void dcn_bias_kernel(float* out, const float* bias, int co, int P, long total, int add) {
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c = (int)((i / P) % co);
+    out[i] = add ? out[i] + bias[c] : bias[c];
+  }
+}
+
+// grad_bias[c] += sum over (n, p) of grad_output : one block per channel
+__global__ __launch_bounds__(256) void dcn_bias_grad_kernel(const float* go, float* gb, int n, int co, int P) {
+  __shared__ float red[256];
+  const int c = blockIdx.x;
+  float acc = 0.f;
+  for (long i = threadIdx.x; i < (long)n * P; i += 256) acc += go[((i / P) * co + c) * P + i % P];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) gb[c] += red[0];
+}
+
+static int dcn_check(DcnGeom& g, int im2col_step) {
+  if (g.n < 1 || g.c < 1 || g.co < 1 || g.kh < 1 || g.kw < 1 || g.sh < 1 || g.sw < 1 || g.dh < 1 || g.dw < 1)
+    return RTP_ERR_SHAPE;  // shape_check, deform_conv_cuda.cpp:62-150
+  if (g.group < 1 || g.dg < 1 || g.c % g.group || g.co % g.group || g.c % g.dg) return RTP_ERR_SHAPE;
+  dcn_out_size(g);
+  if (g.ho < 1 || g.wo < 1) return RTP_ERR_SHAPE;
+  if (im2col_step < 1 || g.n % im2col_step) return RTP_ERR_SHAPE;  // 'im2col step must divide batchsize'
+  return RTP_OK;
+}
+
+extern "C" long rtp_dcn_workspace_bytes(int n, int c, int h, int w, int co, int kh, int kw, int ho, int wo) {
+  (void)h; (void)w; (void)co;
+  return (long)c * kh * kw * n * ho * wo * (long)sizeof(float);  // columns for one chunk of up to n images
+}
+
+static int dcn_forward(const float* input, const float* weight, const float* bias, const float* offset,
+                       const float* mask, float* output, float* ws, DcnGeom g, int step, hipStream_t s) {
+  const int P = g.ho * g.wo, K = g.kh * g.kw;
+  const int cg = g.c / g.group, cog = g.co / g.group;
+  RtpProfScope prof(RTP_FAM_DCN, s);
+  for (int b0 = 0; b0 < g.n; b0 += step) {
+    hipLaunchKernelGGL(dcn_im2col_kernel, dim3(grid1d((long)g.c * step * P)), dim3(256), 0, s, input, offset, mask, ws,
+                       g, b0, step);
+    for (int gi = 0; gi < g.group; ++gi) {
+      // out[b0 + n/P][gi*cog + m][n%P] = W[gi][m][:] . columns[gi][:][n]
+      sgemm(s, mv(weight + (long)gi * cog * cg * K, (long)cg * K, 1),
+            mv(ws + (long)gi * cg * K * step * P, (long)step * P, 1),
+            mv(output + ((long)b0 * g.co + gi * cog) * P, P, 1, P, (long)g.co * P), cog, step * P, cg * K, 1.f, 0.f);
+    }
+  }
+  if (bias) {
+    const long total = (long)g.n * g.co * P;
+    hipLaunchKernelGGL(dcn_bias_kernel, dim3(grid1d(total)), dim3(256), 0, s, output, bias, g.co, P, total, 1);
+  }
+  RTP_CHECK_LAUNCH();
+  return RTP_OK;
+}
+
+static int dcn_backward_input(const float* input, const float* offset, const float* mask, const float* gradOutput,
+                              float* gradInput, float* gradOffset, float* gradMask, const float* weight, float* ws,
+                              DcnGeom g, int step, hipStream_t s) {
+  const int P = g.ho * g.wo, K = g.kh * g.kw;
+  const int cg = g.c / g.group, cog = g.co / g.group;
+  RtpProfScope prof(RTP_FAM_DCN, s);
+  for (int b0 = 0; b0 < g.n; b0 += step) {
+    for (int gi = 0; gi < g.group; ++gi) {
+      // columns[gi] (cg*K x step*P) = W[gi]^T (cg*K x cog) . gradOut chunk (cog x step*P)
+      sgemm(s, mv(weight + (long)gi * cog * cg * K, 1, (long)cg * K),
+            mv(gradOutput + ((long)b0 * g.co + gi * cog) * P, P, 1, P, (long)g.co * P),
+            mv(ws + (long)gi * cg * K * step * P, (long)step * P, 1), cg * K, step * P, cog, 1.f, 0.f);
+    }
+    hipLaunchKernelGGL(dcn_col2im_coord_kernel, dim3(grid1d((long)step * g.dg * K * P)), dim3(256), 0, s, ws, input,
+                       offset, mask, gradOffset, gradMask, g, b0, step);
+    hipLaunchKernelGGL(dcn_col2im_kernel, dim3(grid1d((long)g.c * K * step * P)), dim3(256), 0, s, ws, offset, mask,
+                       gradInput, g, b0, step);
+  }
+  RTP_CHECK_LAUNCH();
+  return RTP_OK;
+}
+
+static int dcn_backward_params(const float* input, const float* offset, const float* mask, const float* gradOutput,
+                               float* gradWeight, float* ws, DcnGeom g, float scale, int step, hipStream_t s) {
+  const int P = g.ho * g.wo, K = g.kh * g.kw;
+  const int cg = g.c / g.group, cog = g.co / g.group;
+  RtpProfScope prof(RTP_FAM_DCN, s);
+  for (int b0 = 0; b0 < g.n; b0 += step) {
+    hipLaunchKernelGGL(dcn_im2col_kernel, dim3(grid1d((long)g.c * step * P)), dim3(256), 0, s, input, offset, mask, ws,
+                       g, b0, step);
+    for (int gi = 0; gi < g.group; ++gi) {
+      // gradW[gi] (cog x cg*K) += scale * gradOut chunk (cog x step*P) . columns[gi]^T (step*P x cg*K)
+      sgemm(s, mv(gradOutput + ((long)b0 * g.co + gi * cog) * P, P, 1, P, (long)g.co * P),
+            mv(ws + (long)gi * cg * K * step * P, 1, (long)step * P),
+            mv(gradWeight + (long)gi * cog * cg * K, (long)cg * K, 1), cog, cg * K, step * P, scale, 1.f);
+    }
+  }
+  RTP_CHECK_LAUNCH();
+  return RTP_OK;
+}
+
+#define DCN_GEOM_V1() DcnGeom g{n, c, h, w, co, kH, kW, dH, dW, padH, padW, dilH, dilW, group, deformable_group, 0, 0}
+
+extern "C" int rtp_deform_conv_forward(const float* input, const float* weight, const float* offset, float* output,
+                                       void* ws, int n, int c, int h, int w, int co, int kW, int kH, int dW, int dH,
+                                       int padW, int padH, int dilW, int dilH, int group, int deformable_group,
+                                       int im2col_step, void* stream) {
+  if (!input || !weight || !offset || !output || !ws) return RTP_ERR_SHAPE;
+  DCN_GEOM_V1();
+  const int rc = dcn_check(g, im2col_step);
+  if (rc) return rc;
+  return dcn_forward(input, weight, nullptr, offset, nullptr, output, (float*)ws, g, im2col_step, (hipStream_t)stream);
+}
+
+extern "C" int rtp_deform_conv_backward_input(const float* input, const float* offset, const float* gradOutput,
+                                              float* gradInput, float* gradOffset, const float* weight, void* ws, int n,
+                                              int c, int h, int w, int co, int kW, int kH, int dW, int dH, int padW,
+                                              int padH, int dilW, int dilH, int group, int deformable_group,
+                                              int im2col_step, void* stream) {
+  if (!input || !offset || !gradOutput || !gradInput || !gradOffset || !weight || !ws) return RTP_ERR_SHAPE;
+  DCN_GEOM_V1();
+  const int rc = dcn_check(g, im2col_step);
+  if (rc) return rc;
+  return dcn_backward_input(input, offset, nullptr, gradOutput, gradInput, gradOffset, nullptr, weight, (float*)ws, g,
+                            im2col_step, (hipStream_t)stream);
+}
+
+extern "C" int rtp_deform_conv_backward_parameters(const float* input, const float* offset, const float* gradOutput,
+                                                   float* gradWeight, void* ws, int n, int c, int h, int w, int co,
+                                                   int kW, int kH, int dW, int dH, int padW, int padH, int dilW,
+                                                   int dilH, int group, int deformable_group, float scale,
+                                                   int im2col_step, void* stream) {
+  if (!input || !offset || !gradOutput || !gradWeight || !ws) return RTP_ERR_SHAPE;
+  DCN_GEOM_V1();
+  const int rc = dcn_check(g, im2col_step);
+  if (rc) return rc;
+  return dcn_backward_params(input, offset, nullptr, gradOutput, gradWeight, (float*)ws, g, scale, im2col_step,
+                             (hipStream_t)stream);
+}
+
+extern "C" int rtp_modulated_deform_conv_forward(const float* input, const float* weight, const float* bias,
+                                                 const float* offset, const float* mask, float* output, void* ws,
+                                                 int n, int c, int h, int w, int co, int kh, int kw, int sh, int sw,
+                                                 int ph, int pw, int dh, int dw, int group, int deformable_group,
+                                                 int with_bias, void* stream) {
+  if (!input || !weight || !offset || !mask || !output || !ws || (with_bias && !bias)) return RTP_ERR_SHAPE;
+  DcnGeom g{n, c, h, w, co, kh, kw, sh, sw, ph, pw, dh, dw, group, deformable_group, 0, 0};
+  const int rc = dcn_check(g, 1);  // the reference walks the batch one image at a time (cpp:539)
+  if (rc) return rc;
+  return dcn_forward(input, weight, with_bias ? bias : nullptr, offset, mask, output, (float*)ws, g, 1,
+                     (hipStream_t)stream);
+}
+
+extern "C" int rtp_modulated_deform_conv_backward(const float* input, const float* weight, const float* bias,
+                                                  const float* offset, const float* mask, float* grad_input,
+                                                  float* grad_weight, float* grad_bias, float* grad_offset,
+                                                  float* grad_mask, const float* grad_output, void* ws, int n, int c,
+                                                  int h, int w, int co, int kh, int kw, int sh, int sw, int ph, int pw,
+                                                  int dh, int dw, int group, int deformable_group, int with_bias,
+                                                  void* stream) {
+  (void)bias;
+  if (!input || !weight || !offset || !mask || !grad_input || !grad_weight || !grad_offset || !grad_mask ||
+      !grad_output || !ws || (with_bias && !grad_bias))
+    return RTP_ERR_SHAPE;
+  DcnGeom g{n, c, h, w, co, kh, kw, sh, sw, ph, pw, dh, dw, group, deformable_group, 0, 0};
+  int rc = dcn_check(g, 1);
+  if (rc) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  rc = dcn_backward_input(input, offset, mask, grad_output, grad_input, grad_offset, grad_mask, weight, (float*)ws, g, 1, s);
+  if (rc) return rc;
+  rc = dcn_backward_params(input, offset, mask, grad_output, grad_weight, (float*)ws, g, 1.f, 1, s);
+  if (rc) return rc;
+  if (with_bias) {
+    hipLaunchKernelGGL(dcn_bias_grad_kernel, dim3(co), dim3(256), 0, s, grad_output, grad_bias, n, co, g.ho * g.wo);
+    RTP_CHECK_LAUNCH();
+  }
+  return RTP_OK;
+}

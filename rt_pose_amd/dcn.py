@@ -1,0 +1,269 @@
+"""Deformable convolution operators on the HIP kernels -- the Python face of det3d/ops/dcn/deform_conv.py.
+
+Same names, argument meaning and error behaviour as the reference wrapper (deform_conv.py:14-112, 115-190, 192-255,
+323-350): DeformConvFunction / ModulatedDeformConvFunction (autograd), deform_conv / modulated_deform_conv,
+DeformConv, DeformConvPack, ModulatedDeformConv, ModulatedDeformConvPack.  The five native calls go through the C ABI
+of include/rtp.h section D instead of the pybind module `deform_conv_cuda`.
+
+Error behaviour kept: non-4-D input -> ValueError; CPU tensors -> NotImplementedError (there is no CPU path here
+either); batch not divisible by im2col_step -> AssertionError('im2col step must divide batchsize'); a failing native
+call -> RuntimeError.  fp32 only (the reference also dispatches fp64/fp16; the pose path never uses them).
+"""
+import ctypes as C
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+from torch.nn.modules.utils import _pair, _single
+
+from . import _lib
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream(t):
+    return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _workspace(x, weight, out_hw, step):
+    lib = _lib.load()
+    n, c, h, w = x.shape
+    nbytes = lib.rtp_dcn_workspace_bytes(step, c, h, w, weight.shape[0], weight.shape[2], weight.shape[3], out_hw[0], out_hw[1])
+    return torch.empty(nbytes // 4, dtype=torch.float32, device=x.device)
+
+
+def _check(x, *others):
+    if not x.is_cuda:
+        raise NotImplementedError
+    for t in (x, *others):
+        if t is not None and t.dtype != torch.float32:
+            raise NotImplementedError("rt_pose_amd.dcn is fp32 (got %s)" % t.dtype)
+
+
+class DeformConvFunction(Function):
+    @staticmethod
+    def forward(ctx, input, offset, weight, stride=1, padding=0, dilation=1, groups=1, deformable_groups=1, im2col_step=64):
+        if input is not None and input.dim() != 4:
+            raise ValueError("Expected 4D tensor as input, got {}D tensor instead.".format(input.dim()))
+        ctx.stride, ctx.padding, ctx.dilation = _pair(stride), _pair(padding), _pair(dilation)
+        ctx.groups, ctx.deformable_groups, ctx.im2col_step = groups, deformable_groups, im2col_step
+        ctx.save_for_backward(input, offset, weight)
+        _check(input, offset, weight)
+        out_size = DeformConvFunction._output_size(input, weight, ctx.padding, ctx.dilation, ctx.stride)
+        output = input.new_empty(out_size)
+        step = min(ctx.im2col_step, input.shape[0])
+        assert (input.shape[0] % step) == 0, "im2col step must divide batchsize"
+        input, offset, weight = input.contiguous(), offset.contiguous(), weight.contiguous()
+        ws = _workspace(input, weight, out_size[2:], step)
+        n, c, h, w = input.shape
+        rc = _lib.load().rtp_deform_conv_forward(
+            _p(input), _p(weight), _p(offset), _p(output), _p(ws), n, c, h, w, weight.size(0), weight.size(3), weight.size(2),
+            ctx.stride[1], ctx.stride[0], ctx.padding[1], ctx.padding[0], ctx.dilation[1], ctx.dilation[0], ctx.groups,
+            ctx.deformable_groups, step, _stream(input))
+        if rc != 0:
+            raise RuntimeError("rtp_deform_conv_forward failed (%d)" % rc)
+        return output
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_output):
+        input, offset, weight = ctx.saved_tensors
+        grad_input = grad_offset = grad_weight = None
+        if not grad_output.is_cuda:
+            raise NotImplementedError
+        step = min(ctx.im2col_step, input.shape[0])
+        assert (input.shape[0] % step) == 0, "im2col step must divide batchsize"
+        lib = _lib.load()
+        input, offset, weight, grad_output = input.contiguous(), offset.contiguous(), weight.contiguous(), grad_output.contiguous()
+        ws = _workspace(input, weight, grad_output.shape[2:], step)
+        n, c, h, w = input.shape
+        geo = (n, c, h, w, weight.size(0), weight.size(3), weight.size(2), ctx.stride[1], ctx.stride[0], ctx.padding[1],
+               ctx.padding[0], ctx.dilation[1], ctx.dilation[0], ctx.groups, ctx.deformable_groups)
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            grad_input = torch.zeros_like(input)
+            grad_offset = torch.zeros_like(offset)
+            rc = lib.rtp_deform_conv_backward_input(_p(input), _p(offset), _p(grad_output), _p(grad_input), _p(grad_offset),
+                                                    _p(weight), _p(ws), *geo, step, _stream(input))
+            if rc != 0:
+                raise RuntimeError("rtp_deform_conv_backward_input failed (%d)" % rc)
+        if ctx.needs_input_grad[2]:
+            grad_weight = torch.zeros_like(weight)
+            rc = lib.rtp_deform_conv_backward_parameters(_p(input), _p(offset), _p(grad_output), _p(grad_weight), _p(ws), *geo,
+                                                         1.0, step, _stream(input))
+            if rc != 0:
+                raise RuntimeError("rtp_deform_conv_backward_parameters failed (%d)" % rc)
+        return (grad_input, grad_offset, grad_weight, None, None, None, None, None, None)
+
+    @staticmethod
+    def _output_size(input, weight, padding, dilation, stride):
+        channels = weight.size(0)
+        output_size = (input.size(0), channels)
+        for d in range(input.dim() - 2):
+            in_size = input.size(d + 2)
+            kernel = dilation[d] * (weight.size(d + 2) - 1) + 1
+            output_size += ((in_size + (2 * padding[d]) - kernel) // stride[d] + 1,)
+        if not all(map(lambda s: s > 0, output_size)):
+            raise ValueError("convolution input is too small (output would be {})".format("x".join(map(str, output_size))))
+        return output_size
+
+
+class ModulatedDeformConvFunction(Function):
+    @staticmethod
+    def forward(ctx, input, offset, mask, weight, bias=None, stride=1, padding=0, dilation=1, groups=1, deformable_groups=1):
+        ctx.stride, ctx.padding, ctx.dilation = stride, padding, dilation
+        ctx.groups, ctx.deformable_groups = groups, deformable_groups
+        ctx.with_bias = bias is not None
+        if not ctx.with_bias:
+            bias = input.new_empty(1)  # fake tensor
+        _check(input, offset, mask, weight)
+        if weight.requires_grad or mask.requires_grad or offset.requires_grad or input.requires_grad:
+            ctx.save_for_backward(input, offset, mask, weight, bias)
+        out_shape = ModulatedDeformConvFunction._infer_shape(ctx, input, weight)
+        output = input.new_empty(out_shape)
+        input, offset, mask, weight = input.contiguous(), offset.contiguous(), mask.contiguous(), weight.contiguous()
+        ws = _workspace(input, weight, out_shape[2:], 1)
+        n, c, h, w = input.shape
+        rc = _lib.load().rtp_modulated_deform_conv_forward(
+            _p(input), _p(weight), _p(bias), _p(offset), _p(mask), _p(output), _p(ws), n, c, h, w, weight.shape[0],
+            weight.shape[2], weight.shape[3], stride, stride, padding, padding, dilation, dilation, groups, deformable_groups,
+            int(ctx.with_bias), _stream(input))
+        if rc != 0:
+            raise RuntimeError("rtp_modulated_deform_conv_forward failed (%d)" % rc)
+        return output
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_output):
+        if not grad_output.is_cuda:
+            raise NotImplementedError
+        input, offset, mask, weight, bias = ctx.saved_tensors
+        grad_input, grad_offset = torch.zeros_like(input), torch.zeros_like(offset)
+        grad_mask, grad_weight, grad_bias = torch.zeros_like(mask), torch.zeros_like(weight), torch.zeros_like(bias)
+        input, offset, mask, weight = input.contiguous(), offset.contiguous(), mask.contiguous(), weight.contiguous()
+        grad_output = grad_output.contiguous()
+        ws = _workspace(input, weight, grad_output.shape[2:], 1)
+        n, c, h, w = input.shape
+        rc = _lib.load().rtp_modulated_deform_conv_backward(
+            _p(input), _p(weight), _p(bias), _p(offset), _p(mask), _p(grad_input), _p(grad_weight), _p(grad_bias),
+            _p(grad_offset), _p(grad_mask), _p(grad_output), _p(ws), n, c, h, w, weight.shape[0], weight.shape[2],
+            weight.shape[3], ctx.stride, ctx.stride, ctx.padding, ctx.padding, ctx.dilation, ctx.dilation, ctx.groups,
+            ctx.deformable_groups, int(ctx.with_bias), _stream(input))
+        if rc != 0:
+            raise RuntimeError("rtp_modulated_deform_conv_backward failed (%d)" % rc)
+        if not ctx.with_bias:
+            grad_bias = None
+        return (grad_input, grad_offset, grad_mask, grad_weight, grad_bias, None, None, None, None, None)
+
+    @staticmethod
+    def _infer_shape(ctx, input, weight):
+        n, channels_out = input.size(0), weight.size(0)
+        height, width = input.shape[2:4]
+        kernel_h, kernel_w = weight.shape[2:4]
+        height_out = (height + 2 * ctx.padding - (ctx.dilation * (kernel_h - 1) + 1)) // ctx.stride + 1
+        width_out = (width + 2 * ctx.padding - (ctx.dilation * (kernel_w - 1) + 1)) // ctx.stride + 1
+        return n, channels_out, height_out, width_out
+
+
+deform_conv = DeformConvFunction.apply
+modulated_deform_conv = ModulatedDeformConvFunction.apply
+
+
+class DeformConv(nn.Module):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1,
+                 deformable_groups=1, bias=False):
+        super().__init__()
+        assert not bias
+        assert in_channels % groups == 0, "in_channels {} cannot be divisible by groups {}".format(in_channels, groups)
+        assert out_channels % groups == 0, "out_channels {} cannot be divisible by groups {}".format(out_channels, groups)
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size, self.stride = _pair(kernel_size), _pair(stride)
+        self.padding, self.dilation = _pair(padding), _pair(dilation)
+        self.groups, self.deformable_groups = groups, deformable_groups
+        self.transposed, self.output_padding = False, _single(0)
+        self.weight = nn.Parameter(torch.Tensor(out_channels, in_channels // self.groups, *self.kernel_size))
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        n = self.in_channels
+        for k in self.kernel_size:
+            n *= k
+        stdv = 1.0 / math.sqrt(n)
+        self.weight.data.uniform_(-stdv, stdv)
+
+    def forward(self, x, offset):
+        input_pad = x.size(2) < self.kernel_size[0] or x.size(3) < self.kernel_size[1]
+        if input_pad:  # deform_conv.py:230-238
+            pad_h = max(self.kernel_size[0] - x.size(2), 0)
+            pad_w = max(self.kernel_size[1] - x.size(3), 0)
+            x = F.pad(x, (0, pad_w, 0, pad_h), "constant", 0).contiguous()
+            offset = F.pad(offset, (0, pad_w, 0, pad_h), "constant", 0).contiguous()
+        out = deform_conv(x, offset, self.weight, self.stride, self.padding, self.dilation, self.groups, self.deformable_groups)
+        if input_pad:
+            out = out[:, :, :out.size(2) - pad_h, :out.size(3) - pad_w].contiguous()
+        return out
+
+
+class DeformConvPack(DeformConv):
+    _version = 2
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.conv_offset = nn.Conv2d(self.in_channels, self.deformable_groups * 2 * self.kernel_size[0] * self.kernel_size[1],
+                                     kernel_size=self.kernel_size, stride=_pair(self.stride), padding=_pair(self.padding), bias=True)
+        self.conv_offset.weight.data.zero_()
+        self.conv_offset.bias.data.zero_()
+
+    def forward(self, x):
+        offset = self.conv_offset(x)
+        return deform_conv(x, offset, self.weight, self.stride, self.padding, self.dilation, self.groups, self.deformable_groups)
+
+
+class ModulatedDeformConv(nn.Module):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1,
+                 deformable_groups=1, bias=True):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size = _pair(kernel_size)
+        self.stride, self.padding, self.dilation = stride, padding, dilation
+        self.groups, self.deformable_groups, self.with_bias = groups, deformable_groups, bias
+        self.transposed, self.output_padding = False, _single(0)
+        self.weight = nn.Parameter(torch.Tensor(out_channels, in_channels // groups, *self.kernel_size))
+        if bias:
+            self.bias = nn.Parameter(torch.Tensor(out_channels))
+        else:
+            self.register_parameter("bias", None)
+        n = self.in_channels
+        for k in self.kernel_size:
+            n *= k
+        stdv = 1.0 / math.sqrt(n)
+        self.weight.data.uniform_(-stdv, stdv)
+        if self.bias is not None:
+            self.bias.data.zero_()
+
+    def forward(self, x, offset, mask):
+        return modulated_deform_conv(x, offset, mask, self.weight, self.bias, self.stride, self.padding, self.dilation,
+                                     self.groups, self.deformable_groups)
+
+
+class ModulatedDeformConvPack(ModulatedDeformConv):
+    _version = 2
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.conv_offset = nn.Conv2d(self.in_channels, self.deformable_groups * 3 * self.kernel_size[0] * self.kernel_size[1],
+                                     kernel_size=self.kernel_size, stride=_pair(self.stride), padding=_pair(self.padding), bias=True)
+        self.conv_offset.weight.data.zero_()
+        self.conv_offset.bias.data.zero_()
+
+    def forward(self, x):
+        out = self.conv_offset(x)
+        o1, o2, mask = torch.chunk(out, 3, dim=1)
+        offset = torch.cat((o1, o2), dim=1)
+        mask = torch.sigmoid(mask)
+        return modulated_deform_conv(x, offset, mask, self.weight, self.bias, self.stride, self.padding, self.dilation,
+                                     self.groups, self.deformable_groups)

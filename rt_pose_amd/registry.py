@@ -77,6 +77,7 @@ ROI_HEAD = Registry("roi_head")
 
 
 def build(cfg, registry, default_args=None):
+    from . import modules  # noqa: F401  (registers RadarPoseNet / HRNet3D / CenterHead / RadarFeatureNet on first use)
     if isinstance(cfg, list):
         import torch.nn as nn
         return nn.Sequential(*[build_from_cfg(c, registry, default_args) for c in cfg])

@@ -1,0 +1,64 @@
+"""Known-answer tests that pin oracle/dcn_ref.py (the reference ships none for this operator -- parity unpinned)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle.dcn_ref import deform_conv2d
+
+
+def rnd(*shape, seed=0, dtype=torch.float64):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed), dtype=dtype)
+
+
+@pytest.mark.parametrize("stride,pad,dil,groups,dg", [(1, 1, 1, 1, 1), (2, 1, 1, 2, 4), (1, 2, 2, 1, 2)])
+def test_zero_offsets_is_plain_conv(stride, pad, dil, groups, dg):
+    x, w = rnd(2, 8, 9, 11, seed=1), rnd(6, 8 // groups, 3, 3, seed=2)
+    ref = F.conv2d(x, w, None, stride, pad, dil, groups)
+    off = torch.zeros(2, dg * 18, ref.shape[2], ref.shape[3], dtype=torch.float64)
+    torch.testing.assert_close(deform_conv2d(x, off, w, stride, pad, dil, groups, dg), ref, rtol=1e-10, atol=1e-10)
+
+
+def test_integer_offsets_shift_the_input():
+    x, w = rnd(1, 4, 10, 10, seed=3), rnd(5, 4, 3, 3, seed=4)
+    off = torch.zeros(1, 18, 10, 10, dtype=torch.float64)
+    off[:, 0::2] = 1.0   # every tap samples one row lower
+    off[:, 1::2] = -2.0  # and two columns to the left
+    shifted = torch.zeros_like(x)
+    shifted[:, :, :-1, 2:] = x[:, :, 1:, :-2]  # shifted[h,w] = x[h+1, w-2], zero outside
+    # interior only: at the border the deformable window (-1,H) differs from zero padding of the shifted image
+    got = deform_conv2d(x, off, w, 1, 1)[:, :, 2:-2, 3:-2]
+    ref = F.conv2d(shifted, w, None, 1, 1)[:, :, 2:-2, 3:-2]
+    torch.testing.assert_close(got, ref, rtol=1e-10, atol=1e-10)
+
+
+def test_taps_pushed_outside_give_zero():
+    x, w = rnd(1, 2, 6, 6, seed=5), rnd(3, 2, 3, 3, seed=6)
+    off = torch.full((1, 18, 6, 6), 100.0, dtype=torch.float64)
+    assert float(deform_conv2d(x, off, w, 1, 1).abs().max()) == 0.0
+    # exactly on the open window edge h = -1 is outside, h = -0.5 is half of row 0
+    off = torch.zeros(1, 2, 1, 1, dtype=torch.float64)
+    x1 = torch.ones(1, 1, 3, 3, dtype=torch.float64)
+    w1 = torch.ones(1, 1, 1, 1, dtype=torch.float64)
+    off[0, 0] = -1.0
+    assert float(deform_conv2d(x1[:, :, :1, :1].expand(1, 1, 1, 1).contiguous(), off, w1)) == 0.0
+    off[0, 0] = -0.5
+    assert float(deform_conv2d(x1[:, :, :1, :1].contiguous(), off, w1)) == pytest.approx(0.5)
+
+
+def test_unit_mask_reduces_v2_to_v1_and_bias_adds():
+    x, w = rnd(2, 8, 7, 7, seed=7), rnd(4, 8, 3, 3, seed=8)
+    off = rnd(2, 2 * 18, 7, 7, seed=9) * 0.7
+    b = rnd(4, seed=10)
+    v1 = deform_conv2d(x, off, w, 1, 1, 1, 1, 2)
+    v2 = deform_conv2d(x, off, w, 1, 1, 1, 1, 2, mask=torch.ones(2, 2 * 9, 7, 7, dtype=torch.float64), bias=b)
+    torch.testing.assert_close(v2, v1 + b.view(1, -1, 1, 1), rtol=1e-12, atol=1e-12)
+
+
+def test_gradcheck_fp64():
+    x = rnd(1, 4, 5, 5, seed=11).requires_grad_(True)
+    w = rnd(2, 2, 3, 3, seed=12).requires_grad_(True)
+    # keep sample points away from integer coordinates (the bilinear kinks) so the numeric Jacobian is well defined
+    off = (torch.rand(1, 2 * 18, 5, 5, generator=torch.Generator().manual_seed(13), dtype=torch.float64) * 0.6 + 0.2).requires_grad_(True)
+    m = torch.rand(1, 2 * 9, 5, 5, generator=torch.Generator().manual_seed(14), dtype=torch.float64).requires_grad_(True)
+    fn = lambda x, off, w, m: deform_conv2d(x, off, w, 1, 1, 1, 2, 2, mask=m)
+    assert torch.autograd.gradcheck(fn, (x, off, w, m), eps=1e-6, atol=1e-5)

@@ -1,0 +1,91 @@
+"""Deformable convolution on a real MI355X: the C-ABI kernels (through rt_pose_amd.dcn) against oracle/dcn_ref.py
+(forward and all gradients), plus the reference wrapper's error behaviour.  fp32; tolerance 2e-4 norm-wise (the
+gradients w.r.t. the input use fp32 atomics, so their summation order varies run to run)."""
+import pytest
+import torch
+
+from oracle.dcn_ref import deform_conv2d
+from tests.util import rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-4
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale
+
+
+CASES = [
+    # n, c, h, w, co, k, stride, pad, dil, groups, dg, im2col_step
+    (2, 8, 9, 11, 6, 3, 1, 1, 1, 1, 1, 64),
+    (4, 16, 12, 10, 8, 3, 2, 1, 1, 2, 4, 2),
+    (2, 64, 16, 20, 64, 3, 1, 1, 1, 1, 4, 64),     # FeatureAdaption shape: 3x3, pad 1, deformable_groups=4 (center_head.py:24-62)
+    (1, 4, 7, 7, 4, 3, 1, 2, 2, 1, 2, 64),
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_dcn_v1_forward_backward(case):
+    from rt_pose_amd.dcn import deform_conv
+    n, c, h, w, co, k, stride, pad, dil, groups, dg, step = case
+    x = rnd(n, c, h, w, seed=1).requires_grad_(True)
+    wt = rnd(co, c // groups, k, k, seed=2, scale=0.2).requires_grad_(True)
+    ho = (h + 2 * pad - (dil * (k - 1) + 1)) // stride + 1
+    wo = (w + 2 * pad - (dil * (k - 1) + 1)) // stride + 1
+    off = (rnd(n, dg * 2 * k * k, ho, wo, seed=3, scale=1.5)).requires_grad_(True)
+    ref = deform_conv2d(x, off, wt, stride, pad, dil, groups, dg)
+    gy = rnd(*ref.shape, seed=4)
+    ref.backward(gy)
+    xg, wg, og = [t.detach().cuda().requires_grad_(True) for t in (x, wt, off)]
+    out = deform_conv(xg, og, wg, stride, pad, dil, groups, dg, step)
+    out.backward(gy.cuda())
+    torch.cuda.synchronize()
+    assert rel_err(out.cpu(), ref) < TOL
+    assert rel_err(xg.grad.cpu(), x.grad) < TOL
+    assert rel_err(wg.grad.cpu(), wt.grad) < TOL
+    assert rel_err(og.grad.cpu(), off.grad) < TOL
+
+
+@pytest.mark.parametrize("with_bias", [True, False])
+def test_dcn_v2_forward_backward(with_bias):
+    from rt_pose_amd.dcn import modulated_deform_conv
+    n, c, h, w, co, k, dg = 2, 16, 10, 12, 8, 3, 2
+    x = rnd(n, c, h, w, seed=5).requires_grad_(True)
+    wt = rnd(co, c, k, k, seed=6, scale=0.2).requires_grad_(True)
+    off = rnd(n, dg * 18, h, w, seed=7, scale=1.2).requires_grad_(True)
+    m = torch.sigmoid(rnd(n, dg * 9, h, w, seed=8)).requires_grad_(True)
+    b = rnd(co, seed=9).requires_grad_(True) if with_bias else None
+    ref = deform_conv2d(x, off, wt, 1, 1, 1, 1, dg, mask=m, bias=b)
+    gy = rnd(*ref.shape, seed=10)
+    ref.backward(gy)
+    ts = [t.detach().cuda().requires_grad_(True) for t in (x, off, m, wt)]
+    bg = b.detach().cuda().requires_grad_(True) if with_bias else None
+    out = modulated_deform_conv(ts[0], ts[1], ts[2], ts[3], bg, 1, 1, 1, 1, dg)
+    out.backward(gy.cuda())
+    torch.cuda.synchronize()
+    assert rel_err(out.cpu(), ref) < TOL
+    for got, want in zip(ts, (x, off, m, wt)):
+        assert rel_err(got.grad.cpu(), want.grad) < TOL
+    if with_bias:
+        assert rel_err(bg.grad.cpu(), b.grad) < TOL
+
+
+def test_zero_offset_pack_is_conv_and_error_behaviour():
+    import torch.nn.functional as F
+    from rt_pose_amd.dcn import DeformConv, DeformConvPack, deform_conv
+    torch.manual_seed(0)
+    m = DeformConvPack(8, 8, 3, padding=1, deformable_groups=4).cuda()   # conv_offset is zero-initialised
+    x = torch.randn(2, 8, 12, 12, device="cuda")
+    assert rel_err(m(x).cpu(), F.conv2d(x, m.weight, None, 1, 1).cpu()) < 1e-5
+    with pytest.raises(ValueError):
+        deform_conv(x[0], x[0], m.weight)                                 # non 4-D input
+    with pytest.raises(NotImplementedError):
+        deform_conv(x.cpu(), torch.zeros(2, 18, 12, 12), m.weight.cpu())  # CPU tensors
+    with pytest.raises(AssertionError):
+        deform_conv(torch.randn(3, 8, 12, 12, device="cuda"), torch.zeros(3, 72, 12, 12, device="cuda"), m.weight, 1, 1, 1, 1, 4, 2)
+    with pytest.raises(AssertionError):
+        DeformConv(8, 8, 3, bias=True)
+    # input smaller than the kernel is padded and cropped (deform_conv.py:230-244)
+    small = DeformConv(4, 4, 3, padding=1).cuda()
+    y = small(torch.randn(1, 4, 2, 2, device="cuda"), torch.zeros(1, 18, 2, 2, device="cuda"))
+    assert tuple(y.shape) == (1, 4, 2, 2)
