@@ -133,3 +133,18 @@ def test_standalone_backbone_and_head_forward():
     for k in ("reg", "hm"):
         assert tuple(preds[0][k].shape) == tuple(rp[0][k].shape)
         assert float((preds[0][k].float() - rp[0][k]).norm() / rp[0][k].norm()) < 4e-2
+
+
+def test_mpjpe_matches_reference_vectors(golden):
+    from rt_pose_amd.evaluate import abs_pjpe, evaluate, pjpe
+    np.testing.assert_allclose(abs_pjpe(golden["pjpe.pred"], golden["pjpe.gt"]), golden["pjpe.abs"], rtol=1e-12)
+    np.testing.assert_allclose(pjpe(golden["pjpe.pred"], golden["pjpe.gt"]), golden["pjpe.rel"], rtol=1e-12)
+    pred, gt = golden["pjpe.pred"], golden["pjpe.gt"]
+    det = {"s1/0/0": {"keypoints": [(i, *pred[i], 0.9) for i in range(15)]},
+           "s1/1/1": {"keypoints": [(i, *gt[i], 0.9) for i in range(15)]},
+           "s2/0/0": {"keypoints": [(i, *pred[i], 0.9) for i in range(15)]}}
+    g = {"s1": {"0": [{"pose": gt.tolist()}], "1": [{"pose": gt.tolist()}]}, "s2": {"0": [{"pose": gt.tolist()}]}}
+    res = evaluate(det, g)
+    m = float(np.mean(golden["pjpe.rel"])) * 1000
+    assert res["seq_results"]["s1"]["MPJPE"] == pytest.approx(m / 2) and res["seq_results"]["s2"]["MPJPE"] == pytest.approx(m)
+    assert res["results"]["MPJPE"] == pytest.approx(0.75 * m)
