@@ -125,9 +125,11 @@ int rtp_grad_combine(const RtpTerm* terms /*host*/, int nterms, const RtpAct* x,
 int rtp_fuse_sum(const RtpTerm* terms /*host*/, int nterms, const float* bias, const RtpAct* out, int n, int d, int h,
                  int w, int relu, void* stream);
 
-/* Adjoint of the trilinear upsample: glow[n][dl][hl][wl][c] = up^T(ghi). */
+/* Adjoint of the trilinear upsample: glow[n][dl][hl][wl][c] = up^T(ghi), as three separable 1-D passes;
+ * scratch fp32 [rtp_upsample_bwd_scratch_floats(...)]. */
 int rtp_upsample_bwd(const RtpAct* ghi, int d, int h, int w, const RtpAct* glow, int dl, int hl, int wl, int n,
-                     void* stream);
+                     float* scratch, void* stream);
+long rtp_upsample_bwd_scratch_floats(int n, int c, int d, int h, int w, int dl, int hl, int wl);
 
 /* layer1.conv1 when Cin == 1 (common.py:111-113): y[v][c] = x[v]*w[c] + b[c]; x fp32 [n][vox]. */
 int rtp_stem_fwd(const float* x, const float* w, const float* b, const RtpAct* y, int n, long vox, void* stream);

@@ -55,7 +55,8 @@ PROTOTYPES = {
     "rtp_gn_bwd_coeffs": [_P, _I, _P, _P, _I, _I, _I, _L, _P, _P, _P, _I, _P],
     "rtp_grad_combine": [_T, _I, _A, _A, _A, _I, _L, _P],
     "rtp_fuse_sum": [_T, _I, _P, _A, _I, _I, _I, _I, _I, _P],
-    "rtp_upsample_bwd": [_A, _I, _I, _I, _A, _I, _I, _I, _I, _P],
+    "rtp_upsample_bwd": [_A, _I, _I, _I, _A, _I, _I, _I, _I, _P, _P],
+    "rtp_upsample_bwd_scratch_floats": [_I] * 8,
     "rtp_stem_fwd": [_P, _P, _P, _A, _I, _L, _P],
     "rtp_stem_bwd": [_P, _A, _I, _L, _P, _P, _P, _I, _P],
     "rtp_stem_bwd_blocks": [],
@@ -79,7 +80,8 @@ PROTOTYPES = {
     "rtp_prof_collect": [_I, C.POINTER(_F), C.POINTER(_I)],
     "rtp_version": [],
 }
-_RESTYPE = {"rtp_version": C.c_char_p, "rtp_dcn_workspace_bytes": C.c_long}
+_RESTYPE = {"rtp_version": C.c_char_p, "rtp_dcn_workspace_bytes": C.c_long,
+            "rtp_upsample_bwd_scratch_floats": C.c_long}
 
 _lib = None
 

@@ -133,8 +133,9 @@ class HipBackend:
 
     def upsample_bwd(self, ghi, glow):
         fn = self.lib.rtp_upsample_bwd
-        args = (_act(ghi), ghi.d, ghi.h, ghi.w, _act(glow), glow.d, glow.h, glow.w, ghi.n)
-        keep = (ghi, glow)
+        scratch = self.alloc((self.lib.rtp_upsample_bwd_scratch_floats(ghi.n, ghi.c, ghi.d, ghi.h, ghi.w, glow.d, glow.h, glow.w),), "f32")
+        args = (_act(ghi), ghi.d, ghi.h, ghi.w, _act(glow), glow.d, glow.h, glow.w, ghi.n, _ptr(scratch))
+        keep = (ghi, glow, scratch)
         return lambda s: check(fn(*args, s), "rtp_upsample_bwd") or keep and None
 
     def stem_fwd(self, x, w, b, y):

@@ -41,11 +41,17 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
 
   int oz[MT], oy[MT], ox[MT];
   bool vok[MT];
+  // Data gradient of a stride-2 conv: only taps with k = (u + pad) mod 2 contribute to output position u, so a tile
+  // whose voxels share their parity needs 1-8 of the 27 taps.  Rows already share (z,y) parity; x is enumerated
+  // evens-first so that 16-voxel tiles share x parity too, and taps no lane needs are skipped wave-uniformly below.
+  const bool parity_x = p.transposed && p.stride == 2;
+  const int half_w = (p.Wo + 1) >> 1;
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     int v = vbase + mt * 16 + lv;
     vok[mt] = v < p.Vo;
     vox_decode(vok[mt] ? v : 0, p.Ho, p.Wo, oz[mt], oy[mt], ox[mt]);
+    if (parity_x) ox[mt] = (ox[mt] < half_w) ? 2 * ox[mt] : 2 * (ox[mt] - half_w) + 1;
   }
 
   f32x4 acc[MT][NT];
@@ -86,6 +92,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
       ok[mt] = v;
       xoff[mt] = (x_n + ((long)iz * p.Hi + iy) * p.Wi + ix) * p.x_cs + p.x_co + q * 8;
     }
+    {
+      bool any = false;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) any |= ok[mt];
+      if (!__any(any)) continue;  // wave-uniform: no lane of this wave has an in-range sample for this tap
+    }
     const bf16_t* wt = wbase + ((long)tap * p.Co + co_base + lv) * p.Ci + q * 8;
     for (int kc = 0; kc < kchunks; ++kc) {
       bf16x8 a[NT], b[MT];
@@ -105,7 +117,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     if (!vok[mt]) continue;
-    const long vo = (long)n * p.Vo + vbase + mt * 16 + lv;
+    const long vo = (long)n * p.Vo + ((long)oz[mt] * p.Ho + oy[mt]) * p.Wo + ox[mt];
     int cls = 0;
     if (p.btab) cls = vox_class(oz[mt], oy[mt], ox[mt], p.Do, p.Ho, p.Wo);
 #pragma unroll

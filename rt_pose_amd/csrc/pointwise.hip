@@ -180,14 +180,10 @@ extern "C" int rtp_fuse_sum(const RtpTerm* terms, int nterms, const float* bias,
 }
 
 // ------------------------------------------------------------------------------------------------
-// rtp_upsample_bwd : one wave per low-res voxel gathers its whole support
+// rtp_upsample_bwd : the trilinear operator is separable, so its adjoint is three 1-D gathers (x, then y, then z).
+// Each pass reads its input once (16 B per lane, neighbours hit L1) instead of the 3-D gather's (2/scale+1)^3-fold
+// re-read of the full-resolution gradient; intermediates stay fp32, only the final result is rounded to bf16.
 // ------------------------------------------------------------------------------------------------
-#define UPB_MAXS 256
-struct UpbParams {
-  const bf16_t* g; int g_cs, g_co; bf16_t* out; int o_cs, o_co;
-  int c, n, d, h, w, dl, hl, wl;
-};
-
 // weight of high-res position o on low-res index il along one dim
 __device__ __forceinline__ float adj_w(int o, int il, int I, int O) {
   int i0, i1; float l0, l1;
@@ -205,68 +201,59 @@ __device__ __forceinline__ void support(int il, int I, int O, int& lo, int& hi) 
   if (hi > O - 1) hi = O - 1;
 }
 
-__global__ __launch_bounds__(64) void upsample_bwd_kernel(UpbParams p) {
-  __shared__ float wz[UPB_MAXS], wy[UPB_MAXS], wx[UPB_MAXS];
-  __shared__ float red[64 * 65];
-  const int lane = threadIdx.x;
-  const long lvox = (long)p.dl * p.hl * p.wl;
-  const int n = blockIdx.x / lvox;
-  const int lv = blockIdx.x - n * lvox;
-  int zl, yl, xl;
-  vox_decode(lv, p.hl, p.wl, zl, yl, xl);
-  int z_lo, z_hi, y_lo, y_hi, x_lo, x_hi;
-  support(zl, p.dl, p.d, z_lo, z_hi);
-  support(yl, p.hl, p.h, y_lo, y_hi);
-  support(xl, p.wl, p.w, x_lo, x_hi);
-  const int nz = z_hi - z_lo + 1, ny = y_hi - y_lo + 1, nx = x_hi - x_lo + 1;
-  for (int i = lane; i < nz; i += 64) wz[i] = adj_w(z_lo + i, zl, p.dl, p.d);
-  for (int i = lane; i < ny; i += 64) wy[i] = adj_w(y_lo + i, yl, p.hl, p.h);
-  for (int i = lane; i < nx; i += 64) wx[i] = adj_w(x_lo + i, xl, p.wl, p.w);
-  __syncthreads();
-  const long hbase = (long)n * p.d * p.h * p.w;
-  const int tot = nz * ny * nx;
-  for (int cb = 0; cb < p.c; cb += 64) {
-    const int cw = (p.c - cb < 64) ? p.c - cb : 64;  // channels in this block (multiple of 8)
-    float acc[64];
+// out[outer][il][inner][c] = sum_o w(o -> il) * in[outer][o][inner][c]   (channels-last, 8 channels per lane)
+template <typename TIN, typename TOUT>
+__global__ __launch_bounds__(256) void adjoint_axis_kernel(const TIN* in, int in_cs, int in_co, TOUT* out, int out_cs,
+                                                           int out_co, int c, long outer, int I, int O, long inner) {
+  const int cpv = c >> 3;
+  const long total = outer * I * inner * cpv;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int ck = (int)(i % cpv);
+    long r = i / cpv;
+    const long in_i = r % inner; r /= inner;
+    const int il = (int)(r % I);
+    const long ou = r / I;
+    int lo, hi;
+    support(il, I, O, lo, hi);
+    float acc[8];
 #pragma unroll
-    for (int j = 0; j < 64; ++j) acc[j] = 0.f;
-    for (int s = lane; s < tot; s += 64) {
-      const int ix = s % nx, iy = (s / nx) % ny, iz = s / (nx * ny);
-      const float wgt = wz[iz] * wy[iy] * wx[ix];
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    for (int o = lo; o <= hi; ++o) {
+      const float wgt = adj_w(o, il, I, O);
       if (wgt == 0.f) continue;
-      const long hv = hbase + ((long)(z_lo + iz) * p.h + (y_lo + iy)) * p.w + (x_lo + ix);
-      const bf16_t* src = p.g + hv * p.g_cs + p.g_co + cb;
+      const TIN* src = in + ((ou * O + o) * inner + in_i) * in_cs + in_co + ck * 8;
 #pragma unroll
-      for (int ck = 0; ck < 8; ++ck) {
-        if (ck * 8 < cw) {
-          bf16x8 tv = ld_bf16x8(src + ck * 8);
-#pragma unroll
-          for (int j = 0; j < 8; ++j) acc[ck * 8 + j] += wgt * bf2f(tv[j]);
-        }
-      }
+      for (int j = 0; j < 8; ++j) acc[j] += wgt * (float)src[j];
     }
-    __syncthreads();
+    TOUT* dst = out + ((ou * I + il) * inner + in_i) * out_cs + out_co + ck * 8;
 #pragma unroll
-    for (int j = 0; j < 64; ++j) red[lane * 65 + j] = acc[j];
-    __syncthreads();
-    if (lane < cw) {
-      float sum = 0.f;
-      for (int l = 0; l < 64; ++l) sum += red[l * 65 + lane];
-      p.out[((long)n * lvox + lv) * p.o_cs + p.o_co + cb + lane] = f2bf(sum);
-    }
+    for (int j = 0; j < 8; ++j) dst[j] = (TOUT)acc[j];
   }
 }
 
+extern "C" long rtp_upsample_bwd_scratch_floats(int n, int c, int d, int h, int w, int dl, int hl, int wl) {
+  (void)w; (void)dl;
+  return (long)n * c * ((long)d * h * wl + (long)d * hl * wl);
+}
+
 extern "C" int rtp_upsample_bwd(const RtpAct* ghi, int d, int h, int w, const RtpAct* glow, int dl, int hl, int wl,
-                                int n, void* stream) {
-  if (!ghi || !glow) return RTP_ERR_SHAPE;
-  if (ghi->c != glow->c || ghi->c % 8 || (ghi->cs % 8) || (ghi->co % 8)) return RTP_ERR_ALIGN;
-  if (d > UPB_MAXS || h > UPB_MAXS || w > UPB_MAXS) return RTP_ERR_UNSUPPORTED;
-  UpbParams p{(const bf16_t*)ghi->ptr, ghi->cs, ghi->co, (bf16_t*)glow->ptr, glow->cs, glow->co,
-              ghi->c, n, d, h, w, dl, hl, wl};
+                                int n, float* scratch, void* stream) {
+  if (!ghi || !glow || !scratch) return RTP_ERR_SHAPE;
+  if (ghi->c != glow->c || ghi->c % 8 || (ghi->cs % 8) || (ghi->co % 8) || (glow->cs % 8) || (glow->co % 8)) return RTP_ERR_ALIGN;
+  const int c = ghi->c;
+  float* t1 = scratch;                               // [n][d][h][wl][c]
+  float* t2 = scratch + (long)n * d * h * wl * c;    // [n][d][hl][wl][c]
   hipStream_t s = (hipStream_t)stream;
   RtpProfScope prof(RTP_FAM_POINTWISE, s);
-  hipLaunchKernelGGL(upsample_bwd_kernel, dim3(n * dl * hl * wl), dim3(64), 0, s, p);
+  // x: outer = n*d*h rows, inner = 1
+  hipLaunchKernelGGL((adjoint_axis_kernel<bf16_t, float>), dim3(grid_for((long)n * d * h * wl * (c / 8))), dim3(256), 0, s,
+                     (const bf16_t*)ghi->ptr, ghi->cs, ghi->co, t1, c, 0, c, (long)n * d * h, wl, w, 1L);
+  // y: outer = n*d, inner = wl
+  hipLaunchKernelGGL((adjoint_axis_kernel<float, float>), dim3(grid_for((long)n * d * hl * wl * (c / 8))), dim3(256), 0, s,
+                     (const float*)t1, c, 0, t2, c, 0, c, (long)n * d, hl, h, (long)wl);
+  // z: outer = n, inner = hl*wl
+  hipLaunchKernelGGL((adjoint_axis_kernel<float, bf16_t>), dim3(grid_for((long)n * dl * hl * wl * (c / 8))), dim3(256), 0, s,
+                     (const float*)t2, c, 0, (bf16_t*)glow->ptr, glow->cs, glow->co, c, (long)n, dl, d, (long)hl * wl);
   RTP_CHECK_LAUNCH();
   return RTP_OK;
 }
