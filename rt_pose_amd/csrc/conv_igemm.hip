@@ -59,6 +59,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // MFMA row (nt, 4q+r) <- output channel 8q + 4nt + r (NT == 2): the lane's two accumulator tiles then hold 8
+  // contiguous channels = one 16-B chunk, so a store instruction covers whole 64-B voxel lines
+  int arow[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) arow[nt] = (NT == 2) ? 8 * (lv >> 2) + 4 * nt + (lv & 3) : nt * 16 + lv;
 
   const bf16_t* wbase = p.w + (long)n * p.w_sample_stride;
   const long x_n = (long)n * p.Di * p.Hi * p.Wi;
@@ -98,11 +103,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
       for (int mt = 0; mt < MT; ++mt) any |= ok[mt];
       if (!__any(any)) continue;  // wave-uniform: no lane of this wave has an in-range sample for this tap
     }
-    const bf16_t* wt = wbase + ((long)tap * p.Co + co_base + lv) * p.Ci + q * 8;
+    const bf16_t* wt = wbase + ((long)tap * p.Co + co_base) * p.Ci + q * 8;
     for (int kc = 0; kc < kchunks; ++kc) {
       bf16x8 a[NT], b[MT];
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) a[nt] = ld_bf16x8(wt + (long)nt * 16 * p.Ci + kc * 32);
+      for (int nt = 0; nt < NT; ++nt) a[nt] = ld_bf16x8(wt + (long)arow[nt] * p.Ci + kc * 32);
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) b[mt] = ok[mt] ? ld_bf16x8(p.x + xoff[mt] + kc * 32) : zero_bf16x8();
 #pragma unroll
@@ -120,30 +125,51 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
     const long vo = (long)n * p.Vo + ((long)oz[mt] * p.Ho + oy[mt]) * p.Wo + ox[mt];
     int cls = 0;
     if (p.btab) cls = vox_class(oz[mt], oy[mt], ox[mt], p.Do, p.Ho, p.Wo);
+    constexpr int CH = 4 * NT;
+    const int c0 = co_base + q * CH;
+    float val[CH];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const int c0 = co_base + nt * 16 + q * 4;
-      f32x4 v = acc[mt][nt];
-      if (p.btab) {
-        const f32x4 bb = *reinterpret_cast<const f32x4*>(p.btab + ((long)(p.w_sample_stride ? n : 0) * 64 + cls) * p.Co + c0);
-        v += bb;
-      }
-      if (p.res) {
-        const bf16x4 r = *reinterpret_cast<const bf16x4*>(p.res + vo * p.r_cs + p.r_co + c0);
+    for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] += bf2f(r[j]);
-      }
-      if (p.relu) {
+      for (int j = 0; j < 4; ++j) val[nt * 4 + j] = acc[mt][nt][j];
+    if (p.btab) {
+      const float* bp = p.btab + ((long)(p.w_sample_stride ? n : 0) * 64 + cls) * p.Co + c0;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : 0.f;
+      for (int k = 0; k < CH; k += 4) {
+        const f32x4 bb = *reinterpret_cast<const f32x4*>(bp + k);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) val[k + j] += bb[j];
       }
-      if (p.y_fp32) {
-        *reinterpret_cast<f32x4*>((float*)p.y + vo * p.y_cs + p.y_co + c0) = v;
+    }
+    if (p.res) {
+      const bf16_t* rp = p.res + vo * p.r_cs + p.r_co + c0;
+#pragma unroll
+      for (int k = 0; k < CH; k += 4) {
+        const bf16x4 r = *reinterpret_cast<const bf16x4*>(rp + k);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) val[k + j] += bf2f(r[j]);
+      }
+    }
+    if (p.relu) {
+#pragma unroll
+      for (int j = 0; j < CH; ++j) val[j] = val[j] > 0.f ? val[j] : 0.f;
+    }
+    if (p.y_fp32) {
+      float* yp = (float*)p.y + vo * p.y_cs + p.y_co + c0;
+#pragma unroll
+      for (int k = 0; k < CH; k += 4) *reinterpret_cast<f32x4*>(yp + k) = f32x4{val[k], val[k + 1], val[k + 2], val[k + 3]};
+    } else {
+      bf16_t* yp = (bf16_t*)p.y + vo * p.y_cs + p.y_co + c0;
+      if constexpr (NT == 2) {
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = f2bf(val[j]);
+        st_bf16x8(yp, o);
       } else {
         bf16x4 o;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = f2bf(v[j]);
-        *reinterpret_cast<bf16x4*>((bf16_t*)p.y + vo * p.y_cs + p.y_co + c0) = o;
+        for (int j = 0; j < 4; ++j) o[j] = f2bf(val[j]);
+        *reinterpret_cast<bf16x4*>(yp) = o;
       }
     }
   }
@@ -158,7 +184,7 @@ extern "C" int rtp_conv_igemm(const RtpAct* x, const void* wf, int w_per_sample,
   if (!x || !y || !wf || !g) return RTP_ERR_SHAPE;
   if (g->ks != 1 && g->ks != 3) return RTP_ERR_UNSUPPORTED;
   if (g->stride != 1 && g->stride != 2) return RTP_ERR_UNSUPPORTED;
-  if ((x->co % 8) || (x->cs % 8) || (y->co % 4) || (y->cs % 4)) return RTP_ERR_ALIGN;
+  if ((x->co % 8) || (x->cs % 8) || (y->co % 8) || (y->cs % 8)) return RTP_ERR_ALIGN;
   if (res && ((res->co % 4) || (res->cs % 4))) return RTP_ERR_ALIGN;
   {
     const int rc = rtp_conv_tiled_try(x, wf, w_per_sample, btab, res, y, g, relu, transposed, y_fp32, (hipStream_t)stream);

@@ -35,17 +35,39 @@ struct TiledParams {
   int y_cs, y_co, r_cs, r_co;
   int relu, y_fp32, flip, w_per_sample;
   int tiles_y, tiles_x, tiles_per_sample, teams_per_sample;
+  int dbg;  // timing experiments only (RTP_TILED_DBG): bit0 = skip the MFMA loop, bit1 = skip staging, bit2 = skip epilogue
 };
 
 __device__ __forceinline__ int swz(int chunk, int xi) { return ((chunk + 2 * (xi >> 2)) & 3) << 3; }  // bf16 elements
 
+// Issue-order plan (sched_group_barrier needs literal arguments, hence the recursion): per (dz,dx) tap group a wave issues
+// R = 3*NT + HY ds_read_b128 (weights for 3 dy taps + HY haloed rows) and M = 12*NT MFMAs.  Group g+1's reads are
+// interleaved one by one under group g's MFMAs; the last group's MFMAs run bare.
 template <int NT>
+__device__ __forceinline__ void cv_sched_prologue() { __builtin_amdgcn_sched_group_barrier(0x100, 3 * NT + HY, 0); }
+
+template <int NT, int IDX>  // IDX enumerates (group 0..7) x (read slot 0..R-1)
+__device__ __forceinline__ void cv_sched() {
+  constexpr int R = 3 * NT + HY, M = 12 * NT;
+  if constexpr (IDX < 8 * R) {
+    constexpr int r = IDX % R;
+    __builtin_amdgcn_sched_group_barrier(0x008, (r < M % R) ? M / R + 1 : M / R, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    cv_sched<NT, IDX + 1>();
+  } else {
+    __builtin_amdgcn_sched_group_barrier(0x008, M, 0);
+  }
+}
+
+template <int NT, bool HAS_BTAB, bool HAS_RES>
 __global__ __launch_bounds__(512, 2) void conv_tiled_kernel(TiledParams p) {
   extern __shared__ __attribute__((aligned(16))) bf16_t lds[];
   bf16_t* wL = lds;                                   // [27][NT*16][32]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int team = wave >> 2, tw = wave & 3, ttid = tid & 255;
   bf16_t* xL = lds + 27 * NT * 16 * 32 + team * (HALO_VOX * 32);  // this team's [HZ][HY][HX][32]
+  // class-bias table in LDS: 27 reachable classes (per axis: interior / first / last; every axis is >= 2 long here)
+  float* bL = reinterpret_cast<float*>(lds + 27 * NT * 16 * 32 + 2 * (HALO_VOX * 32));  // [27][Co]
   const int wgs_per_sample = p.teams_per_sample >> 1;
   const int n = blockIdx.x / wgs_per_sample;
   const int team_id = (blockIdx.x - n * wgs_per_sample) * 2 + team;  // team index within the sample
@@ -70,13 +92,37 @@ __global__ __launch_bounds__(512, 2) void conv_tiled_kernel(TiledParams p) {
           const int ck = i & 3, row = i >> 2;
           const int tap = row / p.Co, co = row - tap * p.Co;
           const int dtap = p.flip ? 26 - tap : tap;
-          st_bf16x8(wL + (dtap * p.Co + co) * 32 + swz(ck, co), val[k]);
+          // MFMA row (nt, 4q+r) <- output channel 8q + 4nt + r: lane (voxel, q) then owns channels 8q..8q+7, one 16-B
+          // chunk, and a wave's store instruction covers 16 voxels x 64 B = 1 KB of contiguous output
+          const int arow = (NT == 2) ? ((co >> 2) & 1) * 16 + (co >> 3) * 4 + (co & 3) : co;
+          st_bf16x8(wL + (dtap * p.Co + arow) * 32 + swz(ck, arow), val[k]);
         }
       }
     }
   }
 
+  if (HAS_BTAB) {
+    for (int i = tid; i < 27 * p.Co; i += 512) {
+      const int co = i % p.Co, k = i / p.Co;
+      const int cz = k / 9, cy = (k / 3) % 3, cx = k % 3;  // 0 interior, 1 first, 2 last
+      const int cls = (cz == 1) | ((cz == 2) << 1) | ((cy == 1) << 2) | ((cy == 2) << 3) | ((cx == 1) << 4) | ((cx == 2) << 5);
+      bL[i] = p.btab[((long)(p.w_per_sample ? n : 0) * 64 + cls) * p.Co + co];
+    }
+  }
   const long vox_n = (long)n * p.D * p.H * p.W;
+  // Staging descriptors (brick-independent, computed once): element offset of each of this thread's 13 sixteen-byte
+  // items relative to the brick origin, its swizzled LDS slot, and six "on the low/high face of the halo" bits.
+  int s_rel[STAGE_BATCH], s_dst[STAGE_BATCH], s_flg[STAGE_BATCH];
+#pragma unroll
+  for (int k = 0; k < STAGE_BATCH; ++k) {
+    const int i = ttid + k * 256;
+    const int ck = i & 3, hv = i >> 2;
+    const int hx = hv % HX, hy = (hv / HX) % HY, hz = hv / (HX * HY);
+    s_dst[k] = (i < HALO_ITEMS) ? hv * 32 + swz(ck, hx) : -1;
+    s_rel[k] = (((hz - 1) * p.H + (hy - 1)) * p.W + (hx - 1)) * 32 + ck * 8;
+    s_flg[k] = (hz == 0) | ((hz == HZ - 1) << 1) | ((hy == 0) << 2) | ((hy == HY - 1) << 3) | ((hx == 0) << 4) | ((hx == HX - 1) << 5);
+  }
+  const bf16_t* xn = p.x + vox_n * 32;
   const int my_tiles = (p.tiles_per_sample - team_id + p.teams_per_sample - 1) / p.teams_per_sample;
   int max_tiles = (p.tiles_per_sample + p.teams_per_sample - 1) / p.teams_per_sample;  // workgroup-uniform
   const int nphase = 2 * max_tiles + 1;
@@ -85,29 +131,22 @@ __global__ __launch_bounds__(512, 2) void conv_tiled_kernel(TiledParams p) {
   for (int phase = 0; phase < nphase; ++phase) {
     const bool loading = ((phase + team) & 1) == 0;  // team-uniform (=> wave-uniform)
     if (loading) {
-      if (load_k < my_tiles) {
+      if (load_k < my_tiles && !(p.dbg & 2)) {
         const int tile = team_id + load_k * p.teams_per_sample;
         const int tx = tile % p.tiles_x, ty = (tile / p.tiles_x) % p.tiles_y, tz = tile / (p.tiles_x * p.tiles_y);
-        const int z0 = tz * TZ - 1, y0 = ty * TY - 1, x0 = tx * TX - 1;
+        const int z0 = tz * TZ, y0 = ty * TY, x0 = tx * TX;
+        const int org = ((z0 * p.H + y0) * p.W + x0) * 32;
+        const int tflg = (z0 == 0) | ((z0 + TZ == p.D) << 1) | ((y0 == 0) << 2) | ((y0 + TY == p.H) << 3) |
+                         ((x0 == 0) << 4) | ((x0 + TX == p.W) << 5);
+        bf16x8 val[STAGE_BATCH];
 #pragma unroll
-        for (int r = 0; r < STAGE_ROUNDS; ++r) {
-          bf16x8 val[STAGE_BATCH];
-          int dst[STAGE_BATCH];
-#pragma unroll
-          for (int k = 0; k < STAGE_BATCH; ++k) {
-            const int i = ttid + (r * STAGE_BATCH + k) * 256;
-            const int ck = i & 3, hv = i >> 2;
-            const int hx = hv % HX, hy = (hv / HX) % HY, hz = hv / (HX * HY);
-            const int gz = z0 + hz, gy = y0 + hy, gx = x0 + hx;
-            dst[k] = (i < HALO_ITEMS) ? hv * 32 + swz(ck, hx) : -1;
-            val[k] = zero_bf16x8();
-            if (i < HALO_ITEMS && (unsigned)gz < (unsigned)p.D && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W)
-              val[k] = ld_bf16x8(p.x + (vox_n + ((long)gz * p.H + gy) * p.W + gx) * 32 + ck * 8);
-          }
-#pragma unroll
-          for (int k = 0; k < STAGE_BATCH; ++k)
-            if (dst[k] >= 0) st_bf16x8(xL + dst[k], val[k]);
+        for (int k = 0; k < STAGE_BATCH; ++k) {
+          val[k] = zero_bf16x8();
+          if (s_dst[k] >= 0 && !(s_flg[k] & tflg)) val[k] = ld_bf16x8(xn + org + s_rel[k]);
         }
+#pragma unroll
+        for (int k = 0; k < STAGE_BATCH; ++k)
+          if (s_dst[k] >= 0) st_bf16x8(xL + s_dst[k], val[k]);
       }
       ++load_k;
     } else if (comp_k < load_k && comp_k < my_tiles) {
@@ -122,63 +161,124 @@ __global__ __launch_bounds__(512, 2) void conv_tiled_kernel(TiledParams p) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[t][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+      // The residual is fetched NOW, under the MFMA loop: loaded after it, its HBM latency sat on the critical path of
+      // every brick (measured: epilogue 78 us of a 132 us launch).  The class bias comes from the LDS table.
+      constexpr int CH = 4 * NT;  // channels this lane owns: [c0, c0 + CH)
+      const int c0 = q * CH;
+      const int oz = z0 + wz, ox = x0 + wx * 16 + v;
+      const int kzx = ((oz == 0) ? 1 : (oz == p.D - 1) ? 2 : 0) * 9 + ((ox == 0) ? 1 : (ox == p.W - 1) ? 2 : 0);
+      bf16x8 pre_r8[TY];
+      bf16x4 pre_r4[TY];
 #pragma unroll
-      for (int dzx = 0; dzx < 9; ++dzx) {  // fully unrolled: lets the scheduler prefetch the next (dz,dx) fragments under the MFMAs
-        const int dz = dzx / 3, dx = dzx - dz * 3;
-        bf16x8 a[3][NT];
+      for (int t = 0; t < TY; ++t) {
+        const long vo = vox_n + ((long)oz * p.H + (y0 + t)) * p.W + ox;
+        pre_r8[t] = zero_bf16x8();
+        pre_r4[t] = bf16x4{(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+        if constexpr (HAS_RES) {  // compile-time: a runtime select per load makes hipcc branch around each one and wait vmcnt(0) early
+          const bf16_t* rp = p.res + vo * p.r_cs + p.r_co + c0;
+          if constexpr (NT == 2) pre_r8[t] = ld_bf16x8(rp);
+          else pre_r4[t] = *reinterpret_cast<const bf16x4*>(rp);
+        }
+      }
+      if (!(p.dbg & 1)) {
+        // Software pipeline over 54 steps = 9 (dz,dx) tap groups x HY haloed rows.  Step s reads its row fragment three
+        // steps early into a 4-deep register ring, and a group's 3*NT weight fragments are read during the previous
+        // group (double-buffered); sched_barrier fences pin that order (left alone, hipcc issues each ds_read right
+        // before its first use and waits lgkmcnt(0) on it, exposing the LDS latency to the single MFMA wave per SIMD).
+        constexpr int DIST = 3, NSTEP = 9 * HY, CO = NT * 16;
+        bf16x8 fa[2][3][NT], fb[4];
+        // Four per-lane LDS byte addresses serve all 54 + 54 fragment reads; everything else is a compile-time
+        // immediate (weights: tap and cout tile; rows: dz and haloed row) -- address registers were the spill source.
+        typedef const __attribute__((address_space(3))) bf16x8* lds_frag;
+        const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) bf16_t*)lds;
+        const unsigned a_base = lds0 + 2u * (v * 32 + swz(q, v));  // swz(q, nt*16+v) == swz(q, v): 8*nt == 0 mod 4
+        unsigned b_base[3];
 #pragma unroll
-        for (int dy = 0; dy < 3; ++dy)
+        for (int dx = 0; dx < 3; ++dx) {
+          const int hx = wx * 16 + v + dx;
+          b_base[dx] = lds0 + 2u * (unsigned)((xL - lds) + (wz * HY * HX + hx) * 32 + swz(q, hx));
+        }
+        auto row_frag = [&](int s) {
+          const int g = s / HY, ry = s - g * HY, dz = g / 3, dx = g - dz * 3;
+          return *(lds_frag)(b_base[dx] + 2u * ((dz * HY + ry) * HX * 32));
+        };
+        auto load_a = [&](int g, bf16x8 (&a)[3][NT]) {
+          const int dz = g / 3, dx = g - dz * 3;
 #pragma unroll
-          for (int nt = 0; nt < NT; ++nt) {
-            const int co = nt * 16 + v;
-            a[dy][nt] = ld_bf16x8(wL + (((dz * 3 + dy) * 3 + dx) * p.Co + co) * 32 + swz(q, co));
-          }
-        const int hx = wx * 16 + v + dx;
-        const bf16_t* xrow = xL + ((wz + dz) * HY * HX + hx) * 32 + swz(q, hx);
+          for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-        for (int ry = 0; ry < HY; ++ry) {
-          const bf16x8 b = ld_bf16x8(xrow + ry * HX * 32);
+            for (int nt = 0; nt < NT; ++nt)
+              a[dy][nt] = *(lds_frag)(a_base + 2u * ((((dz * 3 + dy) * 3 + dx) * CO + nt * 16) * 32));
+        };
+        load_a(0, fa[0]);
+#pragma unroll
+        for (int s = 0; s < DIST; ++s) fb[s & 3] = row_frag(s);
+#pragma unroll
+        for (int s = 0; s < NSTEP; ++s) {
+          const int g = s / HY, ry = s - g * HY;
+          if (s + DIST < NSTEP) fb[(s + DIST) & 3] = row_frag(s + DIST);
+          if (ry == 0 && g + 1 < 9) load_a(g + 1, fa[(g + 1) & 1]);
+          __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int dy = 0; dy < 3; ++dy) {
             const int t = ry - dy;
             if (t >= 0 && t < TY) {
 #pragma unroll
               for (int nt = 0; nt < NT; ++nt)
-                acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[dy][nt], b, acc[t][nt], 0, 0, 0);
+                acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[g & 1][dy][nt], fb[s & 3], acc[t][nt], 0, 0, 0);
             }
           }
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
+      if (p.dbg & 4) { __syncthreads(); continue; }
 
-      // ---- epilogue
-      const int oz = z0 + wz, ox = x0 + wx * 16 + v;
-      const int czx = (oz == 0) | ((oz == p.D - 1) << 1) | ((ox == 0) << 4) | ((ox == p.W - 1) << 5);
+      // ---- epilogue: bias + residual + ReLU in fp32, one rounding, one 16-B store per lane and row
 #pragma unroll
       for (int t = 0; t < TY; ++t) {
         const int oy = y0 + t;
         const long vo = vox_n + ((long)oz * p.H + oy) * p.W + ox;
-        const int cls = czx | ((oy == 0) << 2) | ((oy == p.H - 1) << 3);
+        float val[CH];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-          const int c0 = nt * 16 + q * 4;
-          f32x4 val = acc[t][nt];
-          if (p.btab) val += *reinterpret_cast<const f32x4*>(p.btab + ((long)(p.w_per_sample ? n : 0) * 64 + cls) * p.Co + c0);
-          if (p.res) {
-            const bf16x4 r = *reinterpret_cast<const bf16x4*>(p.res + vo * p.r_cs + p.r_co + c0);
+        for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) val[j] += bf2f(r[j]);
+          for (int j = 0; j < 4; ++j) val[nt * 4 + j] = acc[t][nt][j];
+        if constexpr (HAS_BTAB) {
+          const float* bp = bL + (kzx + ((oy == 0) ? 3 : (oy == p.H - 1) ? 6 : 0)) * p.Co + c0;
+#pragma unroll
+          for (int k = 0; k < CH; k += 4) {
+            const f32x4 bb = *reinterpret_cast<const f32x4*>(bp + k);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) val[k + j] += bb[j];
           }
-          if (p.relu) {
+        }
+        if constexpr (NT == 2) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) val[j] = val[j] > 0.f ? val[j] : 0.f;
-          }
-          if (p.y_fp32) {
-            *reinterpret_cast<f32x4*>((float*)p.y + vo * p.y_cs + p.y_co + c0) = val;
+          for (int j = 0; j < 8; ++j) val[j] += bf2f(pre_r8[t][j]);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) val[j] += bf2f(pre_r4[t][j]);
+        }
+        if (p.relu) {
+#pragma unroll
+          for (int j = 0; j < CH; ++j) val[j] = val[j] > 0.f ? val[j] : 0.f;
+        }
+        if (p.y_fp32) {
+          float* yp = (float*)p.y + vo * p.y_cs + p.y_co + c0;
+#pragma unroll
+          for (int k = 0; k < CH; k += 4) *reinterpret_cast<f32x4*>(yp + k) = f32x4{val[k], val[k + 1], val[k + 2], val[k + 3]};
+        } else {
+          bf16_t* yp = (bf16_t*)p.y + vo * p.y_cs + p.y_co + c0;
+          if constexpr (NT == 2) {
+            bf16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = f2bf(val[j]);
+            st_bf16x8(yp, o);
           } else {
             bf16x4 o;
 #pragma unroll
             for (int j = 0; j < 4; ++j) o[j] = f2bf(val[j]);
-            *reinterpret_cast<bf16x4*>((bf16_t*)p.y + vo * p.y_cs + p.y_co + c0) = o;
+            *reinterpret_cast<bf16x4*>(yp) = o;
           }
         }
       }
@@ -197,7 +297,7 @@ int rtp_conv_tiled_try(const RtpAct* x, const void* wf, int w_per_sample, const 
   const int Ci = transposed ? (g->co + 31) / 32 * 32 : g->ci;
   const int Co = transposed ? g->ci : g->co;
   if (Ci != 32 || (Co != 16 && Co != 32)) return 1;
-  if (g->di % TZ || g->hi % TY || g->wi % TX) return 1;
+  if (g->di % TZ || g->hi % TY || g->wi % TX || g->di < 2 || g->hi < 2) return 1;
   if (x->cs != 32 || x->co != 0) return 1;
   TiledParams p;
   p.x = (const bf16_t*)x->ptr; p.w = (const bf16_t*)wf; p.btab = btab;
@@ -211,18 +311,27 @@ int rtp_conv_tiled_try(const RtpAct* x, const void* wf, int w_per_sample, const 
   if (wgs < 1) wgs = 1;
   if (wgs * 2 > p.tiles_per_sample) wgs = (p.tiles_per_sample + 1) / 2;
   p.teams_per_sample = wgs * 2;
+  static const int dbg = getenv("RTP_TILED_DBG") ? atoi(getenv("RTP_TILED_DBG")) : 0;
+  p.dbg = dbg;
   const int nt = Co / 16;
-  const size_t shm = sizeof(bf16_t) * (27 * (size_t)Co * 32 + 2 * (size_t)HALO_VOX * 32);
+  const size_t shm = sizeof(bf16_t) * (27 * (size_t)Co * 32 + 2 * (size_t)HALO_VOX * 32) + 27 * (size_t)Co * sizeof(float);
   RtpProfScope prof(RTP_FAM_CONV_TILED, s);
-  if (nt == 2) {
-    static bool attr2 = false;
-    if (!attr2) { (void)hipFuncSetAttribute((const void*)conv_tiled_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); attr2 = true; }
-    hipLaunchKernelGGL(conv_tiled_kernel<2>, dim3(p.N * wgs), dim3(512), shm, s, p);
-  } else {
-    static bool attr1 = false;
-    if (!attr1) { (void)hipFuncSetAttribute((const void*)conv_tiled_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); attr1 = true; }
-    hipLaunchKernelGGL(conv_tiled_kernel<1>, dim3(p.N * wgs), dim3(512), shm, s, p);
+  using Kern = void (*)(TiledParams);
+  static const Kern table[2][2][2] = {
+      {{conv_tiled_kernel<1, false, false>, conv_tiled_kernel<1, false, true>},
+       {conv_tiled_kernel<1, true, false>, conv_tiled_kernel<1, true, true>}},
+      {{conv_tiled_kernel<2, false, false>, conv_tiled_kernel<2, false, true>},
+       {conv_tiled_kernel<2, true, false>, conv_tiled_kernel<2, true, true>}}};
+  static bool attr_done = false;
+  if (!attr_done) {
+    const int big = (int)(sizeof(bf16_t) * (27 * (size_t)32 * 32 + 2 * (size_t)HALO_VOX * 32) + 27 * 32 * sizeof(float));
+    for (int a = 0; a < 2; ++a)
+      for (int b = 0; b < 2; ++b)
+        for (int c = 0; c < 2; ++c)
+          (void)hipFuncSetAttribute((const void*)table[a][b][c], hipFuncAttributeMaxDynamicSharedMemorySize, big);
+    attr_done = true;
   }
+  hipLaunchKernelGGL(table[nt - 1][btab ? 1 : 0][res ? 1 : 0], dim3(p.N * wgs), dim3(512), shm, s, p);
   RTP_CHECK_LAUNCH();
   return RTP_OK;
 }

@@ -28,6 +28,7 @@ struct WgTiledParams {
   const bf16_t* gy; const bf16_t* x; float* gp;
   int N, D, H, W, g_cs, g_co;
   int tiles_y, tiles_x, tiles_per_sample, wgs_per_sample;
+  int dbg;  // timing experiments only (RTP_TILED_DBG): bit0 = consumers skip the MFMA work, bit1 = producers skip the DMA
 };
 
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
@@ -48,67 +49,53 @@ __device__ __forceinline__ bf16x8 tr_pair(unsigned lo, unsigned hi) {
   return __builtin_bit_cast(bf16x8, r);
 }
 
-struct LaneAddr {          // 32-bit LDS byte addresses
-  unsigned x[3][2][2];     // [dx][ci sub-tile][lo/hi]  into the haloed x brick
-  unsigned g[2][2];        // [co sub-tile][lo/hi]      into the gy brick
+struct LaneAddr {          // 32-bit LDS byte addresses, already including this wave's tap shifts
+  unsigned x[7][2][2];     // [tap slot][ci sub-tile][lo/hi]  into the haloed x brick (row offset (dz,dy) and dx folded in)
+  unsigned g[2][2];        // [co sub-tile][lo/hi]            into the gy brick
 };
 
-template <int TW, int R, int T>
+// One stage = one tap of one x-row: 4 transposing reads then 4 MFMAs.  The tap (wave-dependent) lives in the address
+// registers, the row (compile-time) in the immediate offset, so all four waves run the SAME straight-line code.
+template <int R, int T>
 __device__ __forceinline__ void wg_tap(const LaneAddr& la, const bf16x8& a0, const bf16x8& a1, f32x4 (&acc)[7][2][2]) {
-  constexpr int tap = TW + 4 * T;
-  if constexpr (tap < 27) {
-    constexpr int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
-    constexpr int rz = R / TY, ry = R % TY;
-    constexpr int off = ((rz + dz) * HY + (ry + dy)) * HX * 64;  // bytes (< 64 KB): folds into the ds_read immediate
-    const bf16x8 b0 = tr_pair<off>(la.x[dx][0][0], la.x[dx][0][1]);
-    const bf16x8 b1 = tr_pair<off>(la.x[dx][1][0], la.x[dx][1][1]);
-    acc[T][0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b0, acc[T][0][0], 0, 0, 0);
-    acc[T][0][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b1, acc[T][0][1], 0, 0, 0);
-    acc[T][1][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b0, acc[T][1][0], 0, 0, 0);
-    acc[T][1][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1, acc[T][1][1], 0, 0, 0);
-  }
+  constexpr int rz = R / TY, ry = R % TY;
+  constexpr int off = (rz * HY + ry) * HX * 64;  // bytes (< 64 KB): folds into the ds_read immediate
+  const bf16x8 b0 = tr_pair<off>(la.x[T][0][0], la.x[T][0][1]);
+  const bf16x8 b1 = tr_pair<off>(la.x[T][1][0], la.x[T][1][1]);
+  acc[T][0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b0, acc[T][0][0], 0, 0, 0);
+  acc[T][0][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b1, acc[T][0][1], 0, 0, 0);
+  acc[T][1][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b0, acc[T][1][0], 0, 0, 0);
+  acc[T][1][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1, acc[T][1][1], 0, 0, 0);
 }
 
-template <int TW, int R>
+template <int R>
 __device__ __forceinline__ void wg_row(const LaneAddr& la, f32x4 (&acc)[7][2][2]) {
   constexpr int goff = R * TX * 64;
   const bf16x8 a0 = tr_pair<goff>(la.g[0][0], la.g[0][1]);
   const bf16x8 a1 = tr_pair<goff>(la.g[1][0], la.g[1][1]);
-  wg_tap<TW, R, 0>(la, a0, a1, acc); wg_tap<TW, R, 1>(la, a0, a1, acc); wg_tap<TW, R, 2>(la, a0, a1, acc);
-  wg_tap<TW, R, 3>(la, a0, a1, acc); wg_tap<TW, R, 4>(la, a0, a1, acc); wg_tap<TW, R, 5>(la, a0, a1, acc);
-  wg_tap<TW, R, 6>(la, a0, a1, acc);
+  wg_tap<R, 0>(la, a0, a1, acc); wg_tap<R, 1>(la, a0, a1, acc); wg_tap<R, 2>(la, a0, a1, acc);
+  wg_tap<R, 3>(la, a0, a1, acc); wg_tap<R, 4>(la, a0, a1, acc); wg_tap<R, 5>(la, a0, a1, acc);
+  wg_tap<R, 6>(la, a0, a1, acc);
 }
 
 // Issue-order plan for the whole (fully unrolled, branch-free) brick: a software pipeline with the LDS reads of
-// stage s+2 issued before the MFMAs of stage s (stage = one tap of one x-row: 4 transposing reads [+4 for the row's
-// gy fragments] then 4 MFMAs).  Without it the scheduler front-loads hundreds of reads and spills.
-template <int S, int K, int TOTAL>
+// stage s+WG_DIST issued before the MFMAs of stage s.  Without it the scheduler front-loads hundreds of reads and spills.
+#define WG_DIST 3  // prefetch distance in stages (8 fragment VGPRs each)
+template <int S, int TOTAL>
 __device__ __forceinline__ void wg_sched() {
   if constexpr (S < TOTAL) {
-    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                    // MFMA x4  (stage S)
-    if constexpr (S + 2 < TOTAL)
-      __builtin_amdgcn_sched_group_barrier(0x100, ((S + 2) % K == 0) ? 8 : 4, 0);         // DS_READ  (stage S+2)
-    wg_sched<S + 1, K, TOTAL>();
+    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                          // MFMA x4  (stage S)
+    if constexpr (S + WG_DIST < TOTAL)
+      __builtin_amdgcn_sched_group_barrier(0x100, ((S + WG_DIST) % 7 == 0) ? 8 : 4, 0);         // DS_READ  (stage S+DIST)
+    wg_sched<S + 1, TOTAL>();
   }
 }
 
-template <int TW>
-__device__ __forceinline__ void wg_brick(const LaneAddr& la0, unsigned boff, f32x4 (&acc)[7][2][2]) {
-  LaneAddr la;  // this brick's buffer: 16 adds per brick buy immediate offsets for every read below
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      la.g[a][b] = la0.g[a][b] + boff;
-#pragma unroll
-      for (int d = 0; d < 3; ++d) la.x[d][a][b] = la0.x[d][a][b] + boff;
-    }
-  wg_row<TW, 0>(la, acc); wg_row<TW, 1>(la, acc); wg_row<TW, 2>(la, acc); wg_row<TW, 3>(la, acc);
-  wg_row<TW, 4>(la, acc); wg_row<TW, 5>(la, acc); wg_row<TW, 6>(la, acc); wg_row<TW, 7>(la, acc);
-  constexpr int K = (TW == 3) ? 6 : 7;
-  __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
-  __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-  wg_sched<0, K, 8 * K>();
+__device__ __forceinline__ void wg_brick(const LaneAddr& la, f32x4 (&acc)[7][2][2]) {
+  wg_row<0>(la, acc); wg_row<1>(la, acc); wg_row<2>(la, acc); wg_row<3>(la, acc);
+  wg_row<4>(la, acc); wg_row<5>(la, acc); wg_row<6>(la, acc); wg_row<7>(la, acc);
+  __builtin_amdgcn_sched_group_barrier(0x100, 8 + 4 * (WG_DIST - 1), 0);  // stages 0 .. DIST-1 (stage 0 includes the row's gy fragments)
+  wg_sched<0, 56>();
 }
 
 __global__ __launch_bounds__(512, 2) void wgrad_tiled_kernel(WgTiledParams p) {
@@ -124,38 +111,50 @@ __global__ __launch_bounds__(512, 2) void wgrad_tiled_kernel(WgTiledParams p) {
   constexpr int BUF = (HALO_VOX + BRICK_VOX) * 32;  // elements per staged brick (x halo + gy)
 
   if (loader) {
-    // ---- producer: brick k -> buffer k&1, one brick ahead of the consumers
+    // ---- producer: brick k -> buffer k&1, one brick ahead of the consumers.
+    // Per-item descriptors are brick-independent and computed ONCE: element offset relative to the brick origin, and
+    // six "touches the low/high face of the halo" bits; a brick then costs ~6 VALU + one LDS-DMA issue per item.
+    // LDS-DMA (global_load_lds, 16 B per lane): a wave-instruction's LDS destination is linear (wave base + lane*16),
+    // so the chunk rotation is applied on the SOURCE side -- the lane whose slot holds rotated chunk (i&3) fetches
+    // logical chunk (i&3) - (x>>2).  Out-of-volume halo voxels fetch a zero line.
+    int rel[STAGE_ITERS], flg[STAGE_ITERS];
+#pragma unroll
+    for (int it = 0; it < STAGE_ITERS; ++it) {
+      const int i = ttid + it * 256;
+      rel[it] = 0; flg[it] = 0;
+      if (i < X_ITEMS) {
+        const int cp = i & 3, hv = i >> 2;
+        const int hx = hv % HX, hy = (hv / HX) % HY, hz = hv / (HX * HY);
+        const int ck = (cp - (hx >> 2)) & 3;
+        rel[it] = (((hz - 1) * p.H + (hy - 1)) * p.W + (hx - 1)) * 32 + ck * 8;
+        flg[it] = (hz == 0) | ((hz == HZ - 1) << 1) | ((hy == 0) << 2) | ((hy == HY - 1) << 3) | ((hx == 0) << 4) | ((hx == HX - 1) << 5);
+      } else if (i < X_ITEMS + G_ITEMS) {
+        const int j = i - X_ITEMS;
+        const int cp = j & 3, bv = j >> 2;
+        const int bx = bv % TX, by = (bv / TX) % TY, bz = bv / (TX * TY);
+        const int ck = (cp - (bx >> 2)) & 3;
+        rel[it] = ((bz * p.H + by) * p.W + bx) * p.g_cs + ck * 8;
+      }
+    }
+    const bf16_t* xn = p.x + vox_n * 32;
+    const bf16_t* gn = p.gy + vox_n * p.g_cs + p.g_co;
     for (int k = 0; k <= my_tiles; ++k) {
       if (k < my_tiles) {
         bf16_t* xL = lds + (k & 1) * BUF;
         const int tile = wg + k * p.wgs_per_sample;
         const int tx = tile % p.tiles_x, ty = (tile / p.tiles_x) % p.tiles_y, tz = tile / (p.tiles_x * p.tiles_y);
         const int z0 = tz * TZ, y0 = ty * TY, x0 = tx * TX;
-        // LDS-DMA (global_load_lds, 16 B per lane): a wave-instruction's LDS destination is linear (wave base +
-        // lane*16), so the chunk rotation is applied on the SOURCE side -- the lane whose slot holds rotated chunk
-        // (i&3) fetches logical chunk (i&3) - (x>>2).  Out-of-volume halo voxels fetch a zero line.
+        const int org = (z0 * p.H + y0) * p.W + x0;  // brick origin voxel (scalar)
+        const int tflg = (z0 == 0) | ((z0 + TZ == p.D) << 1) | ((y0 == 0) << 2) | ((y0 + TY == p.H) << 3) |
+                         ((x0 == 0) << 4) | ((x0 + TX == p.W) << 5);
 #pragma unroll
         for (int it = 0; it < STAGE_ITERS; ++it) {
-          int i = ttid + it * 256;
-          asm volatile("" : "+v"(i));  // keep the per-item decode inside the brick loop (LICM would hoist and spill it)
-          if (it * 256 + (ttid & ~63) < X_ITEMS + G_ITEMS) {  // wave-uniform: region sizes are multiples of 64 items
-            const bf16_t* src = g_zero_line;
-            if (i < X_ITEMS) {
-              const int cp = i & 3, hv = i >> 2;
-              const int hx = hv % HX, hy = (hv / HX) % HY, hz = hv / (HX * HY);
-              const int gz = z0 + hz - 1, gy_ = y0 + hy - 1, gx = x0 + hx - 1;
-              const int ck = (cp - (hx >> 2)) & 3;
-              if ((unsigned)gz < (unsigned)p.D && (unsigned)gy_ < (unsigned)p.H && (unsigned)gx < (unsigned)p.W)
-                src = p.x + (vox_n + ((long)gz * p.H + gy_) * p.W + gx) * 32 + ck * 8;
-            } else {
-              const int j = i - X_ITEMS;
-              const int cp = j & 3, bv = j >> 2;
-              const int bx = bv % TX, by = (bv / TX) % TY, bz = bv / (TX * TY);
-              const int ck = (cp - (bx >> 2)) & 3;
-              src = p.gy + (vox_n + ((long)(z0 + bz) * p.H + (y0 + by)) * p.W + (x0 + bx)) * p.g_cs + p.g_co + ck * 8;
-            }
+          if (!(p.dbg & 2) && it * 256 + (ttid & ~63) < X_ITEMS + G_ITEMS) {  // wave-uniform: region sizes are multiples of 64 items
+            const bool is_x = it * 256 + (ttid & ~63) < X_ITEMS;  // wave-uniform as well (3264 = 51 * 64)
+            const bf16_t* src = is_x ? ((flg[it] & tflg) ? g_zero_line : xn + org * 32 + rel[it])
+                                     : gn + (long)org * p.g_cs + rel[it];
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(xL + (i - lane) * 8), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(xL + (it * 256 + (ttid & ~63)) * 8), 16, 0, 0);
           }
         }
       }
@@ -184,22 +183,29 @@ __global__ __launch_bounds__(512, 2) void wgrad_tiled_kernel(WgTiledParams p) {
         const int xg = 8 * q + a + 4 * h;
         la.g[sub][h] = lds_base + 2u * (HALO_VOX * 32 + xg * 32 + rot(chunk, xg) + within);
 #pragma unroll
-        for (int dx = 0; dx < 3; ++dx) {
+        for (int t = 0; t < 7; ++t) {
+          int tap = tw + 4 * t;
+          if (tap > 26) tap = 26;  // wave 3 has six taps; its seventh slot recomputes tap 26 into a slab row nobody stores
+          const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
           const int xa = xg + dx;
-          la.x[dx][sub][h] = lds_base + 2u * (xa * 32 + rot(chunk, xa) + within);
+          la.x[t][sub][h] = lds_base + 2u * ((dz * HY + dy) * HX * 32 + xa * 32 + rot(chunk, xa) + within);
         }
       }
     }
   }
   __syncthreads();  // brick 0 staged
   for (int k = 0; k < my_tiles; ++k) {
-    const unsigned boff = (k & 1) ? 2u * BUF : 0u;
-    switch (tw) {  // scalar selector: uniform branch, EXEC stays all-ones for the transposing reads
-      case 0: wg_brick<0>(la, boff, acc); break;
-      case 1: wg_brick<1>(la, boff, acc); break;
-      case 2: wg_brick<2>(la, boff, acc); break;
-      default: wg_brick<3>(la, boff, acc); break;
-    }
+    if (!(p.dbg & 1)) wg_brick(la, acc);
+    // flip every fragment address to the other staging buffer (in place: no second address set stays live)
+    const unsigned delta = (k & 1) ? (unsigned)(-(int)(2u * BUF)) : 2u * BUF;
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        la.g[sub][h] += delta;
+#pragma unroll
+        for (int t = 0; t < 7; ++t) la.x[t][sub][h] += delta;
+      }
     __syncthreads();  // brick k consumed, brick k+1 staged
   }
 
@@ -248,6 +254,8 @@ int rtp_wgrad_tiled_try(const RtpAct* gy, const RtpAct* x, const RtpConvGeom* g,
   p.tiles_y = p.H / TY; p.tiles_x = p.W / TX;
   p.tiles_per_sample = (p.D / TZ) * p.tiles_y * p.tiles_x;
   p.wgs_per_sample = nsplit;
+  static const int dbg = getenv("RTP_TILED_DBG") ? atoi(getenv("RTP_TILED_DBG")) : 0;
+  p.dbg = dbg;
   const size_t shm = sizeof(bf16_t) * 2 * (size_t)(HALO_VOX + BRICK_VOX) * 32;
   RtpProfScope prof(RTP_FAM_WGRAD_TILED, s);
   static bool attr = false;

@@ -1,0 +1,24 @@
+import sys, os, time; sys.path.insert(0, '.')
+import torch
+from rt_pose_amd.backend import HipBackend
+from rt_pose_amd.graph import Geom, View
+be = HipBackend('cuda:0')
+n, d, h, w, c = 8, 16, 64, 160, 32
+g = Geom(n, d, h, w, d, h, w, c, c, 3, 1, 1)
+def mk(shape, dt=torch.bfloat16): return torch.randn(shape, device='cuda').to(dt)
+x = View(mk((n, d, h, w, c)), n, d, h, w, c, 0, c)
+y = View(mk((n, d, h, w, c)), n, d, h, w, c, 0, c)
+res = View(mk((n, d, h, w, c)), n, d, h, w, c, 0, c)
+wf = mk((n, 27, c, c)) * 0.05
+bt = torch.randn(n, 64, c, device='cuda')
+S = be.wgrad_nsplit(g)
+gp = torch.zeros(n, S, 27, c, c, device='cuda')
+f_conv = be.conv(x, wf, True, bt, res, y, g, True, False, False)
+f_wg = be.wgrad(y, x, g, S, gp)
+def t(f, it=20):
+    s = be.stream()
+    for _ in range(3): f(s)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(it): f(s)
+    torch.cuda.synchronize(); return (time.perf_counter() - t0) / it * 1e6
+print('dbg', os.environ.get('RTP_TILED_DBG', '0'), 'conv_tiled %.1f us' % t(f_conv), 'wgrad_tiled %.1f us' % t(f_wg))
