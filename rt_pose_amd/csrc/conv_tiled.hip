@@ -120,7 +120,7 @@ __global__ __launch_bounds__(512, 2) void conv_tiled_kernel(TiledParams p) {
     const int hx = hv % HX, hy = (hv / HX) % HY, hz = hv / (HX * HY);
     s_dst[k] = (i < HALO_ITEMS) ? hv * 32 + swz(ck, hx) : -1;
     s_rel[k] = (((hz - 1) * p.H + (hy - 1)) * p.W + (hx - 1)) * 32 + ck * 8;
-    s_flg[k] = (hz == 0) | ((hz == HZ - 1) << 1) | ((hy == 0) << 2) | ((hy == HY - 1) << 3) | ((hx == 0) << 4) | ((hx == HX - 1) << 5);
+    s_flg[k] = (hz == 0) | ((hz == HZ - 1) << 1) | ((hy == 0) << 2) | ((hy == HY - 1) << 3) | ((hx == 0) << 4) | (hx << 8);
   }
   const bf16_t* xn = p.x + vox_n * 32;
   const int my_tiles = (p.tiles_per_sample - team_id + p.teams_per_sample - 1) / p.teams_per_sample;
@@ -136,13 +136,13 @@ __global__ __launch_bounds__(512, 2) void conv_tiled_kernel(TiledParams p) {
         const int tx = tile % p.tiles_x, ty = (tile / p.tiles_x) % p.tiles_y, tz = tile / (p.tiles_x * p.tiles_y);
         const int z0 = tz * TZ, y0 = ty * TY, x0 = tx * TX;
         const int org = ((z0 * p.H + y0) * p.W + x0) * 32;
-        const int tflg = (z0 == 0) | ((z0 + TZ == p.D) << 1) | ((y0 == 0) << 2) | ((y0 + TY == p.H) << 3) |
-                         ((x0 == 0) << 4) | ((x0 + TX == p.W) << 5);
+        const int tflg = (z0 == 0) | ((z0 + TZ == p.D) << 1) | ((y0 == 0) << 2) | ((y0 + TY == p.H) << 3) | ((x0 == 0) << 4);
+        const int xlim = (p.W - x0 + 1) << 8;  // haloed x index >= this lies beyond the volume (W need not be a multiple of TX)
         bf16x8 val[STAGE_BATCH];
 #pragma unroll
         for (int k = 0; k < STAGE_BATCH; ++k) {
           val[k] = zero_bf16x8();
-          if (s_dst[k] >= 0 && !(s_flg[k] & tflg)) val[k] = ld_bf16x8(xn + org + s_rel[k]);
+          if (s_dst[k] >= 0 && !(s_flg[k] & tflg) && s_flg[k] < xlim) val[k] = ld_bf16x8(xn + org + s_rel[k]);
         }
 #pragma unroll
         for (int k = 0; k < STAGE_BATCH; ++k)
@@ -152,6 +152,7 @@ __global__ __launch_bounds__(512, 2) void conv_tiled_kernel(TiledParams p) {
     } else if (comp_k < load_k && comp_k < my_tiles) {
       const int tile = team_id + comp_k * p.teams_per_sample;
       ++comp_k;
+      if ((tile % p.tiles_x) * TX + wx * 16 >= p.W) { __syncthreads(); continue; }  // wave-uniform: this wave's 16-voxel column is padding
       const int tx = tile % p.tiles_x, ty = (tile / p.tiles_x) % p.tiles_y, tz = tile / (p.tiles_x * p.tiles_y);
       const int z0 = tz * TZ, y0 = ty * TY, x0 = tx * TX;
 
@@ -297,7 +298,7 @@ int rtp_conv_tiled_try(const RtpAct* x, const void* wf, int w_per_sample, const 
   const int Ci = transposed ? (g->co + 31) / 32 * 32 : g->ci;
   const int Co = transposed ? g->ci : g->co;
   if (Ci != 32 || (Co != 16 && Co != 32)) return 1;
-  if (g->di % TZ || g->hi % TY || g->wi % TX || g->di < 2 || g->hi < 2) return 1;
+  if (g->di % TZ || g->hi % TY || g->wi % 16 || g->di < 2 || g->hi < 2) return 1;
   if (x->cs != 32 || x->co != 0) return 1;
   TiledParams p;
   p.x = (const bf16_t*)x->ptr; p.w = (const bf16_t*)wf; p.btab = btab;
@@ -305,7 +306,7 @@ int rtp_conv_tiled_try(const RtpAct* x, const void* wf, int w_per_sample, const 
   p.N = g->n; p.D = g->di; p.H = g->hi; p.W = g->wi; p.Co = Co;
   p.y_cs = y->cs; p.y_co = y->co; p.r_cs = res ? res->cs : 0; p.r_co = res ? res->co : 0;
   p.relu = relu; p.y_fp32 = y_fp32; p.flip = transposed; p.w_per_sample = w_per_sample;
-  p.tiles_y = p.H / TY; p.tiles_x = p.W / TX;
+  p.tiles_y = p.H / TY; p.tiles_x = (p.W + TX - 1) / TX;
   p.tiles_per_sample = (p.D / TZ) * p.tiles_y * p.tiles_x;
   int wgs = 256 / p.N;  // workgroups per sample: one workgroup per CU when N divides 256
   if (wgs < 1) wgs = 1;

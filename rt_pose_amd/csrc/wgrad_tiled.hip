@@ -127,13 +127,14 @@ __global__ __launch_bounds__(512, 2) void wgrad_tiled_kernel(WgTiledParams p) {
         const int hx = hv % HX, hy = (hv / HX) % HY, hz = hv / (HX * HY);
         const int ck = (cp - (hx >> 2)) & 3;
         rel[it] = (((hz - 1) * p.H + (hy - 1)) * p.W + (hx - 1)) * 32 + ck * 8;
-        flg[it] = (hz == 0) | ((hz == HZ - 1) << 1) | ((hy == 0) << 2) | ((hy == HY - 1) << 3) | ((hx == 0) << 4) | ((hx == HX - 1) << 5);
+        flg[it] = (hz == 0) | ((hz == HZ - 1) << 1) | ((hy == 0) << 2) | ((hy == HY - 1) << 3) | ((hx == 0) << 4) | (hx << 8);
       } else if (i < X_ITEMS + G_ITEMS) {
         const int j = i - X_ITEMS;
         const int cp = j & 3, bv = j >> 2;
         const int bx = bv % TX, by = (bv / TX) % TY, bz = bv / (TX * TY);
         const int ck = (cp - (bx >> 2)) & 3;
         rel[it] = ((bz * p.H + by) * p.W + bx) * p.g_cs + ck * 8;
+        flg[it] = (bx + 1) << 8;  // same x-limit test as the halo items (halo index = brick index + 1)
       }
     }
     const bf16_t* xn = p.x + vox_n * 32;
@@ -145,14 +146,14 @@ __global__ __launch_bounds__(512, 2) void wgrad_tiled_kernel(WgTiledParams p) {
         const int tx = tile % p.tiles_x, ty = (tile / p.tiles_x) % p.tiles_y, tz = tile / (p.tiles_x * p.tiles_y);
         const int z0 = tz * TZ, y0 = ty * TY, x0 = tx * TX;
         const int org = (z0 * p.H + y0) * p.W + x0;  // brick origin voxel (scalar)
-        const int tflg = (z0 == 0) | ((z0 + TZ == p.D) << 1) | ((y0 == 0) << 2) | ((y0 + TY == p.H) << 3) |
-                         ((x0 == 0) << 4) | ((x0 + TX == p.W) << 5);
+        const int tflg = (z0 == 0) | ((z0 + TZ == p.D) << 1) | ((y0 == 0) << 2) | ((y0 + TY == p.H) << 3) | ((x0 == 0) << 4);
+        const int xlim = (p.W - x0 + 1) << 8;  // haloed x index >= this lies beyond the volume (W need not be a multiple of TX)
 #pragma unroll
         for (int it = 0; it < STAGE_ITERS; ++it) {
           if (!(p.dbg & 2) && it * 256 + (ttid & ~63) < X_ITEMS + G_ITEMS) {  // wave-uniform: region sizes are multiples of 64 items
             const bool is_x = it * 256 + (ttid & ~63) < X_ITEMS;  // wave-uniform as well (3264 = 51 * 64)
-            const bf16_t* src = is_x ? ((flg[it] & tflg) ? g_zero_line : xn + org * 32 + rel[it])
-                                     : gn + (long)org * p.g_cs + rel[it];
+            const bool oob = (flg[it] & tflg & 0xff) || flg[it] >= xlim;
+            const bf16_t* src = oob ? g_zero_line : (is_x ? xn + org * 32 + rel[it] : gn + (long)org * p.g_cs + rel[it]);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(xL + (it * 256 + (ttid & ~63)) * 8), 16, 0, 0);
           }
@@ -230,11 +231,11 @@ static bool wg_tiled_applicable(const RtpConvGeom* g) {
   static const bool disabled = getenv("RTP_DISABLE_TILED") != nullptr;
   if (disabled) return false;
   return g->ks == 3 && g->stride == 1 && g->pad == 1 && g->ci == 32 && (g->co + 31) / 32 * 32 == 32 &&
-         g->di % TZ == 0 && g->hi % TY == 0 && g->wi % TX == 0;
+         g->di % TZ == 0 && g->hi % TY == 0 && g->wi % 16 == 0;
 }
 
 static int wg_tiled_wgs(const RtpConvGeom* g) {
-  const int tiles = (g->di / TZ) * (g->hi / TY) * (g->wi / TX);
+  const int tiles = (g->di / TZ) * (g->hi / TY) * ((g->wi + TX - 1) / TX);
   int wgs = 256 / g->n;
   if (wgs < 1) wgs = 1;
   if (wgs > tiles) wgs = tiles;
@@ -251,7 +252,7 @@ int rtp_wgrad_tiled_try(const RtpAct* gy, const RtpAct* x, const RtpConvGeom* g,
   WgTiledParams p;
   p.gy = (const bf16_t*)gy->ptr; p.x = (const bf16_t*)x->ptr; p.gp = gp;
   p.N = g->n; p.D = g->di; p.H = g->hi; p.W = g->wi; p.g_cs = gy->cs; p.g_co = gy->co;
-  p.tiles_y = p.H / TY; p.tiles_x = p.W / TX;
+  p.tiles_y = p.H / TY; p.tiles_x = (p.W + TX - 1) / TX;
   p.tiles_per_sample = (p.D / TZ) * p.tiles_y * p.tiles_x;
   p.wgs_per_sample = nsplit;
   static const int dbg = getenv("RTP_TILED_DBG") ? atoi(getenv("RTP_TILED_DBG")) : 0;

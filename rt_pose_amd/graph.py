@@ -257,7 +257,7 @@ class ConvOp:
         self.alg_flops = 2 * g.n * ge.do * ge.ho * ge.wo * self.co_real * self.ci_real * ntap
         g.flops["conv_fwd"] += self.alg_flops
         # mirrors the dispatch predicate of rtp_conv_tiled_try (csrc/conv_tiled.hip)
-        brick = ge.ks == 3 and ge.stride == 1 and ge.di % 2 == 0 and ge.hi % 4 == 0 and ge.wi % 32 == 0
+        brick = ge.ks == 3 and ge.stride == 1 and ge.di % 2 == 0 and ge.hi % 4 == 0 and ge.wi % 16 == 0
         self.tiled_fwd = brick and ge.ci == 32 and ge.co in (16, 32) and self.x.cs == 32
         self.tiled_bwd = brick and ge.ci == 32 and pad_to(ge.co, 32) == 32
         g.flops["conv_tiled" if self.tiled_fwd else "conv_generic"] += self.alg_flops

@@ -80,6 +80,8 @@ CONV_CASES = [
     (3, (2, 16, 64), 32, 32, 3, 1, True, False, False, False),
     (1, (2, 16, 64), 32, 15, 3, 1, False, False, False, True),
     (2, (6, 24, 96), 32, 3, 3, 1, False, False, True, True),
+    (2, (8, 32, 80), 32, 32, 3, 1, True, True, True, False),   # W = 80: the last brick column is half padding
+    (1, (2, 4, 16), 32, 32, 3, 1, True, False, True, False),
 ]
 
 
@@ -108,7 +110,7 @@ def test_conv_forward(hip, case):
 @pytest.mark.parametrize("case", [
     (2, (4, 8, 16), 32, 32, 3, 1), (2, (4, 8, 16), 32, 64, 3, 2), (1, (2, 4, 20), 64, 32, 1, 1),
     (2, (4, 8, 8), 32, 15, 3, 1), (1, (1, 2, 4), 64, 64, 3, 2), (1, (5, 6, 7), 32, 32, 3, 2),
-    (2, (4, 8, 32), 32, 32, 3, 1), (1, (2, 16, 64), 32, 15, 3, 1)])  # last two: LDS-tiled kernel, flipped taps
+    (2, (4, 8, 32), 32, 32, 3, 1), (1, (2, 16, 64), 32, 15, 3, 1), (2, (8, 32, 80), 32, 32, 3, 1)])  # LDS-tiled kernel, flipped taps
 def test_conv_transposed_is_data_gradient(hip, case):
     n, dims, ci, co_real, ks, stride = case
     d, h, w = dims
@@ -137,10 +139,10 @@ def test_conv_transposed_is_data_gradient(hip, case):
 
 
 @pytest.mark.parametrize("case", [
-    (2, (4, 8, 16), 32, 32, 3, 1, 4), (2, (8, 8, 16), 32, 64, 3, 2, 2), (1, (2, 4, 20), 64, 32, 1, 1, 1),
+    (2, (4, 8, 16), 32, 32, 3, 1, 3), (2, (8, 8, 16), 32, 64, 3, 2, 2), (1, (2, 4, 20), 64, 32, 1, 1, 1),
     (2, (4, 8, 8), 32, 15, 3, 1, 3), (1, (3, 5, 7), 128, 128, 3, 1, 1), (1, (1, 2, 4), 64, 64, 3, 2, 1),
     # nsplit=None: geometries of the LDS-tiled kernel (csrc/wgrad_tiled.hip), which picks its own slab count
-    (2, (4, 8, 32), 32, 32, 3, 1, None), (1, (2, 16, 64), 32, 15, 3, 1, None), (3, (6, 12, 96), 32, 32, 3, 1, None)])
+    (2, (4, 8, 32), 32, 32, 3, 1, None), (1, (2, 16, 64), 32, 15, 3, 1, None), (3, (6, 12, 96), 32, 32, 3, 1, None), (2, (8, 32, 80), 32, 32, 3, 1, None), (1, (2, 4, 16), 32, 32, 3, 1, None)])
 def test_wgrad(hip, case):
     n, dims, ci, co_real, ks, stride, nsplit = case
     d, h, w = dims
