@@ -64,7 +64,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--model", default="hr3d")
     ap.add_argument("--batch", type=int, default=8, help="frames per GPU")
-    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="replay fwd+loss+bwd as one captured HIP graph (eager two-stream "
+                    "launching is faster while the step is GPU-bound: profiles/r01_notes.md)")
+    ap.add_argument("--no-graph", action="store_true", help="(default) kept for compatibility")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -89,7 +91,7 @@ def main():
 
     spec = configs.spec(args.model)
     tr = DataParallelTrainer(args.model, args.batch, configs.NATIVE_DIMS, total_steps=max(100, args.steps + args.warmup),
-                             device=dev, rank=rank, world_size=world, use_graph=not args.no_graph)
+                             device=dev, rank=rank, world_size=world, use_graph=args.graph)
     ex = synth.make_batch(args.batch, spec["cin"], configs.NATIVE_DIMS, seed=1234, one_hm=spec["heads"]["hm"] == 1, rank=rank)
     tr.load(ex)  # inputs resident in HBM before the timed region
     torch.cuda.synchronize()
@@ -123,7 +125,7 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": "%s train step (fwd+loss+bwd+allreduce+clip+Adam), %d frames/GPU of [%d,16,64,160], "
                                "random-init weights" % (args.model, args.batch, spec["cin"]),
-                   "global_batch": world * args.batch, "parallelism": "dp%d" % world, "hip_graph": not args.no_graph},
+                   "global_batch": world * args.batch, "parallelism": "dp%d" % world, "hip_graph": bool(args.graph)},
         "final_loss": round(loss, 5),
         "train_gflop_per_frame": round(train_flops_per_frame / 1e9, 2),
         "mfma_frac_whole_step": round(frames / elapsed * train_flops_per_frame / (world * PEAK_BF16_TFLOPS * 1e12), 4),

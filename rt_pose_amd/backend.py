@@ -49,6 +49,16 @@ class HipBackend:
     def stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
+    # side stream for work that only the optimiser consumes (fork/join with events: capturable into a HIP graph)
+    def fork_side(self):
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(self.device)
+        self._side.wait_stream(torch.cuda.current_stream(self.device))
+        return C.c_void_p(self._side.cuda_stream)
+
+    def join_side(self):
+        torch.cuda.current_stream(self.device).wait_stream(self._side)
+
     def stem_bwd_blocks(self):
         return self.lib.rtp_stem_bwd_blocks()
 

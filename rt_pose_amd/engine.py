@@ -142,12 +142,28 @@ class PoseEngine:
         for f in self.fwd:
             f(s)
 
+    def _run_bwd(self, s):
+        """Replay the backward list: plain entries on the main stream, ('side', f) entries on the backend's side stream,
+        FORK = side waits for everything queued on main so far, JOIN = main waits for the side stream."""
+        fork = getattr(self.be, "fork_side", None)
+        ss = None
+        for item in self.bwd:
+            if callable(item):
+                item(s)
+            elif item[0] == "side":
+                item[1](ss if ss is not None else s)
+            elif item[0] == "fork":
+                if fork is not None:
+                    ss = fork()
+            elif item[0] == "join":
+                if fork is not None and ss is not None:
+                    self.be.join_side()
+
     def run_loss_backward(self, stream=None):
         s = stream if stream is not None else self.be.stream()
         for f in self.loss_launches:
             f(s)
-        for f in self.bwd:
-            f(s)
+        self._run_bwd(s)
 
     def run_losses_only(self, stream=None):
         """Loss values (and the loss kernels' logit gradients) without the backward sweep."""
@@ -156,9 +172,7 @@ class PoseEngine:
             f(s)
 
     def run_backward_only(self, stream=None):
-        s = stream if stream is not None else self.be.stream()
-        for f in self.bwd:
-            f(s)
+        self._run_bwd(stream if stream is not None else self.be.stream())
 
     def losses(self):
         """The reference's loss dict (center_head.py:260): device scalars, no host sync here."""

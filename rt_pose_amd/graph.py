@@ -19,6 +19,14 @@ closure f(stream) so argument marshalling happens once, at build time.
 from dataclasses import dataclass, field
 from typing import List, Optional
 
+FORK, JOIN = ("fork",), ("join",)  # markers in the backward list: side stream forks from / joins the main stream
+
+
+def side(fn):
+    """Tag a launch for the side stream (the weight-gradient chain runs beside the data-gradient chain)."""
+    return ("side", fn)
+
+
 GROUPS = 8      # nn.GroupNorm(num_groups=8, ...) everywhere on the path (hr_util/common.py:57, hr3d.py:147)
 GN_EPS = 1e-5
 
@@ -213,6 +221,7 @@ class Graph:
             if gy is None:
                 continue
             op.emit_backward(gy)
+        self.bwd.append(JOIN)
 
 
 class StemOp:
@@ -222,7 +231,8 @@ class StemOp:
     def emit_backward(self, gy):
         g = self.g
         scratch = g.be.alloc((g.be.stem_bwd_blocks(), self.y.c, 2), "f32")
-        g.bwd.append(g.be.stem_bwd(self.x, gy, scratch, g.pgrad[self.wname], g.pgrad[self.bname], 0))
+        g.bwd.append(FORK)
+        g.bwd.append(side(g.be.stem_bwd(self.x, gy, scratch, g.pgrad[self.wname], g.pgrad[self.bname], 0)))
 
 
 class ConvOp:
@@ -296,7 +306,10 @@ class ConvOp:
         co32 = pad_to(ge.co, 32)
         assert gy.c == co32, (self.name, gy.c, co32)
         gp = be.alloc((g.n, S, ge.ks ** 3, co32, ge.ci), "f32")
-        g.bwd.append(be.wgrad(gy, x, ge, S, gp))
+        # The weight-gradient chain (wgrad -> class sums -> un-fold) only feeds the optimiser, so it runs on the side
+        # stream beside the rest of the backward sweep; it forks here because it needs the finished gy.
+        g.bwd.append(FORK)
+        g.bwd.append(side(be.wgrad(gy, x, ge, S, gp)))
         g.flops["wgrad"] += self.alg_flops
         g.flops["wgrad_tiled" if self.tiled_wgrad else "wgrad_generic"] += self.alg_flops
         csum = None
@@ -304,11 +317,11 @@ class ConvOp:
             cs_split = max(1, min(64, (gy.d * gy.h + 3) // 4))
             csum = be.alloc((g.n, 64, gy.c), "f32")
             cs_scratch = be.alloc((g.n, cs_split, 64, gy.c), "f32")
-            g.bwd.append(be.class_sums(gy, cs_split, cs_scratch, csum))
-        g.bwd.append(be.wgrad_fold(gp, S, csum, self.mr, g.params[self.gn[0]] if self.gn else None,
-                                   g.params[self.gn[1]] if self.gn else None, self.groups, ge, self.ci_real,
-                                   self.co_real, g.pgrad[self.wname],
-                                   g.pgrad[self.bname] if self.bname else None, 0))
+            g.bwd.append(side(be.class_sums(gy, cs_split, cs_scratch, csum)))
+        g.bwd.append(side(be.wgrad_fold(gp, S, csum, self.mr, g.params[self.gn[0]] if self.gn else None,
+                                        g.params[self.gn[1]] if self.gn else None, self.groups, ge, self.ci_real,
+                                        self.co_real, g.pgrad[self.wname],
+                                        g.pgrad[self.bname] if self.bname else None, 0)))
 
 
 class FuseOp:
