@@ -138,6 +138,7 @@ def main():
                 "wgrad_tiled (32ch full-res)": (_lib.FAM_WGRAD_TILED, g.flops["wgrad_tiled"]),
                 "wgrad generic": (_lib.FAM_WGRAD, g.flops["wgrad_generic"])}
         tr.use_graph = False
+        tr.engine.use_side_stream = False  # one stream while timing kernels: concurrent side-stream work would inflate the events
         for fam, _ in fams.values():
             be.prof_enable(fam, True)
         ksteps = min(args.steps, 5)
@@ -156,8 +157,12 @@ def main():
                              "avg_us_per_launch": round(1e3 * ms / cnt, 2), "tflops": round(tf, 2)}
             if best is None or ms > best[1]:
                 best = (kname, ms, tf)
+        # HBM bytes per launch of the dominant kernel from the PMC passes in profiles/r01_pmc_tiled.md (FETCH_SIZE doubled
+        # per MI355X_MICROARCH.md, + WRITE_SIZE), B=8 full-resolution layer; not re-measured in this process.
+        traffic = {"conv_tiled (fwd+dgrad, 32ch full-res)": 374e6, "wgrad_tiled (32ch full-res)": 251e6}.get(best[0])
         line["roofline"] = {"bound": "mfma", "kernel": best[0], "achieved": round(best[2], 2), "peak": PEAK_BF16_TFLOPS,
-                            "unit": "TFLOP/s", "frac": round(best[2] / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                            "unit": "TFLOP/s", "frac": round(best[2] / PEAK_BF16_TFLOPS, 4),
+                            "traffic": traffic if args.batch == 8 and args.model == "hr3d" else None,
                             "families": detail}
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(args.model)

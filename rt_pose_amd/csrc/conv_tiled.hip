@@ -34,7 +34,7 @@ struct TiledParams {
   int N, D, H, W, Co;  // Co = NT*16
   int y_cs, y_co, r_cs, r_co;
   int relu, y_fp32, flip, w_per_sample;
-  int tiles_y, tiles_x, tiles_per_sample, teams_per_sample;
+  int tiles_y, tiles_x, tiles_z, tiles_per_sample, teams_per_sample;
   int dbg;  // timing experiments only (RTP_TILED_DBG): bit0 = skip the MFMA loop, bit1 = skip staging, bit2 = skip epilogue
 };
 
@@ -123,7 +123,10 @@ __global__ __launch_bounds__(512, 2) void conv_tiled_kernel(TiledParams p) {
     s_flg[k] = (hz == 0) | ((hz == HZ - 1) << 1) | ((hy == 0) << 2) | ((hy == HY - 1) << 3) | ((hx == 0) << 4) | (hx << 8);
   }
   const bf16_t* xn = p.x + vox_n * 32;
-  const int my_tiles = (p.tiles_per_sample - team_id + p.teams_per_sample - 1) / p.teams_per_sample;
+  // contiguous, balanced runs of bricks per team, z fastest: consecutive bricks share two of their four haloed z-planes,
+  // which the second read then finds in this XCD's L2 (PMC: 1.5x over-fetch with the interleaved deal)
+  const int t_begin = (int)((long)team_id * p.tiles_per_sample / p.teams_per_sample);
+  const int my_tiles = (int)((long)(team_id + 1) * p.tiles_per_sample / p.teams_per_sample) - t_begin;
   int max_tiles = (p.tiles_per_sample + p.teams_per_sample - 1) / p.teams_per_sample;  // workgroup-uniform
   const int nphase = 2 * max_tiles + 1;
   int load_k = 0, comp_k = 0;
@@ -132,8 +135,8 @@ __global__ __launch_bounds__(512, 2) void conv_tiled_kernel(TiledParams p) {
     const bool loading = ((phase + team) & 1) == 0;  // team-uniform (=> wave-uniform)
     if (loading) {
       if (load_k < my_tiles && !(p.dbg & 2)) {
-        const int tile = team_id + load_k * p.teams_per_sample;
-        const int tx = tile % p.tiles_x, ty = (tile / p.tiles_x) % p.tiles_y, tz = tile / (p.tiles_x * p.tiles_y);
+        const int tile = t_begin + load_k;
+        const int tz = tile % p.tiles_z, tx = (tile / p.tiles_z) % p.tiles_x, ty = tile / (p.tiles_z * p.tiles_x);  // z fastest
         const int z0 = tz * TZ, y0 = ty * TY, x0 = tx * TX;
         const int org = ((z0 * p.H + y0) * p.W + x0) * 32;
         const int tflg = (z0 == 0) | ((z0 + TZ == p.D) << 1) | ((y0 == 0) << 2) | ((y0 + TY == p.H) << 3) | ((x0 == 0) << 4);
@@ -150,10 +153,10 @@ __global__ __launch_bounds__(512, 2) void conv_tiled_kernel(TiledParams p) {
       }
       ++load_k;
     } else if (comp_k < load_k && comp_k < my_tiles) {
-      const int tile = team_id + comp_k * p.teams_per_sample;
+      const int tile = t_begin + comp_k;
       ++comp_k;
-      if ((tile % p.tiles_x) * TX + wx * 16 >= p.W) { __syncthreads(); continue; }  // wave-uniform: this wave's 16-voxel column is padding
-      const int tx = tile % p.tiles_x, ty = (tile / p.tiles_x) % p.tiles_y, tz = tile / (p.tiles_x * p.tiles_y);
+      if (((tile / p.tiles_z) % p.tiles_x) * TX + wx * 16 >= p.W) { __syncthreads(); continue; }  // wave-uniform: this wave's 16-voxel column is padding
+      const int tz = tile % p.tiles_z, tx = (tile / p.tiles_z) % p.tiles_x, ty = tile / (p.tiles_z * p.tiles_x);  // z fastest
       const int z0 = tz * TZ, y0 = ty * TY, x0 = tx * TX;
 
       f32x4 acc[TY][NT];
@@ -306,7 +309,7 @@ int rtp_conv_tiled_try(const RtpAct* x, const void* wf, int w_per_sample, const 
   p.N = g->n; p.D = g->di; p.H = g->hi; p.W = g->wi; p.Co = Co;
   p.y_cs = y->cs; p.y_co = y->co; p.r_cs = res ? res->cs : 0; p.r_co = res ? res->co : 0;
   p.relu = relu; p.y_fp32 = y_fp32; p.flip = transposed; p.w_per_sample = w_per_sample;
-  p.tiles_y = p.H / TY; p.tiles_x = (p.W + TX - 1) / TX;
+  p.tiles_y = p.H / TY; p.tiles_x = (p.W + TX - 1) / TX; p.tiles_z = p.D / TZ;
   p.tiles_per_sample = (p.D / TZ) * p.tiles_y * p.tiles_x;
   int wgs = 256 / p.N;  // workgroups per sample: one workgroup per CU when N divides 256
   if (wgs < 1) wgs = 1;

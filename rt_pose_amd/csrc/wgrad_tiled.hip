@@ -27,7 +27,7 @@
 struct WgTiledParams {
   const bf16_t* gy; const bf16_t* x; float* gp;
   int N, D, H, W, g_cs, g_co;
-  int tiles_y, tiles_x, tiles_per_sample, wgs_per_sample;
+  int tiles_y, tiles_x, tiles_z, tiles_per_sample, wgs_per_sample;
   int dbg;  // timing experiments only (RTP_TILED_DBG): bit0 = consumers skip the MFMA work, bit1 = producers skip the DMA
 };
 
@@ -107,7 +107,8 @@ __global__ __launch_bounds__(512, 2) void wgrad_tiled_kernel(WgTiledParams p) {
   const int n = blockIdx.x / p.wgs_per_sample;
   const int wg = blockIdx.x - n * p.wgs_per_sample;
   const long vox_n = (long)n * p.D * p.H * p.W;
-  const int my_tiles = (p.tiles_per_sample - wg + p.wgs_per_sample - 1) / p.wgs_per_sample;
+  const int t_begin = (int)((long)wg * p.tiles_per_sample / p.wgs_per_sample);  // contiguous run, z fastest (L2 reuse of shared z-planes)
+  const int my_tiles = (int)((long)(wg + 1) * p.tiles_per_sample / p.wgs_per_sample) - t_begin;
   constexpr int BUF = (HALO_VOX + BRICK_VOX) * 32;  // elements per staged brick (x halo + gy)
 
   if (loader) {
@@ -142,8 +143,8 @@ __global__ __launch_bounds__(512, 2) void wgrad_tiled_kernel(WgTiledParams p) {
     for (int k = 0; k <= my_tiles; ++k) {
       if (k < my_tiles) {
         bf16_t* xL = lds + (k & 1) * BUF;
-        const int tile = wg + k * p.wgs_per_sample;
-        const int tx = tile % p.tiles_x, ty = (tile / p.tiles_x) % p.tiles_y, tz = tile / (p.tiles_x * p.tiles_y);
+        const int tile = t_begin + k;
+        const int tz = tile % p.tiles_z, tx = (tile / p.tiles_z) % p.tiles_x, ty = tile / (p.tiles_z * p.tiles_x);  // z fastest
         const int z0 = tz * TZ, y0 = ty * TY, x0 = tx * TX;
         const int org = (z0 * p.H + y0) * p.W + x0;  // brick origin voxel (scalar)
         const int tflg = (z0 == 0) | ((z0 + TZ == p.D) << 1) | ((y0 == 0) << 2) | ((y0 + TY == p.H) << 3) | ((x0 == 0) << 4);
@@ -252,7 +253,7 @@ int rtp_wgrad_tiled_try(const RtpAct* gy, const RtpAct* x, const RtpConvGeom* g,
   WgTiledParams p;
   p.gy = (const bf16_t*)gy->ptr; p.x = (const bf16_t*)x->ptr; p.gp = gp;
   p.N = g->n; p.D = g->di; p.H = g->hi; p.W = g->wi; p.g_cs = gy->cs; p.g_co = gy->co;
-  p.tiles_y = p.H / TY; p.tiles_x = (p.W + TX - 1) / TX;
+  p.tiles_y = p.H / TY; p.tiles_x = (p.W + TX - 1) / TX; p.tiles_z = p.D / TZ;
   p.tiles_per_sample = (p.D / TZ) * p.tiles_y * p.tiles_x;
   p.wgs_per_sample = nsplit;
   static const int dbg = getenv("RTP_TILED_DBG") ? atoi(getenv("RTP_TILED_DBG")) : 0;

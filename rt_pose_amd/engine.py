@@ -145,7 +145,7 @@ class PoseEngine:
     def _run_bwd(self, s):
         """Replay the backward list: plain entries on the main stream, ('side', f) entries on the backend's side stream,
         FORK = side waits for everything queued on main so far, JOIN = main waits for the side stream."""
-        fork = getattr(self.be, "fork_side", None)
+        fork = getattr(self.be, "fork_side", None) if getattr(self, "use_side_stream", True) else None
         ss = None
         for item in self.bwd:
             if callable(item):
