@@ -67,42 +67,57 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
 
   const bf16_t* wbase = p.w + (long)n * p.w_sample_stride;
   const long x_n = (long)n * p.Di * p.Hi * p.Wi;
-  const int ntap = p.ks * p.ks * p.ks;
   const int kchunks = p.Ci >> 5;
 
-  for (int tap = 0; tap < ntap; ++tap) {
-    const int kz = tap / (p.ks * p.ks);
-    const int ky = (tap / p.ks) % p.ks;
-    const int kx = tap % p.ks;
-    long xoff[MT];
-    bool ok[MT];
+  // Per-axis tap tables, computed once per tile: input coordinate offset (in voxels of the flattened sample) and
+  // validity of each of the (up to) 3 taps along z, y, x.  The 27-tap loop then only ANDs three bits and adds three
+  // offsets; recomputing coordinates and bounds per tap cost more VALU time than the MFMAs on the low-resolution and
+  // stride-2-gradient layers.
+  int offz[MT][3], offy[MT][3], offx[MT][3];
+  unsigned okm[MT];  // bits 0-2: z taps, 3-5: y taps, 6-8: x taps
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
+  for (int mt = 0; mt < MT; ++mt) {
+    okm[mt] = 0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
       int iz, iy, ix;
-      bool v = vok[mt];
+      bool vz = k < p.ks, vy = k < p.ks, vx = k < p.ks;
       if (!p.transposed) {
-        iz = oz[mt] * p.stride + kz - p.pad;
-        iy = oy[mt] * p.stride + ky - p.pad;
-        ix = ox[mt] * p.stride + kx - p.pad;
+        iz = oz[mt] * p.stride + k - p.pad;
+        iy = oy[mt] * p.stride + k - p.pad;
+        ix = ox[mt] * p.stride + k - p.pad;
       } else {
-        int tz = oz[mt] + p.pad - kz, ty = oy[mt] + p.pad - ky, tx = ox[mt] + p.pad - kx;
-        v = v && tz >= 0 && ty >= 0 && tx >= 0;
+        int tz = oz[mt] + p.pad - k, ty = oy[mt] + p.pad - k, tx = ox[mt] + p.pad - k;
+        vz = vz && tz >= 0; vy = vy && ty >= 0; vx = vx && tx >= 0;
         if (p.stride == 2) {
-          v = v && !((tz | ty | tx) & 1);
+          vz = vz && !(tz & 1); vy = vy && !(ty & 1); vx = vx && !(tx & 1);
           tz >>= 1; ty >>= 1; tx >>= 1;
         }
         iz = tz; iy = ty; ix = tx;
       }
-      v = v && (unsigned)iz < (unsigned)p.Di && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
-      ok[mt] = v;
-      xoff[mt] = (x_n + ((long)iz * p.Hi + iy) * p.Wi + ix) * p.x_cs + p.x_co + q * 8;
+      vz = vz && (unsigned)iz < (unsigned)p.Di;
+      vy = vy && (unsigned)iy < (unsigned)p.Hi;
+      vx = vx && (unsigned)ix < (unsigned)p.Wi;
+      offz[mt][k] = iz * p.Hi * p.Wi; offy[mt][k] = iy * p.Wi; offx[mt][k] = ix;
+      okm[mt] |= ((unsigned)vz << k) | ((unsigned)vy << (3 + k)) | ((unsigned)vx << (6 + k));
     }
-    {
-      bool any = false;
+    if (!vok[mt]) okm[mt] = 0;
+  }
+
+  int tap = 0;
+  for (int kz = 0; kz < p.ks; ++kz)
+  for (int ky = 0; ky < p.ks; ++ky)
+  for (int kx = 0; kx < p.ks; ++kx, ++tap) {
+    long xoff[MT];
+    bool ok[MT];
+    bool any = false;
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) any |= ok[mt];
-      if (!__any(any)) continue;  // wave-uniform: no lane of this wave has an in-range sample for this tap
+    for (int mt = 0; mt < MT; ++mt) {
+      ok[mt] = (okm[mt] >> kz) & (okm[mt] >> (3 + ky)) & (okm[mt] >> (6 + kx)) & 1u;
+      any |= ok[mt];
+      xoff[mt] = (x_n + offz[mt][kz] + offy[mt][ky] + offx[mt][kx]) * p.x_cs + p.x_co + q * 8;
     }
+    if (!__any(any)) continue;  // wave-uniform: no lane of this wave has an in-range sample for this tap
     const bf16_t* wt = wbase + ((long)tap * p.Co + co_base) * p.Ci + q * 8;
     for (int kc = 0; kc < kchunks; ++kc) {
       bf16x8 a[NT], b[MT];
@@ -215,16 +230,19 @@ extern "C" int rtp_conv_igemm(const RtpAct* x, const void* wf, int w_per_sample,
   const int ntap = p.ks * p.ks * p.ks;
   p.w_sample_stride = w_per_sample ? (long)ntap * p.Co * p.Ci : 0;
   p.Vo = p.Do * p.Ho * p.Wo;
-  constexpr int MT = 4;
-  p.blocks_per_sample = rtp_div_up(p.Vo, 4 * MT * 16);
   hipStream_t s = (hipStream_t)stream;
-  int nt = (p.Co % 32 == 0) ? 2 : 1;
+  const int nt = (p.Co % 32 == 0) ? 2 : 1;
+  // 64 voxels per wave amortise the weight fragments; small (low-resolution) problems instead take 16 voxels per wave
+  // so that they still spread over the chip (they are latency-, not throughput-bound)
+  const bool small = (long)p.N * p.Vo * (p.Co / (16 * nt)) < 256L * 256 * 2;
+  const int mt = small ? 1 : 4;
+  p.blocks_per_sample = rtp_div_up(p.Vo, 4 * mt * 16);
   dim3 grid(p.N * p.blocks_per_sample, p.Co / (16 * nt));
   RtpProfScope prof(RTP_FAM_CONV, s);
-  if (nt == 2)
-    hipLaunchKernelGGL((conv_igemm_kernel<2, MT>), grid, dim3(256), 0, s, p);
-  else
-    hipLaunchKernelGGL((conv_igemm_kernel<1, MT>), grid, dim3(256), 0, s, p);
+  if (nt == 2 && !small) hipLaunchKernelGGL((conv_igemm_kernel<2, 4>), grid, dim3(256), 0, s, p);
+  else if (nt == 2) hipLaunchKernelGGL((conv_igemm_kernel<2, 1>), grid, dim3(256), 0, s, p);
+  else if (!small) hipLaunchKernelGGL((conv_igemm_kernel<1, 4>), grid, dim3(256), 0, s, p);
+  else hipLaunchKernelGGL((conv_igemm_kernel<1, 1>), grid, dim3(256), 0, s, p);
   RTP_CHECK_LAUNCH();
   return RTP_OK;
 }
