@@ -66,10 +66,12 @@ int rtp_chan_stats(const RtpAct* a, const RtpAct* b, int n, long vox, int nsplit
  *   wf     bf16 [nw][ks^3][co_pad][ci_pad]   nw = n with norm, 1 without
  *   btab   fp32 [nw][64][co_pad]  bias for each boundary class of an output voxel
  *   mr     fp32 [n][groups][2]  (mean, rstd) saved for backward, or NULL
+ *   wd     bf16 [ks^3][ci_pad][cok] or NULL: the same (un-folded) weights packed for the data-gradient conv
+ *          (what rtp_pack_dgrad_w produces), emitted here so training needs no separate packing launch
  * Replaces GroupNorm-apply + weight layout of common.py:25-71 / hr3d.py:147-155. */
 int rtp_fold_fwd(const float* w, const float* bias, const float* gamma, const float* beta, const float* stats,
                  int nsplit, int groups, float eps, const RtpConvGeom* g, int ci_real, int co_real, void* wf,
-                 float* btab, float* mr, void* stream);
+                 float* btab, float* mr, void* wd, void* stream);
 
 /* Pack weights for the data-gradient conv: wd bf16 [ks^3][ci_pad][cok] with cok = co rounded up to 32. */
 int rtp_pack_dgrad_w(const float* w, const RtpConvGeom* g, int ci_real, int co_real, void* wd, void* stream);

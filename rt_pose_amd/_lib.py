@@ -45,7 +45,7 @@ _T = C.POINTER(RtpTerm)
 # name -> argtypes (restype int unless listed in _RESTYPE)
 PROTOTYPES = {
     "rtp_chan_stats": [_A, _A, _I, _L, _I, _P, _P],
-    "rtp_fold_fwd": [_P, _P, _P, _P, _P, _I, _I, _F, _G, _I, _I, _P, _P, _P, _P],
+    "rtp_fold_fwd": [_P, _P, _P, _P, _P, _I, _I, _F, _G, _I, _I, _P, _P, _P, _P, _P],
     "rtp_pack_dgrad_w": [_P, _G, _I, _I, _P, _P],
     "rtp_conv_igemm": [_A, _P, _I, _P, _A, _A, _G, _I, _I, _I, _P],
     "rtp_wgrad": [_A, _A, _G, _I, _P, _P],

@@ -69,11 +69,11 @@ class HipBackend:
         keep = (a, b, out)
         return lambda s: check(fn(aa, bb, n, vox, nsplit, o, s), "rtp_chan_stats") or keep and None
 
-    def fold_fwd(self, w, bias, gamma, beta, stats, nsplit, groups, eps, geom, ci_real, co_real, wf, btab, mr):
+    def fold_fwd(self, w, bias, gamma, beta, stats, nsplit, groups, eps, geom, ci_real, co_real, wf, btab, mr, wd=None):
         fn, g = self.lib.rtp_fold_fwd, _geom(geom)
         args = (_ptr(w), _ptr(bias), _ptr(gamma), _ptr(beta), _ptr(stats), nsplit, groups, eps, g, ci_real, co_real,
-                _ptr(wf), _ptr(btab), _ptr(mr))
-        keep = (w, bias, gamma, beta, stats, wf, btab, mr)
+                _ptr(wf), _ptr(btab), _ptr(mr), _ptr(wd))
+        keep = (w, bias, gamma, beta, stats, wf, btab, mr, wd)
         return lambda s: check(fn(*args, s), "rtp_fold_fwd") or keep and None
 
     def pack_dgrad_w(self, w, geom, ci_real, co_real, wd):

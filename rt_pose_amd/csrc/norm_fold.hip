@@ -90,6 +90,7 @@ struct FoldParams {
   int ci_real, co_real, ci_pad, co_pad, ntap, ks, stride, pad, ci_total, ci_off;
   int di, hi, wi, dov, ho, wo;
   bf16_t* wf; float* btab; float* mr;
+  bf16_t* wd; int cok;  // optional data-gradient packing [tap][ci_pad][cok] (written by the n == 0 blocks)
 };
 
 __device__ __forceinline__ bool tap_inb_class(int tap, int cls, const FoldParams& p) {
@@ -151,7 +152,11 @@ __global__ __launch_bounds__(256) void fold_fwd_kernel(FoldParams p) {
     const int co = co0 + col;
     float v = 0.f;
     if (ci < p.ci_real && co < p.co_real) v = p.w[((long)co * p.ci_total + p.ci_off + ci) * p.ntap + tap] * scale[ci];
-    wf[((long)tap * p.co_pad + co) * p.ci_pad + ci] = f2bf(v);
+    if (co < p.co_pad) wf[((long)tap * p.co_pad + co) * p.ci_pad + ci] = f2bf(v);
+    if (p.wd && n == 0 && co < p.cok) {  // the un-folded weights, transposed for the data-gradient conv
+      const float w0 = (ci < p.ci_real && co < p.co_real) ? p.w[((long)co * p.ci_total + p.ci_off + ci) * p.ntap + tap] : 0.f;
+      p.wd[((long)tap * p.ci_pad + ci) * p.cok + co] = f2bf(w0);
+    }
   }
   if (!p.btab) return;
   // T[col][tap] = sum_ci w*shift   (64 lanes per dot product would be overkill: ci <= 256, ntap*FOLD_COS <= 108 rows)
@@ -170,7 +175,7 @@ __global__ __launch_bounds__(256) void fold_fwd_kernel(FoldParams p) {
     if (norm)
       for (int tap = 0; tap < p.ntap; ++tap)
         if (tap_inb_class(tap, cls, p)) acc += T[col * p.ntap + tap];
-    bt[cls * p.co_pad + co] = acc;
+    if (co < p.co_pad) bt[cls * p.co_pad + co] = acc;
   }
 }
 
@@ -186,7 +191,7 @@ static int fill_fold(FoldParams& p, const RtpConvGeom* g, int ci_real, int co_re
 
 extern "C" int rtp_fold_fwd(const float* w, const float* bias, const float* gamma, const float* beta,
                             const float* stats, int nsplit, int groups, float eps, const RtpConvGeom* g, int ci_real,
-                            int co_real, void* wf, float* btab, float* mr, void* stream) {
+                            int co_real, void* wf, float* btab, float* mr, void* wd, void* stream) {
   FoldParams p;
   int rc = fill_fold(p, g, ci_real, co_real);
   if (rc) return rc;
@@ -194,12 +199,13 @@ extern "C" int rtp_fold_fwd(const float* w, const float* bias, const float* gamm
   p.w = w; p.bias = bias; p.gamma = gamma; p.beta = beta; p.stats = stats;
   p.nsplit = nsplit; p.groups = groups; p.eps = eps;
   p.wf = (bf16_t*)wf; p.btab = btab; p.mr = mr;
+  p.wd = (bf16_t*)wd; p.cok = (g->co + 31) / 32 * 32;
   const int nw = stats ? g->n : 1;
   const size_t shm = sizeof(float) * (2 * p.ci_pad + (size_t)FOLD_COS * p.ntap);
   if (p.co_pad % FOLD_COS) return RTP_ERR_UNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
   RtpProfScope prof(RTP_FAM_NORM, s);
-  hipLaunchKernelGGL(fold_fwd_kernel, dim3(nw, p.co_pad / FOLD_COS), dim3(256), shm, s, p);
+  hipLaunchKernelGGL(fold_fwd_kernel, dim3(nw, (wd ? p.cok : p.co_pad) / FOLD_COS), dim3(256), shm, s, p);
   RTP_CHECK_LAUNCH();
   return RTP_OK;
 }
@@ -392,12 +398,15 @@ struct WFoldParams {
   int groups, n; FoldParams f; int co32, csum_c; float* dw; float* dbias; int accumulate;
 };
 
+// One block per (co, tap).  A thread owns 4 input channels (one 16-B load per slab row) and one of 256/(ci/4) slab
+// groups; the (sample, split) slabs of a group are summed with the sample's GroupNorm scale applied on the fly, then the
+// groups are folded through LDS in fixed order (deterministic).
 __global__ __launch_bounds__(256) void wgrad_fold_kernel(WFoldParams p) {
   extern __shared__ __attribute__((aligned(16))) float sh[];
   const int ntap = p.f.ntap, ci_real = p.f.ci_real, ci_pad = p.f.ci_pad;
   const int co = blockIdx.x / ntap, tap = blockIdx.x - co * ntap, tid = threadIdx.x;
-  float* sdy = sh;                 // [n]
-  float* red = sdy + p.n;          // [8][ci_real]
+  float* sdy = sh;                        // [n]
+  float* red = sdy + ((p.n + 3) & ~3);    // [groups_of_slabs][ci_real]
   const bool norm = p.mr != nullptr;
   for (int n = tid; n < p.n; n += 256) {
     float acc = 0.f;
@@ -413,32 +422,45 @@ __global__ __launch_bounds__(256) void wgrad_fold_kernel(WFoldParams p) {
       for (int cls = 0; cls < 64; ++cls) acc += p.csum[((long)n * 64 + cls) * p.csum_c + co];
     if (p.accumulate) p.dbias[co] += acc; else p.dbias[co] = acc;
   }
-  const int sg = tid >> 5, l32 = tid & 31;  // slab group 0..7, channel lane
+  const int quads = ci_real >> 2;          // 8, 16, 32 or 64 (ci_real is a multiple of 32)
+  const int nsg = 256 / quads;             // slab groups
+  const int cq = tid % quads, sg = tid / quads;
   const int cg = norm ? ci_real / p.groups : 1;
-  for (int ci = l32; ci < ci_real; ci += 32) {
-    float acc = 0.f;
-    for (int n = 0; n < p.n; ++n) {
-      float g = 0.f;
-      for (int s = sg; s < p.nsplit; s += 8)
-        g += p.gp[((((long)n * p.nsplit + s) * ntap + tap) * p.co32 + co) * ci_pad + ci];
-      float sc = 1.f, sf = 0.f;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  if (sg < nsg) {
+    const int total = p.n * p.nsplit;
+    for (int i = sg; i < total; i += nsg) {
+      const int n = i / p.nsplit;
+      const f32x4 g = *reinterpret_cast<const f32x4*>(p.gp + (((long)i * ntap + tap) * p.co32 + co) * ci_pad + cq * 4);
+      f32x4 sc = {1.f, 1.f, 1.f, 1.f};
       if (norm) {
-        const int gi = ci / cg;
-        const float mu = p.mr[((long)n * p.groups + gi) * 2], r = p.mr[((long)n * p.groups + gi) * 2 + 1];
-        sc = r * p.gamma[ci];
-        sf = p.beta[ci] - mu * sc;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int ci = cq * 4 + j, gi = ci / cg;
+          sc[j] = p.mr[((long)n * p.groups + gi) * 2 + 1] * p.gamma[ci];
+        }
       }
-      acc += sc * g + (sg == 0 ? sf * sdy[n] : 0.f);
+      acc += sc * g;
     }
-    red[sg * ci_real + ci] = acc;
+    if (norm && sg == 0) {
+      for (int n = 0; n < p.n; ++n) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int ci = cq * 4 + j, gi = ci / cg;
+          const float mu = p.mr[((long)n * p.groups + gi) * 2], r = p.mr[((long)n * p.groups + gi) * 2 + 1];
+          acc[j] += (p.beta[ci] - mu * r * p.gamma[ci]) * sdy[n];
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) red[sg * ci_real + cq * 4 + j] = acc[j];
   }
   __syncthreads();
   for (int ci = tid; ci < ci_real; ci += 256) {
-    float acc = 0.f;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) acc += red[k * ci_real + ci];
+    float a = 0.f;
+    for (int k = 0; k < nsg; ++k) a += red[k * ci_real + ci];
     float* o = p.dw + ((long)co * p.f.ci_total + p.f.ci_off + ci) * ntap + tap;
-    if (p.accumulate) *o += acc; else *o = acc;
+    if (p.accumulate) *o += a; else *o = a;
   }
 }
 
@@ -452,7 +474,8 @@ extern "C" int rtp_wgrad_fold(const float* gp, int nsplit, const float* csum, co
   p.gp = gp; p.nsplit = nsplit; p.csum = csum; p.mr = mr; p.gamma = gamma; p.beta = beta;
   p.groups = groups; p.n = g->n; p.co32 = (g->co + 31) / 32 * 32; p.csum_c = p.co32;
   p.dw = dw; p.dbias = dbias; p.accumulate = accumulate;
-  const size_t shm = sizeof(float) * ((size_t)p.n + 8 * (size_t)ci_real);
+  if (ci_real % 32 || ci_real > 256) return RTP_ERR_UNSUPPORTED;
+  const size_t shm = sizeof(float) * ((size_t)((p.n + 3) & ~3) + (size_t)(256 / (ci_real / 4)) * ci_real);
   hipStream_t s = (hipStream_t)stream;
   RtpProfScope prof(RTP_FAM_NORM, s);
   hipLaunchKernelGGL(wgrad_fold_kernel, dim3(co_real * p.f.ntap), dim3(256), shm, s, p);

@@ -260,8 +260,11 @@ class ConvOp:
         self.wf = be.alloc((nw, ntap, ge.co, ge.ci), "bf16")
         need_btab = bool(self.gn) or bias is not None
         self.btab = be.alloc((nw, 64, ge.co), "f32") if need_btab else None
+        # training plans also get the data-gradient packing of the same weights out of this launch
+        need_dgrad = g.train and (self.x.needs_grad or bool(self.gn))
+        self.wd = be.alloc((ntap, ge.ci, pad_to(ge.co, 32)), "bf16") if need_dgrad else None
         g.fwd.append(be.fold_fwd(w, bias, gamma, beta, stats, self.x.stats_split if self.gn else 0, self.groups, GN_EPS,
-                                 ge, self.ci_real, self.co_real, self.wf, self.btab, self.mr))
+                                 ge, self.ci_real, self.co_real, self.wf, self.btab, self.mr, self.wd))
         g.fwd.append(be.conv(self.x, self.wf, nw > 1, self.btab, self.residual, self.y, ge, self.relu, False,
                              self.out_fp32))
         self.alg_flops = 2 * g.n * ge.do * ge.ho * ge.wo * self.co_real * self.ci_real * ntap
@@ -281,8 +284,7 @@ class ConvOp:
         if x.needs_grad or self.gn:
             cok = pad_to(ge.co, 32)
             assert gy.c >= cok, (self.name, gy.c, cok)
-            wd = be.alloc((ge.ks ** 3, ge.ci, cok), "bf16")
-            g.bwd.append(be.pack_dgrad_w(w, ge, self.ci_real, self.co_real, wd))
+            wd = self.wd
             dxh_buf = be.alloc((g.n, x.d, x.h, x.w, ge.ci), "bf16")
             dxh = View(dxh_buf, g.n, x.d, x.h, x.w, ge.ci, 0, ge.ci)
             g.bwd.append(be.conv(gy, wd, False, None, None, dxh, ge, False, True, False))

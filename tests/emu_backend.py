@@ -90,8 +90,12 @@ class EmuBackend:
                 out[:, i, :, 1] = (x[:, v0:v1] * y[:, v0:v1]).sum(1)
         return run
 
-    def fold_fwd(self, w, bias, gamma, beta, stats, nsplit, groups, eps, geom, ci_real, co_real, wf, btab, mr):
+    def fold_fwd(self, w, bias, gamma, beta, stats, nsplit, groups, eps, geom, ci_real, co_real, wf, btab, mr, wd=None):
+        pack = self.pack_dgrad_w(w, geom, ci_real, co_real, wd) if wd is not None else None
+
         def run(s):
+            if pack is not None:
+                pack(s)
             g = geom
             ntap = g.ks ** 3
             cit = g.w_ci_total or ci_real

@@ -221,6 +221,13 @@ def test_fold_and_wgrad_fold(hip, ci, co_real, ks, stride, norm, bias, dims, slc
         EMU.fold_fwd(w32.c, g_(b32, "c"), g_(gam, "c"), g_(bet, "c"), g_(stats, "c"), nsplit, groups, 1e-5, geom, ci, co_real, wf.c, bt.c, g_(mr, "c")),
         hip.fold_fwd(w32.g, g_(b32, "g"), g_(gam, "g"), g_(bet, "g"), g_(stats, "g"), nsplit, groups, 1e-5, geom, ci, co_real, wf.g, bt.g, g_(mr, "g")))
     check(wf, BF, "fold wf")
+    # the optional data-gradient packing out of the same launch equals rtp_pack_dgrad_w
+    cok = pad_to(co, 32)
+    wd1, wd2 = Pair(hip, torch.zeros(ntap, ci, cok, dtype=torch.bfloat16)), Pair(hip, torch.ones(ntap, ci, cok, dtype=torch.bfloat16))
+    hip.pack_dgrad_w(w32.g, geom, ci, co_real, wd1.g)(hip.stream())
+    hip.fold_fwd(w32.g, g_(b32, "g"), g_(gam, "g"), g_(bet, "g"), g_(stats, "g"), nsplit, groups, 1e-5, geom, ci, co_real, wf.g, bt.g, g_(mr, "g"), wd2.g)(hip.stream())
+    torch.cuda.synchronize()
+    assert torch.equal(wd1.sync_back(), wd2.sync_back())
     check(bt, F32 * 5, "fold btab")
     if norm:
         check(mr, F32, "fold mr")
