@@ -96,6 +96,8 @@ int rtp_wgrad_nsplit(const RtpConvGeom* g);
 /* Per boundary-class channel sums of an output-side gradient: out fp32 [n][64][c];
  * scratch fp32 [n][nsplit][64][c] (row-split partials, reduced in fixed order). */
 int rtp_class_sums(const RtpAct* gy, int n, int d, int h, int w, int nsplit, float* scratch, float* out, void* stream);
+/* Fixed-order reduction of class-sum partials [n][nsplit][64][c] -> out [n][64][c]. */
+int rtp_class_sums_reduce(const float* scratch, int nsplit, int n, int c, float* out, void* stream);
 
 /* Finish the weight gradient: reduce slabs, undo the GroupNorm fold, write reference-layout fp32 grads.
  *   dw[co][ci][tap] (+)= sum_n scale[n][ci] * sum_s gp + shift[n][ci] * sum_{classes where tap in-bounds} csum[n][cls][co]
@@ -121,6 +123,11 @@ typedef struct RtpTerm {
 /* out = mask(relu_src > 0) * sum_k term_k ; GN terms evaluate A*dxhat + B*x + C.  All same resolution. */
 int rtp_grad_combine(const RtpTerm* terms /*host*/, int nterms, const RtpAct* x, const RtpAct* relu_src,
                      const RtpAct* out, int n, long vox, void* stream);
+/* Same combine, plus per-boundary-class channel partial sums of the result written to cls_scratch fp32
+ * [n][nsplit][64][c] (rows of (z,y) split nsplit ways; reduce with rtp_class_sums_reduce).  Saves the separate
+ * rtp_class_sums scan of a gradient tensor this call produces.  c <= 64. */
+int rtp_grad_combine_cls(const RtpTerm* terms /*host*/, int nterms, const RtpAct* x, const RtpAct* relu_src,
+                         const RtpAct* out, int n, int d, int h, int w, int nsplit, float* cls_scratch, void* stream);
 
 /* out = (relu) sum_k up(term_k): trilinear align_corners=True upsample for terms whose dims differ
  * (hr3d.py:205-229, hrnet3d.py:37-39). bias fp32 [c] or NULL. */

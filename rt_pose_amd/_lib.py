@@ -51,9 +51,11 @@ PROTOTYPES = {
     "rtp_wgrad": [_A, _A, _G, _I, _P, _P],
     "rtp_wgrad_nsplit": [_G],
     "rtp_class_sums": [_A, _I, _I, _I, _I, _I, _P, _P, _P],
+    "rtp_class_sums_reduce": [_P, _I, _I, _I, _P, _P],
     "rtp_wgrad_fold": [_P, _I, _P, _P, _P, _P, _I, _G, _I, _I, _P, _P, _I, _P],
     "rtp_gn_bwd_coeffs": [_P, _I, _P, _P, _I, _I, _I, _L, _P, _P, _P, _I, _P],
     "rtp_grad_combine": [_T, _I, _A, _A, _A, _I, _L, _P],
+    "rtp_grad_combine_cls": [_T, _I, _A, _A, _A, _I, _I, _I, _I, _I, _P, _P],
     "rtp_fuse_sum": [_T, _I, _P, _A, _I, _I, _I, _I, _I, _P],
     "rtp_upsample_bwd": [_A, _I, _I, _I, _A, _I, _I, _I, _I, _P, _P],
     "rtp_upsample_bwd_scratch_floats": [_I] * 8,

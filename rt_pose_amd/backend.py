@@ -104,6 +104,12 @@ class HipBackend:
         keep = (gy, scratch, out)
         return lambda s: check(fn(*args, s), "rtp_class_sums") or keep and None
 
+    def class_sums_reduce(self, scratch, nsplit, n, c, out):
+        fn = self.lib.rtp_class_sums_reduce
+        args = (_ptr(scratch), nsplit, n, c, _ptr(out))
+        keep = (scratch, out)
+        return lambda s: check(fn(*args, s), "rtp_class_sums_reduce") or keep and None
+
     def wgrad_fold(self, gp, nsplit, csum, mr, gamma, beta, groups, geom, ci_real, co_real, dw, dbias, acc):
         fn, g = self.lib.rtp_wgrad_fold, _geom(geom)
         args = (_ptr(gp), nsplit, _ptr(csum), _ptr(mr), _ptr(gamma), _ptr(beta), groups, g, ci_real, co_real,
@@ -129,11 +135,23 @@ class HipBackend:
             arr[i].d, arr[i].h, arr[i].w = (v.d, v.h, v.w) if with_dims else (0, 0, 0)
         return arr
 
-    def grad_combine(self, terms, x, relu_src, out):
-        fn, arr = self.lib.rtp_grad_combine, self._terms(terms, False)
+    def grad_combine(self, terms, x, relu_src, out, cls=None):
+        """cls = (nsplit, scratch): also emit per-boundary-class partial sums of the result (rtp_grad_combine_cls)."""
+        arr = self._terms(terms, False)
+        if cls is not None:
+            fn = self.lib.rtp_grad_combine_cls
+            args = (arr, len(terms), _act(x), _act(relu_src), _act(out), out.n, out.d, out.h, out.w, cls[0], _ptr(cls[1]))
+            keep = (terms, x, relu_src, out, cls)
+            return lambda s: check(fn(*args, s), "rtp_grad_combine_cls") or keep and None
+        fn = self.lib.rtp_grad_combine
         args = (arr, len(terms), _act(x), _act(relu_src), _act(out), out.n, out.vox)
         keep = (terms, x, relu_src, out)
         return lambda s: check(fn(*args, s), "rtp_grad_combine") or keep and None
+
+    @staticmethod
+    def grad_combine_cls_ok(c):
+        """Channel counts rtp_grad_combine_cls accepts."""
+        return c <= 64 and c % 8 == 0 and 64 % (c // 8) == 0
 
     def fuse_sum(self, terms, bias, out, relu):
         fn, arr = self.lib.rtp_fuse_sum, self._terms(terms, True)

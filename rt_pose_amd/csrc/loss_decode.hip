@@ -8,7 +8,7 @@
 #include "rtp_common.h"
 #include "rtp_prof.h"
 
-#define FOCAL_BPS 64  // blocks per sample
+#define FOCAL_BPS 320  // blocks per sample
 extern "C" int rtp_focal_blocks(void) { return FOCAL_BPS; }
 
 struct FocalParams {
@@ -16,19 +16,30 @@ struct FocalParams {
   const long long* cat; int n, ncls, m; long vox; float gscale; float* scratch; bf16_t* g; int g_cs, g_co, g_c;
 };
 
+// Thread per voxel (the fp32 NCDHW targets are then coalesced across lanes); a lane reads its voxel's logits as
+// 16-B vectors and writes the padded bf16 gradient row as 16-B vectors.  The positives that fall into a block's voxel
+// range (usually none) are listed once per block, in index order, so the per-voxel work has no loop over objects.
 __global__ __launch_bounds__(256) void focal_kernel(FocalParams p) {
-  __shared__ long long s_ind[64];
-  __shared__ int s_cat[64];
-  __shared__ float s_msk[64];
+  __shared__ int s_pv[64], s_pc[64];
+  __shared__ float s_pm[64];
+  __shared__ int s_np;
   __shared__ float s_npos;
-  __shared__ float red[256 * 2];
+  __shared__ float red[8 * 2];
   const int n = blockIdx.y, tid = threadIdx.x;
-  if (tid < p.m) {
-    s_ind[tid] = p.ind[(long)n * p.m + tid];
-    s_cat[tid] = (int)p.cat[(long)n * p.m + tid];
-    s_msk[tid] = p.mask[(long)n * p.m + tid] ? 1.f : 0.f;
-  }
+  const long vps = (p.vox + gridDim.x - 1) / gridDim.x;
+  const long v0 = blockIdx.x * vps, v1 = (v0 + vps < p.vox) ? v0 + vps : p.vox;
   if (tid == 0) {
+    int k = 0;
+    for (int i = 0; i < p.m; ++i) {
+      const long long v = p.ind[(long)n * p.m + i];
+      if (v >= v0 && v < v1) {
+        s_pv[k] = (int)(v - v0); s_pc[k] = (int)p.cat[(long)n * p.m + i];
+        s_pm[k] = p.mask[(long)n * p.m + i] ? 1.f : 0.f; ++k;
+      }
+    }
+    s_np = k;
+  }
+  if (tid == 64) {
     float np = 0.f;
     for (int i = 0; i < p.n * p.m; ++i) np += p.mask[i] ? 1.f : 0.f;
     s_npos = np;
@@ -36,65 +47,90 @@ __global__ __launch_bounds__(256) void focal_kernel(FocalParams p) {
   __syncthreads();
   const float denom = s_npos > 0.f ? s_npos : 1.f;
   const float gs = -p.gscale / denom;
-  const long vps = (p.vox + gridDim.x - 1) / gridDim.x;
-  const long v0 = blockIdx.x * vps, v1 = (v0 + vps < p.vox) ? v0 + vps : p.vox;
+  const int npos = s_np;
   float negsum = 0.f, possum = 0.f;
   for (long v = v0 + tid; v < v1; v += 256) {
     const float* lg = p.logits + ((long)n * p.vox + v) * p.cpad;
     bf16_t* gout = p.g + ((long)n * p.vox + v) * p.g_cs + p.g_co;
-    for (int c = 0; c < p.g_c; ++c) {
-      float grad = 0.f;
-      if (c < p.ncls) {
-        const float zl = lg[c];
-        const float praw = 1.f / (1.f + expf(-zl));
-        const bool inside = (praw >= 1e-4f) && (praw <= 1.f - 1e-4f);
-        const float pc = fminf(fmaxf(praw, 1e-4f), 1.f - 1e-4f);
-        const float gt = p.target[((long)n * p.ncls + c) * p.vox + v];
-        float w = 1.f - gt; w = w * w; w = w * w;
-        const float l1p = logf(1.f - pc);
-        negsum += l1p * pc * pc * w;
-        float dldp = (-pc * pc / (1.f - pc) + 2.f * pc * l1p) * w;
-        for (int k = 0; k < p.m; ++k)
-          if (s_ind[k] == v && s_cat[k] == c) {
-            const float lp = logf(pc), omp = 1.f - pc;
-            possum += lp * omp * omp * s_msk[k];
-            dldp += (omp * omp / pc - 2.f * omp * lp) * s_msk[k];
-          }
-        grad = inside ? gs * dldp * praw * (1.f - praw) : 0.f;
+    const float* tg = p.target + (long)n * p.ncls * p.vox + v;
+    const int vrel = (int)(v - v0);
+    for (int c8 = 0; c8 < p.g_c; c8 += 8) {
+      float z[8], gt[8];
+      bf16x8 o;
+      if (c8 < p.cpad) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(lg + c8), b = *reinterpret_cast<const f32x4*>(lg + c8 + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { z[j] = a[j]; z[4 + j] = b[j]; }
       }
-      gout[c] = f2bf(grad);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) gt[j] = (c8 + j < p.ncls) ? tg[(long)(c8 + j) * p.vox] : 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int c = c8 + j;
+        float grad = 0.f;
+        if (c < p.ncls) {
+          const float praw = __frcp_rn(1.f + __expf(-z[j]));
+          const bool inside = (praw >= 1e-4f) && (praw <= 1.f - 1e-4f);
+          const float pc = fminf(fmaxf(praw, 1e-4f), 1.f - 1e-4f);
+          float w = 1.f - gt[j]; w = w * w; w = w * w;
+          const float omp = 1.f - pc;
+          const float l1p = __logf(omp);
+          negsum += l1p * pc * pc * w;
+          float dldp = (-pc * pc * __frcp_rn(omp) + 2.f * pc * l1p) * w;
+          for (int k = 0; k < npos; ++k)
+            if (s_pv[k] == vrel && s_pc[k] == c) {
+              const float lp = __logf(pc);
+              possum += lp * omp * omp * s_pm[k];
+              dldp += (omp * omp * __frcp_rn(pc) - 2.f * omp * lp) * s_pm[k];
+            }
+          grad = inside ? gs * dldp * praw * (1.f - praw) : 0.f;
+        }
+        o[j] = f2bf(grad);
+      }
+      st_bf16x8(gout + c8, o);
     }
   }
-  red[tid] = negsum; red[256 + tid] = possum;
+  // fixed-order block reduction: lanes of a wave by xor-shuffle, then the 4 waves in order
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { negsum += __shfl_xor(negsum, o, 64); possum += __shfl_xor(possum, o, 64); }
+  if ((tid & 63) == 0) { red[(tid >> 6) * 2] = negsum; red[(tid >> 6) * 2 + 1] = possum; }
+  __syncthreads();
+  if (tid == 0) {
+    float* sc = p.scratch + ((long)n * gridDim.x + blockIdx.x) * 2;
+    sc[0] = (red[0] + red[2]) + (red[4] + red[6]); sc[1] = (red[1] + red[3]) + (red[5] + red[7]);
+  }
+}
+
+__global__ __launch_bounds__(256) void focal_final(const float* scratch, int nparts, const unsigned char* mask, int nm,
+                                                   float* out) {
+  __shared__ float red[256 * 2];
+  const int tid = threadIdx.x;
+  float neg = 0.f, pos = 0.f;
+  for (int i = tid; i < nparts; i += 256) { neg += scratch[2 * i]; pos += scratch[2 * i + 1]; }
+  red[tid] = neg; red[256 + tid] = pos;
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) {
     if (tid < o) { red[tid] += red[tid + o]; red[256 + tid] += red[256 + tid + o]; }
     __syncthreads();
   }
   if (tid == 0) {
-    float* sc = p.scratch + ((long)n * gridDim.x + blockIdx.x) * 2;
-    sc[0] = red[0]; sc[1] = red[256];
+    float np = 0.f;
+    for (int i = 0; i < nm; ++i) np += mask[i] ? 1.f : 0.f;
+    out[0] = (np == 0.f) ? -red[0] : -(red[256] + red[0]) / np;
   }
-}
-
-__global__ void focal_final(const float* scratch, int nparts, const unsigned char* mask, int nm, float* out) {
-  if (threadIdx.x != 0) return;
-  float neg = 0.f, pos = 0.f, np = 0.f;
-  for (int i = 0; i < nparts; ++i) { neg += scratch[2 * i]; pos += scratch[2 * i + 1]; }
-  for (int i = 0; i < nm; ++i) np += mask[i] ? 1.f : 0.f;
-  out[0] = (np == 0.f) ? -neg : -(pos + neg) / np;
 }
 
 extern "C" int rtp_focal_loss(const float* logits, int cpad, const float* target, const long long* ind,
                               const unsigned char* mask, const long long* cat, int n, int ncls, long vox, int m,
                               float gscale, float* scratch, float* out_loss, const RtpAct* ghm, void* stream) {
   if (!logits || !target || !ghm || m > 64 || ncls > cpad || ncls > ghm->c) return RTP_ERR_SHAPE;
+  if ((cpad % 8) || (ghm->c % 8) || (ghm->cs % 8) || (ghm->co % 8)) return RTP_ERR_ALIGN;
   FocalParams p{logits, cpad, target, ind, mask, cat, n, ncls, m, vox, gscale, scratch,
                 (bf16_t*)ghm->ptr, ghm->cs, ghm->co, ghm->c};
   hipStream_t s = (hipStream_t)stream;
   RtpProfScope prof(RTP_FAM_LOSS, s);
   hipLaunchKernelGGL(focal_kernel, dim3(FOCAL_BPS, n), dim3(256), 0, s, p);
-  hipLaunchKernelGGL(focal_final, dim3(1), dim3(64), 0, s, scratch, n * FOCAL_BPS, mask, n * m, out_loss);
+  hipLaunchKernelGGL(focal_final, dim3(1), dim3(256), 0, s, scratch, n * FOCAL_BPS, mask, n * m, out_loss);
   RTP_CHECK_LAUNCH();
   return RTP_OK;
 }

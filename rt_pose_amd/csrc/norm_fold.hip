@@ -390,6 +390,17 @@ extern "C" int rtp_class_sums(const RtpAct* gy, int n, int d, int h, int w, int 
   return RTP_OK;
 }
 
+extern "C" int rtp_class_sums_reduce(const float* scratch, int nsplit, int n, int c, float* out, void* stream) {
+  if (!scratch || !out || nsplit < 1) return RTP_ERR_SHAPE;
+  if (c % 8) return RTP_ERR_ALIGN;
+  hipStream_t s = (hipStream_t)stream;
+  RtpProfScope prof(RTP_FAM_NORM, s);
+  const long total = (long)n * 64 * c;  // multiple of 256
+  hipLaunchKernelGGL(class_sums_final, dim3((int)(total / 256)), dim3(256), 0, s, scratch, nsplit, 64 * c, out);
+  RTP_CHECK_LAUNCH();
+  return RTP_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // rtp_wgrad_fold : one block per (co, tap); 8 slab groups x 32 input channels per pass
 // ------------------------------------------------------------------------------------------------

@@ -87,6 +87,153 @@ extern "C" int rtp_grad_combine(const RtpTerm* terms, int nterms, const RtpAct* 
 }
 
 // ------------------------------------------------------------------------------------------------
+// rtp_grad_combine_cls : the same combine, plus per-boundary-class channel sums of the (bf16-rounded) result, so the
+// weight-gradient un-fold needs no separate scan of the gradient tensor.  One wave per x-row: the (z,y) flags are
+// row-uniform and only x==0 / x==W-1 differ, so a lane keeps three register sets (interior / first / last) that are
+// flushed into the wave's own LDS slice when the row class changes -- no atomics, fixed summation order.
+// GroupNorm-backward coefficients of the block's sample sit in LDS.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void grad_combine_cls_kernel(CombParams p, int D, int H, int W, int nsplit,
+                                                               float* part) {
+  extern __shared__ __attribute__((aligned(16))) float cls_lds[];  // [4][64][c] class sums, then [nterms][c][3] coeffs
+  const int n = blockIdx.y, s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = p.c, cpv = c >> 3, chunk = lane % cpv;
+  float* mine = cls_lds + wave * 64 * c;
+  float* cfs = cls_lds + 4 * 64 * c;
+  for (int i = tid; i < 4 * 64 * c; i += 256) cls_lds[i] = 0.f;
+  for (int k = 0; k < p.nterms; ++k)
+    if (p.terms[k].coeff)
+      for (int i = tid; i < c * 3; i += 256) cfs[k * c * 3 + i] = p.terms[k].coeff[(long)n * c * 3 + i];
+  __syncthreads();
+  const long vox = (long)D * H * W;
+  const int rows = D * H;
+  const int rps = (rows + nsplit - 1) / nsplit;
+  const int r0 = s * rps, r1 = (r0 + rps < rows) ? r0 + rps : rows;
+  const int items = W * cpv;
+  float a_in[8], a_f[8], a_l[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) a_in[j] = a_f[j] = a_l[j] = 0.f;
+  int cur = -1;
+  auto flush = [&](int czy) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      for (int o = 32; o >= cpv; o >>= 1) {
+        a_in[j] += __shfl_xor(a_in[j], o, 64);
+        a_f[j] += __shfl_xor(a_f[j], o, 64);
+        a_l[j] += __shfl_xor(a_l[j], o, 64);
+      }
+    if (lane < cpv) {
+      const int cf = czy | (1 << 4) | ((W == 1) << 5), cl = czy | (1 << 5);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        mine[czy * c + chunk * 8 + j] += a_in[j];
+        mine[cf * c + chunk * 8 + j] += a_f[j];
+        if (W > 1) mine[cl * c + chunk * 8 + j] += a_l[j];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a_in[j] = a_f[j] = a_l[j] = 0.f;
+  };
+  for (int r = r0 + wave; r < r1; r += 4) {
+    const int z = r / H, y = r - z * H;
+    const int czy = (z == 0) | ((z == D - 1) << 1) | ((y == 0) << 2) | ((y == H - 1) << 3);
+    if (czy != cur) {
+      if (cur >= 0) flush(cur);
+      cur = czy;
+    }
+    const long vrow = (long)n * vox + (long)r * W;
+    for (int i = lane; i < items; i += 64) {
+      const int x = i / cpv;
+      const long vv = vrow + x;
+      float acc[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+      bf16x8 xv = zero_bf16x8();
+      bool have_x = false;
+#pragma unroll
+      for (int k = 0; k < RTP_MAX_TERMS; ++k) {
+        if (k >= p.nterms) break;
+        const CombTerm& t = p.terms[k];
+        bf16x8 tv = ld_bf16x8(t.t + vv * t.cs + t.co + chunk * 8);
+        if (t.coeff) {
+          if (!have_x) { xv = ld_bf16x8(p.x + vv * p.x_cs + p.x_co + chunk * 8); have_x = true; }
+          const float* cf = cfs + (k * c + chunk * 8) * 3;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc[j] += cf[j * 3] * bf2f(tv[j]) + cf[j * 3 + 1] * bf2f(xv[j]) + cf[j * 3 + 2];
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc[j] += bf2f(tv[j]);
+        }
+      }
+      if (p.relu) {
+        bf16x8 rv = ld_bf16x8(p.relu + vv * p.r_cs + p.r_co + chunk * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = bf2f(rv[j]) > 0.f ? acc[j] : 0.f;
+      }
+      bf16x8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = f2bf(acc[j]);
+      st_bf16x8(p.out + vv * p.o_cs + p.o_co + chunk * 8, o);
+      const bool first = (x == 0), last = (x == W - 1) && !first;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float v = bf2f(o[j]);
+        a_f[j] += first ? v : 0.f;
+        a_l[j] += last ? v : 0.f;
+        a_in[j] += (first || last) ? 0.f : v;
+      }
+    }
+  }
+  if (cur >= 0) flush(cur);
+  __syncthreads();
+  float* o = part + ((long)n * nsplit + s) * 64 * c;
+  for (int i = tid; i < 64 * c; i += 256)
+    o[i] = (cls_lds[i] + cls_lds[64 * c + i]) + (cls_lds[2 * 64 * c + i] + cls_lds[3 * 64 * c + i]);
+}
+
+static int comb_params(CombParams& p, const RtpTerm* terms, int nterms, const RtpAct* x, const RtpAct* relu_src,
+                       const RtpAct* out) {
+  if (!terms || nterms < 1 || nterms > RTP_MAX_TERMS || !out) return RTP_ERR_SHAPE;
+  p.nterms = nterms;
+  p.c = out->c;
+  if (p.c % 8 || (out->cs % 8) || (out->co % 8)) return RTP_ERR_ALIGN;
+  bool need_x = false;
+  for (int k = 0; k < nterms; ++k) {
+    if (terms[k].t.c != p.c || (terms[k].t.cs % 8) || (terms[k].t.co % 8)) return RTP_ERR_ALIGN;
+    p.terms[k] = CombTerm{(const bf16_t*)terms[k].t.ptr, terms[k].t.cs, terms[k].t.co, terms[k].coeff};
+    need_x |= terms[k].coeff != nullptr;
+  }
+  if (need_x && (!x || (x->cs % 8) || (x->co % 8))) return RTP_ERR_SHAPE;
+  p.x = x ? (const bf16_t*)x->ptr : nullptr; p.x_cs = x ? x->cs : 0; p.x_co = x ? x->co : 0;
+  p.relu = relu_src ? (const bf16_t*)relu_src->ptr : nullptr;
+  p.r_cs = relu_src ? relu_src->cs : 0; p.r_co = relu_src ? relu_src->co : 0;
+  p.out = (bf16_t*)out->ptr; p.o_cs = out->cs; p.o_co = out->co;
+  return RTP_OK;
+}
+
+extern "C" int rtp_grad_combine_cls(const RtpTerm* terms, int nterms, const RtpAct* x, const RtpAct* relu_src,
+                                    const RtpAct* out, int n, int d, int h, int w, int nsplit, float* cls_scratch,
+                                    void* stream) {
+  CombParams p;
+  int rc = comb_params(p, terms, nterms, x, relu_src, out);
+  if (rc != RTP_OK) return rc;
+  if (!cls_scratch || nsplit < 1) return RTP_ERR_SHAPE;
+  if (p.c > 64 || (64 % (p.c / 8))) return RTP_ERR_UNSUPPORTED;
+  p.n = n; p.vox = (long)d * h * w;
+  hipStream_t s = (hipStream_t)stream;
+  RtpProfScope prof(RTP_FAM_POINTWISE, s);
+  const size_t lds = sizeof(float) * (4 * 64 * p.c + RTP_MAX_TERMS * p.c * 3);
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)grad_combine_cls_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(grad_combine_cls_kernel, dim3(nsplit, n), dim3(256), lds, s, p, d, h, w, nsplit, cls_scratch);
+  RTP_CHECK_LAUNCH();
+  return RTP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // rtp_fuse_sum : trilinear align_corners=True, PyTorch index rule (upsample_trilinear3d)
 // ------------------------------------------------------------------------------------------------
 struct FuseTerm { const bf16_t* t; int cs, co, d, h, w; };

@@ -83,11 +83,16 @@ class Act(View):
         self.stats_split = 0
         self.contribs = []         # list of (View, coeff tensor | None)
         self.grad: Optional[View] = None
+        self.grad_cls = None       # (nsplit, partial class sums of .grad) when grad_combine emitted them
         self.producer = None
 
 
 def stats_split(vox):
     return max(1, min(64, (vox + 1023) // 1024))
+
+
+def cls_split(d, h):
+    return max(1, min(64, (d * h + 3) // 4))
 
 
 def wgrad_split(vox):
@@ -192,7 +197,9 @@ class Graph:
         """Declare the gradient of a graph output (already scaled; written by a loss kernel or by autograd)."""
         y.contribs.append((gview, None))
 
-    def finalize_grad(self, t: Act):
+    def finalize_grad(self, t: Act, want_cls=False):
+        """want_cls: the consumer needs per-boundary-class sums of this gradient (ConvOp with bias / GroupNorm);
+        when a grad_combine launch produces the tensor anyway, it emits them in the same pass."""
         if not t.contribs:
             return None
         if len(t.contribs) == 1 and t.contribs[0][1] is None and not t.relu:
@@ -210,14 +217,20 @@ class Graph:
             if not first:
                 chunk = [(t.grad, None)] + chunk
             last = not terms
-            self.bwd.append(self.be.grad_combine(chunk, t if need_x else None, t if (t.relu and last) else None, t.grad))
+            cls = None
+            if last and want_cls and self.be.grad_combine_cls_ok(c):
+                nsplit = cls_split(t.d, t.h)
+                cls = (nsplit, self.be.alloc((self.n, nsplit, 64, c), "f32"))
+                t.grad_cls = cls
+            self.bwd.append(self.be.grad_combine(chunk, t if need_x else None, t if (t.relu and last) else None, t.grad,
+                                                 cls))
             first = False
         return t.grad
 
     def build_backward(self):
         assert self.train
         for op in reversed(self.ops):
-            gy = self.finalize_grad(op.y)
+            gy = self.finalize_grad(op.y, isinstance(op, ConvOp) and bool(op.gn or op.bname))
             if gy is None:
                 continue
             op.emit_backward(gy)
@@ -316,10 +329,14 @@ class ConvOp:
         g.flops["wgrad_tiled" if self.tiled_wgrad else "wgrad_generic"] += self.alg_flops
         csum = None
         if self.gn or self.bname:
-            cs_split = max(1, min(64, (gy.d * gy.h + 3) // 4))
             csum = be.alloc((g.n, 64, gy.c), "f32")
-            cs_scratch = be.alloc((g.n, cs_split, 64, gy.c), "f32")
-            g.bwd.append(side(be.class_sums(gy, cs_split, cs_scratch, csum)))
+            if self.y.grad_cls is not None and self.y.grad is gy:
+                cs_split, cs_scratch = self.y.grad_cls
+                g.bwd.append(side(be.class_sums_reduce(cs_scratch, cs_split, g.n, gy.c, csum)))
+            else:
+                cs_split = cls_split(gy.d, gy.h)
+                cs_scratch = be.alloc((g.n, cs_split, 64, gy.c), "f32")
+                g.bwd.append(side(be.class_sums(gy, cs_split, cs_scratch, csum)))
         g.bwd.append(side(be.wgrad_fold(gp, S, csum, self.mr, g.params[self.gn[0]] if self.gn else None,
                                         g.params[self.gn[1]] if self.gn else None, self.groups, ge, self.ci_real,
                                         self.co_real, g.pgrad[self.wname],

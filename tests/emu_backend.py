@@ -261,7 +261,16 @@ class EmuBackend:
         return run
 
     # ---------------------------------------------------------------- point-wise family
-    def grad_combine(self, terms, x, relu_src, out):
+    @staticmethod
+    def grad_combine_cls_ok(c):
+        return c <= 64
+
+    def class_sums_reduce(self, scratch, nsplit, n, c, out):
+        def run(s):
+            out.copy_(scratch.view(n, nsplit, 64, c).sum(1))
+        return run
+
+    def grad_combine(self, terms, x, relu_src, out, cls=None):
         def run(s):
             acc = torch.zeros(out.n, out.d, out.h, out.w, out.c)
             for v, cf in terms:
@@ -273,6 +282,11 @@ class EmuBackend:
             if relu_src is not None:
                 acc = torch.where(_sl(relu_src)[..., :out.c] > 0, acc, torch.zeros(()))
             _store(out, acc)
+            if cls is not None:   # class sums of the stored (rounded) result, all in split 0
+                nsplit, scratch = cls
+                part = scratch.view(out.n, nsplit, 64, out.c)
+                part.zero_()
+                part[:, 0].index_add_(1, _classes(out.d, out.h, out.w).reshape(-1), _sl(out).reshape(out.n, out.vox, out.c))
         return run
 
     def fuse_sum(self, terms, bias, out, relu):

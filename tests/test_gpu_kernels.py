@@ -276,6 +276,27 @@ def test_grad_combine_fuse_upsample(hip):
     op, oc, og = views(hip, torch.zeros(n, d, h, w, c, dtype=torch.bfloat16), n, d, h, w)
     run(hip, EMU.grad_combine([(t1c, None), (t2c, cf.c)], xc, xc, oc), hip.grad_combine([(t1g, None), (t2g, cf.g)], xg, xg, og))
     check(op, BF, "grad_combine")
+    # the same combine with the per-boundary-class sums fused in (incl. depth-1 / width-1 volumes, 64 channels, 2 GN terms)
+    for (dd, hh, ww), ch, ns in (((4, 8, 16), 32, 5), ((1, 6, 1), 64, 2), ((16, 8, 24), 32, 64), ((3, 5, 80), 64, 4)):
+        _, x2c, x2g = views(hip, rnd((n, dd, hh, ww, ch), 130, relu=True), n, dd, hh, ww)
+        _, a1c, a1g = views(hip, rnd((n, dd, hh, ww, ch), 131), n, dd, hh, ww)
+        _, a2c, a2g = views(hip, rnd((n, dd, hh, ww, 2 * ch), 132), n, dd, hh, ww, co=ch, c=ch)
+        _, a3c, a3g = views(hip, rnd((n, dd, hh, ww, ch), 133), n, dd, hh, ww)
+        cf2, cf3 = Pair(hip, rnd((n * ch * 5,), 134, torch.float32)), Pair(hip, rnd((n * ch * 5,), 135, torch.float32))
+        o2p, o2c, o2g = views(hip, torch.zeros(n, dd, hh, ww, ch, dtype=torch.bfloat16), n, dd, hh, ww)
+        sc_c, sc_g = torch.zeros(n, ns, 64, ch), hip.alloc((n, ns, 64, ch), "f32")
+        cs = Pair(hip, torch.ones(n, 64, ch))
+        run(hip, EMU.grad_combine([(a1c, None), (a2c, cf2.c), (a3c, cf3.c)], x2c, x2c, o2c, (ns, sc_c)),
+            hip.grad_combine([(a1g, None), (a2g, cf2.g), (a3g, cf3.g)], x2g, x2g, o2g, (ns, sc_g)))
+        check(o2p, BF, "grad_combine_cls out %r" % ((dd, hh, ww),))
+        run(hip, EMU.class_sums_reduce(sc_c, ns, n, ch, cs.c), hip.class_sums_reduce(sc_g, ns, n, ch, cs.g))
+        # the sums are of the bf16-rounded outputs, which may differ by an ulp between the two -> bf16-level tolerance
+        check(cs, BF * 2, "grad_combine_cls sums %r" % ((dd, hh, ww),))
+        # and they must equal the standalone scan of the tensor the kernel itself wrote, to fp32 accuracy
+        ref = hip.alloc((n, 64, ch), "f32")
+        hip.class_sums(o2g, 3, hip.alloc((n, 3, 64, ch), "f32"), ref)(hip.stream())
+        torch.cuda.synchronize()
+        assert rel_err(cs.g.cpu(), ref.cpu()) < F32, "fused vs standalone class sums"
     # fuse rows: same-res + three lower resolutions (the stage-4 row-0 pattern)
     lows = [((2, 4, 8), 35), ((1, 2, 4), 36), ((1, 1, 2), 37)]
     tc, tg = [t1c], [t1g]
