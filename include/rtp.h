@@ -85,6 +85,17 @@ int rtp_pack_dgrad_w(const float* w, const RtpConvGeom* g, int ci_real, int co_r
 int rtp_conv_igemm(const RtpAct* x, const void* wf, int w_per_sample, const float* btab, const RtpAct* res,
                    const RtpAct* y, const RtpConvGeom* g, int relu, int transposed, int y_fp32, void* stream);
 
+/* rtp_conv_igemm that also emits per-channel statistics of the tensor it writes, saving the rtp_chan_stats read pass:
+ * stat_out fp32 [n][S][cout][2], S = rtp_conv_stats_nsplit(...) partials per sample (reduced by the consumers exactly
+ * like rtp_chan_stats partials).  stat_x == NULL: (sum y, sum y*y) of the stored bf16 output -- what the next
+ * GroupNorm's forward needs.  stat_x != NULL (same shape as y; not together with res): (sum y, sum y*stat_x) -- P and
+ * Q of GroupNorm backward when y is the data gradient dxhat and stat_x the normalised tensor.  Only geometries for
+ * which rtp_conv_stats_nsplit() > 0 (the LDS-tiled kernel's) are accepted; others return RTP_ERR_UNSUPPORTED. */
+int rtp_conv_igemm_stats(const RtpAct* x, const void* wf, int w_per_sample, const float* btab, const RtpAct* res,
+                         const RtpAct* y, const RtpConvGeom* g, int relu, int transposed, int y_fp32,
+                         const RtpAct* stat_x, float* stat_out, void* stream);
+int rtp_conv_stats_nsplit(const RtpAct* x, const RtpConvGeom* g, int transposed);
+
 /* Weight-gradient correlation: gp[n][s][tap][co32][ci_pad] (fp32 partial slabs, s = voxel split) =
  * sum over the split's output voxels of gy[v][co] * x[v*stride + tap - pad][ci].  Replaces
  * nn.Conv3d backward-weight. */

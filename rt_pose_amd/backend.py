@@ -82,12 +82,22 @@ class HipBackend:
         keep = (w, wd)
         return lambda s: check(fn(*args, s), "rtp_pack_dgrad_w") or keep and None
 
-    def conv(self, x, wf, per_sample, btab, res, y, geom, relu, transposed, y_fp32):
-        fn, g = self.lib.rtp_conv_igemm, _geom(geom)
+    def conv(self, x, wf, per_sample, btab, res, y, geom, relu, transposed, y_fp32, stats=None):
+        """stats = (stat_x | None, out [n, S, cout, 2]) with S = conv_stats_nsplit(...) > 0: the conv also emits the
+        per-channel statistics of y (rtp_conv_igemm_stats)."""
+        g = _geom(geom)
         args = (_act(x), _ptr(wf), int(per_sample), _ptr(btab), _act(res), _act(y), g, int(relu), int(transposed),
                 int(y_fp32))
-        keep = (x, wf, btab, res, y)
+        keep = (x, wf, btab, res, y, stats)
+        if stats is not None:
+            fn = self.lib.rtp_conv_igemm_stats
+            args = args + (_act(stats[0]), _ptr(stats[1]))
+            return lambda s: check(fn(*args, s), "rtp_conv_igemm_stats") or keep and None
+        fn = self.lib.rtp_conv_igemm
         return lambda s: check(fn(*args, s), "rtp_conv_igemm") or keep and None
+
+    def conv_stats_nsplit(self, x, geom, transposed):
+        return self.lib.rtp_conv_stats_nsplit(_act(x), _geom(geom), int(transposed))
 
     def wgrad(self, gy, x, geom, nsplit, gp):
         fn, g = self.lib.rtp_wgrad, _geom(geom)

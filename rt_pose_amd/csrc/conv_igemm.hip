@@ -191,20 +191,47 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
 }
 
 int rtp_conv_tiled_try(const RtpAct* x, const void* wf, int w_per_sample, const float* btab, const RtpAct* res,
-                       const RtpAct* y, const RtpConvGeom* g, int relu, int transposed, int y_fp32, hipStream_t s);
+                       const RtpAct* y, const RtpConvGeom* g, int relu, int transposed, int y_fp32,
+                       const RtpAct* stat_x, float* stat_out, hipStream_t s);
+int rtp_conv_tiled_stat_slots(const RtpAct* x, const RtpConvGeom* g, int transposed);
+
+extern "C" int rtp_conv_stats_nsplit(const RtpAct* x, const RtpConvGeom* g, int transposed) {
+  if (!x || !g) return 0;
+  return rtp_conv_tiled_stat_slots(x, g, transposed);
+}
+
+static int conv_dispatch(const RtpAct* x, const void* wf, int w_per_sample, const float* btab, const RtpAct* res,
+                         const RtpAct* y, const RtpConvGeom* g, int relu, int transposed, int y_fp32,
+                         const RtpAct* stat_x, float* stat_out, void* stream);
 
 extern "C" int rtp_conv_igemm(const RtpAct* x, const void* wf, int w_per_sample, const float* btab, const RtpAct* res,
                               const RtpAct* y, const RtpConvGeom* g, int relu, int transposed, int y_fp32,
                               void* stream) {
+  return conv_dispatch(x, wf, w_per_sample, btab, res, y, g, relu, transposed, y_fp32, nullptr, nullptr, stream);
+}
+
+extern "C" int rtp_conv_igemm_stats(const RtpAct* x, const void* wf, int w_per_sample, const float* btab,
+                                    const RtpAct* res, const RtpAct* y, const RtpConvGeom* g, int relu, int transposed,
+                                    int y_fp32, const RtpAct* stat_x, float* stat_out, void* stream) {
+  if (!stat_out) return RTP_ERR_SHAPE;
+  if (stat_x && ((stat_x->cs % 8) || (stat_x->co % 8))) return RTP_ERR_ALIGN;
+  return conv_dispatch(x, wf, w_per_sample, btab, res, y, g, relu, transposed, y_fp32, stat_x, stat_out, stream);
+}
+
+static int conv_dispatch(const RtpAct* x, const void* wf, int w_per_sample, const float* btab, const RtpAct* res,
+                         const RtpAct* y, const RtpConvGeom* g, int relu, int transposed, int y_fp32,
+                         const RtpAct* stat_x, float* stat_out, void* stream) {
   if (!x || !y || !wf || !g) return RTP_ERR_SHAPE;
   if (g->ks != 1 && g->ks != 3) return RTP_ERR_UNSUPPORTED;
   if (g->stride != 1 && g->stride != 2) return RTP_ERR_UNSUPPORTED;
   if ((x->co % 8) || (x->cs % 8) || (y->co % 8) || (y->cs % 8)) return RTP_ERR_ALIGN;
   if (res && ((res->co % 4) || (res->cs % 4))) return RTP_ERR_ALIGN;
   {
-    const int rc = rtp_conv_tiled_try(x, wf, w_per_sample, btab, res, y, g, relu, transposed, y_fp32, (hipStream_t)stream);
+    const int rc = rtp_conv_tiled_try(x, wf, w_per_sample, btab, res, y, g, relu, transposed, y_fp32, stat_x, stat_out,
+                                      (hipStream_t)stream);
     if (rc <= 0) return rc;  // handled (or failed) by the LDS-tiled kernel
   }
+  if (stat_out) return RTP_ERR_UNSUPPORTED;  // only geometries with rtp_conv_stats_nsplit() > 0 emit statistics
   ConvParams p;
   p.x = (const bf16_t*)x->ptr;
   p.w = (const bf16_t*)wf;

@@ -14,7 +14,10 @@
 //     (up to) three output rows it contributes to (dy = 0,1,2);
 //   * both LDS images rotate the 16-B chunk index, chunk' = (chunk + 2*(x>>2)) & 3, which makes every ds_read_b128
 //     lane group hit 16 distinct 16-B slots for any tap shift (derivation in DESIGN.md).
-// Epilogue = generic kernel's: per-boundary-class bias, residual, ReLU, bf16 (or fp32) store.
+// Epilogue = generic kernel's: per-boundary-class bias, residual, ReLU, bf16 (or fp32) store -- plus, on request, the
+// per-channel statistics the next GroupNorm needs of the tensor just produced (forward: sum y, sum y^2; data gradient:
+// P = sum dxhat, Q = sum dxhat * x), accumulated in registers over the workgroup's bricks and written as one partial per
+// workgroup, which removes a separate read pass over the tensor.
 #include "rtp_common.h"
 #include "rtp_prof.h"
 
@@ -30,7 +33,8 @@
 #define STAGE_ROUNDS 1                   // 13 * 256 = 3328 >= 3264: all of a thread's loads in flight at once
 
 struct TiledParams {
-  const bf16_t* x; const bf16_t* w; const float* btab; const bf16_t* res; void* y;
+  const bf16_t* x; const bf16_t* w; const float* btab; const bf16_t* res; void* y;  // res: residual (AUX 1) or the statistics' second operand (AUX 2)
+  float* stat_out;  // [N][workgroups per sample][Co][2] or null
   int N, D, H, W, Co;  // Co = NT*16
   int y_cs, y_co, r_cs, r_co;
   int relu, y_fp32, flip, w_per_sample;
@@ -59,7 +63,8 @@ __device__ __forceinline__ void cv_sched() {
   }
 }
 
-template <int NT, bool HAS_BTAB, bool HAS_RES>
+// AUX: 0 none, 1 residual added in the epilogue, 2 second operand of the statistics (not added).  STAT: emit statistics.
+template <int NT, bool HAS_BTAB, int AUX, bool STAT>
 __global__ __launch_bounds__(512, 2) void conv_tiled_kernel(TiledParams p) {
   extern __shared__ __attribute__((aligned(16))) bf16_t lds[];
   bf16_t* wL = lds;                                   // [27][NT*16][32]
@@ -130,6 +135,9 @@ __global__ __launch_bounds__(512, 2) void conv_tiled_kernel(TiledParams p) {
   int max_tiles = (p.tiles_per_sample + p.teams_per_sample - 1) / p.teams_per_sample;  // workgroup-uniform
   const int nphase = 2 * max_tiles + 1;
   int load_k = 0, comp_k = 0;
+  float st_p[4 * NT], st_q[4 * NT];  // running per-lane statistics of this lane's 4*NT channels (STAT)
+#pragma unroll
+  for (int j = 0; j < 4 * NT; ++j) st_p[j] = st_q[j] = 0.f;
 
   for (int phase = 0; phase < nphase; ++phase) {
     const bool loading = ((phase + team) & 1) == 0;  // team-uniform (=> wave-uniform)
@@ -178,7 +186,7 @@ __global__ __launch_bounds__(512, 2) void conv_tiled_kernel(TiledParams p) {
         const long vo = vox_n + ((long)oz * p.H + (y0 + t)) * p.W + ox;
         pre_r8[t] = zero_bf16x8();
         pre_r4[t] = bf16x4{(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
-        if constexpr (HAS_RES) {  // compile-time: a runtime select per load makes hipcc branch around each one and wait vmcnt(0) early
+        if constexpr (AUX != 0) {  // compile-time: a runtime select per load makes hipcc branch around each one and wait vmcnt(0) early
           const bf16_t* rp = p.res + vo * p.r_cs + p.r_co + c0;
           if constexpr (NT == 2) pre_r8[t] = ld_bf16x8(rp);
           else pre_r4[t] = *reinterpret_cast<const bf16x4*>(rp);
@@ -256,12 +264,17 @@ __global__ __launch_bounds__(512, 2) void conv_tiled_kernel(TiledParams p) {
             for (int j = 0; j < 4; ++j) val[k + j] += bb[j];
           }
         }
+        float aux[CH];
         if constexpr (NT == 2) {
 #pragma unroll
-          for (int j = 0; j < 8; ++j) val[j] += bf2f(pre_r8[t][j]);
+          for (int j = 0; j < 8; ++j) aux[j] = bf2f(pre_r8[t][j]);
         } else {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) val[j] += bf2f(pre_r4[t][j]);
+          for (int j = 0; j < 4; ++j) aux[j] = bf2f(pre_r4[t][j]);
+        }
+        if constexpr (AUX == 1) {
+#pragma unroll
+          for (int j = 0; j < CH; ++j) val[j] += aux[j];
         }
         if (p.relu) {
 #pragma unroll
@@ -278,32 +291,100 @@ __global__ __launch_bounds__(512, 2) void conv_tiled_kernel(TiledParams p) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) o[j] = f2bf(val[j]);
             st_bf16x8(yp, o);
+            if constexpr (STAT) {
+#pragma unroll
+              for (int j = 0; j < 8; ++j) {
+                const float r = bf2f(o[j]);  // statistics of the stored (rounded) values, as a read-back pass would see
+                st_p[j] += r;
+                st_q[j] += r * (AUX == 2 ? aux[j] : r);
+              }
+            }
           } else {
             bf16x4 o;
 #pragma unroll
             for (int j = 0; j < 4; ++j) o[j] = f2bf(val[j]);
             *reinterpret_cast<bf16x4*>(yp) = o;
+            if constexpr (STAT) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                const float r = bf2f(o[j]);
+                st_p[j] += r;
+                st_q[j] += r * (AUX == 2 ? aux[j] : r);
+              }
+            }
           }
         }
       }
     }
     __syncthreads();
   }
+  if constexpr (STAT) {
+    // lanes sharing q own the same channels: fold the 16 voxel lanes, then the 8 waves in fixed order through the (now
+    // idle) halo region, one partial per workgroup
+    constexpr int CHS = 4 * NT;
+#pragma unroll
+    for (int j = 0; j < CHS; ++j)
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) {
+        st_p[j] += __shfl_xor(st_p[j], o, 64);
+        st_q[j] += __shfl_xor(st_q[j], o, 64);
+      }
+    float* red = reinterpret_cast<float*>(lds + 27 * NT * 16 * 32);  // [8 waves][Co][2]
+    if (v == 0) {
+#pragma unroll
+      for (int j = 0; j < CHS; ++j) {
+        red[(wave * p.Co + q * CHS + j) * 2] = st_p[j];
+        red[(wave * p.Co + q * CHS + j) * 2 + 1] = st_q[j];
+      }
+    }
+    __syncthreads();
+    for (int i = tid; i < p.Co * 2; i += 512) {
+      float a = 0.f;
+#pragma unroll
+      for (int w8 = 0; w8 < 8; ++w8) a += red[w8 * p.Co * 2 + i];
+      p.stat_out[((long)blockIdx.x * p.Co) * 2 + i] = a;  // blockIdx.x = n * workgroups_per_sample + workgroup
+    }
+  }
+}
+
+static bool tiled_geometry_ok(const RtpAct* x, const RtpConvGeom* g, int transposed, int* Co_out) {
+  static const bool disabled = getenv("RTP_DISABLE_TILED") != nullptr;
+  if (disabled) return false;
+  if (g->ks != 3 || g->stride != 1 || g->pad != 1) return false;
+  const int Ci = transposed ? (g->co + 31) / 32 * 32 : g->ci;
+  const int Co = transposed ? g->ci : g->co;
+  if (Ci != 32 || (Co != 16 && Co != 32)) return false;
+  if (g->di % TZ || g->hi % TY || g->wi % 16 || g->di < 2 || g->hi < 2) return false;
+  if (x->cs != 32 || x->co != 0) return false;
+  *Co_out = Co;
+  return true;
+}
+
+static int tiled_wgs_per_sample(const RtpConvGeom* g) {
+  const int tiles = (g->di / TZ) * (g->hi / TY) * ((g->wi + TX - 1) / TX);
+  int wgs = 256 / g->n;  // workgroups per sample: one workgroup per CU when N divides 256
+  if (wgs < 1) wgs = 1;
+  if (wgs * 2 > tiles) wgs = (tiles + 1) / 2;
+  return wgs;
+}
+
+// Number of per-sample statistics partials the fused epilogue writes for this conv (0: not this kernel's geometry).
+int rtp_conv_tiled_stat_slots(const RtpAct* x, const RtpConvGeom* g, int transposed) {
+  int Co;
+  return tiled_geometry_ok(x, g, transposed, &Co) ? tiled_wgs_per_sample(g) : 0;
 }
 
 // Returns RTP_OK if it handled the conv, +1 if the geometry is not this kernel's (caller falls through to the
 // generic gather kernel), or a negative error.
 int rtp_conv_tiled_try(const RtpAct* x, const void* wf, int w_per_sample, const float* btab, const RtpAct* res,
-                       const RtpAct* y, const RtpConvGeom* g, int relu, int transposed, int y_fp32, hipStream_t s) {
-  static const bool disabled = getenv("RTP_DISABLE_TILED") != nullptr;
-  if (disabled) return 1;
-  if (g->ks != 3 || g->stride != 1 || g->pad != 1) return 1;
-  const int Ci = transposed ? (g->co + 31) / 32 * 32 : g->ci;
-  const int Co = transposed ? g->ci : g->co;
-  if (Ci != 32 || (Co != 16 && Co != 32)) return 1;
-  if (g->di % TZ || g->hi % TY || g->wi % 16 || g->di < 2 || g->hi < 2) return 1;
-  if (x->cs != 32 || x->co != 0) return 1;
+                       const RtpAct* y, const RtpConvGeom* g, int relu, int transposed, int y_fp32,
+                       const RtpAct* stat_x, float* stat_out, hipStream_t s) {
+  int Co;
+  if (!tiled_geometry_ok(x, g, transposed, &Co)) return 1;
+  if (stat_out && (y_fp32 || (stat_x && res))) return RTP_ERR_UNSUPPORTED;
+  if (stat_x) res = stat_x;  // rides in the residual's prefetch slot
   TiledParams p;
+  p.stat_out = stat_out;
   p.x = (const bf16_t*)x->ptr; p.w = (const bf16_t*)wf; p.btab = btab;
   p.res = res ? (const bf16_t*)res->ptr : nullptr; p.y = y->ptr;
   p.N = g->n; p.D = g->di; p.H = g->hi; p.W = g->wi; p.Co = Co;
@@ -311,9 +392,7 @@ int rtp_conv_tiled_try(const RtpAct* x, const void* wf, int w_per_sample, const 
   p.relu = relu; p.y_fp32 = y_fp32; p.flip = transposed; p.w_per_sample = w_per_sample;
   p.tiles_y = p.H / TY; p.tiles_x = (p.W + TX - 1) / TX; p.tiles_z = p.D / TZ;
   p.tiles_per_sample = (p.D / TZ) * p.tiles_y * p.tiles_x;
-  int wgs = 256 / p.N;  // workgroups per sample: one workgroup per CU when N divides 256
-  if (wgs < 1) wgs = 1;
-  if (wgs * 2 > p.tiles_per_sample) wgs = (p.tiles_per_sample + 1) / 2;
+  const int wgs = tiled_wgs_per_sample(g);
   p.teams_per_sample = wgs * 2;
   static const int dbg = getenv("RTP_TILED_DBG") ? atoi(getenv("RTP_TILED_DBG")) : 0;
   p.dbg = dbg;
@@ -321,21 +400,26 @@ int rtp_conv_tiled_try(const RtpAct* x, const void* wf, int w_per_sample, const 
   const size_t shm = sizeof(bf16_t) * (27 * (size_t)Co * 32 + 2 * (size_t)HALO_VOX * 32) + 27 * (size_t)Co * sizeof(float);
   RtpProfScope prof(RTP_FAM_CONV_TILED, s);
   using Kern = void (*)(TiledParams);
-  static const Kern table[2][2][2] = {
-      {{conv_tiled_kernel<1, false, false>, conv_tiled_kernel<1, false, true>},
-       {conv_tiled_kernel<1, true, false>, conv_tiled_kernel<1, true, true>}},
-      {{conv_tiled_kernel<2, false, false>, conv_tiled_kernel<2, false, true>},
-       {conv_tiled_kernel<2, true, false>, conv_tiled_kernel<2, true, true>}}};
+#define RTP_TILED_ROW(NT, BT) \
+  {{conv_tiled_kernel<NT, BT, 0, false>, conv_tiled_kernel<NT, BT, 0, true>}, \
+   {conv_tiled_kernel<NT, BT, 1, false>, conv_tiled_kernel<NT, BT, 1, true>}, \
+   {nullptr, conv_tiled_kernel<NT, BT, 2, true>}}
+  static const Kern table[2][2][3][2] = {{RTP_TILED_ROW(1, false), RTP_TILED_ROW(1, true)},
+                                         {RTP_TILED_ROW(2, false), RTP_TILED_ROW(2, true)}};
+#undef RTP_TILED_ROW
   static bool attr_done = false;
   if (!attr_done) {
     const int big = (int)(sizeof(bf16_t) * (27 * (size_t)32 * 32 + 2 * (size_t)HALO_VOX * 32) + 27 * 32 * sizeof(float));
     for (int a = 0; a < 2; ++a)
       for (int b = 0; b < 2; ++b)
-        for (int c = 0; c < 2; ++c)
-          (void)hipFuncSetAttribute((const void*)table[a][b][c], hipFuncAttributeMaxDynamicSharedMemorySize, big);
+        for (int c = 0; c < 3; ++c)
+          for (int d = 0; d < 2; ++d)
+            if (table[a][b][c][d])
+              (void)hipFuncSetAttribute((const void*)table[a][b][c][d], hipFuncAttributeMaxDynamicSharedMemorySize, big);
     attr_done = true;
   }
-  hipLaunchKernelGGL(table[nt - 1][btab ? 1 : 0][res ? 1 : 0], dim3(p.N * wgs), dim3(512), shm, s, p);
+  const int aux = stat_x ? 2 : (res ? 1 : 0);
+  hipLaunchKernelGGL(table[nt - 1][btab ? 1 : 0][aux][stat_out ? 1 : 0], dim3(p.N * wgs), dim3(512), shm, s, p);
   RTP_CHECK_LAUNCH();
   return RTP_OK;
 }

@@ -278,8 +278,16 @@ class ConvOp:
         self.wd = be.alloc((ntap, ge.ci, pad_to(ge.co, 32)), "bf16") if need_dgrad else None
         g.fwd.append(be.fold_fwd(w, bias, gamma, beta, stats, self.x.stats_split if self.gn else 0, self.groups, GN_EPS,
                                  ge, self.ci_real, self.co_real, self.wf, self.btab, self.mr, self.wd))
+        # Convs on the LDS-tiled kernel also emit (sum y, sum y^2) per channel from their epilogue, so a GroupNorm
+        # consumer of y needs no statistics pass (ensure_stats finds them)
+        fstats = None
+        S = 0 if self.out_fp32 or ge.co != self.y.c else be.conv_stats_nsplit(self.x, ge, False)
+        if S > 0:
+            self.y.stats_split = S
+            self.y.stats = be.alloc((g.n, S, self.y.c, 2), "f32")
+            fstats = (None, self.y.stats)
         g.fwd.append(be.conv(self.x, self.wf, nw > 1, self.btab, self.residual, self.y, ge, self.relu, False,
-                             self.out_fp32))
+                             self.out_fp32, fstats))
         self.alg_flops = 2 * g.n * ge.do * ge.ho * ge.wo * self.co_real * self.ci_real * ntap
         g.flops["conv_fwd"] += self.alg_flops
         # mirrors the dispatch predicate of rtp_conv_tiled_try (csrc/conv_tiled.hip)
@@ -300,13 +308,17 @@ class ConvOp:
             wd = self.wd
             dxh_buf = be.alloc((g.n, x.d, x.h, x.w, ge.ci), "bf16")
             dxh = View(dxh_buf, g.n, x.d, x.h, x.w, ge.ci, 0, ge.ci)
-            g.bwd.append(be.conv(gy, wd, False, None, None, dxh, ge, False, True, False))
+            # GroupNorm backward needs P = sum dxhat and Q = sum dxhat*x per (sample, channel): the tiled kernel
+            # accumulates them in its epilogue, otherwise a chan_stats pass over (dxhat, x) follows
+            S = be.conv_stats_nsplit(gy, ge, True) if self.gn else 0
+            pq = be.alloc((g.n, S or x.stats_split, ge.ci, 2), "f32") if self.gn else None
+            g.bwd.append(be.conv(gy, wd, False, None, None, dxh, ge, False, True, False, (x, pq) if S else None))
             g.flops["conv_dgrad"] += self.alg_flops
             g.flops["conv_tiled" if self.tiled_bwd else "conv_generic"] += self.alg_flops
             if self.gn:
-                S = x.stats_split
-                pq = be.alloc((g.n, S, ge.ci, 2), "f32")
-                g.bwd.append(be.chan_stats(dxh, x, S, pq))
+                if not S:
+                    S = x.stats_split
+                    g.bwd.append(be.chan_stats(dxh, x, S, pq))
                 coeff = be.alloc((g.n * ge.ci * 5,), "f32")  # [n][c][3] coefficients + [n][c][2] scratch
                 g.bwd.append(be.gn_bwd_coeffs(pq, S, self.mr, g.params[self.gn[0]], g.n, self.ci_real, self.groups,
                                               x.vox, coeff, g.pgrad[self.gn[0]], g.pgrad[self.gn[1]], 0))

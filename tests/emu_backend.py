@@ -144,7 +144,16 @@ class EmuBackend:
             wd.copy_(full.to(wd.dtype))
         return run
 
-    def conv(self, x, wf, per_sample, btab, res, y, geom, relu, transposed, y_fp32):
+    def conv_stats_nsplit(self, x, geom, transposed):
+        """Mirror of the LDS-tiled kernel's predicate so CPU plans exercise the fused-statistics wiring (2 partials)."""
+        g = geom
+        ci = (g.co + 31) // 32 * 32 if transposed else g.ci
+        co = g.ci if transposed else g.co
+        ok = (g.ks == 3 and g.stride == 1 and ci == 32 and co in (16, 32) and g.di % 2 == 0 and g.hi % 4 == 0
+              and g.wi % 16 == 0 and g.di >= 2 and x.cs == 32 and x.co == 0)
+        return 2 if ok else 0
+
+    def conv(self, x, wf, per_sample, btab, res, y, geom, relu, transposed, y_fp32, stats=None):
         def run(s):
             g = geom
             k = g.ks
@@ -171,6 +180,13 @@ class EmuBackend:
             if relu:
                 out = out.clamp_min(0)
             _store(y, out)
+            if stats is not None:   # statistics of the stored values; everything in partial 0
+                sx, so = stats
+                yv = _sl(y).reshape(y.n, y.vox, -1)[..., :so.shape[2]]
+                other = _sl(sx).reshape(y.n, y.vox, -1)[..., :so.shape[2]] if sx is not None else yv
+                so.zero_()
+                so[:, 0, :, 0] = yv.sum(1)
+                so[:, 0, :, 1] = (yv * other).sum(1)
         return run
 
     def wgrad(self, gy, x, geom, nsplit, gp):

@@ -105,6 +105,22 @@ def test_conv_forward(hip, case):
     run(hip, EMU.conv(xc, wf.c, per_sample, bt.c, rc, yc, geom, relu, False, fp32),
         hip.conv(xg, wf.g, per_sample, bt.g, rg, yg, geom, relu, False, fp32))
     check(yp, F32 if fp32 else BF, "conv fwd %r" % (case,))
+    # fused statistics epilogue (sum y, sum y^2) where the LDS-tiled kernel offers it: compared as the sum over partials
+    # with a chan_stats pass over the tensor the kernel itself stored (fp32 accuracy), and with the emulation (bf16-level)
+    S = 0 if fp32 or co != yc_ch else hip.conv_stats_nsplit(xg, geom, False)
+    if S:
+        st = hip.alloc((n, S, co, 2), "f32")
+        hip.conv(xg, wf.g, per_sample, bt.g, rg, yg, geom, relu, False, fp32, (None, st))(hip.stream())
+        ref = hip.alloc((n, 3, co, 2), "f32")
+        hip.chan_stats(yg, None, 3, ref)(hip.stream())
+        torch.cuda.synchronize()
+        check(yp, BF, "conv fwd (stats variant) %r" % (case,))
+        assert rel_err(st.sum(1).cpu(), ref.sum(1).cpu()) < F32, "fused fwd stats %r" % (case,)
+        yv = yc.buf.float().reshape(n, -1, yc_ch)
+        emu = torch.stack([yv.sum(1), (yv * yv).sum(1)], -1)
+        assert rel_err(st.sum(1).cpu(), emu) < BF * 2
+    else:
+        assert fp32 or co != yc_ch or ks != 3 or stride != 1 or ci != 32 or d % 2 or h % 4 or w % 16
 
 
 @pytest.mark.parametrize("case", [
@@ -130,6 +146,16 @@ def test_conv_transposed_is_data_gradient(hip, case):
     run(hip, EMU.conv(gc, wd.c, False, None, None, yc, geom, False, True, False),
         hip.conv(gg, wd.g, False, None, None, yg, geom, False, True, False))
     check(yp, BF, "dgrad %r" % (case,))
+    S = hip.conv_stats_nsplit(gg, geom, True)
+    if S:  # fused P = sum dxhat, Q = sum dxhat * x
+        _, sxc, sxg = views(hip, rnd((n, d, h, w, 2 * ci), 9, relu=True), n, d, h, w, co=ci, c=ci)   # channel-slice view
+        st = hip.alloc((n, S, ci, 2), "f32")
+        hip.conv(gg, wd.g, False, None, None, yg, geom, False, True, False, (sxg, st))(hip.stream())
+        ref = hip.alloc((n, 2, ci, 2), "f32")
+        hip.chan_stats(yg, sxg, 2, ref)(hip.stream())
+        torch.cuda.synchronize()
+        check(yp, BF, "dgrad (stats variant) %r" % (case,))
+        assert rel_err(st.sum(1).cpu(), ref.sum(1).cpu()) < F32, "fused P/Q %r" % (case,)
     # and it IS the autograd data gradient of F.conv3d
     x = torch.zeros(n, ci, d, h, w, requires_grad=True)
     wq = w32.c.to(torch.bfloat16).float()
