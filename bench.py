@@ -138,7 +138,7 @@ def main():
                 "wgrad_tiled (32ch full-res)": (_lib.FAM_WGRAD_TILED, g.flops["wgrad_tiled"]),
                 "wgrad generic": (_lib.FAM_WGRAD, g.flops["wgrad_generic"])}
         tr.use_graph = False
-        tr.engine.use_side_stream = False  # one stream while timing kernels: concurrent side-stream work would inflate the events
+        tr.engine.use_lanes = False  # one stream while timing kernels: concurrent side-stream work would inflate the events
         for fam, _ in fams.values():
             be.prof_enable(fam, True)
         ksteps = min(args.steps, 5)

@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "librtp_hip.so")
+LIB_PATH = os.environ.get("RTP_LIB") or os.path.join(HERE, "lib", "librtp_hip.so")  # RTP_LIB: A/B-test another build
 
 RTP_MAX_TERMS = 6
 

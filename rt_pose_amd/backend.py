@@ -49,15 +49,17 @@ class HipBackend:
     def stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
-    # side stream for work that only the optimiser consumes (fork/join with events: capturable into a HIP graph)
-    def fork_side(self):
-        if getattr(self, "_side", None) is None:
-            self._side = torch.cuda.Stream(self.device)
-        self._side.wait_stream(torch.cuda.current_stream(self.device))
-        return C.c_void_p(self._side.cuda_stream)
+    # one HIP stream per lane of the launch plan (rt_pose_amd/lanes.py); lane 0 is the caller's current stream
+    def lane_streams(self, n):
+        cur = torch.cuda.current_stream(self.device)
+        if len(getattr(self, "_lanes", ())) < n - 1:
+            self._lanes = [torch.cuda.Stream(self.device) for _ in range(n - 1)]
+        streams = [cur] + self._lanes[:n - 1]
+        return streams, [C.c_void_p(st.cuda_stream) for st in streams]
 
-    def join_side(self):
-        torch.cuda.current_stream(self.device).wait_stream(self._side)
+    @staticmethod
+    def new_event():
+        return torch.cuda.Event()
 
     def stem_bwd_blocks(self):
         return self.lib.rtp_stem_bwd_blocks()

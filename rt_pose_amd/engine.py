@@ -17,6 +17,7 @@ import torch
 
 from . import net
 from .graph import Graph, View, pad_to
+from .lanes import LanePlan, LANE_MAP
 
 
 def one_cycle(step, total_step, lr_max, moms=(0.95, 0.85), div_factor=10.0, pct_start=0.4):
@@ -90,6 +91,9 @@ class PoseEngine:
         self.feats = net.build_hrnet3d(g, self.x_in, arch, dims, final_fuse)
         self.outs = net.build_head(g, self.feats, list(self.heads))
         self.fwd = list(g.fwd)
+        self.fwd_plan = LanePlan(be, self.fwd, LANE_MAP)
+        self.bwd_plan = None
+        self.use_lanes = True      # False: replay everything on the caller's stream in list order
         d, h, w = dims
         self.m = max_objs or self.ncls  # max_poses(1) * 15 key-points for hr3d, 1 for the one-heat-map variant
         # ---- decode (inference)
@@ -122,6 +126,7 @@ class PoseEngine:
             g.seed_grad(reg, self.greg)
             g.build_backward()
             self.bwd = list(g.bwd)
+            self.bwd_plan = LanePlan(be, self.bwd, LANE_MAP)
         self.live_params = set(g.used_params)
 
     # ------------------------------------------------------------------ data in (plumbing copies)
@@ -138,26 +143,11 @@ class PoseEngine:
 
     # ------------------------------------------------------------------ launch lists
     def run_forward(self, stream=None):
-        s = stream if stream is not None else self.be.stream()
-        for f in self.fwd:
-            f(s)
+        self.fwd_plan.run(stream if stream is not None else self.be.stream(), self.use_lanes)
 
     def _run_bwd(self, s):
-        """Replay the backward list: plain entries on the main stream, ('side', f) entries on the backend's side stream,
-        FORK = side waits for everything queued on main so far, JOIN = main waits for the side stream."""
-        fork = getattr(self.be, "fork_side", None) if getattr(self, "use_side_stream", True) else None
-        ss = None
-        for item in self.bwd:
-            if callable(item):
-                item(s)
-            elif item[0] == "side":
-                item[1](ss if ss is not None else s)
-            elif item[0] == "fork":
-                if fork is not None:
-                    ss = fork()
-            elif item[0] == "join":
-                if fork is not None and ss is not None:
-                    self.be.join_side()
+        """Replay the backward list, one HIP stream per lane (lanes.LanePlan) unless use_lanes is off."""
+        self.bwd_plan.run(s, self.use_lanes)
 
     def run_loss_backward(self, stream=None):
         s = stream if stream is not None else self.be.stream()

@@ -12,6 +12,10 @@ Backward is emitted mechanically in reverse creation order.  Every activation co
 its consumers (plain addends, or GroupNorm-backward terms A*dxhat + B*x + C); one grad_combine launch per
 activation sums them and applies the activation's own ReLU mask, so no gradient tensor is written twice.
 
+Every list entry is a lanes.Launch: the closure plus its LANE (HIP stream: one per resolution group, plus lanes for
+the weight-gradient chains, which only feed the optimiser) and the buffers it reads / writes, from which
+lanes.LanePlan derives the cross-stream event waits.  List order is always a valid single-stream order.
+
 The `backend` supplies the kernels (rt_pose_amd.backend.HipBackend in the product; tests inject a torch-CPU
 emulation of each kernel to check this file's plan logic without a GPU).  Every backend method returns a
 closure f(stream) so argument marshalling happens once, at build time.
@@ -19,12 +23,7 @@ closure f(stream) so argument marshalling happens once, at build time.
 from dataclasses import dataclass, field
 from typing import List, Optional
 
-FORK, JOIN = ("fork",), ("join",)  # markers in the backward list: side stream forks from / joins the main stream
-
-
-def side(fn):
-    """Tag a launch for the side stream (the weight-gradient chain runs beside the data-gradient chain)."""
-    return ("side", fn)
+from .lanes import Launch, L_FULL, L_MID, L_LOW, L_WG, L_WG_LOW
 
 
 GROUPS = 8      # nn.GroupNorm(num_groups=8, ...) everywhere on the path (hr_util/common.py:57, hr3d.py:147)
@@ -113,6 +112,7 @@ class Graph:
         self.pgrad = {}            # name -> fp32 grad tensor written by the backward plan
         self.used_params = []      # creation order
         self.bytes = 0
+        self.full_vox = None       # voxels of the first (full-resolution) activation: lanes are assigned by resolution
         # algorithmic FLOPs (2*MACs of real channels) per kernel family, per replay of the lists
         self.flops = {"conv_fwd": 0, "conv_dgrad": 0, "wgrad": 0, "conv_tiled": 0, "conv_generic": 0,
                       "wgrad_tiled": 0, "wgrad_generic": 0}
@@ -121,7 +121,23 @@ class Graph:
     def act(self, *a, **k):
         t = Act(self, *a, **k)
         self.acts.append(t)
+        if self.full_vox is None:
+            self.full_vox = t.vox
         return t
+
+    def lane_of(self, v):
+        """Resolution group of a tensor: full resolution / one level down / the two lowest levels."""
+        r = self.full_vox // max(1, v.vox)
+        return L_FULL if r < 4 else L_MID if r < 32 else L_LOW
+
+    def wg_lane_of(self, v):
+        return L_WG if self.lane_of(v) == L_FULL else L_WG_LOW
+
+    def emit_fwd(self, fn, lane, reads=(), writes=()):
+        self.fwd.append(Launch(fn, lane, reads, writes))
+
+    def emit_bwd(self, fn, lane, reads=(), writes=()):
+        self.bwd.append(Launch(fn, lane, reads, writes))
 
     def param(self, name):
         p = self.params[name]
@@ -139,7 +155,7 @@ class Graph:
         if x.stats is None:
             x.stats_split = stats_split(x.vox)
             x.stats = self.be.alloc((self.n, x.stats_split, x.c, 2), "f32")
-            self.fwd.append(self.be.chan_stats(x, None, x.stats_split, x.stats))
+            self.emit_fwd(self.be.chan_stats(x, None, x.stats_split, x.stats), self.lane_of(x), [x], [x.stats])
         return x.stats
 
     # ------------------------------------------------------------------ forward node constructors
@@ -155,12 +171,12 @@ class Graph:
         op = StemOp(self, x_f32, y, wname, bname)
         y.producer = op
         self.ops.append(op)
-        self.fwd.append(self.be.stem_fwd(x_f32, w, b, y))
+        self.emit_fwd(self.be.stem_fwd(x_f32, w, b, y), self.lane_of(y), [x_f32], [y])
         return y
 
     def pack(self, name, x_f32, c, dims):
         y = self.act(name, c, dims, c=pad_to(c, 32), needs_grad=False)
-        self.fwd.append(self.be.pack_ncdhw(x_f32, y, c))
+        self.emit_fwd(self.be.pack_ncdhw(x_f32, y, c), self.lane_of(y), [x_f32], [y])
         return y
 
     def conv(self, name, x: Act, wname, bname=None, gn=None, ks=3, stride=1, relu=False, residual=None,
@@ -189,7 +205,7 @@ class Graph:
         op = FuseOp(self, terms, y)
         y.producer = op
         self.ops.append(op)
-        self.fwd.append(self.be.fuse_sum(terms, None, y, relu))
+        self.emit_fwd(self.be.fuse_sum(terms, None, y, relu), self.lane_of(y), terms, [y])
         return y
 
     # ------------------------------------------------------------------ backward
@@ -222,8 +238,9 @@ class Graph:
                 nsplit = cls_split(t.d, t.h)
                 cls = (nsplit, self.be.alloc((self.n, nsplit, 64, c), "f32"))
                 t.grad_cls = cls
-            self.bwd.append(self.be.grad_combine(chunk, t if need_x else None, t if (t.relu and last) else None, t.grad,
-                                                 cls))
+            self.emit_bwd(self.be.grad_combine(chunk, t if need_x else None, t if (t.relu and last) else None, t.grad, cls),
+                          self.lane_of(t), [v for v, _ in chunk] + [cf for _, cf in chunk] + [t],
+                          [t.grad, cls[1] if cls else None])
             first = False
         return t.grad
 
@@ -234,7 +251,6 @@ class Graph:
             if gy is None:
                 continue
             op.emit_backward(gy)
-        self.bwd.append(JOIN)
 
 
 class StemOp:
@@ -244,8 +260,8 @@ class StemOp:
     def emit_backward(self, gy):
         g = self.g
         scratch = g.be.alloc((g.be.stem_bwd_blocks(), self.y.c, 2), "f32")
-        g.bwd.append(FORK)
-        g.bwd.append(side(g.be.stem_bwd(self.x, gy, scratch, g.pgrad[self.wname], g.pgrad[self.bname], 0)))
+        g.emit_bwd(g.be.stem_bwd(self.x, gy, scratch, g.pgrad[self.wname], g.pgrad[self.bname], 0), g.wg_lane_of(gy),
+                   [self.x, gy], [scratch, g.pgrad[self.wname], g.pgrad[self.bname]])
 
 
 class ConvOp:
@@ -276,8 +292,10 @@ class ConvOp:
         # training plans also get the data-gradient packing of the same weights out of this launch
         need_dgrad = g.train and (self.x.needs_grad or bool(self.gn))
         self.wd = be.alloc((ntap, ge.ci, pad_to(ge.co, 32)), "bf16") if need_dgrad else None
-        g.fwd.append(be.fold_fwd(w, bias, gamma, beta, stats, self.x.stats_split if self.gn else 0, self.groups, GN_EPS,
-                                 ge, self.ci_real, self.co_real, self.wf, self.btab, self.mr, self.wd))
+        lane = g.lane_of(self.y)
+        g.emit_fwd(be.fold_fwd(w, bias, gamma, beta, stats, self.x.stats_split if self.gn else 0, self.groups, GN_EPS,
+                               ge, self.ci_real, self.co_real, self.wf, self.btab, self.mr, self.wd),
+                   lane, [stats], [self.wf, self.btab, self.mr, self.wd])
         # Convs on the LDS-tiled kernel also emit (sum y, sum y^2) per channel from their epilogue, so a GroupNorm
         # consumer of y needs no statistics pass (ensure_stats finds them)
         fstats = None
@@ -286,8 +304,9 @@ class ConvOp:
             self.y.stats_split = S
             self.y.stats = be.alloc((g.n, S, self.y.c, 2), "f32")
             fstats = (None, self.y.stats)
-        g.fwd.append(be.conv(self.x, self.wf, nw > 1, self.btab, self.residual, self.y, ge, self.relu, False,
-                             self.out_fp32, fstats))
+        g.emit_fwd(be.conv(self.x, self.wf, nw > 1, self.btab, self.residual, self.y, ge, self.relu, False,
+                           self.out_fp32, fstats),
+                   lane, [self.x, self.wf, self.btab, self.residual], [self.y, self.y.stats if fstats else None])
         self.alg_flops = 2 * g.n * ge.do * ge.ho * ge.wo * self.co_real * self.ci_real * ntap
         g.flops["conv_fwd"] += self.alg_flops
         # mirrors the dispatch predicate of rtp_conv_tiled_try (csrc/conv_tiled.hip)
@@ -312,16 +331,19 @@ class ConvOp:
             # accumulates them in its epilogue, otherwise a chan_stats pass over (dxhat, x) follows
             S = be.conv_stats_nsplit(gy, ge, True) if self.gn else 0
             pq = be.alloc((g.n, S or x.stats_split, ge.ci, 2), "f32") if self.gn else None
-            g.bwd.append(be.conv(gy, wd, False, None, None, dxh, ge, False, True, False, (x, pq) if S else None))
+            lane = g.lane_of(self.y)   # a stride-2 conv's data gradient runs with the LOWER-resolution group
+            g.emit_bwd(be.conv(gy, wd, False, None, None, dxh, ge, False, True, False, (x, pq) if S else None),
+                       lane, [gy, wd, x if S else None], [dxh, pq if S else None])
             g.flops["conv_dgrad"] += self.alg_flops
             g.flops["conv_tiled" if self.tiled_bwd else "conv_generic"] += self.alg_flops
             if self.gn:
                 if not S:
                     S = x.stats_split
-                    g.bwd.append(be.chan_stats(dxh, x, S, pq))
+                    g.emit_bwd(be.chan_stats(dxh, x, S, pq), lane, [dxh, x], [pq])
                 coeff = be.alloc((g.n * ge.ci * 5,), "f32")  # [n][c][3] coefficients + [n][c][2] scratch
-                g.bwd.append(be.gn_bwd_coeffs(pq, S, self.mr, g.params[self.gn[0]], g.n, self.ci_real, self.groups,
-                                              x.vox, coeff, g.pgrad[self.gn[0]], g.pgrad[self.gn[1]], 0))
+                g.emit_bwd(be.gn_bwd_coeffs(pq, S, self.mr, g.params[self.gn[0]], g.n, self.ci_real, self.groups,
+                                            x.vox, coeff, g.pgrad[self.gn[0]], g.pgrad[self.gn[1]], 0),
+                           lane, [pq, self.mr], [coeff, g.pgrad[self.gn[0]], g.pgrad[self.gn[1]]])
                 if x.needs_grad:
                     x.contribs.append((dxh, coeff))
             elif x.needs_grad:
@@ -333,10 +355,10 @@ class ConvOp:
         co32 = pad_to(ge.co, 32)
         assert gy.c == co32, (self.name, gy.c, co32)
         gp = be.alloc((g.n, S, ge.ks ** 3, co32, ge.ci), "f32")
-        # The weight-gradient chain (wgrad -> class sums -> un-fold) only feeds the optimiser, so it runs on the side
-        # stream beside the rest of the backward sweep; it forks here because it needs the finished gy.
-        g.bwd.append(FORK)
-        g.bwd.append(side(be.wgrad(gy, x, ge, S, gp)))
+        # The weight-gradient chain (wgrad -> class sums -> un-fold) only feeds the optimiser, so it runs on its own
+        # lane beside the rest of the backward sweep.
+        wl = g.wg_lane_of(gy)
+        g.emit_bwd(be.wgrad(gy, x, ge, S, gp), wl, [gy, x], [gp])
         g.flops["wgrad"] += self.alg_flops
         g.flops["wgrad_tiled" if self.tiled_wgrad else "wgrad_generic"] += self.alg_flops
         csum = None
@@ -344,15 +366,15 @@ class ConvOp:
             csum = be.alloc((g.n, 64, gy.c), "f32")
             if self.y.grad_cls is not None and self.y.grad is gy:
                 cs_split, cs_scratch = self.y.grad_cls
-                g.bwd.append(side(be.class_sums_reduce(cs_scratch, cs_split, g.n, gy.c, csum)))
+                g.emit_bwd(be.class_sums_reduce(cs_scratch, cs_split, g.n, gy.c, csum), wl, [cs_scratch], [csum])
             else:
                 cs_split = cls_split(gy.d, gy.h)
                 cs_scratch = be.alloc((g.n, cs_split, 64, gy.c), "f32")
-                g.bwd.append(side(be.class_sums(gy, cs_split, cs_scratch, csum)))
-        g.bwd.append(side(be.wgrad_fold(gp, S, csum, self.mr, g.params[self.gn[0]] if self.gn else None,
-                                        g.params[self.gn[1]] if self.gn else None, self.groups, ge, self.ci_real,
-                                        self.co_real, g.pgrad[self.wname],
-                                        g.pgrad[self.bname] if self.bname else None, 0)))
+                g.emit_bwd(be.class_sums(gy, cs_split, cs_scratch, csum), wl, [gy], [cs_scratch, csum])
+        g.emit_bwd(be.wgrad_fold(gp, S, csum, self.mr, g.params[self.gn[0]] if self.gn else None,
+                                 g.params[self.gn[1]] if self.gn else None, self.groups, ge, self.ci_real,
+                                 self.co_real, g.pgrad[self.wname], g.pgrad[self.bname] if self.bname else None, 0),
+                   wl, [gp, csum, self.mr], [g.pgrad[self.wname], g.pgrad[self.bname] if self.bname else None])
 
 
 class FuseOp:
@@ -369,5 +391,5 @@ class FuseOp:
             else:
                 glow_buf = be.alloc((g.n, t.d, t.h, t.w, t.c), "bf16")
                 glow = View(glow_buf, g.n, t.d, t.h, t.w, t.c, 0, t.c)
-                g.bwd.append(be.upsample_bwd(gy, glow))
+                g.emit_bwd(be.upsample_bwd(gy, glow), g.lane_of(glow), [gy], [glow])
                 t.contribs.append((glow, None))

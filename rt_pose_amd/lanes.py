@@ -1,0 +1,130 @@
+"""Multi-stream replay of a static launch list.
+
+HRNet keeps four resolution branches alive; between fuse points they are independent, and the weight-gradient chains
+of the backward sweep only feed the optimiser.  The full-resolution kernels fill the chip, the low-resolution ones
+(1-40 workgroups) do not, so the plan assigns every launch a LANE (= HIP stream): one per resolution group plus
+lanes for the weight-gradient chains.  List order is a valid serial order; this module derives, once, the
+cross-lane event waits that preserve every read-after-write / write-after-read / write-after-write ordering of that
+serial order (vector clocks keep only the waits not already implied by stream order or earlier waits).  Replay is then
+`wait events -> launch -> record event` per entry, capturable into a HIP graph like any stream fork/join.
+"""
+
+# lane ids
+L_FULL, L_MID, L_LOW, L_WG, L_WG_LOW = 0, 1, 2, 3, 4
+NLANES = 5
+# Lanes -> streams.  Measured on MI355X (hr3d, B=8, ms/step): one stream 11.6; "0,0,0,1,1" (weight-gradient chains beside
+# everything else) 9.32; "0,1,1,2,2" 9.15-9.18 (default); one stream per lane "0,1,2,3,4" 9.56 -- more streams than that
+# only make the big kernels share the chip.  RTP_LANES overrides for experiments.
+import os
+LANE_MAP = [int(v) for v in os.environ.get("RTP_LANES", "0,1,1,2,2").split(",")]
+assert len(LANE_MAP) == NLANES and all(0 <= v < NLANES for v in LANE_MAP)
+
+
+def _key(t):
+    if t is None:
+        return None
+    buf = getattr(t, "buf", t)
+    return buf.data_ptr()
+
+
+class Launch:
+    """One kernel launch of the plan: fn(stream_ptr), its lane, and the buffers it reads / writes."""
+    __slots__ = ("fn", "lane", "reads", "writes")
+
+    def __init__(self, fn, lane=0, reads=(), writes=()):
+        self.fn, self.lane = fn, lane
+        self.reads = tuple(k for k in (_key(t) for t in reads) if k is not None)
+        self.writes = tuple(k for k in (_key(t) for t in writes) if k is not None)
+
+    def __call__(self, s):
+        return self.fn(s)
+
+
+def plan_waits(launches, nlanes=NLANES):
+    """-> (waits, record): waits[i] = indices of earlier launches (on other lanes) launch i must wait for;
+    record[j] = launch j's completion needs an event."""
+    last_w, readers = {}, {}
+    clock = [[-1] * nlanes for _ in range(nlanes)]  # clock[l][m]: newest launch on lane m known finished before lane l's next
+    after = []                                      # clock snapshot implied by the completion of launch i
+    waits, record = [], [False] * len(launches)
+    for i, L in enumerate(launches):
+        deps = set()
+        for k in L.reads:
+            j = last_w.get(k)
+            if j is not None:
+                deps.add(j)
+        for k in L.writes:
+            j = last_w.get(k)
+            if j is not None:
+                deps.add(j)
+            deps.update(readers.get(k, ()))
+        vc = clock[L.lane]
+        need = {}
+        for j in deps:
+            m = launches[j].lane
+            if m != L.lane and j > vc[m]:
+                need[m] = max(need.get(m, -1), j)
+        w = []
+        for m, j in sorted(need.items(), key=lambda kv: -kv[1]):
+            if j > vc[m]:
+                w.append(j)
+                record[j] = True
+                for t in range(nlanes):
+                    vc[t] = max(vc[t], after[j][t])
+        vc[L.lane] = i
+        after.append(list(vc))
+        waits.append(w)
+        for k in L.writes:
+            last_w[k] = i
+            readers[k] = []
+        for k in L.reads:
+            if k not in L.writes:
+                readers.setdefault(k, []).append(i)
+    return waits, record
+
+
+class LanePlan:
+    """A launch list bound to a backend, replayable on one stream or on one stream per lane."""
+
+    def __init__(self, backend, launches, lane_map=None):
+        self.be = backend
+        self.launches = [x if isinstance(x, Launch) else Launch(x) for x in launches]
+        if lane_map is not None:
+            for L in self.launches:
+                L.lane = lane_map[L.lane]
+        self.lanes_used = sorted({L.lane for L in self.launches})
+        self.waits, self.record = plan_waits(self.launches)
+        self._events = None
+
+    def __len__(self):
+        return len(self.launches)
+
+    def run(self, stream_ptr, multi=True):
+        """stream_ptr: the caller's (main) stream handle.  multi=False replays everything on it in list order."""
+        be = self.be
+        if not multi or len(self.lanes_used) <= 1 or not hasattr(be, "lane_streams"):
+            for L in self.launches:
+                L.fn(stream_ptr)
+            return
+        streams, ptrs = be.lane_streams(NLANES)    # [current, side...], their handles
+        if self._events is None:
+            self._events = [be.new_event() if r else None for r in self.record]
+            self._start = be.new_event()
+            self._ends = [be.new_event() for _ in range(NLANES)]
+        ev = self._events
+        main = streams[0]
+        side = [l for l in self.lanes_used if l != 0]
+        self._start.record(main)
+        for l in side:
+            streams[l].wait_event(self._start)
+        waits, record = self.waits, self.record
+        for i, L in enumerate(self.launches):
+            st = streams[L.lane]
+            for j in waits[i]:
+                st.wait_event(ev[j])
+            L.fn(ptrs[L.lane])
+            if record[i]:
+                ev[i].record(st)
+        for l in side:
+            self._ends[l].record(streams[l])
+            main.wait_event(self._ends[l])

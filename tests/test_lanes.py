@@ -1,0 +1,85 @@
+"""Lane scheduler (rt_pose_amd/lanes.py): the cross-stream waits derived from read/write sets must order every
+conflicting pair of launches exactly as the serial list does -- checked on random plans and on the real hr3d plan."""
+import random
+
+import torch
+
+from rt_pose_amd import lanes
+from rt_pose_amd.lanes import Launch, plan_waits
+
+
+class _Buf:
+    def __init__(self, k):
+        self.k = k
+
+    def data_ptr(self):
+        return self.k
+
+
+def _happens_before(launches, waits):
+    """reach[i] = set of launches guaranteed complete before i starts (stream order + event waits, transitively)."""
+    last_on_lane, reach = {}, []
+    for i, L in enumerate(launches):
+        r = set()
+        p = last_on_lane.get(L.lane)
+        if p is not None:
+            r |= reach[p] | {p}
+        for j in waits[i]:
+            assert j < i and launches[j].lane != L.lane
+            r |= reach[j] | {j}
+        reach.append(r)
+        last_on_lane[L.lane] = i
+    return reach
+
+
+def _check(launches):
+    waits, record = plan_waits(launches)
+    reach = _happens_before(launches, waits)
+    for i, a in enumerate(launches):
+        for j in range(i):
+            b = launches[j]
+            conflict = (set(a.reads) & set(b.writes)) or (set(a.writes) & set(b.reads)) or (set(a.writes) & set(b.writes))
+            if conflict:
+                assert j in reach[i], (j, i, conflict)
+    for i, w in enumerate(waits):
+        for j in w:
+            assert record[j]
+    return sum(len(w) for w in waits)
+
+
+def test_random_plans_are_ordered():
+    rng = random.Random(0)
+    for trial in range(30):
+        bufs = [_Buf(k) for k in range(rng.randint(3, 12))]
+        ls = []
+        for _ in range(rng.randint(5, 80)):
+            ls.append(Launch(None, rng.randrange(lanes.NLANES), rng.sample(bufs, rng.randint(0, 3)), rng.sample(bufs, rng.randint(0, 2))))
+        _check(ls)
+
+
+def test_no_waits_within_one_lane_and_minimal_chain():
+    a, b, c = _Buf(1), _Buf(2), _Buf(3)
+    ls = [Launch(None, 0, [], [a]), Launch(None, 0, [a], [b]), Launch(None, 1, [b], [c]), Launch(None, 1, [a, c], [])]
+    waits, record = plan_waits(ls)
+    assert waits == [[], [], [1], []]          # the second lane-1 launch is covered by stream order + the first wait
+    assert record == [False, True, False, False]
+
+
+def test_hr3d_plan_hazards_are_covered():
+    from tests.emu_backend import EmuBackend
+    from rt_pose_amd import configs
+    from rt_pose_amd.engine import PoseEngine, FlatParams
+    from rt_pose_amd.trainer import init_state_dict
+    be = EmuBackend()
+    s = configs.spec("hr3d")
+    shapes = configs.param_shapes("hr3d")
+    flat = FlatParams(shapes, be.alloc)
+    flat.load_state_dict(init_state_dict(shapes, 0))
+    eng = PoseEngine(be, flat.values, s["arch"], s["final_fuse"], s["heads"], s["weight"], s["code_weights"], 1,
+                     (8, 16, 32), train=True, pgrads=flat.grads)
+    assert {L.lane for L in eng.fwd} >= {lanes.L_FULL, lanes.L_MID, lanes.L_LOW}
+    assert {L.lane for L in eng.bwd} >= {lanes.L_FULL, lanes.L_MID, lanes.L_LOW, lanes.L_WG, lanes.L_WG_LOW}
+    nf, nb = _check(eng.fwd), _check(eng.bwd)
+    assert 0 < nf < len(eng.fwd) and 0 < nb < len(eng.bwd)     # far fewer events than launches
+    # every launch declares what it writes (a launch with no write set could never be ordered)
+    assert all(L.writes for L in eng.fwd + eng.bwd)

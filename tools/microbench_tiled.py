@@ -15,10 +15,19 @@ S = be.wgrad_nsplit(g)
 gp = torch.zeros(n, S, 27, c, c, device='cuda')
 f_conv = be.conv(x, wf, True, bt, res, y, g, True, False, False)
 f_wg = be.wgrad(y, x, g, S, gp)
-def t(f, it=20):
+def t(f, it=300):
     s = be.stream()
-    for _ in range(3): f(s)
+    for _ in range(300): f(s)   # long warm-up: the clocks ramp only under sustained load
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(it): f(s)
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / it * 1e6
 print('dbg', os.environ.get('RTP_TILED_DBG', '0'), 'conv_tiled %.1f us' % t(f_conv), 'wgrad_tiled %.1f us' % t(f_wg))
+# level-1 sized problem (8 x 32 x 80): few bricks per workgroup, ragged W
+d1, h1, w1 = 8, 32, 80
+g1 = Geom(n, d1, h1, w1, d1, h1, w1, c, c, 3, 1, 1)
+x1 = View(mk((n, d1, h1, w1, c)), n, d1, h1, w1, c, 0, c)
+y1 = View(mk((n, d1, h1, w1, c)), n, d1, h1, w1, c, 0, c)
+S1 = be.wgrad_nsplit(g1)
+gp1 = torch.zeros(n, S1, 27, c, c, device='cuda')
+print('level-1: conv_tiled %.1f us' % t(be.conv(x1, wf, True, bt, None, y1, g1, True, False, False)),
+      'wgrad_tiled %.1f us' % t(be.wgrad(y1, x1, g1, S1, gp1)))
