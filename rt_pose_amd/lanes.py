@@ -40,9 +40,10 @@ class Launch:
         return self.fn(s)
 
 
-def plan_waits(launches, nlanes=NLANES):
+def plan_waits(launches, nlanes=NLANES, lane_of=None):
     """-> (waits, record): waits[i] = indices of earlier launches (on other lanes) launch i must wait for;
-    record[j] = launch j's completion needs an event."""
+    record[j] = launch j's completion needs an event.  lane_of: optional list overriding each launch's lane."""
+    lane_of = lane_of if lane_of is not None else [L.lane for L in launches]
     last_w, readers = {}, {}
     clock = [[-1] * nlanes for _ in range(nlanes)]  # clock[l][m]: newest launch on lane m known finished before lane l's next
     after = []                                      # clock snapshot implied by the completion of launch i
@@ -58,11 +59,12 @@ def plan_waits(launches, nlanes=NLANES):
             if j is not None:
                 deps.add(j)
             deps.update(readers.get(k, ()))
-        vc = clock[L.lane]
+        lane = lane_of[i]
+        vc = clock[lane]
         need = {}
         for j in deps:
-            m = launches[j].lane
-            if m != L.lane and j > vc[m]:
+            m = lane_of[j]
+            if m != lane and j > vc[m]:
                 need[m] = max(need.get(m, -1), j)
         w = []
         for m, j in sorted(need.items(), key=lambda kv: -kv[1]):
@@ -71,7 +73,7 @@ def plan_waits(launches, nlanes=NLANES):
                 record[j] = True
                 for t in range(nlanes):
                     vc[t] = max(vc[t], after[j][t])
-        vc[L.lane] = i
+        vc[lane] = i
         after.append(list(vc))
         waits.append(w)
         for k in L.writes:
@@ -89,11 +91,9 @@ class LanePlan:
     def __init__(self, backend, launches, lane_map=None):
         self.be = backend
         self.launches = [x if isinstance(x, Launch) else Launch(x) for x in launches]
-        if lane_map is not None:
-            for L in self.launches:
-                L.lane = lane_map[L.lane]
-        self.lanes_used = sorted({L.lane for L in self.launches})
-        self.waits, self.record = plan_waits(self.launches)
+        self.lane_of = [lane_map[L.lane] if lane_map is not None else L.lane for L in self.launches]
+        self.lanes_used = sorted(set(self.lane_of))
+        self.waits, self.record = plan_waits(self.launches, NLANES, self.lane_of)
         self._events = None
 
     def __len__(self):
@@ -117,12 +117,13 @@ class LanePlan:
         self._start.record(main)
         for l in side:
             streams[l].wait_event(self._start)
-        waits, record = self.waits, self.record
+        waits, record, lane_of = self.waits, self.record, self.lane_of
         for i, L in enumerate(self.launches):
-            st = streams[L.lane]
+            lane = lane_of[i]
+            st = streams[lane]
             for j in waits[i]:
                 st.wait_event(ev[j])
-            L.fn(ptrs[L.lane])
+            L.fn(ptrs[lane])
             if record[i]:
                 ev[i].record(st)
         for l in side:

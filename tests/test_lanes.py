@@ -16,6 +16,12 @@ class _Buf:
         return self.k
 
 
+def _relane(L, lane):
+    c = Launch(None, lane)
+    c.reads, c.writes = L.reads, L.writes
+    return c
+
+
 def _happens_before(launches, waits):
     """reach[i] = set of launches guaranteed complete before i starts (stream order + event waits, transitively)."""
     last_on_lane, reach = {}, []
@@ -32,8 +38,10 @@ def _happens_before(launches, waits):
     return reach
 
 
-def _check(launches):
-    waits, record = plan_waits(launches)
+def _check(launches, lane_of=None):
+    waits, record = plan_waits(launches, lanes.NLANES, lane_of)
+    if lane_of is not None:
+        launches = [Launch(None, l) for l in lane_of] and [_relane(L, l) for L, l in zip(launches, lane_of)]
     reach = _happens_before(launches, waits)
     for i, a in enumerate(launches):
         for j in range(i):
@@ -80,6 +88,10 @@ def test_hr3d_plan_hazards_are_covered():
     assert {L.lane for L in eng.fwd} >= {lanes.L_FULL, lanes.L_MID, lanes.L_LOW}
     assert {L.lane for L in eng.bwd} >= {lanes.L_FULL, lanes.L_MID, lanes.L_LOW, lanes.L_WG, lanes.L_WG_LOW}
     nf, nb = _check(eng.fwd), _check(eng.bwd)
+    # and under the default lane -> stream mapping the engine replays with
+    assert eng.fwd_plan.waits == plan_waits(eng.fwd, lanes.NLANES, eng.fwd_plan.lane_of)[0]
+    _check(eng.fwd, eng.fwd_plan.lane_of)
+    _check(eng.bwd, eng.bwd_plan.lane_of)
     assert 0 < nf < len(eng.fwd) and 0 < nb < len(eng.bwd)     # far fewer events than launches
     # every launch declares what it writes (a launch with no write set could never be ordered)
     assert all(L.writes for L in eng.fwd + eng.bwd)
