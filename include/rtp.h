@@ -105,7 +105,7 @@ int rtp_wgrad(const RtpAct* gy, const RtpAct* x, const RtpConvGeom* g, int nspli
 int rtp_wgrad_nsplit(const RtpConvGeom* g);
 
 /* Per boundary-class channel sums of an output-side gradient: out fp32 [n][64][c];
- * scratch fp32 [n][nsplit][64][c] (row-split partials, reduced in fixed order). */
+ * scratch fp32 [n][nsplit][64][c] (row-split partials, reduced in fixed order).  out == NULL: partials only. */
 int rtp_class_sums(const RtpAct* gy, int n, int d, int h, int w, int nsplit, float* scratch, float* out, void* stream);
 /* Fixed-order reduction of class-sum partials [n][nsplit][64][c] -> out [n][64][c]. */
 int rtp_class_sums_reduce(const float* scratch, int nsplit, int n, int c, float* out, void* stream);
@@ -117,9 +117,29 @@ int rtp_wgrad_fold(const float* gp, int nsplit, const float* csum, const float* 
                    const float* beta, int groups, const RtpConvGeom* g, int ci_real, int co_real, float* dw,
                    float* dbias, int accumulate, void* stream);
 
+/* Deferred tail of the backward sweep.  Class-sum reductions, slab folds and GroupNorm parameter sums only feed the
+ * optimiser and are microseconds of work each; instead of ~110 launches per step the host records one descriptor per
+ * item and runs every item of a dependency stage as ONE grid.  Usage: fill host descriptors
+ * (rtp_tail_desc_bytes() bytes each) with the rtp_tail_desc_* calls -- same arguments and semantics as the single-item
+ * entry points, plus the item's block count and dynamic LDS bytes -- copy the array to the device together with
+ * block_start[count+1] (exclusive prefix sums of the block counts) and launch with the MAX of the LDS sizes.
+ * Items of one launch must be independent (class reductions + GroupNorm parameter sums first, the folds second). */
+int rtp_tail_desc_bytes(void);
+int rtp_tail_desc_class_reduce(const float* scratch, int nsplit, int n, int c, float* out, void* desc /*host*/,
+                               int* blocks, int* shm_bytes);
+int rtp_tail_desc_wgrad_fold(const float* gp, int nsplit, const float* csum, const float* mr, const float* gamma,
+                             const float* beta, int groups, const RtpConvGeom* g, int ci_real, int co_real, float* dw,
+                             float* dbias, int accumulate, void* desc /*host*/, int* blocks, int* shm_bytes);
+/* coeff: the buffer rtp_gn_bwd_coeffs(..., dgamma = NULL, dbeta = NULL, ...) wrote. */
+int rtp_tail_desc_gn_param(const float* coeff, int n, int c, float* dgamma, float* dbeta, int accumulate,
+                           void* desc /*host*/, int* blocks, int* shm_bytes);
+int rtp_tail_launch(const void* descs /*device*/, const int* block_start /*device*/, int count, int total_blocks,
+                    int shm_bytes, void* stream);
+
 /* GroupNorm backward coefficients from pq = rtp_chan_stats(dxhat, x):
  *   coeff[n][c] = (A, B, C) with  dx = A*dxhat + B*x + C ;  dgamma/dbeta (+)= per-channel param grads.
- *   The coeff buffer must hold n*c*5 floats (n*c*3 coefficients followed by n*c*2 of scratch). */
+ *   The coeff buffer must hold n*c*5 floats (n*c*3 coefficients followed by n*c*2 of scratch).
+ *   dgamma == dbeta == NULL: only the coefficients (and the scratch rtp_tail_desc_gn_param later sums). */
 int rtp_gn_bwd_coeffs(const float* pq, int nsplit, const float* mr, const float* gamma, int n, int c, int groups,
                       long vox, float* coeff, float* dgamma, float* dbeta, int accumulate, void* stream);
 

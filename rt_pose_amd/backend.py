@@ -136,6 +136,39 @@ class HipBackend:
         keep = (pq, mr, gamma, coeff, dgamma, dbeta)
         return lambda s: check(fn(*args, s), "rtp_gn_bwd_coeffs") or keep and None
 
+    def tail(self, items):
+        """One launch for a list of independent deferred items (rtp_tail_*): tuples ("class_reduce", scratch, nsplit,
+        n, c, out) | ("wgrad_fold", <wgrad_fold args>) | ("gn_param", coeff, n, c, dgamma, dbeta, acc)."""
+        lib = self.lib
+        nb = lib.rtp_tail_desc_bytes()
+        host = C.create_string_buffer(nb * len(items))
+        starts, shm, keep = [0], 0, []
+        for i, it in enumerate(items):
+            d = C.c_void_p(C.addressof(host) + i * nb)
+            blocks, sb = C.c_int(0), C.c_int(0)
+            kind, a = it[0], it[1:]
+            if kind == "class_reduce":
+                rc = lib.rtp_tail_desc_class_reduce(_ptr(a[0]), a[1], a[2], a[3], _ptr(a[4]), d, C.byref(blocks), C.byref(sb))
+            elif kind == "wgrad_fold":
+                gp, nsplit, csum, mr, gamma, beta, groups, geom, ci_real, co_real, dw, dbias, acc = a
+                rc = lib.rtp_tail_desc_wgrad_fold(_ptr(gp), nsplit, _ptr(csum), _ptr(mr), _ptr(gamma), _ptr(beta), groups,
+                                                  _geom(geom), ci_real, co_real, _ptr(dw), _ptr(dbias), int(acc), d,
+                                                  C.byref(blocks), C.byref(sb))
+            elif kind == "gn_param":
+                rc = lib.rtp_tail_desc_gn_param(_ptr(a[0]), a[1], a[2], _ptr(a[3]), _ptr(a[4]), int(a[5]), d,
+                                                C.byref(blocks), C.byref(sb))
+            else:
+                raise ValueError(kind)
+            check(rc, "rtp_tail_desc_" + kind)
+            starts.append(starts[-1] + blocks.value)
+            shm = max(shm, sb.value)
+            keep.append(a)
+        descs = torch.frombuffer(bytearray(host.raw), dtype=torch.uint8).to(self.device)
+        st = torch.tensor(starts, dtype=torch.int32, device=self.device)
+        fn, args = lib.rtp_tail_launch, (_ptr(descs), _ptr(st), len(items), starts[-1], shm)
+        keep = (keep, descs, st)
+        return lambda s: check(fn(*args, s), "rtp_tail_launch") or keep and None
+
     # -------------------------------------------------------------- point-wise family
     @staticmethod
     def _terms(terms, with_dims):

@@ -4,6 +4,8 @@
 // materialised: x_hat[c] = x[c]*scale[n,c] + shift[n,c] is folded into per-sample bf16 weights
 // (W*scale) and a per-boundary-class bias (sum over in-bounds taps of W.shift), because zero padding is
 // applied AFTER the norm.  The backward pass undoes the fold with per-(n,c) sums (P,Q) and per-class sums.
+#include <string.h>
+
 #include "rtp_common.h"
 #include "rtp_prof.h"
 
@@ -301,7 +303,8 @@ extern "C" int rtp_gn_bwd_coeffs(const float* pq, int nsplit, const float* mr, c
   RtpProfScope prof(RTP_FAM_NORM, s);
   float* part = coeff + (long)n * c * 3;  // the coeff buffer carries n*c*2 floats of scratch behind the coefficients
   hipLaunchKernelGGL(gn_bwd_coeffs_kernel, dim3(n), dim3(256), 0, s, pq, nsplit, mr, gamma, c, groups, vox, coeff, part);
-  hipLaunchKernelGGL(gn_bwd_param_kernel, dim3((2 * c + 255) / 256), dim3(256), 0, s, part, n, c, dgamma, dbeta, accumulate);
+  if (dgamma && dbeta)  // NULL: the caller sums `part` later (rtp_tail_desc_gn_param)
+    hipLaunchKernelGGL(gn_bwd_param_kernel, dim3((2 * c + 255) / 256), dim3(256), 0, s, part, n, c, dgamma, dbeta, accumulate);
   RTP_CHECK_LAUNCH();
   return RTP_OK;
 }
@@ -366,17 +369,38 @@ __global__ __launch_bounds__(256) void class_sums_kernel(const bf16_t* g, int cs
   for (int i = tid; i < 64 * c; i += 256) o[i] = cls_sum[i];
 }
 
-__global__ void class_sums_final(const float* part, int nsplit, int per_n, float* out) {
-  const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;  // over n*64*c
-  const long n = i / per_n, r = i - n * per_n;
-  float acc = 0.f;
-  for (int s = 0; s < nsplit; ++s) acc += part[(n * nsplit + s) * per_n + r];
-  out[i] = acc;
+struct ClsRedParams { const float* part; float* out; int nsplit, per_n, n; };
+
+__device__ __forceinline__ void class_reduce_body(const ClsRedParams& p, int bid) {
+  const long i4 = (long)bid * 256 + threadIdx.x;       // one float4 of out[n][64*c] per thread
+  const long total4 = (long)p.n * p.per_n / 4;
+  if (i4 >= total4) return;
+  const long n = (i4 * 4) / p.per_n, r = i4 * 4 - n * p.per_n;
+  const float* src = p.part + n * p.nsplit * p.per_n + r;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  int s = 0;
+  for (; s + 8 <= p.nsplit; s += 8) {
+    f32x4 g[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) g[k] = *reinterpret_cast<const f32x4*>(src + (long)(s + k) * p.per_n);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc += g[k];
+  }
+  for (; s < p.nsplit; ++s) acc += *reinterpret_cast<const f32x4*>(src + (long)s * p.per_n);
+  *reinterpret_cast<f32x4*>(p.out + i4 * 4) = acc;
+}
+
+__global__ __launch_bounds__(256) void class_sums_final(ClsRedParams p) { class_reduce_body(p, blockIdx.x); }
+
+static void launch_class_final(const float* part, int nsplit, int n, int c, float* out, hipStream_t s) {
+  ClsRedParams p;
+  p.part = part; p.out = out; p.nsplit = nsplit; p.per_n = 64 * c; p.n = n;
+  hipLaunchKernelGGL(class_sums_final, dim3(rtp_div_up((long)n * 64 * c / 4, 256)), dim3(256), 0, s, p);
 }
 
 extern "C" int rtp_class_sums(const RtpAct* gy, int n, int d, int h, int w, int nsplit, float* scratch, float* out,
                               void* stream) {
-  if (!gy || !out || !scratch) return RTP_ERR_SHAPE;
+  if (!gy || !scratch) return RTP_ERR_SHAPE;
   const int c = gy->c;
   if (c % 8 || c > 256 || (64 % (c / 8))) return RTP_ERR_UNSUPPORTED;
   if ((gy->cs % 8) || (gy->co % 8)) return RTP_ERR_ALIGN;
@@ -384,8 +408,7 @@ extern "C" int rtp_class_sums(const RtpAct* gy, int n, int d, int h, int w, int 
   RtpProfScope prof(RTP_FAM_NORM, s);
   hipLaunchKernelGGL(class_sums_kernel, dim3(nsplit, n), dim3(256), sizeof(float) * 64 * c, s, (const bf16_t*)gy->ptr,
                      gy->cs, gy->co, c, d, h, w, nsplit, scratch);
-  const long total = (long)n * 64 * c;  // multiple of 256
-  hipLaunchKernelGGL(class_sums_final, dim3((int)(total / 256)), dim3(256), 0, s, scratch, nsplit, 64 * c, out);
+  if (out) launch_class_final(scratch, nsplit, n, c, out, s);  // out == NULL: partials only (reduced later, e.g. by the tail)
   RTP_CHECK_LAUNCH();
   return RTP_OK;
 }
@@ -395,101 +418,255 @@ extern "C" int rtp_class_sums_reduce(const float* scratch, int nsplit, int n, in
   if (c % 8) return RTP_ERR_ALIGN;
   hipStream_t s = (hipStream_t)stream;
   RtpProfScope prof(RTP_FAM_NORM, s);
-  const long total = (long)n * 64 * c;  // multiple of 256
-  hipLaunchKernelGGL(class_sums_final, dim3((int)(total / 256)), dim3(256), 0, s, scratch, nsplit, 64 * c, out);
+  launch_class_final(scratch, nsplit, n, c, out, s);
   RTP_CHECK_LAUNCH();
   return RTP_OK;
 }
 
 // ------------------------------------------------------------------------------------------------
-// rtp_wgrad_fold : one block per (co, tap); 8 slab groups x 32 input channels per pass
+// rtp_wgrad_fold : one block per (tap, group of R = 256/ci_pad output-channel rows)
 // ------------------------------------------------------------------------------------------------
 struct WFoldParams {
   const float* gp; int nsplit; const float* csum; const float* mr; const float* gamma; const float* beta;
   int groups, n; FoldParams f; int co32, csum_c; float* dw; float* dbias; int accumulate;
 };
 
-// One block per (co, tap).  A thread owns 4 input channels (one 16-B load per slab row) and one of 256/(ci/4) slab
-// groups; the (sample, split) slabs of a group are summed with the sample's GroupNorm scale applied on the fly, then the
-// groups are folded through LDS in fixed order (deterministic).
+__host__ __device__ __forceinline__ int wfold_rows(int ci_pad) { return 256 / ci_pad; }  // rows a wave covers with one 1-KB read
+static int wfold_blocks(const WFoldParams& p) {
+  const int R = wfold_rows(p.f.ci_pad);
+  return p.f.ntap * ((p.f.co_real + R - 1) / R);
+}
+static size_t wfold_shm(const WFoldParams& p) {
+  const int R = wfold_rows(p.f.ci_pad);
+  return sizeof(float) * (2 * (size_t)p.n * p.f.ci_pad + (size_t)((p.n * R + R + 3) & ~3) + 4 * 64 * 4);
+}
+
+// The slabs [n][split][tap][co32][ci_pad] are the bulk of the bytes (one slab per workgroup of the tiled weight-gradient
+// kernel: 28 MB per full-resolution layer), so the mapping is built around them: a wave reads 1 KB of CONTIGUOUS slab
+// (R rows) per load, the block's 4 waves take every 4th split, 8 loads are in flight per lane, and the sample's
+// GroupNorm scale is applied on the fly from an LDS table.  Waves are folded through LDS in fixed order (deterministic).
+__device__ __forceinline__ void wgrad_fold_body(const WFoldParams& p, int bid, float* sh) {
+  const int ntap = p.f.ntap, ci_real = p.f.ci_real, ci_pad = p.f.ci_pad, co_real = p.f.co_real;
+  const int R = wfold_rows(ci_pad);
+  const int rgs = (co_real + R - 1) / R;
+  const int tap = bid / rgs, rg = bid - tap * rgs;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool norm = p.mr != nullptr;
+  float* sc = sh;                          // [n][ci_pad] scale
+  float* shc = sc + p.n * ci_pad;          // [n][ci_pad] shift
+  float* sdy = shc + p.n * ci_pad;         // [n][R] sum of dy over the voxels whose tap is in bounds
+  f32x4* red = reinterpret_cast<f32x4*>(sdy + ((p.n * R + R + 3) & ~3));  // [4 waves][64 lanes]
+  const int cg = norm ? ci_real / p.groups : 1;
+  for (int i = tid; i < p.n * ci_pad; i += 256) {
+    const int n = i / ci_pad, ci = i - n * ci_pad;
+    float s = (ci < ci_real) ? 1.f : 0.f, t = 0.f;
+    if (norm && ci < ci_real) {
+      const int gi = ci / cg;
+      const float mu = p.mr[((long)n * p.groups + gi) * 2], r = p.mr[((long)n * p.groups + gi) * 2 + 1];
+      s = r * p.gamma[ci];
+      t = p.beta[ci] - mu * s;
+    }
+    sc[i] = s;
+    shc[i] = t;
+  }
+  // per (sample, row): lanes = boundary classes, one shuffle reduction each
+  if (p.csum && norm) {
+    const bool inb = tap_inb_class(tap, lane, p.f);
+    for (int q = wave; q < p.n * R; q += 4) {
+      const int n = q / R, co = rg * R + (q - n * R);
+      float v = (inb && co < co_real) ? p.csum[((long)n * 64 + lane) * p.csum_c + co] : 0.f;
+      v = wave_sum(v);
+      if (lane == 0) sdy[q] = v;
+    }
+  }
+  if (p.dbias && tap == 0) {
+    for (int r = wave; r < R; r += 4) {
+      const int co = rg * R + r;
+      float v = 0.f;
+      if (co < co_real)
+        for (int n = 0; n < p.n; ++n) v += p.csum[((long)n * 64 + lane) * p.csum_c + co];
+      v = wave_sum(v);
+      if (lane == 0 && co < co_real) {
+        if (p.accumulate) p.dbias[co] += v; else p.dbias[co] = v;
+      }
+    }
+  }
+  __syncthreads();
+  const int r = (lane * 4) / ci_pad, ci = (lane * 4) - r * ci_pad, co = rg * R + r;
+  const long slab = (long)ntap * p.co32 * ci_pad;
+  const float* base = p.gp + ((long)tap * p.co32 + rg * R) * ci_pad + lane * 4;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int n = 0; n < p.n; ++n) {
+    const f32x4 s4 = *reinterpret_cast<const f32x4*>(sc + n * ci_pad + ci);
+    const float* bn = base + (long)n * p.nsplit * slab;
+    f32x4 part = {0.f, 0.f, 0.f, 0.f};
+    int s = wave;
+    for (; s + 28 < p.nsplit; s += 32) {
+      f32x4 g[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) g[k] = *reinterpret_cast<const f32x4*>(bn + (long)(s + 4 * k) * slab);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) part += g[k];
+    }
+    for (; s < p.nsplit; s += 4) part += *reinterpret_cast<const f32x4*>(bn + (long)s * slab);
+    acc += s4 * part;
+  }
+  red[wave * 64 + lane] = acc;
+  __syncthreads();
+  if (wave == 0) {
+    f32x4 a = red[lane];
+#pragma unroll
+    for (int k = 1; k < 4; ++k) a += red[k * 64 + lane];
+    if (norm && p.csum)
+      for (int n = 0; n < p.n; ++n) {
+        const f32x4 t4 = *reinterpret_cast<const f32x4*>(shc + n * ci_pad + ci);
+        a += t4 * sdy[n * R + r];
+      }
+    if (co < co_real) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (ci + j < ci_real) {
+          float* o = p.dw + ((long)co * p.f.ci_total + p.f.ci_off + ci + j) * ntap + tap;
+          if (p.accumulate) *o += a[j]; else *o = a[j];
+        }
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void wgrad_fold_kernel(WFoldParams p) {
   extern __shared__ __attribute__((aligned(16))) float sh[];
-  const int ntap = p.f.ntap, ci_real = p.f.ci_real, ci_pad = p.f.ci_pad;
-  const int co = blockIdx.x / ntap, tap = blockIdx.x - co * ntap, tid = threadIdx.x;
-  float* sdy = sh;                        // [n]
-  float* red = sdy + ((p.n + 3) & ~3);    // [groups_of_slabs][ci_real]
-  const bool norm = p.mr != nullptr;
-  for (int n = tid; n < p.n; n += 256) {
-    float acc = 0.f;
-    if (p.csum && norm)
-      for (int cls = 0; cls < 64; ++cls)
-        if (tap_inb_class(tap, cls, p.f)) acc += p.csum[((long)n * 64 + cls) * p.csum_c + co];
-    sdy[n] = acc;
-  }
-  __syncthreads();
-  if (p.dbias && tap == 0 && tid == 0) {
-    float acc = 0.f;
-    for (int n = 0; n < p.n; ++n)
-      for (int cls = 0; cls < 64; ++cls) acc += p.csum[((long)n * 64 + cls) * p.csum_c + co];
-    if (p.accumulate) p.dbias[co] += acc; else p.dbias[co] = acc;
-  }
-  const int quads = ci_real >> 2;          // 8, 16, 32 or 64 (ci_real is a multiple of 32)
-  const int nsg = 256 / quads;             // slab groups
-  const int cq = tid % quads, sg = tid / quads;
-  const int cg = norm ? ci_real / p.groups : 1;
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  if (sg < nsg) {
-    const int total = p.n * p.nsplit;
-    for (int i = sg; i < total; i += nsg) {
-      const int n = i / p.nsplit;
-      const f32x4 g = *reinterpret_cast<const f32x4*>(p.gp + (((long)i * ntap + tap) * p.co32 + co) * ci_pad + cq * 4);
-      f32x4 sc = {1.f, 1.f, 1.f, 1.f};
-      if (norm) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int ci = cq * 4 + j, gi = ci / cg;
-          sc[j] = p.mr[((long)n * p.groups + gi) * 2 + 1] * p.gamma[ci];
-        }
-      }
-      acc += sc * g;
-    }
-    if (norm && sg == 0) {
-      for (int n = 0; n < p.n; ++n) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int ci = cq * 4 + j, gi = ci / cg;
-          const float mu = p.mr[((long)n * p.groups + gi) * 2], r = p.mr[((long)n * p.groups + gi) * 2 + 1];
-          acc[j] += (p.beta[ci] - mu * r * p.gamma[ci]) * sdy[n];
-        }
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) red[sg * ci_real + cq * 4 + j] = acc[j];
-  }
-  __syncthreads();
-  for (int ci = tid; ci < ci_real; ci += 256) {
-    float a = 0.f;
-    for (int k = 0; k < nsg; ++k) a += red[k * ci_real + ci];
-    float* o = p.dw + ((long)co * p.f.ci_total + p.f.ci_off + ci) * ntap + tap;
-    if (p.accumulate) *o += a; else *o = a;
-  }
+  wgrad_fold_body(p, blockIdx.x, sh);
+}
+
+static int fill_wfold(WFoldParams& p, const float* gp, int nsplit, const float* csum, const float* mr, const float* gamma,
+                      const float* beta, int groups, const RtpConvGeom* g, int ci_real, int co_real, float* dw,
+                      float* dbias, int accumulate) {
+  int rc = fill_fold(p.f, g, ci_real, co_real);
+  if (rc) return rc;
+  if (!gp || !dw || nsplit < 1) return RTP_ERR_SHAPE;
+  if ((mr || dbias) && !csum) return RTP_ERR_SHAPE;
+  if (mr && (!gamma || !beta || groups < 1 || ci_real % groups)) return RTP_ERR_SHAPE;
+  p.gp = gp; p.nsplit = nsplit; p.csum = csum; p.mr = mr; p.gamma = gamma; p.beta = beta;
+  p.groups = groups; p.n = g->n; p.co32 = (g->co + 31) / 32 * 32; p.csum_c = p.co32;
+  p.dw = dw; p.dbias = dbias; p.accumulate = accumulate;
+  if (p.f.ci_pad != 32 && p.f.ci_pad != 64 && p.f.ci_pad != 128 && p.f.ci_pad != 256) return RTP_ERR_UNSUPPORTED;
+  if (wfold_shm(p) > 60 * 1024) return RTP_ERR_UNSUPPORTED;
+  return RTP_OK;
 }
 
 extern "C" int rtp_wgrad_fold(const float* gp, int nsplit, const float* csum, const float* mr, const float* gamma,
                               const float* beta, int groups, const RtpConvGeom* g, int ci_real, int co_real, float* dw,
                               float* dbias, int accumulate, void* stream) {
   WFoldParams p;
-  int rc = fill_fold(p.f, g, ci_real, co_real);
+  int rc = fill_wfold(p, gp, nsplit, csum, mr, gamma, beta, groups, g, ci_real, co_real, dw, dbias, accumulate);
   if (rc) return rc;
-  if ((mr || dbias) && !csum) return RTP_ERR_SHAPE;
-  p.gp = gp; p.nsplit = nsplit; p.csum = csum; p.mr = mr; p.gamma = gamma; p.beta = beta;
-  p.groups = groups; p.n = g->n; p.co32 = (g->co + 31) / 32 * 32; p.csum_c = p.co32;
-  p.dw = dw; p.dbias = dbias; p.accumulate = accumulate;
-  if (ci_real % 32 || ci_real > 256) return RTP_ERR_UNSUPPORTED;
-  const size_t shm = sizeof(float) * ((size_t)((p.n + 3) & ~3) + (size_t)(256 / (ci_real / 4)) * ci_real);
   hipStream_t s = (hipStream_t)stream;
   RtpProfScope prof(RTP_FAM_NORM, s);
-  hipLaunchKernelGGL(wgrad_fold_kernel, dim3(co_real * p.f.ntap), dim3(256), shm, s, p);
+  hipLaunchKernelGGL(wgrad_fold_kernel, dim3(wfold_blocks(p)), dim3(256), wfold_shm(p), s, p);
+  RTP_CHECK_LAUNCH();
+  return RTP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Deferred tail of the backward sweep.  Class-sum reductions, slab folds and GroupNorm parameter gradients only feed
+// the optimiser, and each is a few microseconds of work: launched per layer they are ~110 latency-bound launches per
+// step.  The plan instead records one descriptor per item and runs them as ONE grid per dependency stage (class
+// reductions + GroupNorm parameter sums, then the folds): block -> (descriptor, local block) by binary search.
+// ------------------------------------------------------------------------------------------------
+struct GnParParams { const float* part; float* dgamma; float* dbeta; int n, c, accumulate; };
+enum { TAIL_CLASS_REDUCE = 0, TAIL_WGRAD_FOLD = 1, TAIL_GN_PARAM = 2 };
+struct RtpTailDesc {
+  int kind, blocks;
+  union { WFoldParams wf; ClsRedParams cr; GnParParams gp; } u;
+};
+
+__device__ __forceinline__ void gn_param_body(const GnParParams& p, int bid) {
+  const int t = bid * 256 + threadIdx.x;
+  if (t >= 2 * p.c) return;
+  const int ch = t >> 1, which = t & 1;
+  float acc = 0.f;
+  for (int i = 0; i < p.n; ++i) acc += p.part[((long)i * p.c + ch) * 2 + which];
+  float* o = which ? p.dbeta + ch : p.dgamma + ch;
+  if (p.accumulate) *o += acc; else *o = acc;
+}
+
+__global__ __launch_bounds__(256) void tail_kernel(const RtpTailDesc* descs, const int* starts, int count) {
+  extern __shared__ __attribute__((aligned(16))) float sh[];
+  const int bid = blockIdx.x;
+  int lo = 0, hi = count;  // starts[lo] <= bid < starts[lo + 1]
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (starts[mid] <= bid) lo = mid; else hi = mid;
+  }
+  const RtpTailDesc& d = descs[lo];
+  const int b = bid - starts[lo];
+  if (d.kind == TAIL_WGRAD_FOLD) {
+    const WFoldParams p = d.u.wf;
+    wgrad_fold_body(p, b, sh);
+  } else if (d.kind == TAIL_CLASS_REDUCE) {
+    const ClsRedParams p = d.u.cr;
+    class_reduce_body(p, b);
+  } else {
+    const GnParParams p = d.u.gp;
+    gn_param_body(p, b);
+  }
+}
+
+extern "C" int rtp_tail_desc_bytes(void) { return (int)sizeof(RtpTailDesc); }
+
+extern "C" int rtp_tail_desc_class_reduce(const float* scratch, int nsplit, int n, int c, float* out, void* desc,
+                                          int* blocks, int* shm_bytes) {
+  if (!scratch || !out || !desc || nsplit < 1 || n < 1) return RTP_ERR_SHAPE;
+  if (c % 8) return RTP_ERR_ALIGN;
+  RtpTailDesc d;
+  memset(&d, 0, sizeof(d));
+  d.kind = TAIL_CLASS_REDUCE;
+  d.u.cr.part = scratch; d.u.cr.out = out; d.u.cr.nsplit = nsplit; d.u.cr.per_n = 64 * c; d.u.cr.n = n;
+  d.blocks = rtp_div_up((long)n * 64 * c / 4, 256);
+  memcpy(desc, &d, sizeof(d));
+  if (blocks) *blocks = d.blocks;
+  if (shm_bytes) *shm_bytes = 0;
+  return RTP_OK;
+}
+
+extern "C" int rtp_tail_desc_wgrad_fold(const float* gp, int nsplit, const float* csum, const float* mr,
+                                        const float* gamma, const float* beta, int groups, const RtpConvGeom* g,
+                                        int ci_real, int co_real, float* dw, float* dbias, int accumulate, void* desc,
+                                        int* blocks, int* shm_bytes) {
+  if (!desc) return RTP_ERR_SHAPE;
+  RtpTailDesc d;
+  memset(&d, 0, sizeof(d));
+  d.kind = TAIL_WGRAD_FOLD;
+  int rc = fill_wfold(d.u.wf, gp, nsplit, csum, mr, gamma, beta, groups, g, ci_real, co_real, dw, dbias, accumulate);
+  if (rc) return rc;
+  d.blocks = wfold_blocks(d.u.wf);
+  memcpy(desc, &d, sizeof(d));
+  if (blocks) *blocks = d.blocks;
+  if (shm_bytes) *shm_bytes = (int)wfold_shm(d.u.wf);
+  return RTP_OK;
+}
+
+extern "C" int rtp_tail_desc_gn_param(const float* coeff, int n, int c, float* dgamma, float* dbeta, int accumulate,
+                                      void* desc, int* blocks, int* shm_bytes) {
+  if (!coeff || !dgamma || !dbeta || !desc || n < 1 || c < 1) return RTP_ERR_SHAPE;
+  RtpTailDesc d;
+  memset(&d, 0, sizeof(d));
+  d.kind = TAIL_GN_PARAM;
+  d.u.gp.part = coeff + (long)n * c * 3;  // the scratch rtp_gn_bwd_coeffs leaves behind the coefficients
+  d.u.gp.dgamma = dgamma; d.u.gp.dbeta = dbeta; d.u.gp.n = n; d.u.gp.c = c; d.u.gp.accumulate = accumulate;
+  d.blocks = rtp_div_up(2 * c, 256);
+  memcpy(desc, &d, sizeof(d));
+  if (blocks) *blocks = d.blocks;
+  if (shm_bytes) *shm_bytes = 0;
+  return RTP_OK;
+}
+
+extern "C" int rtp_tail_launch(const void* descs, const int* block_start, int count, int total_blocks, int shm_bytes,
+                               void* stream) {
+  if (!descs || !block_start || count < 1 || total_blocks < 1 || shm_bytes < 0 || shm_bytes > 60 * 1024) return RTP_ERR_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  RtpProfScope prof(RTP_FAM_NORM, s);
+  hipLaunchKernelGGL(tail_kernel, dim3(total_blocks), dim3(256), (size_t)shm_bytes, s, (const RtpTailDesc*)descs, block_start, count);
   RTP_CHECK_LAUNCH();
   return RTP_OK;
 }

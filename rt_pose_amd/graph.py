@@ -112,6 +112,7 @@ class Graph:
         self.pgrad = {}            # name -> fp32 grad tensor written by the backward plan
         self.used_params = []      # creation order
         self.bytes = 0
+        self.tail_a, self.tail_b = [], []   # deferred optimiser-only items (emit_tail)
         self.full_vox = None       # voxels of the first (full-resolution) activation: lanes are assigned by resolution
         # algorithmic FLOPs (2*MACs of real channels) per kernel family, per replay of the lists
         self.flops = {"conv_fwd": 0, "conv_dgrad": 0, "wgrad": 0, "conv_tiled": 0, "conv_generic": 0,
@@ -251,6 +252,22 @@ class Graph:
             if gy is None:
                 continue
             op.emit_backward(gy)
+        self.emit_tail()
+
+    def emit_tail(self):
+        """The deferred items as two launches (stage a: class reductions + GroupNorm parameter sums; stage b: folds)."""
+        import os
+        stages = [self.tail_a, self.tail_b]
+        if os.environ.get("RTP_NO_TAIL"):   # A/B: one launch per item, like a per-layer plan
+            stages = [[it] for it in self.tail_a] + [[it] for it in self.tail_b]
+        for items in stages:
+            if not items:
+                continue
+            bufs = [t for it in items for t in it[1:] if hasattr(t, "data_ptr")]
+            outs = {"class_reduce": (5,), "gn_param": (4, 5), "wgrad_fold": (11, 12)}
+            writes = [it[i] for it in items for i in outs[it[0]] if it[i] is not None]
+            wk = set(t.data_ptr() for t in writes)
+            self.emit_bwd(self.be.tail(items), L_FULL, [t for t in bufs if t.data_ptr() not in wk], writes)
 
 
 class StemOp:
@@ -342,8 +359,9 @@ class ConvOp:
                     g.emit_bwd(be.chan_stats(dxh, x, S, pq), lane, [dxh, x], [pq])
                 coeff = be.alloc((g.n * ge.ci * 5,), "f32")  # [n][c][3] coefficients + [n][c][2] scratch
                 g.emit_bwd(be.gn_bwd_coeffs(pq, S, self.mr, g.params[self.gn[0]], g.n, self.ci_real, self.groups,
-                                            x.vox, coeff, g.pgrad[self.gn[0]], g.pgrad[self.gn[1]], 0),
-                           lane, [pq, self.mr], [coeff, g.pgrad[self.gn[0]], g.pgrad[self.gn[1]]])
+                                            x.vox, coeff, None, None, 0),
+                           lane, [pq, self.mr], [coeff])
+                g.tail_a.append(("gn_param", coeff, g.n, self.ci_real, g.pgrad[self.gn[0]], g.pgrad[self.gn[1]], 0))
                 if x.needs_grad:
                     x.contribs.append((dxh, coeff))
             elif x.needs_grad:
@@ -361,20 +379,21 @@ class ConvOp:
         g.emit_bwd(be.wgrad(gy, x, ge, S, gp), wl, [gy, x], [gp])
         g.flops["wgrad"] += self.alg_flops
         g.flops["wgrad_tiled" if self.tiled_wgrad else "wgrad_generic"] += self.alg_flops
+        # Everything after the correlation itself (class-sum reduction, slab fold + GroupNorm un-fold) only feeds the
+        # optimiser: recorded here, run once for all layers at the end of the sweep (Graph.emit_tail).
         csum = None
         if self.gn or self.bname:
             csum = be.alloc((g.n, 64, gy.c), "f32")
             if self.y.grad_cls is not None and self.y.grad is gy:
                 cs_split, cs_scratch = self.y.grad_cls
-                g.emit_bwd(be.class_sums_reduce(cs_scratch, cs_split, g.n, gy.c, csum), wl, [cs_scratch], [csum])
             else:
                 cs_split = cls_split(gy.d, gy.h)
                 cs_scratch = be.alloc((g.n, cs_split, 64, gy.c), "f32")
-                g.emit_bwd(be.class_sums(gy, cs_split, cs_scratch, csum), wl, [gy], [cs_scratch, csum])
-        g.emit_bwd(be.wgrad_fold(gp, S, csum, self.mr, g.params[self.gn[0]] if self.gn else None,
-                                 g.params[self.gn[1]] if self.gn else None, self.groups, ge, self.ci_real,
-                                 self.co_real, g.pgrad[self.wname], g.pgrad[self.bname] if self.bname else None, 0),
-                   wl, [gp, csum, self.mr], [g.pgrad[self.wname], g.pgrad[self.bname] if self.bname else None])
+                g.emit_bwd(be.class_sums(gy, cs_split, cs_scratch, None), wl, [gy], [cs_scratch])
+            g.tail_a.append(("class_reduce", cs_scratch, cs_split, g.n, gy.c, csum))
+        g.tail_b.append(("wgrad_fold", gp, S, csum, self.mr, g.params[self.gn[0]] if self.gn else None,
+                         g.params[self.gn[1]] if self.gn else None, self.groups, ge, self.ci_real,
+                         self.co_real, g.pgrad[self.wname], g.pgrad[self.bname] if self.bname else None, 0))
 
 
 class FuseOp:

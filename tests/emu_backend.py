@@ -216,8 +216,39 @@ class EmuBackend:
         def run(s):
             cls = _classes(gy.d, gy.h, gy.w).reshape(-1)
             gf = _sl(gy).reshape(gy.n, gy.vox, gy.c)
-            out.zero_()
-            out.index_add_(1, cls, gf)
+            tot = torch.zeros(gy.n, 64, gy.c)
+            tot.index_add_(1, cls, gf)
+            if out is None:   # partials only: everything in split 0
+                scratch.zero_()
+                scratch.view(gy.n, nsplit, 64, gy.c)[:, 0] = tot
+            else:
+                out.copy_(tot)
+        return run
+
+    def tail(self, items):
+        fns = []
+        for it in items:
+            kind, a = it[0], it[1:]
+            if kind == "class_reduce":
+                fns.append(self.class_sums_reduce(*a))
+            elif kind == "wgrad_fold":
+                fns.append(self.wgrad_fold(*a))
+            elif kind == "gn_param":
+                fns.append(self.gn_bwd_param(*a))
+            else:
+                raise ValueError(kind)
+        return lambda s: [f(s) for f in fns] and None
+
+    def gn_bwd_param(self, coeff, n, c, dgamma, dbeta, acc):
+        def run(s):
+            part = coeff[n * c * 3:n * c * 5].view(n, c, 2)
+            dg, db = part[:, :, 0].sum(0), part[:, :, 1].sum(0)
+            if acc:
+                dgamma.add_(dg)
+                dbeta.add_(db)
+            else:
+                dgamma.copy_(dg)
+                dbeta.copy_(db)
         return run
 
     def wgrad_fold(self, gp, nsplit, csum, mr, gamma, beta, groups, geom, ci_real, co_real, dw, dbias, acc):
@@ -266,6 +297,11 @@ class EmuBackend:
             cf[:, :, 0] = r * gam
             cf[:, :, 1] = -r * r * s2 / m
             cf[:, :, 2] = -r * s1 / m + r * r * mu * s2 / m
+            part = coeff[n * c * 3:n * c * 5].view(n, c, 2)
+            part[:, :, 0] = r * (Q - mu * P)
+            part[:, :, 1] = P
+            if dgamma is None:
+                return
             dg = (r * (Q - mu * P)).sum(0)
             db = P.sum(0)
             if acc:

@@ -293,6 +293,54 @@ def test_gn_bwd_coeffs_and_class_sums(hip):
         check(out, F32 * 5, "class_sums %r" % (dims,))
 
 
+def test_deferred_tail_batches(hip):
+    """rtp_tail_*: several independent items per launch equal the single-item entry points' emulation, including slab
+    counts that take the 8-deep unrolled loops (nsplit 37) and every supported channel width."""
+    n, groups = 3, 8
+    stage_a, stage_a_emu, stage_b, stage_b_emu, outs = [], [], [], [], []
+    for k, (ci, co_real, ks, stride, norm, bias, nsplit) in enumerate([
+            (32, 32, 3, 1, True, False, 37), (64, 64, 3, 2, True, False, 5), (128, 64, 1, 1, True, False, 2),
+            (32, 15, 3, 1, False, True, 33), (256, 256, 3, 1, True, False, 1), (32, 32, 3, 1, False, False, 9)]):
+        d, h, w = 4, 8, 8
+        pad = ks // 2
+        do, ho, wo = [(s + 2 * pad - ks) // stride + 1 for s in (d, h, w)]
+        co = pad_to(co_real, 16)
+        co32 = pad_to(co, 32)
+        geom = Geom(n, d, h, w, do, ho, wo, ci, co, ks, stride, pad, 0, 0)
+        ntap = ks ** 3
+        gp = Pair(hip, rnd((n, nsplit, ntap, co32, ci), 100 + k, torch.float32))
+        cs_part = Pair(hip, rnd((n, 7, 64, co32), 120 + k, torch.float32)) if (norm or bias) else None
+        cs = Pair(hip, torch.zeros(n, 64, co32)) if (norm or bias) else None
+        mr = Pair(hip, torch.rand(n, groups, 2, generator=torch.Generator().manual_seed(k)) + 0.5) if norm else None
+        gam = Pair(hip, 1 + 0.2 * rnd((ci,), 140 + k, torch.float32)) if norm else None
+        bet = Pair(hip, 0.2 * rnd((ci,), 160 + k, torch.float32)) if norm else None
+        dw = Pair(hip, torch.zeros(co_real, ci, ks, ks, ks))
+        db = Pair(hip, torch.zeros(co_real)) if bias else None
+        outs += [(dw, "dw%d" % k)] + ([(db, "db%d" % k)] if bias else [])
+
+        def side(p, sd):
+            return None if p is None else getattr(p, sd)
+        for sd, sa, sb in (("c", stage_a_emu, stage_b_emu), ("g", stage_a, stage_b)):
+            if cs is not None:
+                sa.append(("class_reduce", side(cs_part, sd), 7, n, co32, side(cs, sd)))
+            sb.append(("wgrad_fold", side(gp, sd), nsplit, side(cs, sd), side(mr, sd), side(gam, sd), side(bet, sd), groups,
+                       geom, ci, co_real, side(dw, sd), side(db, sd), 0))
+        if norm:
+            c = ci
+            pq = Pair(hip, rnd((n, 3, c, 2), 180 + k, torch.float32))
+            coeff = Pair(hip, torch.zeros(n * c * 5))
+            dg, dbt = Pair(hip, torch.zeros(c)), Pair(hip, torch.zeros(c))
+            run(hip, EMU.gn_bwd_coeffs(pq.c, 3, mr.c, gam.c, n, c, groups, 1000, coeff.c, None, None, 0),
+                hip.gn_bwd_coeffs(pq.g, 3, mr.g, gam.g, n, c, groups, 1000, coeff.g, None, None, 0))
+            stage_a_emu.append(("gn_param", coeff.c, n, c, dg.c, dbt.c, 0))
+            stage_a.append(("gn_param", coeff.g, n, c, dg.g, dbt.g, 0))
+            outs += [(dg, "dgamma%d" % k), (dbt, "dbeta%d" % k)]
+    run(hip, EMU.tail(stage_a_emu), hip.tail(stage_a))
+    run(hip, EMU.tail(stage_b_emu), hip.tail(stage_b))
+    for pair, what in outs:
+        check(pair, F32 * 5, what)
+
+
 def test_grad_combine_fuse_upsample(hip):
     n, d, h, w, c = 2, 4, 8, 16, 32
     _, xc, xg = views(hip, rnd((n, d, h, w, c), 30, relu=True), n, d, h, w)
