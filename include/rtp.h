@@ -67,7 +67,8 @@ int rtp_chan_stats(const RtpAct* a, const RtpAct* b, int n, long vox, int nsplit
  *   btab   fp32 [nw][64][co_pad]  bias for each boundary class of an output voxel
  *   mr     fp32 [n][groups][2]  (mean, rstd) saved for backward, or NULL
  *   wd     bf16 [ks^3][ci_pad][cok] or NULL: the same (un-folded) weights packed for the data-gradient conv
- *          (what rtp_pack_dgrad_w produces), emitted here so training needs no separate packing launch
+ *          (what rtp_pack_dgrad_w produces), emitted here so training needs no separate packing launch;
+ *          wf == NULL with wd != NULL packs only wd (no statistics needed)
  * Replaces GroupNorm-apply + weight layout of common.py:25-71 / hr3d.py:147-155. */
 int rtp_fold_fwd(const float* w, const float* bias, const float* gamma, const float* beta, const float* stats,
                  int nsplit, int groups, float eps, const RtpConvGeom* g, int ci_real, int co_real, void* wf,
@@ -133,6 +134,11 @@ int rtp_tail_desc_wgrad_fold(const float* gp, int nsplit, const float* csum, con
 /* coeff: the buffer rtp_gn_bwd_coeffs(..., dgamma = NULL, dbeta = NULL, ...) wrote. */
 int rtp_tail_desc_gn_param(const float* coeff, int n, int c, float* dgamma, float* dbeta, int accumulate,
                            void* desc /*host*/, int* blocks, int* shm_bytes);
+/* Weight packing that needs no activations (a conv without GroupNorm; wf == NULL: only the data-gradient packing wd):
+ * batched so one launch at the start of a step serves every layer. */
+int rtp_tail_desc_fold_fwd(const float* w, const float* bias, const float* gamma, const float* beta, const float* stats,
+                           int nsplit, int groups, float eps, const RtpConvGeom* g, int ci_real, int co_real, void* wf,
+                           float* btab, float* mr, void* wd, void* desc /*host*/, int* blocks, int* shm_bytes);
 int rtp_tail_launch(const void* descs /*device*/, const int* block_start /*device*/, int count, int total_blocks,
                     int shm_bytes, void* stream);
 

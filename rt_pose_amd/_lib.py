@@ -60,6 +60,7 @@ PROTOTYPES = {
     "rtp_tail_desc_class_reduce": [_P, _I, _I, _I, _P, _P, C.POINTER(_I), C.POINTER(_I)],
     "rtp_tail_desc_wgrad_fold": [_P, _I, _P, _P, _P, _P, _I, _G, _I, _I, _P, _P, _I, _P, C.POINTER(_I), C.POINTER(_I)],
     "rtp_tail_desc_gn_param": [_P, _I, _I, _P, _P, _I, _P, C.POINTER(_I), C.POINTER(_I)],
+    "rtp_tail_desc_fold_fwd": [_P, _P, _P, _P, _P, _I, _I, _F, _G, _I, _I, _P, _P, _P, _P, _P, C.POINTER(_I), C.POINTER(_I)],
     "rtp_tail_launch": [_P, _P, _I, _I, _I, _P],
     "rtp_grad_combine": [_T, _I, _A, _A, _A, _I, _L, _P],
     "rtp_grad_combine_cls": [_T, _I, _A, _A, _A, _I, _I, _I, _I, _I, _P, _P],

@@ -138,7 +138,8 @@ class HipBackend:
 
     def tail(self, items):
         """One launch for a list of independent deferred items (rtp_tail_*): tuples ("class_reduce", scratch, nsplit,
-        n, c, out) | ("wgrad_fold", <wgrad_fold args>) | ("gn_param", coeff, n, c, dgamma, dbeta, acc)."""
+        n, c, out) | ("wgrad_fold", <wgrad_fold args>) | ("gn_param", coeff, n, c, dgamma, dbeta, acc) |
+        ("fold_fwd", <fold_fwd args>)."""
         lib = self.lib
         nb = lib.rtp_tail_desc_bytes()
         host = C.create_string_buffer(nb * len(items))
@@ -154,6 +155,11 @@ class HipBackend:
                 rc = lib.rtp_tail_desc_wgrad_fold(_ptr(gp), nsplit, _ptr(csum), _ptr(mr), _ptr(gamma), _ptr(beta), groups,
                                                   _geom(geom), ci_real, co_real, _ptr(dw), _ptr(dbias), int(acc), d,
                                                   C.byref(blocks), C.byref(sb))
+            elif kind == "fold_fwd":
+                w, bias, gamma, beta, stats, nsplit, groups, eps, geom, ci_real, co_real, wf, btab, mr, wd = a
+                rc = lib.rtp_tail_desc_fold_fwd(_ptr(w), _ptr(bias), _ptr(gamma), _ptr(beta), _ptr(stats), nsplit, groups,
+                                                eps, _geom(geom), ci_real, co_real, _ptr(wf), _ptr(btab), _ptr(mr),
+                                                _ptr(wd), d, C.byref(blocks), C.byref(sb))
             elif kind == "gn_param":
                 rc = lib.rtp_tail_desc_gn_param(_ptr(a[0]), a[1], a[2], _ptr(a[3]), _ptr(a[4]), int(a[5]), d,
                                                 C.byref(blocks), C.byref(sb))

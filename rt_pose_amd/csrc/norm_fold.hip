@@ -93,6 +93,7 @@ struct FoldParams {
   int di, hi, wi, dov, ho, wo;
   bf16_t* wf; float* btab; float* mr;
   bf16_t* wd; int cok;  // optional data-gradient packing [tap][ci_pad][cok] (written by the n == 0 blocks)
+  int cos, nw;          // output channels per block; weight sets (n with GroupNorm, 1 without)
 };
 
 __device__ __forceinline__ bool tap_inb_class(int tap, int cls, const FoldParams& p) {
@@ -103,19 +104,47 @@ __device__ __forceinline__ bool tap_inb_class(int tap, int cls, const FoldParams
          tap_inb_1d(kx, (cls >> 4) & 1, (cls >> 5) & 1, p.wo, p.wi, p.stride, p.pad);
 }
 
-#define FOLD_COS 4  // output channels per block: every block owns all taps of its couts, so the bias table needs no cross-block sum
+// Output channels per block: every block owns all taps of its couts, so the bias table needs no cross-block sum.  Chosen
+// so the block's fp32 weight rows [cos][ci_real*ntap] fit 32 KB of LDS.
+static int fold_cos(int ci_real, int ntap) {
+  int cos = 4;
+  while (cos > 1 && (size_t)cos * ci_real * ntap * sizeof(float) > 32 * 1024) cos >>= 1;
+  return cos;
+}
+static size_t fold_shm(const FoldParams& p) {
+  return sizeof(float) * (2 * (size_t)p.ci_pad + (size_t)((p.cos * p.ntap + 3) & ~3) + (size_t)p.cos * p.ci_real * p.ntap);
+}
 
-__global__ __launch_bounds__(256) void fold_fwd_kernel(FoldParams p) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+// The block first pulls its weight rows into LDS with coalesced loads (in the reference layout [co][ci][tap] consecutive
+// input channels are 108 B apart: read in place, every lane of a wave hit its own cache line, 14 dependent rounds per
+// block), and only then waits for the statistics; everything after that is LDS -> registers -> 16-B stores.
+__device__ __forceinline__ void fold_fwd_body(const FoldParams& p, int n, int by, float* smem) {
   float* scale = smem;                 // [ci_pad]
   float* shift = scale + p.ci_pad;     // [ci_pad]
-  float* T = shift + p.ci_pad;         // [FOLD_COS][ntap]
-  const int n = blockIdx.x, tid = threadIdx.x;
-  const int co0 = blockIdx.y * FOLD_COS;
+  float* T = shift + p.ci_pad;         // [cos][ntap]
+  float* wS = T + ((p.cos * p.ntap + 3) & ~3);  // [cos][ci_real][ntap]
+  const int tid = threadIdx.x, cos = p.cos, ntap = p.ntap;
+  const int co0 = by * cos;
   const bool norm = p.stats != nullptr;
+  const int L = p.ci_real * ntap;
+  for (int col = 0; col < cos; ++col) {
+    const int co = co0 + col;
+    const float* row = p.w + ((long)co * p.ci_total + p.ci_off) * ntap;
+    float* dst = wS + col * L;
+    if (co < p.co_real) {
+      int i = tid;
+      for (; i + 3 * 256 < L; i += 4 * 256) {
+        const float v0 = row[i], v1 = row[i + 256], v2 = row[i + 512], v3 = row[i + 768];
+        dst[i] = v0; dst[i + 256] = v1; dst[i + 512] = v2; dst[i + 768] = v3;
+      }
+      for (; i < L; i += 256) dst[i] = row[i];
+    } else {
+      for (int i = tid; i < L; i += 256) dst[i] = 0.f;
+    }
+  }
   for (int c = tid; c < p.ci_pad; c += 256) { scale[c] = (c < p.ci_real && !norm) ? 1.f : 0.f; shift[c] = 0.f; }
   __syncthreads();
-  if (norm) {
+  if (norm && p.wf) {
     const int cg = p.ci_real / p.groups;
     const double cnt = (double)cg * p.di * p.hi * p.wi;
     // one wave-sized team per group: lanes split the (channel, split) partials, then a shuffle reduction
@@ -134,7 +163,7 @@ __global__ __launch_bounds__(256) void fold_fwd_kernel(FoldParams p) {
       double var = s1 / cnt - mean * mean;
       if (var < 0.0) var = 0.0;
       const float rstd = (float)(1.0 / sqrt(var + (double)p.eps));
-      if (p.mr && blockIdx.y == 0 && lane == 0) {
+      if (p.mr && by == 0 && lane == 0) {
         p.mr[((long)n * p.groups + g) * 2] = (float)mean;
         p.mr[((long)n * p.groups + g) * 2 + 1] = rstd;
       }
@@ -146,39 +175,54 @@ __global__ __launch_bounds__(256) void fold_fwd_kernel(FoldParams p) {
     }
     __syncthreads();
   }
-  // folded weights  wf[n][tap][co][ci] for co in [co0, co0+FOLD_COS)
-  bf16_t* wf = p.wf + (long)n * p.ntap * p.co_pad * p.ci_pad;
-  const int total = p.ntap * FOLD_COS * p.ci_pad;
-  for (int i = tid; i < total; i += 256) {
-    const int ci = i % p.ci_pad, col = (i / p.ci_pad) % FOLD_COS, tap = i / (p.ci_pad * FOLD_COS);
-    const int co = co0 + col;
-    float v = 0.f;
-    if (ci < p.ci_real && co < p.co_real) v = p.w[((long)co * p.ci_total + p.ci_off + ci) * p.ntap + tap] * scale[ci];
-    if (co < p.co_pad) wf[((long)tap * p.co_pad + co) * p.ci_pad + ci] = f2bf(v);
-    if (p.wd && n == 0 && co < p.cok) {  // the un-folded weights, transposed for the data-gradient conv
-      const float w0 = (ci < p.ci_real && co < p.co_real) ? p.w[((long)co * p.ci_total + p.ci_off + ci) * p.ntap + tap] : 0.f;
-      p.wd[((long)tap * p.ci_pad + ci) * p.cok + co] = f2bf(w0);
+  if (p.wd && n == 0) {  // the un-folded weights, transposed for the data-gradient conv: wd[tap][ci_pad][cok]
+    for (int i = tid; i < ntap * p.ci_pad; i += 256) {
+      const int ci = i % p.ci_pad, tap = i / p.ci_pad;
+      bf16_t* o = p.wd + ((long)tap * p.ci_pad + ci) * p.cok + co0;
+      for (int col = 0; col < cos; ++col)
+        if (co0 + col < p.cok) o[col] = f2bf(ci < p.ci_real ? wS[col * L + ci * ntap + tap] : 0.f);
     }
   }
+  if (!p.wf) return;
+  // folded weights  wf[n][tap][co][ci] for co in [co0, co0+cos): one 16-B store per 8 input channels
+  bf16_t* wf = p.wf + (long)n * ntap * p.co_pad * p.ci_pad;
+  const int c8 = p.ci_pad >> 3;
+  for (int i = tid; i < ntap * cos * c8; i += 256) {
+    const int k = i % c8, col = (i / c8) % cos, tap = i / (c8 * cos);
+    const int co = co0 + col;
+    if (co >= p.co_pad) continue;
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int ci = k * 8 + j;
+      o[j] = f2bf(ci < p.ci_real ? wS[col * L + ci * ntap + tap] * scale[ci] : 0.f);
+    }
+    st_bf16x8(wf + ((long)tap * p.co_pad + co) * p.ci_pad + k * 8, o);
+  }
   if (!p.btab) return;
-  // T[col][tap] = sum_ci w*shift   (64 lanes per dot product would be overkill: ci <= 256, ntap*FOLD_COS <= 108 rows)
-  for (int i = tid; i < FOLD_COS * p.ntap; i += 256) {
-    const int tap = i % p.ntap, co = co0 + i / p.ntap;
+  // T[col][tap] = sum_ci w*shift
+  for (int i = tid; i < cos * ntap; i += 256) {
+    const int tap = i % ntap, col = i / ntap;
     float acc = 0.f;
-    if (norm && co < p.co_real)
-      for (int ci = 0; ci < p.ci_real; ++ci) acc += p.w[((long)co * p.ci_total + p.ci_off + ci) * p.ntap + tap] * shift[ci];
+    if (norm)
+      for (int ci = 0; ci < p.ci_real; ++ci) acc += wS[col * L + ci * ntap + tap] * shift[ci];
     T[i] = acc;
   }
   __syncthreads();
   float* bt = p.btab + (long)n * 64 * p.co_pad;
-  for (int i = tid; i < 64 * FOLD_COS; i += 256) {
-    const int col = i % FOLD_COS, cls = i / FOLD_COS, co = co0 + col;
+  for (int i = tid; i < 64 * cos; i += 256) {
+    const int col = i % cos, cls = i / cos, co = co0 + col;
     float acc = (p.bias && co < p.co_real) ? p.bias[co] : 0.f;
     if (norm)
-      for (int tap = 0; tap < p.ntap; ++tap)
-        if (tap_inb_class(tap, cls, p)) acc += T[col * p.ntap + tap];
+      for (int tap = 0; tap < ntap; ++tap)
+        if (tap_inb_class(tap, cls, p)) acc += T[col * ntap + tap];
     if (co < p.co_pad) bt[cls * p.co_pad + co] = acc;
   }
+}
+
+__global__ __launch_bounds__(256) void fold_fwd_kernel(FoldParams p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  fold_fwd_body(p, blockIdx.x, blockIdx.y, smem);
 }
 
 static int fill_fold(FoldParams& p, const RtpConvGeom* g, int ci_real, int co_real) {
@@ -191,23 +235,36 @@ static int fill_fold(FoldParams& p, const RtpConvGeom* g, int ci_real, int co_re
   return RTP_OK;
 }
 
+// wf == NULL: only the data-gradient packing wd (which does not depend on the statistics)
+static int fill_fold_fwd(FoldParams& p, const float* w, const float* bias, const float* gamma, const float* beta,
+                         const float* stats, int nsplit, int groups, float eps, const RtpConvGeom* g, int ci_real,
+                         int co_real, void* wf, float* btab, float* mr, void* wd, int* nw, int* ny) {
+  int rc = fill_fold(p, g, ci_real, co_real);
+  if (rc) return rc;
+  if (!w || (!wf && !wd)) return RTP_ERR_SHAPE;
+  if (stats && (!gamma || !beta || groups < 1 || ci_real % groups)) return RTP_ERR_SHAPE;
+  p.w = w; p.bias = bias; p.gamma = gamma; p.beta = beta; p.stats = stats;
+  p.nsplit = nsplit; p.groups = groups; p.eps = eps;
+  p.wf = (bf16_t*)wf; p.btab = wf ? btab : nullptr; p.mr = wf ? mr : nullptr;
+  p.wd = (bf16_t*)wd; p.cok = (g->co + 31) / 32 * 32;
+  p.cos = fold_cos(ci_real, p.ntap);
+  if (p.ci_pad % 8) return RTP_ERR_UNSUPPORTED;
+  if (fold_shm(p) > 60 * 1024) return RTP_ERR_UNSUPPORTED;
+  *nw = (wf && stats) ? g->n : 1;
+  *ny = (wd ? p.cok : p.co_pad) / p.cos;
+  return RTP_OK;
+}
+
 extern "C" int rtp_fold_fwd(const float* w, const float* bias, const float* gamma, const float* beta,
                             const float* stats, int nsplit, int groups, float eps, const RtpConvGeom* g, int ci_real,
                             int co_real, void* wf, float* btab, float* mr, void* wd, void* stream) {
   FoldParams p;
-  int rc = fill_fold(p, g, ci_real, co_real);
+  int nw, ny;
+  int rc = fill_fold_fwd(p, w, bias, gamma, beta, stats, nsplit, groups, eps, g, ci_real, co_real, wf, btab, mr, wd, &nw, &ny);
   if (rc) return rc;
-  if (stats && (!gamma || !beta || groups < 1 || ci_real % groups)) return RTP_ERR_SHAPE;
-  p.w = w; p.bias = bias; p.gamma = gamma; p.beta = beta; p.stats = stats;
-  p.nsplit = nsplit; p.groups = groups; p.eps = eps;
-  p.wf = (bf16_t*)wf; p.btab = btab; p.mr = mr;
-  p.wd = (bf16_t*)wd; p.cok = (g->co + 31) / 32 * 32;
-  const int nw = stats ? g->n : 1;
-  const size_t shm = sizeof(float) * (2 * p.ci_pad + (size_t)FOLD_COS * p.ntap);
-  if (p.co_pad % FOLD_COS) return RTP_ERR_UNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
   RtpProfScope prof(RTP_FAM_NORM, s);
-  hipLaunchKernelGGL(fold_fwd_kernel, dim3(nw, (wd ? p.cok : p.co_pad) / FOLD_COS), dim3(256), shm, s, p);
+  hipLaunchKernelGGL(fold_fwd_kernel, dim3(nw, ny), dim3(256), fold_shm(p), s, p);
   RTP_CHECK_LAUNCH();
   return RTP_OK;
 }
@@ -574,10 +631,10 @@ extern "C" int rtp_wgrad_fold(const float* gp, int nsplit, const float* csum, co
 // reductions + GroupNorm parameter sums, then the folds): block -> (descriptor, local block) by binary search.
 // ------------------------------------------------------------------------------------------------
 struct GnParParams { const float* part; float* dgamma; float* dbeta; int n, c, accumulate; };
-enum { TAIL_CLASS_REDUCE = 0, TAIL_WGRAD_FOLD = 1, TAIL_GN_PARAM = 2 };
+enum { TAIL_CLASS_REDUCE = 0, TAIL_WGRAD_FOLD = 1, TAIL_GN_PARAM = 2, TAIL_FOLD_FWD = 3 };
 struct RtpTailDesc {
   int kind, blocks;
-  union { WFoldParams wf; ClsRedParams cr; GnParParams gp; } u;
+  union { WFoldParams wf; ClsRedParams cr; GnParParams gp; FoldParams ff; } u;
 };
 
 __device__ __forceinline__ void gn_param_body(const GnParParams& p, int bid) {
@@ -606,6 +663,9 @@ __global__ __launch_bounds__(256) void tail_kernel(const RtpTailDesc* descs, con
   } else if (d.kind == TAIL_CLASS_REDUCE) {
     const ClsRedParams p = d.u.cr;
     class_reduce_body(p, b);
+  } else if (d.kind == TAIL_FOLD_FWD) {
+    const FoldParams p = d.u.ff;
+    fold_fwd_body(p, b % p.nw, b / p.nw, sh);
   } else {
     const GnParParams p = d.u.gp;
     gn_param_body(p, b);
@@ -658,6 +718,25 @@ extern "C" int rtp_tail_desc_gn_param(const float* coeff, int n, int c, float* d
   memcpy(desc, &d, sizeof(d));
   if (blocks) *blocks = d.blocks;
   if (shm_bytes) *shm_bytes = 0;
+  return RTP_OK;
+}
+
+extern "C" int rtp_tail_desc_fold_fwd(const float* w, const float* bias, const float* gamma, const float* beta,
+                                      const float* stats, int nsplit, int groups, float eps, const RtpConvGeom* g,
+                                      int ci_real, int co_real, void* wf, float* btab, float* mr, void* wd, void* desc,
+                                      int* blocks, int* shm_bytes) {
+  if (!desc) return RTP_ERR_SHAPE;
+  RtpTailDesc d;
+  memset(&d, 0, sizeof(d));
+  d.kind = TAIL_FOLD_FWD;
+  int nw, ny;
+  int rc = fill_fold_fwd(d.u.ff, w, bias, gamma, beta, stats, nsplit, groups, eps, g, ci_real, co_real, wf, btab, mr, wd, &nw, &ny);
+  if (rc) return rc;
+  d.u.ff.nw = nw;
+  d.blocks = nw * ny;
+  memcpy(desc, &d, sizeof(d));
+  if (blocks) *blocks = d.blocks;
+  if (shm_bytes) *shm_bytes = (int)fold_shm(d.u.ff);
   return RTP_OK;
 }
 

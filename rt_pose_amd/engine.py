@@ -90,7 +90,7 @@ class PoseEngine:
         self.x_in = g.input_f32("rdr", cin, dims)
         self.feats = net.build_hrnet3d(g, self.x_in, arch, dims, final_fuse)
         self.outs = net.build_head(g, self.feats, list(self.heads))
-        self.fwd = list(g.fwd)
+        self.fwd = list(g.forward_list())
         self.fwd_plan = LanePlan(be, self.fwd, LANE_MAP)
         self.bwd_plan = None
         self.use_lanes = True      # False: replay everything on the caller's stream in list order

@@ -113,6 +113,7 @@ class Graph:
         self.used_params = []      # creation order
         self.bytes = 0
         self.tail_a, self.tail_b = [], []   # deferred optimiser-only items (emit_tail)
+        self.head, self._head_emitted = [], False   # activation-independent weight packing (forward_list)
         self.full_vox = None       # voxels of the first (full-resolution) activation: lanes are assigned by resolution
         # algorithmic FLOPs (2*MACs of real channels) per kernel family, per replay of the lists
         self.flops = {"conv_fwd": 0, "conv_dgrad": 0, "wgrad": 0, "conv_tiled": 0, "conv_generic": 0,
@@ -208,6 +209,14 @@ class Graph:
         self.ops.append(op)
         self.emit_fwd(self.be.fuse_sum(terms, None, y, relu), self.lane_of(y), terms, [y])
         return y
+
+    def forward_list(self):
+        """The forward launches, opened by the one launch that packs every activation-independent weight image."""
+        if self.head and not self._head_emitted:
+            outs = [t for it in self.head for t in it[13:17] if t is not None]
+            self.fwd.insert(0, Launch(self.be.tail(self.head), L_FULL, [it[1] for it in self.head], outs))
+            self._head_emitted = True
+        return self.fwd
 
     # ------------------------------------------------------------------ backward
     def seed_grad(self, y: Act, gview: View):
@@ -306,13 +315,23 @@ class ConvOp:
         self.wf = be.alloc((nw, ntap, ge.co, ge.ci), "bf16")
         need_btab = bool(self.gn) or bias is not None
         self.btab = be.alloc((nw, 64, ge.co), "f32") if need_btab else None
-        # training plans also get the data-gradient packing of the same weights out of this launch
+        # training plans also need the data-gradient packing of the same weights
         need_dgrad = g.train and (self.x.needs_grad or bool(self.gn))
         self.wd = be.alloc((ntap, ge.ci, pad_to(ge.co, 32)), "bf16") if need_dgrad else None
         lane = g.lane_of(self.y)
-        g.emit_fwd(be.fold_fwd(w, bias, gamma, beta, stats, self.x.stats_split if self.gn else 0, self.groups, GN_EPS,
-                               ge, self.ci_real, self.co_real, self.wf, self.btab, self.mr, self.wd),
-                   lane, [stats], [self.wf, self.btab, self.mr, self.wd])
+        # Weight packing that does not depend on activations (everything of a conv without GroupNorm, the data-gradient
+        # packing of every conv) is recorded for the ONE launch that opens the step (Graph.forward_list); only the
+        # GroupNorm fold, which needs this step's statistics, is a launch of its own in front of its conv.
+        if self.gn:
+            g.emit_fwd(be.fold_fwd(w, bias, gamma, beta, stats, self.x.stats_split, self.groups, GN_EPS,
+                                   ge, self.ci_real, self.co_real, self.wf, self.btab, self.mr, None),
+                       lane, [stats], [self.wf, self.btab, self.mr])
+            if self.wd is not None:
+                g.head.append(("fold_fwd", w, None, None, None, None, 0, self.groups, GN_EPS, ge, self.ci_real,
+                               self.co_real, None, None, None, self.wd))
+        else:
+            g.head.append(("fold_fwd", w, bias, None, None, None, 0, self.groups, GN_EPS, ge, self.ci_real,
+                           self.co_real, self.wf, self.btab, None, self.wd))
         # Convs on the LDS-tiled kernel also emit (sum y, sum y^2) per channel from their epilogue, so a GroupNorm
         # consumer of y needs no statistics pass (ensure_stats finds them)
         fstats = None

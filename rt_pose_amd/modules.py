@@ -208,7 +208,7 @@ class _StandaloneEngine:
             self.ncls, self.nreg = mod.heads["hm"], mod.heads["reg"]
             self.dec_out = be.alloc((b, self.ncls, 2 + self.nreg), "f32")
             self.dec = None
-        self.fwd = list(g.fwd)
+        self.fwd = list(g.forward_list())
 
     def load_input(self, x):
         self.x_in.copy_(x.reshape(self.x_in.shape))

@@ -96,6 +96,8 @@ class EmuBackend:
         def run(s):
             if pack is not None:
                 pack(s)
+            if wf is None:
+                return
             g = geom
             ntap = g.ks ** 3
             cit = g.w_ci_total or ci_real
@@ -235,6 +237,8 @@ class EmuBackend:
                 fns.append(self.wgrad_fold(*a))
             elif kind == "gn_param":
                 fns.append(self.gn_bwd_param(*a))
+            elif kind == "fold_fwd":
+                fns.append(self.fold_fwd(*a))
             else:
                 raise ValueError(kind)
         return lambda s: [f(s) for f in fns] and None
