@@ -4,6 +4,7 @@
 // materialised: x_hat[c] = x[c]*scale[n,c] + shift[n,c] is folded into per-sample bf16 weights
 // (W*scale) and a per-boundary-class bias (sum over in-bounds taps of W.shift), because zero padding is
 // applied AFTER the norm.  The backward pass undoes the fold with per-(n,c) sums (P,Q) and per-class sums.
+#include <stdlib.h>
 #include <string.h>
 
 #include "rtp_common.h"
@@ -94,6 +95,7 @@ struct FoldParams {
   bf16_t* wf; float* btab; float* mr;
   bf16_t* wd; int cok;  // optional data-gradient packing [tap][ci_pad][cok] (written by the n == 0 blocks)
   int cos, nw;          // output channels per block; weight sets (n with GroupNorm, 1 without)
+  int dbg;              // timing experiments only (RTP_FOLD_DBG): bit0 skip statistics, bit1 skip wf, bit2 skip bias table, bit3 skip weight staging
 };
 
 __device__ __forceinline__ bool tap_inb_class(int tap, int cls, const FoldParams& p) {
@@ -127,7 +129,7 @@ __device__ __forceinline__ void fold_fwd_body(const FoldParams& p, int n, int by
   const int co0 = by * cos;
   const bool norm = p.stats != nullptr;
   const int L = p.ci_real * ntap;
-  for (int col = 0; col < cos; ++col) {
+  for (int col = 0; col < cos && !(p.dbg & 8); ++col) {
     const int co = co0 + col;
     const float* row = p.w + ((long)co * p.ci_total + p.ci_off) * ntap;
     float* dst = wS + col * L;
@@ -144,7 +146,7 @@ __device__ __forceinline__ void fold_fwd_body(const FoldParams& p, int n, int by
   }
   for (int c = tid; c < p.ci_pad; c += 256) { scale[c] = (c < p.ci_real && !norm) ? 1.f : 0.f; shift[c] = 0.f; }
   __syncthreads();
-  if (norm && p.wf) {
+  if (norm && p.wf && !(p.dbg & 1)) {
     const int cg = p.ci_real / p.groups;
     const double cnt = (double)cg * p.di * p.hi * p.wi;
     // one wave-sized team per group: lanes split the (channel, split) partials, then a shuffle reduction
@@ -184,6 +186,7 @@ __device__ __forceinline__ void fold_fwd_body(const FoldParams& p, int n, int by
     }
   }
   if (!p.wf) return;
+  if (!(p.dbg & 2)) {
   // folded weights  wf[n][tap][co][ci] for co in [co0, co0+cos): one 16-B store per 8 input channels
   bf16_t* wf = p.wf + (long)n * ntap * p.co_pad * p.ci_pad;
   const int c8 = p.ci_pad >> 3;
@@ -199,23 +202,45 @@ __device__ __forceinline__ void fold_fwd_body(const FoldParams& p, int n, int by
     }
     st_bf16x8(wf + ((long)tap * p.co_pad + co) * p.ci_pad + k * 8, o);
   }
-  if (!p.btab) return;
-  // T[col][tap] = sum_ci w*shift
-  for (int i = tid; i < cos * ntap; i += 256) {
-    const int tap = i % ntap, col = i / ntap;
-    float acc = 0.f;
-    if (norm)
-      for (int ci = 0; ci < p.ci_real; ++ci) acc += wS[col * L + ci * ntap + tap] * shift[ci];
-    T[i] = acc;
+  }
+  if (!p.btab || (p.dbg & 4)) return;
+  // T[col][tap] = sum_ci w*shift : two lanes per dot product (halves of the input channels), joined by one shuffle
+  {
+    const int i = tid >> 1, half = tid & 1;
+    for (int i0 = 0; i0 < cos * ntap; i0 += 128) {
+      const int ii = i0 + i;
+      float acc = 0.f;
+      if (norm && ii < cos * ntap) {
+        const int tap = ii % ntap, col = ii / ntap;
+        const int h0 = half * (p.ci_real >> 1), h1 = half ? p.ci_real : (p.ci_real >> 1);
+        const float* wr = wS + col * L + tap;
+        for (int ci = h0; ci < h1; ++ci) acc += wr[ci * ntap] * shift[ci];
+      }
+      acc += __shfl_xor(acc, 1, 64);
+      if (ii < cos * ntap && half == 0) T[ii] = acc;
+    }
   }
   __syncthreads();
+  // bias of a boundary class = bias + sum of T over the taps that stay in bounds for that class.  The in-bounds test
+  // factorises per axis: three 3-bit masks per class instead of 27 full tests.
   float* bt = p.btab + (long)n * 64 * p.co_pad;
   for (int i = tid; i < 64 * cos; i += 256) {
     const int col = i % cos, cls = i / cos, co = co0 + col;
     float acc = (p.bias && co < p.co_real) ? p.bias[co] : 0.f;
-    if (norm)
-      for (int tap = 0; tap < ntap; ++tap)
-        if (tap_inb_class(tap, cls, p)) acc += T[col * ntap + tap];
+    if (norm) {
+      const int ks = p.ks;
+      int mz = 0, my = 0, mx = 0;
+      for (int k = 0; k < ks; ++k) {
+        mz |= (int)tap_inb_1d(k, cls & 1, (cls >> 1) & 1, p.dov, p.di, p.stride, p.pad) << k;
+        my |= (int)tap_inb_1d(k, (cls >> 2) & 1, (cls >> 3) & 1, p.ho, p.hi, p.stride, p.pad) << k;
+        mx |= (int)tap_inb_1d(k, (cls >> 4) & 1, (cls >> 5) & 1, p.wo, p.wi, p.stride, p.pad) << k;
+      }
+      const float* Tc = T + col * ntap;
+      for (int kz = 0; kz < ks; ++kz)
+        for (int ky = 0; ky < ks; ++ky)
+          for (int kx = 0; kx < ks; ++kx)
+            if ((mz >> kz) & (my >> ky) & (mx >> kx) & 1) acc += Tc[(kz * ks + ky) * ks + kx];
+    }
     if (co < p.co_pad) bt[cls * p.co_pad + co] = acc;
   }
 }
@@ -248,6 +273,8 @@ static int fill_fold_fwd(FoldParams& p, const float* w, const float* bias, const
   p.wf = (bf16_t*)wf; p.btab = wf ? btab : nullptr; p.mr = wf ? mr : nullptr;
   p.wd = (bf16_t*)wd; p.cok = (g->co + 31) / 32 * 32;
   p.cos = fold_cos(ci_real, p.ntap);
+  static const int dbg = getenv("RTP_FOLD_DBG") ? atoi(getenv("RTP_FOLD_DBG")) : 0;
+  p.dbg = dbg;
   if (p.ci_pad % 8) return RTP_ERR_UNSUPPORTED;
   if (fold_shm(p) > 60 * 1024) return RTP_ERR_UNSUPPORTED;
   *nw = (wf && stats) ? g->n : 1;

@@ -236,16 +236,17 @@ extern "C" int rtp_grad_combine_cls(const RtpTerm* terms, int nterms, const RtpA
 // ------------------------------------------------------------------------------------------------
 // rtp_fuse_sum : trilinear align_corners=True, PyTorch index rule (upsample_trilinear3d)
 // ------------------------------------------------------------------------------------------------
-struct FuseTerm { const bf16_t* t; int cs, co, d, h, w; };
+struct FuseTerm { const bf16_t* t; int cs, co, d, h, w; float sz, sy, sx; int same; };  // s*: align_corners scale (I-1)/(O-1), computed in fp32 like ATen
 struct FuseParams {
   FuseTerm terms[RTP_MAX_TERMS]; int nterms;
   const float* bias; bf16_t* out; int o_cs, o_co;
   int c, n, d, h, w, relu;
 };
 
-__device__ __forceinline__ void src_index(int o, int I, int O, int& i0, int& i1, float& l0, float& l1) {
+__host__ __device__ __forceinline__ float ac_scale(int I, int O) { return (O > 1) ? (float)(I - 1) / (float)(O - 1) : 0.f; }
+
+__device__ __forceinline__ void src_index(int o, int I, int O, float scale, int& i0, int& i1, float& l0, float& l1) {
   if (I == O) { i0 = i1 = o; l0 = 1.f; l1 = 0.f; return; }
-  const float scale = (O > 1) ? (float)(I - 1) / (float)(O - 1) : 0.f;
   const float src = scale * (float)o;
   i0 = (int)src;
   i1 = i0 + ((i0 < I - 1) ? 1 : 0);
@@ -266,20 +267,18 @@ __global__ __launch_bounds__(256) void fuse_sum_kernel(FuseParams p) {
     float acc[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[j] = p.bias ? p.bias[ck * 8 + j] : 0.f;
-#pragma unroll
-    for (int k = 0; k < RTP_MAX_TERMS; ++k) {
-      if (k >= p.nterms) break;
-      const FuseTerm& t = p.terms[k];
-      if (t.d == p.d && t.h == p.h && t.w == p.w) {
+    for (int k = 0; k < p.nterms; ++k) {   // NOT unrolled: six copies of this body spill the descriptor SGPRs
+      const FuseTerm t = p.terms[k];
+      if (t.same) {
         bf16x8 tv = ld_bf16x8(t.t + vv * t.cs + t.co + ck * 8);
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[j] += bf2f(tv[j]);
       } else {
         int z0, z1, y0, y1, x0, x1;
         float lz0, lz1, ly0, ly1, lx0, lx1;
-        src_index(z, t.d, p.d, z0, z1, lz0, lz1);
-        src_index(y, t.h, p.h, y0, y1, ly0, ly1);
-        src_index(x, t.w, p.w, x0, x1, lx0, lx1);
+        src_index(z, t.d, p.d, t.sz, z0, z1, lz0, lz1);
+        src_index(y, t.h, p.h, t.sy, y0, y1, ly0, ly1);
+        src_index(x, t.w, p.w, t.sx, x0, x1, lx0, lx1);
         const long base = (long)n * t.d * t.h * t.w;
         float up[8];
 #pragma unroll
@@ -307,6 +306,142 @@ __global__ __launch_bounds__(256) void fuse_sum_kernel(FuseParams p) {
   }
 }
 
+// Row-run variant: a thread owns FX consecutive output voxels of one x-row (one 8-channel chunk).  For an up-sampled
+// term the 2x2 (z,y) corner rows are blended ONCE into a short source row (<= FSPAN voxels: the x scale is < 1), from
+// which the FX outputs are interpolated in registers -- 4*FSPAN/FX = 3 sixteen-byte gathers per output instead of 8
+// (the point-per-thread kernel above is bound by L1/TA traffic: 26 gathers per output for a 4-branch fuse row).
+#define FX 4
+#define FSPAN 5
+__global__ __launch_bounds__(256) void fuse_sum_rows_kernel(FuseParams p) {
+  const int cpv = p.c >> 3, runs = p.w / FX;
+  const long total = (long)p.n * p.d * p.h * runs * cpv;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int ck = (int)(i % cpv);
+    long r = i / cpv;
+    const int xs = (int)(r % runs) * FX;
+    r /= runs;
+    const int y = (int)(r % p.h);
+    r /= p.h;
+    const int z = (int)(r % p.d), n = (int)(r / p.d);
+    const long vv0 = (((long)n * p.d + z) * p.h + y) * p.w + xs;
+    float acc[FX][8];
+#pragma unroll
+    for (int j = 0; j < FX; ++j)
+#pragma unroll
+      for (int c = 0; c < 8; ++c) acc[j][c] = p.bias ? p.bias[ck * 8 + c] : 0.f;
+    // The same-resolution terms are the HBM traffic of this kernel (the up-sampled sources sit in L2): their loads
+    // are issued first and consumed last, so they are in flight during every up-sampled term's gather/blend phases
+    // (launched one dependent phase after another the kernel was latency-bound at 1/3 of the HBM rate).
+    bf16x8 pre[2][FX];
+    int npre = 0;
+    for (int k = 0; k < p.nterms && npre < 2; ++k) {
+      const FuseTerm t = p.terms[k];
+      if (!t.same) continue;
+      if (npre == 0) {
+#pragma unroll
+        for (int j = 0; j < FX; ++j) pre[0][j] = ld_bf16x8(t.t + (vv0 + j) * t.cs + t.co + ck * 8);
+      } else {
+#pragma unroll
+        for (int j = 0; j < FX; ++j) pre[1][j] = ld_bf16x8(t.t + (vv0 + j) * t.cs + t.co + ck * 8);
+      }
+      ++npre;
+    }
+    int nsame = 0;
+    for (int k = 0; k < p.nterms; ++k) {   // NOT unrolled (code size, descriptor SGPRs)
+      const FuseTerm t = p.terms[k];
+      if (t.same) {
+        if (nsame++ < 2) continue;          // prefetched above
+#pragma unroll
+        for (int j = 0; j < FX; ++j) {
+          bf16x8 tv = ld_bf16x8(t.t + (vv0 + j) * t.cs + t.co + ck * 8);
+#pragma unroll
+          for (int c = 0; c < 8; ++c) acc[j][c] += bf2f(tv[c]);
+        }
+      } else {
+        int z0, z1, y0, y1, xb, xdummy;
+        float lz0, lz1, ly0, ly1, ldum0, ldum1;
+        src_index(z, t.d, p.d, t.sz, z0, z1, lz0, lz1);
+        src_index(y, t.h, p.h, t.sy, y0, y1, ly0, ly1);
+        src_index(xs, t.w, p.w, t.sx, xb, xdummy, ldum0, ldum1);
+        const long base = (long)n * t.d * t.h * t.w;
+        float row[FSPAN][8];
+#pragma unroll
+        for (int q = 0; q < FSPAN; ++q)
+#pragma unroll
+          for (int c = 0; c < 8; ++c) row[q][c] = 0.f;
+        int qo[FSPAN];  // clamped source offsets: columns past the row end carry zero weight below, so any valid address does
+#pragma unroll
+        for (int q = 0; q < FSPAN; ++q) qo[q] = ((xb + q < t.w) ? q : t.w - 1 - xb) * t.cs;
+#pragma unroll
+        for (int cz = 0; cz < 2; ++cz)
+#pragma unroll
+          for (int cy = 0; cy < 2; ++cy) {
+            const float wgt = (cz ? lz1 : lz0) * (cy ? ly1 : ly0);
+            const bf16_t* src = t.t + (base + ((long)(cz ? z1 : z0) * t.h + (cy ? y1 : y0)) * t.w + xb) * t.cs + t.co + ck * 8;
+            bf16x8 tv[FSPAN];
+#pragma unroll
+            for (int q = 0; q < FSPAN; ++q) tv[q] = ld_bf16x8(src + qo[q]);
+#pragma unroll
+            for (int q = 0; q < FSPAN; ++q)
+#pragma unroll
+              for (int c = 0; c < 8; ++c) row[q][c] += wgt * bf2f(tv[q][c]);
+          }
+#pragma unroll
+        for (int j = 0; j < FX; ++j) {
+          int x0, x1;
+          float lx0, lx1;
+          src_index(xs + j, t.w, p.w, t.sx, x0, x1, lx0, lx1);
+          x0 -= xb;
+          x1 -= xb;
+#pragma unroll
+          for (int q = 0; q < FSPAN; ++q) {
+            const float wq = (q == x0 ? lx0 : 0.f) + (q == x1 ? lx1 : 0.f);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) acc[j][c] += wq * row[q][c];
+          }
+        }
+      }
+    }
+    if (npre > 0) {
+#pragma unroll
+      for (int j = 0; j < FX; ++j)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) acc[j][c] += bf2f(pre[0][j][c]);
+    }
+    if (npre > 1) {
+#pragma unroll
+      for (int j = 0; j < FX; ++j)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) acc[j][c] += bf2f(pre[1][j][c]);
+    }
+#pragma unroll
+    for (int j = 0; j < FX; ++j) {
+      bf16x8 o;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) o[c] = f2bf(p.relu ? (acc[j][c] > 0.f ? acc[j][c] : 0.f) : acc[j][c]);
+      st_bf16x8(p.out + (vv0 + j) * p.o_cs + p.o_co + ck * 8, o);
+    }
+  }
+}
+
+// can every up-sampled term's FX-output run be served from FSPAN source voxels?
+static bool fuse_rows_ok(const FuseParams& p) {
+  if (p.w % FX) return false;
+  for (int k = 0; k < p.nterms; ++k) {
+    const FuseTerm& t = p.terms[k];
+    if (t.same) continue;
+    if (t.w == p.w || p.w < 2) return false;  // same width but another depth/height: not a shape of this path
+    const float scale = t.sx;
+    for (int xs = 0; xs < p.w; xs += FX) {    // exact check with the kernel's own index rule
+      const int lo = (int)(scale * (float)xs);
+      int hi = (int)(scale * (float)(xs + FX - 1));
+      hi += (hi < t.w - 1) ? 1 : 0;
+      if (hi - lo >= FSPAN) return false;
+    }
+  }
+  return true;
+}
+
 extern "C" int rtp_fuse_sum(const RtpTerm* terms, int nterms, const float* bias, const RtpAct* out, int n, int d, int h,
                             int w, int relu, void* stream) {
   if (!terms || nterms < 1 || nterms > RTP_MAX_TERMS || !out) return RTP_ERR_SHAPE;
@@ -315,13 +450,18 @@ extern "C" int rtp_fuse_sum(const RtpTerm* terms, int nterms, const float* bias,
   if (p.c % 8 || (out->cs % 8) || (out->co % 8)) return RTP_ERR_ALIGN;
   for (int k = 0; k < nterms; ++k) {
     if (terms[k].t.c != p.c || (terms[k].t.cs % 8) || (terms[k].t.co % 8)) return RTP_ERR_ALIGN;
-    p.terms[k] = FuseTerm{(const bf16_t*)terms[k].t.ptr, terms[k].t.cs, terms[k].t.co, terms[k].d, terms[k].h, terms[k].w};
+    p.terms[k] = FuseTerm{(const bf16_t*)terms[k].t.ptr, terms[k].t.cs, terms[k].t.co, terms[k].d, terms[k].h, terms[k].w,
+                          ac_scale(terms[k].d, d), ac_scale(terms[k].h, h), ac_scale(terms[k].w, w),
+                          terms[k].d == d && terms[k].h == h && terms[k].w == w};
   }
   p.bias = bias; p.out = (bf16_t*)out->ptr; p.o_cs = out->cs; p.o_co = out->co;
   p.n = n; p.d = d; p.h = h; p.w = w; p.relu = relu;
   hipStream_t s = (hipStream_t)stream;
   RtpProfScope prof(RTP_FAM_POINTWISE, s);
-  hipLaunchKernelGGL(fuse_sum_kernel, dim3(grid_for((long)n * d * h * w * (p.c / 8))), dim3(256), 0, s, p);
+  if (fuse_rows_ok(p))
+    hipLaunchKernelGGL(fuse_sum_rows_kernel, dim3(grid_for((long)n * d * h * (w / FX) * (p.c / 8))), dim3(256), 0, s, p);
+  else
+    hipLaunchKernelGGL(fuse_sum_kernel, dim3(grid_for((long)n * d * h * w * (p.c / 8))), dim3(256), 0, s, p);
   RTP_CHECK_LAUNCH();
   return RTP_OK;
 }
@@ -334,7 +474,7 @@ extern "C" int rtp_fuse_sum(const RtpTerm* terms, int nterms, const float* bias,
 // weight of high-res position o on low-res index il along one dim
 __device__ __forceinline__ float adj_w(int o, int il, int I, int O) {
   int i0, i1; float l0, l1;
-  src_index(o, I, O, i0, i1, l0, l1);
+  src_index(o, I, O, ac_scale(I, O), i0, i1, l0, l1);
   return (i0 == il ? l0 : 0.f) + (i1 == il ? l1 : 0.f);
 }
 

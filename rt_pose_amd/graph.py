@@ -135,11 +135,11 @@ class Graph:
     def wg_lane_of(self, v):
         return L_WG if self.lane_of(v) == L_FULL else L_WG_LOW
 
-    def emit_fwd(self, fn, lane, reads=(), writes=()):
-        self.fwd.append(Launch(fn, lane, reads, writes))
+    def emit_fwd(self, fn, lane, reads=(), writes=(), tag=""):
+        self.fwd.append(Launch(fn, lane, reads, writes, tag))
 
-    def emit_bwd(self, fn, lane, reads=(), writes=()):
-        self.bwd.append(Launch(fn, lane, reads, writes))
+    def emit_bwd(self, fn, lane, reads=(), writes=(), tag=""):
+        self.bwd.append(Launch(fn, lane, reads, writes, tag))
 
     def param(self, name):
         p = self.params[name]
@@ -157,7 +157,7 @@ class Graph:
         if x.stats is None:
             x.stats_split = stats_split(x.vox)
             x.stats = self.be.alloc((self.n, x.stats_split, x.c, 2), "f32")
-            self.emit_fwd(self.be.chan_stats(x, None, x.stats_split, x.stats), self.lane_of(x), [x], [x.stats])
+            self.emit_fwd(self.be.chan_stats(x, None, x.stats_split, x.stats), self.lane_of(x), [x], [x.stats], "stats:" + x.name)
         return x.stats
 
     # ------------------------------------------------------------------ forward node constructors
@@ -173,12 +173,12 @@ class Graph:
         op = StemOp(self, x_f32, y, wname, bname)
         y.producer = op
         self.ops.append(op)
-        self.emit_fwd(self.be.stem_fwd(x_f32, w, b, y), self.lane_of(y), [x_f32], [y])
+        self.emit_fwd(self.be.stem_fwd(x_f32, w, b, y), self.lane_of(y), [x_f32], [y], "stem:" + name)
         return y
 
     def pack(self, name, x_f32, c, dims):
         y = self.act(name, c, dims, c=pad_to(c, 32), needs_grad=False)
-        self.emit_fwd(self.be.pack_ncdhw(x_f32, y, c), self.lane_of(y), [x_f32], [y])
+        self.emit_fwd(self.be.pack_ncdhw(x_f32, y, c), self.lane_of(y), [x_f32], [y], "pack:" + name)
         return y
 
     def conv(self, name, x: Act, wname, bname=None, gn=None, ks=3, stride=1, relu=False, residual=None,
@@ -207,14 +207,14 @@ class Graph:
         op = FuseOp(self, terms, y)
         y.producer = op
         self.ops.append(op)
-        self.emit_fwd(self.be.fuse_sum(terms, None, y, relu), self.lane_of(y), terms, [y])
+        self.emit_fwd(self.be.fuse_sum(terms, None, y, relu), self.lane_of(y), terms, [y], "fuse:" + name)
         return y
 
     def forward_list(self):
         """The forward launches, opened by the one launch that packs every activation-independent weight image."""
         if self.head and not self._head_emitted:
             outs = [t for it in self.head for t in it[13:17] if t is not None]
-            self.fwd.insert(0, Launch(self.be.tail(self.head), L_FULL, [it[1] for it in self.head], outs))
+            self.fwd.insert(0, Launch(self.be.tail(self.head), L_FULL, [it[1] for it in self.head], outs, "pack_weights"))
             self._head_emitted = True
         return self.fwd
 
@@ -250,7 +250,7 @@ class Graph:
                 t.grad_cls = cls
             self.emit_bwd(self.be.grad_combine(chunk, t if need_x else None, t if (t.relu and last) else None, t.grad, cls),
                           self.lane_of(t), [v for v, _ in chunk] + [cf for _, cf in chunk] + [t],
-                          [t.grad, cls[1] if cls else None])
+                          [t.grad, cls[1] if cls else None], "combine:" + t.name)
             first = False
         return t.grad
 
@@ -276,7 +276,7 @@ class Graph:
             outs = {"class_reduce": (5,), "gn_param": (4, 5), "wgrad_fold": (11, 12)}
             writes = [it[i] for it in items for i in outs[it[0]] if it[i] is not None]
             wk = set(t.data_ptr() for t in writes)
-            self.emit_bwd(self.be.tail(items), L_FULL, [t for t in bufs if t.data_ptr() not in wk], writes)
+            self.emit_bwd(self.be.tail(items), L_FULL, [t for t in bufs if t.data_ptr() not in wk], writes, "tail")
 
 
 class StemOp:
@@ -287,7 +287,7 @@ class StemOp:
         g = self.g
         scratch = g.be.alloc((g.be.stem_bwd_blocks(), self.y.c, 2), "f32")
         g.emit_bwd(g.be.stem_bwd(self.x, gy, scratch, g.pgrad[self.wname], g.pgrad[self.bname], 0), g.wg_lane_of(gy),
-                   [self.x, gy], [scratch, g.pgrad[self.wname], g.pgrad[self.bname]])
+                   [self.x, gy], [scratch, g.pgrad[self.wname], g.pgrad[self.bname]], "stem_bwd")
 
 
 class ConvOp:
@@ -325,7 +325,7 @@ class ConvOp:
         if self.gn:
             g.emit_fwd(be.fold_fwd(w, bias, gamma, beta, stats, self.x.stats_split, self.groups, GN_EPS,
                                    ge, self.ci_real, self.co_real, self.wf, self.btab, self.mr, None),
-                       lane, [stats], [self.wf, self.btab, self.mr])
+                       lane, [stats], [self.wf, self.btab, self.mr], "fold:" + self.name)
             if self.wd is not None:
                 g.head.append(("fold_fwd", w, None, None, None, None, 0, self.groups, GN_EPS, ge, self.ci_real,
                                self.co_real, None, None, None, self.wd))
@@ -342,7 +342,8 @@ class ConvOp:
             fstats = (None, self.y.stats)
         g.emit_fwd(be.conv(self.x, self.wf, nw > 1, self.btab, self.residual, self.y, ge, self.relu, False,
                            self.out_fp32, fstats),
-                   lane, [self.x, self.wf, self.btab, self.residual], [self.y, self.y.stats if fstats else None])
+                   lane, [self.x, self.wf, self.btab, self.residual], [self.y, self.y.stats if fstats else None],
+                   "conv:" + self.name)
         self.alg_flops = 2 * g.n * ge.do * ge.ho * ge.wo * self.co_real * self.ci_real * ntap
         g.flops["conv_fwd"] += self.alg_flops
         # mirrors the dispatch predicate of rtp_conv_tiled_try (csrc/conv_tiled.hip)
@@ -369,17 +370,17 @@ class ConvOp:
             pq = be.alloc((g.n, S or x.stats_split, ge.ci, 2), "f32") if self.gn else None
             lane = g.lane_of(self.y)   # a stride-2 conv's data gradient runs with the LOWER-resolution group
             g.emit_bwd(be.conv(gy, wd, False, None, None, dxh, ge, False, True, False, (x, pq) if S else None),
-                       lane, [gy, wd, x if S else None], [dxh, pq if S else None])
+                       lane, [gy, wd, x if S else None], [dxh, pq if S else None], "dgrad:" + self.name)
             g.flops["conv_dgrad"] += self.alg_flops
             g.flops["conv_tiled" if self.tiled_bwd else "conv_generic"] += self.alg_flops
             if self.gn:
                 if not S:
                     S = x.stats_split
-                    g.emit_bwd(be.chan_stats(dxh, x, S, pq), lane, [dxh, x], [pq])
+                    g.emit_bwd(be.chan_stats(dxh, x, S, pq), lane, [dxh, x], [pq], "pq:" + self.name)
                 coeff = be.alloc((g.n * ge.ci * 5,), "f32")  # [n][c][3] coefficients + [n][c][2] scratch
                 g.emit_bwd(be.gn_bwd_coeffs(pq, S, self.mr, g.params[self.gn[0]], g.n, self.ci_real, self.groups,
                                             x.vox, coeff, None, None, 0),
-                           lane, [pq, self.mr], [coeff])
+                           lane, [pq, self.mr], [coeff], "gncoef:" + self.name)
                 g.tail_a.append(("gn_param", coeff, g.n, self.ci_real, g.pgrad[self.gn[0]], g.pgrad[self.gn[1]], 0))
                 if x.needs_grad:
                     x.contribs.append((dxh, coeff))
@@ -395,7 +396,7 @@ class ConvOp:
         # The weight-gradient chain (wgrad -> class sums -> un-fold) only feeds the optimiser, so it runs on its own
         # lane beside the rest of the backward sweep.
         wl = g.wg_lane_of(gy)
-        g.emit_bwd(be.wgrad(gy, x, ge, S, gp), wl, [gy, x], [gp])
+        g.emit_bwd(be.wgrad(gy, x, ge, S, gp), wl, [gy, x], [gp], "wgrad:" + self.name)
         g.flops["wgrad"] += self.alg_flops
         g.flops["wgrad_tiled" if self.tiled_wgrad else "wgrad_generic"] += self.alg_flops
         # Everything after the correlation itself (class-sum reduction, slab fold + GroupNorm un-fold) only feeds the
@@ -408,7 +409,7 @@ class ConvOp:
             else:
                 cs_split = cls_split(gy.d, gy.h)
                 cs_scratch = be.alloc((g.n, cs_split, 64, gy.c), "f32")
-                g.emit_bwd(be.class_sums(gy, cs_split, cs_scratch, None), wl, [gy], [cs_scratch])
+                g.emit_bwd(be.class_sums(gy, cs_split, cs_scratch, None), wl, [gy], [cs_scratch], "cls:" + self.name)
             g.tail_a.append(("class_reduce", cs_scratch, cs_split, g.n, gy.c, csum))
         g.tail_b.append(("wgrad_fold", gp, S, csum, self.mr, g.params[self.gn[0]] if self.gn else None,
                          g.params[self.gn[1]] if self.gn else None, self.groups, ge, self.ci_real,
@@ -429,5 +430,5 @@ class FuseOp:
             else:
                 glow_buf = be.alloc((g.n, t.d, t.h, t.w, t.c), "bf16")
                 glow = View(glow_buf, g.n, t.d, t.h, t.w, t.c, 0, t.c)
-                g.emit_bwd(be.upsample_bwd(gy, glow), g.lane_of(glow), [gy], [glow])
+                g.emit_bwd(be.upsample_bwd(gy, glow), g.lane_of(glow), [gy], [glow], "upbwd:" + t.name)
                 t.contribs.append((glow, None))

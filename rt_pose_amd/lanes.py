@@ -29,10 +29,10 @@ def _key(t):
 
 class Launch:
     """One kernel launch of the plan: fn(stream_ptr), its lane, and the buffers it reads / writes."""
-    __slots__ = ("fn", "lane", "reads", "writes")
+    __slots__ = ("fn", "lane", "reads", "writes", "tag")
 
-    def __init__(self, fn, lane=0, reads=(), writes=()):
-        self.fn, self.lane = fn, lane
+    def __init__(self, fn, lane=0, reads=(), writes=(), tag=""):
+        self.fn, self.lane, self.tag = fn, lane, tag
         self.reads = tuple(k for k in (_key(t) for t in reads) if k is not None)
         self.writes = tuple(k for k in (_key(t) for t in writes) if k is not None)
 

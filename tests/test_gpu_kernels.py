@@ -381,6 +381,17 @@ def test_grad_combine_fuse_upsample(hip):
     for relu in (True, False):
         run(hip, EMU.fuse_sum(tc, None, oc, relu), hip.fuse_sum(tg, None, og, relu))
         check(op, BF, "fuse_sum relu=%s" % relu)
+    # native row width (160 <- 80, 40, 20: the row-run kernel) and a width that takes the point-per-thread kernel
+    for (dd, hh, ww), lowdims in (((2, 4, 160), [(1, 2, 80), (1, 1, 40), (2, 1, 20)]), ((2, 3, 12), [(1, 2, 6), (1, 1, 5)])):
+        _, b0c, b0g = views(hip, rnd((n, dd, hh, ww, c), 230), n, dd, hh, ww)
+        bp, boc, bog = views(hip, torch.zeros(n, dd, hh, ww, c, dtype=torch.bfloat16), n, dd, hh, ww)
+        tc2, tg2 = [b0c], [b0g]
+        for k, (ld, lh, lw) in enumerate(lowdims):
+            _, lc, lg = views(hip, rnd((n, ld, lh, lw, c), 231 + k), n, ld, lh, lw)
+            tc2.append(lc)
+            tg2.append(lg)
+        run(hip, EMU.fuse_sum(tc2, None, boc, True), hip.fuse_sum(tg2, None, bog, True))
+        check(bp, BF, "fuse_sum %r" % ((dd, hh, ww),))
     # upsample adjoint for x2, x4, x8 and a non-integer ratio
     for (ld, lh, lw), ch in (((2, 4, 8), 32), ((1, 2, 4), 64), ((1, 1, 2), 128), ((3, 5, 7), 32)):
         _, gc, gg = views(hip, rnd((n, d, h, w, ch), 38), n, d, h, w)

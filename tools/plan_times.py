@@ -1,0 +1,63 @@
+#!/usr/bin/env python
+"""Per-launch device time of the training plan, with the plan's own labels: every launch of the forward / loss /
+backward lists is replayed REP times back to back between two events on one stream (launches are idempotent), so the
+numbers are serial kernel costs free of launch gaps.  Prints the launches sorted by cost and sums per kind / lane."""
+import argparse
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--model", default="hr3d")
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--rep", type=int, default=10)
+    ap.add_argument("--top", type=int, default=60)
+    a = ap.parse_args()
+    from rt_pose_amd import configs, synth
+    from rt_pose_amd.trainer import DataParallelTrainer
+    spec = configs.spec(a.model)
+    tr = DataParallelTrainer(a.model, a.batch, configs.NATIVE_DIMS, total_steps=100, use_graph=False)
+    ex = synth.make_batch(a.batch, spec["cin"], configs.NATIVE_DIMS, seed=1234, one_hm=spec["heads"]["hm"] == 1)
+    tr.load(ex)
+    for _ in range(3):
+        tr.step()
+    torch.cuda.synchronize()
+    eng = tr.engine
+    launches = [("fwd", L) for L in eng.fwd_plan.launches] + [("bwd", L) for L in eng.bwd_plan.launches]
+    rows = []
+    with torch.cuda.stream(tr.stream):
+        s = tr.be.stream()
+        for phase, L in launches:
+            for _ in range(3):
+                L.fn(s)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(a.rep):
+                L.fn(s)
+            e1.record()
+            rows.append((phase, L, e0, e1))
+    torch.cuda.synchronize()
+    out = [(e0.elapsed_time(e1) * 1e3 / a.rep, phase, L.lane, L.tag) for phase, L, e0, e1 in rows]
+    tot = sum(t for t, *_ in out)
+    print("serial total %.2f ms over %d launches" % (tot / 1e3, len(out)))
+    agg = {}
+    for t, phase, lane, tag in out:
+        k = (phase, tag.split(":")[0])
+        agg[k] = (agg.get(k, (0, 0))[0] + t, agg.get(k, (0, 0))[1] + 1)
+    print("-- by kind")
+    for k, (t, c) in sorted(agg.items(), key=lambda kv: -kv[1][0]):
+        print("%-22s %3d launches %8.1f us  (%.1f avg)" % ("%s %s" % k, c, t, t / c))
+    lag = {}
+    for t, phase, lane, tag in out:
+        lag[(phase, lane)] = lag.get((phase, lane), 0) + t
+    print("-- by lane", {k: round(v) for k, v in sorted(lag.items())})
+    print("-- top launches")
+    for t, phase, lane, tag in sorted(out, key=lambda r: -r[0])[:a.top]:
+        print("%8.1f us  %s lane %d  %s" % (t, phase, lane, tag))
+
+
+if __name__ == "__main__":
+    main()
