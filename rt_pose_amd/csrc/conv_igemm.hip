@@ -7,6 +7,8 @@
 // This file holds the GENERIC kernel: any Cin multiple of 32, Cout multiple of 16, ks in {1,3}, stride in
 // {1,2}, normal or transposed (data-gradient) indexing; the B operand is gathered straight from global/L2.
 // The LDS-tiled kernel for the full-resolution 32->32 layers lives in conv_tiled.hip.
+#include <stdlib.h>
+
 #include "rtp_common.h"
 #include "rtp_prof.h"
 
@@ -26,8 +28,39 @@ struct ConvParams {
   int blocks_per_sample;
 };
 
-// NT = number of 16-wide Cout tiles handled by one wave; MT voxel tiles of 16.
-template <int NT, int MT>
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+
+// One MFMA operand fragment = 16 rows (voxels or output channels) x 64 B.  The MFMA wants lane (row = l & 15, 16-B chunk
+// = l >> 4), which makes the four lanes of every load quad hit four different rows: the texture path then spends a
+// cycle per LANE (64 per wave load -- the gather kernel measured 50 us for a layer whose bytes need 12).  So the load
+// is issued row-major across lanes (lane l: row l >> 2, chunk l & 3: each quad reads 64 contiguous bytes) and the
+// registers are moved to the MFMA's lanes with four ds_bpermute (crossbar only, no LDS memory).
+__device__ __forceinline__ bf16x8 frag_ld(__amdgpu_buffer_rsrc_t r, int voff, int soff, int src_lane4) {
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+  u32x4 o;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) o[i] = (unsigned)__builtin_amdgcn_ds_bpermute(src_lane4, (int)v[i]);
+  return __builtin_bit_cast(bf16x8, o);
+}
+
+// per-axis coefficient of tap index k in the wave-uniform part of the input offset (see the kernel's addressing note)
+__device__ __forceinline__ int tap_coef(int k, int transposed, int stride, int pad) {
+  return !transposed ? k - pad : (stride == 2 ? -(k >> 1) : pad - k);
+}
+
+// NT = number of 16-wide Cout tiles handled by one wave; MT voxel tiles of 16; KS = kernel size (taps fully unrolled).
+//
+// Addressing.  The gather kernel was bound by instruction issue, not by memory (PMC: 58 SALU + 34 VALU instructions per
+// 2 MFMAs, 51 % issue stalls), so the inner loop carries no address arithmetic at all: both operands are BUFFER loads
+// whose address is  descriptor base + per-lane voffset (computed once per tile) + wave-uniform soffset (tap, channel
+// chunk).  The input voxel of output voxel o for tap k separates into a per-lane and a uniform part in every mode:
+//   conv            : i = o*stride + (k - pad)
+//   data grad, s=1  : i = o + (pad - k)
+//   data grad, s=2  : i = ((o + pad) >> 1) - (k >> 1)     (valid taps have k = (o + pad) mod 2)
+// A lane whose tap falls outside the volume loads with voffset = 0x80000000, which the descriptor's range check turns
+// into zeros without touching memory -- the zero padding costs one v_cndmask per tap instead of a data select.
+// The descriptor base is moved back by P = Hi*Wi + Wi + 1 voxels so that every uniform part is >= 0.
+template <int NT, int MT, int KS>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -39,8 +72,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
   const int lv = lane & 15;   // voxel within tile (B column) / cout within tile (A row)
   const int q = lane >> 4;    // k sub-chunk (8 channels)
 
-  int oz[MT], oy[MT], ox[MT];
-  bool vok[MT];
+  // Two voxel roles per lane: the LOAD role (row l >> 2 of the tile: addressing and tap validity) and the MFMA/epilogue
+  // role (column l & 15: which voxel this lane's accumulators belong to).
+  const int lrow = lane >> 2, lchunk = lane & 3;
+  const int src_lane4 = ((lane & 15) * 4 + (lane >> 4)) * 4;  // ds_bpermute byte address: MFMA lane <- load lane
+  int oz[MT], oy[MT], ox[MT], lz_[MT], ly_[MT], lx_[MT];
+  bool vok[MT], lok[MT];
   // Data gradient of a stride-2 conv: only taps with k = (u + pad) mod 2 contribute to output position u, so a tile
   // whose voxels share their parity needs 1-8 of the 27 taps.  Rows already share (z,y) parity; x is enumerated
   // evens-first so that 16-voxel tiles share x parity too, and taps no lane needs are skipped wave-uniformly below.
@@ -52,6 +89,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
     vok[mt] = v < p.Vo;
     vox_decode(vok[mt] ? v : 0, p.Ho, p.Wo, oz[mt], oy[mt], ox[mt]);
     if (parity_x) ox[mt] = (ox[mt] < half_w) ? 2 * ox[mt] : 2 * (ox[mt] - half_w) + 1;
+    // the load role's voxel is column lrow of the same tile: fetch its coordinates from that lane (crossbar) instead of
+    // decoding a second index (two integer divisions)
+    const int from = lrow * 4;
+    lz_[mt] = __builtin_amdgcn_ds_bpermute(from, oz[mt]);
+    ly_[mt] = __builtin_amdgcn_ds_bpermute(from, oy[mt]);
+    lx_[mt] = __builtin_amdgcn_ds_bpermute(from, ox[mt]);
+    lok[mt] = vbase + mt * 16 + lrow < p.Vo;
   }
 
   f32x4 acc[MT][NT];
@@ -61,34 +105,36 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
     for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
   // MFMA row (nt, 4q+r) <- output channel 8q + 4nt + r (NT == 2): the lane's two accumulator tiles then hold 8
   // contiguous channels = one 16-B chunk, so a store instruction covers whole 64-B voxel lines
-  int arow[NT];
+  int wvo[NT];  // per-lane byte offset of this lane's weight row fragment
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) arow[nt] = (NT == 2) ? 8 * (lv >> 2) + 4 * nt + (lv & 3) : nt * 16 + lv;
-
-  const bf16_t* wbase = p.w + (long)n * p.w_sample_stride;
-  const long x_n = (long)n * p.Di * p.Hi * p.Wi;
+  for (int nt = 0; nt < NT; ++nt) {
+    const int arow = (NT == 2) ? 8 * (lrow >> 2) + 4 * nt + (lrow & 3) : nt * 16 + lrow;
+    wvo[nt] = (arow * p.Ci + lchunk * 8) * 2;
+  }
   const int kchunks = p.Ci >> 5;
+  const int P = p.Hi * p.Wi + p.Wi + 1;
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(p.x + ((long)n * p.Di * p.Hi * p.Wi - P) * p.x_cs + p.x_co), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(p.w + (long)n * p.w_sample_stride + (long)co_base * p.Ci), 0, 0x7fffffff, 0x00020000);
 
-  // Per-axis tap tables, computed once per tile: input coordinate offset (in voxels of the flattened sample) and
-  // validity of each of the (up to) 3 taps along z, y, x.  The 27-tap loop then only ANDs three bits and adds three
-  // offsets; recomputing coordinates and bounds per tap cost more VALU time than the MFMAs on the low-resolution and
-  // stride-2-gradient layers.
-  int offz[MT][3], offy[MT][3], offx[MT][3];
-  unsigned okm[MT];  // bits 0-2: z taps, 3-5: y taps, 6-8: x taps
+  // per-axis tap validity (bits 0-2: z taps, 3-5: y taps, 6-8: x taps) and the per-lane byte offset, once per tile
+  int voff[MT];
+  unsigned okm[MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     okm[mt] = 0;
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
+    for (int k = 0; k < KS; ++k) {
       int iz, iy, ix;
-      bool vz = k < p.ks, vy = k < p.ks, vx = k < p.ks;
+      bool vz = true, vy = true, vx = true;
       if (!p.transposed) {
-        iz = oz[mt] * p.stride + k - p.pad;
-        iy = oy[mt] * p.stride + k - p.pad;
-        ix = ox[mt] * p.stride + k - p.pad;
+        iz = lz_[mt] * p.stride + k - p.pad;
+        iy = ly_[mt] * p.stride + k - p.pad;
+        ix = lx_[mt] * p.stride + k - p.pad;
       } else {
-        int tz = oz[mt] + p.pad - k, ty = oy[mt] + p.pad - k, tx = ox[mt] + p.pad - k;
-        vz = vz && tz >= 0; vy = vy && ty >= 0; vx = vx && tx >= 0;
+        int tz = lz_[mt] + p.pad - k, ty = ly_[mt] + p.pad - k, tx = lx_[mt] + p.pad - k;
+        vz = tz >= 0; vy = ty >= 0; vx = tx >= 0;
         if (p.stride == 2) {
           vz = vz && !(tz & 1); vy = vy && !(ty & 1); vx = vx && !(tx & 1);
           tz >>= 1; ty >>= 1; tx >>= 1;
@@ -98,33 +144,51 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
       vz = vz && (unsigned)iz < (unsigned)p.Di;
       vy = vy && (unsigned)iy < (unsigned)p.Hi;
       vx = vx && (unsigned)ix < (unsigned)p.Wi;
-      offz[mt][k] = iz * p.Hi * p.Wi; offy[mt][k] = iy * p.Wi; offx[mt][k] = ix;
       okm[mt] |= ((unsigned)vz << k) | ((unsigned)vy << (3 + k)) | ((unsigned)vx << (6 + k));
     }
-    if (!vok[mt]) okm[mt] = 0;
+    if (!lok[mt]) okm[mt] = 0;
+    int lz, ly, lx;
+    if (!p.transposed) { lz = lz_[mt] * p.stride; ly = ly_[mt] * p.stride; lx = lx_[mt] * p.stride; }
+    else if (p.stride == 2) { lz = (lz_[mt] + p.pad) >> 1; ly = (ly_[mt] + p.pad) >> 1; lx = (lx_[mt] + p.pad) >> 1; }
+    else { lz = lz_[mt]; ly = ly_[mt]; lx = lx_[mt]; }
+    voff[mt] = (((lz * p.Hi + ly) * p.Wi + lx) * p.x_cs + lchunk * 8) * 2;
   }
 
-  int tap = 0;
-  for (int kz = 0; kz < p.ks; ++kz)
-  for (int ky = 0; ky < p.ks; ++ky)
-  for (int kx = 0; kx < p.ks; ++kx, ++tap) {
-    long xoff[MT];
-    bool ok[MT];
+  // Wave-uniform per-axis masks: a tap can only be needed if each of its three axis taps is valid for SOME lane.  The
+  // data gradient of a stride-2 conv (1-8 live taps of 27) and border tiles then skip dead taps on scalar tests alone.
+  unsigned axis_any = 0;
+  {
+    unsigned o = 0;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) o |= okm[mt];
+#pragma unroll
+    for (int b = 0; b < 9; ++b)
+      if (__any((o >> b) & 1u)) axis_any |= 1u << b;
+  }
+#pragma unroll
+  for (int tap = 0; tap < KS * KS * KS; ++tap) {
+    constexpr int K2 = KS * KS;
+    const int kz = tap / K2, ky = (tap / KS) % KS, kx = tap % KS;  // compile-time after unrolling
+    if (!((axis_any >> kz) & (axis_any >> (3 + ky)) & (axis_any >> (6 + kx)) & 1u)) continue;  // scalar
+    int vo[MT];
     bool any = false;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-      ok[mt] = (okm[mt] >> kz) & (okm[mt] >> (3 + ky)) & (okm[mt] >> (6 + kx)) & 1u;
-      any |= ok[mt];
-      xoff[mt] = (x_n + offz[mt][kz] + offy[mt][ky] + offx[mt][kx]) * p.x_cs + p.x_co + q * 8;
+      const bool ok = (okm[mt] >> kz) & (okm[mt] >> (3 + ky)) & (okm[mt] >> (6 + kx)) & 1u;
+      any |= ok;
+      vo[mt] = ok ? voff[mt] : (int)0x80000000;
     }
     if (!__any(any)) continue;  // wave-uniform: no lane of this wave has an in-range sample for this tap
-    const bf16_t* wt = wbase + ((long)tap * p.Co + co_base) * p.Ci + q * 8;
-    for (int kc = 0; kc < kchunks; ++kc) {
+    const int uz = tap_coef(kz, p.transposed, p.stride, p.pad), uy = tap_coef(ky, p.transposed, p.stride, p.pad),
+              ux = tap_coef(kx, p.transposed, p.stride, p.pad);
+    int sx = (((uz * p.Hi + uy) * p.Wi + ux + P) * p.x_cs) * 2;
+    int sw = (tap * p.Co * p.Ci) * 2;
+    for (int kc = 0; kc < kchunks; ++kc, sx += 64, sw += 64) {
       bf16x8 a[NT], b[MT];
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) a[nt] = ld_bf16x8(wt + (long)arow[nt] * p.Ci + kc * 32);
+      for (int nt = 0; nt < NT; ++nt) a[nt] = frag_ld(rw, wvo[nt], sw, src_lane4);
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) b[mt] = ok[mt] ? ld_bf16x8(p.x + xoff[mt] + kc * 32) : zero_bf16x8();
+      for (int mt = 0; mt < MT; ++mt) b[mt] = frag_ld(rx, vo[mt], sx, src_lane4);
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -261,15 +325,17 @@ static int conv_dispatch(const RtpAct* x, const void* wf, int w_per_sample, cons
   const int nt = (p.Co % 32 == 0) ? 2 : 1;
   // 64 voxels per wave amortise the weight fragments; small (low-resolution) problems instead take 16 voxels per wave
   // so that they still spread over the chip (they are latency-, not throughput-bound)
-  const bool small = (long)p.N * p.Vo * (p.Co / (16 * nt)) < 256L * 256 * 2;
+  static const int force_mt = getenv("RTP_IGEMM_MT") ? atoi(getenv("RTP_IGEMM_MT")) : 0;  // experiments: 1 or 4
+  const bool small = force_mt ? force_mt == 1 : (long)p.N * p.Vo * (p.Co / (16 * nt)) < 256L * 256 * 2;
   const int mt = small ? 1 : 4;
   p.blocks_per_sample = rtp_div_up(p.Vo, 4 * mt * 16);
   dim3 grid(p.N * p.blocks_per_sample, p.Co / (16 * nt));
   RtpProfScope prof(RTP_FAM_CONV, s);
-  if (nt == 2 && !small) hipLaunchKernelGGL((conv_igemm_kernel<2, 4>), grid, dim3(256), 0, s, p);
-  else if (nt == 2) hipLaunchKernelGGL((conv_igemm_kernel<2, 1>), grid, dim3(256), 0, s, p);
-  else if (!small) hipLaunchKernelGGL((conv_igemm_kernel<1, 4>), grid, dim3(256), 0, s, p);
-  else hipLaunchKernelGGL((conv_igemm_kernel<1, 1>), grid, dim3(256), 0, s, p);
+  using Kern = void (*)(ConvParams);
+  static const Kern table[2][2][2] = {
+      {{conv_igemm_kernel<1, 1, 1>, conv_igemm_kernel<1, 1, 3>}, {conv_igemm_kernel<1, 4, 1>, conv_igemm_kernel<1, 4, 3>}},
+      {{conv_igemm_kernel<2, 1, 1>, conv_igemm_kernel<2, 1, 3>}, {conv_igemm_kernel<2, 4, 1>, conv_igemm_kernel<2, 4, 3>}}};
+  hipLaunchKernelGGL(table[nt - 1][small ? 0 : 1][p.ks == 3 ? 1 : 0], grid, dim3(256), 0, s, p);
   RTP_CHECK_LAUNCH();
   return RTP_OK;
 }
