@@ -10,7 +10,7 @@
 #include "rtp_common.h"
 #include "rtp_prof.h"
 
-#define WG_VB 256  // voxels per staged chunk
+#define WG_VB 128  // voxels per staged chunk (41 KB of LDS per block: three blocks per CU overlap each other's gathers)
 
 struct WgradParams {
   const bf16_t* gy; const bf16_t* x; float* gp;
@@ -21,6 +21,7 @@ struct WgradParams {
 };
 
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+typedef __attribute__((ext_vector_type(4))) unsigned wg_u32x4;
 
 __device__ __forceinline__ bf16x8 tr_frag(const bf16_t* tile /*[vox][32]*/, int kstep, int sub, int lane) {
   const int q = lane >> 4, i = lane & 15, a = i >> 2, pp = i & 3;
@@ -31,7 +32,13 @@ __device__ __forceinline__ bf16x8 tr_frag(const bf16_t* tile /*[vox][32]*/, int 
   return __builtin_bit_cast(bf16x8, r);
 }
 
-__global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
+#define WG_ITEMS (WG_VB * 4 / 64)  // 16-B items per lane and tap: 8
+
+// A wave's x chunk for its current tap lives in its own LDS buffer, so inside a chunk the waves never meet at a
+// barrier: each one stores the gathered registers, issues the NEXT tap's gather (buffer loads: per-lane offset and
+// per-axis validity bits are computed once per chunk, the tap only changes the wave-uniform soffset; out-of-volume
+// lanes load through an out-of-range offset that the descriptor turns into zeros) and runs this tap's MFMAs under it.
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradParams p) {
   __shared__ __attribute__((aligned(16))) bf16_t gyL[WG_VB * 32];
   __shared__ __attribute__((aligned(16))) bf16_t xL[4][WG_VB * 32];
   __shared__ int coordL[WG_VB];
@@ -50,64 +57,78 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
       for (int b = 0; b < 2; ++b) acc[t][a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const long g_n = (long)n * p.Vo;
-  const long x_n = (long)n * p.Di * p.Hi * p.Wi;
+  const int P = p.Hi * p.Wi + p.Wi + 1;  // descriptor base moved back so every tap's uniform offset is >= 0
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(p.x + ((long)n * p.Di * p.Hi * p.Wi - P) * p.x_cs + p.x_co + cit * 32), 0, 0x7fffffff, 0x00020000);
+  const int ks2 = p.ks * p.ks;
 
   for (int vc = v_begin; vc < v_end; vc += WG_VB) {
     __syncthreads();  // previous chunk fully consumed
-    {
+    if (tid < WG_VB) {
       const int v = vc + tid;
       int z = 0, y = 0, x = 0;
       if (v < v_end) vox_decode(v, p.Ho, p.Wo, z, y, x);
       coordL[tid] = (v < v_end) ? ((z << 20) | (y << 10) | x) : -1;
+    }
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int item = tid + 256 * r, vox = item >> 2, ck = item & 3;
-        bf16x8 val = zero_bf16x8();
-        if (vc + vox < v_end) val = ld_bf16x8(p.gy + (g_n + vc + vox) * p.g_cs + p.g_co + cot * 32 + ck * 8);
-        st_bf16x8(&gyL[vox * 32 + ck * 8], val);
-      }
+    for (int r = 0; r < WG_VB * 4 / 256; ++r) {
+      const int item = tid + 256 * r, vox = item >> 2, ck = item & 3;
+      bf16x8 val = zero_bf16x8();
+      if (vc + vox < v_end) val = ld_bf16x8(p.gy + (g_n + vc + vox) * p.g_cs + p.g_co + cot * 32 + ck * 8);
+      st_bf16x8(&gyL[vox * 32 + ck * 8], val);
     }
     __syncthreads();
+    // per item: byte offset of the tap-(pad,pad,pad) input voxel and the 9 per-axis validity bits
+    int boff[WG_ITEMS];
+    unsigned okm[WG_ITEMS];
+#pragma unroll
+    for (int r = 0; r < WG_ITEMS; ++r) {
+      const int item = lane + 64 * r, vox = item >> 2, ck = item & 3;
+      const int cd = coordL[vox];
+      const int z = (cd >> 20) * p.stride, y = ((cd >> 10) & 1023) * p.stride, x = (cd & 1023) * p.stride;
+      boff[r] = (((z * p.Hi + y) * p.Wi + x) * p.x_cs + ck * 8) * 2;
+      unsigned m = 0;
+      if (cd >= 0) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          m |= (unsigned)((unsigned)(z + k - p.pad) < (unsigned)p.Di) << k;
+          m |= (unsigned)((unsigned)(y + k - p.pad) < (unsigned)p.Hi) << (3 + k);
+          m |= (unsigned)((unsigned)(x + k - p.pad) < (unsigned)p.Wi) << (6 + k);
+        }
+      }
+      okm[r] = m;
+    }
+    bf16x8 val[WG_ITEMS];
+    auto gather = [&](int tap) {
+      const int kz = tap / ks2, ky = (tap - kz * ks2) / p.ks, kx = tap - kz * ks2 - ky * p.ks;
+      const int soff = ((((kz - p.pad) * p.Hi + (ky - p.pad)) * p.Wi + (kx - p.pad) + P) * p.x_cs) * 2;
+#pragma unroll
+      for (int r = 0; r < WG_ITEMS; ++r) {
+        const bool ok = (okm[r] >> kz) & (okm[r] >> (3 + ky)) & (okm[r] >> (6 + kx)) & 1u;
+        const wg_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? boff[r] : (int)0x80000000, soff, 0);
+        val[r] = __builtin_bit_cast(bf16x8, v);
+      }
+    };
+    if (wave < p.ntap) gather(wave);
 #pragma unroll
     for (int t = 0; t < 7; ++t) {
       const int tap = wave + 4 * t;
-      const bool live = tap < p.ntap;  // wave-uniform
-      if (live) {
-        const int kz = tap / (p.ks * p.ks), ky = (tap / p.ks) % p.ks, kx = tap % p.ks;
-        // all 16 gathers of this lane in flight together (one L2 round trip per tap instead of four)
-        bf16x8 val[16];
+      if (tap >= p.ntap) break;  // wave-uniform
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int item = lane + 64 * r, vox = item >> 2, ck = item & 3;
-          const int cd = coordL[vox];
-          val[r] = zero_bf16x8();
-          if (cd >= 0) {
-            const int iz = (cd >> 20) * p.stride + kz - p.pad;
-            const int iy = ((cd >> 10) & 1023) * p.stride + ky - p.pad;
-            const int ix = (cd & 1023) * p.stride + kx - p.pad;
-            if ((unsigned)iz < (unsigned)p.Di && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi)
-              val[r] = ld_bf16x8(p.x + (x_n + ((long)iz * p.Hi + iy) * p.Wi + ix) * p.x_cs + p.x_co + cit * 32 + ck * 8);
-          }
-        }
+      for (int r = 0; r < WG_ITEMS; ++r) {
+        const int item = lane + 64 * r;
+        st_bf16x8(&xL[wave][(item >> 2) * 32 + (item & 3) * 8], val[r]);
+      }
+      if (tap + 4 < p.ntap) gather(tap + 4);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int item = lane + 64 * r;
-          st_bf16x8(&xL[wave][(item >> 2) * 32 + (item & 3) * 8], val[r]);
-        }
+      for (int ks = 0; ks < WG_VB / 32; ++ks) {
+        bf16x8 a0 = tr_frag(gyL, ks, 0, lane), a1 = tr_frag(gyL, ks, 1, lane);
+        bf16x8 b0 = tr_frag(xL[wave], ks, 0, lane), b1 = tr_frag(xL[wave], ks, 1, lane);
+        acc[t][0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b0, acc[t][0][0], 0, 0, 0);
+        acc[t][0][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b1, acc[t][0][1], 0, 0, 0);
+        acc[t][1][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b0, acc[t][1][0], 0, 0, 0);
+        acc[t][1][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1, acc[t][1][1], 0, 0, 0);
       }
-      __syncthreads();
-      if (live) {
-#pragma unroll 2
-        for (int ks = 0; ks < WG_VB / 32; ++ks) {
-          bf16x8 a0 = tr_frag(gyL, ks, 0, lane), a1 = tr_frag(gyL, ks, 1, lane);
-          bf16x8 b0 = tr_frag(xL[wave], ks, 0, lane), b1 = tr_frag(xL[wave], ks, 1, lane);
-          acc[t][0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b0, acc[t][0][0], 0, 0, 0);
-          acc[t][0][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b1, acc[t][0][1], 0, 0, 0);
-          acc[t][1][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b0, acc[t][1][0], 0, 0, 0);
-          acc[t][1][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1, acc[t][1][1], 0, 0, 0);
-        }
-      }
-      __syncthreads();
     }
   }
 

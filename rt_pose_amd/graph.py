@@ -95,7 +95,9 @@ def cls_split(d, h):
 
 
 def wgrad_split(vox):
-    return max(1, min(64, (vox + 511) // 512))
+    """Slabs per sample of the generic weight-gradient kernel: two 128-voxel chunks per block keep the low-resolution
+    layers spread over the chip without multiplying the slab bytes the tail has to fold."""
+    return max(1, min(64, (vox + 255) // 256))
 
 
 class Graph:

@@ -199,7 +199,7 @@ class EmuBackend:
             gyf = gy.buf[..., gy.co:gy.co + co32].float().reshape(g.n, -1, co32)
             xin = _ncdhw(x.buf[..., x.co:x.co + g.ci].float())
             vo = g.do * g.ho * g.wo
-            for i, (v0, v1) in enumerate(_split_ranges(vo, nsplit, 256)):
+            for i, (v0, v1) in enumerate(_split_ranges(vo, nsplit, 128)):  # mirrors WG_VB
                 if v1 <= v0:
                     gp[:, i] = 0
                     continue
