@@ -26,6 +26,9 @@ struct ConvParams {
   long w_sample_stride;  // elements between per-sample weight sets (0 = shared)
   int Vo;                // Do*Ho*Wo
   int blocks_per_sample;
+  // optional per-channel statistics of the stored output (one partial per block): sum y and sum y*y, or, with stat_x
+  // (same shape as y), sum y*stat_x -- what rtp_chan_stats would compute in a separate read pass
+  const bf16_t* stat_x; int s_cs, s_co; float* stat_out;
 };
 
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
@@ -68,7 +71,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
   const int blk = blockIdx.x - n * p.blocks_per_sample;
   const int co_base = blockIdx.y * (NT * 16);
   const int vbase = (blk * 4 + wave) * (MT * 16);
-  if (vbase >= p.Vo) return;  // wave-uniform
+  // (a wave past the end of the volume has no valid voxel: every tap is skipped and nothing is stored, but it stays for
+  // the statistics barrier below)
   const int lv = lane & 15;   // voxel within tile (B column) / cout within tile (A row)
   const int q = lane >> 4;    // k sub-chunk (8 channels)
 
@@ -198,6 +202,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
   }
 
   // epilogue: lane holds couts co_base + nt*16 + 4q .. +3 of voxel (mt, lv)
+  float st_p[4 * NT], st_q[4 * NT];
+#pragma unroll
+  for (int j = 0; j < 4 * NT; ++j) st_p[j] = st_q[j] = 0.f;
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     if (!vok[mt]) continue;
@@ -239,17 +246,58 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
       for (int k = 0; k < CH; k += 4) *reinterpret_cast<f32x4*>(yp + k) = f32x4{val[k], val[k + 1], val[k + 2], val[k + 3]};
     } else {
       bf16_t* yp = (bf16_t*)p.y + vo * p.y_cs + p.y_co + c0;
+      float rnd[CH];  // the stored (rounded) values: the statistics are those a read-back pass would see
       if constexpr (NT == 2) {
         bf16x8 o;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = f2bf(val[j]);
+        for (int j = 0; j < 8; ++j) { o[j] = f2bf(val[j]); rnd[j] = bf2f(o[j]); }
         st_bf16x8(yp, o);
       } else {
         bf16x4 o;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = f2bf(val[j]);
+        for (int j = 0; j < 4; ++j) { o[j] = f2bf(val[j]); rnd[j] = bf2f(o[j]); }
         *reinterpret_cast<bf16x4*>(yp) = o;
       }
+      if (p.stat_out) {
+        float other[CH];
+        if (p.stat_x) {
+          const bf16_t* sp = p.stat_x + vo * p.s_cs + p.s_co + c0;
+#pragma unroll
+          for (int k = 0; k < CH; k += 4) {
+            const bf16x4 r = *reinterpret_cast<const bf16x4*>(sp + k);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) other[k + j] = bf2f(r[j]);
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < CH; ++j) other[j] = rnd[j];
+        }
+#pragma unroll
+        for (int j = 0; j < CH; ++j) { st_p[j] += rnd[j]; st_q[j] += rnd[j] * other[j]; }
+      }
+    }
+  }
+  if (p.stat_out) {  // kernel-uniform
+    // fold the 16 voxel lanes of each channel group, then the block's four waves in fixed order: one partial per block
+    __shared__ float red[4][NT * 16][2];
+    constexpr int CH = 4 * NT;
+#pragma unroll
+    for (int j = 0; j < CH; ++j)
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) {
+        st_p[j] += __shfl_xor(st_p[j], o, 64);
+        st_q[j] += __shfl_xor(st_q[j], o, 64);
+      }
+    if (lv == 0) {
+#pragma unroll
+      for (int j = 0; j < CH; ++j) { red[wave][q * CH + j][0] = st_p[j]; red[wave][q * CH + j][1] = st_q[j]; }
+    }
+    __syncthreads();
+    const int t = threadIdx.x;
+    if (t < NT * 16 * 2) {
+      const int ch = t >> 1, which = t & 1;
+      const float a = (red[0][ch][which] + red[1][ch][which]) + (red[2][ch][which] + red[3][ch][which]);
+      p.stat_out[(((long)n * p.blocks_per_sample + blk) * p.Co + co_base + ch) * 2 + which] = a;
     }
   }
 }
@@ -259,9 +307,28 @@ int rtp_conv_tiled_try(const RtpAct* x, const void* wf, int w_per_sample, const 
                        const RtpAct* stat_x, float* stat_out, hipStream_t s);
 int rtp_conv_tiled_stat_slots(const RtpAct* x, const RtpConvGeom* g, int transposed);
 
+// tile shape of the generic kernel for a problem: (cout tiles per wave, voxel tiles per wave, blocks per sample)
+static void igemm_shape(int N, int Vo, int Co, int* nt, int* mt, int* bps) {
+  static const int force_mt = getenv("RTP_IGEMM_MT") ? atoi(getenv("RTP_IGEMM_MT")) : 0;  // experiments: 1 or 4
+  *nt = (Co % 32 == 0) ? 2 : 1;
+  // 64 voxels per wave amortise the weight fragments; small (low-resolution) problems instead take 16 voxels per wave
+  // so that they still spread over the chip (they are latency-, not throughput-bound)
+  const bool small = force_mt ? force_mt == 1 : (long)N * Vo * (Co / (16 * *nt)) < 256L * 256 * 2;
+  *mt = small ? 1 : 4;
+  *bps = rtp_div_up(Vo, 4 * *mt * 16);
+}
+
 extern "C" int rtp_conv_stats_nsplit(const RtpAct* x, const RtpConvGeom* g, int transposed) {
   if (!x || !g) return 0;
-  return rtp_conv_tiled_stat_slots(x, g, transposed);
+  const int tiled = rtp_conv_tiled_stat_slots(x, g, transposed);
+  if (tiled > 0) return tiled;
+  if ((g->ks != 1 && g->ks != 3) || (g->stride != 1 && g->stride != 2)) return 0;
+  const int Co = transposed ? g->ci : g->co;
+  const int Vo = transposed ? g->di * g->hi * g->wi : g->dov * g->ho * g->wo;
+  if (Co % 16) return 0;
+  int nt, mt, bps;
+  igemm_shape(g->n, Vo, Co, &nt, &mt, &bps);
+  return bps;  // one partial per block of the generic kernel
 }
 
 static int conv_dispatch(const RtpAct* x, const void* wf, int w_per_sample, const float* btab, const RtpAct* res,
@@ -295,7 +362,6 @@ static int conv_dispatch(const RtpAct* x, const void* wf, int w_per_sample, cons
                                       (hipStream_t)stream);
     if (rc <= 0) return rc;  // handled (or failed) by the LDS-tiled kernel
   }
-  if (stat_out) return RTP_ERR_UNSUPPORTED;  // only geometries with rtp_conv_stats_nsplit() > 0 emit statistics
   ConvParams p;
   p.x = (const bf16_t*)x->ptr;
   p.w = (const bf16_t*)wf;
@@ -322,13 +388,13 @@ static int conv_dispatch(const RtpAct* x, const void* wf, int w_per_sample, cons
   p.w_sample_stride = w_per_sample ? (long)ntap * p.Co * p.Ci : 0;
   p.Vo = p.Do * p.Ho * p.Wo;
   hipStream_t s = (hipStream_t)stream;
-  const int nt = (p.Co % 32 == 0) ? 2 : 1;
-  // 64 voxels per wave amortise the weight fragments; small (low-resolution) problems instead take 16 voxels per wave
-  // so that they still spread over the chip (they are latency-, not throughput-bound)
-  static const int force_mt = getenv("RTP_IGEMM_MT") ? atoi(getenv("RTP_IGEMM_MT")) : 0;  // experiments: 1 or 4
-  const bool small = force_mt ? force_mt == 1 : (long)p.N * p.Vo * (p.Co / (16 * nt)) < 256L * 256 * 2;
-  const int mt = small ? 1 : 4;
-  p.blocks_per_sample = rtp_div_up(p.Vo, 4 * mt * 16);
+  int nt, mt;
+  igemm_shape(p.N, p.Vo, p.Co, &nt, &mt, &p.blocks_per_sample);
+  const bool small = mt == 1;
+  if (stat_out && (y_fp32 || (stat_x && stat_x->c < p.Co))) return RTP_ERR_UNSUPPORTED;
+  p.stat_out = stat_out;
+  p.stat_x = (stat_out && stat_x) ? (const bf16_t*)stat_x->ptr : nullptr;
+  p.s_cs = stat_x ? stat_x->cs : 0; p.s_co = stat_x ? stat_x->co : 0;
   dim3 grid(p.N * p.blocks_per_sample, p.Co / (16 * nt));
   RtpProfScope prof(RTP_FAM_CONV, s);
   using Kern = void (*)(ConvParams);

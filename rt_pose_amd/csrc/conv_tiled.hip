@@ -74,8 +74,12 @@ __global__ __launch_bounds__(512, 2) void conv_tiled_kernel(TiledParams p) {
   // class-bias table in LDS: 27 reachable classes (per axis: interior / first / last; every axis is >= 2 long here)
   float* bL = reinterpret_cast<float*>(lds + 27 * NT * 16 * 32 + 2 * (HALO_VOX * 32));  // [27][Co]
   const int wgs_per_sample = p.teams_per_sample >> 1;
-  const int n = blockIdx.x / wgs_per_sample;
-  const int team_id = (blockIdx.x - n * wgs_per_sample) * 2 + team;  // team index within the sample
+  // XCD-aware placement: workgroups are dealt round-robin over the 8 XCDs (b and b + 8 share an L2), so the logical
+  // workgroup index is permuted to give every XCD one contiguous run of bricks -- haloes shared with the y/x neighbour
+  // columns then hit that XCD's L2 instead of being re-read from HBM (PMC: x fetched 2.4x with the identity map).
+  const int bid = (gridDim.x % 8 == 0) ? (int)(blockIdx.x % 8) * (int)(gridDim.x / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
+  const int n = bid / wgs_per_sample;
+  const int team_id = (bid - n * wgs_per_sample) * 2 + team;  // team index within the sample
   const int v = lane & 15, q = lane >> 4;
   const int wz = tw >> 1, wx = tw & 1;
 
@@ -342,7 +346,7 @@ __global__ __launch_bounds__(512, 2) void conv_tiled_kernel(TiledParams p) {
       float a = 0.f;
 #pragma unroll
       for (int w8 = 0; w8 < 8; ++w8) a += red[w8 * p.Co * 2 + i];
-      p.stat_out[((long)blockIdx.x * p.Co) * 2 + i] = a;  // blockIdx.x = n * workgroups_per_sample + workgroup
+      p.stat_out[((long)bid * p.Co) * 2 + i] = a;  // bid = n * workgroups_per_sample + workgroup
     }
   }
 }

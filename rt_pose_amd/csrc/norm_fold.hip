@@ -333,16 +333,28 @@ __global__ __launch_bounds__(256) void gn_bwd_coeffs_kernel(const float* pq, int
                                                             const float* gamma, int c, int groups, long vox,
                                                             float* coeff, float* part /*[n][c][2]*/) {
   __shared__ float P[256], Q[256], S1[64], S2[64];
+  __shared__ float2 part_pq[256];
   const int tid = threadIdx.x, i = blockIdx.x;
   const int cg = c / groups;
   const float m = (float)cg * (float)vox;
   float pc = 0.f, qc = 0.f, mu = 0.f, r = 0.f, gam = 0.f;
+  {
+    // the partials of a channel are split over 256/c threads (a conv epilogue may leave hundreds per sample), then
+    // folded in fixed order
+    const int np = 256 / c, ch = tid % c, pt = tid / c;
+    float2 a = make_float2(0.f, 0.f);
+    if (pt < np)
+      for (int s = pt; s < nsplit; s += np) {
+        const float2 q = *reinterpret_cast<const float2*>(pq + (((long)i * nsplit + s) * c + ch) * 2);
+        a.x += q.x;
+        a.y += q.y;
+      }
+    part_pq[tid] = a;
+    __syncthreads();
+    if (tid < c)
+      for (int k = 0; k < np; ++k) { pc += part_pq[k * c + tid].x; qc += part_pq[k * c + tid].y; }
+  }
   if (tid < c) {
-    for (int s = 0; s < nsplit; ++s) {
-      const float* q = pq + (((long)i * nsplit + s) * c + tid) * 2;
-      pc += q[0];
-      qc += q[1];
-    }
     const int g = tid / cg;
     mu = mr[((long)i * groups + g) * 2];
     r = mr[((long)i * groups + g) * 2 + 1];

@@ -104,8 +104,10 @@ __global__ __launch_bounds__(512, 2) void wgrad_tiled_kernel(WgTiledParams p) {
   const bool loader = __builtin_amdgcn_readfirstlane(wave >> 2) == 1;  // waves 4-7 stage, waves 0-3 run the MFMAs
   const int tw = __builtin_amdgcn_readfirstlane(wave & 3);
   const int ttid = tid & 255;
-  const int n = blockIdx.x / p.wgs_per_sample;
-  const int wg = blockIdx.x - n * p.wgs_per_sample;
+  // XCD-aware placement (see conv_tiled.hip): one contiguous run of bricks per XCD
+  const int bid = (gridDim.x % 8 == 0) ? (int)(blockIdx.x % 8) * (int)(gridDim.x / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
+  const int n = bid / p.wgs_per_sample;
+  const int wg = bid - n * p.wgs_per_sample;
   const long vox_n = (long)n * p.D * p.H * p.W;
   const int t_begin = (int)((long)wg * p.tiles_per_sample / p.wgs_per_sample);  // contiguous run, z fastest (L2 reuse of shared z-planes)
   const int my_tiles = (int)((long)(wg + 1) * p.tiles_per_sample / p.wgs_per_sample) - t_begin;

@@ -184,7 +184,8 @@ class Graph:
         return y
 
     def conv(self, name, x: Act, wname, bname=None, gn=None, ks=3, stride=1, relu=False, residual=None,
-             out_fp32=False, w_ci_total=0, w_ci_off=0, ci_real=None):
+             out_fp32=False, w_ci_total=0, w_ci_off=0, ci_real=None, want_stats=True):
+        """want_stats: a GroupNorm will consume the output, so the conv's epilogue should emit its statistics."""
         w = self.param(wname)
         co_real = w.shape[0]
         ci_real = ci_real if ci_real is not None else w.shape[1]
@@ -197,6 +198,7 @@ class Graph:
         y = self.act(name, co_real, (do, ho, wo), c=co_pad if out_fp32 else pad_to(co_real, 32) if co_real % 16 else co_real,
                      dtype="f32" if out_fp32 else "bf16", relu=relu)
         op = ConvOp(self, name, x, y, geom, wname, bname, gn, relu, residual, out_fp32, ci_real, co_real)
+        op.want_stats = want_stats
         y.producer = op
         self.ops.append(op)
         op.emit_forward()
@@ -337,7 +339,7 @@ class ConvOp:
         # Convs on the LDS-tiled kernel also emit (sum y, sum y^2) per channel from their epilogue, so a GroupNorm
         # consumer of y needs no statistics pass (ensure_stats finds them)
         fstats = None
-        S = 0 if self.out_fp32 or ge.co != self.y.c else be.conv_stats_nsplit(self.x, ge, False)
+        S = 0 if (self.out_fp32 or ge.co != self.y.c or not self.want_stats) else be.conv_stats_nsplit(self.x, ge, False)
         if S > 0:
             self.y.stats_split = S
             self.y.stats = be.alloc((g.n, S, self.y.c, 2), "f32")

@@ -30,9 +30,10 @@ def _resblock(g: Graph, p, x, tag):
                   relu=True, residual=x)
 
 
-def _seq(g: Graph, p, x, tag, ks, stride, relu):
+def _seq(g: Graph, p, x, tag, ks, stride, relu, want_stats=True):
     """nn.Sequential(GroupNorm, Conv3d(bias=False)[, ReLU])."""
-    return g.conv(tag, x, p + ".1.weight", gn=(p + ".0.weight", p + ".0.bias"), ks=ks, stride=stride, relu=relu)
+    return g.conv(tag, x, p + ".1.weight", gn=(p + ".0.weight", p + ".0.bias"), ks=ks, stride=stride, relu=relu,
+                  want_stats=want_stats)
 
 
 def build_backbone(g: Graph, x_f32, arch, dims, prefix="backbone.backbone", live_rows_last=None):
@@ -64,12 +65,13 @@ def build_backbone(g: Graph, x_f32, arch, dims, prefix="backbone.backbone", live
                 if j == i:
                     terms.append(xs[j])
                 elif j > i:
-                    terms.append(_seq(g, "%s.fuse_layers.%d.%d" % (sp, i, j), xs[j], "s%d.f%d%d" % (stage, i, j), 1, 1, False))
+                    terms.append(_seq(g, "%s.fuse_layers.%d.%d" % (sp, i, j), xs[j], "s%d.f%d%d" % (stage, i, j), 1, 1, False,
+                                      want_stats=False))   # feeds only the fuse sum
                 else:
                     t = xs[j]
                     for k in range(i - j):
                         t = _seq(g, "%s.fuse_layers.%d.%d.%d" % (sp, i, j, k), t, "s%d.f%d%d.%d" % (stage, i, j, k), 3, 2,
-                                 relu=(k != i - j - 1))
+                                 relu=(k != i - j - 1), want_stats=(k != i - j - 1))
                     terms.append(t)
             ys.append(g.fuse("s%d.row%d" % (stage, i), terms, relu=True))
     return ys
@@ -82,7 +84,8 @@ def build_hrnet3d(g: Graph, x_f32, arch, dims, final_fuse, prefix="backbone"):
         ys = build_backbone(g, x_f32, arch, dims, prefix + ".backbone", live_rows_last=1)
         f = ys[0]
         if has_final:
-            f = g.conv("final", f, prefix + ".final_conv.weight", bname=prefix + ".final_conv.bias", ks=1)
+            f = g.conv("final", f, prefix + ".final_conv.weight", bname=prefix + ".final_conv.bias", ks=1,
+                       want_stats=(prefix.replace("backbone", "pose_head") + ".shared_conv.1.weight") in g.params)
         return f
     ys = build_backbone(g, x_f32, arch, dims, prefix + ".backbone")
     if final_fuse != "conat_conv" or not has_final:
@@ -94,7 +97,7 @@ def build_hrnet3d(g: Graph, x_f32, arch, dims, final_fuse, prefix="backbone"):
     for j, y in enumerate(ys):
         terms.append(g.conv("final.%d" % j, y, prefix + ".final_conv.weight",
                             bname=(prefix + ".final_conv.bias") if j == 0 else None, ks=1,
-                            w_ci_total=total, w_ci_off=off, ci_real=ch[j]))
+                            w_ci_total=total, w_ci_off=off, ci_real=ch[j], want_stats=False))
         off += ch[j]
     return g.fuse("final.sum", terms, relu=False)
 
@@ -107,6 +110,6 @@ def build_head(g: Graph, feats, heads, prefix="pose_head"):
     out = {}
     for name in heads:
         p = "%s.tasks.0.%s" % (prefix, name)
-        t = g.conv("head.%s.0" % name, feats, p + ".0.weight", bname=p + ".0.bias", relu=True)
+        t = g.conv("head.%s.0" % name, feats, p + ".0.weight", bname=p + ".0.bias", relu=True, want_stats=False)
         out[name] = g.conv("head.%s.2" % name, t, p + ".2.weight", bname=p + ".2.bias", out_fp32=True)
     return out

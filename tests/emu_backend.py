@@ -153,7 +153,10 @@ class EmuBackend:
         co = g.ci if transposed else g.co
         ok = (g.ks == 3 and g.stride == 1 and ci == 32 and co in (16, 32) and g.di % 2 == 0 and g.hi % 4 == 0
               and g.wi % 16 == 0 and g.di >= 2 and x.cs == 32 and x.co == 0)
-        return 2 if ok else 0
+        if ok:
+            return 2
+        co_k = g.ci if transposed else g.co
+        return 3 if co_k % 16 == 0 else 0   # the generic kernel: one partial per block (any count works for the plan)
 
     def conv(self, x, wf, per_sample, btab, res, y, geom, relu, transposed, y_fp32, stats=None):
         def run(s):

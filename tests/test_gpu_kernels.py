@@ -120,7 +120,7 @@ def test_conv_forward(hip, case):
         emu = torch.stack([yv.sum(1), (yv * yv).sum(1)], -1)
         assert rel_err(st.sum(1).cpu(), emu) < BF * 2
     else:
-        assert fp32 or co != yc_ch or ks != 3 or stride != 1 or ci != 32 or d % 2 or h % 4 or w % 16
+        assert fp32 or co != yc_ch   # both kernels (LDS-tiled and generic) emit statistics for bf16 outputs
 
 
 @pytest.mark.parametrize("case", [

@@ -1,0 +1,17 @@
+#!/bin/bash
+# HBM bytes of a whole training step: FETCH_SIZE and WRITE_SIZE summed over every kernel of `bench.py --steps 6 --warmup 2`
+export TMPDIR=/tmp
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d gpurun_out/pmc_step_f -o run --output-format csv -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-roofline > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d gpurun_out/pmc_step_w -o run --output-format csv -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-roofline > /dev/null 2>&1
+python3 - <<'P'
+import csv, collections
+for d, nm in (("f", "FETCH_SIZE"), ("w", "WRITE_SIZE")):
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    for r in csv.DictReader(open("gpurun_out/pmc_step_%s/run_counter_collection.csv" % d)):
+        if r["Counter_Name"] != nm: continue
+        a = agg[r["Kernel_Name"][:50]]; a[0] += 1; a[1] += float(r["Counter_Value"])
+    tot = sum(v[1] for v in agg.values())
+    print(nm, "total KiB over 8 steps: %.0f -> per step %.1f MB%s" % (tot, tot * 1024 / 8 / 1e6, " (x2 for reads: %.1f MB)" % (tot * 1024 / 8 / 1e6 * 2) if d == "f" else ""))
+    for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:14]:
+        print("   %-52s calls %4d  %.1f MB/step" % (k, v[0], v[1] * 1024 / 8 / 1e6 * (2 if d == "f" else 1)))
+P
