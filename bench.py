@@ -23,6 +23,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA, MI355X_MICROARCH.md chip table
+PEAK_HBM_GBPS = 8000.0     # HBM3E peak (same guide; ~6.3 TB/s achievable)
 
 
 def cpu_baseline(name, seconds_budget=30.0):
@@ -133,13 +134,13 @@ def main():
 
     if world == 1 and not args.no_roofline:
         be = tr.be
-        fams = {"conv_tiled (fwd+dgrad, 32ch full-res)": (_lib.FAM_CONV_TILED, g.flops["conv_tiled"]),
-                "conv_igemm generic (fwd+dgrad)": (_lib.FAM_CONV, g.flops["conv_generic"]),
-                "wgrad_tiled (32ch full-res)": (_lib.FAM_WGRAD_TILED, g.flops["wgrad_tiled"]),
-                "wgrad generic": (_lib.FAM_WGRAD, g.flops["wgrad_generic"])}
+        fams = {"conv_tiled (fwd+dgrad, 32ch 3x3x3)": (_lib.FAM_CONV_TILED, g.flops["conv_tiled"], g.alg_bytes["conv_tiled"]),
+                "conv_igemm generic (fwd+dgrad)": (_lib.FAM_CONV, g.flops["conv_generic"], g.alg_bytes["conv_generic"]),
+                "wgrad_tiled (32ch 3x3x3)": (_lib.FAM_WGRAD_TILED, g.flops["wgrad_tiled"], g.alg_bytes["wgrad_tiled"]),
+                "wgrad generic": (_lib.FAM_WGRAD, g.flops["wgrad_generic"], g.alg_bytes["wgrad_generic"])}
         tr.use_graph = False
         tr.engine.use_lanes = False  # one stream while timing kernels: concurrent side-stream work would inflate the events
-        for fam, _ in fams.values():
+        for fam, _, _ in fams.values():
             be.prof_enable(fam, True)
         ksteps = min(args.steps, 5)
         for _ in range(ksteps):
@@ -147,22 +148,28 @@ def main():
         torch.cuda.synchronize()
         best = None
         detail = {}
-        for kname, (fam, flops) in fams.items():
+        for kname, (fam, flops, nbytes) in fams.items():
             ms, cnt = be.prof_collect(fam)
             be.prof_enable(fam, False)
             if cnt == 0:
                 continue
             tf = flops * ksteps / (ms * 1e-3) / 1e12
+            gbps = nbytes * ksteps / (ms * 1e-3) / 1e9
             detail[kname] = {"launches_per_step": cnt // ksteps, "ms_per_step": round(ms / ksteps, 3),
-                             "avg_us_per_launch": round(1e3 * ms / cnt, 2), "tflops": round(tf, 2)}
+                             "avg_us_per_launch": round(1e3 * ms / cnt, 2), "tflops": round(tf, 2),
+                             "algorithmic_GBps": round(gbps, 1), "hbm_frac": round(gbps / PEAK_HBM_GBPS, 4)}
             if best is None or ms > best[1]:
-                best = (kname, ms, tf)
+                best = (kname, ms, tf, gbps)
         # HBM bytes per launch of the dominant kernel from the PMC passes in profiles/r01_pmc_tiled.md (FETCH_SIZE doubled
-        # per MI355X_MICROARCH.md, + WRITE_SIZE), B=8 full-resolution layer; not re-measured in this process.
-        traffic = {"conv_tiled (fwd+dgrad, 32ch full-res)": 374e6, "wgrad_tiled (32ch full-res)": 251e6}.get(best[0])
+        # per MI355X_MICROARCH.md, + WRITE_SIZE), B=8 full-resolution layer with residual; not re-measured in this process.
+        traffic = {"conv_tiled (fwd+dgrad, 32ch 3x3x3)": 279e6, "wgrad_tiled (32ch 3x3x3)": 208e6}.get(best[0])
+        # The 32-channel 3x3x3 layers sit at the ridge (288-431 algorithmic flop/B against 2500/8 = 312): the MFMA bound is
+        # the one SURVEY 8d names; the same launches against the HBM roof are reported beside it.
         line["roofline"] = {"bound": "mfma", "kernel": best[0], "achieved": round(best[2], 2), "peak": PEAK_BF16_TFLOPS,
                             "unit": "TFLOP/s", "frac": round(best[2] / PEAK_BF16_TFLOPS, 4),
                             "traffic": traffic if args.batch == 8 and args.model == "hr3d" else None,
+                            "hbm_view": {"achieved": round(best[3], 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                                         "frac": round(best[3] / PEAK_HBM_GBPS, 4)},
                             "families": detail}
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(args.model)

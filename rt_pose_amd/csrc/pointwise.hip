@@ -630,13 +630,24 @@ __global__ __launch_bounds__(256) void stem_bwd_partial(const float* x, const bf
   float sw[8], sb[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) sw[j] = sb[j] = 0.f;
-  if (vsub < vper)
-    for (long v = (long)blockIdx.x * vper + vsub; v < total_vox; v += (long)gridDim.x * vper) {
-      const float xv = x[v];
-      bf16x8 gv = ld_bf16x8(g + v * g_cs + g_co + ck * 8);
+  if (vsub < vper) {
+    const long step = (long)gridDim.x * vper;
+    for (long v0 = (long)blockIdx.x * vper + vsub; v0 < total_vox; v0 += 4 * step) {   // four voxels in flight per lane
+      float xv[4];
+      bf16x8 gv[4];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { const float gf = bf2f(gv[j]); sw[j] += xv * gf; sb[j] += gf; }
+      for (int u = 0; u < 4; ++u) {
+        const long v = v0 + u * step;
+        xv[u] = 0.f;
+        gv[u] = zero_bf16x8();
+        if (v < total_vox) { xv[u] = x[v]; gv[u] = ld_bf16x8(g + v * g_cs + g_co + ck * 8); }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float gf = bf2f(gv[u][j]); sw[j] += xv[u] * gf; sb[j] += gf; }
     }
+  }
 #pragma unroll
   for (int j = 0; j < 8; ++j) { red[tid * 17 + j] = sw[j]; red[tid * 17 + 8 + j] = sb[j]; }
   __syncthreads();
@@ -648,14 +659,22 @@ __global__ __launch_bounds__(256) void stem_bwd_partial(const float* x, const bf
   }
 }
 
-__global__ void stem_bwd_final(const float* scratch, int nblk, int c, float* dw, float* db, int accumulate) {
-  const int t = threadIdx.x;
-  if (t >= 2 * c) return;
-  const int ch = t >> 1, which = t & 1;
+// 256 threads: output (channel, which) = t % 2c, the block partials dealt over 256/(2c) threads and folded in fixed order
+__global__ __launch_bounds__(256) void stem_bwd_final(const float* scratch, int nblk, int c, float* dw, float* db, int accumulate) {
+  __shared__ float red[256];
+  const int t = threadIdx.x, no = 2 * c, np = 256 / no;
+  const int o_ = t % no, pt = t / no;
   float acc = 0.f;
-  for (int b = 0; b < nblk; ++b) acc += scratch[((long)b * c + ch) * 2 + which];
+  if (pt < np)
+    for (int b = pt; b < nblk; b += np) acc += scratch[(long)b * no + o_];   // [blk][c][2] flattened
+  red[t] = acc;
+  __syncthreads();
+  if (t >= no) return;
+  float a = 0.f;
+  for (int k = 0; k < np; ++k) a += red[k * no + t];
+  const int ch = t >> 1, which = t & 1;
   float* o = which ? db + ch : dw + ch;
-  if (accumulate) *o += acc; else *o = acc;
+  if (accumulate) *o += a; else *o = a;
 }
 
 extern "C" int rtp_stem_bwd(const float* x, const RtpAct* gy, int n, long vox, float* scratch, float* dw, float* db,

@@ -120,6 +120,8 @@ class Graph:
         # algorithmic FLOPs (2*MACs of real channels) per kernel family, per replay of the lists
         self.flops = {"conv_fwd": 0, "conv_dgrad": 0, "wgrad": 0, "conv_tiled": 0, "conv_generic": 0,
                       "wgrad_tiled": 0, "wgrad_generic": 0}
+        # algorithmic HBM bytes (fused minimum, SURVEY 8d: every operand tensor of a launch read or written once) per family
+        self.alg_bytes = {"conv_tiled": 0, "conv_generic": 0, "wgrad_tiled": 0, "wgrad_generic": 0}
 
     # ------------------------------------------------------------------ helpers
     def act(self, *a, **k):
@@ -355,6 +357,10 @@ class ConvOp:
         self.tiled_fwd = brick and ge.ci == 32 and ge.co in (16, 32) and self.x.cs == 32
         self.tiled_bwd = brick and ge.ci == 32 and pad_to(ge.co, 32) == 32
         g.flops["conv_tiled" if self.tiled_fwd else "conv_generic"] += self.alg_flops
+        esz = 4 if self.out_fp32 else 2
+        self.bytes_fwd = 2 * g.n * self.x.vox * ge.ci + esz * g.n * self.y.vox * self.y.c + (
+            2 * g.n * self.y.vox * self.y.c if self.residual is not None else 0)
+        g.alg_bytes["conv_tiled" if self.tiled_fwd else "conv_generic"] += self.bytes_fwd
 
     def emit_backward(self, gy: View):
         g, be, ge, x = self.g, self.g.be, self.geom, self.x
@@ -377,6 +383,9 @@ class ConvOp:
                        lane, [gy, wd, x if S else None], [dxh, pq if S else None], "dgrad:" + self.name)
             g.flops["conv_dgrad"] += self.alg_flops
             g.flops["conv_tiled" if self.tiled_bwd else "conv_generic"] += self.alg_flops
+            # data gradient: read gy, write dxhat, (GroupNorm: read x for Q)
+            g.alg_bytes["conv_tiled" if self.tiled_bwd else "conv_generic"] += 2 * g.n * (
+                gy.vox * pad_to(ge.co, 32) + x.vox * ge.ci * (2 if self.gn else 1))
             if self.gn:
                 if not S:
                     S = x.stats_split
@@ -403,6 +412,8 @@ class ConvOp:
         g.emit_bwd(be.wgrad(gy, x, ge, S, gp), wl, [gy, x], [gp], "wgrad:" + self.name)
         g.flops["wgrad"] += self.alg_flops
         g.flops["wgrad_tiled" if self.tiled_wgrad else "wgrad_generic"] += self.alg_flops
+        g.alg_bytes["wgrad_tiled" if self.tiled_wgrad else "wgrad_generic"] += 2 * g.n * (gy.vox * co32 + x.vox * ge.ci) + (
+            4 * g.n * S * ge.ks ** 3 * co32 * ge.ci)
         # Everything after the correlation itself (class-sum reduction, slab fold + GroupNorm un-fold) only feeds the
         # optimiser: recorded here, run once for all layers at the end of the sweep (Graph.emit_tail).
         csum = None

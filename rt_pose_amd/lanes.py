@@ -12,11 +12,10 @@ serial order (vector clocks keep only the waits not already implied by stream or
 # lane ids
 L_FULL, L_MID, L_LOW, L_WG, L_WG_LOW = 0, 1, 2, 3, 4
 NLANES = 5
-# Lanes -> streams.  Measured on MI355X (hr3d, B=8, ms/step): one stream 11.6; "0,0,0,1,1" (weight-gradient chains beside
-# everything else) 9.32; "0,1,1,2,2" 9.15-9.18 (default); one stream per lane "0,1,2,3,4" 9.56 -- more streams than that
-# only make the big kernels share the chip.  RTP_LANES overrides for experiments.
+# Lanes -> streams.  Measured on MI355X (hr3d, B=8, ms/step) with the main stream at high priority: one stream 8.9;
+# "0,1,1,2,2" 7.1; one stream per lane "0,1,2,3,4" 6.96 (default).  RTP_LANES overrides for experiments.
 import os
-LANE_MAP = [int(v) for v in os.environ.get("RTP_LANES", "0,1,1,2,2").split(",")]
+LANE_MAP = [int(v) for v in os.environ.get("RTP_LANES", "0,1,2,3,4").split(",")]
 assert len(LANE_MAP) == NLANES and all(0 <= v < NLANES for v in LANE_MAP)
 
 

@@ -70,7 +70,11 @@ class DataParallelTrainer:
         self._graph = None
         # All work of a step goes to ONE explicit (non-default) HIP stream: a graph launched on the legacy NULL stream
         # was observed NOT to be ordered against the optimiser kernels queued behind it on ROCm 7.x.
-        self.stream = torch.cuda.Stream(self.be.device) if self.be.name == "hip" else None
+        # High priority: this stream carries the full-resolution chain, the critical path of the lane plan (side lanes
+        # keep the default priority, so their small kernels fill in around it instead of delaying it).
+        import os
+        prio = int(os.environ.get("RTP_MAIN_PRIORITY", "-1"))
+        self.stream = torch.cuda.Stream(self.be.device, priority=prio) if self.be.name == "hip" else None
 
     # ------------------------------------------------------------------ one step
     def _on_stream(self):
