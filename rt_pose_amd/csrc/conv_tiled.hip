@@ -18,6 +18,8 @@
 // per-channel statistics the next GroupNorm needs of the tensor just produced (forward: sum y, sum y^2; data gradient:
 // P = sum dxhat, Q = sum dxhat * x), accumulated in registers over the workgroup's bricks and written as one partial per
 // workgroup, which removes a separate read pass over the tensor.
+#include <stdlib.h>
+
 #include "rtp_common.h"
 #include "rtp_prof.h"
 
@@ -366,7 +368,8 @@ static bool tiled_geometry_ok(const RtpAct* x, const RtpConvGeom* g, int transpo
 
 static int tiled_wgs_per_sample(const RtpConvGeom* g) {
   const int tiles = (g->di / TZ) * (g->hi / TY) * ((g->wi + TX - 1) / TX);
-  int wgs = 256 / g->n;  // workgroups per sample: one workgroup per CU when N divides 256
+  static const int total_wgs = getenv("RTP_TILED_WGS") ? atoi(getenv("RTP_TILED_WGS")) : 256;  // experiments: leave CUs to other streams
+  int wgs = total_wgs / g->n;  // workgroups per sample: one workgroup per CU when N divides 256
   if (wgs < 1) wgs = 1;
   if (wgs * 2 > tiles) wgs = (tiles + 1) / 2;
   return wgs;

@@ -9,6 +9,8 @@
 // accumulators in registers across ALL bricks of the team, so a workgroup emits ONE fp32 slab [27][32][32]
 // (team 1's accumulators are folded into team 0's through LDS at the end).
 // LDS images rotate the 16-B chunk index by (x>>2) -- conflict-free for the tr-read lane groups (voxels v and v+8).
+#include <stdlib.h>
+
 #include "rtp_common.h"
 #include "rtp_prof.h"
 
@@ -239,7 +241,8 @@ static bool wg_tiled_applicable(const RtpConvGeom* g) {
 
 static int wg_tiled_wgs(const RtpConvGeom* g) {
   const int tiles = (g->di / TZ) * (g->hi / TY) * ((g->wi + TX - 1) / TX);
-  int wgs = 256 / g->n;
+  static const int total_wgs = getenv("RTP_TILED_WGS") ? atoi(getenv("RTP_TILED_WGS")) : 256;  // experiments: leave CUs to other streams
+  int wgs = total_wgs / g->n;
   if (wgs < 1) wgs = 1;
   if (wgs > tiles) wgs = tiles;
   return wgs;

@@ -23,7 +23,7 @@ closure f(stream) so argument marshalling happens once, at build time.
 from dataclasses import dataclass, field
 from typing import List, Optional
 
-from .lanes import Launch, L_FULL, L_MID, L_LOW, L_WG, L_WG_LOW
+from .lanes import Launch, L_FULL, L_MID, L_LOW, L_LOW3, L_WG, L_WG_LOW
 
 
 GROUPS = 8      # nn.GroupNorm(num_groups=8, ...) everywhere on the path (hr_util/common.py:57, hr3d.py:147)
@@ -132,9 +132,10 @@ class Graph:
         return t
 
     def lane_of(self, v):
-        """Resolution group of a tensor: full resolution / one level down / the two lowest levels."""
+        """Resolution group of a tensor: one lane per HRNet level (the low-resolution branches are chains of small
+        latency-bound launches, so each level gets its own stream)."""
         r = self.full_vox // max(1, v.vox)
-        return L_FULL if r < 4 else L_MID if r < 32 else L_LOW
+        return L_FULL if r < 4 else L_MID if r < 32 else L_LOW if r < 256 else L_LOW3
 
     def wg_lane_of(self, v):
         return L_WG if self.lane_of(v) == L_FULL else L_WG_LOW

@@ -10,12 +10,12 @@ serial order (vector clocks keep only the waits not already implied by stream or
 """
 
 # lane ids
-L_FULL, L_MID, L_LOW, L_WG, L_WG_LOW = 0, 1, 2, 3, 4
-NLANES = 5
+L_FULL, L_MID, L_LOW, L_WG, L_WG_LOW, L_LOW3 = 0, 1, 2, 3, 4, 5
+NLANES = 6
 # Lanes -> streams.  Measured on MI355X (hr3d, B=8, ms/step) with the main stream at high priority: one stream 8.9;
 # "0,1,1,2,2" 7.1; one stream per lane "0,1,2,3,4" 6.96 (default).  RTP_LANES overrides for experiments.
 import os
-LANE_MAP = [int(v) for v in os.environ.get("RTP_LANES", "0,1,2,3,4").split(",")]
+LANE_MAP = [int(v) for v in os.environ.get("RTP_LANES", "0,1,2,3,4,5").split(",")]
 assert len(LANE_MAP) == NLANES and all(0 <= v < NLANES for v in LANE_MAP)
 
 
