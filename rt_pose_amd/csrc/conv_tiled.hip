@@ -34,6 +34,8 @@
 #define STAGE_BATCH 13
 #define STAGE_ROUNDS 1                   // 13 * 256 = 3328 >= 3264: all of a thread's loads in flight at once
 
+__device__ __attribute__((aligned(16))) bf16_t g_zero_line_c[8];  // zero-initialised: source of padding voxels
+
 struct TiledParams {
   const bf16_t* x; const bf16_t* w; const float* btab; const bf16_t* res; void* y;  // res: residual (AUX 1) or the statistics' second operand (AUX 2)
   float* stat_out;  // [N][workgroups per sample][Co][2] or null
@@ -123,15 +125,19 @@ __global__ __launch_bounds__(512, 2) void conv_tiled_kernel(TiledParams p) {
   const long vox_n = (long)n * p.D * p.H * p.W;
   // Staging descriptors (brick-independent, computed once): element offset of each of this thread's 13 sixteen-byte
   // items relative to the brick origin, its swizzled LDS slot, and six "on the low/high face of the halo" bits.
-  int s_rel[STAGE_BATCH], s_dst[STAGE_BATCH], s_flg[STAGE_BATCH];
+  // LDS-DMA staging (global_load_lds, 16 B per lane, no VGPRs for the data): a wave instruction's LDS destination is
+  // linear (wave base + lane * 16), so the chunk rotation is applied on the SOURCE side -- the lane whose slot holds
+  // rotated chunk cp of haloed voxel hv fetches logical chunk (cp - 2*(hx>>2)) & 3; out-of-volume voxels fetch a zero line.
+  // s_pk packs the six face bits (bits 0-5) and the haloed x index (8-13).
+  int s_rel[STAGE_BATCH], s_pk[STAGE_BATCH];
 #pragma unroll
   for (int k = 0; k < STAGE_BATCH; ++k) {
     const int i = ttid + k * 256;
-    const int ck = i & 3, hv = i >> 2;
+    const int cp = i & 3, hv = i >> 2;
     const int hx = hv % HX, hy = (hv / HX) % HY, hz = hv / (HX * HY);
-    s_dst[k] = (i < HALO_ITEMS) ? hv * 32 + swz(ck, hx) : -1;
+    const int ck = (cp - 2 * (hx >> 2)) & 3;
+    s_pk[k] = (hz == 0) | ((hz == HZ - 1) << 1) | ((hy == 0) << 2) | ((hy == HY - 1) << 3) | ((hx == 0) << 4) | (hx << 8);
     s_rel[k] = (((hz - 1) * p.H + (hy - 1)) * p.W + (hx - 1)) * 32 + ck * 8;
-    s_flg[k] = (hz == 0) | ((hz == HZ - 1) << 1) | ((hy == 0) << 2) | ((hy == HY - 1) << 3) | ((hx == 0) << 4) | (hx << 8);
   }
   const bf16_t* xn = p.x + vox_n * 32;
   // contiguous, balanced runs of bricks per team, z fastest: consecutive bricks share two of their four haloed z-planes,
@@ -139,8 +145,19 @@ __global__ __launch_bounds__(512, 2) void conv_tiled_kernel(TiledParams p) {
   const int t_begin = (int)((long)team_id * p.tiles_per_sample / p.teams_per_sample);
   const int my_tiles = (int)((long)(team_id + 1) * p.tiles_per_sample / p.teams_per_sample) - t_begin;
   int max_tiles = (p.tiles_per_sample + p.teams_per_sample - 1) / p.teams_per_sample;  // workgroup-uniform
-  const int nphase = 2 * max_tiles + 1;
+  const int nphase = 2 * max_tiles + 2;  // every compute phase is followed by a load phase of the same team (its epilogue runs there)
   int load_k = 0, comp_k = 0;
+  // State of the brick whose MFMAs are done but whose epilogue is still pending: the epilogue (bias, residual, ReLU,
+  // rounding, stores, statistics) runs at the start of the team's NEXT load phase, right after that phase's global loads
+  // have been issued -- it then overlaps both those loads' latency and the OTHER team's MFMA phase, instead of sitting
+  // between two MFMA phases with the matrix pipe idle (measured: MFMA loop alone 52 us, whole kernel 80 us).
+  constexpr int CH = 4 * NT;  // channels this lane owns: [c0, c0 + CH)
+  const int c0 = q * CH;
+  f32x4 acc[TY][NT];
+  bf16x8 pre_r8[TY];
+  bf16x4 pre_r4[TY];
+  bool pend = false;
+  int e_oz = 0, e_ox = 0, e_y0 = 0, e_kzx = 0;
   float st_p[4 * NT], st_q[4 * NT];  // running per-lane statistics of this lane's 4*NT channels (STAT)
 #pragma unroll
   for (int j = 0; j < 4 * NT; ++j) st_p[j] = st_q[j] = 0.f;
@@ -155,15 +172,89 @@ __global__ __launch_bounds__(512, 2) void conv_tiled_kernel(TiledParams p) {
         const int org = ((z0 * p.H + y0) * p.W + x0) * 32;
         const int tflg = (z0 == 0) | ((z0 + TZ == p.D) << 1) | ((y0 == 0) << 2) | ((y0 + TY == p.H) << 3) | ((x0 == 0) << 4);
         const int xlim = (p.W - x0 + 1) << 8;  // haloed x index >= this lies beyond the volume (W need not be a multiple of TX)
-        bf16x8 val[STAGE_BATCH];
 #pragma unroll
         for (int k = 0; k < STAGE_BATCH; ++k) {
-          val[k] = zero_bf16x8();
-          if (s_dst[k] >= 0 && !(s_flg[k] & tflg) && s_flg[k] < xlim) val[k] = ld_bf16x8(xn + org + s_rel[k]);
+          if (k * 256 + (ttid & ~63) < HALO_ITEMS) {  // wave-uniform: 3264 items = 51 waves' worth
+            const bool oob = (s_pk[k] & tflg & 0xff) || s_pk[k] >= xlim;
+            const bf16_t* src = oob ? g_zero_line_c : xn + org + s_rel[k];
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(xL + (k * 256 + (ttid & ~63)) * 8), 16, 0, 0);
+          }
         }
+      }
+      if (pend) {
+        pend = false;
+        // ---- epilogue of the previous brick: bias + residual + ReLU in fp32, one rounding, one 16-B store per lane and row
+        const int oz = e_oz, ox = e_ox, y0 = e_y0, kzx = e_kzx;
 #pragma unroll
-        for (int k = 0; k < STAGE_BATCH; ++k)
-          if (s_dst[k] >= 0) st_bf16x8(xL + s_dst[k], val[k]);
+        for (int t = 0; t < TY; ++t) {
+          const int oy = y0 + t;
+          const long vo = vox_n + ((long)oz * p.H + oy) * p.W + ox;
+          float ev[CH];
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ev[nt * 4 + j] = acc[t][nt][j];
+          if constexpr (HAS_BTAB) {
+            const float* bp = bL + (kzx + ((oy == 0) ? 3 : (oy == p.H - 1) ? 6 : 0)) * p.Co + c0;
+#pragma unroll
+            for (int k = 0; k < CH; k += 4) {
+              const f32x4 bb = *reinterpret_cast<const f32x4*>(bp + k);
+#pragma unroll
+              for (int j = 0; j < 4; ++j) ev[k + j] += bb[j];
+            }
+          }
+          float aux[CH];
+          if constexpr (NT == 2) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) aux[j] = bf2f(pre_r8[t][j]);
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) aux[j] = bf2f(pre_r4[t][j]);
+          }
+          if constexpr (AUX == 1) {
+#pragma unroll
+            for (int j = 0; j < CH; ++j) ev[j] += aux[j];
+          }
+          if (p.relu) {
+#pragma unroll
+            for (int j = 0; j < CH; ++j) ev[j] = ev[j] > 0.f ? ev[j] : 0.f;
+          }
+          if (p.y_fp32) {
+            float* yp = (float*)p.y + vo * p.y_cs + p.y_co + c0;
+#pragma unroll
+            for (int k = 0; k < CH; k += 4) *reinterpret_cast<f32x4*>(yp + k) = f32x4{ev[k], ev[k + 1], ev[k + 2], ev[k + 3]};
+          } else {
+            bf16_t* yp = (bf16_t*)p.y + vo * p.y_cs + p.y_co + c0;
+            if constexpr (NT == 2) {
+              bf16x8 o;
+#pragma unroll
+              for (int j = 0; j < 8; ++j) o[j] = f2bf(ev[j]);
+              st_bf16x8(yp, o);
+              if constexpr (STAT) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                  const float r = bf2f(o[j]);  // statistics of the stored (rounded) values, as a read-back pass would see
+                  st_p[j] += r;
+                  st_q[j] += r * (AUX == 2 ? aux[j] : r);
+                }
+              }
+            } else {
+              bf16x4 o;
+#pragma unroll
+              for (int j = 0; j < 4; ++j) o[j] = f2bf(ev[j]);
+              *reinterpret_cast<bf16x4*>(yp) = o;
+              if constexpr (STAT) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                  const float r = bf2f(o[j]);
+                  st_p[j] += r;
+                  st_q[j] += r * (AUX == 2 ? aux[j] : r);
+                }
+              }
+            }
+          }
+        }
       }
       ++load_k;
     } else if (comp_k < load_k && comp_k < my_tiles) {
@@ -173,7 +264,6 @@ __global__ __launch_bounds__(512, 2) void conv_tiled_kernel(TiledParams p) {
       const int tz = tile % p.tiles_z, tx = (tile / p.tiles_z) % p.tiles_x, ty = tile / (p.tiles_z * p.tiles_x);  // z fastest
       const int z0 = tz * TZ, y0 = ty * TY, x0 = tx * TX;
 
-      f32x4 acc[TY][NT];
 #pragma unroll
       for (int t = 0; t < TY; ++t)
 #pragma unroll
@@ -181,12 +271,8 @@ __global__ __launch_bounds__(512, 2) void conv_tiled_kernel(TiledParams p) {
 
       // The residual is fetched NOW, under the MFMA loop: loaded after it, its HBM latency sat on the critical path of
       // every brick (measured: epilogue 78 us of a 132 us launch).  The class bias comes from the LDS table.
-      constexpr int CH = 4 * NT;  // channels this lane owns: [c0, c0 + CH)
-      const int c0 = q * CH;
       const int oz = z0 + wz, ox = x0 + wx * 16 + v;
       const int kzx = ((oz == 0) ? 1 : (oz == p.D - 1) ? 2 : 0) * 9 + ((ox == 0) ? 1 : (ox == p.W - 1) ? 2 : 0);
-      bf16x8 pre_r8[TY];
-      bf16x4 pre_r4[TY];
 #pragma unroll
       for (int t = 0; t < TY; ++t) {
         const long vo = vox_n + ((long)oz * p.H + (y0 + t)) * p.W + ox;
@@ -250,77 +336,8 @@ __global__ __launch_bounds__(512, 2) void conv_tiled_kernel(TiledParams p) {
         }
       }
       if (p.dbg & 4) { __syncthreads(); continue; }
-
-      // ---- epilogue: bias + residual + ReLU in fp32, one rounding, one 16-B store per lane and row
-#pragma unroll
-      for (int t = 0; t < TY; ++t) {
-        const int oy = y0 + t;
-        const long vo = vox_n + ((long)oz * p.H + oy) * p.W + ox;
-        float val[CH];
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) val[nt * 4 + j] = acc[t][nt][j];
-        if constexpr (HAS_BTAB) {
-          const float* bp = bL + (kzx + ((oy == 0) ? 3 : (oy == p.H - 1) ? 6 : 0)) * p.Co + c0;
-#pragma unroll
-          for (int k = 0; k < CH; k += 4) {
-            const f32x4 bb = *reinterpret_cast<const f32x4*>(bp + k);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) val[k + j] += bb[j];
-          }
-        }
-        float aux[CH];
-        if constexpr (NT == 2) {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) aux[j] = bf2f(pre_r8[t][j]);
-        } else {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) aux[j] = bf2f(pre_r4[t][j]);
-        }
-        if constexpr (AUX == 1) {
-#pragma unroll
-          for (int j = 0; j < CH; ++j) val[j] += aux[j];
-        }
-        if (p.relu) {
-#pragma unroll
-          for (int j = 0; j < CH; ++j) val[j] = val[j] > 0.f ? val[j] : 0.f;
-        }
-        if (p.y_fp32) {
-          float* yp = (float*)p.y + vo * p.y_cs + p.y_co + c0;
-#pragma unroll
-          for (int k = 0; k < CH; k += 4) *reinterpret_cast<f32x4*>(yp + k) = f32x4{val[k], val[k + 1], val[k + 2], val[k + 3]};
-        } else {
-          bf16_t* yp = (bf16_t*)p.y + vo * p.y_cs + p.y_co + c0;
-          if constexpr (NT == 2) {
-            bf16x8 o;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = f2bf(val[j]);
-            st_bf16x8(yp, o);
-            if constexpr (STAT) {
-#pragma unroll
-              for (int j = 0; j < 8; ++j) {
-                const float r = bf2f(o[j]);  // statistics of the stored (rounded) values, as a read-back pass would see
-                st_p[j] += r;
-                st_q[j] += r * (AUX == 2 ? aux[j] : r);
-              }
-            }
-          } else {
-            bf16x4 o;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] = f2bf(val[j]);
-            *reinterpret_cast<bf16x4*>(yp) = o;
-            if constexpr (STAT) {
-#pragma unroll
-              for (int j = 0; j < 4; ++j) {
-                const float r = bf2f(o[j]);
-                st_p[j] += r;
-                st_q[j] += r * (AUX == 2 ? aux[j] : r);
-              }
-            }
-          }
-        }
-      }
+      pend = true;
+      e_oz = oz; e_ox = ox; e_y0 = y0; e_kzx = kzx;
     }
     __syncthreads();
   }
