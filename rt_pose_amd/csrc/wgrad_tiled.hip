@@ -241,7 +241,7 @@ static bool wg_tiled_applicable(const RtpConvGeom* g) {
 
 static int wg_tiled_wgs(const RtpConvGeom* g) {
   const int tiles = (g->di / TZ) * (g->hi / TY) * ((g->wi + TX - 1) / TX);
-  static const int total_wgs = getenv("RTP_TILED_WGS") ? atoi(getenv("RTP_TILED_WGS")) : 256;  // experiments: leave CUs to other streams
+  static const int total_wgs = getenv("RTP_WGRAD_TILED_WGS") ? atoi(getenv("RTP_WGRAD_TILED_WGS")) : 256;  // experiments: fewer slabs / CUs left to other streams
   int wgs = total_wgs / g->n;
   if (wgs < 1) wgs = 1;
   if (wgs > tiles) wgs = tiles;
