@@ -215,6 +215,37 @@ int rtp_decode(const float* logits, int hm_cpad, const float* reg, int reg_cpad,
                void* stream);
 int rtp_decode_scratch_floats(int n, int ncls);
 
+/* ---------------------------------------------------------------- C'. input pipeline --- */
+
+/* Raw radar cubes -> network input (det3d/datasets/cruw_pose/cruw_pose.py:167-194 get_cube / get_cube_phase, plus the
+ * channel-axis rule of det3d/datasets/pipelines/pose.py:163-170).
+ *   cube_f16  device fp16 [lead][zs][ys][xs]: `lead` = frames x leading channels (1, D, or 2*D for the phase cubes)
+ *   roi_zyx   HOST int[6] = inclusive index ranges (z0,z1,y0,y1,x0,x1) (CRUW_POSE_Dataset.consider_roi_cube)
+ *   normalise != 0: out = max(0, (x - norm_lo) / (norm_hi - norm_lo)) in fp32 (get_cube); 0: crop only (get_cube_phase)
+ *   out       device fp32 [lead][Z][Y][X] -- for a batch this IS the NCDHW network input */
+int rtp_cube_prep(const void* cube_f16, long lead, int zs, int ys, int xs, const int* roi_zyx, float norm_lo,
+                  float norm_hi, int normalise, float* out, void* stream);
+
+/* gaussian3D((2r+1,)*3, sigma=(2r+1)/6) of det3d/core/utils/center_utils.py:67-72 in float64, rounded to fp32, into HOST
+ * memory out_host[(2r+1)^3] (upload it once; it is the `table` of rtp_assign_labels). */
+int rtp_gaussian_table(int radius, float* out_host);
+
+/* CenterNet-style label assignment on the device (pipelines/pose.py:186-254 AssignLabelPose when one_hm == 0,
+ * :386-451 AssignLabelPose2 when one_hm != 0), one task.
+ *   poses   device fp64 [frames][max_in][15][3] (x,y,z metres), nposes device int [frames] (poses present per frame)
+ *   M = 15*max_poses slots (one_hm == 0: slot k = key-point k%15 of pose k/15, class = key-point) or max_poses slots
+ *       (one_hm != 0: slot k = pose k, centre = key-point 0, class 0)
+ *   hm      device fp32 [frames][15|1][fz][fy][fx]: max-splat of the gaussian table (radius r) at each in-range centre.
+ *           NOT memset here: `prev` (device int [frames][M][4], zero-initialised by the caller once) records the boxes
+ *           written by the previous call, which are cleared first.
+ *   anno    device fp32 [frames][M][3|45], ind/cat device int64 [frames][M], mask device uint8 [frames][M]
+ * A key-point whose voxel lies outside the map keeps its slot with ind = mask = cat = 0 (the reference's `continue`).
+ * The reference raises IndexError when 0 < poses present < max_poses (15-map variant); the host wrapper checks that. */
+int rtp_assign_labels(const double* poses, const int* nposes, int frames, int max_in, int max_poses, int one_hm,
+                      int radius, const double* range_min_zyx, const double* voxel_size_xyz,
+                      const int* out_size_factor_zyx, int fz, int fy, int fx, const float* table, float* hm, float* anno,
+                      long long* ind, unsigned char* mask, long long* cat, int* prev, void* stream);
+
 /* Global grad-norm partials and the fused clip + decoupled-weight-decay + Adam step over a flat fp32
  * parameter buffer (fastai_optim.py:154-172, hooks/optimizer.py:14-24, torch.optim.Adam).
  *   hyper (device fp32[10]) = {lr, beta1, beta2, eps, wd, max_norm, 1-beta1^t, 1-beta2^t, grad_scale, -}

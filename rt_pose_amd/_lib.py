@@ -77,6 +77,10 @@ PROTOTYPES = {
     "rtp_reg_loss": [_P, _I, _P, _P, _P, _P, _I, _I, _L, _I, _F, _P, _A, _P],
     "rtp_decode": [_P, _I, _P, _I, _I, _I, _I, _I, _I, _I, C.POINTER(_F), C.POINTER(_F), _P, _P, _P],
     "rtp_decode_scratch_floats": [_I, _I],
+    "rtp_cube_prep": [_P, _L, _I, _I, _I, C.POINTER(_I), _F, _F, _I, _P, _P],
+    "rtp_gaussian_table": [_I, C.POINTER(_F)],
+    "rtp_assign_labels": [_P, _P, _I, _I, _I, _I, _I, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_I), _I, _I, _I,
+                          _P, _P, _P, _P, _P, _P, _P, _P],
     "rtp_sqnorm": [_P, _L, _P, _P, _P],
     "rtp_sqnorm_blocks": [],
     "rtp_adam_step": [_P, _P, _P, _P, _L, _P, _P, _I, _P, _P],

@@ -123,6 +123,25 @@ class DataParallelTrainer:
         self.opt.run()
         self.step_idx += 1
 
+    # ------------------------------------------------------------------ raw-input feeding
+    def attach_input_pipeline(self, pipe):
+        """pipe: rt_pose_amd.input_pipeline.DeviceInputPipeline built on this trainer's engine."""
+        self.pipe = pipe
+        self._step_done = torch.cuda.Event()
+        self._fed = None
+
+    def feed_raw(self, cubes_f16, poses):
+        """Queue the NEXT batch from raw fp16 cubes + key-points: its H2D copy overlaps the step in flight, its two
+        preparation kernels run right after that step."""
+        self._fed = self.pipe.submit(cubes_f16, poses, after=self._step_done if self.step_idx > 0 else None)
+
+    def step_fed(self):
+        """One training step on the batch queued by feed_raw."""
+        with self._on_stream():
+            self.stream.wait_event(self._fed)
+            self._step()
+            self._step_done.record(self.stream)
+
     def losses(self):
         return self.engine.losses()
 

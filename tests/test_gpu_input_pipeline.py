@@ -1,0 +1,155 @@
+"""Device input pipeline (rt_pose_amd.input_pipeline -> csrc/input_pipe.hip) against the numpy oracle
+(oracle/input_pipeline_ref.py) and the vectors captured from the reference (tests/golden/input_pipeline_golden.npz).
+Integer / index results and the fp32 cube are bit-exact; heat-map values are exact (one float64 -> fp32 rounding of the
+same table); offsets are exact against the oracle (same float64 intermediate) and within 2e-5 of the captured vectors
+(numpy >= 2 evaluates the reference's expression in fp32)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import hrradarpose_ref as O
+from oracle import input_pipeline_ref as R
+from rt_pose_amd import configs
+from tests.golden.gen_golden_input import GRID_SIZE, ROI1, synth_cube_f16, synth_poses
+
+pytestmark = pytest.mark.gpu
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "input_pipeline_golden.npz"))
+RMIN = (ROI1["z"][0], ROI1["y"][0], ROI1["x"][0])
+
+
+def make_engine(name, batch, max_poses=1):
+    from rt_pose_amd.backend import HipBackend
+    from rt_pose_amd.engine import FlatParams, PoseEngine
+    be = HipBackend("cuda:0")
+    arch, fin, fout, fuse, heads, weight, cw = O.MODEL_CONFIGS[name]
+    shapes = O.param_shapes(arch, fin, fout, fout, heads)
+    flat = FlatParams(shapes, be.alloc)
+    flat.load_state_dict(O.seeded_state_dict(shapes, seed=1))
+    one_hm = heads["hm"] == 1
+    return PoseEngine(be, flat.values, arch, fuse, heads, weight, cw, batch, configs.NATIVE_DIMS, pgrads=flat.grads,
+                      max_objs=(max_poses if one_hm else 15 * max_poses))
+
+
+def check_labels(eng, frames_poses, max_poses, min_radius, one_hm):
+    hm = eng.tgt_hm.cpu().numpy()
+    for f, poses in enumerate(frames_poses):
+        r = R.assign_labels(poses, configs.NATIVE_DIMS, RMIN, GRID_SIZE, (1, 1, 1), max_poses, min_radius, one_hm=one_hm)
+        assert np.array_equal(hm[f], r["hm"]), "hm frame %d" % f
+        assert np.array_equal(eng.tgt_ind[f].cpu().numpy(), r["ind"])
+        assert np.array_equal(eng.tgt_mask[f].cpu().numpy(), r["mask"])
+        assert np.array_equal(eng.tgt_cat[f].cpu().numpy(), r["cat"])
+        assert np.array_equal(eng.tgt_pose[f].cpu().numpy(), r["anno_pose"]), "anno frame %d" % f
+
+
+def test_hr3d_cube_and_labels_three_batches():
+    from rt_pose_amd.input_pipeline import DeviceInputPipeline, roi_indices
+    assert roi_indices(ROI1) == G["roi_idx"].tolist()
+    b = 3
+    eng = make_engine("hr3d", b)
+    norm = (20000, 45000)
+    pipe = DeviceInputPipeline(eng, ROI1, GRID_SIZE, norm, "zyx_real", max_poses=1, min_radius=1)
+    for it in range(3):   # successive batches: the previous batch's boxes must be cleared, nothing else touched
+        cubes = np.stack([synth_cube_f16(100 + 10 * it + f) for f in range(b)])
+        poses = [synth_poses(200 + 10 * it + f, 1) for f in range(b)]
+        if it == 1:
+            poses[1] = []            # a frame without a pose
+        torch.cuda.current_stream().wait_event(pipe.submit(cubes, poses))
+        torch.cuda.synchronize()
+        x = eng.x_in.cpu().numpy()
+        for f in range(b):
+            assert np.array_equal(x[f], R.prep_cube(cubes[f], pipe.roi_idx, norm, False)), "cube frame %d" % f
+        check_labels(eng, poses, 1, 1, False)
+    # the captured reference vectors, through the device path
+    seed, nposes, max_poses, min_radius, ncls = [int(v) for v in G["lab_a15_cfg"]]
+    gp = G["lab_a15_poses"].tolist()
+    cube = synth_cube_f16(int(G["cube_zyx_seed"][0]))
+    torch.cuda.current_stream().wait_event(pipe.submit(np.stack([cube] * b), [gp] * b))
+    torch.cuda.synchronize()
+    t = eng.x_in[0].cpu().numpy()
+    assert np.array_equal(t.reshape(-1)[::997], G["cube_zyx_sample"])
+    hm = eng.tgt_hm[0].cpu().numpy()
+    nz = np.flatnonzero(hm)
+    assert np.array_equal(nz, G["lab_a15_hm_idx"]) and np.array_equal(hm.reshape(-1)[nz], G["lab_a15_hm_val"])
+    assert np.array_equal(eng.tgt_ind[0].cpu().numpy(), G["lab_a15_ind"])
+    assert np.array_equal(eng.tgt_mask[0].cpu().numpy(), G["lab_a15_mask"])
+    assert np.abs(eng.tgt_pose[0].cpu().numpy() - G["lab_a15_anno"]).max() <= 2e-5
+    # and the plan trains on what the pipeline wrote
+    eng.run_forward()
+    eng.run_loss_backward()
+    torch.cuda.synchronize()
+    assert np.isfinite(float(eng.losses()["loss"]))
+
+
+def test_two_poses_and_reference_error_behaviour():
+    from rt_pose_amd.input_pipeline import DeviceInputPipeline
+    eng = make_engine("hr3d", 2, max_poses=2)
+    pipe = DeviceInputPipeline(eng, ROI1, GRID_SIZE, (20000, 45000), "zyx_real", max_poses=2, min_radius=1)
+    cubes = np.stack([synth_cube_f16(7), synth_cube_f16(8)])
+    poses = [G["lab_a15_two_poses"].tolist(), []]
+    torch.cuda.current_stream().wait_event(pipe.submit(cubes, poses))
+    torch.cuda.synchronize()
+    check_labels(eng, poses, 2, 1, False)
+    hm = eng.tgt_hm[0].cpu().numpy()
+    nz = np.flatnonzero(hm)
+    assert np.array_equal(nz, G["lab_a15_two_hm_idx"]) and np.array_equal(hm.reshape(-1)[nz], G["lab_a15_two_hm_val"])
+    with pytest.raises(IndexError):   # one pose present, max_poses 2: the reference indexes past its key-point list
+        pipe.submit(cubes, [synth_poses(1, 1), []])
+
+
+def test_one_heat_map_doppler():
+    from rt_pose_amd.input_pipeline import DeviceInputPipeline
+    eng = make_engine("hr3d_one_hm_doppler", 1)
+    norm = (0, 10)
+    pipe = DeviceInputPipeline(eng, ROI1, GRID_SIZE, norm, "dzyx_real", max_poses=1, min_radius=2)
+    for it in range(2):
+        cube = (synth_cube_f16(50 + it, 32) / 4000.0).astype(np.float16)
+        poses = [synth_poses(60 + it, 1)]
+        torch.cuda.current_stream().wait_event(pipe.submit(cube[None], poses))
+        torch.cuda.synchronize()
+        assert np.array_equal(eng.x_in[0].cpu().numpy(), R.prep_cube(cube, pipe.roi_idx, norm, True))
+        check_labels(eng, poses, 1, 2, True)
+    gp = G["lab_a1_poses"].tolist()
+    torch.cuda.current_stream().wait_event(pipe.submit(cube[None], [gp]))
+    torch.cuda.synchronize()
+    hm = eng.tgt_hm[0].cpu().numpy()
+    nz = np.flatnonzero(hm)
+    assert np.array_equal(nz, G["lab_a1_hm_idx"]) and np.array_equal(hm.reshape(-1)[nz], G["lab_a1_hm_val"])
+    assert np.array_equal(eng.tgt_ind[0].cpu().numpy(), G["lab_a1_ind"])
+    assert np.abs(eng.tgt_pose[0].cpu().numpy() - G["lab_a1_anno"]).max() <= 2e-5
+
+
+def test_trainer_fed_from_raw_batches_matches_resident_inputs():
+    """Two steps fed through the pipeline (H2D beside the step in flight) produce the same losses as the same two batches
+    prepared by the oracle and loaded as resident tensors."""
+    from rt_pose_amd.input_pipeline import DeviceInputPipeline
+    from rt_pose_amd.trainer import DataParallelTrainer
+    b, norm = 2, (20000, 45000)
+    batches = [(np.stack([synth_cube_f16(300 + 7 * i + f) for f in range(b)]), [synth_poses(400 + 7 * i + f, 1) for f in range(b)])
+               for i in range(2)]
+    tr = DataParallelTrainer("hr3d", b, configs.NATIVE_DIMS, total_steps=100, use_graph=False)
+    tr.attach_input_pipeline(DeviceInputPipeline(tr.engine, ROI1, GRID_SIZE, norm, "zyx_real"))
+    got = []
+    tr.feed_raw(*batches[0])
+    for i in range(2):
+        tr.step_fed()
+        if i == 0:
+            tr.feed_raw(*batches[1])
+        torch.cuda.synchronize()
+        got.append(float(tr.losses()["loss"]))
+    ref = DataParallelTrainer("hr3d", b, configs.NATIVE_DIMS, total_steps=100, use_graph=False)
+    roi_idx = G["roi_idx"].tolist()
+    want = []
+    for cubes, poses in batches:
+        labs = [R.assign_labels(p, configs.NATIVE_DIMS, RMIN, GRID_SIZE) for p in poses]
+        ex = {"rdr": {"rdr_tensor": torch.from_numpy(np.stack([R.prep_cube(c, roi_idx, norm, False) for c in cubes])),
+                      "hm": [torch.from_numpy(np.stack([l["hm"] for l in labs]))],
+                      "ind": [torch.from_numpy(np.stack([l["ind"] for l in labs]))],
+                      "mask": [torch.from_numpy(np.stack([l["mask"] for l in labs]))],
+                      "cat": [torch.from_numpy(np.stack([l["cat"] for l in labs]))],
+                      "anno_pose": [torch.from_numpy(np.stack([l["anno_pose"] for l in labs]))]}}
+        ref.step(ex)
+        torch.cuda.synchronize()
+        want.append(float(ref.losses()["loss"]))
+    assert np.allclose(got, want, rtol=1e-4), (got, want)
