@@ -1,0 +1,41 @@
+"""Evaluation plumbing after the path: detections dict, prediction JSON layout, per-sequence MPJPE
+(tools/test.py:41-63, 194-216; det3d/datasets/cruw_pose/cruw_pose.py:277-311; eval_util.py:5-10)."""
+import json
+
+import numpy as np
+
+from rt_pose_amd import evaluate as E
+
+
+def test_prediction_file_layout_and_mpjpe(tmp_path):
+    rng = np.random.default_rng(0)
+    gt, dets = {}, {}
+    for seq, frames in (("7", ["10", "9", "100"]), ("3", ["2"])):
+        gt[seq] = {}
+        for fr in frames:
+            pose = rng.normal(0, 1, (15, 3))
+            gt[seq][fr] = [{"pose": pose.tolist()}]
+            pred = pose + rng.normal(0, 0.05, (15, 3)) + np.array([0.3, 0, 0])   # constant shift: vanishes in the root-relative error
+            out = [{"keypoints": [(i, *pred[i].tolist(), 0.9) for i in range(15)], "metadata": {"seq": seq, "frame": fr, "rdr_frame": fr}}]
+            E.collect_detections(out, dets)
+    assert set(dets) == {"7/10/10", "7/9/9", "7/100/100", "3/2/2"} and "metadata" not in dets["3/2/2"]
+    names = {"7": "2024_b", "3": "2024_a"}
+    path = E.save_pred(dets, str(tmp_path), "epoch_5", "test", names)
+    assert path.endswith("epoch_5/test_prediction.json")
+    js = json.load(open(path))
+    assert list(js) == ["2024_a", "2024_b"] and list(js["2024_b"]) == ["9_9", "10_10", "100_100"]     # name order, int(frame) order
+    res = E.evaluate(dets, gt, names)
+    # restated inline: per sequence mean over frames (mm), mean over joints; then mean over sequences
+    per_seq = {}
+    for seq in gt:
+        rel, ab = [], []
+        for fr in gt[seq]:
+            g = np.array(gt[seq][fr][0]["pose"]); k = np.array([p[1:4] for p in dets["%s/%s/%s" % (seq, fr, fr)]["keypoints"]])
+            ab.append(np.linalg.norm(k - g, axis=-1))
+            rel.append(np.linalg.norm((k - k[:1]) - (g - g[:1]), axis=-1))
+        per_seq[names[seq]] = (np.mean(np.mean(rel, 0) * 1000), np.mean(np.mean(ab, 0) * 1000))
+    assert np.isclose(res["seq_results"]["2024_b"]["MPJPE"], per_seq["2024_b"][0])
+    assert np.isclose(res["results"]["MPJPE"], np.mean([v[0] for v in per_seq.values()]))
+    assert np.isclose(res["results"]["ABS_MPJPE"], np.mean([v[1] for v in per_seq.values()]))
+    assert res["results"]["ABS_MPJPE"] > res["results"]["MPJPE"] + 100      # the 0.3 m shift only shows in the absolute error
+    assert res["seq_results"]["ALL"] == res["results"] and "PJPE_14" in res["results"]
