@@ -53,7 +53,10 @@ class HipBackend:
     def lane_streams(self, n):
         cur = torch.cuda.current_stream(self.device)
         if len(getattr(self, "_lanes", ())) < n - 1:
-            self._lanes = [torch.cuda.Stream(self.device) for _ in range(n - 1)]
+            import os
+            # stream priority per side lane (0 = default, -1 = high); RTP_LANE_PRIORITIES="p1,p2,..." for experiments
+            pr = [int(v) for v in os.environ.get("RTP_LANE_PRIORITIES", "").split(",") if v.strip() != ""]
+            self._lanes = [torch.cuda.Stream(self.device, priority=(pr[i] if i < len(pr) else 0)) for i in range(n - 1)]
         streams = [cur] + self._lanes[:n - 1]
         return streams, [C.c_void_p(st.cuda_stream) for st in streams]
 

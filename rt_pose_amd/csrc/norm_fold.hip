@@ -129,6 +129,22 @@ __device__ __forceinline__ void fold_fwd_body(const FoldParams& p, int n, int by
   const int co0 = by * cos;
   const bool norm = p.stats != nullptr;
   const int L = p.ci_real * ntap;
+  // Statistics partials [n][nsplit][C][2] are requested FIRST so that their latency overlaps the weight staging below:
+  // thread t owns channel t % C and every (256/C)-th partial (C a power of two: shifts, no division; the loads of one
+  // wave are consecutive float2s), keeping an fp32 running pair per thread.
+  const bool do_norm = norm && p.wf && !(p.dbg & 1);
+  const bool pow2 = (p.ci_real & (p.ci_real - 1)) == 0 && p.ci_real <= 256;
+  float ps0 = 0.f, ps1 = 0.f;
+  float2 pre4[4] = {make_float2(0.f, 0.f), make_float2(0.f, 0.f), make_float2(0.f, 0.f), make_float2(0.f, 0.f)};
+  float gam_r = 0.f, bet_r = 0.f;   // this thread's channel's affine parameters, also requested up front
+  if (do_norm && pow2 && tid < p.ci_real) { gam_r = p.gamma[tid]; bet_r = p.beta[tid]; }
+  if (do_norm && pow2) {   // the first four partials of this thread: loads only, consumed after the weight staging
+    const int C = p.ci_real, c = tid & (C - 1), sh = __ffs(C) - 1, s_first = tid >> sh, s_step = 256 >> sh;
+    const float2* q = reinterpret_cast<const float2*>(p.stats) + ((long)n * p.nsplit) * C + c;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (s_first + k * s_step < p.nsplit) pre4[k] = q[(long)(s_first + k * s_step) * C];
+  }
   for (int col = 0; col < cos && !(p.dbg & 8); ++col) {
     const int co = co0 + col;
     const float* row = p.w + ((long)co * p.ci_total + p.ci_off) * ntap;
@@ -145,8 +161,48 @@ __device__ __forceinline__ void fold_fwd_body(const FoldParams& p, int n, int by
     }
   }
   for (int c = tid; c < p.ci_pad; c += 256) { scale[c] = (c < p.ci_real && !norm) ? 1.f : 0.f; shift[c] = 0.f; }
+  if (do_norm && pow2) {
+    {
+      const int C = p.ci_real, c = tid & (C - 1), sh = __ffs(C) - 1, s_first = tid >> sh, s_step = 256 >> sh;
+      const float2* q = reinterpret_cast<const float2*>(p.stats) + ((long)n * p.nsplit) * C + c;
+      ps0 = (pre4[0].x + pre4[1].x) + (pre4[2].x + pre4[3].x);
+      ps1 = (pre4[0].y + pre4[1].y) + (pre4[2].y + pre4[3].y);
+      for (int s_ = s_first + 4 * s_step; s_ < p.nsplit; s_ += s_step) { const float2 a0 = q[(long)s_ * C]; ps0 += a0.x; ps1 += a0.y; }
+    }
+    // fold: the 256/C threads of a channel and the cg channels of a group, in fixed order, in double
+    __shared__ float2 part[256];
+    part[tid] = make_float2(ps0, ps1);
+    __syncthreads();
+    const int C = p.ci_real, cg = C / p.groups, np = 256 / C;
+    __shared__ float mr_l[64][2];
+    if (tid < p.groups) {
+      double s0 = 0.0, s1 = 0.0;
+      for (int k = 0; k < np; ++k)
+        for (int j = 0; j < cg; ++j) { const float2 v = part[k * C + tid * cg + j]; s0 += v.x; s1 += v.y; }
+      // sums and the E[x^2] - E[x]^2 cancellation in double; the reciprocal square root in fp32 (as ATen's group_norm):
+      // a double divide + sqrt on this one thread was ~1 us of every fold launch
+      const double inv = 1.0 / ((double)cg * p.di * p.hi * p.wi);
+      const double mean = s0 * inv;
+      double var = s1 * inv - mean * mean;
+      if (var < 0.0) var = 0.0;
+      const float rstd = 1.0f / sqrtf((float)var + p.eps);
+      mr_l[tid][0] = (float)mean;
+      mr_l[tid][1] = rstd;
+      if (p.mr && by == 0) {
+        p.mr[((long)n * p.groups + tid) * 2] = (float)mean;
+        p.mr[((long)n * p.groups + tid) * 2 + 1] = rstd;
+      }
+    }
+    __syncthreads();
+    if (tid < C) {
+      const float mean = mr_l[tid / cg][0], sc = mr_l[tid / cg][1] * gam_r;
+      scale[tid] = sc;
+      shift[tid] = bet_r - mean * sc;
+    }
+    __syncthreads();
+  } else {
   __syncthreads();
-  if (norm && p.wf && !(p.dbg & 1)) {
+  if (do_norm) {
     const int cg = p.ci_real / p.groups;
     const double cnt = (double)cg * p.di * p.hi * p.wi;
     // one wave-sized team per group: lanes split the (channel, split) partials, then a shuffle reduction
@@ -177,6 +233,7 @@ __device__ __forceinline__ void fold_fwd_body(const FoldParams& p, int n, int by
     }
     __syncthreads();
   }
+  }
   if (p.wd && n == 0) {  // the un-folded weights, transposed for the data-gradient conv: wd[tap][ci_pad][cok]
     for (int i = tid; i < ntap * p.ci_pad; i += 256) {
       const int ci = i % p.ci_pad, tap = i / p.ci_pad;
@@ -204,18 +261,27 @@ __device__ __forceinline__ void fold_fwd_body(const FoldParams& p, int n, int by
   }
   }
   if (!p.btab || (p.dbg & 4)) return;
-  // T[col][tap] = sum_ci w*shift : two lanes per dot product (halves of the input channels), joined by one shuffle
+  // T[col][tap] = sum_ci w*shift : two lanes per dot product (halves of the input channels), four independent partial
+  // sums per lane (the LDS reads of a serial chain each waited their full latency), joined by one shuffle
   {
     const int i = tid >> 1, half = tid & 1;
     for (int i0 = 0; i0 < cos * ntap; i0 += 128) {
       const int ii = i0 + i;
-      float acc = 0.f;
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
       if (norm && ii < cos * ntap) {
         const int tap = ii % ntap, col = ii / ntap;
         const int h0 = half * (p.ci_real >> 1), h1 = half ? p.ci_real : (p.ci_real >> 1);
         const float* wr = wS + col * L + tap;
-        for (int ci = h0; ci < h1; ++ci) acc += wr[ci * ntap] * shift[ci];
+        int ci = h0;
+        for (; ci + 3 < h1; ci += 4) {
+          a0 += wr[ci * ntap] * shift[ci];
+          a1 += wr[(ci + 1) * ntap] * shift[ci + 1];
+          a2 += wr[(ci + 2) * ntap] * shift[ci + 2];
+          a3 += wr[(ci + 3) * ntap] * shift[ci + 3];
+        }
+        for (; ci < h1; ++ci) a0 += wr[ci * ntap] * shift[ci];
       }
+      float acc = (a0 + a1) + (a2 + a3);
       acc += __shfl_xor(acc, 1, 64);
       if (ii < cos * ntap && half == 0) T[ii] = acc;
     }
@@ -230,16 +296,21 @@ __device__ __forceinline__ void fold_fwd_body(const FoldParams& p, int n, int by
     if (norm) {
       const int ks = p.ks;
       int mz = 0, my = 0, mx = 0;
-      for (int k = 0; k < ks; ++k) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        if (k >= ks) break;
         mz |= (int)tap_inb_1d(k, cls & 1, (cls >> 1) & 1, p.dov, p.di, p.stride, p.pad) << k;
         my |= (int)tap_inb_1d(k, (cls >> 2) & 1, (cls >> 3) & 1, p.ho, p.hi, p.stride, p.pad) << k;
         mx |= (int)tap_inb_1d(k, (cls >> 4) & 1, (cls >> 5) & 1, p.wo, p.wi, p.stride, p.pad) << k;
       }
       const float* Tc = T + col * ntap;
-      for (int kz = 0; kz < ks; ++kz)
-        for (int ky = 0; ky < ks; ++ky)
-          for (int kx = 0; kx < ks; ++kx)
-            if ((mz >> kz) & (my >> ky) & (mx >> kx) & 1) acc += Tc[(kz * ks + ky) * ks + kx];
+      if (ks == 3) {   // straight-line: 27 predicated adds
+#pragma unroll
+        for (int t = 0; t < 27; ++t)
+          acc += (((mz >> (t / 9)) & (my >> ((t / 3) % 3)) & (mx >> (t % 3))) & 1) ? Tc[t] : 0.f;
+      } else {
+        acc += ((mz & my & mx) & 1) ? Tc[0] : 0.f;
+      }
     }
     if (co < p.co_pad) bt[cls * p.co_pad + co] = acc;
   }
