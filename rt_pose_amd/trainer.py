@@ -10,6 +10,7 @@ reference (centernet_loss.py:22,48-54), so nothing else crosses GPUs.  The refer
 all-reduce (core/utils/dist_utils.py:45-57) is not reproduced.
 """
 import math
+import os
 from collections import OrderedDict
 
 import torch
@@ -68,11 +69,17 @@ class DataParallelTrainer:
         self.pg = process_group
         self.use_graph = use_graph and self.be.name == "hip"
         self._graph = None
+        if self.use_graph and "RTP_LANES" not in os.environ:
+            # hipStreamEndCapture crashes (ROCm 7.2) on a capture that forks into all six lane streams; three streams
+            # capture and replay fine, so graph mode folds the lanes: {full}, {mid, low, lowest}, {weight gradients}
+            from .lanes import LanePlan
+            gmap = [0, 1, 1, 2, 2, 1]
+            self.engine.fwd_plan = LanePlan(self.be, self.engine.fwd, gmap)
+            self.engine.bwd_plan = LanePlan(self.be, self.engine.bwd, gmap)
         # All work of a step goes to ONE explicit (non-default) HIP stream: a graph launched on the legacy NULL stream
         # was observed NOT to be ordered against the optimiser kernels queued behind it on ROCm 7.x.
         # High priority: this stream carries the full-resolution chain, the critical path of the lane plan (side lanes
         # keep the default priority, so their small kernels fill in around it instead of delaying it).
-        import os
         prio = int(os.environ.get("RTP_MAIN_PRIORITY", "-1"))
         self.stream = torch.cuda.Stream(self.be.device, priority=prio) if self.be.name == "hip" else None
 
