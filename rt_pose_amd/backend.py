@@ -87,10 +87,21 @@ class HipBackend:
         keep = (w, wd)
         return lambda s: check(fn(*args, s), "rtp_pack_dgrad_w") or keep and None
 
-    def conv(self, x, wf, per_sample, btab, res, y, geom, relu, transposed, y_fp32, stats=None):
+    def conv_tiled_ok(self, x, geom, transposed):
+        return bool(self.lib.rtp_conv_tiled_ok(_act(x), _geom(geom), int(transposed)))
+
+    def conv(self, x, wf, per_sample, btab, res, y, geom, relu, transposed, y_fp32, stats=None, acc=None):
         """stats = (stat_x | None, out [n, S, cout, 2]) with S = conv_stats_nsplit(...) > 0: the conv also emits the
-        per-channel statistics of y (rtp_conv_igemm_stats)."""
+        per-channel statistics of y (rtp_conv_igemm_stats).
+        acc = (fp32 [n, vox, acc_cs], acc_cs): partial result of earlier input-channel slices (rtp_conv_igemm_acc)."""
         g = _geom(geom)
+        if acc is not None:
+            assert stats is None and not transposed
+            fn = self.lib.rtp_conv_igemm_acc
+            args = (_act(x), _ptr(wf), int(per_sample), _ptr(btab), _act(res), _act(y), g, int(relu), int(y_fp32),
+                    _ptr(acc[0]), int(acc[1]))
+            keep = (x, wf, btab, res, y, acc)
+            return lambda s: check(fn(*args, s), "rtp_conv_igemm_acc") or keep and None
         args = (_act(x), _ptr(wf), int(per_sample), _ptr(btab), _act(res), _act(y), g, int(relu), int(transposed),
                 int(y_fp32))
         keep = (x, wf, btab, res, y, stats)

@@ -304,7 +304,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
 
 int rtp_conv_tiled_try(const RtpAct* x, const void* wf, int w_per_sample, const float* btab, const RtpAct* res,
                        const RtpAct* y, const RtpConvGeom* g, int relu, int transposed, int y_fp32,
-                       const RtpAct* stat_x, float* stat_out, hipStream_t s);
+                       const RtpAct* stat_x, float* stat_out, const float* acc32, int acc_cs, hipStream_t s);
 int rtp_conv_tiled_stat_slots(const RtpAct* x, const RtpConvGeom* g, int transposed);
 
 // tile shape of the generic kernel for a problem: (cout tiles per wave, voxel tiles per wave, blocks per sample)
@@ -316,6 +316,12 @@ static void igemm_shape(int N, int Vo, int Co, int* nt, int* mt, int* bps) {
   const bool small = force_mt ? force_mt == 1 : (long)N * Vo * (Co / (16 * *nt)) < 256L * 256 * 2;
   *mt = small ? 1 : 4;
   *bps = rtp_div_up(Vo, 4 * *mt * 16);
+}
+
+int rtp_conv_tiled_stat_slots(const RtpAct* x, const RtpConvGeom* g, int transposed);
+/* 1 if this (slice) geometry runs on the LDS-tiled kernel -- the only one that accepts rtp_conv_igemm_acc. */
+extern "C" int rtp_conv_tiled_ok(const RtpAct* x, const RtpConvGeom* g, int transposed) {
+  return (x && g && rtp_conv_tiled_stat_slots(x, g, transposed) > 0) ? 1 : 0;
 }
 
 extern "C" int rtp_conv_stats_nsplit(const RtpAct* x, const RtpConvGeom* g, int transposed) {
@@ -333,7 +339,14 @@ extern "C" int rtp_conv_stats_nsplit(const RtpAct* x, const RtpConvGeom* g, int 
 
 static int conv_dispatch(const RtpAct* x, const void* wf, int w_per_sample, const float* btab, const RtpAct* res,
                          const RtpAct* y, const RtpConvGeom* g, int relu, int transposed, int y_fp32,
-                         const RtpAct* stat_x, float* stat_out, void* stream);
+                         const RtpAct* stat_x, float* stat_out, void* stream, const float* acc32 = nullptr, int acc_cs = 0);
+
+extern "C" int rtp_conv_igemm_acc(const RtpAct* x, const void* wf, int w_per_sample, const float* btab, const RtpAct* res,
+                                  const RtpAct* y, const RtpConvGeom* g, int relu, int y_fp32, const float* acc32,
+                                  int acc_cs, void* stream) {
+  if (!acc32) return RTP_ERR_SHAPE;
+  return conv_dispatch(x, wf, w_per_sample, btab, res, y, g, relu, 0, y_fp32, nullptr, nullptr, stream, acc32, acc_cs);
+}
 
 extern "C" int rtp_conv_igemm(const RtpAct* x, const void* wf, int w_per_sample, const float* btab, const RtpAct* res,
                               const RtpAct* y, const RtpConvGeom* g, int relu, int transposed, int y_fp32,
@@ -351,7 +364,7 @@ extern "C" int rtp_conv_igemm_stats(const RtpAct* x, const void* wf, int w_per_s
 
 static int conv_dispatch(const RtpAct* x, const void* wf, int w_per_sample, const float* btab, const RtpAct* res,
                          const RtpAct* y, const RtpConvGeom* g, int relu, int transposed, int y_fp32,
-                         const RtpAct* stat_x, float* stat_out, void* stream) {
+                         const RtpAct* stat_x, float* stat_out, void* stream, const float* acc32, int acc_cs) {
   if (!x || !y || !wf || !g) return RTP_ERR_SHAPE;
   if (g->ks != 1 && g->ks != 3) return RTP_ERR_UNSUPPORTED;
   if (g->stride != 1 && g->stride != 2) return RTP_ERR_UNSUPPORTED;
@@ -359,9 +372,10 @@ static int conv_dispatch(const RtpAct* x, const void* wf, int w_per_sample, cons
   if (res && ((res->co % 4) || (res->cs % 4))) return RTP_ERR_ALIGN;
   {
     const int rc = rtp_conv_tiled_try(x, wf, w_per_sample, btab, res, y, g, relu, transposed, y_fp32, stat_x, stat_out,
-                                      (hipStream_t)stream);
+                                      acc32, acc_cs, (hipStream_t)stream);
     if (rc <= 0) return rc;  // handled (or failed) by the LDS-tiled kernel
   }
+  if (acc32) return RTP_ERR_UNSUPPORTED;  // partial-sum input: only the LDS-tiled kernel (rtp_conv_tiled_ok)
   ConvParams p;
   p.x = (const bf16_t*)x->ptr;
   p.w = (const bf16_t*)wf;

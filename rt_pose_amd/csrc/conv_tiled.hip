@@ -43,6 +43,8 @@ struct TiledParams {
   int y_cs, y_co, r_cs, r_co;
   int relu, y_fp32, flip, w_per_sample;
   int tiles_y, tiles_x, tiles_z, tiles_per_sample, teams_per_sample;
+  int x_cs, x_co;          // x may be a 32-channel slice of a wider tensor (channel stride / first channel)
+  const float* acc32; int a_cs;  // optional fp32 partial result [N][vox][a_cs] added before bias / ReLU (input-channel split)
   int dbg;  // timing experiments only (RTP_TILED_DBG): bit0 = skip the MFMA loop, bit1 = skip staging, bit2 = skip epilogue
 };
 
@@ -137,9 +139,9 @@ __global__ __launch_bounds__(512, 2) void conv_tiled_kernel(TiledParams p) {
     const int hx = hv % HX, hy = (hv / HX) % HY, hz = hv / (HX * HY);
     const int ck = (cp - 2 * (hx >> 2)) & 3;
     s_pk[k] = (hz == 0) | ((hz == HZ - 1) << 1) | ((hy == 0) << 2) | ((hy == HY - 1) << 3) | ((hx == 0) << 4) | (hx << 8);
-    s_rel[k] = (((hz - 1) * p.H + (hy - 1)) * p.W + (hx - 1)) * 32 + ck * 8;
+    s_rel[k] = (((hz - 1) * p.H + (hy - 1)) * p.W + (hx - 1)) * p.x_cs + ck * 8;
   }
-  const bf16_t* xn = p.x + vox_n * 32;
+  const bf16_t* xn = p.x + vox_n * p.x_cs + p.x_co;
   // contiguous, balanced runs of bricks per team, z fastest: consecutive bricks share two of their four haloed z-planes,
   // which the second read then finds in this XCD's L2 (PMC: 1.5x over-fetch with the interleaved deal)
   const int t_begin = (int)((long)team_id * p.tiles_per_sample / p.teams_per_sample);
@@ -169,7 +171,7 @@ __global__ __launch_bounds__(512, 2) void conv_tiled_kernel(TiledParams p) {
         const int tile = t_begin + load_k;
         const int tz = tile % p.tiles_z, tx = (tile / p.tiles_z) % p.tiles_x, ty = tile / (p.tiles_z * p.tiles_x);  // z fastest
         const int z0 = tz * TZ, y0 = ty * TY, x0 = tx * TX;
-        const int org = ((z0 * p.H + y0) * p.W + x0) * 32;
+        const int org = ((z0 * p.H + y0) * p.W + x0) * p.x_cs;
         const int tflg = (z0 == 0) | ((z0 + TZ == p.D) << 1) | ((y0 == 0) << 2) | ((y0 + TY == p.H) << 3) | ((x0 == 0) << 4);
         const int xlim = (p.W - x0 + 1) << 8;  // haloed x index >= this lies beyond the volume (W need not be a multiple of TX)
 #pragma unroll
@@ -195,6 +197,15 @@ __global__ __launch_bounds__(512, 2) void conv_tiled_kernel(TiledParams p) {
           for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int j = 0; j < 4; ++j) ev[nt * 4 + j] = acc[t][nt][j];
+          if (p.acc32) {   // kernel-uniform
+            const float* ap = p.acc32 + vo * p.a_cs + c0;
+#pragma unroll
+            for (int k = 0; k < CH; k += 4) {
+              const f32x4 aa = *reinterpret_cast<const f32x4*>(ap + k);
+#pragma unroll
+              for (int j = 0; j < 4; ++j) ev[k + j] += aa[j];
+            }
+          }
           if constexpr (HAS_BTAB) {
             const float* bp = bL + (kzx + ((oy == 0) ? 3 : (oy == p.H - 1) ? 6 : 0)) * p.Co + c0;
 #pragma unroll
@@ -378,7 +389,7 @@ static bool tiled_geometry_ok(const RtpAct* x, const RtpConvGeom* g, int transpo
   const int Co = transposed ? g->ci : g->co;
   if (Ci != 32 || (Co != 16 && Co != 32)) return false;
   if (g->di % TZ || g->hi % TY || g->wi % 16 || g->di < 2 || g->hi < 2) return false;
-  if (x->cs != 32 || x->co != 0) return false;
+  if (x->cs % 32 || x->co % 8) return false;   // a 32-channel slice of a wider channels-last tensor is fine
   *Co_out = Co;
   return true;
 }
@@ -402,14 +413,16 @@ int rtp_conv_tiled_stat_slots(const RtpAct* x, const RtpConvGeom* g, int transpo
 // generic gather kernel), or a negative error.
 int rtp_conv_tiled_try(const RtpAct* x, const void* wf, int w_per_sample, const float* btab, const RtpAct* res,
                        const RtpAct* y, const RtpConvGeom* g, int relu, int transposed, int y_fp32,
-                       const RtpAct* stat_x, float* stat_out, hipStream_t s) {
+                       const RtpAct* stat_x, float* stat_out, const float* acc32, int acc_cs, hipStream_t s) {
   int Co;
   if (!tiled_geometry_ok(x, g, transposed, &Co)) return 1;
+  if (acc32 && (acc_cs % 4 || acc_cs < Co)) return RTP_ERR_ALIGN;
   if (stat_out && (y_fp32 || (stat_x && res))) return RTP_ERR_UNSUPPORTED;
   if (stat_x) res = stat_x;  // rides in the residual's prefetch slot
   TiledParams p;
   p.stat_out = stat_out;
   p.x = (const bf16_t*)x->ptr; p.w = (const bf16_t*)wf; p.btab = btab;
+  p.x_cs = x->cs; p.x_co = x->co; p.acc32 = acc32; p.a_cs = acc_cs;
   p.res = res ? (const bf16_t*)res->ptr : nullptr; p.y = y->ptr;
   p.N = g->n; p.D = g->di; p.H = g->hi; p.W = g->wi; p.Co = Co;
   p.y_cs = y->cs; p.y_co = y->co; p.r_cs = res ? res->cs : 0; p.r_co = res ? res->co : 0;

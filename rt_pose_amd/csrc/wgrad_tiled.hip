@@ -29,6 +29,7 @@
 struct WgTiledParams {
   const bf16_t* gy; const bf16_t* x; float* gp;
   int N, D, H, W, g_cs, g_co;
+  int x_cs, x_co;   // x may be a 32-channel slice of a wider tensor
   int tiles_y, tiles_x, tiles_z, tiles_per_sample, wgs_per_sample;
   int dbg;  // timing experiments only (RTP_TILED_DBG): bit0 = consumers skip the MFMA work, bit1 = producers skip the DMA
 };
@@ -131,7 +132,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_tiled_kernel(WgTiledParams p) {
         const int cp = i & 3, hv = i >> 2;
         const int hx = hv % HX, hy = (hv / HX) % HY, hz = hv / (HX * HY);
         const int ck = (cp - (hx >> 2)) & 3;
-        rel[it] = (((hz - 1) * p.H + (hy - 1)) * p.W + (hx - 1)) * 32 + ck * 8;
+        rel[it] = (((hz - 1) * p.H + (hy - 1)) * p.W + (hx - 1)) * p.x_cs + ck * 8;
         flg[it] = (hz == 0) | ((hz == HZ - 1) << 1) | ((hy == 0) << 2) | ((hy == HY - 1) << 3) | ((hx == 0) << 4) | (hx << 8);
       } else if (i < X_ITEMS + G_ITEMS) {
         const int j = i - X_ITEMS;
@@ -142,7 +143,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_tiled_kernel(WgTiledParams p) {
         flg[it] = (bx + 1) << 8;  // same x-limit test as the halo items (halo index = brick index + 1)
       }
     }
-    const bf16_t* xn = p.x + vox_n * 32;
+    const bf16_t* xn = p.x + vox_n * p.x_cs + p.x_co;
     const bf16_t* gn = p.gy + vox_n * p.g_cs + p.g_co;
     for (int k = 0; k <= my_tiles; ++k) {
       if (k < my_tiles) {
@@ -158,7 +159,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_tiled_kernel(WgTiledParams p) {
           if (!(p.dbg & 2) && it * 256 + (ttid & ~63) < X_ITEMS + G_ITEMS) {  // wave-uniform: region sizes are multiples of 64 items
             const bool is_x = it * 256 + (ttid & ~63) < X_ITEMS;  // wave-uniform as well (3264 = 51 * 64)
             const bool oob = (flg[it] & tflg & 0xff) || flg[it] >= xlim;
-            const bf16_t* src = oob ? g_zero_line : (is_x ? xn + org * 32 + rel[it] : gn + (long)org * p.g_cs + rel[it]);
+            const bf16_t* src = oob ? g_zero_line : (is_x ? xn + (long)org * p.x_cs + rel[it] : gn + (long)org * p.g_cs + rel[it]);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(xL + (it * 256 + (ttid & ~63)) * 8), 16, 0, 0);
           }
@@ -254,9 +255,10 @@ extern "C" int rtp_wgrad_nsplit(const RtpConvGeom* g) { return (g && wg_tiled_ap
 
 int rtp_wgrad_tiled_try(const RtpAct* gy, const RtpAct* x, const RtpConvGeom* g, int nsplit, float* gp, hipStream_t s) {
   if (!wg_tiled_applicable(g)) return 1;
-  if (x->cs != 32 || x->co != 0 || nsplit != wg_tiled_wgs(g)) return 1;
+  if (x->cs % 32 || x->co % 8 || nsplit != wg_tiled_wgs(g)) return 1;   // x may be a 32-channel slice of a wider tensor
   WgTiledParams p;
   p.gy = (const bf16_t*)gy->ptr; p.x = (const bf16_t*)x->ptr; p.gp = gp;
+  p.x_cs = x->cs; p.x_co = x->co;
   p.N = g->n; p.D = g->di; p.H = g->hi; p.W = g->wi; p.g_cs = gy->cs; p.g_co = gy->co;
   p.tiles_y = p.H / TY; p.tiles_x = (p.W + TX - 1) / TX; p.tiles_z = p.D / TZ;
   p.tiles_per_sample = (p.D / TZ) * p.tiles_y * p.tiles_x;

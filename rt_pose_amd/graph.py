@@ -199,6 +199,19 @@ class Graph:
         pad = ks // 2
         do, ho, wo = [(s + 2 * pad - ks) // stride + 1 for s in x.dims]
         co_pad = pad_to(co_real, 16)
+        # A wide 3x3x3 conv without GroupNorm (the head towers of the 128/256-channel configs, center_head.py:86-93) runs as
+        # 32-channel input slices on the LDS-tiled kernel when its geometry allows (SplitConvOp)
+        if (gn is None and ks == 3 and stride == 1 and residual is None and not out_fp32 and ci_real > 32 and ci_real % 32 == 0
+                and x.c == ci_real and x.co == 0 and not w_ci_total and co_pad in (16, 32) and co_real % 16 == 0
+                and hasattr(self.be, "conv_tiled_ok")):
+            gs = Geom(self.n, x.d, x.h, x.w, do, ho, wo, 32, co_pad, ks, stride, pad, ci_real, 0)
+            if self.be.conv_tiled_ok(View(x.buf, x.n, x.d, x.h, x.w, x.cs, 0, 32), gs, False):
+                y = self.act(name, co_real, (do, ho, wo), c=co_real, relu=relu)
+                op = SplitConvOp(self, name, x, y, gs, wname, bname, relu, ci_real, co_real)
+                y.producer = op
+                self.ops.append(op)
+                op.emit_forward()
+                return y
         geom = Geom(self.n, x.d, x.h, x.w, do, ho, wo, pad_to(ci_real, 32), co_pad, ks, stride, pad,
                     w_ci_total, w_ci_off)
         assert x.c >= geom.ci, (name, x.c, geom.ci)
@@ -268,7 +281,7 @@ class Graph:
     def build_backward(self):
         assert self.train
         for op in reversed(self.ops):
-            gy = self.finalize_grad(op.y, isinstance(op, ConvOp) and bool(op.gn or op.bname))
+            gy = self.finalize_grad(op.y, isinstance(op, (ConvOp, SplitConvOp)) and bool(op.gn or op.bname))
             if gy is None:
                 continue
             op.emit_backward(gy)
@@ -437,6 +450,95 @@ class ConvOp:
         g.tail_b.append(("wgrad_fold", gp, S, csum, self.mr, g.params[self.gn[0]] if self.gn else None,
                          g.params[self.gn[1]] if self.gn else None, self.groups, ge, self.ci_real,
                          self.co_real, g.pgrad[self.wname], g.pgrad[self.bname] if self.bname else None, 0))
+
+
+class SplitConvOp:
+    """Conv3d(Cin = 32*K, Cout in {16, 32}, 3x3x3, bias) [+ ReLU] as K input-channel slices on the LDS-tiled kernels.
+    Forward: slice k adds the fp32 partial sum of the slices before it (in place, one fp32 buffer); the last slice adds
+    the bias, applies the ReLU and writes bf16.  Backward: K independent data-gradient launches, each writing its
+    32-channel slice of the input gradient, and K weight-gradient launches over the matching slices of x."""
+
+    def __init__(self, g, name, x, y, gs, wname, bname, relu, ci_real, co_real):
+        self.g, self.name, self.x, self.y, self.gs = g, name, x, y, gs
+        self.wname, self.bname, self.relu, self.ci_real, self.co_real = wname, bname, relu, ci_real, co_real
+        self.gn = None
+        self.K = ci_real // 32
+
+    def slice_geom(self, k):
+        s = self.gs
+        return Geom(s.n, s.di, s.hi, s.wi, s.do, s.ho, s.wo, 32, s.co, s.ks, s.stride, s.pad, self.ci_real, 32 * k)
+
+    def x_slice(self, k):
+        x = self.x
+        return View(x.buf, x.n, x.d, x.h, x.w, x.cs, 32 * k, 32)
+
+    def emit_forward(self):
+        g, be, gs = self.g, self.g.be, self.gs
+        w = g.param(self.wname)
+        bias = g.param(self.bname) if self.bname else None
+        ntap = gs.ks ** 3
+        need_dgrad = g.train and self.x.needs_grad
+        self.wf, self.wd, self.btab = [], [], None
+        lane = g.lane_of(self.y)
+        acc = be.alloc((g.n, self.y.vox, gs.co), "f32")
+        accv = View(acc.view(g.n, self.y.d, self.y.h, self.y.w, gs.co), g.n, self.y.d, self.y.h, self.y.w, gs.co, 0, gs.co)
+        for k in range(self.K):
+            last = k == self.K - 1
+            gk = self.slice_geom(k)
+            wf = be.alloc((1, ntap, gs.co, 32), "bf16")
+            wd = be.alloc((ntap, 32, pad_to(gs.co, 32)), "bf16") if need_dgrad else None
+            bt = be.alloc((1, 64, gs.co), "f32") if (last and bias is not None) else None
+            self.wf.append(wf)
+            self.wd.append(wd)
+            if bt is not None:
+                self.btab = bt
+            g.head.append(("fold_fwd", w, bias if bt is not None else None, None, None, None, 0, 1, GN_EPS, gk, 32,
+                           self.co_real, wf, bt, None, wd))
+            g.emit_fwd(be.conv(self.x_slice(k), wf, False, bt, None, self.y if last else accv, gk, self.relu and last, False,
+                               not last, None, (acc, gs.co) if k > 0 else None),
+                       lane, [self.x, wf, bt, acc if k > 0 else None], [self.y if last else acc], "conv:%s.%d" % (self.name, k))
+        self.alg_flops = 2 * g.n * gs.do * gs.ho * gs.wo * self.co_real * self.ci_real * ntap
+        g.flops["conv_fwd"] += self.alg_flops
+        g.flops["conv_tiled"] += self.alg_flops
+        g.alg_bytes["conv_tiled"] += 2 * g.n * (self.x.vox * self.ci_real + self.y.vox * self.y.c)
+
+    def emit_backward(self, gy: View):
+        g, be, gs, x = self.g, self.g.be, self.gs, self.x
+        co32 = pad_to(gs.co, 32)
+        assert gy.c >= co32, (self.name, gy.c, co32)
+        lane = g.lane_of(self.y)
+        if x.needs_grad:
+            dxb = be.alloc((g.n, x.d, x.h, x.w, self.ci_real), "bf16")
+            for k in range(self.K):
+                dk = View(dxb, g.n, x.d, x.h, x.w, self.ci_real, 32 * k, 32)
+                g.emit_bwd(be.conv(gy, self.wd[k], False, None, None, dk, self.slice_geom(k), False, True, False), lane,
+                           [gy, self.wd[k]], [dxb], "dgrad:%s.%d" % (self.name, k))
+            x.contribs.append((View(dxb, g.n, x.d, x.h, x.w, self.ci_real, 0, self.ci_real), None))
+            g.flops["conv_dgrad"] += self.alg_flops
+            g.flops["conv_tiled"] += self.alg_flops
+            g.alg_bytes["conv_tiled"] += 2 * g.n * (gy.vox * co32 + x.vox * self.ci_real)
+        wl = g.wg_lane_of(gy)
+        csum = None
+        if self.bname:
+            csum = be.alloc((g.n, 64, gy.c), "f32")
+            if self.y.grad_cls is not None and self.y.grad is gy:
+                cs_split, cs_scratch = self.y.grad_cls
+            else:
+                cs_split = cls_split(gy.d, gy.h)
+                cs_scratch = be.alloc((g.n, cs_split, 64, gy.c), "f32")
+                g.emit_bwd(be.class_sums(gy, cs_split, cs_scratch, None), wl, [gy], [cs_scratch], "cls:" + self.name)
+            g.tail_a.append(("class_reduce", cs_scratch, cs_split, g.n, gy.c, csum))
+        for k in range(self.K):
+            gk = self.slice_geom(k)
+            S = be.wgrad_nsplit(gk) or wgrad_split(gy.vox)
+            gp = be.alloc((g.n, S, gs.ks ** 3, co32, 32), "f32")
+            g.emit_bwd(be.wgrad(gy, self.x_slice(k), gk, S, gp), wl, [gy, x], [gp], "wgrad:%s.%d" % (self.name, k))
+            first = k == 0 and self.bname
+            g.tail_b.append(("wgrad_fold", gp, S, csum if first else None, None, None, None, 1, gk, 32, self.co_real,
+                             g.pgrad[self.wname], g.pgrad[self.bname] if first else None, 0))
+            g.alg_bytes["wgrad_tiled"] += 2 * g.n * (gy.vox * co32 + x.vox * 32) + 4 * g.n * S * gs.ks ** 3 * co32 * 32
+        g.flops["wgrad"] += self.alg_flops
+        g.flops["wgrad_tiled"] += self.alg_flops
 
 
 class FuseOp:

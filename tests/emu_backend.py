@@ -152,13 +152,21 @@ class EmuBackend:
         ci = (g.co + 31) // 32 * 32 if transposed else g.ci
         co = g.ci if transposed else g.co
         ok = (g.ks == 3 and g.stride == 1 and ci == 32 and co in (16, 32) and g.di % 2 == 0 and g.hi % 4 == 0
-              and g.wi % 16 == 0 and g.di >= 2 and x.cs == 32 and x.co == 0)
+              and g.wi % 16 == 0 and g.di >= 2 and x.cs % 32 == 0 and x.co % 8 == 0)
         if ok:
             return 2
         co_k = g.ci if transposed else g.co
         return 3 if co_k % 16 == 0 else 0   # the generic kernel: one partial per block (any count works for the plan)
 
-    def conv(self, x, wf, per_sample, btab, res, y, geom, relu, transposed, y_fp32, stats=None):
+    def conv_tiled_ok(self, x, geom, transposed):
+        """Mirror of the LDS-tiled kernel's geometry predicate (x may be a 32-channel slice of a wider tensor)."""
+        g = geom
+        ci = (g.co + 31) // 32 * 32 if transposed else g.ci
+        co = g.ci if transposed else g.co
+        return bool(g.ks == 3 and g.stride == 1 and ci == 32 and co in (16, 32) and g.di % 2 == 0 and g.hi % 4 == 0
+                    and g.wi % 16 == 0 and g.di >= 2 and x.cs % 32 == 0 and x.co % 8 == 0)
+
+    def conv(self, x, wf, per_sample, btab, res, y, geom, relu, transposed, y_fp32, stats=None, acc=None):
         def run(s):
             g = geom
             k = g.ks
@@ -170,6 +178,8 @@ class EmuBackend:
                     wn = wf[n if per_sample else 0].float().reshape(k, k, k, co, ci).permute(3, 4, 0, 1, 2)
                     outs.append(F.conv3d(xin[n:n + 1], wn, None, g.stride, g.pad))
                 out = _ndhwc(torch.cat(outs))
+                if acc is not None:   # fp32 partial result of the input-channel slices before this one
+                    out = out + acc[0].view(g.n, g.do, g.ho, g.wo, acc[1])[..., :out.shape[-1]]
                 if btab is not None:
                     cls = _classes(g.do, g.ho, g.wo)
                     out = out + torch.stack([btab[n if per_sample else 0][cls] for n in range(g.n)])

@@ -293,6 +293,50 @@ def test_gn_bwd_coeffs_and_class_sums(hip):
         check(out, F32 * 5, "class_sums %r" % (dims,))
 
 
+def test_split_conv_slices_on_the_tiled_kernels(hip):
+    """A 128-channel 3x3x3 conv as four 32-channel input slices (graph.SplitConvOp): forward with the fp32 partial-sum
+    chain (rtp_conv_igemm_acc), data gradient into channel slices of one buffer, weight gradient over slices of x --
+    each against the emulation, and the forward against one plain conv over all 128 channels."""
+    n, d, h, w, ci, co = 2, 4, 8, 32, 128, 32
+    xp, xc, xg = views(hip, rnd((n, d, h, w, ci), 301, relu=True), n, d, h, w)
+    w32 = rnd((co, ci, 3, 3, 3), 302, torch.float32, 0.05)
+    bias = rnd((co,), 303, torch.float32)
+    yp, yc, yg = views(hip, torch.zeros(n, d, h, w, co, dtype=torch.bfloat16), n, d, h, w)
+    acc = Pair(hip, torch.zeros(n, d * h * w, co))
+    accv_c = View(acc.c.view(n, d, h, w, co), n, d, h, w, co, 0, co)
+    accv_g = View(acc.g.view(n, d, h, w, co), n, d, h, w, co, 0, co)
+    for k in range(4):
+        geom = Geom(n, d, h, w, d, h, w, 32, co, 3, 1, 1, ci, 32 * k)
+        sl_c, sl_g = View(xc.buf, n, d, h, w, ci, 32 * k, 32), View(xg.buf, n, d, h, w, ci, 32 * k, 32)
+        assert hip.conv_tiled_ok(sl_g, geom, False) and EMU.conv_tiled_ok(sl_c, geom, False)
+        wf = Pair(hip, w32[:, 32 * k:32 * k + 32].permute(2, 3, 4, 0, 1).reshape(1, 27, co, 32).contiguous().to(torch.bfloat16))
+        last = k == 3
+        bt = Pair(hip, bias.view(1, 1, co).expand(1, 64, co).contiguous()) if last else None
+        a_c, a_g = ((acc.c, co), (acc.g, co)) if k else (None, None)
+        run(hip, EMU.conv(sl_c, wf.c, False, bt.c if last else None, None, yc if last else accv_c, geom, last, False, not last, None, a_c),
+            hip.conv(sl_g, wf.g, False, bt.g if last else None, None, yg if last else accv_g, geom, last, False, not last, None, a_g))
+        if not last:
+            check(acc, F32 * 5, "partial sum after slice %d" % k)
+    check(yp, BF, "split conv forward")
+    ref = torch.relu(torch.nn.functional.conv3d(xc.buf.float().permute(0, 4, 1, 2, 3), w32.to(torch.bfloat16).float(), bias, 1, 1))
+    assert rel_err(yp.sync_back().float().permute(0, 4, 1, 2, 3), ref) < BF
+    # backward: data gradient slices + weight gradient over x slices
+    gp_, gc, gg = views(hip, rnd((n, d, h, w, 32), 304), n, d, h, w)
+    dxp, _, _ = views(hip, torch.zeros(n, d, h, w, ci, dtype=torch.bfloat16), n, d, h, w)
+    for k in range(4):
+        geom = Geom(n, d, h, w, d, h, w, 32, co, 3, 1, 1, ci, 32 * k)
+        wd = Pair(hip, w32[:, 32 * k:32 * k + 32].permute(2, 3, 4, 1, 0).reshape(27, 32, co).contiguous().to(torch.bfloat16))
+        dk_c, dk_g = View(dxp.c, n, d, h, w, ci, 32 * k, 32), View(dxp.g, n, d, h, w, ci, 32 * k, 32)
+        run(hip, EMU.conv(gc, wd.c, False, None, None, dk_c, geom, False, True, False), hip.conv(gg, wd.g, False, None, None, dk_g, geom, False, True, False))
+        S = hip.wgrad_nsplit(geom)
+        assert S > 0
+        gpk = Pair(hip, torch.zeros(n, S, 27, 32, 32))
+        sl_c, sl_g = View(xc.buf, n, d, h, w, ci, 32 * k, 32), View(xg.buf, n, d, h, w, ci, 32 * k, 32)
+        run(hip, EMU.wgrad(gc, sl_c, geom, S, gpk.c), hip.wgrad(gg, sl_g, geom, S, gpk.g))
+        assert rel_err(gpk.sync_back().sum(1), gpk.c.sum(1)) < F32 * 5, "wgrad slice %d" % k
+    check(dxp, BF, "split conv data gradient")
+
+
 def test_deferred_tail_batches(hip):
     """rtp_tail_*: several independent items per launch equal the single-item entry points' emulation, including slab
     counts that take the 8-deep unrolled loops (nsplit 37) and every supported channel width."""
