@@ -97,13 +97,15 @@ int rtp_conv_igemm_stats(const RtpAct* x, const void* wf, int w_per_sample, cons
                          const RtpAct* stat_x, float* stat_out, void* stream);
 int rtp_conv_stats_nsplit(const RtpAct* x, const RtpConvGeom* g, int transposed);
 
-/* Input-channel split of a wide conv (Cin = 64 / 128 / 256 head towers, center_head.py:86-93): each 32-channel slice of x
- * (an RtpAct with cs = Cin, co = 32*k) is one conv on the LDS-tiled kernel; slice k > 0 adds the fp32 partial result of the
- * slices before it (acc32: dense fp32 [n][vox][acc_cs], written by the previous slice with y_fp32 = 1) before bias / ReLU.
- * Forward only; geometries for which rtp_conv_tiled_ok() returns 0 are RTP_ERR_UNSUPPORTED. */
+/* Contraction split of a wide conv (head towers, center_head.py:86-93): each 32-channel slice of the contracted tensor
+ * (an RtpAct with cs = total channels, co = 32*k) is one conv on the LDS-tiled kernel; slice k > 0 adds the fp32 partial
+ * result of the slices before it (acc32: dense fp32 [n][vox][acc_cs], written by the previous slice with y_fp32 = 1)
+ * before bias / ReLU.  Forward (Cin = 64/128/256 split) and transposed (data gradient of a Cout = 48 conv: the contraction
+ * over the output-side gradient's channels is split); geometries for which rtp_conv_tiled_ok() returns 0 are
+ * RTP_ERR_UNSUPPORTED. */
 int rtp_conv_igemm_acc(const RtpAct* x, const void* wf, int w_per_sample, const float* btab, const RtpAct* res,
-                       const RtpAct* y, const RtpConvGeom* g, int relu, int y_fp32, const float* acc32, int acc_cs,
-                       void* stream);
+                       const RtpAct* y, const RtpConvGeom* g, int relu, int transposed, int y_fp32, const float* acc32,
+                       int acc_cs, void* stream);
 int rtp_conv_tiled_ok(const RtpAct* x, const RtpConvGeom* g, int transposed);
 
 /* Weight-gradient correlation: gp[n][s][tap][co32][ci_pad] (fp32 partial slabs, s = voxel split) =

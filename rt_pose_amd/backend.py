@@ -96,10 +96,10 @@ class HipBackend:
         acc = (fp32 [n, vox, acc_cs], acc_cs): partial result of earlier input-channel slices (rtp_conv_igemm_acc)."""
         g = _geom(geom)
         if acc is not None:
-            assert stats is None and not transposed
+            assert stats is None
             fn = self.lib.rtp_conv_igemm_acc
-            args = (_act(x), _ptr(wf), int(per_sample), _ptr(btab), _act(res), _act(y), g, int(relu), int(y_fp32),
-                    _ptr(acc[0]), int(acc[1]))
+            args = (_act(x), _ptr(wf), int(per_sample), _ptr(btab), _act(res), _act(y), g, int(relu), int(transposed),
+                    int(y_fp32), _ptr(acc[0]), int(acc[1]))
             keep = (x, wf, btab, res, y, acc)
             return lambda s: check(fn(*args, s), "rtp_conv_igemm_acc") or keep and None
         args = (_act(x), _ptr(wf), int(per_sample), _ptr(btab), _act(res), _act(y), g, int(relu), int(transposed),

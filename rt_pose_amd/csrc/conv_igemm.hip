@@ -342,10 +342,10 @@ static int conv_dispatch(const RtpAct* x, const void* wf, int w_per_sample, cons
                          const RtpAct* stat_x, float* stat_out, void* stream, const float* acc32 = nullptr, int acc_cs = 0);
 
 extern "C" int rtp_conv_igemm_acc(const RtpAct* x, const void* wf, int w_per_sample, const float* btab, const RtpAct* res,
-                                  const RtpAct* y, const RtpConvGeom* g, int relu, int y_fp32, const float* acc32,
-                                  int acc_cs, void* stream) {
+                                  const RtpAct* y, const RtpConvGeom* g, int relu, int transposed, int y_fp32,
+                                  const float* acc32, int acc_cs, void* stream) {
   if (!acc32) return RTP_ERR_SHAPE;
-  return conv_dispatch(x, wf, w_per_sample, btab, res, y, g, relu, 0, y_fp32, nullptr, nullptr, stream, acc32, acc_cs);
+  return conv_dispatch(x, wf, w_per_sample, btab, res, y, g, relu, transposed, y_fp32, nullptr, nullptr, stream, acc32, acc_cs);
 }
 
 extern "C" int rtp_conv_igemm(const RtpAct* x, const void* wf, int w_per_sample, const float* btab, const RtpAct* res,

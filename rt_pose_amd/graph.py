@@ -201,6 +201,18 @@ class Graph:
         co_pad = pad_to(co_real, 16)
         # A wide 3x3x3 conv without GroupNorm (the head towers of the 128/256-channel configs, center_head.py:86-93) runs as
         # 32-channel input slices on the LDS-tiled kernel when its geometry allows (SplitConvOp)
+        # ... and a 32 -> 45 tower output (the 45-offset regression head of the one-heat-map configs) as output-channel
+        # slices 32 + 16 (CoSplitConvOp)
+        if (gn is None and ks == 3 and stride == 1 and residual is None and out_fp32 and ci_real == 32 and x.c == 32
+                and x.co == 0 and co_pad == 48 and bname and not w_ci_total and hasattr(self.be, "conv_tiled_ok")):
+            gs = Geom(self.n, x.d, x.h, x.w, do, ho, wo, 32, 32, ks, stride, pad)
+            if self.be.conv_tiled_ok(x, gs, False):
+                y = self.act(name, co_real, (do, ho, wo), c=co_pad, dtype="f32", relu=relu)
+                op = CoSplitConvOp(self, name, x, y, wname, bname, relu, co_real)
+                y.producer = op
+                self.ops.append(op)
+                op.emit_forward()
+                return y
         if (gn is None and ks == 3 and stride == 1 and residual is None and not out_fp32 and ci_real > 32 and ci_real % 32 == 0
                 and x.c == ci_real and x.co == 0 and not w_ci_total and co_pad in (16, 32) and co_real % 16 == 0
                 and hasattr(self.be, "conv_tiled_ok")):
@@ -281,7 +293,7 @@ class Graph:
     def build_backward(self):
         assert self.train
         for op in reversed(self.ops):
-            gy = self.finalize_grad(op.y, isinstance(op, (ConvOp, SplitConvOp)) and bool(op.gn or op.bname))
+            gy = self.finalize_grad(op.y, isinstance(op, (ConvOp, SplitConvOp, CoSplitConvOp)) and bool(op.gn or op.bname))
             if gy is None:
                 continue
             op.emit_backward(gy)
@@ -537,6 +549,78 @@ class SplitConvOp:
             g.tail_b.append(("wgrad_fold", gp, S, csum if first else None, None, None, None, 1, gk, 32, self.co_real,
                              g.pgrad[self.wname], g.pgrad[self.bname] if first else None, 0))
             g.alg_bytes["wgrad_tiled"] += 2 * g.n * (gy.vox * co32 + x.vox * 32) + 4 * g.n * S * gs.ks ** 3 * co32 * 32
+        g.flops["wgrad"] += self.alg_flops
+        g.flops["wgrad_tiled"] += self.alg_flops
+
+
+class CoSplitConvOp:
+    """Conv3d(32, Cout in (32, 48], 3x3x3, bias) with fp32 output as two output-channel slices (32 + the rest, padded to
+    16) on the LDS-tiled kernels.  Forward and weight gradient are independent per slice (parameter / gradient views);
+    the data gradient contracts over the output channels, so its two launches chain through an fp32 partial sum."""
+
+    def __init__(self, g, name, x, y, wname, bname, relu, co_real):
+        self.g, self.name, self.x, self.y = g, name, x, y
+        self.wname, self.bname, self.relu, self.co_real = wname, bname, relu, co_real
+        self.gn = None
+        self.slices = [(0, 32), (32, co_real - 32)]
+
+    def geom(self, c):
+        x, y = self.x, self.y
+        return Geom(self.g.n, x.d, x.h, x.w, y.d, y.h, y.w, 32, pad_to(c, 16), 3, 1, 1)
+
+    def emit_forward(self):
+        g, be, x, y = self.g, self.g.be, self.x, self.y
+        w, bias = g.param(self.wname), g.param(self.bname)
+        need_dgrad = g.train and x.needs_grad
+        lane = g.lane_of(y)
+        self.wd = []
+        for k, (a, c) in enumerate(self.slices):
+            gk = self.geom(c)
+            wf = be.alloc((1, 27, gk.co, 32), "bf16")
+            bt = be.alloc((1, 64, gk.co), "f32")
+            wd = be.alloc((27, 32, 32), "bf16") if need_dgrad else None
+            self.wd.append(wd)
+            g.head.append(("fold_fwd", w[a:a + c], bias[a:a + c], None, None, None, 0, 1, GN_EPS, gk, 32, c, wf, bt, None, wd))
+            yk = View(y.buf, y.n, y.d, y.h, y.w, y.cs, a, gk.co)
+            g.emit_fwd(be.conv(x, wf, False, bt, None, yk, gk, self.relu, False, True), lane, [x, wf, bt], [y],
+                       "conv:%s.co%d" % (self.name, k))
+        self.alg_flops = 2 * g.n * y.vox * self.co_real * 32 * 27
+        g.flops["conv_fwd"] += self.alg_flops
+        g.flops["conv_tiled"] += self.alg_flops
+        g.alg_bytes["conv_tiled"] += 2 * g.n * x.vox * 32 + 4 * g.n * y.vox * y.c
+
+    def emit_backward(self, gy: View):
+        g, be, x, y = self.g, self.g.be, self.x, self.y
+        assert gy.c >= 64, (self.name, gy.c)
+        lane = g.lane_of(y)
+        gys = [View(gy.buf, gy.n, gy.d, gy.h, gy.w, gy.cs, gy.co + 32 * k, 32) for k in range(2)]
+        if x.needs_grad:
+            acc = be.alloc((g.n, x.vox, 32), "f32")
+            accv = View(acc.view(g.n, x.d, x.h, x.w, 32), g.n, x.d, x.h, x.w, 32, 0, 32)
+            dxb = be.alloc((g.n, x.d, x.h, x.w, 32), "bf16")
+            dxh = View(dxb, g.n, x.d, x.h, x.w, 32, 0, 32)
+            g.emit_bwd(be.conv(gys[0], self.wd[0], False, None, None, accv, self.geom(self.slices[0][1]), False, True, True),
+                       lane, [gy, self.wd[0]], [acc], "dgrad:%s.co0" % self.name)
+            g.emit_bwd(be.conv(gys[1], self.wd[1], False, None, None, dxh, self.geom(self.slices[1][1]), False, True, False,
+                               None, (acc, 32)), lane, [gy, self.wd[1], acc], [dxb], "dgrad:%s.co1" % self.name)
+            x.contribs.append((dxh, None))
+            g.flops["conv_dgrad"] += self.alg_flops
+            g.flops["conv_tiled"] += self.alg_flops
+            g.alg_bytes["conv_tiled"] += 2 * g.n * (gy.vox * 64 + x.vox * 32)
+        wl = g.wg_lane_of(gy)
+        for k, (a, c) in enumerate(self.slices):
+            gk = self.geom(c)
+            S = be.wgrad_nsplit(gk) or wgrad_split(gy.vox)
+            gp = be.alloc((g.n, S, 27, 32, 32), "f32")
+            g.emit_bwd(be.wgrad(gys[k], x, gk, S, gp), wl, [gy, x], [gp], "wgrad:%s.co%d" % (self.name, k))
+            cs_split = cls_split(gy.d, gy.h)
+            cs_scratch = be.alloc((g.n, cs_split, 64, 32), "f32")
+            csum = be.alloc((g.n, 64, 32), "f32")
+            g.emit_bwd(be.class_sums(gys[k], cs_split, cs_scratch, None), wl, [gy], [cs_scratch], "cls:%s.co%d" % (self.name, k))
+            g.tail_a.append(("class_reduce", cs_scratch, cs_split, g.n, 32, csum))
+            g.tail_b.append(("wgrad_fold", gp, S, csum, None, None, None, 1, gk, 32, c, g.pgrad[self.wname][a:a + c],
+                             g.pgrad[self.bname][a:a + c], 0))
+            g.alg_bytes["wgrad_tiled"] += 2 * g.n * (gy.vox * 32 + x.vox * 32) + 4 * g.n * S * 27 * 32 * 32
         g.flops["wgrad"] += self.alg_flops
         g.flops["wgrad_tiled"] += self.alg_flops
 

@@ -190,6 +190,8 @@ class EmuBackend:
                 op = [i - ((o - 1) * g.stride - 2 * g.pad + k) for i, o in
                       zip((g.di, g.hi, g.wi), (g.do, g.ho, g.wo))]
                 out = _ndhwc(F.conv_transpose3d(xin, wt, None, g.stride, g.pad, output_padding=tuple(op)))
+                if acc is not None:
+                    out = out + acc[0].view(g.n, g.di, g.hi, g.wi, acc[1])[..., :out.shape[-1]]
             if res is not None:
                 out = out + _sl(res)[..., :out.shape[-1]]
             if relu:
