@@ -134,7 +134,13 @@ def main():
 
     if world == 1 and not args.no_roofline:
         be = tr.be
-        fams = {"conv_tiled (fwd+dgrad, 32ch 3x3x3)": (_lib.FAM_CONV_TILED, g.flops["conv_tiled"], g.alg_bytes["conv_tiled"]),
+        # the LDS-tiled conv is timed in two groups: its dominant geometry (32 -> 32 channels, full resolution) and the rest
+        # (level-1 tensors, 16-channel head outputs); graph.py's conv_tiled totals include both
+        rest_f = g.flops["conv_tiled"] - g.flops["conv_tiled_full"]
+        rest_b = g.alg_bytes["conv_tiled"] - g.alg_bytes["conv_tiled_full"]
+        fams = {"conv_tiled_kernel<2,...> 32->32ch 3x3x3 at full resolution (fwd+dgrad)":
+                    (_lib.FAM_CONV_TILED_FULL, g.flops["conv_tiled_full"], g.alg_bytes["conv_tiled_full"]),
+                "conv_tiled other geometries (level 1, 16-channel outputs)": (_lib.FAM_CONV_TILED, rest_f, rest_b),
                 "conv_igemm generic (fwd+dgrad)": (_lib.FAM_CONV, g.flops["conv_generic"], g.alg_bytes["conv_generic"]),
                 "wgrad_tiled (32ch 3x3x3)": (_lib.FAM_WGRAD_TILED, g.flops["wgrad_tiled"], g.alg_bytes["wgrad_tiled"]),
                 "wgrad generic": (_lib.FAM_WGRAD, g.flops["wgrad_generic"], g.alg_bytes["wgrad_generic"])}
@@ -162,7 +168,8 @@ def main():
                 best = (kname, ms, tf, gbps)
         # HBM bytes per launch of the dominant kernel from the PMC passes in profiles/r01_pmc_tiled.md (FETCH_SIZE doubled
         # per MI355X_MICROARCH.md, + WRITE_SIZE), B=8 full-resolution layer with residual; not re-measured in this process.
-        traffic = {"conv_tiled (fwd+dgrad, 32ch 3x3x3)": 279e6, "wgrad_tiled (32ch 3x3x3)": 208e6}.get(best[0])
+        traffic = {"conv_tiled_kernel<2,...> 32->32ch 3x3x3 at full resolution (fwd+dgrad)": 280e6,
+                   "wgrad_tiled (32ch 3x3x3)": 204e6}.get(best[0])
         # The 32-channel 3x3x3 layers sit at the ridge (288-431 algorithmic flop/B against 2500/8 = 312): the MFMA bound is
         # the one SURVEY 8d names; the same launches against the HBM roof are reported beside it.
         line["roofline"] = {"bound": "mfma", "kernel": best[0], "achieved": round(best[2], 2), "peak": PEAK_BF16_TFLOPS,

@@ -12,7 +12,8 @@ enum RtpFamily {
   RTP_FAM_OPTIM = 6,
   RTP_FAM_DCN = 7,
   RTP_FAM_WGRAD_TILED = 8,
-  RTP_FAM_COUNT = 9
+  RTP_FAM_CONV_TILED_FULL = 9,  // the LDS-tiled conv at its dominant geometry: 32 -> 32 channels, >= 2^20 output voxels per launch
+  RTP_FAM_COUNT = 10
 };
 
 void rtp_prof_begin(int fam, hipStream_t s);

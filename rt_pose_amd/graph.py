@@ -123,9 +123,9 @@ class Graph:
         self.full_vox = None       # voxels of the first (full-resolution) activation: lanes are assigned by resolution
         # algorithmic FLOPs (2*MACs of real channels) per kernel family, per replay of the lists
         self.flops = {"conv_fwd": 0, "conv_dgrad": 0, "wgrad": 0, "conv_tiled": 0, "conv_generic": 0,
-                      "wgrad_tiled": 0, "wgrad_generic": 0}
+                      "wgrad_tiled": 0, "wgrad_generic": 0, "conv_tiled_full": 0}
         # algorithmic HBM bytes (fused minimum, SURVEY 8d: every operand tensor of a launch read or written once) per family
-        self.alg_bytes = {"conv_tiled": 0, "conv_generic": 0, "wgrad_tiled": 0, "wgrad_generic": 0}
+        self.alg_bytes = {"conv_tiled": 0, "conv_generic": 0, "wgrad_tiled": 0, "wgrad_generic": 0, "conv_tiled_full": 0}
 
     # ------------------------------------------------------------------ helpers
     def act(self, *a, **k):
@@ -394,6 +394,11 @@ class ConvOp:
         self.bytes_fwd = 2 * g.n * self.x.vox * ge.ci + esz * g.n * self.y.vox * self.y.c + (
             2 * g.n * self.y.vox * self.y.c if self.residual is not None else 0)
         g.alg_bytes["conv_tiled" if self.tiled_fwd else "conv_generic"] += self.bytes_fwd
+        # the tiled kernel at its dominant geometry (csrc/conv_tiled.hip: 32 output channels, >= 2^20 voxels per launch)
+        self.full_fwd = self.tiled_fwd and ge.co == 32 and g.n * self.y.vox >= (1 << 20)
+        if self.full_fwd:
+            g.flops["conv_tiled_full"] += self.alg_flops
+            g.alg_bytes["conv_tiled_full"] += self.bytes_fwd
 
     def emit_backward(self, gy: View):
         g, be, ge, x = self.g, self.g.be, self.geom, self.x
@@ -417,8 +422,11 @@ class ConvOp:
             g.flops["conv_dgrad"] += self.alg_flops
             g.flops["conv_tiled" if self.tiled_bwd else "conv_generic"] += self.alg_flops
             # data gradient: read gy, write dxhat, (GroupNorm: read x for Q)
-            g.alg_bytes["conv_tiled" if self.tiled_bwd else "conv_generic"] += 2 * g.n * (
-                gy.vox * pad_to(ge.co, 32) + x.vox * ge.ci * (2 if self.gn else 1))
+            nb = 2 * g.n * (gy.vox * pad_to(ge.co, 32) + x.vox * ge.ci * (2 if self.gn else 1))
+            g.alg_bytes["conv_tiled" if self.tiled_bwd else "conv_generic"] += nb
+            if self.tiled_bwd and ge.ci == 32 and g.n * x.vox >= (1 << 20):   # transposed: the kernel's Cout is the conv's Cin
+                g.flops["conv_tiled_full"] += self.alg_flops
+                g.alg_bytes["conv_tiled_full"] += nb
             if self.gn:
                 if not S:
                     S = x.stats_split
@@ -512,7 +520,12 @@ class SplitConvOp:
         self.alg_flops = 2 * g.n * gs.do * gs.ho * gs.wo * self.co_real * self.ci_real * ntap
         g.flops["conv_fwd"] += self.alg_flops
         g.flops["conv_tiled"] += self.alg_flops
-        g.alg_bytes["conv_tiled"] += 2 * g.n * (self.x.vox * self.ci_real + self.y.vox * self.y.c)
+        nb = 2 * g.n * (self.x.vox * self.ci_real + self.y.vox * self.y.c)
+        g.alg_bytes["conv_tiled"] += nb
+        self.full = gs.co == 32 and g.n * self.y.vox >= (1 << 20)   # the profiling family of these launches (conv_tiled.hip)
+        if self.full:
+            g.flops["conv_tiled_full"] += self.alg_flops
+            g.alg_bytes["conv_tiled_full"] += nb
 
     def emit_backward(self, gy: View):
         g, be, gs, x = self.g, self.g.be, self.gs, self.x
@@ -528,7 +541,11 @@ class SplitConvOp:
             x.contribs.append((View(dxb, g.n, x.d, x.h, x.w, self.ci_real, 0, self.ci_real), None))
             g.flops["conv_dgrad"] += self.alg_flops
             g.flops["conv_tiled"] += self.alg_flops
-            g.alg_bytes["conv_tiled"] += 2 * g.n * (gy.vox * co32 + x.vox * self.ci_real)
+            nb = 2 * g.n * (gy.vox * co32 + x.vox * self.ci_real)
+            g.alg_bytes["conv_tiled"] += nb
+            if g.n * x.vox >= (1 << 20):
+                g.flops["conv_tiled_full"] += self.alg_flops
+                g.alg_bytes["conv_tiled_full"] += nb
         wl = g.wg_lane_of(gy)
         csum = None
         if self.bname:
@@ -588,6 +605,10 @@ class CoSplitConvOp:
         g.flops["conv_fwd"] += self.alg_flops
         g.flops["conv_tiled"] += self.alg_flops
         g.alg_bytes["conv_tiled"] += 2 * g.n * x.vox * 32 + 4 * g.n * y.vox * y.c
+        self.big = g.n * y.vox >= (1 << 20)
+        if self.big:   # the 32-channel slice runs in the dominant-geometry family, the 16-channel slice in the other
+            g.flops["conv_tiled_full"] += self.alg_flops * 32 // self.co_real
+            g.alg_bytes["conv_tiled_full"] += 2 * g.n * x.vox * 32 + 4 * g.n * y.vox * 32
 
     def emit_backward(self, gy: View):
         g, be, x, y = self.g, self.g.be, self.x, self.y
@@ -607,6 +628,9 @@ class CoSplitConvOp:
             g.flops["conv_dgrad"] += self.alg_flops
             g.flops["conv_tiled"] += self.alg_flops
             g.alg_bytes["conv_tiled"] += 2 * g.n * (gy.vox * 64 + x.vox * 32)
+            if self.big:
+                g.flops["conv_tiled_full"] += self.alg_flops
+                g.alg_bytes["conv_tiled_full"] += 2 * g.n * (gy.vox * 64 + x.vox * 32)
         wl = g.wg_lane_of(gy)
         for k, (a, c) in enumerate(self.slices):
             gk = self.geom(c)
