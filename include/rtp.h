@@ -257,6 +257,31 @@ int rtp_assign_labels(const double* poses, const int* nposes, int frames, int ma
                       const int* out_size_factor_zyx, int fz, int fy, int fx, const float* table, float* hm, float* anno,
                       long long* ind, unsigned char* mask, long long* cat, int* prev, void* stream);
 
+/* ---------------------------------------------------------------- C''. LiDAR stream --- */
+
+/* points[:, :3] = (P_L2R @ [x, y, z, 1])[:3] in float64, rounded once to fp32, in place
+ * (det3d/datasets/pipelines/pose.py:34-38).  points device fp32 [n][c]; P_L2R HOST double[12] = first three rows. */
+int rtp_lidar_transform(float* points, int n, int c, const double* P_L2R, void* stream);
+
+/* Dynamic voxelisation (det3d/models/readers/dynamic_voxel_encoder.py:8-19 `voxelization` + core/utils/scatter.py):
+ *   keep points with min <= p <= max on x, y, z (both ends inclusive); voxel coordinate = trunc((p - min) / voxel_size) in
+ *   fp32; voxels = the distinct (z, y, x) coordinates in ascending lexicographic order (torch.unique(dim=0));
+ *   voxels[v][:] = mean over the voxel's points (summed in input order) of ALL c point features.
+ *   points device fp32 [n][c]; pc_range HOST fp32[6] = (xmin,ymin,zmin,xmax,ymax,zmax); voxel_size HOST fp32[3] = (x,y,z)
+ *   voxels device fp32 [n][c] (capacity), coords device int64 [n][3] = (z,y,x), num_voxels device int
+ *   workspace: rtp_voxelize_workspace_bytes(n) bytes of device memory (keys, permutation, rocPRIM temporaries).
+ * Stable radix sort by voxel key + one sequential sum per (voxel, feature): deterministic, bit-identical to the reference's
+ * CPU arithmetic (its GPU path sums with atomics). */
+long rtp_voxelize_workspace_bytes(int n);
+int rtp_dynamic_voxelize(const float* points, int n, int c, const float* pc_range, const float* voxel_size, float* voxels,
+                         long long* coords, int* num_voxels, void* workspace, long ws_bytes, void* stream);
+
+/* Voxel means scattered into a dense grid for fusion with the radar feature (this repo's own step; the reference has no
+ * fusion detector): grid fp32 [Z][Y][X][c] (zeroed here), occ uint8 [Z][Y][X] or NULL; voxels outside the grid (a point
+ * exactly on the upper range bound) are dropped.  max_voxels bounds the launch; the device count decides. */
+int rtp_voxels_to_dense(const float* voxels, const long long* coords, const int* num_voxels, int max_voxels, int c, int Z,
+                        int Y, int X, float* grid, unsigned char* occ, void* stream);
+
 /* Global grad-norm partials and the fused clip + decoupled-weight-decay + Adam step over a flat fp32
  * parameter buffer (fastai_optim.py:154-172, hooks/optimizer.py:14-24, torch.optim.Adam).
  *   hyper (device fp32[10]) = {lr, beta1, beta2, eps, wd, max_norm, 1-beta1^t, 1-beta2^t, grad_scale, -}

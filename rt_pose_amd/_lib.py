@@ -83,6 +83,10 @@ PROTOTYPES = {
     "rtp_gaussian_table": [_I, C.POINTER(_F)],
     "rtp_assign_labels": [_P, _P, _I, _I, _I, _I, _I, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_I), _I, _I, _I,
                           _P, _P, _P, _P, _P, _P, _P, _P],
+    "rtp_lidar_transform": [_P, _I, _I, C.POINTER(C.c_double), _P],
+    "rtp_voxelize_workspace_bytes": [_I],
+    "rtp_dynamic_voxelize": [_P, _I, _I, C.POINTER(_F), C.POINTER(_F), _P, _P, _P, _P, _L, _P],
+    "rtp_voxels_to_dense": [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P],
     "rtp_sqnorm": [_P, _L, _P, _P, _P],
     "rtp_sqnorm_blocks": [],
     "rtp_adam_step": [_P, _P, _P, _P, _L, _P, _P, _I, _P, _P],
@@ -96,7 +100,7 @@ PROTOTYPES = {
     "rtp_prof_collect": [_I, C.POINTER(_F), C.POINTER(_I)],
     "rtp_version": [],
 }
-_RESTYPE = {"rtp_version": C.c_char_p, "rtp_dcn_workspace_bytes": C.c_long,
+_RESTYPE = {"rtp_version": C.c_char_p, "rtp_dcn_workspace_bytes": C.c_long, "rtp_voxelize_workspace_bytes": C.c_long,
             "rtp_upsample_bwd_scratch_floats": C.c_long}
 
 _lib = None

@@ -73,6 +73,10 @@ class RadarFeatureNet(nn.Module):
         return rdr_cube
 
 
+from .lidar import DynamicVoxelEncoder  # noqa: E402  (det3d/models/readers/dynamic_voxel_encoder.py:69-101)
+READERS.register_module(DynamicVoxelEncoder)
+
+
 @BACKBONES.register_module
 class HRNet3D(nn.Module):
     def __init__(self, backbone_cfg="hr_tiny_feat32_zyx_l4", feat_transform=None, **kwargs):
