@@ -68,6 +68,49 @@ __global__ __launch_bounds__(256) void dcn_im2col_kernel(const float* x, const f
 }
 
 // grad_im[b][c] += bilinear-adjoint of columns-gradient (atomic scatter to the 4 live corners)
+// col2im with the image plane in LDS: one block owns one (sample, channel) plane of grad_im (H*W fp32 <= 60 KB), adds
+// all of that plane's 4-corner contributions (every tap x every output position) with LDS atomics and then adds the
+// plane to global memory with plain stores -- no global atomics (the scatter kernel below issues 4 per column element:
+// 13.6 ms per 64-sample chunk at [32,64,160]) and no other block touches the plane.
+__global__ __launch_bounds__(256) void dcn_col2im_plane_kernel(const float* col, const float* offset, const float* mask,
+                                                               float* grad_im, DcnGeom g, int b0, int step) {
+  extern __shared__ float plane[];
+  const int P = g.ho * g.wo, K = g.kh * g.kw, HW = g.h * g.w;
+  const int c = blockIdx.x % g.c, bl = blockIdx.x / g.c;
+  const int b = b0 + bl, cpg = g.c / g.dg, dgi = c / cpg;
+  for (int i = threadIdx.x; i < HW; i += 256) plane[i] = 0.f;
+  __syncthreads();
+  const float* off = offset + ((long)b * g.dg + dgi) * 2 * K * P;
+  for (int t = 0; t < K; ++t) {
+    const int ki = t / g.kw, kj = t - ki * g.kw;
+    const float* colp = col + (((long)c * K + t) * step + bl) * P;
+    const float* mk = mask ? mask + ((long)b * g.dg + dgi) * K * P + (long)t * P : nullptr;
+    for (int p = threadIdx.x; p < P; p += 256) {
+      const int wo = p % g.wo, ho = p / g.wo;
+      const float hi = ho * g.sh - g.ph + ki * g.dh + off[(2 * t) * P + p];
+      const float wi = wo * g.sw - g.pw + kj * g.dw + off[(2 * t + 1) * P + p];
+      if (!(hi > -1.f && wi > -1.f && hi < g.h && wi < g.w)) continue;
+      float top = colp[p];
+      if (mk) top *= mk[p];
+      const int h_low = (int)floorf(hi), w_low = (int)floorf(wi);
+      const float lh = hi - h_low, lw = wi - w_low;
+#pragma unroll
+      for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+          const int yy = h_low + dy, xx = w_low + dx;
+          if (yy >= 0 && yy <= g.h - 1 && xx >= 0 && xx <= g.w - 1) {
+            const float wgt = (dy ? lh : 1.f - lh) * (dx ? lw : 1.f - lw);
+            if (wgt != 0.f) atomicAdd(&plane[yy * g.w + xx], wgt * top);
+          }
+        }
+    }
+  }
+  __syncthreads();
+  float* gim = grad_im + ((long)b * g.c + c) * HW;
+  for (int i = threadIdx.x; i < HW; i += 256) gim[i] += plane[i];
+}
+
 __global__ __launch_bounds__(256) void dcn_col2im_kernel(const float* col, const float* offset, const float* mask,
                                                          float* grad_im, DcnGeom g, int b0, int step) {
   const int P = g.ho * g.wo, K = g.kh * g.kw;
@@ -164,30 +207,35 @@ struct MatView {
 };
 
 // C[M][N] = alpha * A[M][K] * B[K][N] + beta * C
+// gridDim.z > 1: split-K -- slice z contracts k in [z*kchunk, (z+1)*kchunk) and ADDS alpha * partial to C with fp32 atomics
+// (only for beta == 1: the weight-gradient GEMM, M x N = 32 x 288 against K = 655 360, was 5 blocks of 41 000 iterations).
 __global__ __launch_bounds__(256) void sgemm_kernel(MatView A, MatView B, MatView C, int M, int N, int K, float alpha,
-                                                    float beta) {
+                                                    float beta, int kchunk) {
   __shared__ float As[16][64 + 4];
   __shared__ float Bs[16][64 + 4];
   const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
   const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+  const bool split = gridDim.z > 1;
+  const int kbeg = split ? blockIdx.z * kchunk : 0;
+  const int kend = split ? (kbeg + kchunk < K ? kbeg + kchunk : K) : K;
   float acc[4][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
-  for (int k0 = 0; k0 < K; k0 += 16) {
+  for (int k0 = kbeg; k0 < kend; k0 += 16) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int e = threadIdx.x + r * 256;  // 1024 elements per tile
       {
         const int kk = e & 15, mm = e >> 4;  // A tile: 64 rows x 16 k
         const int m = m0 + mm, k = k0 + kk;
-        As[kk][mm] = (m < M && k < K) ? A.p[A.at(m, k)] : 0.f;
+        As[kk][mm] = (m < M && k < kend) ? A.p[A.at(m, k)] : 0.f;
       }
       {
         const int nn = e & 63, kk = e >> 6;  // B tile: 16 k x 64 cols
         const int n = n0 + nn, k = k0 + kk;
-        Bs[kk][nn] = (n < N && k < K) ? B.p[B.at(k, n)] : 0.f;
+        Bs[kk][nn] = (n < N && k < kend) ? B.p[B.at(k, n)] : 0.f;
       }
     }
     __syncthreads();
@@ -212,14 +260,23 @@ __global__ __launch_bounds__(256) void sgemm_kernel(MatView A, MatView B, MatVie
       const int m = m0 + ty * 4 + i, n = n0 + tx * 4 + j;
       if (m < M && n < N) {
         float* dst = C.p + C.at(m, n);
-        *dst = alpha * acc[i][j] + (beta != 0.f ? beta * *dst : 0.f);
+        if (split) atomicAdd(dst, alpha * acc[i][j]);
+        else *dst = alpha * acc[i][j] + (beta != 0.f ? beta * *dst : 0.f);
       }
     }
 }
 
 static void sgemm(hipStream_t s, MatView A, MatView B, MatView C, int M, int N, int K, float alpha, float beta) {
   dim3 grid((N + 63) / 64, (M + 63) / 64);
-  hipLaunchKernelGGL(sgemm_kernel, grid, dim3(256), 0, s, A, B, C, M, N, K, alpha, beta);
+  int kchunk = K;
+  // few output tiles against a long contraction (and an accumulating GEMM): spread K over the chip
+  if (beta == 1.f && (long)grid.x * grid.y < 128 && K >= 8192) {
+    int splits = (int)(1024 / ((long)grid.x * grid.y));
+    kchunk = ((K + splits - 1) / splits + 15) & ~15;
+    if (kchunk < 2048) kchunk = 2048;
+    grid.z = (K + kchunk - 1) / kchunk;
+  }
+  hipLaunchKernelGGL(sgemm_kernel, grid, dim3(256), 0, s, A, B, C, M, N, K, alpha, beta, kchunk);
 }
 
 static inline MatView mv(const float* p, long s_row, long s_col, int split = 1 << 30, long s_outer = 0) {
@@ -306,8 +363,12 @@ static int dcn_backward_input(const float* input, const float* offset, const flo
     }
     hipLaunchKernelGGL(dcn_col2im_coord_kernel, dim3(grid1d((long)step * g.dg * K * P)), dim3(256), 0, s, ws, input,
                        offset, mask, gradOffset, gradMask, g, b0, step);
-    hipLaunchKernelGGL(dcn_col2im_kernel, dim3(grid1d((long)g.c * K * step * P)), dim3(256), 0, s, ws, offset, mask,
-                       gradInput, g, b0, step);
+    if ((size_t)g.h * g.w * sizeof(float) <= 60 * 1024)
+      hipLaunchKernelGGL(dcn_col2im_plane_kernel, dim3(step * g.c), dim3(256), sizeof(float) * g.h * g.w, s, ws, offset, mask,
+                         gradInput, g, b0, step);
+    else
+      hipLaunchKernelGGL(dcn_col2im_kernel, dim3(grid1d((long)g.c * K * step * P)), dim3(256), 0, s, ws, offset, mask,
+                         gradInput, g, b0, step);
   }
   RTP_CHECK_LAUNCH();
   return RTP_OK;
