@@ -310,6 +310,171 @@ __global__ __launch_bounds__(256) void dcn_bias_grad_kernel(const float* go, flo
   if (threadIdx.x == 0) gb[c] += red[0];
 }
 
+// ------------------------------------------------------------------------------------------------ fused forward
+// Deformable im2col fused with the GEMM: no `columns` round trip (the unfused forward writes and re-reads 1.5 GB of
+// columns at [128,32,64,160]).  out[b][co][p] = sum_{c,t} W[co][c][t] * sample(x[b][c], p, t) on the fp32 matrix pipe:
+// v_mfma_f32_32x32x2_f32 with A = W (32 co x 2 channels) and B = the gathered samples (2 channels x 32 positions).  In
+// that instruction's B layout lane l holds position l%32 of channel l/32 -- so one wave-wide gather (4 corner loads per
+// lane, lanes of a half-wave on consecutive positions of one channel plane) feeds one MFMA per 32 output channels.
+// A wave owns 64 consecutive output positions (two 32-position MFMA column groups); sample coordinates and bilinear
+// weights are computed once per (position, deformable group, tap) and reused by all channels of the group.  Weights are
+// pre-transposed to [c][tap][co] (dcn_wt_kernel, into the caller's workspace) and staged per deformable group in LDS
+// with a row stride that puts the two half-waves on disjoint banks.  Corner loads go through a buffer resource over the
+// image, so an out-of-range corner is a voffset past num_records and reads 0 (the reference's per-corner bounds,
+// deform_conv_cuda_kernel.cu:85-115).
+typedef float dcn_f32x16 __attribute__((ext_vector_type(16)));
+#define DCN_OOB ((int)0x80000000)
+
+__global__ void dcn_wt_kernel(const float* w, float* wt, int co, int c, int K, int cop) {
+  const int total = c * K * cop;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    const int o = i % cop, ck = i / cop;
+    wt[i] = o < co ? w[(long)o * c * K + ck] : 0.f;
+  }
+}
+
+template <int MT>
+__global__ __launch_bounds__(256) void dcn_fused_fwd_kernel(const float* x, const float* offset, const float* mask,
+                                                            const float* wt, const float* bias, float* out, DcnGeom g,
+                                                            int rs) {
+  extern __shared__ float wl[];
+  constexpr int COP = 32 * MT;
+  const int P = g.ho * g.wo, K = g.kh * g.kw, HW = g.h * g.w;
+  const int cpg = g.c / g.dg;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int half = lane >> 5, l32 = lane & 31;
+  const int b = blockIdx.y;
+  const int p0 = blockIdx.x * 256 + wave * 64;
+  const __amdgpu_buffer_rsrc_t rx =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(x + (long)b * g.c * HW), 0, g.c * HW * 4, 0x00020000);
+  const int pl = p0 + lane;
+  const bool pl_ok = pl < P;
+  int hin[2], win[2];
+  bool pg_ok[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int pg = p0 + 32 * q + l32;
+    const int ho = pg / g.wo, wo = pg - ho * g.wo;
+    hin[q] = ho * g.sh - g.ph;
+    win[q] = wo * g.sw - g.pw;
+    pg_ok[q] = pg < P;
+  }
+  dcn_f32x16 acc[2][MT];
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[q][m][r] = 0.f;
+  const float* offb = offset + (long)b * g.dg * 2 * K * P;
+  const float* mkb = mask ? mask + (long)b * g.dg * K * P : nullptr;
+  const int stage_n = cpg * K * COP;
+  for (int dgi = 0; dgi < g.dg; ++dgi) {
+    __syncthreads();
+    for (int i = threadIdx.x * 4; i < stage_n; i += 1024) {
+      const float4 v = *(const float4*)(wt + (long)dgi * stage_n + i);
+      const int cl = i / (K * COP), r = i - cl * (K * COP);
+      *(float4*)&wl[cl * rs + r] = v;
+    }
+    __syncthreads();
+    const float* offd = offb + (long)dgi * 2 * K * P;
+    for (int t = 0; t < K; ++t) {
+      const int ki = t / g.kw, kj = t - ki * g.kw;
+      const float oh = pl_ok ? offd[(long)(2 * t) * P + pl] : 0.f;
+      const float ow = pl_ok ? offd[(long)(2 * t + 1) * P + pl] : 0.f;
+      const float mv_ = (mkb && pl_ok) ? mkb[((long)dgi * K + t) * P + pl] : 1.f;
+      float w1[2], w2[2], w3[2], w4[2], mk[2];
+      int a1[2], a2[2], a3[2], a4[2];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int src = (32 * q + l32) * 4;
+        const float ohq = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(oh)));
+        const float owq = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(ow)));
+        mk[q] = mkb ? __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(mv_))) : 1.f;
+        const float hi = hin[q] + ki * g.dh + ohq;
+        const float wi = win[q] + kj * g.dw + owq;
+        const bool in = pg_ok[q] && hi > -1.f && wi > -1.f && hi < g.h && wi < g.w;
+        const float hf = floorf(hi), wf = floorf(wi);
+        const int h_low = (int)hf, w_low = (int)wf;
+        const float lh = hi - hf, lw = wi - wf, hh = 1.f - lh, hw = 1.f - lw;
+        w1[q] = hh * hw; w2[q] = hh * lw; w3[q] = lh * hw; w4[q] = lh * lw;
+        const bool r0 = in && h_low >= 0, r1 = in && h_low + 1 <= g.h - 1;
+        const bool c0 = w_low >= 0, c1 = w_low + 1 <= g.w - 1;
+        const int base = (h_low * g.w + w_low + half * HW) * 4;
+        a1[q] = (r0 && c0) ? base : DCN_OOB;
+        a2[q] = (r0 && c1) ? base + 4 : DCN_OOB;
+        a3[q] = (r1 && c0) ? base + g.w * 4 : DCN_OOB;
+        a4[q] = (r1 && c1) ? base + g.w * 4 + 4 : DCN_OOB;
+      }
+      for (int cq = 0; cq < cpg; cq += 2) {
+        const int coff = (dgi * cpg + cq) * HW * 4;  // OOB markers stay past num_records after the add (c*HW*4 < 2^31)
+        float bv[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const float v1 = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, a1[q] + coff, 0, 0));
+          const float v2 = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, a2[q] + coff, 0, 0));
+          const float v3 = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, a3[q] + coff, 0, 0));
+          const float v4 = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, a4[q] + coff, 0, 0));
+          bv[q] = (w1[q] * v1 + w2[q] * v2 + w3[q] * v3 + w4[q] * v4) * mk[q];
+        }
+        const float* wrow = wl + (cq + half) * rs + t * COP + l32;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          const float a = wrow[m * 32];
+#pragma unroll
+          for (int q = 0; q < 2; ++q) acc[q][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv[q], acc[q][m], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // D[m][n]: lane l, register r -> n = l%32 (position), m = 8*(r/4) + 4*(l/32) + r%4 (output channel within the tile)
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int pg = p0 + 32 * q + l32;
+    if (pg >= P) continue;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = m * 32 + 8 * (r >> 2) + 4 * half + (r & 3);
+        if (co < g.co) out[((long)b * g.co + co) * P + pg] = acc[q][m][r] + (bias ? bias[co] : 0.f);
+      }
+  }
+}
+
+static int dcn_fused_rs(int K, int cop) {
+  int rs = K * cop;            // a multiple of 32: the half-waves (channel cq, cq+1) must sit 32 banks apart
+  if (rs % 64 == 0) rs += 32;
+  return rs;
+}
+
+// The fused kernel covers the configurations the model uses (group 1, an even number of channels per deformable group,
+// <= 64 output channels); everything else takes the im2col + GEMM path below.  RTP_DCN_UNFUSED=1 forces that path (A/B).
+static bool dcn_fused_ok(const DcnGeom& g, int step) {
+  const char* e = getenv("RTP_DCN_UNFUSED");
+  const bool off = e && atoi(e);
+  if (off || g.group != 1 || g.co > 64) return false;
+  const int cpg = g.c / g.dg, K = g.kh * g.kw, cop = g.co > 32 ? 64 : 32;
+  if (cpg % 2) return false;
+  if ((long)g.c * g.h * g.w * 4 >= (1L << 31) - (1L << 20)) return false;
+  if ((long)cpg * dcn_fused_rs(K, cop) * 4 > 64 * 1024) return false;
+  if ((long)step * g.ho * g.wo < cop) return false;  // the transposed weights borrow the columns workspace
+  return true;
+}
+
+static void dcn_forward_fused(const float* input, const float* weight, const float* bias, const float* offset,
+                              const float* mask, float* output, float* ws, const DcnGeom& g, hipStream_t s) {
+  const int P = g.ho * g.wo, K = g.kh * g.kw, cpg = g.c / g.dg;
+  const int cop = g.co > 32 ? 64 : 32, rs = dcn_fused_rs(K, cop);
+  hipLaunchKernelGGL(dcn_wt_kernel, dim3((g.c * K * cop + 255) / 256), dim3(256), 0, s, weight, ws, g.co, g.c, K, cop);
+  const dim3 grid((P + 255) / 256, g.n);
+  const size_t lds = (size_t)cpg * rs * sizeof(float);
+  if (cop == 32)
+    hipLaunchKernelGGL(dcn_fused_fwd_kernel<1>, grid, dim3(256), lds, s, input, offset, mask, ws, bias, output, g, rs);
+  else
+    hipLaunchKernelGGL(dcn_fused_fwd_kernel<2>, grid, dim3(256), lds, s, input, offset, mask, ws, bias, output, g, rs);
+}
+
 static int dcn_check(DcnGeom& g, int im2col_step) {
   if (g.n < 1 || g.c < 1 || g.co < 1 || g.kh < 1 || g.kw < 1 || g.sh < 1 || g.sw < 1 || g.dh < 1 || g.dw < 1)
     return RTP_ERR_SHAPE;  // shape_check, deform_conv_cuda.cpp:62-150
@@ -330,6 +495,11 @@ static int dcn_forward(const float* input, const float* weight, const float* bia
   const int P = g.ho * g.wo, K = g.kh * g.kw;
   const int cg = g.c / g.group, cog = g.co / g.group;
   RtpProfScope prof(RTP_FAM_DCN, s);
+  if (dcn_fused_ok(g, step)) {
+    dcn_forward_fused(input, weight, bias, offset, mask, output, ws, g, s);
+    RTP_CHECK_LAUNCH();
+    return RTP_OK;
+  }
   for (int b0 = 0; b0 < g.n; b0 += step) {
     hipLaunchKernelGGL(dcn_im2col_kernel, dim3(grid1d((long)g.c * step * P)), dim3(256), 0, s, input, offset, mask, ws,
                        g, b0, step);

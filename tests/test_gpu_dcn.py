@@ -21,11 +21,15 @@ CASES = [
     (4, 16, 12, 10, 8, 3, 2, 1, 1, 2, 4, 2),
     (2, 64, 16, 20, 64, 3, 1, 1, 1, 1, 4, 64),     # FeatureAdaption shape: 3x3, pad 1, deformable_groups=4 (center_head.py:24-62)
     (1, 4, 7, 7, 4, 3, 1, 2, 2, 1, 2, 64),
+    (3, 12, 33, 41, 40, 3, 1, 1, 1, 1, 2, 3),      # ragged: P = 1353 is no multiple of the 256-position block, co = 40 -> two MFMA row tiles
 ]
 
 
+@pytest.mark.parametrize("unfused", ["0", "1"])
 @pytest.mark.parametrize("case", CASES)
-def test_dcn_v1_forward_backward(case):
+def test_dcn_v1_forward_backward(case, unfused, monkeypatch):
+    # RTP_DCN_UNFUSED=1: the im2col + GEMM forward (the only path for groups > 1 / odd channels per deformable group)
+    monkeypatch.setenv("RTP_DCN_UNFUSED", unfused)
     from rt_pose_amd.dcn import deform_conv
     n, c, h, w, co, k, stride, pad, dil, groups, dg, step = case
     x = rnd(n, c, h, w, seed=1).requires_grad_(True)
