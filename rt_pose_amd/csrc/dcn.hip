@@ -323,6 +323,7 @@ __global__ __launch_bounds__(256) void dcn_bias_grad_kernel(const float* go, flo
 // image, so an out-of-range corner is a voffset past num_records and reads 0 (the reference's per-corner bounds,
 // deform_conv_cuda_kernel.cu:85-115).
 typedef float dcn_f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned dcn_u32x2 __attribute__((ext_vector_type(2)));
 #define DCN_OOB ((int)0x80000000)
 
 __global__ void dcn_wt_kernel(const float* w, float* wt, int co, int c, int K, int cop) {
@@ -333,8 +334,9 @@ __global__ void dcn_wt_kernel(const float* w, float* wt, int co, int c, int K, i
   }
 }
 
+#define DCN_FWD_THREADS 512
 template <int MT>
-__global__ __launch_bounds__(256) void dcn_fused_fwd_kernel(const float* x, const float* offset, const float* mask,
+__global__ __launch_bounds__(DCN_FWD_THREADS) void dcn_fused_fwd_kernel(const float* x, const float* offset, const float* mask,
                                                             const float* wt, const float* bias, float* out, DcnGeom g,
                                                             int rs) {
   extern __shared__ float wl[];
@@ -344,7 +346,7 @@ __global__ __launch_bounds__(256) void dcn_fused_fwd_kernel(const float* x, cons
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int half = lane >> 5, l32 = lane & 31;
   const int b = blockIdx.y;
-  const int p0 = blockIdx.x * 256 + wave * 64;
+  const int p0 = blockIdx.x * DCN_FWD_THREADS + wave * 64;
   const __amdgpu_buffer_rsrc_t rx =
       __builtin_amdgcn_make_buffer_rsrc((void*)(x + (long)b * g.c * HW), 0, g.c * HW * 4, 0x00020000);
   const int pl = p0 + lane;
@@ -371,7 +373,7 @@ __global__ __launch_bounds__(256) void dcn_fused_fwd_kernel(const float* x, cons
   const int stage_n = cpg * K * COP;
   for (int dgi = 0; dgi < g.dg; ++dgi) {
     __syncthreads();
-    for (int i = threadIdx.x * 4; i < stage_n; i += 1024) {
+    for (int i = threadIdx.x * 4; i < stage_n; i += DCN_FWD_THREADS * 4) {
       const float4 v = *(const float4*)(wt + (long)dgi * stage_n + i);
       const int cl = i / (K * COP), r = i - cl * (K * COP);
       *(float4*)&wl[cl * rs + r] = v;
@@ -384,7 +386,8 @@ __global__ __launch_bounds__(256) void dcn_fused_fwd_kernel(const float* x, cons
       const float ow = pl_ok ? offd[(long)(2 * t + 1) * P + pl] : 0.f;
       const float mv_ = (mkb && pl_ok) ? mkb[((long)dgi * K + t) * P + pl] : 1.f;
       float w1[2], w2[2], w3[2], w4[2], mk[2];
-      int a1[2], a2[2], a3[2], a4[2];
+      int a0[2], a1[2];
+      bool lo_y[2], hi_x[2];
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
         const int src = (32 * q + l32) * 4;
@@ -397,32 +400,51 @@ __global__ __launch_bounds__(256) void dcn_fused_fwd_kernel(const float* x, cons
         const float hf = floorf(hi), wf = floorf(wi);
         const int h_low = (int)hf, w_low = (int)wf;
         const float lh = hi - hf, lw = wi - wf, hh = 1.f - lh, hw = 1.f - lw;
-        w1[q] = hh * hw; w2[q] = hh * lw; w3[q] = lh * hw; w4[q] = lh * lw;
-        const bool r0 = in && h_low >= 0, r1 = in && h_low + 1 <= g.h - 1;
+        // one 8-byte load per row fetches both columns: the pair starts at xs = clamp(w_low, 0, W-2); at the left edge
+        // (w_low = -1) the high column is the pair's .x, at the right edge (w_low = W-1) the low column is its .y, and
+        // the column that falls outside the image gets weight 0
         const bool c0 = w_low >= 0, c1 = w_low + 1 <= g.w - 1;
-        const int base = (h_low * g.w + w_low + half * HW) * 4;
-        a1[q] = (r0 && c0) ? base : DCN_OOB;
-        a2[q] = (r0 && c1) ? base + 4 : DCN_OOB;
-        a3[q] = (r1 && c0) ? base + g.w * 4 : DCN_OOB;
-        a4[q] = (r1 && c1) ? base + g.w * 4 + 4 : DCN_OOB;
+        lo_y[q] = !c1;
+        hi_x[q] = !c0;
+        w1[q] = c0 ? hh * hw : 0.f; w2[q] = c1 ? hh * lw : 0.f; w3[q] = c0 ? lh * hw : 0.f; w4[q] = c1 ? lh * lw : 0.f;
+        const int xs = w_low < 0 ? 0 : (c1 ? w_low : g.w - 2);
+        const bool r0 = in && h_low >= 0, r1 = in && h_low + 1 <= g.h - 1;
+        const int base = (h_low * g.w + xs + half * HW) * 4;
+        a0[q] = r0 ? base : DCN_OOB;
+        a1[q] = r1 ? base + g.w * 4 : DCN_OOB;
       }
-      for (int cq = 0; cq < cpg; cq += 2) {
-        const int coff = (dgi * cpg + cq) * HW * 4;  // OOB markers stay past num_records after the add (c*HW*4 < 2^31)
-        float bv[2];
+      // four channel pairs per round: all 16 gathers are issued before the first blend, so a wave keeps 16 loads in
+      // flight (one round at cpg = 8); the L2-hit latency of a dependent gather is what bounds this kernel otherwise
+      for (int cq = 0; cq < cpg; cq += 8) {
+        dcn_u32x2 pr[4][2][2];
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          const float v1 = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, a1[q] + coff, 0, 0));
-          const float v2 = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, a2[q] + coff, 0, 0));
-          const float v3 = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, a3[q] + coff, 0, 0));
-          const float v4 = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, a4[q] + coff, 0, 0));
-          bv[q] = (w1[q] * v1 + w2[q] * v2 + w3[q] * v3 + w4[q] * v4) * mk[q];
+        for (int u = 0; u < 4; ++u) {
+          const bool live = cq + 2 * u < cpg;
+          const int coff = live ? (dgi * cpg + cq + 2 * u) * HW * 4 : 0;  // OOB markers stay past num_records after the add
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            pr[u][q][0] = __builtin_amdgcn_raw_buffer_load_b64(rx, live ? a0[q] + coff : DCN_OOB, 0, 0);
+            pr[u][q][1] = __builtin_amdgcn_raw_buffer_load_b64(rx, live ? a1[q] + coff : DCN_OOB, 0, 0);
+          }
         }
-        const float* wrow = wl + (cq + half) * rs + t * COP + l32;
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
-          const float a = wrow[m * 32];
+        for (int u = 0; u < 4; ++u) {
+          if (cq + 2 * u >= cpg) break;
+          float bv[2];
 #pragma unroll
-          for (int q = 0; q < 2; ++q) acc[q][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv[q], acc[q][m], 0, 0, 0);
+          for (int q = 0; q < 2; ++q) {
+            const dcn_u32x2 p0_ = pr[u][q][0], p1_ = pr[u][q][1];
+            const float v1 = __uint_as_float(lo_y[q] ? p0_.y : p0_.x), v2 = __uint_as_float(hi_x[q] ? p0_.x : p0_.y);
+            const float v3 = __uint_as_float(lo_y[q] ? p1_.y : p1_.x), v4 = __uint_as_float(hi_x[q] ? p1_.x : p1_.y);
+            bv[q] = (w1[q] * v1 + w2[q] * v2 + w3[q] * v3 + w4[q] * v4) * mk[q];
+          }
+          const float* wrow = wl + (cq + 2 * u + half) * rs + t * COP + l32;
+#pragma unroll
+          for (int m = 0; m < MT; ++m) {
+            const float a = wrow[m * 32];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) acc[q][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv[q], acc[q][m], 0, 0, 0);
+          }
         }
       }
     }
@@ -455,7 +477,7 @@ static bool dcn_fused_ok(const DcnGeom& g, int step) {
   const bool off = e && atoi(e);
   if (off || g.group != 1 || g.co > 64) return false;
   const int cpg = g.c / g.dg, K = g.kh * g.kw, cop = g.co > 32 ? 64 : 32;
-  if (cpg % 2) return false;
+  if (cpg % 2 || g.w < 2) return false;
   if ((long)g.c * g.h * g.w * 4 >= (1L << 31) - (1L << 20)) return false;
   if ((long)cpg * dcn_fused_rs(K, cop) * 4 > 64 * 1024) return false;
   if ((long)step * g.ho * g.wo < cop) return false;  // the transposed weights borrow the columns workspace
@@ -467,12 +489,12 @@ static void dcn_forward_fused(const float* input, const float* weight, const flo
   const int P = g.ho * g.wo, K = g.kh * g.kw, cpg = g.c / g.dg;
   const int cop = g.co > 32 ? 64 : 32, rs = dcn_fused_rs(K, cop);
   hipLaunchKernelGGL(dcn_wt_kernel, dim3((g.c * K * cop + 255) / 256), dim3(256), 0, s, weight, ws, g.co, g.c, K, cop);
-  const dim3 grid((P + 255) / 256, g.n);
+  const dim3 grid((P + DCN_FWD_THREADS - 1) / DCN_FWD_THREADS, g.n);
   const size_t lds = (size_t)cpg * rs * sizeof(float);
   if (cop == 32)
-    hipLaunchKernelGGL(dcn_fused_fwd_kernel<1>, grid, dim3(256), lds, s, input, offset, mask, ws, bias, output, g, rs);
+    hipLaunchKernelGGL(dcn_fused_fwd_kernel<1>, grid, dim3(DCN_FWD_THREADS), lds, s, input, offset, mask, ws, bias, output, g, rs);
   else
-    hipLaunchKernelGGL(dcn_fused_fwd_kernel<2>, grid, dim3(256), lds, s, input, offset, mask, ws, bias, output, g, rs);
+    hipLaunchKernelGGL(dcn_fused_fwd_kernel<2>, grid, dim3(DCN_FWD_THREADS), lds, s, input, offset, mask, ws, bias, output, g, rs);
 }
 
 static int dcn_check(DcnGeom& g, int im2col_step) {

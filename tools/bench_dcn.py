@@ -37,10 +37,11 @@ def main():
         deform_conv(x, off, wt, 1, 1, 1, 1, 4, 64).backward(g)
     ms_fb = t(fb)
     ref = t(lambda: torch.nn.functional.conv2d(x, wt, None, 1, 1))
-    col_bytes = b * c * 9 * h * w * 4
+    alg = (x.numel() + off.numel() + y.numel()) * 4
     print("DCNv1 3x3 [%d,%d,%d,%d] -> %d, dg=4: forward %.2f ms, forward+backward %.2f ms; torch conv2d forward %.2f ms" % (b, c, h, w, co, ms_f, ms_fb, ref))
-    print("  columns %.0f MB fp32 written+read per forward -> %.0f GB/s effective; input %.0f MB, offsets %.0f MB" % (
-        col_bytes / 1e6, 2 * col_bytes / ms_f / 1e6, x.numel() * 4 / 1e6, off.numel() * 4 / 1e6))
+    print("  forward algorithmic bytes (input %.0f MB + offsets %.0f MB + output %.0f MB) -> %.0f GB/s; %.1f TFLOP/s fp32; "
+          "%.1f G corner samples/s" % (x.numel() * 4 / 1e6, off.numel() * 4 / 1e6, y.numel() * 4 / 1e6, alg / ms_f / 1e6,
+                                     2.0 * b * h * w * co * c * 9 / ms_f / 1e9, 4.0 * b * h * w * c * 9 / ms_f / 1e6))
 
 
 if __name__ == "__main__":
