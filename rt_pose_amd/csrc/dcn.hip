@@ -464,6 +464,165 @@ __global__ __launch_bounds__(DCN_FWD_THREADS) void dcn_fused_fwd_kernel(const fl
   }
 }
 
+// ------------------------------------------------------------------------------------------------ windowed forward
+// The gather kernel above is bound by the texture-address path (about four lane addresses per clock per CU whatever
+// the load width), not by HBM or the matrix pipe.  Learned offsets are small, so the samples of a tile of 512 consecutive
+// output positions fall in a band of input rows: this kernel stages that band ("window": the rows the undeformed taps
+// touch plus `halo` rows either side, full width, rows outside the image as zeros) for `nch` channels in LDS with
+// coalesced 16-byte loads and gathers the bilinear corners from LDS (two ds_read2_b32 per sample).  A sample whose rows
+// leave the window is fetched with the buffer loads of the gather kernel instead -- per lane, under a wave-uniform
+// branch that is not taken when no lane of the wave missed -- so any offset field gives the reference's result; only
+// the speed depends on the offsets being small.
+struct DcnWin {
+  int rs, halo, wr, ws, nch;  // weight row stride, halo rows, window rows, per-channel window stride (floats), channels per stage
+};
+
+template <int MT>
+__global__ __launch_bounds__(DCN_FWD_THREADS) void dcn_win_fwd_kernel(const float* x, const float* offset, const float* mask,
+                                                                      const float* wt, const float* bias, float* out,
+                                                                      DcnGeom g, DcnWin wn) {
+  extern __shared__ float lds[];
+  constexpr int COP = 32 * MT;
+  float* win = lds;                    // [nch][ws]
+  float* wl = lds + wn.nch * wn.ws;    // [nch][rs]
+  const int P = g.ho * g.wo, K = g.kh * g.kw, HW = g.h * g.w;
+  const int cpg = g.c / g.dg;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int half = lane >> 5, l32 = lane & 31;
+  const int b = blockIdx.y;
+  const int pfirst = blockIdx.x * DCN_FWD_THREADS;
+  const int p0 = pfirst + wave * 64;
+  const int wy0 = (pfirst / g.wo) * g.sh - g.ph - wn.halo;  // first staged input row (may be negative)
+  const float* xb = x + (long)b * g.c * HW;
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, g.c * HW * 4, 0x00020000);
+  const int pl = p0 + lane;
+  const bool pl_ok = pl < P;
+  int hin[2], win_[2];
+  bool pg_ok[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int pg = p0 + 32 * q + l32;
+    const int ho = pg / g.wo, wo = pg - ho * g.wo;
+    hin[q] = ho * g.sh - g.ph;
+    win_[q] = wo * g.sw - g.pw;
+    pg_ok[q] = pg < P;
+  }
+  dcn_f32x16 acc[2][MT];
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[q][m][r] = 0.f;
+  const float* offb = offset + (long)b * g.dg * 2 * K * P;
+  const float* mkb = mask ? mask + (long)b * g.dg * K * P : nullptr;
+  const int wcount = wn.wr * g.w;      // floats per staged channel
+  const int f0 = wy0 * g.w;            // image-plane index of window element 0
+  const bool vec4 = (g.w & 3) == 0;
+  for (int dgi = 0; dgi < g.dg; ++dgi) {
+    const float* offd = offb + (long)dgi * 2 * K * P;
+    for (int c0 = 0; c0 < cpg; c0 += wn.nch) {
+      const int cabs = dgi * cpg + c0;
+      __syncthreads();
+      if (vec4) {
+        const int q4 = wcount >> 2;
+        for (int i = threadIdx.x; i < wn.nch * q4; i += DCN_FWD_THREADS) {
+          const int ch = i / q4, e = (i - ch * q4) * 4, f = f0 + e;
+          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (f >= 0 && f < HW) v = *(const float4*)(xb + (long)(cabs + ch) * HW + f);
+          *(float4*)&win[ch * wn.ws + e] = v;
+        }
+      } else {
+        for (int i = threadIdx.x; i < wn.nch * wcount; i += DCN_FWD_THREADS) {
+          const int ch = i / wcount, e = i - ch * wcount, f = f0 + e;
+          win[ch * wn.ws + e] = (f >= 0 && f < HW) ? xb[(long)(cabs + ch) * HW + f] : 0.f;
+        }
+      }
+      for (int i = threadIdx.x * 4; i < wn.nch * K * COP; i += DCN_FWD_THREADS * 4) {
+        const float4 v = *(const float4*)(wt + (long)cabs * K * COP + i);
+        const int cl = i / (K * COP), r = i - cl * (K * COP);
+        *(float4*)&wl[cl * wn.rs + r] = v;
+      }
+      __syncthreads();
+      for (int t = 0; t < K; ++t) {
+        const int ki = t / g.kw, kj = t - ki * g.kw;
+        const float oh = pl_ok ? offd[(long)(2 * t) * P + pl] : 0.f;
+        const float ow = pl_ok ? offd[(long)(2 * t + 1) * P + pl] : 0.f;
+        const float mv_ = (mkb && pl_ok) ? mkb[((long)dgi * K + t) * P + pl] : 1.f;
+        float w1[2], w2[2], w3[2], w4[2], mk[2];
+        int la[2], ga0[2], ga1[2];
+        bool lo_y[2], hi_x[2], miss[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const int src = (32 * q + l32) * 4;
+          const float ohq = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(oh)));
+          const float owq = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(ow)));
+          mk[q] = mkb ? __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(mv_))) : 1.f;
+          const float hi = hin[q] + ki * g.dh + ohq;
+          const float wi = win_[q] + kj * g.dw + owq;
+          const bool in = pg_ok[q] && hi > -1.f && wi > -1.f && hi < g.h && wi < g.w;
+          const float hf = floorf(hi), wf = floorf(wi);
+          const int h_low = (int)hf, w_low = (int)wf;
+          const float lh = hi - hf, lw = wi - wf, hh = 1.f - lh, hw = 1.f - lw;
+          const bool c0_ = in && w_low >= 0, c1_ = in && w_low + 1 <= g.w - 1;
+          lo_y[q] = w_low + 1 > g.w - 1;
+          hi_x[q] = w_low < 0;
+          w1[q] = c0_ ? hh * hw : 0.f; w2[q] = c1_ ? hh * lw : 0.f; w3[q] = c0_ ? lh * hw : 0.f; w4[q] = c1_ ? lh * lw : 0.f;
+          const int xs = w_low < 0 ? 0 : (w_low + 1 <= g.w - 1 ? w_low : g.w - 2);
+          const int ry = h_low - wy0;
+          const bool inwin = ry >= 0 && ry + 1 < wn.wr;  // both rows are staged (rows outside the image as zeros)
+          miss[q] = in && !inwin;
+          la[q] = (in && inwin) ? (ry * g.w + xs + half * wn.ws) * 4 : half * wn.ws * 4;
+          const int gbase = (h_low * g.w + xs + half * HW) * 4;
+          ga0[q] = (miss[q] && h_low >= 0) ? gbase : DCN_OOB;
+          ga1[q] = (miss[q] && h_low + 1 <= g.h - 1) ? gbase + g.w * 4 : DCN_OOB;
+        }
+        const bool anymiss = __builtin_amdgcn_ballot_w64(miss[0] || miss[1]) != 0;
+        for (int cq = 0; cq < wn.nch; cq += 2) {
+          float bv[2];
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            const float* r0 = (const float*)((const char*)win + la[q]) + cq * wn.ws;
+            const float* r1 = r0 + g.w;
+            float p0x = r0[0], p0y = r0[1], p1x = r1[0], p1y = r1[1];
+            if (anymiss) {
+              const int coff = (cabs + cq) * HW * 4;
+              const dcn_u32x2 b0 = __builtin_amdgcn_raw_buffer_load_b64(rx, ga0[q] + coff, 0, 0);
+              const dcn_u32x2 b1 = __builtin_amdgcn_raw_buffer_load_b64(rx, ga1[q] + coff, 0, 0);
+              if (miss[q]) {
+                p0x = __uint_as_float(b0.x); p0y = __uint_as_float(b0.y);
+                p1x = __uint_as_float(b1.x); p1y = __uint_as_float(b1.y);
+              }
+            }
+            const float v1 = lo_y[q] ? p0y : p0x, v2 = hi_x[q] ? p0x : p0y;
+            const float v3 = lo_y[q] ? p1y : p1x, v4 = hi_x[q] ? p1x : p1y;
+            bv[q] = (w1[q] * v1 + w2[q] * v2 + w3[q] * v3 + w4[q] * v4) * mk[q];
+          }
+          const float* wrow = wl + (cq + half) * wn.rs + t * COP + l32;
+#pragma unroll
+          for (int m = 0; m < MT; ++m) {
+            const float a = wrow[m * 32];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) acc[q][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv[q], acc[q][m], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int pg = p0 + 32 * q + l32;
+    if (pg >= P) continue;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = m * 32 + 8 * (r >> 2) + 4 * half + (r & 3);
+        if (co < g.co) out[((long)b * g.co + co) * P + pg] = acc[q][m][r] + (bias ? bias[co] : 0.f);
+      }
+  }
+}
+
 static int dcn_fused_rs(int K, int cop) {
   int rs = K * cop;            // a multiple of 32: the half-waves (channel cq, cq+1) must sit 32 banks apart
   if (rs % 64 == 0) rs += 32;
@@ -484,12 +643,46 @@ static bool dcn_fused_ok(const DcnGeom& g, int step) {
   return true;
 }
 
+// Window plan for the tile size of the kernel; nch = 0 when no even divisor of cpg fits the LDS budget.
+static DcnWin dcn_win_plan(const DcnGeom& g, int cop) {
+  const int K = g.kh * g.kw, cpg = g.c / g.dg;
+  const char* e = getenv("RTP_DCN_HALO");
+  DcnWin wn;
+  wn.rs = dcn_fused_rs(K, cop);
+  wn.halo = e ? atoi(e) : 2;
+  if (wn.halo < 0) wn.halo = 0;
+  const int rows = (DCN_FWD_THREADS + g.wo - 2) / g.wo + 1;  // output rows a tile of consecutive positions can touch
+  wn.wr = (rows - 1) * g.sh + (g.kh - 1) * g.dh + 2 + 2 * wn.halo;
+  wn.ws = wn.wr * g.w;
+  wn.ws = (wn.ws + 31) / 32 * 32;
+  if (wn.ws % 64 == 0) wn.ws += 32;  // channel cq+1 (upper half-wave) 32 banks away from channel cq
+  wn.nch = 0;
+  const char* nw = getenv("RTP_DCN_NOWIN");
+  if (nw && atoi(nw)) return wn;
+  for (int budget : {72 * 1024, 156 * 1024}) {
+    for (int n = cpg; n >= 2; --n) {
+      if (cpg % n || n % 2) continue;
+      if ((long)n * (wn.ws + wn.rs) * 4 <= budget) { wn.nch = n; return wn; }
+    }
+  }
+  return wn;
+}
+
 static void dcn_forward_fused(const float* input, const float* weight, const float* bias, const float* offset,
                               const float* mask, float* output, float* ws, const DcnGeom& g, hipStream_t s) {
   const int P = g.ho * g.wo, K = g.kh * g.kw, cpg = g.c / g.dg;
   const int cop = g.co > 32 ? 64 : 32, rs = dcn_fused_rs(K, cop);
   hipLaunchKernelGGL(dcn_wt_kernel, dim3((g.c * K * cop + 255) / 256), dim3(256), 0, s, weight, ws, g.co, g.c, K, cop);
   const dim3 grid((P + DCN_FWD_THREADS - 1) / DCN_FWD_THREADS, g.n);
+  const DcnWin wn = dcn_win_plan(g, cop);
+  if (wn.nch) {
+    const size_t lds = (size_t)wn.nch * (wn.ws + wn.rs) * sizeof(float);
+    if (cop == 32)
+      hipLaunchKernelGGL(dcn_win_fwd_kernel<1>, grid, dim3(DCN_FWD_THREADS), lds, s, input, offset, mask, ws, bias, output, g, wn);
+    else
+      hipLaunchKernelGGL(dcn_win_fwd_kernel<2>, grid, dim3(DCN_FWD_THREADS), lds, s, input, offset, mask, ws, bias, output, g, wn);
+    return;
+  }
   const size_t lds = (size_t)cpg * rs * sizeof(float);
   if (cop == 32)
     hipLaunchKernelGGL(dcn_fused_fwd_kernel<1>, grid, dim3(DCN_FWD_THREADS), lds, s, input, offset, mask, ws, bias, output, g, rs);

@@ -25,11 +25,22 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("unfused", ["0", "1"])
+MODES = {"window": {}, "gather": {"RTP_DCN_NOWIN": "1"}, "unfused": {"RTP_DCN_UNFUSED": "1"}}
+
+
+def set_mode(monkeypatch, mode):
+    """Forward paths of csrc/dcn.hip: LDS-window fused kernel (default), global-gather fused kernel, im2col + GEMM (the
+    only path for groups > 1 or an odd number of channels per deformable group)."""
+    for k in ("RTP_DCN_NOWIN", "RTP_DCN_UNFUSED"):
+        monkeypatch.delenv(k, raising=False)
+    for k, v in MODES[mode].items():
+        monkeypatch.setenv(k, v)
+
+
+@pytest.mark.parametrize("mode", list(MODES))
 @pytest.mark.parametrize("case", CASES)
-def test_dcn_v1_forward_backward(case, unfused, monkeypatch):
-    # RTP_DCN_UNFUSED=1: the im2col + GEMM forward (the only path for groups > 1 / odd channels per deformable group)
-    monkeypatch.setenv("RTP_DCN_UNFUSED", unfused)
+def test_dcn_v1_forward_backward(case, mode, monkeypatch):
+    set_mode(monkeypatch, mode)
     from rt_pose_amd.dcn import deform_conv
     n, c, h, w, co, k, stride, pad, dil, groups, dg, step = case
     x = rnd(n, c, h, w, seed=1).requires_grad_(True)
@@ -50,8 +61,28 @@ def test_dcn_v1_forward_backward(case, unfused, monkeypatch):
     assert rel_err(og.grad.cpu(), off.grad) < TOL
 
 
+@pytest.mark.parametrize("mode", list(MODES))
+@pytest.mark.parametrize("off_scale,halo", [(6.0, "2"), (3.0, "0"), (40.0, "1")])
+def test_dcn_forward_offsets_leaving_the_window(off_scale, halo, mode, monkeypatch):
+    """Offsets far larger than the staged halo (and past the image): the window kernel fetches those samples from global
+    memory per lane; every forward path must still give the oracle's result.  Several 512-position tiles per image."""
+    from rt_pose_amd.dcn import deform_conv
+    set_mode(monkeypatch, mode)
+    monkeypatch.setenv("RTP_DCN_HALO", halo)
+    n, c, h, w, co, dg = 2, 8, 48, 40, 8, 2
+    x = rnd(n, c, h, w, seed=11)
+    wt = rnd(co, c, 3, 3, seed=12, scale=0.2)
+    off = rnd(n, dg * 18, h, w, seed=13, scale=off_scale)
+    ref = deform_conv2d(x, off, wt, 1, 1, 1, 1, dg)
+    out = deform_conv(x.cuda(), off.cuda(), wt.cuda(), 1, 1, 1, 1, dg, 2)
+    torch.cuda.synchronize()
+    assert rel_err(out.cpu(), ref) < TOL
+
+
+@pytest.mark.parametrize("mode", list(MODES))
 @pytest.mark.parametrize("with_bias", [True, False])
-def test_dcn_v2_forward_backward(with_bias):
+def test_dcn_v2_forward_backward(with_bias, mode, monkeypatch):
+    set_mode(monkeypatch, mode)
     from rt_pose_amd.dcn import modulated_deform_conv
     n, c, h, w, co, k, dg = 2, 16, 10, 12, 8, 3, 2
     x = rnd(n, c, h, w, seed=5).requires_grad_(True)
