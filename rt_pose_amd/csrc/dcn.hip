@@ -85,25 +85,38 @@ __global__ __launch_bounds__(256) void dcn_col2im_plane_kernel(const float* col,
     const int ki = t / g.kw, kj = t - ki * g.kw;
     const float* colp = col + (((long)c * K + t) * step + bl) * P;
     const float* mk = mask ? mask + ((long)b * g.dg + dgi) * K * P + (long)t * P : nullptr;
-    for (int p = threadIdx.x; p < P; p += 256) {
-      const int wo = p % g.wo, ho = p / g.wo;
-      const float hi = ho * g.sh - g.ph + ki * g.dh + off[(2 * t) * P + p];
-      const float wi = wo * g.sw - g.pw + kj * g.dw + off[(2 * t + 1) * P + p];
-      if (!(hi > -1.f && wi > -1.f && hi < g.h && wi < g.w)) continue;
-      float top = colp[p];
-      if (mk) top *= mk[p];
-      const int h_low = (int)floorf(hi), w_low = (int)floorf(wi);
-      const float lh = hi - h_low, lw = wi - w_low;
+    // four positions per thread and round: their 12 loads are in flight together before the first LDS atomic
+    for (int pb = threadIdx.x; pb < P; pb += 4 * 256) {
+      float oh[4], ow[4], top[4];
 #pragma unroll
-      for (int dy = 0; dy < 2; ++dy)
+      for (int u = 0; u < 4; ++u) {
+        const int p = pb + u * 256;
+        const bool ok = p < P;
+        oh[u] = ok ? off[(2 * t) * P + p] : 0.f;
+        ow[u] = ok ? off[(2 * t + 1) * P + p] : 0.f;
+        top[u] = ok ? colp[p] * (mk ? mk[p] : 1.f) : 0.f;
+      }
 #pragma unroll
-        for (int dx = 0; dx < 2; ++dx) {
-          const int yy = h_low + dy, xx = w_low + dx;
-          if (yy >= 0 && yy <= g.h - 1 && xx >= 0 && xx <= g.w - 1) {
-            const float wgt = (dy ? lh : 1.f - lh) * (dx ? lw : 1.f - lw);
-            if (wgt != 0.f) atomicAdd(&plane[yy * g.w + xx], wgt * top);
+      for (int u = 0; u < 4; ++u) {
+        const int p = pb + u * 256;
+        if (p >= P) break;
+        const int wo = p % g.wo, ho = p / g.wo;
+        const float hi = ho * g.sh - g.ph + ki * g.dh + oh[u];
+        const float wi = wo * g.sw - g.pw + kj * g.dw + ow[u];
+        if (!(hi > -1.f && wi > -1.f && hi < g.h && wi < g.w)) continue;
+        const int h_low = (int)floorf(hi), w_low = (int)floorf(wi);
+        const float lh = hi - h_low, lw = wi - w_low;
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+          for (int dx = 0; dx < 2; ++dx) {
+            const int yy = h_low + dy, xx = w_low + dx;
+            if (yy >= 0 && yy <= g.h - 1 && xx >= 0 && xx <= g.w - 1) {
+              const float wgt = (dy ? lh : 1.f - lh) * (dx ? lw : 1.f - lw);
+              if (wgt != 0.f) atomicAdd(&plane[yy * g.w + xx], wgt * top[u]);
+            }
           }
-        }
+      }
     }
   }
   __syncthreads();
@@ -519,8 +532,9 @@ __global__ __launch_bounds__(DCN_FWD_THREADS) void dcn_win_fwd_kernel(const floa
   const int wcount = wn.wr * g.w;      // floats per staged channel
   const int f0 = wy0 * g.w;            // image-plane index of window element 0
   const bool vec4 = (g.w & 3) == 0;
+  float oh_n = pl_ok ? offb[pl] : 0.f, ow_n = pl_ok ? offb[P + pl] : 0.f;
+  float mv_n = (mkb && pl_ok) ? mkb[pl] : 1.f;
   for (int dgi = 0; dgi < g.dg; ++dgi) {
-    const float* offd = offb + (long)dgi * 2 * K * P;
     for (int c0 = 0; c0 < cpg; c0 += wn.nch) {
       const int cabs = dgi * cpg + c0;
       __syncthreads();
@@ -546,9 +560,17 @@ __global__ __launch_bounds__(DCN_FWD_THREADS) void dcn_win_fwd_kernel(const floa
       __syncthreads();
       for (int t = 0; t < K; ++t) {
         const int ki = t / g.kw, kj = t - ki * g.kw;
-        const float oh = pl_ok ? offd[(long)(2 * t) * P + pl] : 0.f;
-        const float ow = pl_ok ? offd[(long)(2 * t + 1) * P + pl] : 0.f;
-        const float mv_ = (mkb && pl_ok) ? mkb[((long)dgi * K + t) * P + pl] : 1.f;
+        const float oh = oh_n, ow = ow_n, mv_ = mv_n;
+        {  // the next tap's offsets (and mask) are loaded now and consumed one tap later
+          int tn = t + 1, dn = dgi;
+          if (tn == K) { tn = 0; if (c0 + wn.nch >= cpg) ++dn; }
+          if (dn < g.dg && pl_ok) {
+            const float* on = offb + ((long)dn * 2 * K + 2 * tn) * P + pl;
+            oh_n = on[0];
+            ow_n = on[P];
+            if (mkb) mv_n = mkb[((long)dn * K + tn) * P + pl];
+          }
+        }
         float w1[2], w2[2], w3[2], w4[2], mk[2];
         int la[2], ga0[2], ga1[2];
         bool lo_y[2], hi_x[2], miss[2];

@@ -29,6 +29,9 @@ def main():
     fwd = lambda: deform_conv(x, off, wt, 1, 1, 1, 1, 4, 64)
     ms_f = t(fwd)
     y = fwd()
+    if "fwd" in sys.argv:
+        print("forward %.3f ms" % ms_f)
+        return
     g = torch.randn_like(y)
 
     def fb():
