@@ -70,6 +70,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="(default) kept for compatibility")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-forward", action="store_true", help="skip the forward-only (config 2) leg")
     args = ap.parse_args()
 
     import torch
@@ -131,6 +132,31 @@ def main():
         "train_gflop_per_frame": round(train_flops_per_frame / 1e9, 2),
         "mfma_frac_whole_step": round(frames / elapsed * train_flops_per_frame / (world * PEAK_BF16_TFLOPS * 1e12), 4),
     }
+
+    # BASELINE config 2, reported beside the metric: forward + key-point decode only (the same plan's forward list; in
+    # training mode it also writes the statistics the backward needs), same batch, timed after the train steps
+    if not args.no_forward:
+        tr.engine.set_test_cfg(configs.test_cfg())
+        for _ in range(3):
+            tr.forward_only()
+        barrier()
+        t1 = time.perf_counter()
+        nf = max(10, args.steps)
+        for _ in range(nf):
+            with tr._on_stream():
+                tr.engine.run_forward()
+                tr.engine.run_decode()
+        barrier()
+        el_f = time.perf_counter() - t1
+        if world > 1:
+            t = torch.tensor([el_f], device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el_f = float(t)
+        line["forward_only"] = {"workload": "%s backbone + head forward + decode, %d frames/GPU, bf16 (BASELINE config 2)" % (args.model, args.batch),
+                                "value": round(world * args.batch * nf / el_f, 2), "unit": "frames/s",
+                                "ms_per_batch": round(1e3 * el_f / nf, 3),
+                                "mfma_frac": round(world * args.batch * nf / el_f * g.flops["conv_fwd"] / args.batch
+                                                   / (world * PEAK_BF16_TFLOPS * 1e12), 4)}
 
     if world == 1 and not args.no_roofline:
         be = tr.be
