@@ -486,6 +486,20 @@ __global__ __launch_bounds__(DCN_FWD_THREADS) void dcn_fused_fwd_kernel(const fl
 // leave the window is fetched with the buffer loads of the gather kernel instead -- per lane, under a wave-uniform
 // branch that is not taken when no lane of the wave missed -- so any offset field gives the reference's result; only
 // the speed depends on the offsets being small.
+// Both halves of a wave get the value the lower (q = 0) / upper (q = 1) half computed: v_permlane32_swap of a register
+// with a copy of itself yields (lo, lo) and (hi, hi).
+__device__ __forceinline__ void dcn_bcast_halves(unsigned v, unsigned (&o)[2]) {
+  const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+  o[0] = r[0];
+  o[1] = r[1];
+}
+__device__ __forceinline__ void dcn_bcast_halves(float v, float (&o)[2]) {
+  unsigned u[2];
+  dcn_bcast_halves(__float_as_uint(v), u);
+  o[0] = __uint_as_float(u[0]);
+  o[1] = __uint_as_float(u[1]);
+}
+
 struct DcnWin {
   int rs, halo, wr, ws, nch;  // weight row stride, halo rows, window rows, per-channel window stride (floats), channels per stage
 };
@@ -510,16 +524,8 @@ __global__ __launch_bounds__(DCN_FWD_THREADS) void dcn_win_fwd_kernel(const floa
   const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, g.c * HW * 4, 0x00020000);
   const int pl = p0 + lane;
   const bool pl_ok = pl < P;
-  int hin[2], win_[2];
-  bool pg_ok[2];
-#pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    const int pg = p0 + 32 * q + l32;
-    const int ho = pg / g.wo, wo = pg - ho * g.wo;
-    hin[q] = ho * g.sh - g.ph;
-    win_[q] = wo * g.sw - g.pw;
-    pg_ok[q] = pg < P;
-  }
+  const int ho_l = pl / g.wo, wo_l = pl - ho_l * g.wo;
+  const int hin_l = ho_l * g.sh - g.ph, win_l = wo_l * g.sw - g.pw;
   dcn_f32x16 acc[2][MT];
 #pragma unroll
   for (int q = 0; q < 2; ++q)
@@ -539,12 +545,23 @@ __global__ __launch_bounds__(DCN_FWD_THREADS) void dcn_win_fwd_kernel(const floa
       const int cabs = dgi * cpg + c0;
       __syncthreads();
       if (vec4) {
-        const int q4 = wcount >> 2;
-        for (int i = threadIdx.x; i < wn.nch * q4; i += DCN_FWD_THREADS) {
-          const int ch = i / q4, e = (i - ch * q4) * 4, f = f0 + e;
-          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (f >= 0 && f < HW) v = *(const float4*)(xb + (long)(cabs + ch) * HW + f);
-          *(float4*)&win[ch * wn.ws + e] = v;
+        // four 16-byte loads in flight per thread before the first LDS write (a stage costs ~2 memory latencies, not 8)
+        const int q4 = wcount >> 2, passes = (q4 + DCN_FWD_THREADS - 1) / DCN_FWD_THREADS, items = wn.nch * passes;
+        for (int it0 = 0; it0 < items; it0 += 4) {
+          float4 v[4];
+          int dst[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int it = it0 + u, ch = it / passes, e = ((it - ch * passes) * DCN_FWD_THREADS + threadIdx.x) * 4;
+            const int f = f0 + e;
+            const bool ok = it < items && e < wcount;
+            dst[u] = ok ? ch * wn.ws + e : -1;
+            v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ok && f >= 0 && f < HW) v[u] = *(const float4*)(xb + (long)(cabs + ch) * HW + f);
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            if (dst[u] >= 0) *(float4*)&win[dst[u]] = v[u];
         }
       } else {
         for (int i = threadIdx.x; i < wn.nch * wcount; i += DCN_FWD_THREADS) {
@@ -571,35 +588,47 @@ __global__ __launch_bounds__(DCN_FWD_THREADS) void dcn_win_fwd_kernel(const floa
             if (mkb) mv_n = mkb[((long)dn * K + tn) * P + pl];
           }
         }
+        // each lane works out ONE position's sample (its own: p0 + lane); the two 32-position MFMA column groups pick
+        // their values up with v_permlane32_swap: (lo, lo) and (hi, hi) of a register in one VALU instruction
         float w1[2], w2[2], w3[2], w4[2], mk[2];
         int la[2], ga0[2], ga1[2];
         bool lo_y[2], hi_x[2], miss[2];
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          const int src = (32 * q + l32) * 4;
-          const float ohq = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(oh)));
-          const float owq = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(ow)));
-          mk[q] = mkb ? __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(mv_))) : 1.f;
-          const float hi = hin[q] + ki * g.dh + ohq;
-          const float wi = win_[q] + kj * g.dw + owq;
-          const bool in = pg_ok[q] && hi > -1.f && wi > -1.f && hi < g.h && wi < g.w;
+        bool anymiss;
+        {
+          const float hi = hin_l + ki * g.dh + oh;
+          const float wi = win_l + kj * g.dw + ow;
+          const bool in = pl_ok && hi > -1.f && wi > -1.f && hi < g.h && wi < g.w;
           const float hf = floorf(hi), wf = floorf(wi);
           const int h_low = (int)hf, w_low = (int)wf;
           const float lh = hi - hf, lw = wi - wf, hh = 1.f - lh, hw = 1.f - lw;
           const bool c0_ = in && w_low >= 0, c1_ = in && w_low + 1 <= g.w - 1;
-          lo_y[q] = w_low + 1 > g.w - 1;
-          hi_x[q] = w_low < 0;
-          w1[q] = c0_ ? hh * hw : 0.f; w2[q] = c1_ ? hh * lw : 0.f; w3[q] = c0_ ? lh * hw : 0.f; w4[q] = c1_ ? lh * lw : 0.f;
-          const int xs = w_low < 0 ? 0 : (w_low + 1 <= g.w - 1 ? w_low : g.w - 2);
+          const bool loy = w_low + 1 > g.w - 1, hix = w_low < 0;
+          const int xs = hix ? 0 : (loy ? g.w - 2 : w_low);
           const int ry = h_low - wy0;
           const bool inwin = ry >= 0 && ry + 1 < wn.wr;  // both rows are staged (rows outside the image as zeros)
-          miss[q] = in && !inwin;
-          la[q] = (in && inwin) ? (ry * g.w + xs + half * wn.ws) * 4 : half * wn.ws * 4;
-          const int gbase = (h_low * g.w + xs + half * HW) * 4;
-          ga0[q] = (miss[q] && h_low >= 0) ? gbase : DCN_OOB;
-          ga1[q] = (miss[q] && h_low + 1 <= g.h - 1) ? gbase + g.w * 4 : DCN_OOB;
+          const bool missl = in && !inwin;
+          unsigned u[2];
+          dcn_bcast_halves((in && inwin) ? (unsigned)(ry * g.w + xs) * 4u : 0u, u);
+          la[0] = (int)u[0] + half * wn.ws * 4; la[1] = (int)u[1] + half * wn.ws * 4;
+          dcn_bcast_halves(c0_ ? hh * hw : 0.f, w1);
+          dcn_bcast_halves(c1_ ? hh * lw : 0.f, w2);
+          dcn_bcast_halves(c0_ ? lh * hw : 0.f, w3);
+          dcn_bcast_halves(c1_ ? lh * lw : 0.f, w4);
+          dcn_bcast_halves((loy ? 1u : 0u) | (hix ? 2u : 0u) | (missl ? 4u : 0u), u);
+#pragma unroll
+          for (int q = 0; q < 2; ++q) { lo_y[q] = u[q] & 1u; hi_x[q] = u[q] & 2u; miss[q] = u[q] & 4u; }
+          mk[0] = 1.f; mk[1] = 1.f;
+          if (mkb) dcn_bcast_halves(mv_, mk);
+          anymiss = __builtin_amdgcn_ballot_w64(missl) != 0;
+          ga0[0] = ga0[1] = ga1[0] = ga1[1] = DCN_OOB;
+          if (anymiss) {  // global pair addresses of the lanes whose sample left the window (others stay out of range)
+            const int gbase = (h_low * g.w + xs) * 4;
+            dcn_bcast_halves((missl && h_low >= 0) ? (unsigned)gbase : (unsigned)DCN_OOB, u);
+            ga0[0] = (int)u[0] + half * HW * 4; ga0[1] = (int)u[1] + half * HW * 4;
+            dcn_bcast_halves((missl && h_low + 1 <= g.h - 1) ? (unsigned)(gbase + g.w * 4) : (unsigned)DCN_OOB, u);
+            ga1[0] = (int)u[0] + half * HW * 4; ga1[1] = (int)u[1] + half * HW * 4;
+          }
         }
-        const bool anymiss = __builtin_amdgcn_ballot_w64(miss[0] || miss[1]) != 0;
         for (int cq = 0; cq < wn.nch; cq += 2) {
           float bv[2];
 #pragma unroll
