@@ -159,6 +159,114 @@ __global__ __launch_bounds__(256) void dcn_col2im_kernel(const float* col, const
   }
 }
 
+// ------------------------------------------------------------------------------------------------ col2im as a gather
+// grad_im without atomics for samples whose offsets are at most R pixels (the usual case: learned offsets are small).
+// A thread owns one pixel (y, x) of CH channels of one deformable group.  A sample (output position p, tap t) with
+// |offset| <= R can only touch the pixel if its undeformed tap position lies within R of it, so the thread walks those
+// (2R+1)^2 candidate positions per tap, recomputes the sample's bilinear weight for ITS pixel (the reference's weight
+// for whichever of the four corners the pixel is, deform_conv_cuda_kernel.cu:117-143) once for all CH channels and
+// accumulates col * weight in registers: coalesced loads (lanes = consecutive x -> consecutive wo), a fixed summation
+// order (bit-reproducible, unlike the atomic scatter), one plain read-modify-write of grad_im at the end.
+// Samples with a larger offset ("outliers") are skipped here and scattered by dcn_col2im_outlier_kernel with global
+// fp32 atomics, so any offset field gives the reference's result; only the speed depends on offsets being small.
+__device__ __forceinline__ int dcn_floor_div(int a, int b) {  // b > 0
+  const int q = a / b;
+  return (a % b != 0 && a < 0) ? q - 1 : q;
+}
+
+template <int CH>
+__global__ __launch_bounds__(256) void dcn_col2im_gather_kernel(const float* col, const float* offset, const float* mask,
+                                                                float* grad_im, DcnGeom g, int b0, int step, int R) {
+  const int P = g.ho * g.wo, K = g.kh * g.kw, HW = g.h * g.w;
+  const int cpg = g.c / g.dg, chunks = cpg / CH;
+  const long total = (long)step * g.dg * chunks * HW;
+  const float Rf = (float)R;
+  for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int x = (int)(idx % g.w), y = (int)((idx / g.w) % g.h);
+    const int ck = (int)((idx / HW) % chunks), dgi = (int)((idx / ((long)HW * chunks)) % g.dg);
+    const int bl = (int)(idx / ((long)HW * chunks * g.dg)), b = b0 + bl;
+    const int c0 = dgi * cpg + ck * CH;
+    const float* off = offset + ((long)b * g.dg + dgi) * 2 * K * P;
+    const float* mk = mask ? mask + ((long)b * g.dg + dgi) * K * P : nullptr;
+    float acc[CH];
+#pragma unroll
+    for (int cc = 0; cc < CH; ++cc) acc[cc] = 0.f;
+    for (int t = 0; t < K; ++t) {
+      const int ki = t / g.kw, kj = t - ki * g.kw;
+      // undeformed tap position ho*sh - ph + ki*dh within [y - R, y + R]
+      const int hb = g.ph - ki * g.dh, wb = g.pw - kj * g.dw;
+      int ho0 = dcn_floor_div(y - R + hb + g.sh - 1, g.sh), ho1 = dcn_floor_div(y + R + hb, g.sh);
+      int wo0 = dcn_floor_div(x - R + wb + g.sw - 1, g.sw), wo1 = dcn_floor_div(x + R + wb, g.sw);
+      ho0 = ho0 < 0 ? 0 : ho0; wo0 = wo0 < 0 ? 0 : wo0;
+      ho1 = ho1 > g.ho - 1 ? g.ho - 1 : ho1; wo1 = wo1 > g.wo - 1 ? g.wo - 1 : wo1;
+      const float* oh_t = off + (long)(2 * t) * P;
+      const float* ow_t = oh_t + P;
+      const float* colt = col + (((long)c0 * K + t) * step + bl) * P;
+      for (int ho = ho0; ho <= ho1; ++ho)
+        for (int wo = wo0; wo <= wo1; ++wo) {
+          const int p = ho * g.wo + wo;
+          const float oh = oh_t[p], ow = ow_t[p];
+          if (!(fabsf(oh) <= Rf && fabsf(ow) <= Rf)) continue;  // outlier: scattered by dcn_col2im_outlier_kernel
+          const float hi = ho * g.sh - g.ph + ki * g.dh + oh;
+          const float wi = wo * g.sw - g.pw + kj * g.dw + ow;
+          if (!(hi > -1.f && wi > -1.f && hi < g.h && wi < g.w)) continue;
+          const int h_low = (int)floorf(hi), w_low = (int)floorf(wi);
+          const int dy = y - h_low, dx = x - w_low;
+          if ((unsigned)dy > 1u || (unsigned)dx > 1u) continue;
+          const float lh = hi - h_low, lw = wi - w_low;
+          const float wgt = (dy ? lh : 1.f - lh) * (dx ? lw : 1.f - lw);
+          if (wgt == 0.f) continue;
+          const float m = mk ? mk[(long)t * P + p] : 1.f;
+#pragma unroll
+          for (int cc = 0; cc < CH; ++cc) acc[cc] += wgt * (colt[(long)cc * K * step * P + p] * m);
+        }
+    }
+    float* gim = grad_im + ((long)b * g.c + c0) * HW + y * g.w + x;
+#pragma unroll
+    for (int cc = 0; cc < CH; ++cc) gim[(long)cc * HW] += acc[cc];
+  }
+}
+
+// the samples the gather kernel leaves out: an offset component beyond R (or not a number)
+__global__ __launch_bounds__(256) void dcn_col2im_outlier_kernel(const float* col, const float* offset, const float* mask,
+                                                                 float* grad_im, DcnGeom g, int b0, int step, int R) {
+  const int P = g.ho * g.wo, K = g.kh * g.kw;
+  const long total = (long)step * g.dg * K * P;
+  const int cpg = g.c / g.dg;
+  const float Rf = (float)R;
+  for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int p = (int)(idx % P);
+    const int t = (int)((idx / P) % K);
+    const int dgi = (int)((idx / ((long)P * K)) % g.dg);
+    const int bl = (int)(idx / ((long)P * K * g.dg)), b = b0 + bl;
+    const float* off = offset + ((long)b * g.dg + dgi) * 2 * K * P;
+    const float oh = off[(long)(2 * t) * P + p], ow = off[(long)(2 * t + 1) * P + p];
+    if (fabsf(oh) <= Rf && fabsf(ow) <= Rf) continue;
+    const int wo = p % g.wo, ho = p / g.wo, ki = t / g.kw, kj = t - ki * g.kw;
+    const float hi = ho * g.sh - g.ph + ki * g.dh + oh;
+    const float wi = wo * g.sw - g.pw + kj * g.dw + ow;
+    if (!(hi > -1.f && wi > -1.f && hi < g.h && wi < g.w)) continue;
+    const int h_low = (int)floorf(hi), w_low = (int)floorf(wi);
+    const float lh = hi - h_low, lw = wi - w_low;
+    const float m = mask ? mask[((long)b * g.dg + dgi) * K * P + (long)t * P + p] : 1.f;
+    for (int cc = 0; cc < cpg; ++cc) {
+      const int c = dgi * cpg + cc;
+      const float top = col[(((long)c * K + t) * step + bl) * P + p] * m;
+      float* gim = grad_im + ((long)b * g.c + c) * g.h * g.w;
+#pragma unroll
+      for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+          const int yy = h_low + dy, xx = w_low + dx;
+          if (yy >= 0 && yy <= g.h - 1 && xx >= 0 && xx <= g.w - 1) {
+            const float wgt = (dy ? lh : 1.f - lh) * (dx ? lw : 1.f - lw);
+            if (wgt != 0.f) atomicAdd(gim + yy * g.w + xx, wgt * top);
+          }
+        }
+    }
+  }
+}
+
 __device__ __forceinline__ float dcn_coord_weight(const float* im, int H, int W, float h, float w, int dir) {
   // d bilinear / d h (dir 0) or / d w (dir 1), per-corner bounds as the forward (kernel.cu:145-188)
   const int h_low = (int)floorf(h), w_low = (int)floorf(w);
@@ -799,7 +907,23 @@ static int dcn_backward_input(const float* input, const float* offset, const flo
     }
     hipLaunchKernelGGL(dcn_col2im_coord_kernel, dim3(grid1d((long)step * g.dg * K * P)), dim3(256), 0, s, ws, input,
                        offset, mask, gradOffset, gradMask, g, b0, step);
-    if ((size_t)g.h * g.w * sizeof(float) <= 60 * 1024)
+    const char* re = getenv("RTP_DCN_GATHER_R");
+    const int R = re ? atoi(re) : 2;  // offsets up to R pixels take the atomic-free gather; 0: scatter everything
+    if (R > 0) {
+      const int cpg = g.c / g.dg;
+      const int ch = cpg % 8 == 0 ? 8 : cpg % 4 == 0 ? 4 : cpg % 2 == 0 ? 2 : 1;
+      const int blocks = grid1d((long)step * g.dg * (cpg / ch) * g.h * g.w);
+#define DCN_GATHER(CH_) \
+  hipLaunchKernelGGL(dcn_col2im_gather_kernel<CH_>, dim3(blocks), dim3(256), 0, s, ws, offset, mask, gradInput, g, b0, step, R)
+      switch (ch) {
+        case 8: DCN_GATHER(8); break;
+        case 4: DCN_GATHER(4); break;
+        case 2: DCN_GATHER(2); break;
+        default: DCN_GATHER(1); break;
+      }
+      hipLaunchKernelGGL(dcn_col2im_outlier_kernel, dim3(grid1d((long)step * g.dg * K * P)), dim3(256), 0, s, ws, offset, mask,
+                         gradInput, g, b0, step, R);
+    } else if ((size_t)g.h * g.w * sizeof(float) <= 60 * 1024)
       hipLaunchKernelGGL(dcn_col2im_plane_kernel, dim3(step * g.c), dim3(256), sizeof(float) * g.h * g.w, s, ws, offset, mask,
                          gradInput, g, b0, step);
     else

@@ -79,6 +79,43 @@ def test_dcn_forward_offsets_leaving_the_window(off_scale, halo, mode, monkeypat
     assert rel_err(out.cpu(), ref) < TOL
 
 
+@pytest.mark.parametrize("R", ["0", "1", "3"])
+@pytest.mark.parametrize("off_scale", [0.4, 2.5])
+def test_dcn_grad_input_gather_radius(R, off_scale, monkeypatch):
+    """grad_input paths of csrc/dcn.hip: atomic-free gather for offsets <= R pixels + atomic scatter of the outliers
+    (R = 0: everything through the LDS-plane scatter).  Stride 2 / dilation 2 / modulated cases included."""
+    from rt_pose_amd.dcn import deform_conv, modulated_deform_conv
+    monkeypatch.setenv("RTP_DCN_GATHER_R", R)
+    for (n, c, h, w, co, stride, pad, dil, dg) in [(2, 8, 20, 24, 8, 1, 1, 1, 2), (2, 6, 21, 17, 4, 2, 2, 2, 3)]:
+        x = rnd(n, c, h, w, seed=21).requires_grad_(True)
+        wt = rnd(co, c, 3, 3, seed=22, scale=0.2).requires_grad_(True)
+        ho = (h + 2 * pad - (dil * 2 + 1)) // stride + 1
+        wo = (w + 2 * pad - (dil * 2 + 1)) // stride + 1
+        off = rnd(n, dg * 18, ho, wo, seed=23, scale=off_scale).requires_grad_(True)
+        ref = deform_conv2d(x, off, wt, stride, pad, dil, 1, dg)
+        gy = rnd(*ref.shape, seed=24)
+        ref.backward(gy)
+        xg, wg, og = [t.detach().cuda().requires_grad_(True) for t in (x, wt, off)]
+        deform_conv(xg, og, wg, stride, pad, dil, 1, dg, n).backward(gy.cuda())
+        torch.cuda.synchronize()
+        assert rel_err(xg.grad.cpu(), x.grad) < TOL
+        assert rel_err(og.grad.cpu(), off.grad) < TOL
+    # modulated (mask multiplies the column gradient before the scatter)
+    n, c, h, w, co, dg = 2, 8, 14, 18, 4, 2
+    x = rnd(n, c, h, w, seed=31).requires_grad_(True)
+    wt = rnd(co, c, 3, 3, seed=32, scale=0.2).requires_grad_(True)
+    off = rnd(n, dg * 18, h, w, seed=33, scale=off_scale).requires_grad_(True)
+    m = torch.sigmoid(rnd(n, dg * 9, h, w, seed=34)).requires_grad_(True)
+    ref = deform_conv2d(x, off, wt, 1, 1, 1, 1, dg, mask=m)
+    gy = rnd(*ref.shape, seed=35)
+    ref.backward(gy)
+    ts = [t.detach().cuda().requires_grad_(True) for t in (x, off, m, wt)]
+    modulated_deform_conv(ts[0], ts[1], ts[2], ts[3], None, 1, 1, 1, 1, dg).backward(gy.cuda())
+    torch.cuda.synchronize()
+    for got, want in zip(ts, (x, off, m, wt)):
+        assert rel_err(got.grad.cpu(), want.grad) < TOL
+
+
 @pytest.mark.parametrize("mode", list(MODES))
 @pytest.mark.parametrize("with_bias", [True, False])
 def test_dcn_v2_forward_backward(with_bias, mode, monkeypatch):
