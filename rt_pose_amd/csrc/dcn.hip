@@ -174,53 +174,82 @@ __device__ __forceinline__ int dcn_floor_div(int a, int b) {  // b > 0
   return (a % b != 0 && a < 0) ? q - 1 : q;
 }
 
+// A block owns an 8 x 32 pixel tile of CH channels of one deformable group.  Per tap it stages the candidate output
+// positions of the whole tile -- (8 + 2R) x (32 + 2R) at stride 1 -- in LDS: the two offsets and CH column values
+// (pre-multiplied by the mask) per position, positions outside the output marked with a huge offset.  Every column
+// element then crosses the memory system ~1.7x instead of once per candidate pixel (the un-tiled version of this kernel
+// moved 17 GB per launch through L2 and ran at its bandwidth).
+#define DCN_GT_Y 8
+#define DCN_GT_X 32
 template <int CH>
 __global__ __launch_bounds__(256) void dcn_col2im_gather_kernel(const float* col, const float* offset, const float* mask,
-                                                                float* grad_im, DcnGeom g, int b0, int step, int R) {
+                                                                float* grad_im, DcnGeom g, int b0, int step, int R,
+                                                                int rh_max, int rw_max) {
+  extern __shared__ float reg[];  // [2 + CH][rh_max * rw_max]
   const int P = g.ho * g.wo, K = g.kh * g.kw, HW = g.h * g.w;
   const int cpg = g.c / g.dg, chunks = cpg / CH;
-  const long total = (long)step * g.dg * chunks * HW;
+  const int tiles_x = (g.w + DCN_GT_X - 1) / DCN_GT_X, tiles_y = (g.h + DCN_GT_Y - 1) / DCN_GT_Y;
+  int bid = blockIdx.x;
+  const int tx = bid % tiles_x; bid /= tiles_x;
+  const int ty = bid % tiles_y; bid /= tiles_y;
+  const int ck = bid % chunks; bid /= chunks;
+  const int dgi = bid % g.dg, bl = bid / g.dg, b = b0 + bl;
+  const int c0 = dgi * cpg + ck * CH;
+  const int y0 = ty * DCN_GT_Y, x0 = tx * DCN_GT_X;
+  const int x = x0 + (threadIdx.x & (DCN_GT_X - 1)), y = y0 + (threadIdx.x >> 5);
+  const bool pix_ok = x < g.w && y < g.h;
   const float Rf = (float)R;
-  for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-    const int x = (int)(idx % g.w), y = (int)((idx / g.w) % g.h);
-    const int ck = (int)((idx / HW) % chunks), dgi = (int)((idx / ((long)HW * chunks)) % g.dg);
-    const int bl = (int)(idx / ((long)HW * chunks * g.dg)), b = b0 + bl;
-    const int c0 = dgi * cpg + ck * CH;
-    const float* off = offset + ((long)b * g.dg + dgi) * 2 * K * P;
-    const float* mk = mask ? mask + ((long)b * g.dg + dgi) * K * P : nullptr;
-    float acc[CH];
+  const int plane = rh_max * rw_max;
+  const float* off = offset + ((long)b * g.dg + dgi) * 2 * K * P;
+  const float* mk = mask ? mask + ((long)b * g.dg + dgi) * K * P : nullptr;
+  float acc[CH];
 #pragma unroll
-    for (int cc = 0; cc < CH; ++cc) acc[cc] = 0.f;
-    for (int t = 0; t < K; ++t) {
-      const int ki = t / g.kw, kj = t - ki * g.kw;
-      // undeformed tap position ho*sh - ph + ki*dh within [y - R, y + R]
-      const int hb = g.ph - ki * g.dh, wb = g.pw - kj * g.dw;
-      int ho0 = dcn_floor_div(y - R + hb + g.sh - 1, g.sh), ho1 = dcn_floor_div(y + R + hb, g.sh);
-      int wo0 = dcn_floor_div(x - R + wb + g.sw - 1, g.sw), wo1 = dcn_floor_div(x + R + wb, g.sw);
-      ho0 = ho0 < 0 ? 0 : ho0; wo0 = wo0 < 0 ? 0 : wo0;
-      ho1 = ho1 > g.ho - 1 ? g.ho - 1 : ho1; wo1 = wo1 > g.wo - 1 ? g.wo - 1 : wo1;
-      const float* oh_t = off + (long)(2 * t) * P;
-      const float* ow_t = oh_t + P;
-      const float* colt = col + (((long)c0 * K + t) * step + bl) * P;
-      for (int ho = ho0; ho <= ho1; ++ho)
-        for (int wo = wo0; wo <= wo1; ++wo) {
-          const int p = ho * g.wo + wo;
-          const float oh = oh_t[p], ow = ow_t[p];
-          if (!(fabsf(oh) <= Rf && fabsf(ow) <= Rf)) continue;  // outlier: scattered by dcn_col2im_outlier_kernel
-          const float hi = ho * g.sh - g.ph + ki * g.dh + oh;
-          const float wi = wo * g.sw - g.pw + kj * g.dw + ow;
-          if (!(hi > -1.f && wi > -1.f && hi < g.h && wi < g.w)) continue;
-          const int h_low = (int)floorf(hi), w_low = (int)floorf(wi);
-          const int dy = y - h_low, dx = x - w_low;
-          if ((unsigned)dy > 1u || (unsigned)dx > 1u) continue;
-          const float lh = hi - h_low, lw = wi - w_low;
-          const float wgt = (dy ? lh : 1.f - lh) * (dx ? lw : 1.f - lw);
-          if (wgt == 0.f) continue;
-          const float m = mk ? mk[(long)t * P + p] : 1.f;
+  for (int cc = 0; cc < CH; ++cc) acc[cc] = 0.f;
+  for (int t = 0; t < K; ++t) {
+    const int ki = t / g.kw, kj = t - ki * g.kw;
+    const int hb = g.ph - ki * g.dh, wb = g.pw - kj * g.dw;
+    // candidate output positions of the tile: undeformed tap position within R of some tile pixel
+    const int rho0 = dcn_floor_div(y0 - R + hb + g.sh - 1, g.sh), rho1 = dcn_floor_div(y0 + DCN_GT_Y - 1 + R + hb, g.sh);
+    const int rwo0 = dcn_floor_div(x0 - R + wb + g.sw - 1, g.sw), rwo1 = dcn_floor_div(x0 + DCN_GT_X - 1 + R + wb, g.sw);
+    const int rh = rho1 - rho0 + 1, rw = rwo1 - rwo0 + 1;  // <= rh_max, rw_max
+    const float* colt = col + (((long)c0 * K + t) * step + bl) * P;
+    __syncthreads();
+    for (int i = threadIdx.x; i < rh * rw; i += 256) {
+      const int r = i / rw, cidx = i - r * rw;
+      const int ho = rho0 + r, wo = rwo0 + cidx;
+      const bool ok = ho >= 0 && ho < g.ho && wo >= 0 && wo < g.wo;
+      const int p = ho * g.wo + wo;
+      reg[i] = ok ? off[(long)(2 * t) * P + p] : 1e30f;
+      reg[plane + i] = ok ? off[(long)(2 * t + 1) * P + p] : 1e30f;
+      const float m = (ok && mk) ? mk[(long)t * P + p] : 1.f;
 #pragma unroll
-          for (int cc = 0; cc < CH; ++cc) acc[cc] += wgt * (colt[(long)cc * K * step * P + p] * m);
-        }
+      for (int cc = 0; cc < CH; ++cc) reg[(2 + cc) * plane + i] = ok ? colt[(long)cc * K * step * P + p] * m : 0.f;
     }
+    __syncthreads();
+    if (!pix_ok) continue;
+    int ho0 = dcn_floor_div(y - R + hb + g.sh - 1, g.sh), ho1 = dcn_floor_div(y + R + hb, g.sh);
+    int wo0 = dcn_floor_div(x - R + wb + g.sw - 1, g.sw), wo1 = dcn_floor_div(x + R + wb, g.sw);
+    ho0 = ho0 < rho0 ? rho0 : ho0; wo0 = wo0 < rwo0 ? rwo0 : wo0;
+    ho1 = ho1 > rho1 ? rho1 : ho1; wo1 = wo1 > rwo1 ? rwo1 : wo1;
+    for (int ho = ho0; ho <= ho1; ++ho)
+      for (int wo = wo0; wo <= wo1; ++wo) {
+        const int i = (ho - rho0) * rw + (wo - rwo0);
+        const float oh = reg[i], ow = reg[plane + i];
+        if (!(fabsf(oh) <= Rf && fabsf(ow) <= Rf)) continue;  // outlier (or outside the output): not gathered here
+        const float hi = ho * g.sh - g.ph + ki * g.dh + oh;
+        const float wi = wo * g.sw - g.pw + kj * g.dw + ow;
+        if (!(hi > -1.f && wi > -1.f && hi < g.h && wi < g.w)) continue;
+        const int h_low = (int)floorf(hi), w_low = (int)floorf(wi);
+        const int dy = y - h_low, dx = x - w_low;
+        if ((unsigned)dy > 1u || (unsigned)dx > 1u) continue;
+        const float lh = hi - h_low, lw = wi - w_low;
+        const float wgt = (dy ? lh : 1.f - lh) * (dx ? lw : 1.f - lw);
+        if (wgt == 0.f) continue;
+#pragma unroll
+        for (int cc = 0; cc < CH; ++cc) acc[cc] += wgt * reg[(2 + cc) * plane + i];
+      }
+  }
+  if (pix_ok) {
     float* gim = grad_im + ((long)b * g.c + c0) * HW + y * g.w + x;
 #pragma unroll
     for (int cc = 0; cc < CH; ++cc) gim[(long)cc * HW] += acc[cc];
@@ -909,12 +938,16 @@ static int dcn_backward_input(const float* input, const float* offset, const flo
                        offset, mask, gradOffset, gradMask, g, b0, step);
     const char* re = getenv("RTP_DCN_GATHER_R");
     const int R = re ? atoi(re) : 2;  // offsets up to R pixels take the atomic-free gather; 0: scatter everything
-    if (R > 0) {
+    if (R > 0 && R <= 8) {
       const int cpg = g.c / g.dg;
       const int ch = cpg % 8 == 0 ? 8 : cpg % 4 == 0 ? 4 : cpg % 2 == 0 ? 2 : 1;
-      const int blocks = grid1d((long)step * g.dg * (cpg / ch) * g.h * g.w);
-#define DCN_GATHER(CH_) \
-  hipLaunchKernelGGL(dcn_col2im_gather_kernel<CH_>, dim3(blocks), dim3(256), 0, s, ws, offset, mask, gradInput, g, b0, step, R)
+      const int tiles = ((g.h + DCN_GT_Y - 1) / DCN_GT_Y) * ((g.w + DCN_GT_X - 1) / DCN_GT_X);
+      const int blocks = step * g.dg * (cpg / ch) * tiles;
+      const int rh_max = (DCN_GT_Y - 1 + 2 * R) / g.sh + 2, rw_max = (DCN_GT_X - 1 + 2 * R) / g.sw + 2;
+      const size_t lds = (size_t)(2 + ch) * rh_max * rw_max * sizeof(float);
+#define DCN_GATHER(CH_)                                                                                              \
+  hipLaunchKernelGGL(dcn_col2im_gather_kernel<CH_>, dim3(blocks), dim3(256), lds, s, ws, offset, mask, gradInput, g, b0, \
+                     step, R, rh_max, rw_max)
       switch (ch) {
         case 8: DCN_GATHER(8); break;
         case 4: DCN_GATHER(4); break;
