@@ -429,6 +429,164 @@ static void sgemm(hipStream_t s, MatView A, MatView B, MatView C, int M, int N, 
   hipLaunchKernelGGL(sgemm_kernel, grid, dim3(256), 0, s, A, B, C, M, N, K, alpha, beta, kchunk);
 }
 
+// ------------------------------------------------------------------------------------------------ skinny MFMA GEMMs
+// The two GEMMs of the DCN backward have one long dimension (step * P = 655 360 positions) and two short ones
+// (cog <= 64 output channels, cg * K = 288 column rows): HBM-bound (755 MB of columns written / read), which the
+// 64x64x16 VALU tile kernel above does not reach (0.87 ms each).  Both run on v_mfma_f32_32x32x2_f32 (exact fp32).
+typedef float dcn_f32x16 __attribute__((ext_vector_type(16)));
+
+// columns[r][n] = sum_co W[co][r] * gO[b0 + n / P][co][n % P]      (r < ck = cg * K, n < step * P)
+// A = W^T from LDS ([co][r], one ds_read_b32 per MFMA), B = gO straight from global memory (a half-wave reads 32
+// consecutive positions of one channel = 128 contiguous bytes) held in registers for all row tiles; a wave owns 64
+// positions and walks the ck / 32 row tiles; each accumulator row is a 128-byte contiguous store.
+template <int KP>  // KP = ceil(cog / 2) k-steps held in registers
+__global__ __launch_bounds__(256) void dcn_colgrad_mfma_kernel(const float* w, const float* go, float* cols, int cog,
+                                                               int ck_total, int rows_per_block, int co_total, int P, long N) {
+  extern __shared__ float wl[];  // [2 * KP][ckp] (rows >= cog and columns >= ck are zero)
+  // blockIdx.y: chunk of column rows (the weight slice of a chunk must fit LDS; the gO tile is re-read per chunk)
+  const int r0 = blockIdx.y * rows_per_block;
+  const int ck = ck_total - r0 < rows_per_block ? ck_total - r0 : rows_per_block;
+  cols += (long)r0 * N;
+  const int ckp = (ck + 31) / 32 * 32;
+  for (int i = threadIdx.x; i < 2 * KP * ckp; i += 256) {
+    const int co = i / ckp, r = i - co * ckp;
+    wl[i] = (co < cog && r < ck) ? w[(long)co * ck_total + r0 + r] : 0.f;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, l32 = lane & 31;
+  const long n0 = (blockIdx.x * 4L + wave) * 64;
+  float bv[2][KP];
+  long nn[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    nn[q] = n0 + 32 * q + l32;
+    const bool ok = nn[q] < N;
+    const long bl = ok ? nn[q] / P : 0;
+    const int p = ok ? (int)(nn[q] - bl * P) : 0;
+    const float* src = go + (bl * co_total) * P + p;
+#pragma unroll
+    for (int kk = 0; kk < KP; ++kk) {
+      const int co = 2 * kk + half;
+      bv[q][kk] = (ok && co < cog) ? src[(long)co * P] : 0.f;
+    }
+  }
+  for (int rt = 0; rt < ckp / 32; ++rt) {
+    dcn_f32x16 acc[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < KP; ++kk) {
+      const float a = wl[(2 * kk + half) * ckp + rt * 32 + l32];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv[q][kk], acc[q], 0, 0, 0);
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      if (nn[q] >= N) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = rt * 32 + 8 * (r >> 2) + 4 * half + (r & 3);
+        if (row < ck) cols[(long)row * N + nn[q]] = acc[q][r];
+      }
+    }
+  }
+}
+
+// gradW[co][r] += scale * sum_n gO[b0 + n / P][co][n % P] * cols[r][n]     (co < cog <= 32, r < ck <= 288; P % 64 == 0)
+// The contraction runs over positions, contiguous in memory for BOTH operands, while the MFMA wants lane l to hold
+// (row l % 32, k = l / 32).  Summation order is free, so within a unit of 64 positions lane-half h takes positions
+// 32h .. 32h+31 of its row as eight 16-byte loads: the first load of a 128-byte line misses, the seven issued right
+// behind it hit L1, and every line crosses L2 once.  A wave keeps all ck / 32 column tiles as accumulators (<= 144
+// registers), walks its share of the 64-position units and adds its partial result to gradW with fp32 atomics.
+#define DCN_GW_TILES 9
+__global__ __launch_bounds__(64) void dcn_gradw_mfma_kernel(const float* go, const float* cols, float* gw, int cog,
+                                                            int ck_total, int co_total, int P, long N, float scale,
+                                                            int units_per_wave) {
+  const int lane = threadIdx.x, half = lane >> 5, l32 = lane & 31;
+  // blockIdx.y: chunk of 9 column tiles (288 rows of the column matrix); the gO tile is re-read per chunk
+  const int r0 = blockIdx.y * 32 * DCN_GW_TILES;
+  const int ck = ck_total - r0 < 32 * DCN_GW_TILES ? ck_total - r0 : 32 * DCN_GW_TILES;
+  cols += (long)r0 * N;
+  gw += r0;
+  const int ntiles = (ck + 31) / 32;
+  dcn_f32x16 acc[DCN_GW_TILES];
+#pragma unroll
+  for (int t = 0; t < DCN_GW_TILES; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  const long units = N / 64;
+  const long u0 = (long)blockIdx.x * units_per_wave;
+  for (long u = u0; u < u0 + units_per_wave && u < units; ++u) {
+    const long n = u * 64 + 32 * half;  // this half's 32 positions (one image: P % 64 == 0)
+    const long bl = n / P;
+    const int p = (int)(n - bl * P);
+    float4 a4[8];
+    {
+      const float* src = go + (bl * co_total + l32) * P + p;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a4[j] = l32 < cog ? *(const float4*)(src + 4 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int t = 0; t < DCN_GW_TILES; ++t) {
+      if (t >= ntiles) break;
+      const int row = t * 32 + l32;
+      float4 b4[8];
+      const float* src = cols + (long)row * N + n;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) b4[j] = row < ck ? *(const float4*)(src + 4 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j].x, b4[j].x, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j].y, b4[j].y, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j].z, b4[j].z, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j].w, b4[j].w, acc[t], 0, 0, 0);
+      }
+    }
+  }
+  // D[m = co][n = r]: lane l, register i -> n = l % 32, m = 8 * (i / 4) + 4 * (l / 32) + i % 4
+#pragma unroll
+  for (int t = 0; t < DCN_GW_TILES; ++t) {
+    if (t >= ntiles) break;
+    const int r = t * 32 + l32;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int co = 8 * (i >> 2) + 4 * half + (i & 3);
+      if (co < cog && r < ck) atomicAdd(gw + (long)co * ck_total + r, scale * acc[t][i]);
+    }
+  }
+}
+
+// dispatchers: true when the MFMA kernel took the GEMM
+static bool dcn_colgrad_mfma(hipStream_t s, const float* w, const float* go, float* cols, int cog, int ck, int co_total,
+                             int P, long N) {
+  const char* e = getenv("RTP_DCN_VALU_GEMM");
+  if ((e && atoi(e)) || cog > 64) return false;
+  const int kp = (cog + 1) / 2;
+  const int kpt = kp <= 8 ? 8 : kp <= 16 ? 16 : 32;
+  int rpb = (48 * 1024 / (2 * kpt * (int)sizeof(float))) / 32 * 32;  // column rows per block: weight slice <= 48 KB of LDS
+  if (rpb > (ck + 31) / 32 * 32) rpb = (ck + 31) / 32 * 32;
+  const size_t lds = (size_t)2 * kpt * rpb * sizeof(float);
+  const dim3 grid((unsigned)((N + 255) / 256), (unsigned)((ck + rpb - 1) / rpb));
+  if (kpt == 8) hipLaunchKernelGGL(dcn_colgrad_mfma_kernel<8>, grid, dim3(256), lds, s, w, go, cols, cog, ck, rpb, co_total, P, N);
+  else if (kpt == 16) hipLaunchKernelGGL(dcn_colgrad_mfma_kernel<16>, grid, dim3(256), lds, s, w, go, cols, cog, ck, rpb, co_total, P, N);
+  else hipLaunchKernelGGL(dcn_colgrad_mfma_kernel<32>, grid, dim3(256), lds, s, w, go, cols, cog, ck, rpb, co_total, P, N);
+  return true;
+}
+
+static bool dcn_gradw_mfma(hipStream_t s, const float* go, const float* cols, float* gw, int cog, int ck, int co_total,
+                           int P, long N, float scale) {
+  const char* e = getenv("RTP_DCN_VALU_GEMM");
+  if ((e && atoi(e)) || cog > 32 || P % 64) return false;
+  const long units = N / 64;
+  int upw = (int)((units + 1023) / 1024);  // ~1024 waves: one per SIMD
+  if (upw < 1) upw = 1;
+  const dim3 blocks((unsigned)((units + upw - 1) / upw), (unsigned)((ck + 32 * DCN_GW_TILES - 1) / (32 * DCN_GW_TILES)));
+  hipLaunchKernelGGL(dcn_gradw_mfma_kernel, blocks, dim3(64), 0, s, go, cols, gw, cog, ck, co_total, P, N, scale, upw);
+  return true;
+}
+
 static inline MatView mv(const float* p, long s_row, long s_col, int split = 1 << 30, long s_outer = 0) {
   return MatView{const_cast<float*>(p), s_row, s_col, split, s_outer};
 }
@@ -472,7 +630,6 @@ __global__ __launch_bounds__(256) void dcn_bias_grad_kernel(const float* go, flo
 // with a row stride that puts the two half-waves on disjoint banks.  Corner loads go through a buffer resource over the
 // image, so an out-of-range corner is a voffset past num_records and reads 0 (the reference's per-corner bounds,
 // deform_conv_cuda_kernel.cu:85-115).
-typedef float dcn_f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned dcn_u32x2 __attribute__((ext_vector_type(2)));
 #define DCN_OOB ((int)0x80000000)
 
@@ -930,9 +1087,11 @@ static int dcn_backward_input(const float* input, const float* offset, const flo
   for (int b0 = 0; b0 < g.n; b0 += step) {
     for (int gi = 0; gi < g.group; ++gi) {
       // columns[gi] (cg*K x step*P) = W[gi]^T (cg*K x cog) . gradOut chunk (cog x step*P)
-      sgemm(s, mv(weight + (long)gi * cog * cg * K, 1, (long)cg * K),
-            mv(gradOutput + ((long)b0 * g.co + gi * cog) * P, P, 1, P, (long)g.co * P),
-            mv(ws + (long)gi * cg * K * step * P, (long)step * P, 1), cg * K, step * P, cog, 1.f, 0.f);
+      if (!dcn_colgrad_mfma(s, weight + (long)gi * cog * cg * K, gradOutput + ((long)b0 * g.co + gi * cog) * P,
+                            ws + (long)gi * cg * K * step * P, cog, cg * K, g.co, P, (long)step * P))
+        sgemm(s, mv(weight + (long)gi * cog * cg * K, 1, (long)cg * K),
+              mv(gradOutput + ((long)b0 * g.co + gi * cog) * P, P, 1, P, (long)g.co * P),
+              mv(ws + (long)gi * cg * K * step * P, (long)step * P, 1), cg * K, step * P, cog, 1.f, 0.f);
     }
     hipLaunchKernelGGL(dcn_col2im_coord_kernel, dim3(grid1d((long)step * g.dg * K * P)), dim3(256), 0, s, ws, input,
                        offset, mask, gradOffset, gradMask, g, b0, step);
@@ -977,9 +1136,11 @@ static int dcn_backward_params(const float* input, const float* offset, const fl
                        g, b0, step);
     for (int gi = 0; gi < g.group; ++gi) {
       // gradW[gi] (cog x cg*K) += scale * gradOut chunk (cog x step*P) . columns[gi]^T (step*P x cg*K)
-      sgemm(s, mv(gradOutput + ((long)b0 * g.co + gi * cog) * P, P, 1, P, (long)g.co * P),
-            mv(ws + (long)gi * cg * K * step * P, 1, (long)step * P),
-            mv(gradWeight + (long)gi * cog * cg * K, (long)cg * K, 1), cog, cg * K, step * P, scale, 1.f);
+      if (!dcn_gradw_mfma(s, gradOutput + ((long)b0 * g.co + gi * cog) * P, ws + (long)gi * cg * K * step * P,
+                          gradWeight + (long)gi * cog * cg * K, cog, cg * K, g.co, P, (long)step * P, scale))
+        sgemm(s, mv(gradOutput + ((long)b0 * g.co + gi * cog) * P, P, 1, P, (long)g.co * P),
+              mv(ws + (long)gi * cg * K * step * P, 1, (long)step * P),
+              mv(gradWeight + (long)gi * cog * cg * K, (long)cg * K, 1), cog, cg * K, step * P, scale, 1.f);
     }
   }
   RTP_CHECK_LAUNCH();

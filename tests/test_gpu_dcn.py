@@ -21,6 +21,8 @@ CASES = [
     (4, 16, 12, 10, 8, 3, 2, 1, 1, 2, 4, 2),
     (2, 64, 16, 20, 64, 3, 1, 1, 1, 1, 4, 64),     # FeatureAdaption shape: 3x3, pad 1, deformable_groups=4 (center_head.py:24-62)
     (1, 4, 7, 7, 4, 3, 1, 2, 2, 1, 2, 64),
+    (2, 8, 16, 16, 8, 3, 1, 1, 1, 1, 2, 2),        # P = 256: the MFMA weight-gradient GEMM (needs P % 64 == 0, <= 32 output channels)
+    (2, 40, 8, 8, 24, 3, 1, 1, 1, 1, 4, 1),        # 360 column rows: two row chunks in both MFMA GEMMs of the backward
     (3, 12, 33, 41, 40, 3, 1, 1, 1, 1, 2, 3),      # ragged: P = 1353 is no multiple of the 256-position block, co = 40 -> two MFMA row tiles
 ]
 
