@@ -67,6 +67,57 @@ __global__ __launch_bounds__(256) void dcn_im2col_kernel(const float* x, const f
   }
 }
 
+// im2col with the sample set-up shared by a deformable group: one thread per (image, deformable group, position) computes
+// each tap's coordinates and bilinear weights once and walks the group's channels (the kernel above recomputes them per
+// channel); corners come as 8-byte column pairs through a buffer resource over the image (out-of-image rows = offset
+// past num_records = zeros; see dcn_fused_fwd_kernel).  Column writes stay coalesced along p.
+typedef unsigned dcn_u32x2 __attribute__((ext_vector_type(2)));
+#define DCN_OOB ((int)0x80000000)
+__global__ __launch_bounds__(256) void dcn_im2col_group_kernel(const float* x, const float* offset, const float* mask,
+                                                               float* col, DcnGeom g, int b0, int step) {
+  const int P = g.ho * g.wo, K = g.kh * g.kw, HW = g.h * g.w;
+  const long total = (long)step * g.dg * P;
+  const int cpg = g.c / g.dg;
+  for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int p = (int)(idx % P);
+    const int dgi = (int)((idx / P) % g.dg);
+    const int bl = (int)(idx / ((long)P * g.dg)), b = b0 + bl;
+    const int wo = p % g.wo, ho = p / g.wo;
+    const __amdgpu_buffer_rsrc_t rx =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(x + (long)b * g.c * HW), 0, g.c * HW * 4, 0x00020000);
+    const float* off = offset + ((long)b * g.dg + dgi) * 2 * K * P + p;
+    const float* mk = mask ? mask + ((long)b * g.dg + dgi) * K * P + p : nullptr;
+    const int h_in = ho * g.sh - g.ph, w_in = wo * g.sw - g.pw;
+    for (int t = 0; t < K; ++t) {
+      const int i = t / g.kw, j = t - i * g.kw;
+      const float hi = h_in + i * g.dh + off[(long)(2 * t) * P];
+      const float wi = w_in + j * g.dw + off[(long)(2 * t + 1) * P];
+      const float m = mk ? mk[(long)t * P] : 1.f;
+      const bool in = hi > -1.f && wi > -1.f && hi < g.h && wi < g.w;
+      const float hf = floorf(hi), wf = floorf(wi);
+      const int h_low = (int)hf, w_low = (int)wf;
+      const float lh = hi - hf, lw = wi - wf, hh = 1.f - lh, hw = 1.f - lw;
+      const bool c0 = w_low >= 0, c1 = w_low + 1 <= g.w - 1;
+      const float w1 = c0 ? hh * hw : 0.f, w2 = c1 ? hh * lw : 0.f, w3 = c0 ? lh * hw : 0.f, w4 = c1 ? lh * lw : 0.f;
+      const int xs = w_low < 0 ? 0 : (c1 ? w_low : g.w - 2);
+      const int base = (h_low * g.w + xs) * 4;
+      const int a0 = (in && h_low >= 0) ? base : DCN_OOB;
+      const int a1 = (in && h_low + 1 <= g.h - 1) ? base + g.w * 4 : DCN_OOB;
+      float* dst = col + (((long)dgi * cpg * K + t) * step + bl) * P + p;
+      for (int cc = 0; cc < cpg; ++cc) {
+        const int coff = (dgi * cpg + cc) * HW * 4;
+        const dcn_u32x2 p0 = __builtin_amdgcn_raw_buffer_load_b64(rx, a0 + coff, 0, 0);
+        const dcn_u32x2 p1 = __builtin_amdgcn_raw_buffer_load_b64(rx, a1 + coff, 0, 0);
+        const float v1 = __uint_as_float(c1 ? p0.x : p0.y), v2 = __uint_as_float(c0 ? p0.y : p0.x);
+        const float v3 = __uint_as_float(c1 ? p1.x : p1.y), v4 = __uint_as_float(c0 ? p1.y : p1.x);
+        float v = w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4;
+        if (mk) v *= m;
+        dst[(long)cc * K * step * P] = v;
+      }
+    }
+  }
+}
+
 // grad_im[b][c] += bilinear-adjoint of columns-gradient (atomic scatter to the 4 live corners)
 // col2im with the image plane in LDS: one block owns one (sample, channel) plane of grad_im (H*W fp32 <= 60 KB), adds
 // all of that plane's 4-corner contributions (every tap x every output position) with LDS atomics and then adds the
@@ -630,8 +681,6 @@ __global__ __launch_bounds__(256) void dcn_bias_grad_kernel(const float* go, flo
 // with a row stride that puts the two half-waves on disjoint banks.  Corner loads go through a buffer resource over the
 // image, so an out-of-range corner is a voffset past num_records and reads 0 (the reference's per-corner bounds,
 // deform_conv_cuda_kernel.cu:85-115).
-typedef unsigned dcn_u32x2 __attribute__((ext_vector_type(2)));
-#define DCN_OOB ((int)0x80000000)
 
 __global__ void dcn_wt_kernel(const float* w, float* wt, int co, int c, int K, int cop) {
   const int total = c * K * cop;
@@ -1035,6 +1084,17 @@ static void dcn_forward_fused(const float* input, const float* weight, const flo
     hipLaunchKernelGGL(dcn_fused_fwd_kernel<2>, grid, dim3(DCN_FWD_THREADS), lds, s, input, offset, mask, ws, bias, output, g, rs);
 }
 
+static void dcn_im2col(hipStream_t s, const float* input, const float* offset, const float* mask, float* ws, const DcnGeom& g,
+                       int b0, int step) {
+  const int P = g.ho * g.wo;
+  if (g.w >= 2 && (long)g.c * g.h * g.w * 4 < (1L << 31) - (1L << 20))
+    hipLaunchKernelGGL(dcn_im2col_group_kernel, dim3(grid1d((long)step * g.dg * P)), dim3(256), 0, s, input, offset, mask, ws,
+                       g, b0, step);
+  else
+    hipLaunchKernelGGL(dcn_im2col_kernel, dim3(grid1d((long)g.c * step * P)), dim3(256), 0, s, input, offset, mask, ws, g, b0,
+                       step);
+}
+
 static int dcn_check(DcnGeom& g, int im2col_step) {
   if (g.n < 1 || g.c < 1 || g.co < 1 || g.kh < 1 || g.kw < 1 || g.sh < 1 || g.sw < 1 || g.dh < 1 || g.dw < 1)
     return RTP_ERR_SHAPE;  // shape_check, deform_conv_cuda.cpp:62-150
@@ -1061,8 +1121,7 @@ static int dcn_forward(const float* input, const float* weight, const float* bia
     return RTP_OK;
   }
   for (int b0 = 0; b0 < g.n; b0 += step) {
-    hipLaunchKernelGGL(dcn_im2col_kernel, dim3(grid1d((long)g.c * step * P)), dim3(256), 0, s, input, offset, mask, ws,
-                       g, b0, step);
+    dcn_im2col(s, input, offset, mask, ws, g, b0, step);
     for (int gi = 0; gi < g.group; ++gi) {
       // out[b0 + n/P][gi*cog + m][n%P] = W[gi][m][:] . columns[gi][:][n]
       sgemm(s, mv(weight + (long)gi * cog * cg * K, (long)cg * K, 1),
@@ -1132,8 +1191,7 @@ static int dcn_backward_params(const float* input, const float* offset, const fl
   const int cg = g.c / g.group, cog = g.co / g.group;
   RtpProfScope prof(RTP_FAM_DCN, s);
   for (int b0 = 0; b0 < g.n; b0 += step) {
-    hipLaunchKernelGGL(dcn_im2col_kernel, dim3(grid1d((long)g.c * step * P)), dim3(256), 0, s, input, offset, mask, ws,
-                       g, b0, step);
+    dcn_im2col(s, input, offset, mask, ws, g, b0, step);
     for (int gi = 0; gi < g.group; ++gi) {
       // gradW[gi] (cog x cg*K) += scale * gradOut chunk (cog x step*P) . columns[gi]^T (step*P x cg*K)
       if (!dcn_gradw_mfma(s, gradOutput + ((long)b0 * g.co + gi * cog) * P, ws + (long)gi * cg * K * step * P,
