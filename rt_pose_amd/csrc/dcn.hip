@@ -368,6 +368,7 @@ __global__ __launch_bounds__(256) void dcn_col2im_coord_kernel(const float* col,
   const int P = g.ho * g.wo, K = g.kh * g.kw;
   const long total = (long)step * g.dg * K * P;
   const int cpg = g.c / g.dg;
+  const bool pairs = g.w >= 2 && (long)g.c * g.h * g.w * 4 < (1L << 31) - (1L << 20);
   for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
     const int p = (int)(idx % P);
     const int t = (int)((idx / P) % K);
@@ -382,7 +383,31 @@ __global__ __launch_bounds__(256) void dcn_col2im_coord_kernel(const float* col,
     const bool inside = hi > -1.f && wi > -1.f && hi < g.h && wi < g.w;
     const float mk = mask ? mask[((long)b * g.dg + dgi) * K * P + t * P + p] : 1.f;
     float gh = 0.f, gw = 0.f, gm = 0.f;
-    if (inside) {
+    if (inside && pairs) {
+      // corners as 8-byte column pairs through a buffer resource over the image (see dcn_im2col_group_kernel); a corner
+      // outside the image counts as 0, exactly the per-corner bounds of the reference (kernel.cu:145-188)
+      const __amdgpu_buffer_rsrc_t rx =
+          __builtin_amdgcn_make_buffer_rsrc((void*)(x + (long)b * g.c * g.h * g.w), 0, g.c * g.h * g.w * 4, 0x00020000);
+      const float hf = floorf(hi), wf = floorf(wi);
+      const int h_low = (int)hf, w_low = (int)wf;
+      const float lh = hi - hf, lw = wi - wf;
+      const bool c0 = w_low >= 0, c1 = w_low + 1 <= g.w - 1;
+      const int xs = w_low < 0 ? 0 : (c1 ? w_low : g.w - 2);
+      const int base = (h_low * g.w + xs) * 4;
+      const int a0 = h_low >= 0 ? base : DCN_OOB, a1 = h_low + 1 <= g.h - 1 ? base + g.w * 4 : DCN_OOB;
+      for (int cc = 0; cc < cpg; ++cc) {
+        const int c = dgi * cpg + cc;
+        const float cv = col[(((long)c * K + t) * step + bl) * P + p];
+        const int coff = c * g.h * g.w * 4;
+        const dcn_u32x2 p0 = __builtin_amdgcn_raw_buffer_load_b64(rx, a0 + coff, 0, 0);
+        const dcn_u32x2 p1 = __builtin_amdgcn_raw_buffer_load_b64(rx, a1 + coff, 0, 0);
+        const float v1 = c0 ? __uint_as_float(c1 ? p0.x : p0.y) : 0.f, v2 = c1 ? __uint_as_float(c0 ? p0.y : p0.x) : 0.f;
+        const float v3 = c0 ? __uint_as_float(c1 ? p1.x : p1.y) : 0.f, v4 = c1 ? __uint_as_float(c0 ? p1.y : p1.x) : 0.f;
+        gh += cv * mk * (-(1.f - lw) * v1 - lw * v2 + (1.f - lw) * v3 + lw * v4);
+        gw += cv * mk * (-(1.f - lh) * v1 + (1.f - lh) * v2 - lh * v3 + lh * v4);
+        if (grad_mask) gm += cv * ((1.f - lh) * (1.f - lw) * v1 + (1.f - lh) * lw * v2 + lh * (1.f - lw) * v3 + lh * lw * v4);
+      }
+    } else if (inside) {
       for (int cc = 0; cc < cpg; ++cc) {
         const int c = dgi * cpg + cc;
         const float cv = col[(((long)c * K + t) * step + bl) * P + p];
