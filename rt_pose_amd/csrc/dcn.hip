@@ -282,23 +282,31 @@ __global__ __launch_bounds__(256) void dcn_col2im_gather_kernel(const float* col
     int wo0 = dcn_floor_div(x - R + wb + g.sw - 1, g.sw), wo1 = dcn_floor_div(x + R + wb, g.sw);
     ho0 = ho0 < rho0 ? rho0 : ho0; wo0 = wo0 < rwo0 ? rwo0 : wo0;
     ho1 = ho1 > rho1 ? rho1 : ho1; wo1 = wo1 > rwo1 ? rwo1 : wo1;
-    for (int ho = ho0; ho <= ho1; ++ho)
+    // quick reject first: the sample's row / column must fall in [y-1, y+1) x [x-1, x+1) (exact float compares, two
+    // VALU each); only the ~4 of (2R+1)^2 candidates that pass pay for the full weight computation
+    const float ym1 = (float)(y - 1), yp1 = (float)(y + 1), xm1 = (float)(x - 1), xp1 = (float)(x + 1);
+    for (int ho = ho0; ho <= ho1; ++ho) {
+      const float nomh = (float)(ho * g.sh - g.ph + ki * g.dh);
+      const int ib = (ho - rho0) * rw - rwo0;
       for (int wo = wo0; wo <= wo1; ++wo) {
-        const int i = (ho - rho0) * rw + (wo - rwo0);
-        const float oh = reg[i], ow = reg[plane + i];
-        if (!(fabsf(oh) <= Rf && fabsf(ow) <= Rf)) continue;  // outlier (or outside the output): not gathered here
-        const float hi = ho * g.sh - g.ph + ki * g.dh + oh;
-        const float wi = wo * g.sw - g.pw + kj * g.dw + ow;
+        const int i = ib + wo;
+        const float oh = reg[i];
+        const float hi = nomh + oh;
+        if (!(hi >= ym1 && hi < yp1)) continue;  // also drops positions outside the output (offset 1e30)
+        const float ow = reg[plane + i];
+        const float wi = (float)(wo * g.sw - g.pw + kj * g.dw) + ow;
+        if (!(wi >= xm1 && wi < xp1)) continue;
+        if (!(fabsf(oh) <= Rf && fabsf(ow) <= Rf)) continue;  // outlier: scattered by dcn_col2im_outlier_kernel
         if (!(hi > -1.f && wi > -1.f && hi < g.h && wi < g.w)) continue;
         const int h_low = (int)floorf(hi), w_low = (int)floorf(wi);
-        const int dy = y - h_low, dx = x - w_low;
-        if ((unsigned)dy > 1u || (unsigned)dx > 1u) continue;
+        const int dy = y - h_low, dx = x - w_low;  // 0 or 1
         const float lh = hi - h_low, lw = wi - w_low;
         const float wgt = (dy ? lh : 1.f - lh) * (dx ? lw : 1.f - lw);
         if (wgt == 0.f) continue;
 #pragma unroll
         for (int cc = 0; cc < CH; ++cc) acc[cc] += wgt * reg[(2 + cc) * plane + i];
       }
+    }
   }
   if (pix_ok) {
     float* gim = grad_im + ((long)b * g.c + c0) * HW + y * g.w + x;
