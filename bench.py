@@ -58,6 +58,41 @@ def cpu_baseline(name, seconds_budget=30.0):
                        % (steps, batch, O.ARCHS[arch]["inplanes"], cores))
 
 
+def dcn_op_bench(dev, batch, iters=10):
+    import torch
+    from rt_pose_amd.dcn import deform_conv
+    n, c, h, w, co = batch * 16, 32, 64, 160, 32
+    g = torch.Generator(device=dev).manual_seed(7)
+    x = torch.randn(n, c, h, w, device=dev, generator=g).requires_grad_(True)
+    off = (torch.randn(n, 4 * 18, h, w, device=dev, generator=g) * 0.5).requires_grad_(True)
+    wt = (torch.randn(co, c, 3, 3, device=dev, generator=g) * 0.05).requires_grad_(True)
+    gy = torch.randn(n, co, h, w, device=dev, generator=g)
+
+    def fwd():
+        return deform_conv(x, off, wt, 1, 1, 1, 1, 4, 64)
+
+    def fb():
+        for v in (x, off, wt):
+            v.grad = None
+        fwd().backward(gy)
+
+    out = {}
+    for name, f in (("forward_ms", fwd), ("forward_backward_ms", fb)):
+        for _ in range(3):
+            f()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            f()
+        torch.cuda.synchronize()
+        out[name] = round((time.perf_counter() - t0) / iters * 1e3, 3)
+    alg = (x.numel() + off.numel() + gy.numel()) * 4
+    out.update(workload="DCNv1 3x3 [%d,%d,%d,%d] -> %d, deformable_groups 4, im2col_step 64, fp32 (BASELINE config 4, op level)" % (n, c, h, w, co),
+               forward_algorithmic_GBps=round(alg / out["forward_ms"] / 1e6, 1),
+               forward_tflops_fp32=round(2.0 * n * h * w * co * c * 9 / out["forward_ms"] / 1e9, 2))
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -70,6 +105,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="(default) kept for compatibility")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-dcn", action="store_true", help="skip the DCN operator (config 4) leg")
     ap.add_argument("--no-forward", action="store_true", help="skip the forward-only (config 2) leg")
     args = ap.parse_args()
 
@@ -204,6 +240,10 @@ def main():
                             "hbm_view": {"achieved": round(best[3], 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                                          "frac": round(best[3] / PEAK_HBM_GBPS, 4)},
                             "families": detail}
+    # BASELINE config 4, op level (the reference's DCN head cannot run on its own 5-D feature): DCNv1 3x3,
+    # deformable_groups 4, im2col_step 64 on the level-0 feature with Z folded into the batch, [B*16, 32, 64, 160] fp32
+    if world == 1 and not args.no_dcn:
+        line["dcn_op"] = dcn_op_bench(dev, args.batch)
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(args.model)
     if rank == 0:
