@@ -93,6 +93,39 @@ def dcn_op_bench(dev, batch, iters=10):
     return out
 
 
+def lidar_bench(dev, batch, npts=200000, iters=5):
+    import numpy as np
+    import torch
+    from rt_pose_amd.lidar import DynamicVoxelEncoder, lidar_to_radar
+    enc = DynamicVoxelEncoder([0.0, -10.05, -5.8, 11.6, 10.05, 5.8], [0.0725, 0.314, 0.725])
+    g = torch.Generator(device=dev).manual_seed(11)
+    frames = [torch.rand(npts, 4, device=dev, generator=g) * torch.tensor([14.0, 24.0, 14.0, 1.0], device=dev)
+              - torch.tensor([1.0, 12.0, 7.0, 0.0], device=dev) for _ in range(batch)]
+    P = np.eye(4)
+    P[:3, 3] = [0.1, -0.05, 0.2]
+
+    def run():
+        nv = 0
+        for f in frames:
+            pts = f.clone()
+            lidar_to_radar(pts, P)   # in place
+            v, c = enc.voxelize(pts)
+            enc.to_dense(v, c)
+            nv += v.shape[0]
+        return nv
+
+    run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        nv = run()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / iters * 1e3
+    return {"workload": "%d LiDAR frames x %d points: extrinsic transform + dynamic voxelisation (stable radix sort, in-order means) "
+                        "+ dense scatter (BASELINE config 5 pieces)" % (batch, npts),
+            "ms_per_batch": round(ms, 3), "points_per_s": round(batch * npts / ms * 1e3, 1), "voxels": int(nv)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -105,6 +138,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="(default) kept for compatibility")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-lidar", action="store_true", help="skip the LiDAR voxelisation (config 5 pieces) leg")
     ap.add_argument("--no-dcn", action="store_true", help="skip the DCN operator (config 4) leg")
     ap.add_argument("--no-forward", action="store_true", help="skip the forward-only (config 2) leg")
     args = ap.parse_args()
@@ -244,6 +278,10 @@ def main():
     # deformable_groups 4, im2col_step 64 on the level-0 feature with Z folded into the batch, [B*16, 32, 64, 160] fp32
     if world == 1 and not args.no_dcn:
         line["dcn_op"] = dcn_op_bench(dev, args.batch)
+    # BASELINE config 5, the pieces the reference defines: extrinsic transform + dynamic voxelisation +
+    # dense scatter of one 200 000-point LiDAR frame per radar frame
+    if world == 1 and not args.no_lidar:
+        line["lidar_stream"] = lidar_bench(dev, args.batch)
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(args.model)
     if rank == 0:
