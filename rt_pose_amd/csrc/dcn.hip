@@ -21,6 +21,16 @@ struct DcnGeom {
   int n, c, h, w, co, kh, kw, sh, sw, ph, pw, dh, dw, group, dg, ho, wo;
 };
 
+// Two layouts of the caller's workspace:
+//   columns          [c*K + t][bl*P + p]           written by im2col, read by the GEMMs of forward / weight gradient
+//   column GRADIENT  [bl][dg][t][p][c % cpg]       written by the column-gradient GEMM, read by the coordinate gradient and
+//                                                  col2im: a position's channels of one deformable group are contiguous
+//                                                  (one 16/32-byte load instead of cpg loads 23 MB apart)
+__host__ __device__ __forceinline__ long dcn_cg_index(const DcnGeom& g, int c, int t, int bl, int p) {
+  const int cpg = g.c / g.dg, K = g.kh * g.kw, P = g.ho * g.wo;
+  return ((((long)bl * g.dg + c / cpg) * K + t) * P + p) * cpg + c % cpg;
+}
+
 static inline void dcn_out_size(DcnGeom& g) {
   g.ho = (g.h + 2 * g.ph - (g.dh * (g.kh - 1) + 1)) / g.sh + 1;
   g.wo = (g.w + 2 * g.pw - (g.dw * (g.kw - 1) + 1)) / g.sw + 1;
@@ -134,7 +144,8 @@ __global__ __launch_bounds__(256) void dcn_col2im_plane_kernel(const float* col,
   const float* off = offset + ((long)b * g.dg + dgi) * 2 * K * P;
   for (int t = 0; t < K; ++t) {
     const int ki = t / g.kw, kj = t - ki * g.kw;
-    const float* colp = col + (((long)c * K + t) * step + bl) * P;
+    const float* colp = col + dcn_cg_index(g, c, t, bl, 0);
+    const int cstr = g.c / g.dg;  // channel-innermost column gradient: positions are cpg floats apart
     const float* mk = mask ? mask + ((long)b * g.dg + dgi) * K * P + (long)t * P : nullptr;
     // four positions per thread and round: their 12 loads are in flight together before the first LDS atomic
     for (int pb = threadIdx.x; pb < P; pb += 4 * 256) {
@@ -145,7 +156,7 @@ __global__ __launch_bounds__(256) void dcn_col2im_plane_kernel(const float* col,
         const bool ok = p < P;
         oh[u] = ok ? off[(2 * t) * P + p] : 0.f;
         ow[u] = ok ? off[(2 * t + 1) * P + p] : 0.f;
-        top[u] = ok ? colp[p] * (mk ? mk[p] : 1.f) : 0.f;
+        top[u] = ok ? colp[(long)p * cstr] * (mk ? mk[p] : 1.f) : 0.f;
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
@@ -192,7 +203,7 @@ __global__ __launch_bounds__(256) void dcn_col2im_kernel(const float* col, const
     const float hi = ho * g.sh - g.ph + i * g.dh + off[(2 * t) * P + p];
     const float wi = wo * g.sw - g.pw + j * g.dw + off[(2 * t + 1) * P + p];
     if (!(hi > -1.f && wi > -1.f && hi < g.h && wi < g.w)) continue;
-    float top = col[idx];
+    float top = col[dcn_cg_index(g, c, t, bl, p)];
     if (mask) top *= mask[((long)b * g.dg + dgi) * K * P + t * P + p];
     const int h_low = (int)floorf(hi), w_low = (int)floorf(wi);
     const float lh = hi - h_low, lw = wi - w_low;
@@ -263,7 +274,7 @@ __global__ __launch_bounds__(256) void dcn_col2im_gather_kernel(const float* col
     const int rho0 = dcn_floor_div(y0 - R + hb + g.sh - 1, g.sh), rho1 = dcn_floor_div(y0 + DCN_GT_Y - 1 + R + hb, g.sh);
     const int rwo0 = dcn_floor_div(x0 - R + wb + g.sw - 1, g.sw), rwo1 = dcn_floor_div(x0 + DCN_GT_X - 1 + R + wb, g.sw);
     const int rh = rho1 - rho0 + 1, rw = rwo1 - rwo0 + 1;  // <= rh_max, rw_max
-    const float* colt = col + (((long)c0 * K + t) * step + bl) * P;
+    const float* colt = col + dcn_cg_index(g, c0, t, bl, 0);  // [p][cpg]: the CH channels of a position are contiguous
     __syncthreads();
     for (int i = threadIdx.x; i < rh * rw; i += 256) {
       const int r = i / rw, cidx = i - r * rw;
@@ -273,8 +284,19 @@ __global__ __launch_bounds__(256) void dcn_col2im_gather_kernel(const float* col
       reg[i] = ok ? off[(long)(2 * t) * P + p] : 1e30f;
       reg[plane + i] = ok ? off[(long)(2 * t + 1) * P + p] : 1e30f;
       const float m = (ok && mk) ? mk[(long)t * P + p] : 1.f;
+      float v[CH];
+      if (CH % 4 == 0) {
 #pragma unroll
-      for (int cc = 0; cc < CH; ++cc) reg[(2 + cc) * plane + i] = ok ? colt[(long)cc * K * step * P + p] * m : 0.f;
+        for (int q4 = 0; q4 < CH / 4; ++q4) {
+          const float4 f = ok ? *(const float4*)(colt + (long)p * cpg + 4 * q4) : make_float4(0.f, 0.f, 0.f, 0.f);
+          v[4 * q4] = f.x; v[4 * q4 + 1] = f.y; v[4 * q4 + 2] = f.z; v[4 * q4 + 3] = f.w;
+        }
+      } else {
+#pragma unroll
+        for (int cc = 0; cc < CH; ++cc) v[cc] = ok ? colt[(long)p * cpg + cc] : 0.f;
+      }
+#pragma unroll
+      for (int cc = 0; cc < CH; ++cc) reg[(2 + cc) * plane + i] = v[cc] * m;
     }
     __syncthreads();
     if (!pix_ok) continue;
@@ -339,7 +361,7 @@ __global__ __launch_bounds__(256) void dcn_col2im_outlier_kernel(const float* co
     const float m = mask ? mask[((long)b * g.dg + dgi) * K * P + (long)t * P + p] : 1.f;
     for (int cc = 0; cc < cpg; ++cc) {
       const int c = dgi * cpg + cc;
-      const float top = col[(((long)c * K + t) * step + bl) * P + p] * m;
+      const float top = col[dcn_cg_index(g, c, t, bl, p)] * m;
       float* gim = grad_im + ((long)b * g.c + c) * g.h * g.w;
 #pragma unroll
       for (int dy = 0; dy < 2; ++dy)
@@ -372,17 +394,38 @@ __device__ __forceinline__ float dcn_coord_weight(const float* im, int H, int W,
 // grad_offset[b][dg*2K + 2t + dir][p] = sum_{c in dg} col[c,t] * (mask) * d bilinear/d coord ; grad_mask likewise
 __global__ __launch_bounds__(256) void dcn_col2im_coord_kernel(const float* col, const float* x, const float* offset,
                                                                const float* mask, float* grad_offset, float* grad_mask,
-                                                               DcnGeom g, int b0, int step) {
+                                                               DcnGeom g, int b0, int step, int use_lds) {
+  // blockIdx.y: tile of 256 positions; blockIdx.x: (image, deformable group, tap).  The tile's column gradient
+  // ([256 positions][cpg], contiguous) is read with coalesced 16-byte loads and transposed through LDS (row stride
+  // cpg + 1: conflict-free), so that each thread then walks its own position's channels.
+  extern __shared__ float tile[];
   const int P = g.ho * g.wo, K = g.kh * g.kw;
-  const long total = (long)step * g.dg * K * P;
   const int cpg = g.c / g.dg;
   const bool pairs = g.w >= 2 && (long)g.c * g.h * g.w * 4 < (1L << 31) - (1L << 20);
-  for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-    const int p = (int)(idx % P);
-    const int t = (int)((idx / P) % K);
-    const int dgi = (int)((idx / ((long)P * K)) % g.dg);
-    const int bl = (int)(idx / ((long)P * K * g.dg));
+  (void)step;
+  {
+    int yb = blockIdx.x;
+    const int t = yb % K; yb /= K;
+    const int dgi = yb % g.dg, bl = yb / g.dg;
     const int b = b0 + bl;
+    const int pt0 = blockIdx.y * 256, p = pt0 + threadIdx.x;
+    const float* ctile = col + dcn_cg_index(g, dgi * cpg, t, bl, pt0);
+    if (use_lds) {
+      const int npos = P - pt0 < 256 ? P - pt0 : 256, nfl = npos * cpg;
+      if ((cpg & 3) == 0) {
+        for (int i = threadIdx.x * 4; i < nfl; i += 1024) {
+          const float4 v = *(const float4*)(ctile + i);
+          const int pl = i / cpg, cc = i - pl * cpg;
+          float* d = tile + pl * (cpg + 1) + cc;
+          d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        }
+      } else {
+        for (int i = threadIdx.x; i < nfl; i += 256) tile[(i / cpg) * (cpg + 1) + i % cpg] = ctile[i];
+      }
+      __syncthreads();
+    }
+    if (p >= P) return;
+    const float* colp = use_lds ? tile + threadIdx.x * (cpg + 1) : ctile + (long)threadIdx.x * cpg;
     const int wo = p % g.wo, ho = p / g.wo;
     const int i = t / g.kw, j = t - i * g.kw;
     const float* off = offset + ((long)b * g.dg + dgi) * 2 * K * P;
@@ -405,7 +448,7 @@ __global__ __launch_bounds__(256) void dcn_col2im_coord_kernel(const float* col,
       const int a0 = h_low >= 0 ? base : DCN_OOB, a1 = h_low + 1 <= g.h - 1 ? base + g.w * 4 : DCN_OOB;
       for (int cc = 0; cc < cpg; ++cc) {
         const int c = dgi * cpg + cc;
-        const float cv = col[(((long)c * K + t) * step + bl) * P + p];
+        const float cv = colp[cc];
         const int coff = c * g.h * g.w * 4;
         const dcn_u32x2 p0 = __builtin_amdgcn_raw_buffer_load_b64(rx, a0 + coff, 0, 0);
         const dcn_u32x2 p1 = __builtin_amdgcn_raw_buffer_load_b64(rx, a1 + coff, 0, 0);
@@ -418,7 +461,7 @@ __global__ __launch_bounds__(256) void dcn_col2im_coord_kernel(const float* col,
     } else if (inside) {
       for (int cc = 0; cc < cpg; ++cc) {
         const int c = dgi * cpg + cc;
-        const float cv = col[(((long)c * K + t) * step + bl) * P + p];
+        const float cv = colp[cc];
         const float* im = x + ((long)b * g.c + c) * g.h * g.w;
         gh += cv * mk * dcn_coord_weight(im, g.h, g.w, hi, wi, 0);
         gw += cv * mk * dcn_coord_weight(im, g.h, g.w, hi, wi, 1);
@@ -443,8 +486,10 @@ struct MatView {
 // C[M][N] = alpha * A[M][K] * B[K][N] + beta * C
 // gridDim.z > 1: split-K -- slice z contracts k in [z*kchunk, (z+1)*kchunk) and ADDS alpha * partial to C with fp32 atomics
 // (only for beta == 1: the weight-gradient GEMM, M x N = 32 x 288 against K = 655 360, was 5 blocks of 41 000 iterations).
+// cgl.use: C is the column gradient in its channel-innermost layout (row m = c_local * K + t, column n = bl * P + p)
+struct CgLayout { int use, c_base; DcnGeom g; };
 __global__ __launch_bounds__(256) void sgemm_kernel(MatView A, MatView B, MatView C, int M, int N, int K, float alpha,
-                                                    float beta, int kchunk) {
+                                                    float beta, int kchunk, CgLayout cgl) {
   __shared__ float As[16][64 + 4];
   __shared__ float Bs[16][64 + 4];
   const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
@@ -494,13 +539,20 @@ __global__ __launch_bounds__(256) void sgemm_kernel(MatView A, MatView B, MatVie
       const int m = m0 + ty * 4 + i, n = n0 + tx * 4 + j;
       if (m < M && n < N) {
         float* dst = C.p + C.at(m, n);
+        if (cgl.use) {
+          const int KK = cgl.g.kh * cgl.g.kw, PP = cgl.g.ho * cgl.g.wo;
+          dst = C.p + dcn_cg_index(cgl.g, cgl.c_base + m / KK, m % KK, n / PP, n % PP);
+        }
         if (split) atomicAdd(dst, alpha * acc[i][j]);
         else *dst = alpha * acc[i][j] + (beta != 0.f ? beta * *dst : 0.f);
       }
     }
 }
 
-static void sgemm(hipStream_t s, MatView A, MatView B, MatView C, int M, int N, int K, float alpha, float beta) {
+static void sgemm(hipStream_t s, MatView A, MatView B, MatView C, int M, int N, int K, float alpha, float beta,
+                  const DcnGeom* cg_geom = nullptr, int c_base = 0) {
+  CgLayout cgl{};
+  if (cg_geom) { cgl.use = 1; cgl.c_base = c_base; cgl.g = *cg_geom; }
   dim3 grid((N + 63) / 64, (M + 63) / 64);
   int kchunk = K;
   // few output tiles against a long contraction (and an accumulating GEMM): spread K over the chip
@@ -510,7 +562,7 @@ static void sgemm(hipStream_t s, MatView A, MatView B, MatView C, int M, int N, 
     if (kchunk < 2048) kchunk = 2048;
     grid.z = (K + kchunk - 1) / kchunk;
   }
-  hipLaunchKernelGGL(sgemm_kernel, grid, dim3(256), 0, s, A, B, C, M, N, K, alpha, beta, kchunk);
+  hipLaunchKernelGGL(sgemm_kernel, grid, dim3(256), 0, s, A, B, C, M, N, K, alpha, beta, kchunk, cgl);
 }
 
 // ------------------------------------------------------------------------------------------------ skinny MFMA GEMMs
@@ -525,35 +577,39 @@ typedef float dcn_f32x16 __attribute__((ext_vector_type(16)));
 // positions and walks the ck / 32 row tiles; each accumulator row is a 128-byte contiguous store.
 template <int KP>  // KP = ceil(cog / 2) k-steps held in registers
 __global__ __launch_bounds__(256) void dcn_colgrad_mfma_kernel(const float* w, const float* go, float* cols, int cog,
-                                                               int ck_total, int rows_per_block, int co_total, int P, long N) {
+                                                               int rows_per_block, int c_base, int cg, DcnGeom g, long N) {
   extern __shared__ float wl[];  // [2 * KP][ckp] (rows >= cog and columns >= ck are zero)
-  // blockIdx.y: chunk of column rows (the weight slice of a chunk must fit LDS; the gO tile is re-read per chunk)
+  // Rows are walked tap-major (r' = t * cg + c_local) so that a lane's four consecutive accumulator rows are four
+  // consecutive channels of one tap: one 16-byte store into the channel-innermost column gradient.
+  // blockIdx.y: chunk of rows (the weight slice of a chunk must fit LDS; the gO tile is re-read per chunk)
+  const int K = g.kh * g.kw, P = g.ho * g.wo, ck_total = cg * K;
   const int r0 = blockIdx.y * rows_per_block;
   const int ck = ck_total - r0 < rows_per_block ? ck_total - r0 : rows_per_block;
-  cols += (long)r0 * N;
   const int ckp = (ck + 31) / 32 * 32;
   for (int i = threadIdx.x; i < 2 * KP * ckp; i += 256) {
-    const int co = i / ckp, r = i - co * ckp;
-    wl[i] = (co < cog && r < ck) ? w[(long)co * ck_total + r0 + r] : 0.f;
+    const int co = i / ckp, r = i - co * ckp, rp = r0 + r;
+    wl[i] = (co < cog && r < ck) ? w[(long)co * ck_total + (rp % cg) * K + rp / cg] : 0.f;
   }
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, l32 = lane & 31;
   const long n0 = (blockIdx.x * 4L + wave) * 64;
   float bv[2][KP];
-  long nn[2];
+  bool nok[2];
+  int nbl[2], np_[2];
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
-    nn[q] = n0 + 32 * q + l32;
-    const bool ok = nn[q] < N;
-    const long bl = ok ? nn[q] / P : 0;
-    const int p = ok ? (int)(nn[q] - bl * P) : 0;
-    const float* src = go + (bl * co_total) * P + p;
+    const long nn = n0 + 32 * q + l32;
+    nok[q] = nn < N;
+    nbl[q] = nok[q] ? (int)(nn / P) : 0;
+    np_[q] = nok[q] ? (int)(nn - (long)nbl[q] * P) : 0;
+    const float* src = go + ((long)nbl[q] * g.co) * P + np_[q];
 #pragma unroll
     for (int kk = 0; kk < KP; ++kk) {
       const int co = 2 * kk + half;
-      bv[q][kk] = (ok && co < cog) ? src[(long)co * P] : 0.f;
+      bv[q][kk] = (nok[q] && co < cog) ? src[(long)co * P] : 0.f;
     }
   }
+  const bool vec = (cg & 3) == 0 && ((g.c / g.dg) & 3) == 0 && (c_base & 3) == 0;
   for (int rt = 0; rt < ckp / 32; ++rt) {
     dcn_f32x16 acc[2];
 #pragma unroll
@@ -568,11 +624,22 @@ __global__ __launch_bounds__(256) void dcn_colgrad_mfma_kernel(const float* w, c
     }
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-      if (nn[q] >= N) continue;
+      if (!nok[q]) continue;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = rt * 32 + 8 * (r >> 2) + 4 * half + (r & 3);
-        if (row < ck) cols[(long)row * N + nn[q]] = acc[q][r];
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const int row = rt * 32 + 8 * r4 + 4 * half;  // rows row .. row+3 = registers 4*r4 .. 4*r4+3
+        if (row >= ck) continue;
+        const int rp = r0 + row, t = rp / cg, cl = rp - t * cg;
+        if (vec) {
+          *(float4*)(cols + dcn_cg_index(g, c_base + cl, t, nbl[q], np_[q])) =
+              make_float4(acc[q][4 * r4], acc[q][4 * r4 + 1], acc[q][4 * r4 + 2], acc[q][4 * r4 + 3]);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int rj = rp + j;
+            if (row + j < ck) cols[dcn_cg_index(g, c_base + rj % cg, rj / cg, nbl[q], np_[q])] = acc[q][4 * r4 + j];
+          }
+        }
       }
     }
   }
@@ -643,19 +710,20 @@ __global__ __launch_bounds__(64) void dcn_gradw_mfma_kernel(const float* go, con
 }
 
 // dispatchers: true when the MFMA kernel took the GEMM
-static bool dcn_colgrad_mfma(hipStream_t s, const float* w, const float* go, float* cols, int cog, int ck, int co_total,
-                             int P, long N) {
+static bool dcn_colgrad_mfma(hipStream_t s, const float* w, const float* go, float* cols, int cog, int c_base, int cg,
+                             const DcnGeom& g, long N) {
   const char* e = getenv("RTP_DCN_VALU_GEMM");
   if ((e && atoi(e)) || cog > 64) return false;
+  const int ck = cg * g.kh * g.kw;
   const int kp = (cog + 1) / 2;
   const int kpt = kp <= 8 ? 8 : kp <= 16 ? 16 : 32;
-  int rpb = (48 * 1024 / (2 * kpt * (int)sizeof(float))) / 32 * 32;  // column rows per block: weight slice <= 48 KB of LDS
+  int rpb = (48 * 1024 / (2 * kpt * (int)sizeof(float))) / 32 * 32;  // rows per block: weight slice <= 48 KB of LDS
   if (rpb > (ck + 31) / 32 * 32) rpb = (ck + 31) / 32 * 32;
   const size_t lds = (size_t)2 * kpt * rpb * sizeof(float);
   const dim3 grid((unsigned)((N + 255) / 256), (unsigned)((ck + rpb - 1) / rpb));
-  if (kpt == 8) hipLaunchKernelGGL(dcn_colgrad_mfma_kernel<8>, grid, dim3(256), lds, s, w, go, cols, cog, ck, rpb, co_total, P, N);
-  else if (kpt == 16) hipLaunchKernelGGL(dcn_colgrad_mfma_kernel<16>, grid, dim3(256), lds, s, w, go, cols, cog, ck, rpb, co_total, P, N);
-  else hipLaunchKernelGGL(dcn_colgrad_mfma_kernel<32>, grid, dim3(256), lds, s, w, go, cols, cog, ck, rpb, co_total, P, N);
+  if (kpt == 8) hipLaunchKernelGGL(dcn_colgrad_mfma_kernel<8>, grid, dim3(256), lds, s, w, go, cols, cog, rpb, c_base, cg, g, N);
+  else if (kpt == 16) hipLaunchKernelGGL(dcn_colgrad_mfma_kernel<16>, grid, dim3(256), lds, s, w, go, cols, cog, rpb, c_base, cg, g, N);
+  else hipLaunchKernelGGL(dcn_colgrad_mfma_kernel<32>, grid, dim3(256), lds, s, w, go, cols, cog, rpb, c_base, cg, g, N);
   return true;
 }
 
@@ -1178,20 +1246,26 @@ static int dcn_backward_input(const float* input, const float* offset, const flo
   RtpProfScope prof(RTP_FAM_DCN, s);
   for (int b0 = 0; b0 < g.n; b0 += step) {
     for (int gi = 0; gi < g.group; ++gi) {
-      // columns[gi] (cg*K x step*P) = W[gi]^T (cg*K x cog) . gradOut chunk (cog x step*P)
-      if (!dcn_colgrad_mfma(s, weight + (long)gi * cog * cg * K, gradOutput + ((long)b0 * g.co + gi * cog) * P,
-                            ws + (long)gi * cg * K * step * P, cog, cg * K, g.co, P, (long)step * P))
+      // column gradient of group gi = W[gi]^T (cg*K x cog) . gradOut chunk (cog x step*P), written channel-innermost
+      // into the whole workspace (every group addresses its own channels through dcn_cg_index)
+      if (!dcn_colgrad_mfma(s, weight + (long)gi * cog * cg * K, gradOutput + ((long)b0 * g.co + gi * cog) * P, ws, cog,
+                            gi * cg, cg, g, (long)step * P))
         sgemm(s, mv(weight + (long)gi * cog * cg * K, 1, (long)cg * K),
-              mv(gradOutput + ((long)b0 * g.co + gi * cog) * P, P, 1, P, (long)g.co * P),
-              mv(ws + (long)gi * cg * K * step * P, (long)step * P, 1), cg * K, step * P, cog, 1.f, 0.f);
+              mv(gradOutput + ((long)b0 * g.co + gi * cog) * P, P, 1, P, (long)g.co * P), mv(ws, 0, 0), cg * K, step * P,
+              cog, 1.f, 0.f, &g, gi * cg);
     }
-    hipLaunchKernelGGL(dcn_col2im_coord_kernel, dim3(grid1d((long)step * g.dg * K * P)), dim3(256), 0, s, ws, input,
-                       offset, mask, gradOffset, gradMask, g, b0, step);
+    {
+      const int cpg = g.c / g.dg;
+      const size_t lds = (size_t)256 * (cpg + 1) * sizeof(float);
+      const int use_lds = lds <= 64 * 1024;
+      hipLaunchKernelGGL(dcn_col2im_coord_kernel, dim3(step * g.dg * K, (P + 255) / 256), dim3(256), use_lds ? lds : 0, s, ws,
+                         input, offset, mask, gradOffset, gradMask, g, b0, step, use_lds);
+    }
     const char* re = getenv("RTP_DCN_GATHER_R");
     const int R = re ? atoi(re) : 2;  // offsets up to R pixels take the atomic-free gather; 0: scatter everything
     if (R > 0 && R <= 8) {
       const int cpg = g.c / g.dg;
-      const int ch = cpg % 8 == 0 ? 8 : cpg % 4 == 0 ? 4 : cpg % 2 == 0 ? 2 : 1;
+      const int ch = cpg % 16 == 0 ? 16 : cpg % 8 == 0 ? 8 : cpg % 4 == 0 ? 4 : cpg % 2 == 0 ? 2 : 1;
       const int tiles = ((g.h + DCN_GT_Y - 1) / DCN_GT_Y) * ((g.w + DCN_GT_X - 1) / DCN_GT_X);
       const int blocks = step * g.dg * (cpg / ch) * tiles;
       const int rh_max = (DCN_GT_Y - 1 + 2 * R) / g.sh + 2, rw_max = (DCN_GT_X - 1 + 2 * R) / g.sw + 2;
@@ -1200,6 +1274,7 @@ static int dcn_backward_input(const float* input, const float* offset, const flo
   hipLaunchKernelGGL(dcn_col2im_gather_kernel<CH_>, dim3(blocks), dim3(256), lds, s, ws, offset, mask, gradInput, g, b0, \
                      step, R, rh_max, rw_max)
       switch (ch) {
+        case 16: DCN_GATHER(16); break;
         case 8: DCN_GATHER(8); break;
         case 4: DCN_GATHER(4); break;
         case 2: DCN_GATHER(2); break;
