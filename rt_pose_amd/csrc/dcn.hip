@@ -946,6 +946,7 @@ __device__ __forceinline__ void dcn_bcast_halves(float v, float (&o)[2]) {
 
 struct DcnWin {
   int rs, halo, wr, ws, nch;  // weight row stride, halo rows, window rows, per-channel window stride (floats), channels per stage
+  int wrs;                    // padded-row variant: window row stride (W + 4), 0 = contiguous rows
 };
 
 template <int MT>
@@ -1118,6 +1119,179 @@ __global__ __launch_bounds__(DCN_FWD_THREADS) void dcn_win_fwd_kernel(const floa
   }
 }
 
+// Padded-row variant of the window kernel (W % 4 == 0): window row ry starts at ry * wrs with wrs = W + 4; floats 0..3 of
+// a row are zero and column x sits at 4 + x, so the column pair (w_low, w_low + 1) is addressable for w_low in
+// [-1, W-1] (x = -1 is the row's own pad, x = W the next row's pad or the 4-float tail).  With rows outside the image
+// staged as zeros a sample inside the window needs no per-corner logic at all: two ds_read2_b32 and four FMAs; an
+// invalid sample points at the zero pad of row 0 with zero weights.  Samples that leave the window contribute nothing
+// in the main loop and are added by a second pass over the channel pairs (global 8-byte pair loads) that only runs for
+// waves that have such a lane.  The mask (v2) is folded into the four bilinear weights.
+template <int MT>
+__global__ __launch_bounds__(DCN_FWD_THREADS) void dcn_winp_fwd_kernel(const float* x, const float* offset, const float* mask,
+                                                                       const float* wt, const float* bias, float* out,
+                                                                       DcnGeom g, DcnWin wn) {
+  extern __shared__ float lds[];
+  constexpr int COP = 32 * MT;
+  float* win = lds;                    // [nch][ws]
+  float* wl = lds + wn.nch * wn.ws;    // [nch][rs]
+  const int P = g.ho * g.wo, K = g.kh * g.kw, HW = g.h * g.w;
+  const int cpg = g.c / g.dg;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int half = lane >> 5, l32 = lane & 31;
+  const int b = blockIdx.y;
+  const int pfirst = blockIdx.x * DCN_FWD_THREADS;
+  const int p0 = pfirst + wave * 64;
+  const int wy0 = (pfirst / g.wo) * g.sh - g.ph - wn.halo;  // first staged input row (may be negative)
+  const float* xb = x + (long)b * g.c * HW;
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, g.c * HW * 4, 0x00020000);
+  const int pl = p0 + lane;
+  const bool pl_ok = pl < P;
+  const int ho_l = pl / g.wo, wo_l = pl - ho_l * g.wo;
+  const int hin_l = ho_l * g.sh - g.ph, win_l = wo_l * g.sw - g.pw;
+  dcn_f32x16 acc[2][MT];
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[q][m][r] = 0.f;
+  const float* offb = offset + (long)b * g.dg * 2 * K * P;
+  const float* mkb = mask ? mask + (long)b * g.dg * K * P : nullptr;
+  // staging: thread -> (row group st_r, 16-byte slot st_j of a row) once; slot 0 is the row's zero pad
+  const int slots = wn.wrs >> 2, rpp = DCN_FWD_THREADS / slots;
+  const int st_j = threadIdx.x % slots, st_r = threadIdx.x / slots;
+  const int nrows = wn.nch * wn.wr;
+  const int half_off = half * wn.ws * 4, wrs4 = wn.wrs * 4;
+  float oh_n = pl_ok ? offb[pl] : 0.f, ow_n = pl_ok ? offb[P + pl] : 0.f;
+  float mv_n = (mkb && pl_ok) ? mkb[pl] : 1.f;
+  for (int dgi = 0; dgi < g.dg; ++dgi) {
+    for (int c0 = 0; c0 < cpg; c0 += wn.nch) {
+      const int cabs = dgi * cpg + c0;
+      __syncthreads();
+      if (st_r < rpp) {
+        for (int rb = st_r; rb < nrows; rb += 4 * rpp) {  // four rows' loads in flight before the first LDS write
+          float4 v[4];
+          int dst[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int rr = rb + u * rpp, ch = rr / wn.wr, ry = rr - ch * wn.wr, y = wy0 + ry;
+            dst[u] = rr < nrows ? ch * wn.ws + ry * wn.wrs + st_j * 4 : -1;
+            v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (rr < nrows && st_j > 0 && y >= 0 && y < g.h)
+              v[u] = *(const float4*)(xb + (long)(cabs + ch) * HW + y * g.w + (st_j - 1) * 4);
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            if (dst[u] >= 0) *(float4*)&win[dst[u]] = v[u];
+        }
+      }
+      if (threadIdx.x < wn.nch * 4) win[(threadIdx.x >> 2) * wn.ws + wn.wr * wn.wrs + (threadIdx.x & 3)] = 0.f;  // tail pad
+      for (int i = threadIdx.x * 4; i < wn.nch * K * COP; i += DCN_FWD_THREADS * 4) {
+        const float4 v = *(const float4*)(wt + (long)cabs * K * COP + i);
+        const int cl = i / (K * COP), r = i - cl * (K * COP);
+        *(float4*)&wl[cl * wn.rs + r] = v;
+      }
+      __syncthreads();
+      for (int t = 0; t < K; ++t) {
+        const int ki = t / g.kw, kj = t - ki * g.kw;
+        const float oh = oh_n, ow = ow_n, mv_ = mv_n;
+        {  // the next tap's offsets (and mask) are loaded now and consumed one tap later
+          int tn = t + 1, dn = dgi;
+          if (tn == K) { tn = 0; if (c0 + wn.nch >= cpg) ++dn; }
+          if (dn < g.dg && pl_ok) {
+            const float* on = offb + ((long)dn * 2 * K + 2 * tn) * P + pl;
+            oh_n = on[0];
+            ow_n = on[P];
+            if (mkb) mv_n = mkb[((long)dn * K + tn) * P + pl];
+          }
+        }
+        // this lane's own position; the two 32-position column groups pick the values up with v_permlane32_swap
+        const float hi = hin_l + ki * g.dh + oh, wi = win_l + kj * g.dw + ow;
+        const bool in = pl_ok && hi > -1.f && wi > -1.f && hi < g.h && wi < g.w;
+        const float hf = floorf(hi), wf = floorf(wi);
+        const int h_low = (int)hf, w_low = (int)wf;
+        const float lh = hi - hf, lw = wi - wf, hh = 1.f - lh, hw = 1.f - lw;
+        const int ry = h_low - wy0;
+        const bool inwin = ry >= 0 && ry + 1 < wn.wr;  // both rows are staged (rows outside the image as zeros)
+        const bool missl = in && !inwin;
+        const float wa = in ? hh * hw * mv_ : 0.f, wb = in ? hh * lw * mv_ : 0.f;
+        const float wc = in ? lh * hw * mv_ : 0.f, wd = in ? lh * lw * mv_ : 0.f;
+        float w1[2], w2[2], w3[2], w4[2];
+        unsigned la[2];
+        dcn_bcast_halves((in && inwin) ? (unsigned)(ry * wn.wrs + 4 + w_low) * 4u : 0u, la);
+        dcn_bcast_halves(wa, w1);
+        dcn_bcast_halves(wb, w2);
+        dcn_bcast_halves(wc, w3);
+        dcn_bcast_halves(wd, w4);
+        const float* wrow = wl + half * wn.rs + t * COP + l32;
+        const char* wb0 = (const char*)win + half_off;
+        for (int cq = 0; cq < wn.nch; cq += 2) {
+          float bv[2];
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            const float* r0 = (const float*)(wb0 + la[q]) + cq * wn.ws;
+            const float* r1 = (const float*)((const char*)r0 + wrs4);
+            bv[q] = w1[q] * r0[0] + w2[q] * r0[1] + w3[q] * r1[0] + w4[q] * r1[1];
+          }
+#pragma unroll
+          for (int m = 0; m < MT; ++m) {
+            const float a = wrow[cq * wn.rs + m * 32];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) acc[q][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv[q], acc[q][m], 0, 0, 0);
+          }
+        }
+        if (__builtin_amdgcn_ballot_w64(missl) != 0) {
+          // second pass for the lanes whose sample left the window: their corners from global memory as 8-byte pairs
+          // starting at clamp(w_low, 0, W-2), the column outside the image with weight 0; every other lane adds 0
+          const bool c0_ = w_low >= 0, c1_ = w_low + 1 <= g.w - 1;
+          const int xs = !c0_ ? 0 : (c1_ ? w_low : g.w - 2);
+          const int gbase = (h_low * g.w + xs) * 4;
+          unsigned ga0[2], ga1[2], fl[2];
+          float m1[2], m2[2], m3[2], m4[2];
+          dcn_bcast_halves((missl && h_low >= 0) ? (unsigned)gbase : (unsigned)DCN_OOB, ga0);
+          dcn_bcast_halves((missl && h_low + 1 <= g.h - 1) ? (unsigned)(gbase + g.w * 4) : (unsigned)DCN_OOB, ga1);
+          dcn_bcast_halves((c1_ ? 0u : 1u) | (c0_ ? 0u : 2u), fl);
+          dcn_bcast_halves((missl && c0_) ? wa : 0.f, m1);
+          dcn_bcast_halves((missl && c1_) ? wb : 0.f, m2);
+          dcn_bcast_halves((missl && c0_) ? wc : 0.f, m3);
+          dcn_bcast_halves((missl && c1_) ? wd : 0.f, m4);
+          for (int cq = 0; cq < wn.nch; cq += 2) {
+            float bv[2];
+            const int coff = (cabs + cq + half) * HW * 4;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+              const dcn_u32x2 b0 = __builtin_amdgcn_raw_buffer_load_b64(rx, (int)ga0[q] + coff, 0, 0);
+              const dcn_u32x2 b1 = __builtin_amdgcn_raw_buffer_load_b64(rx, (int)ga1[q] + coff, 0, 0);
+              const bool loy = fl[q] & 1u, hix = fl[q] & 2u;
+              const float v1 = __uint_as_float(loy ? b0.y : b0.x), v2 = __uint_as_float(hix ? b0.x : b0.y);
+              const float v3 = __uint_as_float(loy ? b1.y : b1.x), v4 = __uint_as_float(hix ? b1.x : b1.y);
+              bv[q] = m1[q] * v1 + m2[q] * v2 + m3[q] * v3 + m4[q] * v4;
+            }
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+              const float a = wrow[cq * wn.rs + m * 32];
+#pragma unroll
+              for (int q = 0; q < 2; ++q) acc[q][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv[q], acc[q][m], 0, 0, 0);
+            }
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int pg = p0 + 32 * q + l32;
+    if (pg >= P) continue;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = m * 32 + 8 * (r >> 2) + 4 * half + (r & 3);
+        if (co < g.co) out[((long)b * g.co + co) * P + pg] = acc[q][m][r] + (bias ? bias[co] : 0.f);
+      }
+  }
+}
+
 static int dcn_fused_rs(int K, int cop) {
   int rs = K * cop;            // a multiple of 32: the half-waves (channel cq, cq+1) must sit 32 banks apart
   if (rs % 64 == 0) rs += 32;
@@ -1148,13 +1322,15 @@ static DcnWin dcn_win_plan(const DcnGeom& g, int cop) {
   if (wn.halo < 0) wn.halo = 0;
   const int rows = (DCN_FWD_THREADS + g.wo - 2) / g.wo + 1;  // output rows a tile of consecutive positions can touch
   wn.wr = (rows - 1) * g.sh + (g.kh - 1) * g.dh + 2 + 2 * wn.halo;
-  wn.ws = wn.wr * g.w;
+  const char* pe = getenv("RTP_DCN_NOPAD");
+  wn.wrs = ((g.w & 3) == 0 && g.w + 4 <= 4 * DCN_FWD_THREADS && !(pe && atoi(pe))) ? g.w + 4 : 0;
+  wn.ws = wn.wrs ? wn.wr * wn.wrs + 4 : wn.wr * g.w;
   wn.ws = (wn.ws + 31) / 32 * 32;
   if (wn.ws % 64 == 0) wn.ws += 32;  // channel cq+1 (upper half-wave) 32 banks away from channel cq
   wn.nch = 0;
   const char* nw = getenv("RTP_DCN_NOWIN");
   if (nw && atoi(nw)) return wn;
-  for (int budget : {72 * 1024, 156 * 1024}) {
+  for (int budget : {78 * 1024, 156 * 1024})  // two blocks per CU, else one {
     for (int n = cpg; n >= 2; --n) {
       if (cpg % n || n % 2) continue;
       if ((long)n * (wn.ws + wn.rs) * 4 <= budget) { wn.nch = n; return wn; }
@@ -1172,7 +1348,12 @@ static void dcn_forward_fused(const float* input, const float* weight, const flo
   const DcnWin wn = dcn_win_plan(g, cop);
   if (wn.nch) {
     const size_t lds = (size_t)wn.nch * (wn.ws + wn.rs) * sizeof(float);
-    if (cop == 32)
+    if (wn.wrs) {
+      if (cop == 32)
+        hipLaunchKernelGGL(dcn_winp_fwd_kernel<1>, grid, dim3(DCN_FWD_THREADS), lds, s, input, offset, mask, ws, bias, output, g, wn);
+      else
+        hipLaunchKernelGGL(dcn_winp_fwd_kernel<2>, grid, dim3(DCN_FWD_THREADS), lds, s, input, offset, mask, ws, bias, output, g, wn);
+    } else if (cop == 32)
       hipLaunchKernelGGL(dcn_win_fwd_kernel<1>, grid, dim3(DCN_FWD_THREADS), lds, s, input, offset, mask, ws, bias, output, g, wn);
     else
       hipLaunchKernelGGL(dcn_win_fwd_kernel<2>, grid, dim3(DCN_FWD_THREADS), lds, s, input, offset, mask, ws, bias, output, g, wn);
