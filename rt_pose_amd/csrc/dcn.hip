@@ -1330,7 +1330,7 @@ static DcnWin dcn_win_plan(const DcnGeom& g, int cop) {
   wn.nch = 0;
   const char* nw = getenv("RTP_DCN_NOWIN");
   if (nw && atoi(nw)) return wn;
-  for (int budget : {78 * 1024, 156 * 1024})  // two blocks per CU, else one {
+  for (int budget : {78 * 1024, 156 * 1024}) {  // two blocks per CU, else one
     for (int n = cpg; n >= 2; --n) {
       if (cpg % n || n % 2) continue;
       if ((long)n * (wn.ws + wn.rs) * 4 <= budget) { wn.nch = n; return wn; }
