@@ -206,27 +206,34 @@ def main():
     # BASELINE config 2, reported beside the metric: forward + key-point decode only (the same plan's forward list; in
     # training mode it also writes the statistics the backward needs), same batch, timed after the train steps
     if not args.no_forward:
-        tr.engine.set_test_cfg(configs.test_cfg())
-        for _ in range(3):
-            tr.forward_only()
+        from rt_pose_amd.engine import PoseEngine
+        inf = PoseEngine(tr.be, tr.flat.values, spec["arch"], spec["final_fuse"], spec["heads"], spec["weight"],
+                         spec["code_weights"], args.batch, configs.NATIVE_DIMS, train=False, test_cfg=configs.test_cfg())
+        with tr._on_stream():
+            inf.load_input(ex["rdr"]["rdr_tensor"])
+            for _ in range(3):
+                inf.run_forward()
+                inf.run_decode()
         barrier()
         t1 = time.perf_counter()
         nf = max(10, args.steps)
         for _ in range(nf):
             with tr._on_stream():
-                tr.engine.run_forward()
-                tr.engine.run_decode()
+                inf.run_forward()
+                inf.run_decode()
         barrier()
         el_f = time.perf_counter() - t1
         if world > 1:
             t = torch.tensor([el_f], device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el_f = float(t)
-        line["forward_only"] = {"workload": "%s backbone + head forward + decode, %d frames/GPU, bf16 (BASELINE config 2)" % (args.model, args.batch),
+        line["forward_only"] = {"workload": "%s backbone + head forward + key-point decode (inference plan), %d frames/GPU, bf16 "
+                                            "(BASELINE config 2)" % (args.model, args.batch),
                                 "value": round(world * args.batch * nf / el_f, 2), "unit": "frames/s",
                                 "ms_per_batch": round(1e3 * el_f / nf, 3),
                                 "mfma_frac": round(world * args.batch * nf / el_f * g.flops["conv_fwd"] / args.batch
                                                    / (world * PEAK_BF16_TFLOPS * 1e12), 4)}
+        del inf
 
     if world == 1 and not args.no_roofline:
         be = tr.be
