@@ -295,7 +295,9 @@ int rtp_adam_step(float* p, const float* g, float* m, float* v, long n, const fl
 /* ---------------------------------------------------------------- D. deformable convolution --- */
 /* One-for-one replacements of deform_conv_cuda.cpp:152-157, 262-268, 376-381, 490-496, 571-578.
  * Tensors are contiguous NCHW fp32 as in the reference; `columns`/`ones` scratch is replaced by
- * an explicit workspace (size from rtp_dcn_workspace_bytes).  Argument order keeps the reference's
+ * an explicit workspace (size from rtp_dcn_workspace_bytes, n = im2col_step images; opaque scratch: transposed
+ * weights for the fused forward, columns, the column gradient in its own layout -- contents are undefined after a
+ * call, 16-byte aligned base required).  Argument order keeps the reference's
  * (kW,kH,dW,dH,padW,padH,dilW,dilH) W-before-H convention. */
 long rtp_dcn_workspace_bytes(int n, int c, int h, int w, int co, int kh, int kw, int ho, int wo);
 int rtp_deform_conv_forward(const float* input, const float* weight, const float* offset, float* output, void* ws,
