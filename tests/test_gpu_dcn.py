@@ -163,3 +163,57 @@ def test_zero_offset_pack_is_conv_and_error_behaviour():
     small = DeformConv(4, 4, 3, padding=1).cuda()
     y = small(torch.randn(1, 4, 2, 2, device="cuda"), torch.zeros(1, 18, 2, 2, device="cuda"))
     assert tuple(y.shape) == (1, 4, 2, 2)
+
+
+def test_full_size_properties():
+    """BASELINE config 4 shape ([128,32,64,160], deformable_groups 4, im2col_step 64), where the oracle is too slow:
+    size-independent properties.  (a) zero offsets: DCN == conv2d (forward and all three gradients, torch fp32 as the
+    comparator); (b) integer offsets (every tap shifted by (+1, -2)): DCN == conv2d of the shifted image (away from the border);
+    (c) linearity in the input at random fractional offsets; (d) the gather and the LDS-plane / scatter grad_input paths
+    agree at random offsets."""
+    import os
+    import torch.nn.functional as F
+    from rt_pose_amd.dcn import deform_conv
+    n, c, h, w, co, dg = 128, 32, 64, 160, 32, 4
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.randn(n, c, h, w, device="cuda", generator=g)
+    wt = torch.randn(co, c, 3, 3, device="cuda", generator=g) * 0.05
+    gy = torch.randn(n, co, h, w, device="cuda", generator=g)
+    zero = torch.zeros(n, dg * 18, h, w, device="cuda")
+    # (a)
+    xa, wa, oa = x.clone().requires_grad_(True), wt.clone().requires_grad_(True), zero.clone().requires_grad_(True)
+    ya = deform_conv(xa, oa, wa, 1, 1, 1, 1, dg, 64)
+    ya.backward(gy)
+    xr, wr = x.clone().requires_grad_(True), wt.clone().requires_grad_(True)
+    yr = F.conv2d(xr, wr, None, 1, 1)
+    yr.backward(gy)
+    assert rel_err(ya, yr) < 1e-5
+    assert rel_err(xa.grad, xr.grad) < 1e-5
+    assert rel_err(wa.grad, wr.grad) < 1e-4   # 1.3 M-term fp32 sums in different orders
+    # (b)
+    off = zero.clone()
+    off[:, 0::2] = 1.0
+    off[:, 1::2] = -2.0
+    yb = deform_conv(x, off, wt, 1, 1, 1, 1, dg, 64)
+    xs = torch.zeros_like(x)
+    xs[:, :, :h - 1, 2:] = x[:, :, 1:, :w - 2]           # xs[y, x] = x[y + 1, x - 2]
+    # interior only: at the border the shifted taps read real pixels where the plain conv sees its zero padding
+    assert rel_err(yb[:, :, 2:h - 2, 4:w - 4], F.conv2d(xs, wt, None, 1, 1)[:, :, 2:h - 2, 4:w - 4]) < 1e-5
+    # (c) + (d)
+    offr = torch.randn(n, dg * 18, h, w, device="cuda", generator=g) * 0.8
+    x2 = torch.randn(n, c, h, w, device="cuda", generator=g)
+    y1, y2 = deform_conv(x, offr, wt, 1, 1, 1, 1, dg, 64), deform_conv(x2, offr, wt, 1, 1, 1, 1, dg, 64)
+    y12 = deform_conv(x + 2.0 * x2, offr, wt, 1, 1, 1, 1, dg, 64)
+    assert rel_err(y12, y1 + 2.0 * y2) < 1e-5
+    grads = {}
+    for R in ("2", "0"):
+        os.environ["RTP_DCN_GATHER_R"] = R
+        try:
+            xg = x.clone().requires_grad_(True)
+            og = offr.clone().requires_grad_(True)
+            deform_conv(xg, og, wt, 1, 1, 1, 1, dg, 64).backward(gy)
+            grads[R] = (xg.grad.clone(), og.grad.clone())
+        finally:
+            del os.environ["RTP_DCN_GATHER_R"]
+    assert rel_err(grads["2"][0], grads["0"][0]) < 1e-5
+    assert rel_err(grads["2"][1], grads["0"][1]) < 1e-6
