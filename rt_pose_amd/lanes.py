@@ -19,10 +19,15 @@ LANE_MAP = [int(v) for v in os.environ.get("RTP_LANES", "0,1,2,3,4,5").split(","
 assert len(LANE_MAP) == NLANES and all(0 <= v < NLANES for v in LANE_MAP)
 
 
+BUF_BYTES = {}   # data_ptr -> bytes of every buffer a launch names (tools/plan_times.py prices launches with it)
+
+
 def _key(t):
     if t is None:
         return None
     buf = getattr(t, "buf", t)
+    if hasattr(buf, "numel"):
+        BUF_BYTES[buf.data_ptr()] = buf.numel() * buf.element_size()
     return buf.data_ptr()
 
 

@@ -40,7 +40,10 @@ def main():
             e1.record()
             rows.append((phase, L, e0, e1))
     torch.cuda.synchronize()
+    from rt_pose_amd.lanes import BUF_BYTES
+    nbytes = {id(L): sum(BUF_BYTES.get(k, 0) for k in set(L.reads) | set(L.writes)) for _, L in launches}
     out = [(e0.elapsed_time(e1) * 1e3 / a.rep, phase, L.lane, L.tag) for phase, L, e0, e1 in rows]
+    bybytes = {(phase, L.tag): nbytes[id(L)] for phase, L, _, _ in rows}
     tot = sum(t for t, *_ in out)
     print("serial total %.2f ms over %d launches" % (tot / 1e3, len(out)))
     agg = {}
@@ -56,7 +59,8 @@ def main():
     print("-- by lane", {k: round(v) for k, v in sorted(lag.items())})
     print("-- top launches")
     for t, phase, lane, tag in sorted(out, key=lambda r: -r[0])[:a.top]:
-        print("%8.1f us  %s lane %d  %s" % (t, phase, lane, tag))
+        nb = bybytes.get((phase, tag), 0)
+        print("%8.1f us  %s lane %d  %-28s %7.1f MB named buffers -> %5.0f GB/s" % (t, phase, lane, tag, nb / 1e6, nb / t / 1e3))
 
 
 if __name__ == "__main__":
