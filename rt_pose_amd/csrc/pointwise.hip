@@ -563,6 +563,49 @@ __global__ __launch_bounds__(256) void adjoint_axis_kernel(const TIN* in, int in
   }
 }
 
+// x and y passes in one kernel: out[n*d][hl][wl][c] = sum_oy wy(oy -> hl) * (sum_ox wx(ox -> wl) * in[n*d][oy][ox][c]) with the
+// row sums formed first, in the same order as the two separate passes (bit-identical results) -- but the fp32 row
+// intermediate [n][d][h][wl][c] (as many bytes as the bf16 input) is neither written nor read back: 346 -> 178 MB per
+// level-1 -> level-0 adjoint.  Neighbouring outputs share their (2/scale + 2)^2 inputs through L1.
+__global__ __launch_bounds__(256) void adjoint_xy_kernel(const bf16_t* in, int in_cs, int in_co, float* out, int c, long outer,
+                                                         int HL, int H, int WL, int W) {
+  const int cpv = c >> 3;
+  const long total = outer * HL * WL * cpv;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int ck = (int)(i % cpv);
+    long r = i / cpv;
+    const int xl = (int)(r % WL); r /= WL;
+    const int yl = (int)(r % HL);
+    const long ou = r / HL;
+    int ylo, yhi, xlo, xhi;
+    support(yl, HL, H, ylo, yhi);
+    support(xl, WL, W, xlo, xhi);
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    for (int oy = ylo; oy <= yhi; ++oy) {
+      const float wy = adj_w(oy, yl, HL, H);
+      if (wy == 0.f) continue;
+      float row[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) row[j] = 0.f;
+      const bf16_t* srow = in + ((ou * H + oy) * W) * in_cs + in_co + ck * 8;
+      for (int ox = xlo; ox <= xhi; ++ox) {
+        const float wx = adj_w(ox, xl, WL, W);
+        if (wx == 0.f) continue;
+        const bf16_t* src = srow + (long)ox * in_cs;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) row[j] += wx * (float)src[j];
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += wy * row[j];
+    }
+    float* dst = out + ((ou * HL + yl) * WL + xl) * c + ck * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dst[j] = acc[j];
+  }
+}
+
 extern "C" long rtp_upsample_bwd_scratch_floats(int n, int c, int d, int h, int w, int dl, int hl, int wl) {
   (void)w; (void)dl;
   return (long)n * c * ((long)d * h * wl + (long)d * hl * wl);
@@ -577,12 +620,18 @@ extern "C" int rtp_upsample_bwd(const RtpAct* ghi, int d, int h, int w, const Rt
   float* t2 = scratch + (long)n * d * h * wl * c;    // [n][d][hl][wl][c]
   hipStream_t s = (hipStream_t)stream;
   RtpProfScope prof(RTP_FAM_POINTWISE, s);
-  // x: outer = n*d*h rows, inner = 1
-  hipLaunchKernelGGL((adjoint_axis_kernel<bf16_t, float>), dim3(grid_for((long)n * d * h * wl * (c / 8))), dim3(256), 0, s,
-                     (const bf16_t*)ghi->ptr, ghi->cs, ghi->co, t1, c, 0, c, (long)n * d * h, wl, w, 1L);
-  // y: outer = n*d, inner = wl
-  hipLaunchKernelGGL((adjoint_axis_kernel<float, float>), dim3(grid_for((long)n * d * hl * wl * (c / 8))), dim3(256), 0, s,
-                     (const float*)t1, c, 0, t2, c, 0, c, (long)n * d, hl, h, (long)wl);
+  if (h <= 3 * hl && w <= 3 * wl) {
+    // x and y fused (small supports: the x2 adjoints from the full-resolution level): outer = n*d slices
+    hipLaunchKernelGGL(adjoint_xy_kernel, dim3(grid_for((long)n * d * hl * wl * (c / 8))), dim3(256), 0, s,
+                       (const bf16_t*)ghi->ptr, ghi->cs, ghi->co, t2, c, (long)n * d, hl, h, wl, w);
+  } else {
+    // x: outer = n*d*h rows, inner = 1
+    hipLaunchKernelGGL((adjoint_axis_kernel<bf16_t, float>), dim3(grid_for((long)n * d * h * wl * (c / 8))), dim3(256), 0, s,
+                       (const bf16_t*)ghi->ptr, ghi->cs, ghi->co, t1, c, 0, c, (long)n * d * h, wl, w, 1L);
+    // y: outer = n*d, inner = wl
+    hipLaunchKernelGGL((adjoint_axis_kernel<float, float>), dim3(grid_for((long)n * d * hl * wl * (c / 8))), dim3(256), 0, s,
+                       (const float*)t1, c, 0, t2, c, 0, c, (long)n * d, hl, h, (long)wl);
+  }
   // z: outer = n, inner = hl*wl
   hipLaunchKernelGGL((adjoint_axis_kernel<float, bf16_t>), dim3(grid_for((long)n * dl * hl * wl * (c / 8))), dim3(256), 0, s,
                      (const float*)t2, c, 0, (bf16_t*)glow->ptr, glow->cs, glow->co, c, (long)n, dl, d, (long)hl * wl);
