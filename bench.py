@@ -58,6 +58,74 @@ def cpu_baseline(name, seconds_budget=30.0):
                        % (steps, batch, O.ARCHS[arch]["inplanes"], cores))
 
 
+def torch_gpu_child_run(name="hr3d", batch=8, amp=False, steps=3, warm=2, dev="cuda:0"):
+    import torch
+    from oracle import hrradarpose_ref as O
+    arch, fin, fout, fuse, heads, weight, cw = O.MODEL_CONFIGS[name]
+    shapes = O.param_shapes(arch, fin, fout, fout, heads)
+    sd = {k: v.to(dev).requires_grad_(True) for k, v in O.seeded_state_dict(shapes, seed=1).items()}
+    opt = O.AdamTrueWD(list(sd.values()))
+    ex = O.synth_example(batch, O.ARCHS[arch]["inplanes"], (16, 64, 160), seed=1234, one_hm=heads["hm"] == 1)
+
+    def to_dev(v):
+        if torch.is_tensor(v):
+            return v.to(dev)
+        if isinstance(v, dict):
+            return {k: to_dev(x) for k, x in v.items()}
+        if isinstance(v, (list, tuple)):
+            return type(v)(to_dev(x) for x in v)
+        return v
+    ex = to_dev(ex)
+
+    def step():
+        for p in sd.values():
+            p.grad = None
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+            loss = O.radar_pose_net(sd, ex, fuse, weight, cw)["loss"][0]
+        loss.backward()
+        opt.step(1e-4, 0.95)
+        return loss
+
+    t0 = time.perf_counter()
+    for _ in range(warm):
+        step()
+    torch.cuda.synchronize()
+    t_warm = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    return dict(value=round(batch * steps / el, 2), unit="frames/s", ms_per_step=round(1e3 * el / steps, 2),
+                dtype="bf16 autocast" if amp else "fp32", batch=batch, warmup_s=round(t_warm, 1), loss=float(loss),
+                peak_mem_GB=round(torch.cuda.max_memory_allocated() / 1e9, 1))
+
+
+
+def torch_gpu_baseline(name, batch, limit_s=300):
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--torch-gpu-child", name, str(batch)]
+    out = {"what": "oracle/hrradarpose_ref.py (the reference's model + train step in plain PyTorch) with its tensors on this GPU: "
+                   "ATen / MIOpen kernels, eager autograd, %d frames" % batch, "unit": "frames/s"}
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=limit_s)
+        for ln in r.stdout.splitlines():
+            if ln.startswith("TORCH_GPU "):
+                d = json.loads(ln[len("TORCH_GPU "):])
+                out[d["dtype"].replace(" ", "_")] = {"value": d["value"], "ms_per_step": d["ms_per_step"]}
+        if len(out) == 2:
+            out["error"] = "no result (exit code %d)" % r.returncode
+    except subprocess.TimeoutExpired as e:
+        for ln in (e.stdout or b"").decode(errors="replace").splitlines() if isinstance(e.stdout, bytes) else (e.stdout or "").splitlines():
+            if ln.startswith("TORCH_GPU "):
+                d = json.loads(ln[len("TORCH_GPU "):])
+                out[d["dtype"].replace(" ", "_")] = {"value": d["value"], "ms_per_step": d["ms_per_step"]}
+        out["note"] = "stopped after %d s" % limit_s
+    except Exception as e:  # informational leg: never fail the bench line
+        out["error"] = repr(e)
+    return out
+
+
 def dcn_op_bench(dev, batch, iters=10):
     import torch
     from rt_pose_amd.dcn import deform_conv
@@ -127,6 +195,11 @@ def lidar_bench(dev, batch, npts=200000, iters=5):
 
 
 def main():
+    if len(sys.argv) >= 4 and sys.argv[1] == "--torch-gpu-child":   # child process of the torch_gpu_baseline leg
+        for amp in (True, False):
+            print("TORCH_GPU " + json.dumps(torch_gpu_child_run(sys.argv[2], int(sys.argv[3]), amp, steps=3 if amp else 2,
+                                                                warm=2 if amp else 1)), flush=True)
+        return
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -138,6 +211,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="(default) kept for compatibility")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-torch-gpu", action="store_true", help="skip the PyTorch-eager-on-this-GPU baseline leg")
     ap.add_argument("--no-lidar", action="store_true", help="skip the LiDAR voxelisation (config 5 pieces) leg")
     ap.add_argument("--no-dcn", action="store_true", help="skip the DCN operator (config 4) leg")
     ap.add_argument("--no-forward", action="store_true", help="skip the forward-only (config 2) leg")
@@ -289,6 +363,11 @@ def main():
     # dense scatter of one 200 000-point LiDAR frame per radar frame
     if world == 1 and not args.no_lidar:
         line["lidar_stream"] = lidar_bench(dev, args.batch)
+    # The reference-style PyTorch path on this same GPU (the oracle with its tensors on the device: stock ATen / MIOpen
+    # kernels, eager autograd -- what the reference itself would execute here), in a child process with a time limit so
+    # that nothing it does can touch this process; informational like cpu_baseline.
+    if world == 1 and not args.no_torch_gpu:
+        line["torch_gpu_baseline"] = torch_gpu_baseline(args.model, args.batch)
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(args.model)
     if rank == 0:
