@@ -217,3 +217,54 @@ def test_full_size_properties():
             del os.environ["RTP_DCN_GATHER_R"]
     assert rel_err(grads["2"][0], grads["0"][0]) < 1e-5
     assert rel_err(grads["2"][1], grads["0"][1]) < 1e-6
+
+
+def _random_case(rs):
+    k = int(rs.choice([1, 3, 3, 3]))
+    stride, dil = int(rs.choice([1, 1, 2])), int(rs.choice([1, 1, 2]))
+    pad = int(rs.randint(0, 3))
+    groups = int(rs.choice([1, 1, 1, 2]))
+    dg = int(rs.choice([1, 2, 4]))
+    cmul = int(rs.randint(1, 5))
+    c = groups * dg * cmul * int(rs.choice([1, 2]))
+    co = groups * int(rs.randint(1, 21))
+    h, w = int(rs.randint(5, 40)), int(rs.randint(5, 40))
+    if rs.rand() < 0.5:
+        w = (w + 3) // 4 * 4          # the padded-row window kernel needs W % 4 == 0
+    n = int(rs.choice([1, 2, 3, 4]))
+    step = int(rs.choice([d for d in (1, 2, 3, 4) if n % d == 0]))
+    return n, c, h, w, co, k, stride, pad, dil, groups, dg, step
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_dcn_random_geometries(seed):
+    """Random kernel size / stride / padding / dilation / groups / deformable groups / image sizes (ragged tiles, windows
+    that hang over the image, single-row outputs ...) and offset scales against the oracle: forward + all gradients."""
+    import numpy as np
+    from rt_pose_amd.dcn import deform_conv
+    rs = np.random.RandomState(1000 + seed)
+    for _ in range(20):
+        n, c, h, w, co, k, stride, pad, dil, groups, dg, step = _random_case(rs)
+        ho = (h + 2 * pad - (dil * (k - 1) + 1)) // stride + 1
+        wo = (w + 2 * pad - (dil * (k - 1) + 1)) // stride + 1
+        if ho >= 1 and wo >= 1:
+            break
+    else:
+        pytest.skip("no valid geometry drawn")
+    scale = float(rs.choice([0.0, 0.3, 1.0, 3.0, 12.0]))
+    x = rnd(n, c, h, w, seed=seed * 7 + 1).requires_grad_(True)
+    wt = rnd(co, c // groups, k, k, seed=seed * 7 + 2, scale=0.3).requires_grad_(True)
+    off = rnd(n, dg * 2 * k * k, ho, wo, seed=seed * 7 + 3, scale=scale).requires_grad_(True)
+    ref = deform_conv2d(x, off, wt, stride, pad, dil, groups, dg)
+    gy = rnd(*ref.shape, seed=seed * 7 + 4)
+    ref.backward(gy)
+    xg, wg, og = [t.detach().cuda().requires_grad_(True) for t in (x, wt, off)]
+    out = deform_conv(xg, og, wg, stride, pad, dil, groups, dg, step)
+    out.backward(gy.cuda())
+    torch.cuda.synchronize()
+    case = (n, c, h, w, co, k, stride, pad, dil, groups, dg, step, scale)
+    assert rel_err(out.cpu(), ref) < TOL, case
+    assert rel_err(xg.grad.cpu(), x.grad) < TOL, case
+    assert rel_err(wg.grad.cpu(), wt.grad) < TOL, case
+    if scale > 0 or float(off.grad.abs().max()) > 0:
+        assert rel_err(og.grad.cpu(), off.grad) < TOL, case
