@@ -199,6 +199,27 @@ def test_wgrad(hip, case):
     assert rel_err(got, wz.grad) < 1e-3
 
 
+@pytest.mark.parametrize("seed", range(16))
+def test_conv_kernels_random_geometries(hip, seed):
+    """Random volumes (tiled-friendly and ragged, down to single voxels), channel counts, kernel sizes, strides and
+    epilogue options through the three convolution entry points (forward, data gradient, weight gradient); a run of
+    360 such draws was clean when this was added."""
+    rs = np.random.RandomState(4200 + seed)
+    if rs.randint(0, 3) == 0:
+        d3 = (int(rs.choice([2, 4, 6])), int(rs.choice([8, 16, 24])), int(rs.choice([32, 64, 80, 96])))
+    else:
+        d3 = (int(rs.randint(1, 7)), int(rs.randint(1, 20)), int(rs.randint(1, 50)))
+    n = int(rs.randint(1, 4))
+    ci = int(rs.choice([32, 32, 64, 128]))
+    co_real = int(rs.choice([3, 15, 16, 32, 32, 45, 64, 128]))
+    ks, stride = int(rs.choice([1, 3, 3])), int(rs.choice([1, 1, 2]))
+    per_sample, has_res, relu = bool(rs.rand() < 0.6), bool(rs.rand() < 0.4), bool(rs.rand() < 0.5)
+    fp32 = bool(co_real % 16 != 0 or rs.rand() < 0.2)
+    test_conv_forward(hip, (n, d3, ci, co_real, ks, stride, per_sample, has_res, relu, fp32))
+    test_conv_transposed_is_data_gradient(hip, (n, d3, ci, co_real, ks, stride))
+    test_wgrad(hip, (n, d3, ci, co_real, ks, stride, int(rs.randint(1, 5))))
+
+
 @pytest.mark.parametrize("c,vox,nsplit,with_b", [(32, 1000, 3, False), (64, 333, 1, True), (128, 2048, 7, True), (32, 64, 4, False)])
 def test_chan_stats(hip, c, vox, nsplit, with_b):
     n = 2
