@@ -97,6 +97,30 @@ def test_train_step_vs_oracle_and_emulated_plan(hip, name):
     assert all(float(flat.grads[k].abs().max()) == 0 for k in dead)
 
 
+@pytest.mark.parametrize("name,dims,batch", [("hr3d", (8, 24, 40), 3), ("hr3d", (24, 8, 16), 1), ("hr3d_one_hm", (16, 16, 48), 1),
+                                             ("hr3d_one_hm_doppler", (8, 8, 8), 3)])
+def test_train_step_other_shapes(hip, name, dims, batch):
+    """Volumes with other aspect ratios (non-tiled widths, the smallest volume the three stride-2 levels allow) and odd
+    batch sizes against the oracle's fp32 autograd: loss and parameter-gradient direction (24 such combinations were
+    clean when this was added)."""
+    arch, fin, fout, fuse, heads, weight, cw = O.MODEL_CONFIGS[name]
+    ex = O.synth_example(batch, O.ARCHS[arch]["inplanes"], dims, seed=4321, one_hm=heads["hm"] == 1)
+    eng, flat, sd = make(hip, name, batch, dims)
+    eng.load_input(ex["rdr"]["rdr_tensor"])
+    eng.load_targets(ex["rdr"])
+    eng.run_forward()
+    eng.run_loss_backward()
+    torch.cuda.synchronize()
+    sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ref = O.radar_pose_net(sdr, ex, fuse, weight, cw)
+    ref["loss"][0].backward()
+    live = [k for k in sd if sdr[k].grad is not None]
+    gh, gr = cat_grads(flat, live), torch.cat([sdr[k].grad.reshape(-1) for k in live])
+    loss, lref = float(eng.losses()["loss"].float().sum()), float(ref["loss"][0].detach())
+    assert abs(loss - lref) < 3e-2 * abs(lref) + 1e-4
+    assert float(torch.dot(gh, gr) / (gh.norm() * gr.norm())) > 0.96
+
+
 def test_native_shape_properties(hip):
     """[2,1,16,64,160]: determinism, batch independence (GroupNorm is per-sample), loss decreases under the
     reference's optimiser rule, oracle agreement of the forward on one frame."""
