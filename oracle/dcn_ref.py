@@ -2,9 +2,10 @@
 
 TEST INFRASTRUCTURE (see oracle/__init__.py).  PARITY UNPINNED by the reference: it ships no tests for this operator
 and its CUDA sources (det3d/ops/dcn/src/*.cu, THC headers, nvcc) cannot be built or imported in this image, so this
-file restates the published algorithm from the reference's own kernels and is pinned only by known-answer tests
+file restates the published algorithm from the reference's own kernels and is held only by property tests
 (tests/test_dcn_oracle.py: zero offsets == F.conv2d, integer offsets == shifted conv, out-of-window taps == 0,
-mask == 1 reduces v2 to v1, fp64 gradcheck).
+mask == 1 reduces v2 to v1, fp64 gradcheck) and a small fixed case whose expected values this file itself produced
+(tests/golden/dcn_known_answer.json -- not an external pin; see its provenance).
 
 Restated from det3d/ops/dcn/src/deform_conv_cuda_kernel.cu:
   bilinear sample with per-corner bounds ................. :85-115  (dmcn_im2col_bilinear :467-495)

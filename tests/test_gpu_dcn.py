@@ -268,3 +268,16 @@ def test_dcn_random_geometries(seed):
     assert rel_err(wg.grad.cpu(), wt.grad) < TOL, case
     if scale > 0 or float(off.grad.abs().max()) > 0:
         assert rel_err(og.grad.cpu(), off.grad) < TOL, case
+
+
+@pytest.mark.parametrize("mode", list(MODES))
+def test_small_fixed_case_on_the_gpu(mode, monkeypatch):
+    """The HIP operator (through the C ABI) on the small fixed case of tests/golden/dcn_known_answer.json, whose expected
+    values were generated by the oracle (self-consistency, not an external pin): forward and all gradients."""
+    from rt_pose_amd.dcn import deform_conv
+    from tests.test_dcn_oracle import run_known_answer
+    set_mode(monkeypatch, mode)
+
+    def dcn(x, off, w):
+        return deform_conv(x.cuda(), off.cuda(), w.cuda(), 1, 0, 1, 1, 1, 1).cpu()
+    run_known_answer(dcn)
