@@ -95,9 +95,12 @@ def _voxel_coords(p_xyz, range_zyx_min, voxel_size_xyz, osf_zyx):
     """(x,y,z) metres -> fp32 voxel coordinates (pose.py:222-227); the intermediate is kept in float64 and rounded once,
     which is what numpy 1.x (the reference's era) does; numpy >= 2 evaluates it in fp32 (<= 1 ulp apart)."""
     x, y, z = [float(v) for v in p_xyz]
-    c = [(x - float(range_zyx_min[2])) / float(voxel_size_xyz[0]) / float(osf_zyx[2]),
-         (y - float(range_zyx_min[1])) / float(voxel_size_xyz[1]) / float(osf_zyx[1]),
-         (z - float(range_zyx_min[0])) / float(voxel_size_xyz[2]) / float(osf_zyx[0])]
+    # the reference holds the ROI bounds in an np.float32 array (pose.py:190), so the subtraction sees the fp32-ROUNDED
+    # bound (-10.05 -> -10.0500001907...); the voxel size stays a Python double (info.DATASET.RDR_CUBE.GRID_SIZE)
+    rz, ry, rx = [float(np.float32(v)) for v in range_zyx_min]
+    c = [(x - rx) / float(voxel_size_xyz[0]) / float(osf_zyx[2]),
+         (y - ry) / float(voxel_size_xyz[1]) / float(osf_zyx[1]),
+         (z - rz) / float(voxel_size_xyz[2]) / float(osf_zyx[0])]
     return np.array(c, dtype=np.float32)
 
 

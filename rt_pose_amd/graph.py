@@ -304,10 +304,11 @@ class Graph:
     def emit_tail(self, lane=L_FULL):
         """The deferred items as two launches (stage a: class reductions + GroupNorm parameter sums; stage b: folds)."""
         import os
-        stages = [self.tail_a, self.tail_b]
+        a, b = self.tail_a, self.tail_b
         self.tail_a, self.tail_b = [], []
+        stages = [a, b]
         if os.environ.get("RTP_NO_TAIL"):   # A/B: one launch per item, like a per-layer plan
-            stages = [[it] for it in self.tail_a] + [[it] for it in self.tail_b]
+            stages = [[it] for it in a] + [[it] for it in b]
         for items in stages:
             if not items:
                 continue

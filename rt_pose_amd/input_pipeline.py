@@ -58,7 +58,8 @@ class DeviceInputPipeline:
         z, y, x = [self.roi_idx[2 * i + 1] - self.roi_idx[2 * i] + 1 for i in range(3)]
         if (z, y, x) != tuple(engine.dims):
             raise ValueError("ROI %r gives %r, the engine was planned for %r" % (roi, (z, y, x), engine.dims))
-        self.range_min = (C.c_double * 3)(roi["z"][0], roi["y"][0], roi["x"][0])
+        # the reference keeps the ROI bounds in an np.float32 array (pipelines/pose.py:190): use the fp32-rounded minima
+        self.range_min = (C.c_double * 3)(*[float(np.float32(roi[k][0])) for k in ("z", "y", "x")])
         self.vsize = (C.c_double * 3)(*[float(v) for v in voxel_size_xyz])
         self.osf = (C.c_int * 3)(*[int(v) for v in out_size_factor])
         self.roi_c = (C.c_int * 6)(*self.roi_idx)
@@ -83,6 +84,7 @@ class DeviceInputPipeline:
         engine.tgt_hm.zero_()   # once: from here on only the previously written boxes are cleared
         n_cube = self.b * self.cin * int(np.prod(self.stored))
         self.stream = torch.cuda.Stream(dev)
+        self.stream.wait_stream(torch.cuda.current_stream(dev))   # the zero fill above precedes the first splat
         self.ring = []
         for _ in range(ring):
             self.ring.append(dict(

@@ -82,6 +82,11 @@ class DataParallelTrainer:
         # keep the default priority, so their small kernels fill in around it instead of delaying it).
         prio = int(os.environ.get("RTP_MAIN_PRIORITY", "-1"))
         self.stream = torch.cuda.Stream(self.be.device, priority=prio) if self.be.name == "hip" else None
+        if self.stream is not None:
+            # construction-time work (zero fills, parameter upload, code weights) was queued on the current stream; the
+            # step stream is non-blocking with respect to it, so order the first step behind it explicitly
+            self.stream.wait_stream(torch.cuda.current_stream(self.be.device))
+            self._step_done = torch.cuda.Event()
 
     # ------------------------------------------------------------------ one step
     def _on_stream(self):
@@ -112,6 +117,8 @@ class DataParallelTrainer:
             self.load(example)
         with self._on_stream():
             self._step()
+            if self.stream is not None:
+                self._step_done.record(self.stream)   # feed_raw after a plain step() waits on a recorded event
 
     def _step(self):
         if self.use_graph:
@@ -134,7 +141,6 @@ class DataParallelTrainer:
     def attach_input_pipeline(self, pipe):
         """pipe: rt_pose_amd.input_pipeline.DeviceInputPipeline built on this trainer's engine."""
         self.pipe = pipe
-        self._step_done = torch.cuda.Event()
         self._fed = None
 
     def feed_raw(self, cubes_f16, poses):

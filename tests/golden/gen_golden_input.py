@@ -118,6 +118,17 @@ def synth_poses(seed, n):
     return poses
 
 
+def edge_poses():
+    """One pose whose key-points sit exactly on voxel boundaries of the EXACT (double) ROI minimum: p = min + k * voxel.
+    The reference subtracts the fp32-ROUNDED minimum (pose.py:190), so each of these lands a hair above or below an
+    integer voxel coordinate -- the case where rounding the bound differently changes ind / mask / the heat-map."""
+    p = []
+    for k in range(15):
+        p.append([ROI1["x"][0] + (3 + 9 * k) * GRID_SIZE[0], ROI1["y"][0] + (2 + 4 * k) * GRID_SIZE[1],
+                  ROI1["z"][0] + (k % 16) * GRID_SIZE[2]])
+    return [p]
+
+
 def main():
     pose_mod, ds_mod = import_reference()
     DS = ds_mod.CRUW_POSE_Dataset
@@ -174,10 +185,11 @@ def main():
     names15 = ["k%d" % i for i in range(15)]
     cases = [("a15", pose_mod.AssignLabelPose, names15, 1, 1, 1, 21), ("a15_none", pose_mod.AssignLabelPose, names15, 1, 1, 0, 22),
              ("a15_two", pose_mod.AssignLabelPose, names15, 2, 1, 2, 23), ("a1", pose_mod.AssignLabelPose2, ["Pelvis"], 1, 2, 1, 24),
-             ("a1_two", pose_mod.AssignLabelPose2, ["Pelvis"], 2, 2, 2, 25), ("a1_none", pose_mod.AssignLabelPose2, ["Pelvis"], 1, 2, 0, 26)]
+             ("a1_two", pose_mod.AssignLabelPose2, ["Pelvis"], 2, 2, 2, 25), ("a1_none", pose_mod.AssignLabelPose2, ["Pelvis"], 1, 2, 0, 26),
+             ("a15_edge", pose_mod.AssignLabelPose, names15, 1, 1, 1, -1), ("a1_edge", pose_mod.AssignLabelPose2, ["Pelvis"], 1, 2, 1, -1)]
     dummy = np.zeros((16, 64, 160), np.float32)
     for tag, cls, names, max_poses, min_radius, nposes, seed in cases:
-        poses = synth_poses(seed, nposes)
+        poses = synth_poses(seed, nposes) if seed >= 0 else edge_poses()
         cfg = AttrDict(out_size_factor=[1, 1, 1], target_assigner=AttrDict(tasks=[AttrDict(class_names=names)]),
                        gaussian_overlap=0.1, max_poses=max_poses, min_radius=min_radius)
         res, _ = cls(cfg=cfg)({"rdr_cube": dummy, "mode": "train", "meta": {}, "poses": poses, "hm_size": (16, 64, 160)}, info)

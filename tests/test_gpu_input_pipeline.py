@@ -153,3 +153,22 @@ def test_trainer_fed_from_raw_batches_matches_resident_inputs():
         torch.cuda.synchronize()
         want.append(float(ref.losses()["loss"]))
     assert np.allclose(got, want, rtol=1e-4), (got, want)
+
+
+@pytest.mark.parametrize("name,tag,min_radius", [("hr3d", "a15_edge", 1), ("hr3d_one_hm", "a1_edge", 2)])
+def test_keypoints_on_voxel_boundaries_follow_the_reference_fp32_bounds(name, tag, min_radius):
+    """Key-points exactly on voxel boundaries of the double-precision ROI minimum: the reference subtracts the
+    fp32-rounded minimum (pipelines/pose.py:190), which decides the integer voxel -- captured vectors, device path."""
+    from rt_pose_amd.input_pipeline import DeviceInputPipeline
+    eng = make_engine(name, 1)
+    rdr = "zyx_real"
+    pipe = DeviceInputPipeline(eng, ROI1, GRID_SIZE, (20000, 45000), rdr, max_poses=1, min_radius=min_radius)
+    gp = G["lab_%s_poses" % tag].tolist()
+    torch.cuda.current_stream().wait_event(pipe.submit(np.stack([synth_cube_f16(5)]), [gp]))
+    torch.cuda.synchronize()
+    hm = eng.tgt_hm[0].cpu().numpy()
+    nz = np.flatnonzero(hm)
+    assert np.array_equal(nz, G["lab_%s_hm_idx" % tag]) and np.array_equal(hm.reshape(-1)[nz], G["lab_%s_hm_val" % tag])
+    assert np.array_equal(eng.tgt_ind[0].cpu().numpy(), G["lab_%s_ind" % tag])
+    assert np.array_equal(eng.tgt_mask[0].cpu().numpy(), G["lab_%s_mask" % tag])
+    assert np.abs(eng.tgt_pose[0].cpu().numpy() - G["lab_%s_anno" % tag]).max() <= 2e-5

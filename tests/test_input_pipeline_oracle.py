@@ -38,7 +38,7 @@ def test_cube_phase():
     assert np.array_equal(t.reshape(-1)[::997], G["cube_phase_sample"])
 
 
-@pytest.mark.parametrize("tag", ["a15", "a15_none", "a15_two", "a1", "a1_two", "a1_none"])
+@pytest.mark.parametrize("tag", ["a15", "a15_none", "a15_two", "a1", "a1_two", "a1_none", "a15_edge", "a1_edge"])
 def test_label_assignment(tag):
     seed, nposes, max_poses, min_radius, ncls = [int(v) for v in G["lab_%s_cfg" % tag]]
     poses = G["lab_%s_poses" % tag].tolist()

@@ -128,3 +128,24 @@ def test_flat_params_runs():
     fp = FlatParams(shapes, EmuBackend().alloc)
     assert fp.numel == 16
     assert fp.runs({"a", "b", "d"}) == [(0, 10, True), (10, 15, False), (15, 16, True)]
+
+
+def test_no_tail_switch_keeps_every_deferred_item(monkeypatch):
+    """RTP_NO_TAIL (the per-item A/B switch of DESIGN 8d) must emit one launch per deferred item, not drop them:
+    parameter gradients are identical with and without it."""
+    grads = {}
+    for flag in (None, "1"):
+        if flag:
+            monkeypatch.setenv("RTP_NO_TAIL", flag)
+        else:
+            monkeypatch.delenv("RTP_NO_TAIL", raising=False)
+        eng, flat, sd, ex, _ = make("hr3d", exact=True)
+        eng.load_input(ex["rdr"]["rdr_tensor"])
+        eng.load_targets(ex["rdr"])
+        eng.run_forward()
+        eng.run_loss_backward()
+        grads[flag] = flat.g.clone()
+        ntail = sum(1 for L in eng.bwd if L.tag == "tail")
+        assert ntail > 50 if flag else ntail <= 3, ntail
+    assert float(grads[None].abs().max()) > 0
+    assert torch.equal(grads[None], grads["1"])

@@ -1,8 +1,9 @@
 #!/bin/bash
 # HBM bytes of a whole training step: FETCH_SIZE and WRITE_SIZE summed over every kernel of `bench.py --steps 6 --warmup 2`
+# (only the train-step leg is active: every other bench leg, and the torch child process, is switched off)
 export TMPDIR=/tmp
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d gpurun_out/pmc_step_f -o run --output-format csv -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-roofline > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d gpurun_out/pmc_step_w -o run --output-format csv -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-roofline > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d gpurun_out/pmc_step_f -o run --output-format csv -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-roofline --no-forward --no-dcn --no-lidar --no-torch-gpu > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d gpurun_out/pmc_step_w -o run --output-format csv -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-roofline --no-forward --no-dcn --no-lidar --no-torch-gpu > /dev/null 2>&1
 python3 - <<'P'
 import csv, collections
 for d, nm in (("f", "FETCH_SIZE"), ("w", "WRITE_SIZE")):
