@@ -87,6 +87,8 @@ class DataParallelTrainer:
             # step stream is non-blocking with respect to it, so order the first step behind it explicitly
             self.stream.wait_stream(torch.cuda.current_stream(self.be.device))
             self._step_done = torch.cuda.Event()
+            self._ar_events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(64)]
+            self._ar_count = 0
 
     # ------------------------------------------------------------------ one step
     def _on_stream(self):
@@ -130,7 +132,17 @@ class DataParallelTrainer:
         scale = 1.0
         if self.world > 1:
             import torch.distributed as dist
+            # ONE collective over the flat fp32 gradient buffer, queued the moment the backward's last launch (the batched
+            # slab folds, which finish every weight gradient at once) is queued; bracketed by events on the step stream
+            # (the process group's internal stream is ordered against it on both sides) for allreduce_ms()
+            timed = self.stream is not None
+            if timed:
+                e0, e1 = self._ar_events[self.step_idx % len(self._ar_events)]
+                e0.record(self.stream)
             dist.all_reduce(self.flat.g, op=dist.ReduceOp.SUM, group=self.pg)
+            if timed:
+                e1.record(self.stream)
+                self._ar_count += 1
             scale = 1.0 / self.world
         lr, beta1 = one_cycle(self.step_idx, self.total_steps, self.lr_max)
         self.opt.set_hyper(lr, beta1, grad_scale=scale)
@@ -157,6 +169,16 @@ class DataParallelTrainer:
 
     def losses(self):
         return self.engine.losses()
+
+    def allreduce_ms(self):
+        """Mean duration of the gradient all-reduce over the last (up to 64) steps, by events on the step stream; None when
+        single-rank.  Synchronises the device."""
+        if self.world <= 1 or self.stream is None or self._ar_count == 0:
+            return None
+        torch.cuda.synchronize(self.be.device)
+        k = min(self._ar_count, len(self._ar_events))
+        idx = [(self.step_idx - 1 - i) % len(self._ar_events) for i in range(k)]
+        return sum(self._ar_events[i][0].elapsed_time(self._ar_events[i][1]) for i in idx) / k
 
     def forward_only(self):
         with self._on_stream():

@@ -64,10 +64,13 @@ def _split_ranges(vox, nsplit, mult=1):
 class EmuBackend:
     name = "emu"
 
-    def __init__(self, exact=False):
-        """exact=True keeps every 'bf16' buffer in fp32: isolates plan-logic errors from rounding."""
+    def __init__(self, exact=False, fast=False):
+        """exact=True keeps every 'bf16' buffer in fp32: isolates plan-logic errors from rounding.
+        fast=True: the weight-gradient emulation puts the whole correlation into slab 0 (one pass per sample instead of one
+        per slab; the slabs' sum -- all the plan consumes -- is the same) for native-shape comparisons."""
         self.bytes = 0
         self.exact = exact
+        self.fast = fast
 
     def alloc(self, shape, dtype):
         if self.exact and dtype == "bf16":
@@ -214,6 +217,13 @@ class EmuBackend:
             gyf = gy.buf[..., gy.co:gy.co + co32].float().reshape(g.n, -1, co32)
             xin = _ncdhw(x.buf[..., x.co:x.co + g.ci].float())
             vo = g.do * g.ho * g.wo
+            if self.fast:
+                go = _ncdhw(gyf.reshape(g.n, g.do, g.ho, g.wo, co32))
+                gp.zero_()
+                for n in range(g.n):
+                    dw = torch.nn.grad.conv3d_weight(xin[n:n + 1], (co32, g.ci, k, k, k), go[n:n + 1], g.stride, g.pad)
+                    gp[n, 0] = dw.reshape(co32, g.ci, k ** 3).permute(2, 0, 1)
+                return
             for i, (v0, v1) in enumerate(_split_ranges(vo, nsplit, 128)):  # mirrors WG_VB
                 if v1 <= v0:
                     gp[:, i] = 0

@@ -1,0 +1,252 @@
+"""Test reach on a real MI355X that the engine-level tests do not give (round-1 review):
+
+  * the REGISTRY DOOR -- RadarPoseNet / HRNet3D / CenterHead built by build_detector from the reference's model dict
+    (through install_det3d_shim) running on HipBackend: model(example, return_loss=True) -> loss.backward() -> p.grad,
+    model(example, return_loss=False) -> key-point list (det3d/models/detectors/radar_pose_net.py:36-46,
+    det3d/models/pose_heads/center_head.py:232-330);
+  * the BENCH WORKLOAD itself -- a train step at the dataset-native shape with B = 8 (one sample per XCD, 32 workgroups
+    per sample on the tiled kernels: a different placement path from B = 2) against the oracle's fp32 autograd and
+    against the emulated plan, with PER-PARAMETER-TENSOR gates instead of one global cosine.
+
+Per-tensor tolerances (stated, from bf16 rounding): a tensor's gradient is a sum over >= 10^6 voxel products of bf16
+activations (relative rounding 2^-9 = 2e-3 each, independent) times gradients that crossed up to ~40 bf16-stored layers;
+rounding errors add in quadrature along a chain, ReLU-mask flips add a sparse term.  Large, well-averaged tensors (conv
+weights) measure 1-4 % relative error against fp32 autograd; the worst are GroupNorm beta/gamma of low-resolution branches
+(32-128 numbers, each a difference of large cancelling sums).  Gates: relative error <= GATE_REL of the tensor's norm
+OR absolute error <= GATE_ABS of the largest tensor norm of the model (tiny-norm tensors), cosine >= GATE_COS.
+"""
+from collections import OrderedDict
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import hrradarpose_ref as O
+from rt_pose_amd import configs, synth
+from rt_pose_amd.engine import FlatParams, PoseEngine
+from tests.emu_backend import EmuBackend
+from tests.util import rel_err
+
+pytestmark = pytest.mark.gpu
+NATIVE = configs.NATIVE_DIMS
+
+# per-tensor gates: (vs fp32 oracle autograd, vs emulated bf16 plan)
+GATE_REL = {"oracle": 0.12, "emu": 0.12}
+GATE_COS = {"oracle": 0.992, "emu": 0.992}
+GATE_ABS = 2e-3   # of the model's largest per-tensor gradient norm
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from rt_pose_amd.backend import HipBackend
+    return HipBackend("cuda:0")
+
+
+def to_dev(v, dev):
+    if torch.is_tensor(v):
+        return v.to(dev)
+    if isinstance(v, dict):
+        return {k: to_dev(x, dev) for k, x in v.items()}
+    if isinstance(v, (list, tuple)):
+        return type(v)(to_dev(x, dev) for x in v)
+    return v
+
+
+def tensor_report(got: dict, want: dict, names):
+    """-> rows (name, numel, |want|, rel err, cosine) sorted by rel err descending."""
+    rows = []
+    for k in names:
+        a, b = got[k].detach().double().cpu().reshape(-1), want[k].detach().double().cpu().reshape(-1)
+        nb = float(b.norm())
+        rel = float((a - b).norm()) / (nb + 1e-30)
+        cos = float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-30))
+        rows.append((k, a.numel(), nb, rel, cos, float((a - b).norm())))
+    rows.sort(key=lambda r: -r[3])
+    return rows
+
+
+def gate(rows, kind, label):
+    top = max(r[2] for r in rows)
+    worst = "\n".join("   %-62s n=%-7d |g|=%.3e rel=%.4f cos=%.5f" % r[:5] for r in rows[:5])
+    print("\n[%s] worst 5 parameter tensors vs %s:\n%s" % (label, kind, worst))
+    bad = [r for r in rows if not ((r[3] <= GATE_REL[kind] and r[4] >= GATE_COS[kind]) or r[5] <= GATE_ABS * top)]
+    assert not bad, "%s: %d tensors outside the per-tensor gates vs %s:\n%s" % (
+        label, len(bad), kind, "\n".join("   %-62s n=%-7d |g|=%.3e rel=%.4f cos=%.5f" % r[:5] for r in bad[:10]))
+    med = float(np.median([r[3] for r in rows]))
+    return med
+
+
+# ------------------------------------------------------------------------------------------------ registry door
+@pytest.mark.parametrize("name", ["hr3d", "hr3d_one_hm_doppler"])
+def test_registry_door_on_hip(hip, name):
+    """build_detector(model dict) -> RadarPoseNet on HipBackend: the reference's call convention end to end, compared with
+    the PoseEngine driven directly (same kernels: equal up to the class-sum atomics) and with the oracle."""
+    from rt_pose_amd import registry
+    registry.install_det3d_shim()
+    from det3d.models import build_detector   # the name a reference tools/train.py imports
+
+    dims, b = (8, 16, 32), 2
+    arch, fin, fout, fuse, heads, weight, cw = O.MODEL_CONFIGS[name]
+    spec = configs.spec(name)
+    model = build_detector(configs.model_dict(name), train_cfg=None, test_cfg=configs.test_cfg())
+    sd = O.seeded_state_dict(O.param_shapes(arch, fin, fout, fout, heads), seed=1)
+    model.load_state_dict(sd)
+    ex = O.synth_example(b, spec["cin"], dims, seed=1234, one_hm=heads["hm"] == 1)
+    exd = to_dev(ex, "cuda:0")
+    # ---- training call
+    out = model(exd, return_loss=True)
+    assert set(out.keys()) == {"loss", "hm_loss", "loc_loss", "loc_loss_elem", "num_positive"}
+    loss = sum(out["loss"])
+    assert loss.requires_grad and loss.is_cuda
+    loss.backward()
+    torch.cuda.synchronize()
+    named = dict(model.named_parameters())
+    assert all(p.is_cuda for p in named.values()), "parameters were re-pointed at the flat device buffer"
+    # the same step on the engine directly
+    flat = FlatParams(O.param_shapes(arch, fin, fout, fout, heads), hip.alloc)
+    flat.load_state_dict(sd)
+    eng = PoseEngine(hip, flat.values, arch, fuse, heads, weight, cw, b, dims, pgrads=flat.grads, test_cfg=configs.test_cfg())
+    eng.load_input(ex["rdr"]["rdr_tensor"])
+    eng.load_targets(ex["rdr"])
+    eng.run_forward()
+    eng.run_loss_backward()
+    torch.cuda.synchronize()
+    el = eng.losses()
+    for k in ("loss", "hm_loss", "loc_loss"):
+        got = float(sum(out[k]).detach().float().sum())
+        assert abs(got - float(el[k])) <= 1e-5 * abs(float(el[k])) + 1e-7, (k, got, float(el[k]))
+    assert torch.allclose(out["loc_loss_elem"][0].float().cpu(), el["loc_loss_elem"].float().cpu(), rtol=1e-5, atol=1e-7)
+    assert float(out["num_positive"][0]) == float(el["num_positive"])
+    # oracle: loss dict 2 %, live-parameter set, per-tensor gradients
+    sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ref = O.radar_pose_net(sdr, ex, fuse, weight, cw)
+    ref["loss"][0].backward()
+    for k in ("loss", "hm_loss", "loc_loss"):
+        want = float(ref[k][0].detach())
+        assert abs(float(sum(out[k]).detach().float().sum()) - want) < 2e-2 * abs(want) + 1e-4, k
+    live = [k for k in sd if sdr[k].grad is not None]
+    assert all(named[k].grad is not None for k in live)
+    assert all(named[k].grad is None for k in sd if sdr[k].grad is None)   # stage-4 fuse rows 1..3 under 'top'
+    for k in live:   # module door == engine door (identical launches; only the class-sum LDS atomics reorder)
+        assert rel_err(named[k].grad, flat.grads[k]) < 1e-5, k
+    gm = torch.cat([named[k].grad.detach().float().cpu().reshape(-1) for k in live])
+    gr = torch.cat([sdr[k].grad.reshape(-1) for k in live])
+    assert float(torch.dot(gm, gr) / (gm.norm() * gr.norm())) > 0.97
+    # a plain torch optimiser steps the flattened parameters
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+    before = named["pose_head.tasks.0.hm.2.weight"].detach().clone()
+    opt.step()
+    assert not torch.equal(before, named["pose_head.tasks.0.hm.2.weight"].detach())
+    # ---- inference call on the same (reloaded) weights == engine decode == oracle decode of the engine's logits
+    model.load_state_dict(sd)
+    with torch.no_grad():
+        preds = model(exd, return_loss=False)
+    torch.cuda.synchronize()
+    assert len(preds) == b and set(preds[0]) == {"keypoints", "metadata"}
+    assert preds[1]["metadata"] == ex["meta"][1]
+    inf = PoseEngine(hip, flat.values, arch, fuse, heads, weight, cw, b, dims, train=False, test_cfg=configs.test_cfg())
+    inf.load_input(ex["rdr"]["rdr_tensor"])
+    inf.run_forward()
+    inf.run_decode()
+    torch.cuda.synchronize()
+    for a, c in zip(preds, inf.keypoints()):
+        np.testing.assert_allclose(np.asarray(a["keypoints"]), np.asarray(c["keypoints"]), rtol=1e-6, atol=1e-6)
+    own = [{"reg": inf.output("reg").float().cpu(), "hm": inf.output("hm").float().cpu()}]
+    for a, c in zip(preds, O.center_head_predict(own, configs.test_cfg())):
+        np.testing.assert_allclose(np.asarray(a["keypoints"]), np.asarray(c["keypoints"]), rtol=1e-5, atol=1e-4)
+
+
+def test_standalone_backbone_and_head_on_hip(hip):
+    """HRNet3D.forward and CenterHead.forward / predict as registered modules of their own (hrnet3d.py:29-56,
+    center_head.py:232-238, 272-330)."""
+    from rt_pose_amd import registry
+    name = "hr3d"
+    arch, fin, fout, fuse, heads, weight, cw = O.MODEL_CONFIGS[name]
+    md = configs.model_dict(name)
+    bb = registry.build_backbone(md["backbone"])
+    hd = registry.build_head(md["pose_head"])
+    sd = O.seeded_state_dict(O.param_shapes(arch, fin, fout, fout, heads), seed=1)
+    bb.load_state_dict({k[len("backbone."):]: v for k, v in sd.items() if k.startswith("backbone.")})
+    hd.load_state_dict({k[len("pose_head."):]: v for k, v in sd.items() if k.startswith("pose_head.")})
+    bb, hd = bb.to("cuda:0"), hd.to("cuda:0")
+    x = O.synth_example(1, 1, (8, 16, 32), seed=3)["rdr"]["rdr_tensor"]
+    feats = bb(x.to("cuda:0"))
+    preds, same = hd(feats)
+    kps = hd.predict({"meta": [{"frame": 0}]}, preds, configs.test_cfg())
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        rf = O.hrnet3d(sd, x, fuse)
+        rp, _ = O.center_head(sd, rf)
+    assert feats.is_cuda and tuple(feats.shape) == tuple(rf.shape)
+    assert rel_err(feats.float().cpu(), rf) < 3e-2
+    for k in ("reg", "hm"):
+        assert tuple(preds[0][k].shape) == tuple(rp[0][k].shape)
+        assert rel_err(preds[0][k].float().cpu(), rp[0][k]) < 4e-2
+    own = [{k: preds[0][k].float().cpu() for k in ("reg", "hm")}]
+    np.testing.assert_allclose(np.asarray(kps[0]["keypoints"]), np.asarray(O.center_head_predict(own, configs.test_cfg())[0]["keypoints"]),
+                               rtol=1e-5, atol=1e-4)
+
+
+# ------------------------------------------------------------------------------------------------ the bench workload
+@pytest.mark.parametrize("name", ["hr3d", "hr3d_one_hm_doppler"])
+def test_native_b8_train_step_per_tensor(hip, name):
+    """The bench's own workload (B = 8 frames of [Cin,16,64,160]): loss dict vs the oracle (2 %), every live parameter
+    tensor's gradient vs the oracle's fp32 autograd AND vs the emulated bf16 plan, worst five reported."""
+    b = 8
+    arch, fin, fout, fuse, heads, weight, cw = O.MODEL_CONFIGS[name]
+    spec = configs.spec(name)
+    shapes = O.param_shapes(arch, fin, fout, fout, heads)
+    sd = O.seeded_state_dict(shapes, seed=1)
+    ex = synth.make_batch(b, spec["cin"], NATIVE, seed=1234, one_hm=heads["hm"] == 1)
+    res = {}
+    for tag, be in (("hip", hip), ("emu", EmuBackend(fast=True))):
+        flat = FlatParams(shapes, be.alloc)
+        flat.load_state_dict(sd)
+        eng = PoseEngine(be, flat.values, arch, fuse, heads, weight, cw, b, NATIVE, pgrads=flat.grads)
+        eng.load_input(ex["rdr"]["rdr_tensor"])
+        eng.load_targets(ex["rdr"])
+        eng.run_forward()
+        eng.run_loss_backward()
+        if tag == "hip":
+            torch.cuda.synchronize()
+        res[tag] = (eng, flat, {k: v.detach().float().cpu() for k, v in eng.losses().items()})
+        hm = eng.output("hm").float().cpu()
+        res[tag + "_hm"] = hm
+    sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ref = O.radar_pose_net(sdr, ex, fuse, weight, cw)
+    ref["loss"][0].backward()
+    eng, flat, losses = res["hip"]
+    live = [k for k in sd if sdr[k].grad is not None]
+    assert set(live) == eng.live_params
+    for k in ("loss", "hm_loss", "loc_loss"):
+        want = float(ref[k][0].detach())
+        assert abs(float(losses[k].sum()) - want) < 2e-2 * abs(want) + 1e-4, (k, float(losses[k].sum()), want)
+        assert abs(float(losses[k].sum()) - float(res["emu"][2][k].sum())) < 1e-2 * abs(want) + 1e-4, k
+    np.testing.assert_allclose(losses["loc_loss_elem"].numpy(), ref["loc_loss_elem"][0].detach().numpy(), rtol=3e-2, atol=1e-4)
+    assert float(losses["num_positive"]) == float(ref["num_positive"][0])
+    assert rel_err(res["hip_hm"], res["emu_hm"]) < 1e-2      # same rounding points, different summation order
+    got = OrderedDict((k, flat.grads[k]) for k in live)
+    med_o = gate(tensor_report(got, {k: sdr[k].grad for k in live}, live), "oracle", name + " B=8 native")
+    med_e = gate(tensor_report(got, res["emu"][1].grads, live), "emu", name + " B=8 native")
+    assert med_o < 0.04 and med_e < 0.04, (med_o, med_e)
+    gh = torch.cat([got[k].detach().float().cpu().reshape(-1) for k in live])
+    gr = torch.cat([sdr[k].grad.reshape(-1) for k in live])
+    assert float(torch.dot(gh, gr) / (gh.norm() * gr.norm())) > 0.995
+    assert abs(float(gh.norm() / gr.norm()) - 1) < 0.02
+    dead = [k for k in sd if sdr[k].grad is None]
+    assert all(float(flat.grads[k].abs().max()) == 0 for k in dead)
+
+
+# ------------------------------------------------------------------------------------------------ MPJPE proxy
+def test_keypoint_agreement_bf16_vs_fp32_on_trained_weights():
+    """Train the product path until the heat-maps peak, then decode held-out frames with the HIP bf16 plan and with the
+    oracle's fp32 forward on the same weights (tests/keypoint_agreement.py): the bf16 path must not move key-points by more
+    than a voxel, and the MPJPE difference must stay far inside the north star's 0.5 cm budget."""
+    from tests.keypoint_agreement import run
+    r = run(steps=240, eval_batches=1)
+    print("\nkey-point agreement:", r)
+    assert r["loss_history"][-1][1] < 0.5 * r["loss_history"][0][1], "training did not make progress"
+    assert r["mean_peak_score"]["oracle_fp32"] > 0.2, "heat-maps did not peak: the comparison would be meaningless"
+    assert r["argmax_within_1_voxel"] >= 0.97
+    assert r["argmax_agreement"] >= 0.85
+    assert abs(r["mpjpe_cm"]["delta"]) < 0.5 and abs(r["abs_mpjpe_cm"]["delta"]) < 0.5
