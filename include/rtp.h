@@ -250,12 +250,16 @@ int rtp_gaussian_table(int radius, float* out_host);
  *           NOT memset here: `prev` (device int [frames][M][4], zero-initialised by the caller once) records the boxes
  *           written by the previous call, which are cleared first.
  *   anno    device fp32 [frames][M][3|45], ind/cat device int64 [frames][M], mask device uint8 [frames][M]
+ * Voxel coordinate (x - radar_range[k]) / voxel_size[k] / out_size_factor[k] (pose.py:222-227; range_min_zyx must hold the
+ * fp32-ROUNDED bounds, the reference keeps them in an np.float32 array, :190): numpy_legacy == 0 evaluates every step in
+ * fp32 as NumPy >= 2 does (NEP 50; what the captured vectors pin), != 0 keeps NumPy 1.x's float64 intermediate with one
+ * rounding to fp32.  The two differ by <= 1 ulp, which decides the integer voxel of a key-point on a voxel boundary.
  * A key-point whose voxel lies outside the map keeps its slot with ind = mask = cat = 0 (the reference's `continue`).
  * The reference raises IndexError when 0 < poses present < max_poses (15-map variant); the host wrapper checks that. */
 int rtp_assign_labels(const double* poses, const int* nposes, int frames, int max_in, int max_poses, int one_hm,
                       int radius, const double* range_min_zyx, const double* voxel_size_xyz,
                       const int* out_size_factor_zyx, int fz, int fy, int fx, const float* table, float* hm, float* anno,
-                      long long* ind, unsigned char* mask, long long* cat, int* prev, void* stream);
+                      long long* ind, unsigned char* mask, long long* cat, int* prev, int numpy_legacy, void* stream);
 
 /* ---------------------------------------------------------------- C''. LiDAR stream --- */
 

@@ -17,7 +17,8 @@ container (tests/golden/gen_golden_input.py).
 
 Arithmetic notes kept from the reference: the cube is cast fp16 -> fp32 first and normalised in fp32
 ((x - lo) / (hi - lo), negatives clamped to 0); voxel coordinates are computed per key-point as
-(p - range_min) / voxel_size / out_size_factor, rounded to fp32 and truncated toward zero for the integer voxel; a
+(p - fp32(range_min)) / voxel_size / out_size_factor in fp32 (NumPy >= 2 promotion, what the captured vectors pin; NumPy 1.x's
+float64 intermediate is available as numpy_legacy=True) and truncated toward zero for the integer voxel; a
 key-point whose voxel falls outside the feature map is skipped but keeps its slot (ind = 0, mask = 0).
 """
 import numpy as np
@@ -91,21 +92,27 @@ def draw_gaussian3d(hm, center, radius):
     return hm
 
 
-def _voxel_coords(p_xyz, range_zyx_min, voxel_size_xyz, osf_zyx):
-    """(x,y,z) metres -> fp32 voxel coordinates (pose.py:222-227); the intermediate is kept in float64 and rounded once,
-    which is what numpy 1.x (the reference's era) does; numpy >= 2 evaluates it in fp32 (<= 1 ulp apart)."""
+def _voxel_coords(p_xyz, range_zyx_min, voxel_size_xyz, osf_zyx, numpy_legacy=False):
+    """(x,y,z) metres -> fp32 voxel coordinates (pose.py:222-227): (x - radar_range[k]) / voxel_size[k] / osf[k] with x a
+    Python float, radar_range an np.float32 array (pose.py:190: the bound is the fp32-ROUNDED value), voxel_size / osf Python
+    scalars.  NumPy >= 2 (NEP 50, weak Python scalars) evaluates every step in fp32 -- the captured vectors come from 2.2 and
+    pin exactly that; numpy_legacy=True restates NumPy 1.x (value-based promotion: float64 intermediate, one rounding)."""
     x, y, z = [float(v) for v in p_xyz]
-    # the reference holds the ROI bounds in an np.float32 array (pose.py:190), so the subtraction sees the fp32-ROUNDED
-    # bound (-10.05 -> -10.0500001907...); the voxel size stays a Python double (info.DATASET.RDR_CUBE.GRID_SIZE)
-    rz, ry, rx = [float(np.float32(v)) for v in range_zyx_min]
-    c = [(x - rx) / float(voxel_size_xyz[0]) / float(osf_zyx[2]),
-         (y - ry) / float(voxel_size_xyz[1]) / float(osf_zyx[1]),
-         (z - rz) / float(voxel_size_xyz[2]) / float(osf_zyx[0])]
+    rz, ry, rx = [np.float32(v) for v in range_zyx_min]
+    if numpy_legacy:
+        c = [(x - float(rx)) / float(voxel_size_xyz[0]) / float(osf_zyx[2]),
+             (y - float(ry)) / float(voxel_size_xyz[1]) / float(osf_zyx[1]),
+             (z - float(rz)) / float(voxel_size_xyz[2]) / float(osf_zyx[0])]
+        return np.array(c, dtype=np.float32)
+    f = np.float32
+    c = [(f(x) - rx) / f(voxel_size_xyz[0]) / f(osf_zyx[2]),
+         (f(y) - ry) / f(voxel_size_xyz[1]) / f(osf_zyx[1]),
+         (f(z) - rz) / f(voxel_size_xyz[2]) / f(osf_zyx[0])]
     return np.array(c, dtype=np.float32)
 
 
 def assign_labels(poses, fmap_zyx, range_zyx_min, voxel_size_xyz, osf_zyx=(1, 1, 1), max_poses=1, min_radius=1,
-                  one_hm=False):
+                  one_hm=False, numpy_legacy=False):
     """One frame.  poses: list of [15][3] (x,y,z metres).  Returns dict(hm, anno_pose, ind, mask, cat) as the reference's
     per-task arrays (single task).
       one_hm=False  AssignLabelPose  (pose.py:186-254): 15 classes, slot k = key-point k of the FIRST pose(s) in list order
@@ -132,10 +139,10 @@ def assign_labels(poses, fmap_zyx, range_zyx_min, voxel_size_xyz, osf_zyx=(1, 1,
     for k in range(num):
         cls_id, payload = pts[k]   # IndexError when max_poses exceeds the poses present, exactly as the reference
         if not one_hm:
-            ct = _voxel_coords(payload, range_zyx_min, voxel_size_xyz, osf_zyx)
+            ct = _voxel_coords(payload, range_zyx_min, voxel_size_xyz, osf_zyx, numpy_legacy)
             ct_int = ct.astype(np.int32)
         else:
-            ct = np.concatenate([_voxel_coords(p, range_zyx_min, voxel_size_xyz, osf_zyx) for p in payload])
+            ct = np.concatenate([_voxel_coords(p, range_zyx_min, voxel_size_xyz, osf_zyx, numpy_legacy) for p in payload])
             ct_int = ct.astype(np.int32)[:3]
         if not (0 <= ct_int[0] < fx and 0 <= ct_int[1] < fy and 0 <= ct_int[2] < fz):
             continue

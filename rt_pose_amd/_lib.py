@@ -82,7 +82,7 @@ PROTOTYPES = {
     "rtp_cube_prep": [_P, _L, _I, _I, _I, C.POINTER(_I), _F, _F, _I, _P, _P],
     "rtp_gaussian_table": [_I, C.POINTER(_F)],
     "rtp_assign_labels": [_P, _P, _I, _I, _I, _I, _I, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_I), _I, _I, _I,
-                          _P, _P, _P, _P, _P, _P, _P, _P],
+                          _P, _P, _P, _P, _P, _P, _P, _I, _P],
     "rtp_lidar_transform": [_P, _I, _I, C.POINTER(C.c_double), _P],
     "rtp_voxelize_workspace_bytes": [_I],
     "rtp_dynamic_voxelize": [_P, _I, _I, C.POINTER(_F), C.POINTER(_F), _P, _P, _P, _P, _L, _P],

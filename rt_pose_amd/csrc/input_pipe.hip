@@ -95,14 +95,21 @@ struct LabelParams {
   double rmin[3];          // range minimum, (z, y, x)
   double vsize[3];         // voxel size, (x, y, z)
   double osf[3];           // out_size_factor, (z, y, x)
-  int fz, fy, fx, ncls, m, width;
+  int fz, fy, fx, ncls, m, width, legacy;
   const float* table;      // [(2r+1)^3] device
   float* hm; float* anno; long long* ind; unsigned char* mask; long long* cat;
   int* prev;               // [frames][m][4] = (valid, class, centre voxel index, -): boxes splatted by the previous call
 };
 
-__device__ __forceinline__ float vox_coord(double p, double rmin, double vs, double osf) {
-  return (float)(((p - rmin) / vs) / osf);   // float64 intermediate, one rounding to fp32 (pose.py:222-227 under numpy 1.x)
+// pose.py:222-227: (x - radar_range[k]) / voxel_size[k] / out_size_factor[k] with x a Python float, radar_range an
+// np.float32 array, voxel_size Python floats.  NumPy >= 2 (NEP 50: Python scalars are weakly typed) evaluates every step
+// in fp32 -- that is what the captured vectors pin.  legacy: NumPy 1.x value-based promotion, float64 intermediate with
+// one rounding to fp32.  The two differ by <= 1 ulp, which flips the integer voxel of a key-point on a voxel boundary.
+__device__ __forceinline__ float vox_coord(double p, double rmin, double vs, double osf, int legacy) {
+  if (legacy) return (float)(((p - rmin) / vs) / osf);
+  float c = (float)p - (float)rmin;
+  c = c / (float)vs;
+  return c / (float)osf;
 }
 
 // pass 0: clear the boxes of the previous call; pass 1: this call's slots.  One block per (frame, slot).
@@ -133,9 +140,9 @@ __global__ __launch_bounds__(128) void assign_labels_kernel(LabelParams p, int p
   float cx = 0.f, cy = 0.f, cz = 0.f;
   const double* q = p.poses + (((long)f * p.max_in + (present ? pose : 0)) * 15 + kp) * 3;
   if (present) {
-    cx = vox_coord(q[0], p.rmin[2], p.vsize[0], p.osf[2]);
-    cy = vox_coord(q[1], p.rmin[1], p.vsize[1], p.osf[1]);
-    cz = vox_coord(q[2], p.rmin[0], p.vsize[2], p.osf[0]);
+    cx = vox_coord(q[0], p.rmin[2], p.vsize[0], p.osf[2], p.legacy);
+    cy = vox_coord(q[1], p.rmin[1], p.vsize[1], p.osf[1], p.legacy);
+    cz = vox_coord(q[2], p.rmin[0], p.vsize[2], p.osf[0], p.legacy);
     ix = (int)cx; iy = (int)cy; iz = (int)cz;   // astype(int32): truncation toward zero
     ok = ix >= 0 && ix < p.fx && iy >= 0 && iy < p.fy && iz >= 0 && iz < p.fz;
   }
@@ -154,9 +161,9 @@ __global__ __launch_bounds__(128) void assign_labels_kernel(LabelParams p, int p
       if (ok) {
         const int j = i / 3, a = i % 3;
         const double* qq = p.poses + (((long)f * p.max_in + pose) * 15 + j) * 3;
-        const float c = a == 0 ? vox_coord(qq[0], p.rmin[2], p.vsize[0], p.osf[2])
-                      : a == 1 ? vox_coord(qq[1], p.rmin[1], p.vsize[1], p.osf[1])
-                               : vox_coord(qq[2], p.rmin[0], p.vsize[2], p.osf[0]);
+        const float c = a == 0 ? vox_coord(qq[0], p.rmin[2], p.vsize[0], p.osf[2], p.legacy)
+                      : a == 1 ? vox_coord(qq[1], p.rmin[1], p.vsize[1], p.osf[1], p.legacy)
+                               : vox_coord(qq[2], p.rmin[0], p.vsize[2], p.osf[0], p.legacy);
         v = c - (float)(a == 0 ? ix : a == 1 ? iy : iz);
       }
       anno[i] = v;
@@ -176,7 +183,7 @@ extern "C" int rtp_assign_labels(const double* poses, const int* nposes, int fra
                                  int radius, const double* range_min_zyx /*host [3]*/, const double* voxel_size_xyz /*host [3]*/,
                                  const int* out_size_factor_zyx /*host [3]*/, int fz, int fy, int fx, const float* table,
                                  float* hm, float* anno, long long* ind, unsigned char* mask, long long* cat, int* prev,
-                                 void* stream) {
+                                 int numpy_legacy, void* stream) {
   if (!poses || !nposes || !table || !hm || !anno || !ind || !mask || !cat || !prev || !range_min_zyx || !voxel_size_xyz ||
       !out_size_factor_zyx)
     return RTP_ERR_SHAPE;
@@ -188,7 +195,7 @@ extern "C" int rtp_assign_labels(const double* poses, const int* nposes, int fra
     p.rmin[i] = range_min_zyx[i]; p.vsize[i] = voxel_size_xyz[i]; p.osf[i] = (double)out_size_factor_zyx[i];
     if (p.vsize[i] == 0.0 || p.osf[i] == 0.0) return RTP_ERR_SHAPE;
   }
-  p.fz = fz; p.fy = fy; p.fx = fx;
+  p.fz = fz; p.fy = fy; p.fx = fx; p.legacy = numpy_legacy;
   p.ncls = one_hm ? 1 : 15; p.m = one_hm ? max_poses : 15 * max_poses; p.width = one_hm ? 45 : 3;
   p.table = table; p.hm = hm; p.anno = anno; p.ind = ind; p.mask = mask; p.cat = cat; p.prev = prev;
   hipStream_t s = (hipStream_t)stream;

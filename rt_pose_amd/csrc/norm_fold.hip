@@ -477,6 +477,115 @@ extern "C" int rtp_gn_bwd_coeffs(const float* pq, int nsplit, const float* mr, c
 }
 
 // ------------------------------------------------------------------------------------------------
+// rtp_gn_bwd_coeffs_cls : the same coefficients WITHOUT a pass over dxhat (one block per sample).
+//   Q[ci] = sum_v dxhat[v][ci] x[v][ci] = sum_{tap,co} W[co][ci][tap] G[tap][co][ci]   (G = this sample's weight-gradient
+//           correlation; the tiled weight-gradient kernel contracts each slab with the weights: qpart[n][slab][ci])
+//   P[ci] = sum_v dxhat[v][ci]          = sum_{tap,co} W[co][ci][tap] * (sum of gy[.][co] over the voxels whose `tap` is in
+//           bounds) -- the per-boundary-class sums of gy the bias / un-fold already needs.
+// W is the bf16 data-gradient packing wd[tap][ci_pad][cok] -- the very values the data-gradient conv multiplies with.
+// With P and Q known BEFORE the data gradient runs, its epilogue writes the finished dx = A*dxhat + B*x + C.
+// ------------------------------------------------------------------------------------------------
+struct GnClsParams {
+  const float* qpart; int q_nsplit; const float* cls_part; int cls_nsplit; float* csum_out;
+  const bf16_t* wd; const float* mr; const float* gamma; FoldParams f; int groups, co32; long vox; float* coeff; float* part;
+};
+
+__global__ __launch_bounds__(256) void gn_bwd_coeffs_cls_kernel(GnClsParams p) {
+  extern __shared__ __attribute__((aligned(16))) float sh[];
+  const int tid = threadIdx.x, n = blockIdx.x;
+  const int co32 = p.co32, ntap = p.f.ntap, C = p.f.ci_real, cip = p.f.ci_pad;
+  float* csum = sh;                       // [64][co32]
+  float* CS = csum + 64 * co32;           // [ntap][co32]
+  float* red = CS + ntap * co32;          // [256]
+  float* Pq = red + 256;                  // [2][256]: gamma*P, gamma*r*(Q - mu P) per channel
+  float* S12 = Pq + 512;                  // [2][64]
+  for (int i = tid; i < 64 * co32; i += 256) {
+    float a = 0.f;
+    const float* src = p.cls_part + (long)n * p.cls_nsplit * 64 * co32 + i;
+    for (int s = 0; s < p.cls_nsplit; ++s) a += src[(long)s * 64 * co32];
+    csum[i] = a;
+    if (p.csum_out) p.csum_out[(long)n * 64 * co32 + i] = a;
+  }
+  __syncthreads();
+  for (int i = tid; i < ntap * co32; i += 256) {
+    const int tap = i / co32, co = i - tap * co32;
+    float a = 0.f;
+    for (int cls = 0; cls < 64; ++cls)
+      if (tap_inb_class(tap, cls, p.f)) a += csum[cls * co32 + co];
+    CS[i] = a;
+  }
+  __syncthreads();
+  // P: thread (c, k) takes taps k, k + np, ...; a tap's weight row wd[tap][c][0..co32) is contiguous
+  const int np = 256 / C, c = tid % C, k = tid / C;
+  float pacc = 0.f;
+  if (k < np)
+    for (int tap = k; tap < ntap; tap += np) {
+      const bf16_t* wr = p.wd + ((long)tap * cip + c) * co32;
+      const float* cr = CS + tap * co32;
+      for (int co = 0; co < co32; co += 8) {
+        const bf16x8 w8 = ld_bf16x8(wr + co);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pacc += bf2f(w8[j]) * cr[co + j];
+      }
+    }
+  red[tid] = pacc;
+  __syncthreads();
+  float pc = 0.f, qc = 0.f, mu = 0.f, r = 0.f, gam = 0.f;
+  const int cg = C / p.groups;
+  const float m = (float)cg * (float)p.vox;
+  if (tid < C) {
+    for (int kk = 0; kk < np; ++kk) pc += red[kk * C + tid];
+    const float* q = p.qpart + (long)n * p.q_nsplit * cip + tid;
+    for (int s = 0; s < p.q_nsplit; ++s) qc += q[(long)s * cip];
+    const int g = tid / cg;
+    mu = p.mr[((long)n * p.groups + g) * 2];
+    r = p.mr[((long)n * p.groups + g) * 2 + 1];
+    gam = p.gamma[tid];
+    Pq[tid] = gam * pc;
+    Pq[256 + tid] = gam * r * (qc - mu * pc);
+    p.part[((long)n * C + tid) * 2] = r * (qc - mu * pc);
+    p.part[((long)n * C + tid) * 2 + 1] = pc;
+  }
+  __syncthreads();
+  if (tid < p.groups) {
+    float s1 = 0.f, s2 = 0.f;
+    for (int j = tid * cg; j < (tid + 1) * cg; ++j) { s1 += Pq[j]; s2 += Pq[256 + j]; }
+    S12[tid] = s1;
+    S12[64 + tid] = s2;
+  }
+  __syncthreads();
+  if (tid < C) {
+    const int g = tid / cg;
+    float* o = p.coeff + ((long)n * C + tid) * 3;
+    o[0] = r * gam;
+    o[1] = -r * r * S12[64 + g] / m;
+    o[2] = -r * S12[g] / m + r * r * mu * S12[64 + g] / m;
+  }
+}
+
+
+extern "C" int rtp_gn_bwd_coeffs_cls(const float* qpart, int q_nsplit, const float* cls_part, int cls_nsplit, float* csum_out,
+                                     const void* wd, const float* mr, const float* gamma, const RtpConvGeom* g, int ci_real,
+                                     int co_real, int groups, float* coeff, void* stream) {
+  if (!qpart || !cls_part || !wd || !mr || !gamma || !g || !coeff || q_nsplit < 1 || cls_nsplit < 1) return RTP_ERR_SHAPE;
+  GnClsParams p;
+  int rc = fill_fold(p.f, g, ci_real, co_real);
+  if (rc) return rc;
+  if (ci_real > 256 || 256 % ci_real || groups > 64 || ci_real % groups || ci_real != p.f.ci_pad) return RTP_ERR_UNSUPPORTED;
+  p.co32 = (g->co + 31) / 32 * 32;
+  const size_t shm = sizeof(float) * ((size_t)64 * p.co32 + (size_t)p.f.ntap * p.co32 + 256 + 512 + 128);
+  if (shm > 60 * 1024) return RTP_ERR_UNSUPPORTED;
+  p.qpart = qpart; p.q_nsplit = q_nsplit; p.cls_part = cls_part; p.cls_nsplit = cls_nsplit; p.csum_out = csum_out;
+  p.wd = (const bf16_t*)wd; p.mr = mr; p.gamma = gamma; p.groups = groups; p.vox = (long)g->di * g->hi * g->wi;
+  p.coeff = coeff; p.part = coeff + (long)g->n * ci_real * 3;
+  hipStream_t s = (hipStream_t)stream;
+  RtpProfScope prof(RTP_FAM_NORM, s);
+  hipLaunchKernelGGL(gn_bwd_coeffs_cls_kernel, dim3(g->n), dim3(256), shm, s, p);
+  RTP_CHECK_LAUNCH();
+  return RTP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // rtp_class_sums : out[n][64][c]  (partials [n][nsplit][64][c] in `scratch`, then a fixed-order reduction)
 // One wave per x-row: the (z,y) flags are row-uniform, only x==0 / x==W-1 differ, so lanes accumulate three
 // register sets (interior / first / last) and touch the LDS buckets once per row.

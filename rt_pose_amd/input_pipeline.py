@@ -50,8 +50,10 @@ class DeviceInputPipeline:
     """
 
     def __init__(self, engine, roi, voxel_size_xyz, norm, rdr_type="zyx_real", max_poses=1, min_radius=1,
-                 out_size_factor=(1, 1, 1), stored_dims=(32, 128, 256), ring=2, max_in=None):
+                 out_size_factor=(1, 1, 1), stored_dims=(32, 128, 256), ring=2, max_in=None, numpy_legacy=False):
         self.eng, self.be = engine, engine.be
+        # voxel-coordinate arithmetic: fp32 throughout (NumPy >= 2, the captured vectors) or NumPy 1.x's float64 intermediate
+        self.numpy_legacy = bool(numpy_legacy)
         self.lib = _lib.load()
         dev = self.be.device
         self.roi_idx = roi_indices(roi)
@@ -140,6 +142,6 @@ class DeviceInputPipeline:
                                              C.c_void_p(self.table.data_ptr()), C.c_void_p(eng.tgt_hm.data_ptr()),
                                              C.c_void_p(eng.tgt_pose.data_ptr()), C.c_void_p(eng.tgt_ind.data_ptr()),
                                              C.c_void_p(eng.tgt_mask.data_ptr()), C.c_void_p(eng.tgt_cat.data_ptr()),
-                                             C.c_void_p(self.prev.data_ptr()), s), "rtp_assign_labels")
+                                             C.c_void_p(self.prev.data_ptr()), int(self.numpy_legacy), s), "rtp_assign_labels")
             slot["done"].record(self.stream)
         return slot["done"]

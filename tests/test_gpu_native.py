@@ -30,10 +30,18 @@ from tests.util import rel_err
 pytestmark = pytest.mark.gpu
 NATIVE = configs.NATIVE_DIMS
 
-# per-tensor gates: (vs fp32 oracle autograd, vs emulated bf16 plan)
-GATE_REL = {"oracle": 0.12, "emu": 0.12}
-GATE_COS = {"oracle": 0.992, "emu": 0.992}
-GATE_ABS = 2e-3   # of the model's largest per-tensor gradient norm
+# per-tensor gates (relative error, cosine) per configuration: vs the oracle's fp32 autograd, and vs the emulated bf16 plan
+# (tests/emu_backend.py: same rounding points as the kernels, fp32 CPU arithmetic in between -- differs from the HIP path
+# only by summation order and the ReLU / L1-sign decisions that a last-bit difference flips).
+#   hr3d: measured worst tensor 0.094 / 0.067 (transition1 / layer1.conv2, round 2).
+#   hr3d_one_hm_doppler: the regression target is 45 offsets in U(-8, 8) under an L1 loss at ONE voxel per frame, so
+#   the gradient signal is a sum of +-1 signs; a sign decided differently in bf16 is a discontinuity no precision removes.
+#   The emulated plan itself (no HIP code involved) sits 0.20-0.27 from fp32 autograd on layer1 / stage2 tensors
+#   (measured on CPU at B=2), so the oracle gate is loose here and the emulated-plan gate is the sharp one.
+GATES = {"hr3d": {"oracle": (0.13, 0.991), "emu": (0.10, 0.994)},
+         "hr3d_one_hm_doppler": {"oracle": (0.40, 0.93), "emu": (0.20, 0.98)}}
+GATE_ABS = 2e-3   # of the model's largest per-tensor gradient norm (tensors whose own norm is tiny)
+MEDIAN_REL = {"hr3d": (0.04, 0.04), "hr3d_one_hm_doppler": (0.08, 0.06)}
 
 
 @pytest.fixture(scope="module")
@@ -65,15 +73,14 @@ def tensor_report(got: dict, want: dict, names):
     return rows
 
 
-def gate(rows, kind, label):
+def gate(rows, kind, label, name):
+    rel_max, cos_min = GATES[name][kind]
     top = max(r[2] for r in rows)
-    worst = "\n".join("   %-62s n=%-7d |g|=%.3e rel=%.4f cos=%.5f" % r[:5] for r in rows[:5])
-    print("\n[%s] worst 5 parameter tensors vs %s:\n%s" % (label, kind, worst))
-    bad = [r for r in rows if not ((r[3] <= GATE_REL[kind] and r[4] >= GATE_COS[kind]) or r[5] <= GATE_ABS * top)]
-    assert not bad, "%s: %d tensors outside the per-tensor gates vs %s:\n%s" % (
-        label, len(bad), kind, "\n".join("   %-62s n=%-7d |g|=%.3e rel=%.4f cos=%.5f" % r[:5] for r in bad[:10]))
+    fmt = "   %-62s n=%-7d |g|=%.3e rel=%.4f cos=%.5f"
+    print("\n[%s] worst 5 parameter tensors vs %s:\n%s" % (label, kind, "\n".join(fmt % r[:5] for r in rows[:5])))
+    bad = [r for r in rows if not ((r[3] <= rel_max and r[4] >= cos_min) or r[5] <= GATE_ABS * top)]
     med = float(np.median([r[3] for r in rows]))
-    return med
+    return med, ["%s vs %s: %s" % (label, kind, fmt % r[:5]) for r in bad]
 
 
 # ------------------------------------------------------------------------------------------------ registry door
@@ -226,13 +233,18 @@ def test_native_b8_train_step_per_tensor(hip, name):
     assert float(losses["num_positive"]) == float(ref["num_positive"][0])
     assert rel_err(res["hip_hm"], res["emu_hm"]) < 1e-2      # same rounding points, different summation order
     got = OrderedDict((k, flat.grads[k]) for k in live)
-    med_o = gate(tensor_report(got, {k: sdr[k].grad for k in live}, live), "oracle", name + " B=8 native")
-    med_e = gate(tensor_report(got, res["emu"][1].grads, live), "emu", name + " B=8 native")
-    assert med_o < 0.04 and med_e < 0.04, (med_o, med_e)
+    med_o, bad_o = gate(tensor_report(got, {k: sdr[k].grad for k in live}, live), "oracle", name + " B=8 native", name)
+    med_e, bad_e = gate(tensor_report(got, res["emu"][1].grads, live), "emu", name + " B=8 native", name)
     gh = torch.cat([got[k].detach().float().cpu().reshape(-1) for k in live])
     gr = torch.cat([sdr[k].grad.reshape(-1) for k in live])
-    assert float(torch.dot(gh, gr) / (gh.norm() * gr.norm())) > 0.995
-    assert abs(float(gh.norm() / gr.norm()) - 1) < 0.02
+    ge = torch.cat([res["emu"][1].grads[k].detach().float().reshape(-1) for k in live])
+    cos = lambda a, b: float(torch.dot(a, b) / (a.norm() * b.norm()))
+    print("median rel: oracle %.4f emu %.4f; global cosine: oracle %.5f emu %.5f; norm ratio %.4f"
+          % (med_o, med_e, cos(gh, gr), cos(gh, ge), float(gh.norm() / gr.norm())))
+    assert not (bad_o + bad_e), "tensors outside the per-tensor gates:\n" + "\n".join(bad_o + bad_e)
+    assert med_o < MEDIAN_REL[name][0] and med_e < MEDIAN_REL[name][1], (med_o, med_e)
+    assert cos(gh, ge) > (0.997 if name == "hr3d" else 0.985) and cos(gh, gr) > (0.995 if name == "hr3d" else 0.96)
+    assert abs(float(gh.norm() / gr.norm()) - 1) < (0.02 if name == "hr3d" else 0.06)
     dead = [k for k in sd if sdr[k].grad is None]
     assert all(float(flat.grads[k].abs().max()) == 0 for k in dead)
 

@@ -49,9 +49,12 @@ def test_label_assignment(tag):
     assert np.array_equal(r["ind"], G["lab_%s_ind" % tag])
     assert np.array_equal(r["mask"], G["lab_%s_mask" % tag])
     assert np.array_equal(r["cat"], G["lab_%s_cat" % tag])
-    # the captured vectors come from numpy >= 2 (fp32 intermediate); the restatement keeps the float64 intermediate of
-    # numpy 1.x: the two differ by at most one fp32 ulp of a coordinate < 160
-    assert np.abs(r["anno_pose"] - G["lab_%s_anno" % tag]).max() <= 2e-5
+    assert np.array_equal(r["anno_pose"], G["lab_%s_anno" % tag])     # bit-exact: same fp32 arithmetic as NumPy >= 2
+    # NumPy 1.x promotion (float64 intermediate, one rounding) stays within one fp32 ulp of a coordinate < 160
+    r1 = R.assign_labels(poses, (16, 64, 160), RANGE_ZYX_MIN, GRID_SIZE, (1, 1, 1), max_poses, min_radius, one_hm=(ncls == 1),
+                         numpy_legacy=True)
+    if "edge" not in tag:    # off the voxel boundaries the two promotions pick the same voxels
+        assert np.array_equal(r1["ind"], r["ind"]) and np.abs(r1["anno_pose"] - r["anno_pose"]).max() <= 2e-5
     if nposes:
         assert r["mask"].sum() > 0 and r["mask"].sum() < r["mask"].size + 1
 
