@@ -116,9 +116,23 @@ int rtp_wgrad(const RtpAct* gy, const RtpAct* x, const RtpConvGeom* g, int nspli
  * kernel will run and any nsplit >= 1 is accepted. */
 int rtp_wgrad_nsplit(const RtpConvGeom* g);
 
+/* rtp_wgrad on the LDS-tiled kernel (rtp_wgrad_nsplit(g) > 0 and nsplit equal to it) that ALSO contracts every slab with
+ * the data-gradient weights wd (bf16 [ks^3][ci_pad][cok], what rtp_fold_fwd / rtp_pack_dgrad_w write):
+ *   qpart[n][s][ci] = sum_{tap,co} wd[tap][ci][co] * gp[n][s][tap][co][ci]
+ * Summed over s this is Q = sum_v dxhat[v][ci] * x[v][ci] of GroupNorm backward (dxhat = the data gradient), obtained
+ * without a pass over dxhat -- so the data gradient can run AFTER its GroupNorm coefficients are known and write the
+ * finished gradient (rtp_conv_dgrad_fused). */
+int rtp_wgrad_q(const RtpAct* gy, const RtpAct* x, const RtpConvGeom* g, int nsplit, float* gp, const void* wd,
+                float* qpart, void* stream);
+
 /* Per boundary-class channel sums of an output-side gradient: out fp32 [n][64][c];
  * scratch fp32 [n][nsplit][64][c] (row-split partials, reduced in fixed order).  out == NULL: partials only. */
 int rtp_class_sums(const RtpAct* gy, int n, int d, int h, int w, int nsplit, float* scratch, float* out, void* stream);
+/* rtp_class_sums of a tensor whose per-channel TOTALS are already known (tot_part fp32 [n][tot_nsplit][c], e.g. written by
+ * rtp_conv_dgrad_fused): only the boundary voxels are read (1/6 of a 16x64x160 volume); the interior class is the total
+ * minus the boundary classes.  out fp32 [n][64][c]; scratch fp32 [n][nsplit][64][c]. */
+int rtp_class_sums_boundary(const RtpAct* gy, int n, int d, int h, int w, int nsplit, float* scratch, const float* tot_part,
+                            int tot_nsplit, float* out, void* stream);
 /* Fixed-order reduction of class-sum partials [n][nsplit][64][c] -> out [n][64][c]. */
 int rtp_class_sums_reduce(const float* scratch, int nsplit, int n, int c, float* out, void* stream);
 
@@ -160,6 +174,16 @@ int rtp_tail_launch(const void* descs /*device*/, const int* block_start /*devic
 int rtp_gn_bwd_coeffs(const float* pq, int nsplit, const float* mr, const float* gamma, int n, int c, int groups,
                       long vox, float* coeff, float* dgamma, float* dbeta, int accumulate, void* stream);
 
+/* The same coefficients without a pass over dxhat (one block per sample):
+ *   Q[n][ci] = sum_s qpart[n][s][ci]                              (rtp_wgrad_q)
+ *   P[n][ci] = sum_{tap,co} wd[tap][ci][co] * sum_{boundary classes in which `tap` stays in bounds} csum[n][cls][co]
+ * cls_part: fp32 [n][cls_nsplit][64][co32] class-sum partials of the conv's OUTPUT gradient (rtp_class_sums with
+ * out == NULL, rtp_grad_combine_cls); csum_out (optional) receives their fixed-order reduction [n][64][co32], i.e. what
+ * rtp_class_sums_reduce would write.  coeff: as rtp_gn_bwd_coeffs (n*ci*5 floats).  ci_real == g->ci required. */
+int rtp_gn_bwd_coeffs_cls(const float* qpart, int q_nsplit, const float* cls_part, int cls_nsplit, float* csum_out,
+                          const void* wd, const float* mr, const float* gamma, const RtpConvGeom* g, int ci_real,
+                          int co_real, int groups, float* coeff, void* stream);
+
 /* ---------------------------------------------------------------- B. point-wise family --- */
 
 typedef struct RtpTerm {
@@ -167,6 +191,18 @@ typedef struct RtpTerm {
   const float* coeff; /* NULL = DIRECT term, else GN-backward coefficients [n][c][3] */
   int d, h, w;       /* spatial dims of the term (fuse_sum: low-res terms are upsampled) */
 } RtpTerm;
+
+/* Data gradient of a 3x3x3 stride-1 conv with 32 input channels that writes the FINISHED gradient of the conv's input x,
+ * absorbing the gradient fan-in pass (rtp_grad_combine) into its epilogue:
+ *   dx = [x > 0 if mask] * (A * conv_transpose(gy; wd) + B*x + C + sum_k term_k)
+ * coeff: this conv's GroupNorm-backward coefficients [n][32][3] or NULL (conv without GroupNorm: A = 1, B = C = 0);
+ * terms (host, <= 3): gradient contributions of x's OTHER consumers, already complete -- DIRECT addends or another
+ * GroupNorm consumer's dxhat with its coefficients (evaluated like rtp_grad_combine's GN terms).
+ * Geometries: rtp_conv_tiled_ok(gy, g, 1); others return RTP_ERR_UNSUPPORTED (use rtp_conv_igemm + rtp_grad_combine).
+ * tot_out (optional): per-channel sums of the stored dx, one fp32 partial per workgroup
+ * [n][rtp_conv_stats_nsplit(gy, g, 1)][32], which rtp_class_sums_boundary completes to per-boundary-class sums. */
+int rtp_conv_dgrad_fused(const RtpAct* gy, const void* wd, const RtpAct* x, const float* coeff, const RtpTerm* terms /*host*/,
+                         int nterms, int mask, const RtpAct* dx, const RtpConvGeom* g, float* tot_out, void* stream);
 
 /* out = mask(relu_src > 0) * sum_k term_k ; GN terms evaluate A*dxhat + B*x + C.  All same resolution. */
 int rtp_grad_combine(const RtpTerm* terms /*host*/, int nterms, const RtpAct* x, const RtpAct* relu_src,

@@ -124,6 +124,36 @@ class HipBackend:
     def wgrad_nsplit(self, geom):
         return self.lib.rtp_wgrad_nsplit(_geom(geom))
 
+    def wgrad_q(self, gy, x, geom, nsplit, gp, wd, qpart):
+        """rtp_wgrad_q: the tiled weight-gradient correlation + each slab's contraction with the data-gradient weights."""
+        fn, g = self.lib.rtp_wgrad_q, _geom(geom)
+        args = (_act(gy), _act(x), g, nsplit, _ptr(gp), _ptr(wd), _ptr(qpart))
+        keep = (gy, x, gp, wd, qpart)
+        return lambda s: check(fn(*args, s), "rtp_wgrad_q") or keep and None
+
+    def gn_bwd_coeffs_cls(self, qpart, q_nsplit, cls_part, cls_nsplit, csum_out, wd, mr, gamma, geom, ci_real, co_real, groups,
+                          coeff):
+        fn, g = self.lib.rtp_gn_bwd_coeffs_cls, _geom(geom)
+        args = (_ptr(qpart), q_nsplit, _ptr(cls_part), cls_nsplit, _ptr(csum_out), _ptr(wd), _ptr(mr), _ptr(gamma), g, ci_real,
+                co_real, groups, _ptr(coeff))
+        keep = (qpart, cls_part, csum_out, wd, mr, gamma, coeff)
+        return lambda s: check(fn(*args, s), "rtp_gn_bwd_coeffs_cls") or keep and None
+
+    def conv_dgrad_fused(self, gy, wd, x, coeff, terms, mask, dx, geom, tot_out=None):
+        """rtp_conv_dgrad_fused: terms = [(View, coeff | None)] contributions of x's other consumers (<= 3);
+        tot_out fp32 [n][conv_stats_nsplit(gy, geom, True)][32]: per-channel totals of the stored dx."""
+        fn, g = self.lib.rtp_conv_dgrad_fused, _geom(geom)
+        arr = self._terms(terms, False) if terms else None
+        args = (_act(gy), _ptr(wd), _act(x), _ptr(coeff), arr, len(terms), int(mask), _act(dx), g, _ptr(tot_out))
+        keep = (gy, wd, x, coeff, terms, dx, arr, tot_out)
+        return lambda s: check(fn(*args, s), "rtp_conv_dgrad_fused") or keep and None
+
+    def class_sums_boundary(self, gy, nsplit, scratch, tot_part, tot_nsplit, out):
+        fn = self.lib.rtp_class_sums_boundary
+        args = (_act(gy), gy.n, gy.d, gy.h, gy.w, nsplit, _ptr(scratch), _ptr(tot_part), tot_nsplit, _ptr(out))
+        keep = (gy, scratch, tot_part, out)
+        return lambda s: check(fn(*args, s), "rtp_class_sums_boundary") or keep and None
+
     def class_sums(self, gy, nsplit, scratch, out):
         fn = self.lib.rtp_class_sums
         args = (_act(gy), gy.n, gy.d, gy.h, gy.w, nsplit, _ptr(scratch), _ptr(out))

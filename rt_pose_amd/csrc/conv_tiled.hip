@@ -46,6 +46,15 @@ struct TiledParams {
   int x_cs, x_co;          // x may be a 32-channel slice of a wider tensor (channel stride / first channel)
   const float* acc32; int a_cs;  // optional fp32 partial result [N][vox][a_cs] added before bias / ReLU (input-channel split)
   int dbg;  // timing experiments only (RTP_TILED_DBG): bit0 = skip the MFMA loop, bit1 = skip staging, bit2 = skip epilogue
+  // FUSE: a data gradient that writes the FINISHED gradient of its input tensor x (= p.res, the AUX operand):
+  //   y = [x > 0] * (A0 * acc + Bt * x + Ct + sum_e Ae * ex_e)
+  // coef[0] = this conv's GroupNorm-backward coefficients [N][32][3] (A, B, C) or null (1, 0, 0); ex_e = gradient terms of
+  // x's OTHER consumers, already complete: plain addends (coef[1+e] null) or other GroupNorm consumers' dxhat with their
+  // coefficients (A scales the term, B and C join Bt / Ct).  Replaces the separate fan-in pass over the tensor.
+  const float* coef[4];
+  const bf16_t* ex[3]; int ex_cs[3], ex_co[3];
+  int nextra, mask;
+  float* tot_out;   // FUSE, optional: per-channel sums of the stored output, one partial per workgroup [N][wgs][32]
 };
 
 __device__ __forceinline__ int swz(int chunk, int xi) { return ((chunk + 2 * (xi >> 2)) & 3) << 3; }  // bf16 elements
@@ -70,8 +79,9 @@ __device__ __forceinline__ void cv_sched() {
 }
 
 // AUX: 0 none, 1 residual added in the epilogue, 2 second operand of the statistics (not added).  STAT: emit statistics.
-template <int NT, bool HAS_BTAB, int AUX, bool STAT>
+template <int NT, bool HAS_BTAB, int AUX, bool STAT, bool FUSE = false>
 __global__ __launch_bounds__(512, 2) void conv_tiled_kernel(TiledParams p) {
+  static_assert(!FUSE || (NT == 2 && !HAS_BTAB && AUX == 2 && !STAT), "fused data-gradient epilogue: 32 channels, x in the AUX slot");
   extern __shared__ __attribute__((aligned(16))) bf16_t lds[];
   bf16_t* wL = lds;                                   // [27][NT*16][32]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -124,6 +134,20 @@ __global__ __launch_bounds__(512, 2) void conv_tiled_kernel(TiledParams p) {
       bL[i] = p.btab[((long)(p.w_per_sample ? n : 0) * 64 + cls) * p.Co + co];
     }
   }
+  if constexpr (FUSE) {   // coefficient table in the (unused) class-bias region: [A0 | Bt | Ct | A1 | A2 | A3][32]
+    if (tid < 32) {
+      float a0 = 1.f, bt = 0.f, ct = 0.f;
+      if (p.coef[0]) { const float* k = p.coef[0] + ((long)n * 32 + tid) * 3; a0 = k[0]; bt = k[1]; ct = k[2]; }
+#pragma unroll
+      for (int e = 0; e < 3; ++e) {
+        float ae = 1.f;
+        if (e < p.nextra && p.coef[1 + e]) { const float* k = p.coef[1 + e] + ((long)n * 32 + tid) * 3; ae = k[0]; bt += k[1]; ct += k[2]; }
+        bL[(3 + e) * 32 + tid] = ae;
+      }
+      bL[tid] = a0; bL[32 + tid] = bt; bL[64 + tid] = ct;
+    }
+    if (tid < 256) bL[192 + tid] = 0.f;   // per-wave running totals [8 waves][32]
+  }
   const long vox_n = (long)n * p.D * p.H * p.W;
   // Staging descriptors (brick-independent, computed once): element offset of each of this thread's 13 sixteen-byte
   // items relative to the brick origin, its swizzled LDS slot, and six "on the low/high face of the halo" bits.
@@ -167,6 +191,19 @@ __global__ __launch_bounds__(512, 2) void conv_tiled_kernel(TiledParams p) {
   for (int phase = 0; phase < nphase; ++phase) {
     const bool loading = ((phase + team) & 1) == 0;  // team-uniform (=> wave-uniform)
     if (loading) {
+      bf16x8 exr[3][TY];
+      if constexpr (FUSE) {
+        // the other consumers' terms of the pending brick: requested first, so they arrive under the DMA issue below
+        if (pend) {
+#pragma unroll
+          for (int e = 0; e < 3; ++e)
+            if (e < p.nextra) {
+#pragma unroll
+              for (int t = 0; t < TY; ++t)
+                exr[e][t] = ld_bf16x8(p.ex[e] + (vox_n + ((long)e_oz * p.H + (e_y0 + t)) * p.W + e_ox) * p.ex_cs[e] + p.ex_co[e] + c0);
+            }
+        }
+      }
       if (load_k < my_tiles && !(p.dbg & 2)) {
         const int tile = t_begin + load_k;
         const int tz = tile % p.tiles_z, tx = (tile / p.tiles_z) % p.tiles_x, ty = tile / (p.tiles_z * p.tiles_x);  // z fastest
@@ -188,6 +225,7 @@ __global__ __launch_bounds__(512, 2) void conv_tiled_kernel(TiledParams p) {
         pend = false;
         // ---- epilogue of the previous brick: bias + residual + ReLU in fp32, one rounding, one 16-B store per lane and row
         const int oz = e_oz, ox = e_ox, y0 = e_y0, kzx = e_kzx;
+        float tsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int t = 0; t < TY; ++t) {
           const int oy = y0 + t;
@@ -223,6 +261,32 @@ __global__ __launch_bounds__(512, 2) void conv_tiled_kernel(TiledParams p) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) aux[j] = bf2f(pre_r4[t][j]);
           }
+          if constexpr (FUSE) {
+            float ka[CH], kb[CH], kc[CH];
+#pragma unroll
+            for (int k = 0; k < CH; k += 4) {
+              const f32x4 a4 = *reinterpret_cast<const f32x4*>(bL + c0 + k), b4 = *reinterpret_cast<const f32x4*>(bL + 32 + c0 + k),
+                          c4 = *reinterpret_cast<const f32x4*>(bL + 64 + c0 + k);
+#pragma unroll
+              for (int j = 0; j < 4; ++j) { ka[k + j] = a4[j]; kb[k + j] = b4[j]; kc[k + j] = c4[j]; }
+            }
+#pragma unroll
+            for (int j = 0; j < CH; ++j) ev[j] = ev[j] * ka[j] + (kb[j] * aux[j] + kc[j]);
+#pragma unroll
+            for (int e = 0; e < 3; ++e)
+              if (e < p.nextra) {
+#pragma unroll
+                for (int k = 0; k < CH; k += 4) {
+                  const f32x4 a4 = *reinterpret_cast<const f32x4*>(bL + (3 + e) * 32 + c0 + k);
+#pragma unroll
+                  for (int j = 0; j < 4; ++j) ev[k + j] += a4[j] * bf2f(exr[e][t][k + j]);
+                }
+              }
+            if (p.mask) {
+#pragma unroll
+              for (int j = 0; j < CH; ++j) ev[j] = aux[j] > 0.f ? ev[j] : 0.f;
+            }
+          }
           if constexpr (AUX == 1) {
 #pragma unroll
             for (int j = 0; j < CH; ++j) ev[j] += aux[j];
@@ -242,6 +306,10 @@ __global__ __launch_bounds__(512, 2) void conv_tiled_kernel(TiledParams p) {
 #pragma unroll
               for (int j = 0; j < 8; ++j) o[j] = f2bf(ev[j]);
               st_bf16x8(yp, o);
+              if constexpr (FUSE) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) tsum[j] += bf2f(o[j]);   // totals of the stored (rounded) values
+              }
               if constexpr (STAT) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
@@ -262,6 +330,24 @@ __global__ __launch_bounds__(512, 2) void conv_tiled_kernel(TiledParams p) {
                   st_p[j] += r;
                   st_q[j] += r * (AUX == 2 ? aux[j] : r);
                 }
+              }
+            }
+          }
+        }
+        if constexpr (FUSE) {
+          if (p.tot_out) {   // fold the 16 voxel lanes, then this wave's own LDS slots (no atomics: fixed order)
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+              for (int o = 1; o < 16; o <<= 1) tsum[j] += __shfl_xor(tsum[j], o, 64);
+            if (v == 0) {
+              float* tp = bL + 192 + wave * 32 + c0;
+#pragma unroll
+              for (int k = 0; k < 8; k += 4) {
+                f32x4 a4 = *reinterpret_cast<const f32x4*>(tp + k);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) a4[j] += tsum[k + j];
+                *reinterpret_cast<f32x4*>(tp + k) = a4;
               }
             }
           }
@@ -352,6 +438,14 @@ __global__ __launch_bounds__(512, 2) void conv_tiled_kernel(TiledParams p) {
     }
     __syncthreads();
   }
+  if constexpr (FUSE) {
+    if (p.tot_out && tid < 32) {   // (the phase loop ends with a barrier)
+      float a = 0.f;
+#pragma unroll
+      for (int w8 = 0; w8 < 8; ++w8) a += bL[192 + w8 * 32 + tid];
+      p.tot_out[(long)bid * 32 + tid] = a;
+    }
+  }
   if constexpr (STAT) {
     // lanes sharing q own the same channels: fold the 16 voxel lanes, then the 8 waves in fixed order through the (now
     // idle) halo region, one partial per workgroup
@@ -411,13 +505,18 @@ int rtp_conv_tiled_stat_slots(const RtpAct* x, const RtpConvGeom* g, int transpo
 
 // Returns RTP_OK if it handled the conv, +1 if the geometry is not this kernel's (caller falls through to the
 // generic gather kernel), or a negative error.
+struct TiledFuse { const float* coef[4]; const RtpAct* ex[3]; int nextra, mask; float* tot_out; };
+
 int rtp_conv_tiled_try(const RtpAct* x, const void* wf, int w_per_sample, const float* btab, const RtpAct* res,
                        const RtpAct* y, const RtpConvGeom* g, int relu, int transposed, int y_fp32,
-                       const RtpAct* stat_x, float* stat_out, const float* acc32, int acc_cs, hipStream_t s) {
+                       const RtpAct* stat_x, float* stat_out, const float* acc32, int acc_cs, hipStream_t s,
+                       const TiledFuse* fuse = nullptr) {
   int Co;
   if (!tiled_geometry_ok(x, g, transposed, &Co)) return 1;
+  if (fuse && (Co != 32 || !transposed || btab || res || !stat_x || stat_out || acc32 || y_fp32 || relu)) return RTP_ERR_UNSUPPORTED;
   if (acc32 && (acc_cs % 4 || acc_cs < Co)) return RTP_ERR_ALIGN;
   if (stat_out && (y_fp32 || (stat_x && res))) return RTP_ERR_UNSUPPORTED;
+  if (!fuse && stat_x && !stat_out) return RTP_ERR_SHAPE;
   if (stat_x) res = stat_x;  // rides in the residual's prefetch slot
   TiledParams p;
   p.stat_out = stat_out;
@@ -433,6 +532,19 @@ int rtp_conv_tiled_try(const RtpAct* x, const void* wf, int w_per_sample, const 
   p.teams_per_sample = wgs * 2;
   static const int dbg = getenv("RTP_TILED_DBG") ? atoi(getenv("RTP_TILED_DBG")) : 0;
   p.dbg = dbg;
+  p.nextra = 0; p.mask = 0; p.tot_out = nullptr;
+  for (int e = 0; e < 4; ++e) p.coef[e] = nullptr;
+  for (int e = 0; e < 3; ++e) { p.ex[e] = nullptr; p.ex_cs[e] = p.ex_co[e] = 0; }
+  if (fuse) {
+    if (fuse->nextra < 0 || fuse->nextra > 3) return RTP_ERR_SHAPE;
+    p.nextra = fuse->nextra; p.mask = fuse->mask; p.tot_out = fuse->tot_out;
+    p.coef[0] = fuse->coef[0];
+    for (int e = 0; e < fuse->nextra; ++e) {
+      if (!fuse->ex[e] || fuse->ex[e]->c < 32 || (fuse->ex[e]->cs % 8) || (fuse->ex[e]->co % 8)) return RTP_ERR_ALIGN;
+      p.ex[e] = (const bf16_t*)fuse->ex[e]->ptr; p.ex_cs[e] = fuse->ex[e]->cs; p.ex_co[e] = fuse->ex[e]->co;
+      p.coef[1 + e] = fuse->coef[1 + e];
+    }
+  }
   const int nt = Co / 16;
   const size_t shm = sizeof(bf16_t) * (27 * (size_t)Co * 32 + 2 * (size_t)HALO_VOX * 32) + 27 * (size_t)Co * sizeof(float);
   RtpProfScope prof((Co == 32 && (long)p.N * p.D * p.H * p.W >= (1L << 20)) ? RTP_FAM_CONV_TILED_FULL : RTP_FAM_CONV_TILED, s);
@@ -456,7 +568,39 @@ int rtp_conv_tiled_try(const RtpAct* x, const void* wf, int w_per_sample, const 
     attr_done = true;
   }
   const int aux = stat_x ? 2 : (res ? 1 : 0);
+  if (fuse) {
+    static bool fattr = false;
+    if (!fattr) {
+      (void)hipFuncSetAttribute((const void*)conv_tiled_kernel<2, false, 2, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(sizeof(bf16_t) * (27 * (size_t)32 * 32 + 2 * (size_t)HALO_VOX * 32) + 27 * 32 * sizeof(float)));
+      fattr = true;
+    }
+    hipLaunchKernelGGL((conv_tiled_kernel<2, false, 2, false, true>), dim3(p.N * wgs), dim3(512), shm, s, p);
+    RTP_CHECK_LAUNCH();
+    return RTP_OK;
+  }
   hipLaunchKernelGGL(table[nt - 1][btab ? 1 : 0][aux][stat_out ? 1 : 0], dim3(p.N * wgs), dim3(512), shm, s, p);
   RTP_CHECK_LAUNCH();
   return RTP_OK;
+}
+
+// Data gradient of a 3x3x3 stride-1 32 -> <=32-channel conv that writes the FINISHED gradient of the conv's input x:
+//   dx = [x > 0 if mask] * (A*convT(gy; wd) + B*x + C + sum_k term_k)
+// coeff = this conv's GroupNorm-backward coefficients [n][32][3] (rtp_gn_bwd_coeffs / _cls) or NULL (no GroupNorm);
+// terms = the contributions of x's other consumers (RtpTerm: plain addend, or dxhat + coefficients of another GroupNorm
+// consumer), at most 3.  tot_out (optional): per-channel sums of the stored dx, one partial per workgroup
+// [n][rtp_conv_stats_nsplit(gy, g, 1)][32] (rtp_class_sums_boundary completes them to per-class sums).
+// Only the LDS-tiled kernel's geometries (rtp_conv_tiled_ok(gy, g, 1)).
+extern "C" int rtp_conv_dgrad_fused(const RtpAct* gy, const void* wd, const RtpAct* x, const float* coeff,
+                                    const RtpTerm* terms /*host*/, int nterms, int mask, const RtpAct* dx,
+                                    const RtpConvGeom* g, float* tot_out, void* stream) {
+  if (!gy || !wd || !x || !dx || !g || nterms < 0 || nterms > 3 || (nterms && !terms)) return RTP_ERR_SHAPE;
+  if ((gy->co % 8) || (gy->cs % 8) || (dx->co % 8) || (dx->cs % 8) || (x->co % 8) || (x->cs % 8)) return RTP_ERR_ALIGN;
+  if (x->c < 32 || dx->c < 32) return RTP_ERR_SHAPE;
+  TiledFuse f;
+  f.nextra = nterms; f.mask = mask; f.tot_out = tot_out;
+  f.coef[0] = coeff;
+  for (int e = 0; e < 3; ++e) { f.ex[e] = e < nterms ? &terms[e].t : nullptr; f.coef[1 + e] = e < nterms ? terms[e].coeff : nullptr; }
+  const int rc = rtp_conv_tiled_try(gy, wd, 0, nullptr, nullptr, dx, g, 0, 1, 0, x, nullptr, nullptr, 0, (hipStream_t)stream, &f);
+  return rc > 0 ? RTP_ERR_UNSUPPORTED : rc;
 }

@@ -499,19 +499,41 @@ __global__ __launch_bounds__(256) void gn_bwd_coeffs_cls_kernel(GnClsParams p) {
   float* red = CS + ntap * co32;          // [256]
   float* Pq = red + 256;                  // [2][256]: gamma*P, gamma*r*(Q - mu P) per channel
   float* S12 = Pq + 512;                  // [2][64]
+  unsigned* vm = reinterpret_cast<unsigned*>(S12 + 128);   // [ntap][2]: bit cls set = tap in bounds for that boundary class
+  for (int i = tid; i < ntap * 2; i += 256) vm[i] = 0u;
   for (int i = tid; i < 64 * co32; i += 256) {
-    float a = 0.f;
     const float* src = p.cls_part + (long)n * p.cls_nsplit * 64 * co32 + i;
-    for (int s = 0; s < p.cls_nsplit; ++s) a += src[(long)s * 64 * co32];
+    float a = 0.f;
+    int s_ = 0;
+    for (; s_ + 8 <= p.cls_nsplit; s_ += 8) {   // eight loads in flight
+      float g8[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) g8[k] = src[(long)(s_ + k) * 64 * co32];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) a += g8[k];
+    }
+    for (; s_ < p.cls_nsplit; ++s_) a += src[(long)s_ * 64 * co32];
     csum[i] = a;
     if (p.csum_out) p.csum_out[(long)n * 64 * co32 + i] = a;
+  }
+  __syncthreads();
+  for (int i = tid; i < ntap * 64; i += 256) {
+    const int tap = i >> 6, cls = i & 63;
+    if (tap_inb_class(tap, cls, p.f)) atomicOr(&vm[tap * 2 + (cls >> 5)], 1u << (cls & 31));
   }
   __syncthreads();
   for (int i = tid; i < ntap * co32; i += 256) {
     const int tap = i / co32, co = i - tap * co32;
     float a = 0.f;
-    for (int cls = 0; cls < 64; ++cls)
-      if (tap_inb_class(tap, cls, p.f)) a += csum[cls * co32 + co];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      unsigned m = vm[tap * 2 + h];
+      while (m) {
+        const int b = __ffs(m) - 1;
+        m &= m - 1;
+        a += csum[(h * 32 + b) * co32 + co];
+      }
+    }
     CS[i] = a;
   }
   __syncthreads();
@@ -573,7 +595,7 @@ extern "C" int rtp_gn_bwd_coeffs_cls(const float* qpart, int q_nsplit, const flo
   if (rc) return rc;
   if (ci_real > 256 || 256 % ci_real || groups > 64 || ci_real % groups || ci_real != p.f.ci_pad) return RTP_ERR_UNSUPPORTED;
   p.co32 = (g->co + 31) / 32 * 32;
-  const size_t shm = sizeof(float) * ((size_t)64 * p.co32 + (size_t)p.f.ntap * p.co32 + 256 + 512 + 128);
+  const size_t shm = sizeof(float) * ((size_t)64 * p.co32 + (size_t)p.f.ntap * p.co32 + 256 + 512 + 128 + 64);
   if (shm > 60 * 1024) return RTP_ERR_UNSUPPORTED;
   p.qpart = qpart; p.q_nsplit = q_nsplit; p.cls_part = cls_part; p.cls_nsplit = cls_nsplit; p.csum_out = csum_out;
   p.wd = (const bf16_t*)wd; p.mr = mr; p.gamma = gamma; p.groups = groups; p.vox = (long)g->di * g->hi * g->wi;
@@ -590,8 +612,11 @@ extern "C" int rtp_gn_bwd_coeffs_cls(const float* qpart, int q_nsplit, const flo
 // One wave per x-row: the (z,y) flags are row-uniform, only x==0 / x==W-1 differ, so lanes accumulate three
 // register sets (interior / first / last) and touch the LDS buckets once per row.
 // ------------------------------------------------------------------------------------------------
+// boundary_only: voxels of the interior class (no face touched: the bulk of the tensor) are skipped -- their class sum is
+// derived from the per-channel TOTAL the producing kernel emitted (class_sums_final_tot_kernel), so only ~1/6 of a
+// 16 x 64 x 160 tensor is read.
 __global__ __launch_bounds__(256) void class_sums_kernel(const bf16_t* g, int cs, int co, int c, int D, int H, int W,
-                                                         int nsplit, float* part) {
+                                                         int nsplit, float* part, int boundary_only) {
   extern __shared__ __attribute__((aligned(16))) float cls_sum[];  // [64][c]
   const int n = blockIdx.y, s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const long vox = (long)D * H * W;
@@ -609,8 +634,9 @@ __global__ __launch_bounds__(256) void class_sums_kernel(const bf16_t* g, int cs
 #pragma unroll
     for (int j = 0; j < 8; ++j) a_in[j] = a_f[j] = a_l[j] = 0.f;
     const bf16_t* row = g + ((long)n * vox + (long)r * W) * cs + co;
-    for (int i = lane; i < W * cpv; i += 64) {
-      const int x = i / cpv;
+    const bool edge_only = boundary_only && czy == 0 && W > 2;   // interior row: only its first and last voxel
+    for (int i = lane; i < (edge_only ? 2 : W) * cpv; i += 64) {
+      const int x = edge_only ? ((i / cpv) ? W - 1 : 0) : i / cpv;
       bf16x8 t = ld_bf16x8(row + (long)x * cs + chunk * 8);
       const bool first = (x == 0), last = (x == W - 1);
 #pragma unroll
@@ -683,8 +709,59 @@ extern "C" int rtp_class_sums(const RtpAct* gy, int n, int d, int h, int w, int 
   hipStream_t s = (hipStream_t)stream;
   RtpProfScope prof(RTP_FAM_NORM, s);
   hipLaunchKernelGGL(class_sums_kernel, dim3(nsplit, n), dim3(256), sizeof(float) * 64 * c, s, (const bf16_t*)gy->ptr,
-                     gy->cs, gy->co, c, d, h, w, nsplit, scratch);
+                     gy->cs, gy->co, c, d, h, w, nsplit, scratch, 0);
   if (out) launch_class_final(scratch, nsplit, n, c, out, s);  // out == NULL: partials only (reduced later, e.g. by the tail)
+  RTP_CHECK_LAUNCH();
+  return RTP_OK;
+}
+
+// Final reduction for the boundary-only scan: classes 1..63 from the partials, class 0 (interior) = total - their sum.
+__global__ __launch_bounds__(512) void class_sums_final_tot_kernel(const float* part, int nsplit, const float* tot, int tot_nsplit,
+                                                                   float* out, int c) {
+  extern __shared__ __attribute__((aligned(16))) float shc[];  // [64][c]
+  const int n = blockIdx.x, tid = threadIdx.x;
+  const int per_n = 64 * c;
+  for (int i4 = tid; i4 < per_n / 4; i4 += 512) {
+    const float* src = part + (long)n * nsplit * per_n + i4 * 4;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    int s_ = 0;
+    for (; s_ + 8 <= nsplit; s_ += 8) {
+      f32x4 g8[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) g8[k] = *reinterpret_cast<const f32x4*>(src + (long)(s_ + k) * per_n);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc += g8[k];
+    }
+    for (; s_ < nsplit; ++s_) acc += *reinterpret_cast<const f32x4*>(src + (long)s_ * per_n);
+    *reinterpret_cast<f32x4*>(shc + i4 * 4) = acc;
+  }
+  __syncthreads();
+  for (int ch = tid; ch < c; ch += 512) {
+    float t = 0.f;
+    for (int s_ = 0; s_ < tot_nsplit; ++s_) t += tot[((long)n * tot_nsplit + s_) * c + ch];
+    float b = 0.f;
+    for (int cls = 1; cls < 64; ++cls) b += shc[cls * c + ch];
+    shc[ch] = t - b;
+  }
+  __syncthreads();
+  for (int i4 = tid; i4 < per_n / 4; i4 += 512)
+    *reinterpret_cast<f32x4*>(out + (long)n * per_n + i4 * 4) = *reinterpret_cast<const f32x4*>(shc + i4 * 4);
+}
+
+// rtp_class_sums for a tensor whose per-channel totals are already known (tot_part fp32 [n][tot_nsplit][c], e.g. from
+// rtp_conv_dgrad_fused): scans only the boundary voxels; out fp32 [n][64][c] as rtp_class_sums.
+extern "C" int rtp_class_sums_boundary(const RtpAct* gy, int n, int d, int h, int w, int nsplit, float* scratch,
+                                       const float* tot_part, int tot_nsplit, float* out, void* stream) {
+  if (!gy || !scratch || !tot_part || !out || nsplit < 1 || tot_nsplit < 1) return RTP_ERR_SHAPE;
+  const int c = gy->c;
+  if (c % 8 || c > 128 || (64 % (c / 8))) return RTP_ERR_UNSUPPORTED;
+  if ((gy->cs % 8) || (gy->co % 8)) return RTP_ERR_ALIGN;
+  hipStream_t s = (hipStream_t)stream;
+  RtpProfScope prof(RTP_FAM_NORM, s);
+  hipLaunchKernelGGL(class_sums_kernel, dim3(nsplit, n), dim3(256), sizeof(float) * 64 * c, s, (const bf16_t*)gy->ptr,
+                     gy->cs, gy->co, c, d, h, w, nsplit, scratch, 1);
+  hipLaunchKernelGGL(class_sums_final_tot_kernel, dim3(n), dim3(512), sizeof(float) * 64 * c, s, scratch, nsplit, tot_part,
+                     tot_nsplit, out, c);
   RTP_CHECK_LAUNCH();
   return RTP_OK;
 }

@@ -32,6 +32,9 @@ struct WgTiledParams {
   int x_cs, x_co;   // x may be a 32-channel slice of a wider tensor
   int tiles_y, tiles_x, tiles_z, tiles_per_sample, wgs_per_sample;
   int dbg;  // timing experiments only (RTP_TILED_DBG): bit0 = consumers skip the MFMA work, bit1 = producers skip the DMA
+  // optional: contract this workgroup's slab with the data-gradient weights wd[tap][ci][co] (bf16) -> qpart[n][wg][ci] =
+  // sum_{tap,co} wd * slab, the slab's share of Q = sum_v dxhat*x of GroupNorm backward (norm_fold.hip, gn_bwd_coeffs_cls)
+  const bf16_t* wd; float* qpart;
 };
 
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
@@ -231,6 +234,36 @@ __global__ __launch_bounds__(512, 2) void wgrad_tiled_kernel(WgTiledParams p) {
           for (int r = 0; r < 4; ++r)
             out[(tap * 32 + a * 16 + q * 4 + r) * 32 + b * 16 + i] = acc[t][a][b][r];
   }
+  if (p.qpart) {
+    // lane holds slab[tap][co = a*16 + 4q + r][ci = b*16 + i]; wd[tap][ci][co..co+3] is one 8-byte read
+    float qs[2] = {0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 7; ++t) {
+      const int tap = tw + 4 * t;
+      if (tap < 27)
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < 2; ++b) {
+            const bf16x4 w4 = *reinterpret_cast<const bf16x4*>(p.wd + ((long)tap * 32 + b * 16 + i) * 32 + a * 16 + q * 4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) qs[b] += bf2f(w4[r]) * acc[t][a][b][r];
+          }
+    }
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      qs[b] += __shfl_xor(qs[b], 16, 64);
+      qs[b] += __shfl_xor(qs[b], 32, 64);
+    }
+    // fold the four consumer waves in fixed order through LDS (the staging buffers are idle now; the loader waves have
+    // exited, which the hardware barrier accounts for)
+    float* red = reinterpret_cast<float*>(lds);
+    __syncthreads();
+    if (q == 0) { red[tw * 32 + i] = qs[0]; red[tw * 32 + 16 + i] = qs[1]; }
+    __syncthreads();
+    if (tw == 0 && lane < 32)
+      p.qpart[((long)n * p.wgs_per_sample + wg) * 32 + lane] = (red[lane] + red[32 + lane]) + (red[64 + lane] + red[96 + lane]);
+  }
 }
 
 static bool wg_tiled_applicable(const RtpConvGeom* g) {
@@ -253,7 +286,8 @@ static int wg_tiled_wgs(const RtpConvGeom* g) {
 // any nsplit accepted).
 extern "C" int rtp_wgrad_nsplit(const RtpConvGeom* g) { return (g && wg_tiled_applicable(g)) ? wg_tiled_wgs(g) : 0; }
 
-int rtp_wgrad_tiled_try(const RtpAct* gy, const RtpAct* x, const RtpConvGeom* g, int nsplit, float* gp, hipStream_t s) {
+int rtp_wgrad_tiled_try(const RtpAct* gy, const RtpAct* x, const RtpConvGeom* g, int nsplit, float* gp, hipStream_t s,
+                        const void* wd, float* qpart) {
   if (!wg_tiled_applicable(g)) return 1;
   if (x->cs % 32 || x->co % 8 || nsplit != wg_tiled_wgs(g)) return 1;   // x may be a 32-channel slice of a wider tensor
   WgTiledParams p;
@@ -265,6 +299,7 @@ int rtp_wgrad_tiled_try(const RtpAct* gy, const RtpAct* x, const RtpConvGeom* g,
   p.wgs_per_sample = nsplit;
   static const int dbg = getenv("RTP_TILED_DBG") ? atoi(getenv("RTP_TILED_DBG")) : 0;
   p.dbg = dbg;
+  p.wd = (const bf16_t*)wd; p.qpart = wd ? qpart : nullptr;
   const size_t shm = sizeof(bf16_t) * 2 * (size_t)(HALO_VOX + BRICK_VOX) * 32;
   RtpProfScope prof(RTP_FAM_WGRAD_TILED, s);
   static bool attr = false;

@@ -83,6 +83,8 @@ class Act(View):
         self.contribs = []         # list of (View, coeff tensor | None)
         self.grad: Optional[View] = None
         self.grad_cls = None       # (nsplit, partial class sums of .grad) when grad_combine emitted them
+        self.final = False         # .grad was written complete by a fused data gradient (no fan-in pass needed)
+        self.grad_tot = None       # (nsplit, per-channel total partials of .grad) when that fused data gradient emitted them
         self.producer = None
 
 
@@ -262,6 +264,8 @@ class Graph:
     def finalize_grad(self, t: Act, want_cls=False):
         """want_cls: the consumer needs per-boundary-class sums of this gradient (ConvOp with bias / GroupNorm);
         when a grad_combine launch produces the tensor anyway, it emits them in the same pass."""
+        if t.final:
+            return t.grad
         if not t.contribs:
             return None
         if len(t.contribs) == 1 and t.contribs[0][1] is None and not t.relu:
@@ -290,8 +294,46 @@ class Graph:
             first = False
         return t.grad
 
+    def class_sums_for(self, y: Act, gy: View, lane, name, early=False):
+        """Per-boundary-class channel sums [n][64][c] of gy, the gradient of activation y (bias gradient, GroupNorm un-fold of
+        the weight gradient, and P of the fused GroupNorm backward).  The pass that produced gy may already have emitted
+        them (grad_combine) or the per-channel totals (fused data gradient: only the boundary voxels are scanned then).
+        early: the sums are needed during the sweep, not just by the deferred tail."""
+        be = self.be
+        csum = be.alloc((self.n, 64, gy.c), "f32")
+        if y.grad is gy and y.grad_cls is not None:
+            split, scratch = y.grad_cls
+            if early:
+                self.emit_bwd(be.class_sums_reduce(scratch, split, self.n, gy.c, csum), lane, [scratch], [csum], "clsred:" + name)
+            else:
+                self.tail_a.append(("class_reduce", scratch, split, self.n, gy.c, csum))
+        elif y.grad is gy and y.grad_tot is not None and hasattr(be, "class_sums_boundary"):
+            tsplit, tot = y.grad_tot
+            split = min(32, cls_split(gy.d, gy.h))
+            scratch = be.alloc((self.n, split, 64, gy.c), "f32")
+            self.emit_bwd(be.class_sums_boundary(gy, split, scratch, tot, tsplit, csum), lane, [gy, tot], [scratch, csum],
+                          "clsb:" + name)
+        else:
+            split = cls_split(gy.d, gy.h)
+            scratch = be.alloc((self.n, split, 64, gy.c), "f32")
+            if early:
+                self.emit_bwd(be.class_sums(gy, split, scratch, csum), lane, [gy], [scratch, csum], "cls:" + name)
+            else:
+                self.emit_bwd(be.class_sums(gy, split, scratch, None), lane, [gy], [scratch], "cls:" + name)
+                self.tail_a.append(("class_reduce", scratch, split, self.n, gy.c, csum))
+        return csum
+
     def build_backward(self):
         assert self.train
+        import os
+        # The FIRST-created consumer of an activation is the LAST to add its gradient contribution in the reversed sweep:
+        # if that consumer is a conv whose data gradient runs on the LDS-tiled kernel, its epilogue absorbs the fan-in
+        # (all other contributions + GroupNorm backward + ReLU mask) and writes the finished gradient (ConvOp.emit_backward).
+        self.first_consumer = {}
+        self.fused_dgrad = not os.environ.get("RTP_NO_FUSED_DGRAD") and hasattr(self.be, "conv_dgrad_fused")
+        for op in self.ops:
+            for t in op.inputs():
+                self.first_consumer.setdefault(id(t), op)
         for op in reversed(self.ops):
             gy = self.finalize_grad(op.y, isinstance(op, (ConvOp, SplitConvOp, CoSplitConvOp)) and bool(op.gn or op.bname))
             if gy is None:
@@ -323,6 +365,9 @@ class StemOp:
     def __init__(self, g, x_f32, y, wname, bname):
         self.g, self.x, self.y, self.wname, self.bname = g, x_f32, y, wname, bname
 
+    def inputs(self):
+        return []
+
     def emit_backward(self, gy):
         g = self.g
         scratch = g.be.alloc((g.be.stem_bwd_blocks(), self.y.c, 2), "f32")
@@ -336,6 +381,9 @@ class ConvOp:
         self.wname, self.bname, self.gn, self.relu, self.residual, self.out_fp32 = wname, bname, gn, relu, residual, out_fp32
         self.ci_real, self.co_real = ci_real, co_real
         self.mr = None
+
+    def inputs(self):
+        return [self.x] + ([self.residual] if self.residual is not None else [])
 
     def emit_forward(self):
         g, be, ge = self.g, self.g.be, self.geom
@@ -406,6 +454,8 @@ class ConvOp:
         if self.residual is not None and self.residual.needs_grad:
             self.residual.contribs.append((gy, None))
         w = g.params[self.wname]
+        if self._fusable(gy):
+            return self._emit_backward_fused(gy)
         # ---- data gradient (and GroupNorm backward terms)
         if x.needs_grad or self.gn:
             cok = pad_to(ge.co, 32)
@@ -458,19 +508,84 @@ class ConvOp:
             4 * g.n * S * ge.ks ** 3 * co32 * ge.ci)
         # Everything after the correlation itself (class-sum reduction, slab fold + GroupNorm un-fold) only feeds the
         # optimiser: recorded here, run once for all layers at the end of the sweep (Graph.emit_tail).
-        csum = None
-        if self.gn or self.bname:
-            csum = be.alloc((g.n, 64, gy.c), "f32")
-            if self.y.grad_cls is not None and self.y.grad is gy:
-                cs_split, cs_scratch = self.y.grad_cls
-            else:
-                cs_split = cls_split(gy.d, gy.h)
-                cs_scratch = be.alloc((g.n, cs_split, 64, gy.c), "f32")
-                g.emit_bwd(be.class_sums(gy, cs_split, cs_scratch, None), wl, [gy], [cs_scratch], "cls:" + self.name)
-            g.tail_a.append(("class_reduce", cs_scratch, cs_split, g.n, gy.c, csum))
+        csum = g.class_sums_for(self.y, gy, wl, self.name) if (self.gn or self.bname) else None
         g.tail_b.append(("wgrad_fold", gp, S, csum, self.mr, g.params[self.gn[0]] if self.gn else None,
                          g.params[self.gn[1]] if self.gn else None, self.groups, ge, self.ci_real,
                          self.co_real, g.pgrad[self.wname], g.pgrad[self.bname] if self.bname else None, 0))
+
+
+    # ------------------------------------------------------------------ fused backward (no fan-in pass)
+    def _fusable(self, gy):
+        """This conv's data gradient can write the FINISHED gradient of x: it runs on the LDS-tiled kernel, it is the last
+        contribution to x in the sweep, and x's other contributions fit the kernel's epilogue."""
+        g, be, ge, x = self.g, self.g.be, self.geom, self.x
+        if not (g.fused_dgrad and self.tiled_bwd and x.needs_grad and g.first_consumer.get(id(x)) is self):
+            return False
+        if self.residual is x or x.c != 32 or x.cs != 32 or x.co != 0 or gy.c < 32:
+            return False
+        if len(x.contribs) > 3 or any(v.c < 32 or (cf is not None and v.c != 32) for v, cf in x.contribs):
+            return False
+        if self.gn and not (be.wgrad_nsplit(ge) > 0 and gy.c == 32 and pad_to(ge.co, 32) == 32):
+            return False   # Q comes from the tiled weight-gradient kernel's slabs
+        return be.conv_tiled_ok(gy, ge, True)
+
+    def _emit_backward_fused(self, gy: View):
+        """GroupNorm conv:  class sums of gy (P) | weight gradient + slab contraction (Q)  ->  coefficients  ->  data
+        gradient whose epilogue evaluates A*dxhat + B*x + C, adds x's other contributions and applies x's ReLU mask.
+        Conv without GroupNorm (head towers): the data gradient adds the other contributions and the mask."""
+        g, be, ge, x = self.g, self.g.be, self.geom, self.x   # (the residual's contribution was added by emit_backward)
+        lane, wl = g.lane_of(self.y), g.wg_lane_of(gy)
+        co32 = pad_to(ge.co, 32)
+        assert gy.c == co32, (self.name, gy.c, co32)
+        ntap = ge.ks ** 3
+        # ---- per-boundary-class sums of gy: bias / un-fold need them, and now P does too
+        csum = g.class_sums_for(self.y, gy, wl, self.name, early=bool(self.gn)) if (self.gn or self.bname) else None
+        # ---- weight gradient (for a GroupNorm conv it now precedes the data gradient: its slabs give Q)
+        S = be.wgrad_nsplit(ge) if x.cs == 32 and x.co == 0 else 0
+        self.tiled_wgrad = S > 0
+        S = S or wgrad_split(gy.vox)
+        gp = be.alloc((g.n, S, ntap, co32, ge.ci), "f32")
+        coeff = None
+        if self.gn:
+            qpart = be.alloc((g.n, S, ge.ci), "f32")
+            g.emit_bwd(be.wgrad_q(gy, x, ge, S, gp, self.wd, qpart), lane, [gy, x, self.wd], [gp, qpart], "wgrad:" + self.name)
+            coeff = be.alloc((g.n * ge.ci * 5,), "f32")
+            g.emit_bwd(be.gn_bwd_coeffs_cls(qpart, S, csum, 1, None, self.wd, self.mr, g.params[self.gn[0]], ge,
+                                            self.ci_real, self.co_real, self.groups, coeff),
+                       lane, [qpart, csum, self.wd, self.mr], [coeff], "gncoef:" + self.name)
+            g.tail_a.append(("gn_param", coeff, g.n, self.ci_real, g.pgrad[self.gn[0]], g.pgrad[self.gn[1]], 0))
+        else:
+            g.emit_bwd(be.wgrad(gy, x, ge, S, gp), wl, [gy, x], [gp], "wgrad:" + self.name)
+        g.flops["wgrad"] += self.alg_flops
+        g.flops["wgrad_tiled" if self.tiled_wgrad else "wgrad_generic"] += self.alg_flops
+        g.alg_bytes["wgrad_tiled" if self.tiled_wgrad else "wgrad_generic"] += 2 * g.n * (gy.vox * co32 + x.vox * ge.ci) + (
+            4 * g.n * S * ntap * co32 * ge.ci)
+        g.tail_b.append(("wgrad_fold", gp, S, csum, self.mr, g.params[self.gn[0]] if self.gn else None,
+                         g.params[self.gn[1]] if self.gn else None, self.groups, ge, self.ci_real,
+                         self.co_real, g.pgrad[self.wname], g.pgrad[self.bname] if self.bname else None, 0))
+        # ---- data gradient -> finished gradient of x
+        terms = list(x.contribs)
+        dx_buf = be.alloc((g.n, x.d, x.h, x.w, ge.ci), "bf16")
+        dx = View(dx_buf, g.n, x.d, x.h, x.w, ge.ci, 0, ge.ci)
+        reads = [gy, self.wd, x, coeff] + [v for v, _ in terms] + [cf for _, cf in terms]
+        # x's producer will want the per-boundary-class sums of this gradient: emit the per-channel totals here
+        tot, prod = None, x.producer
+        if isinstance(prod, (ConvOp, SplitConvOp)) and (prod.gn or prod.bname) and hasattr(be, "class_sums_boundary"):
+            ts = be.conv_stats_nsplit(gy, ge, True)
+            if ts > 0:
+                tot = be.alloc((g.n, ts, 32), "f32")
+                x.grad_tot = (ts, tot)
+        g.emit_bwd(be.conv_dgrad_fused(gy, self.wd, x, coeff, terms, x.relu, dx, ge, tot), lane, reads, [dx_buf, tot],
+                   "dgrad:" + self.name)
+        x.grad, x.final, x.contribs = dx, True, []
+        g.flops["conv_dgrad"] += self.alg_flops
+        g.flops["conv_tiled"] += self.alg_flops
+        # read gy + x (+ the other contributions), write dx
+        nb = 2 * g.n * (gy.vox * co32 + x.vox * ge.ci * (2 + len(terms)))
+        g.alg_bytes["conv_tiled"] += nb
+        if g.n * x.vox >= (1 << 20):
+            g.flops["conv_tiled_full"] += self.alg_flops
+            g.alg_bytes["conv_tiled_full"] += nb
 
 
 class SplitConvOp:
@@ -484,6 +599,9 @@ class SplitConvOp:
         self.wname, self.bname, self.relu, self.ci_real, self.co_real = wname, bname, relu, ci_real, co_real
         self.gn = None
         self.K = ci_real // 32
+
+    def inputs(self):
+        return [self.x]
 
     def slice_geom(self, k):
         s = self.gs
@@ -548,16 +666,7 @@ class SplitConvOp:
                 g.flops["conv_tiled_full"] += self.alg_flops
                 g.alg_bytes["conv_tiled_full"] += nb
         wl = g.wg_lane_of(gy)
-        csum = None
-        if self.bname:
-            csum = be.alloc((g.n, 64, gy.c), "f32")
-            if self.y.grad_cls is not None and self.y.grad is gy:
-                cs_split, cs_scratch = self.y.grad_cls
-            else:
-                cs_split = cls_split(gy.d, gy.h)
-                cs_scratch = be.alloc((g.n, cs_split, 64, gy.c), "f32")
-                g.emit_bwd(be.class_sums(gy, cs_split, cs_scratch, None), wl, [gy], [cs_scratch], "cls:" + self.name)
-            g.tail_a.append(("class_reduce", cs_scratch, cs_split, g.n, gy.c, csum))
+        csum = g.class_sums_for(self.y, gy, wl, self.name) if self.bname else None
         for k in range(self.K):
             gk = self.slice_geom(k)
             S = be.wgrad_nsplit(gk) or wgrad_split(gy.vox)
@@ -581,6 +690,9 @@ class CoSplitConvOp:
         self.wname, self.bname, self.relu, self.co_real = wname, bname, relu, co_real
         self.gn = None
         self.slices = [(0, 32), (32, co_real - 32)]
+
+    def inputs(self):
+        return [self.x]
 
     def geom(self, c):
         x, y = self.x, self.y
@@ -653,6 +765,9 @@ class CoSplitConvOp:
 class FuseOp:
     def __init__(self, g, terms, y):
         self.g, self.terms, self.y = g, terms, y
+
+    def inputs(self):
+        return list(self.terms)
 
     def emit_backward(self, gy: View):
         g, be = self.g, self.g.be

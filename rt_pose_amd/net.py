@@ -53,10 +53,13 @@ def build_backbone(g: Graph, x_f32, arch, dims, prefix="backbone.backbone", live
     ys = [_resblock(g, p, t0, "l1")]
     for stage in (2, 3, 4):
         nb = stage
-        new = _seq(g, "%s.transition%d.%d.0" % (prefix, stage - 1, stage - 1), ys[-1], "t%d" % (stage - 1), 3, 2, True)
-        xs = ys + [new]
         sp = "%s.stage%d.0" % (prefix, stage)
-        xs = [_resblock(g, "%s.branches.%d.0" % (sp, i), xs[i], "s%d.b%d" % (stage, i)) for i in range(nb)]
+        # Creation order = launch order, and the backward sweep runs it in reverse: the existing branches' blocks are created
+        # BEFORE the transition conv, so that a branch block's first conv -- whose data gradient runs on the LDS-tiled kernel --
+        # is the last gradient contribution to the previous stage's output and can absorb the others (graph.ConvOp._fusable)
+        xs = [_resblock(g, "%s.branches.%d.0" % (sp, i), ys[i], "s%d.b%d" % (stage, i)) for i in range(nb - 1)]
+        new = _seq(g, "%s.transition%d.%d.0" % (prefix, stage - 1, stage - 1), ys[-1], "t%d" % (stage - 1), 3, 2, True)
+        xs.append(_resblock(g, "%s.branches.%d.0" % (sp, nb - 1), new, "s%d.b%d" % (stage, nb - 1)))
         rows = nb if (stage < 4 or live_rows_last is None) else live_rows_last
         ys = []
         for i in range(rows):

@@ -237,7 +237,11 @@ class EmuBackend:
         return run
 
     def wgrad_nsplit(self, geom):
-        return 0
+        """Mirror of the LDS-tiled weight-gradient kernel's predicate (2 slabs) so CPU plans exercise the fused backward."""
+        g = geom
+        ok = (g.ks == 3 and g.stride == 1 and g.pad == 1 and g.ci == 32 and (g.co + 31) // 32 * 32 == 32 and g.di % 2 == 0
+              and g.hi % 4 == 0 and g.wi % 16 == 0)
+        return 2 if ok else 0
 
     def class_sums(self, gy, nsplit, scratch, out):
         def run(s):
@@ -339,6 +343,85 @@ class EmuBackend:
             else:
                 dgamma.copy_(dg)
                 dbeta.copy_(db)
+        return run
+
+    def wgrad_q(self, gy, x, geom, nsplit, gp, wd, qpart):
+        """rtp_wgrad_q: the correlation plus each slab's contraction with the data-gradient weights wd[tap][ci][cok]."""
+        base = self.wgrad(gy, x, geom, nsplit, gp)
+
+        def run(s):
+            base(s)
+            qpart.copy_(torch.einsum("tic,nstci->nsi", wd.float(), gp))
+        return run
+
+    def gn_bwd_coeffs_cls(self, qpart, q_nsplit, cls_part, cls_nsplit, csum_out, wd, mr, gamma, geom, ci_real, co_real, groups,
+                          coeff):
+        """rtp_gn_bwd_coeffs_cls: P from the class sums of the output gradient, Q from the slab contractions."""
+        def run(s):
+            g, n, c = geom, geom.n, ci_real
+            co32 = (g.co + 31) // 32 * 32
+            ntap = g.ks ** 3
+            csum = cls_part.view(n, cls_nsplit, 64, co32).sum(1)
+            if csum_out is not None:
+                csum_out.copy_(csum)
+            inb = torch.tensor([[_tap_inb(t, k, g) for k in range(64)] for t in range(ntap)], dtype=torch.float32)
+            CS = torch.einsum("tk,nkc->ntc", inb, csum)
+            P = torch.einsum("tic,ntc->ni", wd.float(), CS)[:, :c]
+            Q = qpart.view(n, q_nsplit, -1).sum(1)[:, :c]
+            cg = c // groups
+            mu = mr[:, :, 0].repeat_interleave(cg, 1)
+            r = mr[:, :, 1].repeat_interleave(cg, 1)
+            gam = gamma.detach().float()
+            m = float(cg * g.di * g.hi * g.wi)
+            s1 = (gam * P).reshape(n, groups, cg).sum(2).repeat_interleave(cg, 1)
+            s2 = (gam * r * (Q - mu * P)).reshape(n, groups, cg).sum(2).repeat_interleave(cg, 1)
+            cf = coeff[:n * c * 3].view(n, c, 3)
+            cf[:, :, 0] = r * gam
+            cf[:, :, 1] = -r * r * s2 / m
+            cf[:, :, 2] = -r * s1 / m + r * r * mu * s2 / m
+            part = coeff[n * c * 3:n * c * 5].view(n, c, 2)
+            part[:, :, 0] = r * (Q - mu * P)
+            part[:, :, 1] = P
+        return run
+
+    def class_sums_boundary(self, gy, nsplit, scratch, tot_part, tot_nsplit, out):
+        """rtp_class_sums_boundary: boundary classes by a scan, the interior class as total - boundary."""
+        def run(s):
+            cls = _classes(gy.d, gy.h, gy.w).reshape(-1)
+            gf = _sl(gy).reshape(gy.n, gy.vox, gy.c)
+            tot = torch.zeros(gy.n, 64, gy.c)
+            keep = cls != 0
+            tot.index_add_(1, cls[keep], gf[:, keep])
+            tot[:, 0] = tot_part.view(gy.n, tot_nsplit, -1)[:, :, :gy.c].sum(1) - tot[:, 1:].sum(1)
+            out.copy_(tot)
+        return run
+
+    def conv_dgrad_fused(self, gy, wd, x, coeff, terms, mask, dx, geom, tot_out=None):
+        """rtp_conv_dgrad_fused: dx = [x > 0] * (A*convT(gy; wd) + B*x + C + sum terms), one rounding."""
+        def run(s):
+            g = geom
+            k = g.ks
+            cok = (g.co + 31) // 32 * 32
+            xin = _ncdhw(gy.buf[..., gy.co:gy.co + cok].float())
+            wt = wd.float().reshape(k, k, k, g.ci, cok).permute(4, 3, 0, 1, 2)
+            acc = _ndhwc(F.conv_transpose3d(xin, wt, None, g.stride, g.pad))
+            c = acc.shape[-1]
+            xv = _sl(x)[..., :c]
+            if coeff is not None:
+                cf = coeff[:g.n * c * 3].view(g.n, 1, 1, 1, c, 3)
+                acc = cf[..., 0] * acc + cf[..., 1] * xv + cf[..., 2]
+            for v, cf2 in terms:
+                if cf2 is None:
+                    acc = acc + _sl(v)[..., :c]
+                else:
+                    k2 = cf2[:g.n * c * 3].view(g.n, 1, 1, 1, c, 3)
+                    acc = acc + k2[..., 0] * _sl(v)[..., :c] + k2[..., 1] * xv + k2[..., 2]
+            if mask:
+                acc = torch.where(xv > 0, acc, torch.zeros(()))
+            _store(dx, acc)
+            if tot_out is not None:   # totals of the stored (rounded) values, everything in partial 0
+                tot_out.zero_()
+                tot_out.view(g.n, -1, tot_out.shape[-1])[:, 0, :c] = _sl(dx)[..., :c].reshape(g.n, -1, c).sum(1)
         return run
 
     # ---------------------------------------------------------------- point-wise family

@@ -542,3 +542,122 @@ def test_adam_and_sqnorm(hip):
     check(v, 1e-5, "adam v")
     run(hip, EMU.adam_step(p.c, None, None, None, nel, hyper.c, pc, 1, None), hip.adam_step(p.g, None, None, None, nel, hyper.g, pg, 1, None))
     check(p, 1e-6, "decay only")
+
+
+# ---------------------------------------------------------------------------------------------- fused backward chain
+FUSED_CASES = [
+    # n, dims, co_real, with GroupNorm, extras (plain / GN terms), mask
+    (2, (4, 8, 32), 32, True, (), True),
+    (2, (4, 8, 32), 32, True, ("plain",), True),
+    (3, (2, 16, 64), 32, True, ("plain", "gn"), False),
+    (2, (8, 32, 80), 32, True, ("gn", "plain", "plain"), True),     # ragged W (half-padding brick column), 3 extras
+    (1, (2, 4, 16), 15, False, (), True),                            # head tower: no GroupNorm, 15 real output channels
+    (2, (4, 8, 16), 3, False, ("plain",), True),
+    (8, (4, 16, 64), 32, True, ("plain",), True),                    # one sample per XCD
+]
+
+
+@pytest.mark.parametrize("case", FUSED_CASES)
+def test_fused_backward_chain(hip, case):
+    """rtp_wgrad_q -> rtp_gn_bwd_coeffs_cls -> rtp_conv_dgrad_fused against the emulation, and against the UNFUSED chain on
+    the GPU (data gradient + chan_stats(dxhat, x) + gn_bwd_coeffs + grad_combine): P and Q obtained from the class sums and
+    the slab contraction equal the sums over dxhat."""
+    n, dims, co_real, has_gn, extras, mask = case
+    d, h, w = dims
+    ci, co = 32, pad_to(co_real, 16)
+    co32 = pad_to(co, 32)
+    geom = Geom(n, d, h, w, d, h, w, ci, co, 3, 1, 1)
+    xp, xc, xg = views(hip, rnd((n, d, h, w, ci), 1, relu=True), n, d, h, w)
+    gyt = rnd((n, d, h, w, co32), 2)
+    gyt[..., co_real:] = 0
+    gp_, gyc, gyg = views(hip, gyt, n, d, h, w)
+    wt = rnd((co_real, ci, 27), 3, torch.float32, scale=0.05)
+    w32 = Pair(hip, wt)
+    wd = Pair(hip, torch.zeros(27, ci, co32, dtype=torch.bfloat16))
+    run(hip, EMU.pack_dgrad_w(w32.c, geom, ci, co_real, wd.c), hip.pack_dgrad_w(w32.g, geom, ci, co_real, wd.g))
+    S = hip.wgrad_nsplit(geom)
+    assert S > 0
+    Sc = 2
+    slab = Pair(hip, torch.zeros(n, S, 27, co32, ci))
+    slab_e = torch.zeros(n, Sc, 27, co32, ci)
+    qp = Pair(hip, torch.zeros(n, S, ci))
+    qp_e = torch.zeros(n, Sc, ci)
+    coeff = coeff_e = None
+    groups = 8
+    if has_gn:
+        # slabs + Q partials
+        EMU.wgrad_q(gyc, xc, geom, Sc, slab_e, wd.c, qp_e)(None)
+        hip.wgrad_q(gyg, xg, geom, S, slab.g, wd.g, qp.g)(hip.stream())
+        torch.cuda.synchronize()
+        assert rel_err(slab.g.sum(1).cpu(), slab_e.sum(1)) < BF
+        assert rel_err(qp.g.sum(1).cpu(), qp_e.sum(1)) < 2e-3, "Q partials"
+        # plain rtp_wgrad writes the same slabs
+        slab2 = hip.alloc((n, S, 27, co32, ci), "f32")
+        hip.wgrad(gyg, xg, geom, S, slab2)(hip.stream())
+        torch.cuda.synchronize()
+        assert torch.equal(slab2, slab.g)
+        # coefficients
+        cs_split = 3
+        clsp = Pair(hip, torch.zeros(n, cs_split, 64, co32))
+        run(hip, EMU.class_sums(gyc, cs_split, clsp.c, None), hip.class_sums(gyg, cs_split, clsp.g, None))
+        mr = Pair(hip, torch.stack([rnd((n, groups), 5, torch.float32, 0.3), rnd((n, groups), 6, torch.float32, 0.2).abs() + 0.5], -1))
+        gam = Pair(hip, rnd((ci,), 7, torch.float32) + 1.5)
+        cf = Pair(hip, torch.zeros(n * ci * 5))
+        cso = Pair(hip, torch.zeros(n, 64, co32))
+        cf_e = torch.zeros(n * ci * 5)
+        cso_e = torch.zeros(n, 64, co32)
+        EMU.gn_bwd_coeffs_cls(qp_e, Sc, clsp.c, cs_split, cso_e, wd.c, mr.c, gam.c, geom, ci, co_real, groups, cf_e)(None)
+        hip.gn_bwd_coeffs_cls(qp.g, S, clsp.g, cs_split, cso.g, wd.g, mr.g, gam.g, geom, ci, co_real, groups, cf.g)(hip.stream())
+        torch.cuda.synchronize()
+        assert rel_err(cso.g.cpu(), cso_e) < F32
+        got, want = cf.g.cpu()[:n * ci * 3].view(n, ci, 3), cf_e[:n * ci * 3].view(n, ci, 3)
+        for k, nm in enumerate("ABC"):
+            assert rel_err(got[..., k], want[..., k]) < 3e-3, "coefficient " + nm
+        assert rel_err(cf.g.cpu()[n * ci * 3:], cf_e[n * ci * 3:]) < 3e-3, "dgamma / dbeta partials"
+        coeff, coeff_e = cf.g, cf_e
+        # ... and they equal the coefficients of the unfused chain (sums over the stored dxhat), to bf16 level
+        dxh_p, dxh_c, dxh_g = views(hip, torch.zeros(n, d, h, w, ci, dtype=torch.bfloat16), n, d, h, w)
+        hip.conv(gyg, wd.g, False, None, None, dxh_g, geom, False, True, False)(hip.stream())
+        pq = hip.alloc((n, 4, ci, 2), "f32")
+        hip.chan_stats(dxh_g, xg, 4, pq)(hip.stream())
+        cf_old = hip.alloc((n * ci * 5,), "f32")
+        hip.gn_bwd_coeffs(pq, 4, mr.g, gam.g, n, ci, groups, d * h * w, cf_old, None, None, 0)(hip.stream())
+        torch.cuda.synchronize()
+        old = cf_old.cpu()[:n * ci * 3].view(n, ci, 3)
+        for k, nm in enumerate("ABC"):
+            assert rel_err(got[..., k], old[..., k]) < 2e-2, "coefficient %s vs the dxhat-pass chain" % nm
+    # extras
+    terms_c, terms_g = [], []
+    for i, kind in enumerate(extras):
+        ep, ec, eg = views(hip, rnd((n, d, h, w, ci), 20 + i), n, d, h, w)
+        if kind == "gn":
+            k = Pair(hip, torch.cat([rnd((n * ci * 3,), 30 + i, torch.float32, 0.5), torch.zeros(n * ci * 2)]))
+            terms_c.append((ec, k.c)); terms_g.append((eg, k.g))
+        else:
+            terms_c.append((ec, None)); terms_g.append((eg, None))
+    dxp, dxc, dxg = views(hip, torch.zeros(n, d, h, w, ci, dtype=torch.bfloat16), n, d, h, w)
+    ts = hip.conv_stats_nsplit(gyg, geom, True)
+    assert ts > 0
+    tot = hip.alloc((n, ts, 32), "f32")
+    EMU.conv_dgrad_fused(gyc, wd.c, xc, coeff_e, terms_c, mask, dxc, geom)(None)
+    hip.conv_dgrad_fused(gyg, wd.g, xg, coeff, terms_g, mask, dxg, geom, tot)(hip.stream())
+    torch.cuda.synchronize()
+    check(dxp, BF, "fused data gradient %r" % (case,))
+    if mask:
+        assert float(dxp.sync_back().float()[xp.c.float() <= 0].abs().max()) == 0.0
+    # per-channel totals of the STORED gradient, and the boundary-only class sums built on them == a full class-sum scan
+    stored = dxg.buf.float().reshape(n, -1, ci)
+    assert rel_err(tot.sum(1).cpu(), stored.sum(1).cpu()) < F32, "epilogue totals"
+    full = hip.alloc((n, 64, ci), "f32")
+    hip.class_sums(dxg, 5, hip.alloc((n, 5, 64, ci), "f32"), full)(hip.stream())
+    bnd = hip.alloc((n, 64, ci), "f32")
+    hip.class_sums_boundary(dxg, 4, hip.alloc((n, 4, 64, ci), "f32"), tot, ts, bnd)(hip.stream())
+    torch.cuda.synchronize()
+    assert torch.equal(bnd[:, 1:].cpu(), full[:, 1:].cpu()) or rel_err(bnd[:, 1:].cpu(), full[:, 1:].cpu()) < 1e-6
+    assert (bnd[:, 0] - full[:, 0]).abs().max() <= 2e-4 * max(1.0, float(stored.abs().sum(1).max())), "interior class = total - boundary"
+    # the same without the second pass through the emulation
+    bnd_e = torch.zeros(n, 64, ci)
+    tot_e = torch.zeros(n, 2, 32)
+    EMU.conv_dgrad_fused(gyc, wd.c, xc, coeff_e, terms_c, mask, dxc, geom, tot_e)(None)
+    EMU.class_sums_boundary(dxc, 4, None, tot_e, 2, bnd_e)(None)
+    assert rel_err(bnd.cpu(), bnd_e) < 2e-2
