@@ -184,6 +184,10 @@ int rtp_gn_bwd_coeffs_cls(const float* qpart, int q_nsplit, const float* cls_par
                           const void* wd, const float* mr, const float* gamma, const RtpConvGeom* g, int ci_real,
                           int co_real, int groups, float* coeff, void* stream);
 
+/* P alone (the class-sum half of rtp_gn_bwd_coeffs_cls): p_out fp32 [n][ci]; runs beside the weight gradient. */
+int rtp_gn_bwd_p(const float* cls_part, int cls_nsplit, float* csum_out, const void* wd, const RtpConvGeom* g, int ci_real,
+                 int co_real, float* p_out, void* stream);
+
 /* ---------------------------------------------------------------- B. point-wise family --- */
 
 typedef struct RtpTerm {
@@ -192,17 +196,29 @@ typedef struct RtpTerm {
   int d, h, w;       /* spatial dims of the term (fuse_sum: low-res terms are upsampled) */
 } RtpTerm;
 
+/* GroupNorm-backward inputs from which rtp_conv_dgrad_fused computes its coefficients in its own prologue (no kernel of
+ * their own between the weight gradient and the data gradient). */
+typedef struct RtpGnBwd {
+  const float* qpart; int q_nsplit; /* [n][q_nsplit][32] slab contractions (rtp_wgrad_q): Q = their sum                 */
+  const float* p;                   /* [n][32]  P = sum dxhat, from the class sums (rtp_gn_bwd_p)                        */
+  const float* mr;                  /* [n][groups][2] (mean, rstd) saved by rtp_fold_fwd                                 */
+  const float* gamma; int groups;
+  float* coeff_out;                 /* optional [n*32*5]: the coefficients + dgamma/dbeta partials, as rtp_gn_bwd_coeffs */
+} RtpGnBwd;
+
 /* Data gradient of a 3x3x3 stride-1 conv with 32 input channels that writes the FINISHED gradient of the conv's input x,
  * absorbing the gradient fan-in pass (rtp_grad_combine) into its epilogue:
  *   dx = [x > 0 if mask] * (A * conv_transpose(gy; wd) + B*x + C + sum_k term_k)
- * coeff: this conv's GroupNorm-backward coefficients [n][32][3] or NULL (conv without GroupNorm: A = 1, B = C = 0);
+ * coeff: this conv's GroupNorm-backward coefficients [n][32][3], or NULL with gn != NULL (computed in the kernel from P and
+ * the slab contractions), or both NULL (conv without GroupNorm: A = 1, B = C = 0);
  * terms (host, <= 3): gradient contributions of x's OTHER consumers, already complete -- DIRECT addends or another
  * GroupNorm consumer's dxhat with its coefficients (evaluated like rtp_grad_combine's GN terms).
  * Geometries: rtp_conv_tiled_ok(gy, g, 1); others return RTP_ERR_UNSUPPORTED (use rtp_conv_igemm + rtp_grad_combine).
  * tot_out (optional): per-channel sums of the stored dx, one fp32 partial per workgroup
  * [n][rtp_conv_stats_nsplit(gy, g, 1)][32], which rtp_class_sums_boundary completes to per-boundary-class sums. */
-int rtp_conv_dgrad_fused(const RtpAct* gy, const void* wd, const RtpAct* x, const float* coeff, const RtpTerm* terms /*host*/,
-                         int nterms, int mask, const RtpAct* dx, const RtpConvGeom* g, float* tot_out, void* stream);
+int rtp_conv_dgrad_fused(const RtpAct* gy, const void* wd, const RtpAct* x, const float* coeff, const RtpGnBwd* gn /*host*/,
+                         const RtpTerm* terms /*host*/, int nterms, int mask, const RtpAct* dx, const RtpConvGeom* g,
+                         float* tot_out, void* stream);
 
 /* out = mask(relu_src > 0) * sum_k term_k ; GN terms evaluate A*dxhat + B*x + C.  All same resolution. */
 int rtp_grad_combine(const RtpTerm* terms /*host*/, int nterms, const RtpAct* x, const RtpAct* relu_src,

@@ -30,6 +30,11 @@ class RtpConvGeom(C.Structure):
                 ("pad", C.c_int), ("w_ci_total", C.c_int), ("w_ci_off", C.c_int)]
 
 
+class RtpGnBwd(C.Structure):
+    _fields_ = [("qpart", C.c_void_p), ("q_nsplit", C.c_int), ("p", C.c_void_p), ("mr", C.c_void_p), ("gamma", C.c_void_p),
+                ("groups", C.c_int), ("coeff_out", C.c_void_p)]
+
+
 class RtpTerm(C.Structure):
     _fields_ = [("t", RtpAct), ("coeff", C.c_void_p), ("d", C.c_int), ("h", C.c_int), ("w", C.c_int)]
 
@@ -56,7 +61,8 @@ PROTOTYPES = {
     "rtp_wgrad_nsplit": [_G],
     "rtp_wgrad_q": [_A, _A, _G, _I, _P, _P, _P, _P],
     "rtp_gn_bwd_coeffs_cls": [_P, _I, _P, _I, _P, _P, _P, _P, _G, _I, _I, _I, _P, _P],
-    "rtp_conv_dgrad_fused": [_A, _P, _A, _P, _T, _I, _I, _A, _G, _P, _P],
+    "rtp_conv_dgrad_fused": [_A, _P, _A, _P, _P, _T, _I, _I, _A, _G, _P, _P],
+    "rtp_gn_bwd_p": [_P, _I, _P, _P, _G, _I, _I, _P, _P],
     "rtp_class_sums_boundary": [_A, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P],
     "rtp_class_sums": [_A, _I, _I, _I, _I, _I, _P, _P, _P],
     "rtp_class_sums_reduce": [_P, _I, _I, _I, _P, _P],

@@ -139,13 +139,25 @@ class HipBackend:
         keep = (qpart, cls_part, csum_out, wd, mr, gamma, coeff)
         return lambda s: check(fn(*args, s), "rtp_gn_bwd_coeffs_cls") or keep and None
 
-    def conv_dgrad_fused(self, gy, wd, x, coeff, terms, mask, dx, geom, tot_out=None):
+    def gn_bwd_p(self, cls_part, cls_nsplit, csum_out, wd, geom, ci_real, co_real, p_out):
+        fn, g = self.lib.rtp_gn_bwd_p, _geom(geom)
+        args = (_ptr(cls_part), cls_nsplit, _ptr(csum_out), _ptr(wd), g, ci_real, co_real, _ptr(p_out))
+        keep = (cls_part, csum_out, wd, p_out)
+        return lambda s: check(fn(*args, s), "rtp_gn_bwd_p") or keep and None
+
+    def conv_dgrad_fused(self, gy, wd, x, coeff, terms, mask, dx, geom, tot_out=None, gn=None):
         """rtp_conv_dgrad_fused: terms = [(View, coeff | None)] contributions of x's other consumers (<= 3);
-        tot_out fp32 [n][conv_stats_nsplit(gy, geom, True)][32]: per-channel totals of the stored dx."""
+        tot_out fp32 [n][conv_stats_nsplit(gy, geom, True)][32]: per-channel totals of the stored dx;
+        gn = dict(qpart, q_nsplit, p, mr, gamma, groups, coeff_out): coefficients computed in the kernel (coeff is None)."""
         fn, g = self.lib.rtp_conv_dgrad_fused, _geom(geom)
         arr = self._terms(terms, False) if terms else None
-        args = (_act(gy), _ptr(wd), _act(x), _ptr(coeff), arr, len(terms), int(mask), _act(dx), g, _ptr(tot_out))
-        keep = (gy, wd, x, coeff, terms, dx, arr, tot_out)
+        gs = None
+        if gn is not None:
+            gs = _lib.RtpGnBwd(gn["qpart"].data_ptr(), gn["q_nsplit"], gn["p"].data_ptr(), gn["mr"].data_ptr(),
+                               gn["gamma"].data_ptr(), gn["groups"], gn["coeff_out"].data_ptr() if gn.get("coeff_out") is not None else None)
+        args = (_act(gy), _ptr(wd), _act(x), _ptr(coeff), C.byref(gs) if gs is not None else None, arr, len(terms), int(mask),
+                _act(dx), g, _ptr(tot_out))
+        keep = (gy, wd, x, coeff, terms, dx, arr, tot_out, gn, gs)
         return lambda s: check(fn(*args, s), "rtp_conv_dgrad_fused") or keep and None
 
     def class_sums_boundary(self, gy, nsplit, scratch, tot_part, tot_nsplit, out):

@@ -55,6 +55,12 @@ struct TiledParams {
   const bf16_t* ex[3]; int ex_cs[3], ex_co[3];
   int nextra, mask;
   float* tot_out;   // FUSE, optional: per-channel sums of the stored output, one partial per workgroup [N][wgs][32]
+  // FUSE, optional: this conv's GroupNorm-backward coefficients are computed HERE (every workgroup, in its prologue) instead
+  // of by a kernel of their own between the weight gradient and this launch: Q = sum of the slab contractions qpart
+  // [N][q_nsplit][32] (rtp_wgrad_q), P [N][32] from the class sums (rtp_gn_bwd_p); workgroup 0 of a sample also writes them
+  // (coef_out [N*32*3] + dgamma/dbeta partials [N*32*2]) for the other consumers of the coefficients.
+  const float* qpart; int q_nsplit; const float* gn_p; const float* gn_mr; const float* gn_gamma; int gn_groups; float gn_m;
+  float* coef_out;
 };
 
 __device__ __forceinline__ int swz(int chunk, int xi) { return ((chunk + 2 * (xi >> 2)) & 3) << 3; }  // bf16 elements
@@ -79,8 +85,12 @@ __device__ __forceinline__ void cv_sched() {
 }
 
 // AUX: 0 none, 1 residual added in the epilogue, 2 second operand of the statistics (not added).  STAT: emit statistics.
-template <int NT, bool HAS_BTAB, int AUX, bool STAT, bool FUSE = false>
+// FUSEX: 0 = plain epilogue; 1 + NEX = fused data-gradient epilogue with NEX (0..3) extra gradient terms (compile-time: the
+// terms' prefetch registers exist only in the variant that needs them -- the kernel sits at the 256-VGPR limit).
+template <int NT, bool HAS_BTAB, int AUX, bool STAT, int FUSEX = 0>
 __global__ __launch_bounds__(512, 2) void conv_tiled_kernel(TiledParams p) {
+  constexpr bool FUSE = FUSEX > 0;
+  constexpr int NEX = FUSE ? FUSEX - 1 : 0;
   static_assert(!FUSE || (NT == 2 && !HAS_BTAB && AUX == 2 && !STAT), "fused data-gradient epilogue: 32 channels, x in the AUX slot");
   extern __shared__ __attribute__((aligned(16))) bf16_t lds[];
   bf16_t* wL = lds;                                   // [27][NT*16][32]
@@ -135,13 +145,52 @@ __global__ __launch_bounds__(512, 2) void conv_tiled_kernel(TiledParams p) {
     }
   }
   if constexpr (FUSE) {   // coefficient table in the (unused) class-bias region: [A0 | Bt | Ct | A1 | A2 | A3][32]
+    float gq = 0.f, gp_ = 0.f, gmu = 0.f, gr = 0.f, ggam = 0.f;
+    if (p.qpart) {   // workgroup-uniform
+      float* scr = bL + 448;   // [256] partial Q, then [2][32] group-sum operands at +256
+      if (tid < 256) {
+        const int c = tid & 31, k = tid >> 5;
+        float q = 0.f;
+        for (int s_ = k; s_ < p.q_nsplit; s_ += 8) q += p.qpart[((long)n * p.q_nsplit + s_) * 32 + c];
+        scr[tid] = q;
+      }
+      __syncthreads();
+      if (tid < 32) {
+        const int cg = 32 / p.gn_groups, g = tid / cg;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) gq += scr[k * 32 + tid];
+        gp_ = p.gn_p[(long)n * 32 + tid];
+        gmu = p.gn_mr[((long)n * p.gn_groups + g) * 2];
+        gr = p.gn_mr[((long)n * p.gn_groups + g) * 2 + 1];
+        ggam = p.gn_gamma[tid];
+        scr[256 + tid] = ggam * gp_;
+        scr[288 + tid] = ggam * gr * (gq - gmu * gp_);
+      }
+      __syncthreads();
+    }
     if (tid < 32) {
       float a0 = 1.f, bt = 0.f, ct = 0.f;
       if (p.coef[0]) { const float* k = p.coef[0] + ((long)n * 32 + tid) * 3; a0 = k[0]; bt = k[1]; ct = k[2]; }
+      if (p.qpart) {
+        const float* scr = bL + 448;
+        const int cg = 32 / p.gn_groups, g0 = (tid / cg) * cg;
+        float s1 = 0.f, s2 = 0.f;
+        for (int j = g0; j < g0 + cg; ++j) { s1 += scr[256 + j]; s2 += scr[288 + j]; }
+        a0 = gr * ggam;
+        bt = -gr * gr * s2 / p.gn_m;
+        ct = -gr * s1 / p.gn_m + gr * gr * gmu * s2 / p.gn_m;
+        if (p.coef_out && bid == n * wgs_per_sample) {
+          float* o = p.coef_out + ((long)n * 32 + tid) * 3;
+          o[0] = a0; o[1] = bt; o[2] = ct;
+          float* pt = p.coef_out + (long)p.N * 32 * 3 + ((long)n * 32 + tid) * 2;
+          pt[0] = gr * (gq - gmu * gp_);
+          pt[1] = gp_;
+        }
+      }
 #pragma unroll
       for (int e = 0; e < 3; ++e) {
         float ae = 1.f;
-        if (e < p.nextra && p.coef[1 + e]) { const float* k = p.coef[1 + e] + ((long)n * 32 + tid) * 3; ae = k[0]; bt += k[1]; ct += k[2]; }
+        if (e < NEX && p.coef[1 + e]) { const float* k = p.coef[1 + e] + ((long)n * 32 + tid) * 3; ae = k[0]; bt += k[1]; ct += k[2]; }
         bL[(3 + e) * 32 + tid] = ae;
       }
       bL[tid] = a0; bL[32 + tid] = bt; bL[64 + tid] = ct;
@@ -191,17 +240,16 @@ __global__ __launch_bounds__(512, 2) void conv_tiled_kernel(TiledParams p) {
   for (int phase = 0; phase < nphase; ++phase) {
     const bool loading = ((phase + team) & 1) == 0;  // team-uniform (=> wave-uniform)
     if (loading) {
-      bf16x8 exr[3][TY];
-      if constexpr (FUSE) {
+      bf16x8 exr[NEX > 0 ? NEX : 1][TY];
+      if constexpr (NEX > 0) {
         // the other consumers' terms of the pending brick: requested first, so they arrive under the DMA issue below
         if (pend) {
 #pragma unroll
-          for (int e = 0; e < 3; ++e)
-            if (e < p.nextra) {
+          for (int e = 0; e < NEX; ++e) {
 #pragma unroll
-              for (int t = 0; t < TY; ++t)
-                exr[e][t] = ld_bf16x8(p.ex[e] + (vox_n + ((long)e_oz * p.H + (e_y0 + t)) * p.W + e_ox) * p.ex_cs[e] + p.ex_co[e] + c0);
-            }
+            for (int t = 0; t < TY; ++t)
+              exr[e][t] = ld_bf16x8(p.ex[e] + (vox_n + ((long)e_oz * p.H + (e_y0 + t)) * p.W + e_ox) * p.ex_cs[e] + p.ex_co[e] + c0);
+          }
         }
       }
       if (load_k < my_tiles && !(p.dbg & 2)) {
@@ -226,6 +274,22 @@ __global__ __launch_bounds__(512, 2) void conv_tiled_kernel(TiledParams p) {
         // ---- epilogue of the previous brick: bias + residual + ReLU in fp32, one rounding, one 16-B store per lane and row
         const int oz = e_oz, ox = e_ox, y0 = e_y0, kzx = e_kzx;
         float tsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        float ka[CH], kb[CH], kc[CH], ke[NEX > 0 ? NEX : 1][CH];
+        if constexpr (FUSE) {
+#pragma unroll
+          for (int k = 0; k < CH; k += 4) {
+            const f32x4 a4 = *reinterpret_cast<const f32x4*>(bL + c0 + k), b4 = *reinterpret_cast<const f32x4*>(bL + 32 + c0 + k),
+                        c4 = *reinterpret_cast<const f32x4*>(bL + 64 + c0 + k);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { ka[k + j] = a4[j]; kb[k + j] = b4[j]; kc[k + j] = c4[j]; }
+#pragma unroll
+            for (int e = 0; e < NEX; ++e) {
+              const f32x4 e4 = *reinterpret_cast<const f32x4*>(bL + (3 + e) * 32 + c0 + k);
+#pragma unroll
+              for (int j = 0; j < 4; ++j) ke[e][k + j] = e4[j];
+            }
+          }
+        }
 #pragma unroll
         for (int t = 0; t < TY; ++t) {
           const int oy = y0 + t;
@@ -262,26 +326,13 @@ __global__ __launch_bounds__(512, 2) void conv_tiled_kernel(TiledParams p) {
             for (int j = 0; j < 4; ++j) aux[j] = bf2f(pre_r4[t][j]);
           }
           if constexpr (FUSE) {
-            float ka[CH], kb[CH], kc[CH];
-#pragma unroll
-            for (int k = 0; k < CH; k += 4) {
-              const f32x4 a4 = *reinterpret_cast<const f32x4*>(bL + c0 + k), b4 = *reinterpret_cast<const f32x4*>(bL + 32 + c0 + k),
-                          c4 = *reinterpret_cast<const f32x4*>(bL + 64 + c0 + k);
-#pragma unroll
-              for (int j = 0; j < 4; ++j) { ka[k + j] = a4[j]; kb[k + j] = b4[j]; kc[k + j] = c4[j]; }
-            }
 #pragma unroll
             for (int j = 0; j < CH; ++j) ev[j] = ev[j] * ka[j] + (kb[j] * aux[j] + kc[j]);
 #pragma unroll
-            for (int e = 0; e < 3; ++e)
-              if (e < p.nextra) {
+            for (int e = 0; e < NEX; ++e) {
 #pragma unroll
-                for (int k = 0; k < CH; k += 4) {
-                  const f32x4 a4 = *reinterpret_cast<const f32x4*>(bL + (3 + e) * 32 + c0 + k);
-#pragma unroll
-                  for (int j = 0; j < 4; ++j) ev[k + j] += a4[j] * bf2f(exr[e][t][k + j]);
-                }
-              }
+              for (int j = 0; j < CH; ++j) ev[j] += ke[e][j] * bf2f(exr[e][t][j]);
+            }
             if (p.mask) {
 #pragma unroll
               for (int j = 0; j < CH; ++j) ev[j] = aux[j] > 0.f ? ev[j] : 0.f;
@@ -335,12 +386,16 @@ __global__ __launch_bounds__(512, 2) void conv_tiled_kernel(TiledParams p) {
           }
         }
         if constexpr (FUSE) {
-          if (p.tot_out) {   // fold the 16 voxel lanes, then this wave's own LDS slots (no atomics: fixed order)
+          if (p.tot_out) {   // fold the 16 voxel lanes (DPP row shifts: lane 15 of a row ends up with the row's sum), then
+                             // this wave's own LDS slots (no atomics: fixed order)
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
-#pragma unroll
-              for (int o = 1; o < 16; o <<= 1) tsum[j] += __shfl_xor(tsum[j], o, 64);
-            if (v == 0) {
+            for (int j = 0; j < 8; ++j) {
+              tsum[j] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, tsum[j]), 0x111, 0xf, 0xf, true));
+              tsum[j] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, tsum[j]), 0x112, 0xf, 0xf, true));
+              tsum[j] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, tsum[j]), 0x114, 0xf, 0xf, true));
+              tsum[j] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, tsum[j]), 0x118, 0xf, 0xf, true));
+            }
+            if (v == 15) {
               float* tp = bL + 192 + wave * 32 + c0;
 #pragma unroll
               for (int k = 0; k < 8; k += 4) {
@@ -505,7 +560,7 @@ int rtp_conv_tiled_stat_slots(const RtpAct* x, const RtpConvGeom* g, int transpo
 
 // Returns RTP_OK if it handled the conv, +1 if the geometry is not this kernel's (caller falls through to the
 // generic gather kernel), or a negative error.
-struct TiledFuse { const float* coef[4]; const RtpAct* ex[3]; int nextra, mask; float* tot_out; };
+struct TiledFuse { const float* coef[4]; const RtpAct* ex[3]; int nextra, mask; float* tot_out; const RtpGnBwd* gn; };
 
 int rtp_conv_tiled_try(const RtpAct* x, const void* wf, int w_per_sample, const float* btab, const RtpAct* res,
                        const RtpAct* y, const RtpConvGeom* g, int relu, int transposed, int y_fp32,
@@ -533,12 +588,20 @@ int rtp_conv_tiled_try(const RtpAct* x, const void* wf, int w_per_sample, const 
   static const int dbg = getenv("RTP_TILED_DBG") ? atoi(getenv("RTP_TILED_DBG")) : 0;
   p.dbg = dbg;
   p.nextra = 0; p.mask = 0; p.tot_out = nullptr;
+  p.qpart = nullptr; p.q_nsplit = 0; p.gn_p = p.gn_mr = p.gn_gamma = nullptr; p.gn_groups = 1; p.gn_m = 1.f; p.coef_out = nullptr;
   for (int e = 0; e < 4; ++e) p.coef[e] = nullptr;
   for (int e = 0; e < 3; ++e) { p.ex[e] = nullptr; p.ex_cs[e] = p.ex_co[e] = 0; }
   if (fuse) {
     if (fuse->nextra < 0 || fuse->nextra > 3) return RTP_ERR_SHAPE;
     p.nextra = fuse->nextra; p.mask = fuse->mask; p.tot_out = fuse->tot_out;
     p.coef[0] = fuse->coef[0];
+    if (fuse->gn) {
+      const RtpGnBwd* q = fuse->gn;
+      if (!q->qpart || !q->p || !q->mr || !q->gamma || q->q_nsplit < 1 || q->groups < 1 || 32 % q->groups) return RTP_ERR_SHAPE;
+      p.qpart = q->qpart; p.q_nsplit = q->q_nsplit; p.gn_p = q->p; p.gn_mr = q->mr; p.gn_gamma = q->gamma;
+      p.gn_groups = q->groups; p.gn_m = (float)(32 / q->groups) * (float)((long)g->di * g->hi * g->wi);
+      p.coef_out = q->coeff_out;
+    }
     for (int e = 0; e < fuse->nextra; ++e) {
       if (!fuse->ex[e] || fuse->ex[e]->c < 32 || (fuse->ex[e]->cs % 8) || (fuse->ex[e]->co % 8)) return RTP_ERR_ALIGN;
       p.ex[e] = (const bf16_t*)fuse->ex[e]->ptr; p.ex_cs[e] = fuse->ex[e]->cs; p.ex_co[e] = fuse->ex[e]->co;
@@ -569,13 +632,16 @@ int rtp_conv_tiled_try(const RtpAct* x, const void* wf, int w_per_sample, const 
   }
   const int aux = stat_x ? 2 : (res ? 1 : 0);
   if (fuse) {
+    static const Kern ftab[4] = {conv_tiled_kernel<2, false, 2, false, 1>, conv_tiled_kernel<2, false, 2, false, 2>,
+                                 conv_tiled_kernel<2, false, 2, false, 3>, conv_tiled_kernel<2, false, 2, false, 4>};
     static bool fattr = false;
     if (!fattr) {
-      (void)hipFuncSetAttribute((const void*)conv_tiled_kernel<2, false, 2, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)(sizeof(bf16_t) * (27 * (size_t)32 * 32 + 2 * (size_t)HALO_VOX * 32) + 27 * 32 * sizeof(float)));
+      for (int e = 0; e < 4; ++e)
+        (void)hipFuncSetAttribute((const void*)ftab[e], hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)(sizeof(bf16_t) * (27 * (size_t)32 * 32 + 2 * (size_t)HALO_VOX * 32) + 27 * 32 * sizeof(float)));
       fattr = true;
     }
-    hipLaunchKernelGGL((conv_tiled_kernel<2, false, 2, false, true>), dim3(p.N * wgs), dim3(512), shm, s, p);
+    hipLaunchKernelGGL(ftab[p.nextra], dim3(p.N * wgs), dim3(512), shm, s, p);
     RTP_CHECK_LAUNCH();
     return RTP_OK;
   }
@@ -591,14 +657,15 @@ int rtp_conv_tiled_try(const RtpAct* x, const void* wf, int w_per_sample, const 
 // consumer), at most 3.  tot_out (optional): per-channel sums of the stored dx, one partial per workgroup
 // [n][rtp_conv_stats_nsplit(gy, g, 1)][32] (rtp_class_sums_boundary completes them to per-class sums).
 // Only the LDS-tiled kernel's geometries (rtp_conv_tiled_ok(gy, g, 1)).
-extern "C" int rtp_conv_dgrad_fused(const RtpAct* gy, const void* wd, const RtpAct* x, const float* coeff,
+extern "C" int rtp_conv_dgrad_fused(const RtpAct* gy, const void* wd, const RtpAct* x, const float* coeff, const RtpGnBwd* gn,
                                     const RtpTerm* terms /*host*/, int nterms, int mask, const RtpAct* dx,
                                     const RtpConvGeom* g, float* tot_out, void* stream) {
+  if (coeff && gn) return RTP_ERR_SHAPE;
   if (!gy || !wd || !x || !dx || !g || nterms < 0 || nterms > 3 || (nterms && !terms)) return RTP_ERR_SHAPE;
   if ((gy->co % 8) || (gy->cs % 8) || (dx->co % 8) || (dx->cs % 8) || (x->co % 8) || (x->cs % 8)) return RTP_ERR_ALIGN;
   if (x->c < 32 || dx->c < 32) return RTP_ERR_SHAPE;
   TiledFuse f;
-  f.nextra = nterms; f.mask = mask; f.tot_out = tot_out;
+  f.nextra = nterms; f.mask = mask; f.tot_out = tot_out; f.gn = gn;
   f.coef[0] = coeff;
   for (int e = 0; e < 3; ++e) { f.ex[e] = e < nterms ? &terms[e].t : nullptr; f.coef[1 + e] = e < nterms ? terms[e].coeff : nullptr; }
   const int rc = rtp_conv_tiled_try(gy, wd, 0, nullptr, nullptr, dx, g, 0, 1, 0, x, nullptr, nullptr, 0, (hipStream_t)stream, &f);

@@ -488,6 +488,7 @@ extern "C" int rtp_gn_bwd_coeffs(const float* pq, int nsplit, const float* mr, c
 struct GnClsParams {
   const float* qpart; int q_nsplit; const float* cls_part; int cls_nsplit; float* csum_out;
   const bf16_t* wd; const float* mr; const float* gamma; FoldParams f; int groups, co32; long vox; float* coeff; float* part;
+  float* p_out;   // non-null: write P [n][ci] only (no Q, no coefficients)
 };
 
 __global__ __launch_bounds__(256) void gn_bwd_coeffs_cls_kernel(GnClsParams p) {
@@ -553,6 +554,13 @@ __global__ __launch_bounds__(256) void gn_bwd_coeffs_cls_kernel(GnClsParams p) {
   red[tid] = pacc;
   __syncthreads();
   float pc = 0.f, qc = 0.f, mu = 0.f, r = 0.f, gam = 0.f;
+  if (p.p_out) {
+    if (tid < C) {
+      for (int kk = 0; kk < np; ++kk) pc += red[kk * C + tid];
+      p.p_out[(long)n * C + tid] = pc;
+    }
+    return;
+  }
   const int cg = C / p.groups;
   const float m = (float)cg * (float)p.vox;
   if (tid < C) {
@@ -599,7 +607,27 @@ extern "C" int rtp_gn_bwd_coeffs_cls(const float* qpart, int q_nsplit, const flo
   if (shm > 60 * 1024) return RTP_ERR_UNSUPPORTED;
   p.qpart = qpart; p.q_nsplit = q_nsplit; p.cls_part = cls_part; p.cls_nsplit = cls_nsplit; p.csum_out = csum_out;
   p.wd = (const bf16_t*)wd; p.mr = mr; p.gamma = gamma; p.groups = groups; p.vox = (long)g->di * g->hi * g->wi;
-  p.coeff = coeff; p.part = coeff + (long)g->n * ci_real * 3;
+  p.coeff = coeff; p.part = coeff + (long)g->n * ci_real * 3; p.p_out = nullptr;
+  hipStream_t s = (hipStream_t)stream;
+  RtpProfScope prof(RTP_FAM_NORM, s);
+  hipLaunchKernelGGL(gn_bwd_coeffs_cls_kernel, dim3(g->n), dim3(256), shm, s, p);
+  RTP_CHECK_LAUNCH();
+  return RTP_OK;
+}
+
+extern "C" int rtp_gn_bwd_p(const float* cls_part, int cls_nsplit, float* csum_out, const void* wd, const RtpConvGeom* g,
+                            int ci_real, int co_real, float* p_out, void* stream) {
+  if (!cls_part || !wd || !g || !p_out || cls_nsplit < 1) return RTP_ERR_SHAPE;
+  GnClsParams p;
+  int rc = fill_fold(p.f, g, ci_real, co_real);
+  if (rc) return rc;
+  if (ci_real > 256 || 256 % ci_real || ci_real != p.f.ci_pad) return RTP_ERR_UNSUPPORTED;
+  p.co32 = (g->co + 31) / 32 * 32;
+  const size_t shm = sizeof(float) * ((size_t)64 * p.co32 + (size_t)p.f.ntap * p.co32 + 256 + 512 + 128 + 64);
+  if (shm > 60 * 1024) return RTP_ERR_UNSUPPORTED;
+  p.qpart = nullptr; p.q_nsplit = 0; p.cls_part = cls_part; p.cls_nsplit = cls_nsplit; p.csum_out = csum_out;
+  p.wd = (const bf16_t*)wd; p.mr = nullptr; p.gamma = nullptr; p.groups = 1; p.vox = 1; p.coeff = nullptr; p.part = nullptr;
+  p.p_out = p_out;
   hipStream_t s = (hipStream_t)stream;
   RtpProfScope prof(RTP_FAM_NORM, s);
   hipLaunchKernelGGL(gn_bwd_coeffs_cls_kernel, dim3(g->n), dim3(256), shm, s, p);
@@ -715,6 +743,92 @@ extern "C" int rtp_class_sums(const RtpAct* gy, int n, int d, int h, int w, int 
   return RTP_OK;
 }
 
+// Boundary-only scan with the work dealt evenly (the faces are a small, very uneven part of the row space): every wave of
+// the grid takes full rows of the z / y faces round-robin (all loads of a row in flight at once), then one lane per
+// (interior row, x side, 16-B chunk) takes the x-face voxels.  D, H, W > 2.
+__global__ __launch_bounds__(256) void class_sums_boundary_kernel(const bf16_t* g, int cs, int co, int c, int D, int H, int W,
+                                                                  int nsplit, float* part) {
+  extern __shared__ __attribute__((aligned(16))) float cls_sum[];  // [64][c]
+  const int n = blockIdx.y, s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long vox = (long)D * H * W;
+  for (int i = tid; i < 64 * c; i += 256) cls_sum[i] = 0.f;
+  __syncthreads();
+  const int cpv = c >> 3, chunk = lane % cpv;
+  const int gw = s * 4 + wave, NW = nsplit * 4;
+  const bf16_t* gn = g + (long)n * vox * cs + co;
+  // ---- full rows: 2*H rows of the z faces, then 2*(D-2) rows of the y faces
+  const int nfull = 2 * H + 2 * (D - 2);
+  for (int fr = gw; fr < nfull; fr += NW) {
+    int z, y;
+    if (fr < 2 * H) { z = (fr < H) ? 0 : D - 1; y = fr % H; }
+    else { const int k = fr - 2 * H; z = 1 + (k >> 1); y = (k & 1) ? H - 1 : 0; }
+    const int czy = (z == 0) | ((z == D - 1) << 1) | ((y == 0) << 2) | ((y == H - 1) << 3);
+    float a_in[8], a_f[8], a_l[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a_in[j] = a_f[j] = a_l[j] = 0.f;
+    const bf16_t* row = gn + ((long)z * H + y) * W * cs;
+    const int items = W * cpv;
+    for (int i0 = 0; i0 < items; i0 += 64 * 4) {
+      bf16x8 t4[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int i = i0 + k * 64 + lane;
+        t4[k] = (i < items) ? ld_bf16x8(row + (long)(i / cpv) * cs + chunk * 8) : zero_bf16x8();
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int i = i0 + k * 64 + lane, x = i / cpv;
+        const bool first = (x == 0), last = (x == W - 1);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float v = bf2f(t4[k][j]);
+          if (first) a_f[j] += v; else if (last) a_l[j] += v; else a_in[j] += v;
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      for (int o = 32; o >= cpv; o >>= 1) {
+        a_in[j] += __shfl_xor(a_in[j], o, 64);
+        a_f[j] += __shfl_xor(a_f[j], o, 64);
+        a_l[j] += __shfl_xor(a_l[j], o, 64);
+      }
+    if (lane < cpv) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        atomicAdd(&cls_sum[czy * c + chunk * 8 + j], a_in[j]);
+        atomicAdd(&cls_sum[(czy | 16) * c + chunk * 8 + j], a_f[j]);
+        atomicAdd(&cls_sum[(czy | 32) * c + chunk * 8 + j], a_l[j]);
+      }
+    }
+  }
+  // ---- x faces of the interior rows: item = (row, side, chunk); lanes sharing (side, chunk) sit 2*cpv apart
+  const int per_row = 2 * cpv, nint = (D - 2) * (H - 2);
+  const int rows_per_wave = 64 / per_row;
+  for (int r0 = gw * rows_per_wave; r0 < nint; r0 += NW * rows_per_wave) {
+    const int r = r0 + lane / per_row, side = (lane / cpv) & 1;
+    float a[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] = 0.f;
+    if (r < nint) {
+      const int z = 1 + r / (H - 2), y = 1 + r % (H - 2);
+      const bf16x8 t = ld_bf16x8(gn + (((long)z * H + y) * W + (side ? W - 1 : 0)) * cs + chunk * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a[j] = bf2f(t[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      for (int o = 32; o >= per_row; o >>= 1) a[j] += __shfl_xor(a[j], o, 64);
+    if (lane < per_row) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) atomicAdd(&cls_sum[(side ? 32 : 16) * c + chunk * 8 + j], a[j]);
+    }
+  }
+  __syncthreads();
+  float* o = part + ((long)n * nsplit + s) * 64 * c;
+  for (int i = tid; i < 64 * c; i += 256) o[i] = cls_sum[i];
+}
+
 // Final reduction for the boundary-only scan: classes 1..63 from the partials, class 0 (interior) = total - their sum.
 __global__ __launch_bounds__(512) void class_sums_final_tot_kernel(const float* part, int nsplit, const float* tot, int tot_nsplit,
                                                                    float* out, int c) {
@@ -758,8 +872,12 @@ extern "C" int rtp_class_sums_boundary(const RtpAct* gy, int n, int d, int h, in
   if ((gy->cs % 8) || (gy->co % 8)) return RTP_ERR_ALIGN;
   hipStream_t s = (hipStream_t)stream;
   RtpProfScope prof(RTP_FAM_NORM, s);
-  hipLaunchKernelGGL(class_sums_kernel, dim3(nsplit, n), dim3(256), sizeof(float) * 64 * c, s, (const bf16_t*)gy->ptr,
-                     gy->cs, gy->co, c, d, h, w, nsplit, scratch, 1);
+  if (d > 2 && h > 2 && w > 2 && 64 % (2 * (c / 8)) == 0)
+    hipLaunchKernelGGL(class_sums_boundary_kernel, dim3(nsplit, n), dim3(256), sizeof(float) * 64 * c, s, (const bf16_t*)gy->ptr,
+                       gy->cs, gy->co, c, d, h, w, nsplit, scratch);
+  else   // thin volumes: (nearly) everything is boundary
+    hipLaunchKernelGGL(class_sums_kernel, dim3(nsplit, n), dim3(256), sizeof(float) * 64 * c, s, (const bf16_t*)gy->ptr,
+                       gy->cs, gy->co, c, d, h, w, nsplit, scratch, 1);
   hipLaunchKernelGGL(class_sums_final_tot_kernel, dim3(n), dim3(512), sizeof(float) * 64 * c, s, scratch, nsplit, tot_part,
                      tot_nsplit, out, c);
   RTP_CHECK_LAUNCH();

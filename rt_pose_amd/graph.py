@@ -545,14 +545,23 @@ class ConvOp:
         self.tiled_wgrad = S > 0
         S = S or wgrad_split(gy.vox)
         gp = be.alloc((g.n, S, ntap, co32, ge.ci), "f32")
-        coeff = None
+        coeff = gnq = None
         if self.gn:
+            import os
             qpart = be.alloc((g.n, S, ge.ci), "f32")
             g.emit_bwd(be.wgrad_q(gy, x, ge, S, gp, self.wd, qpart), lane, [gy, x, self.wd], [gp, qpart], "wgrad:" + self.name)
             coeff = be.alloc((g.n * ge.ci * 5,), "f32")
-            g.emit_bwd(be.gn_bwd_coeffs_cls(qpart, S, csum, 1, None, self.wd, self.mr, g.params[self.gn[0]], ge,
-                                            self.ci_real, self.co_real, self.groups, coeff),
-                       lane, [qpart, csum, self.wd, self.mr], [coeff], "gncoef:" + self.name)
+            if os.environ.get("RTP_GNCOEF_KERNEL"):   # A/B: coefficients by a kernel of their own on the main chain
+                g.emit_bwd(be.gn_bwd_coeffs_cls(qpart, S, csum, 1, None, self.wd, self.mr, g.params[self.gn[0]], ge,
+                                                self.ci_real, self.co_real, self.groups, coeff),
+                           lane, [qpart, csum, self.wd, self.mr], [coeff], "gncoef:" + self.name)
+            else:
+                # P beside the weight gradient (side lane); Q and the coefficients in the data gradient's own prologue
+                pbuf = be.alloc((g.n, ge.ci), "f32")
+                g.emit_bwd(be.gn_bwd_p(csum, 1, None, self.wd, ge, self.ci_real, self.co_real, pbuf), wl, [csum, self.wd], [pbuf],
+                           "gnp:" + self.name)
+                gnq = dict(qpart=qpart, q_nsplit=S, p=pbuf, mr=self.mr, gamma=g.params[self.gn[0]], groups=self.groups,
+                           coeff_out=coeff)
             g.tail_a.append(("gn_param", coeff, g.n, self.ci_real, g.pgrad[self.gn[0]], g.pgrad[self.gn[1]], 0))
         else:
             g.emit_bwd(be.wgrad(gy, x, ge, S, gp), wl, [gy, x], [gp], "wgrad:" + self.name)
@@ -575,8 +584,13 @@ class ConvOp:
             if ts > 0:
                 tot = be.alloc((g.n, ts, 32), "f32")
                 x.grad_tot = (ts, tot)
-        g.emit_bwd(be.conv_dgrad_fused(gy, self.wd, x, coeff, terms, x.relu, dx, ge, tot), lane, reads, [dx_buf, tot],
-                   "dgrad:" + self.name)
+        if gnq is not None:
+            reads += [gnq["qpart"], gnq["p"], self.mr]
+            g.emit_bwd(be.conv_dgrad_fused(gy, self.wd, x, None, terms, x.relu, dx, ge, tot, gnq), lane, reads, [dx_buf, tot, coeff],
+                       "dgrad:" + self.name)
+        else:
+            g.emit_bwd(be.conv_dgrad_fused(gy, self.wd, x, coeff, terms, x.relu, dx, ge, tot), lane, reads, [dx_buf, tot],
+                       "dgrad:" + self.name)
         x.grad, x.final, x.contribs = dx, True, []
         g.flops["conv_dgrad"] += self.alg_flops
         g.flops["conv_tiled"] += self.alg_flops

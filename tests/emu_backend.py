@@ -396,10 +396,47 @@ class EmuBackend:
             out.copy_(tot)
         return run
 
-    def conv_dgrad_fused(self, gy, wd, x, coeff, terms, mask, dx, geom, tot_out=None):
-        """rtp_conv_dgrad_fused: dx = [x > 0] * (A*convT(gy; wd) + B*x + C + sum terms), one rounding."""
+    def gn_bwd_p(self, cls_part, cls_nsplit, csum_out, wd, geom, ci_real, co_real, p_out):
+        """rtp_gn_bwd_p: P = sum dxhat from the class sums of the output gradient."""
+        def run(s):
+            g, n = geom, geom.n
+            co32 = (g.co + 31) // 32 * 32
+            csum = cls_part.view(n, cls_nsplit, 64, co32).sum(1)
+            if csum_out is not None:
+                csum_out.copy_(csum)
+            inb = torch.tensor([[_tap_inb(t, k, g) for k in range(64)] for t in range(g.ks ** 3)], dtype=torch.float32)
+            CS = torch.einsum("tk,nkc->ntc", inb, csum)
+            p_out.copy_(torch.einsum("tic,ntc->ni", wd.float(), CS)[:, :ci_real])
+        return run
+
+    def conv_dgrad_fused(self, gy, wd, x, coeff, terms, mask, dx, geom, tot_out=None, gn=None):
+        """rtp_conv_dgrad_fused: dx = [x > 0] * (A*convT(gy; wd) + B*x + C + sum terms), one rounding.
+        gn: the coefficients are computed here from Q (slab contractions) and P, and written to gn['coeff_out']."""
         def run(s):
             g = geom
+            nonlocal coeff
+            if gn is not None:
+                n, c, groups = g.n, g.ci, gn["groups"]
+                cg = c // groups
+                Q = gn["qpart"].view(n, gn["q_nsplit"], -1).sum(1)[:, :c]
+                P = gn["p"].view(n, -1)[:, :c]
+                mu = gn["mr"][:, :, 0].repeat_interleave(cg, 1)
+                r = gn["mr"][:, :, 1].repeat_interleave(cg, 1)
+                gam = gn["gamma"].detach().float()
+                m = float(cg * g.di * g.hi * g.wi)
+                s1 = (gam * P).reshape(n, groups, cg).sum(2).repeat_interleave(cg, 1)
+                s2 = (gam * r * (Q - mu * P)).reshape(n, groups, cg).sum(2).repeat_interleave(cg, 1)
+                buf = gn.get("coeff_out")
+                if buf is None:
+                    buf = torch.zeros(n * c * 5)
+                cf = buf[:n * c * 3].view(n, c, 3)
+                cf[:, :, 0] = r * gam
+                cf[:, :, 1] = -r * r * s2 / m
+                cf[:, :, 2] = -r * s1 / m + r * r * mu * s2 / m
+                part = buf[n * c * 3:n * c * 5].view(n, c, 2)
+                part[:, :, 0] = r * (Q - mu * P)
+                part[:, :, 1] = P
+                coeff = buf
             k = g.ks
             cok = (g.co + 31) // 32 * 32
             xin = _ncdhw(gy.buf[..., gy.co:gy.co + cok].float())

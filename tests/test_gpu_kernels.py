@@ -655,6 +655,20 @@ def test_fused_backward_chain(hip, case):
     torch.cuda.synchronize()
     assert torch.equal(bnd[:, 1:].cpu(), full[:, 1:].cpu()) or rel_err(bnd[:, 1:].cpu(), full[:, 1:].cpu()) < 1e-6
     assert (bnd[:, 0] - full[:, 0]).abs().max() <= 2e-4 * max(1.0, float(stored.abs().sum(1).max())), "interior class = total - boundary"
+    if has_gn:
+        # coefficients computed in the data gradient's own prologue (P from rtp_gn_bwd_p, Q from the slab contractions)
+        pb = hip.alloc((n, ci), "f32")
+        hip.gn_bwd_p(cso.g, 1, None, wd.g, geom, ci, co_real, pb)(hip.stream())
+        cf2 = hip.alloc((n * ci * 5,), "f32")
+        dx2p, dx2c, dx2g = views(hip, torch.zeros(n, d, h, w, ci, dtype=torch.bfloat16), n, d, h, w)
+        gn = dict(qpart=qp.g, q_nsplit=S, p=pb, mr=mr.g, gamma=gam.g, groups=groups, coeff_out=cf2)
+        hip.conv_dgrad_fused(gyg, wd.g, xg, None, terms_g, mask, dx2g, geom, None, gn)(hip.stream())
+        torch.cuda.synchronize()
+        assert rel_err(cf2.cpu(), cf.g.cpu()) < 1e-5, "in-kernel coefficients == rtp_gn_bwd_coeffs_cls"
+        assert rel_err(dx2g.buf.float().cpu(), dxg.buf.float().cpu()) < 1e-3
+        pe = torch.zeros(n, ci)
+        EMU.gn_bwd_p(cso_e, 1, None, wd.c, geom, ci, co_real, pe)(None)
+        assert rel_err(pb.cpu(), pe) < 2e-3
     # the same without the second pass through the emulation
     bnd_e = torch.zeros(n, 64, ci)
     tot_e = torch.zeros(n, 2, 32)
