@@ -133,6 +133,13 @@ int rtp_class_sums(const RtpAct* gy, int n, int d, int h, int w, int nsplit, flo
  * minus the boundary classes.  out fp32 [n][64][c]; scratch fp32 [n][nsplit][64][c]. */
 int rtp_class_sums_boundary(const RtpAct* gy, int n, int d, int h, int w, int nsplit, float* scratch, const float* tot_part,
                             int tot_nsplit, float* out, void* stream);
+/* Class sums of gy AND (wd != NULL) P of the GroupNorm backward of the conv whose output gradient gy is (rtp_gn_bwd_p), in
+ * ONE launch: the last scan block of each sample (agent-scope counter) reduces the partials and computes P.
+ * tot_part != NULL: boundary-only scan as rtp_class_sums_boundary.  counters: device int [n], zeroed once by the caller
+ * (each launch leaves them zero).  csum_out fp32 [n][64][c]; p_out fp32 [n][ci]. */
+int rtp_class_sums_p(const RtpAct* gy, int n, int d, int h, int w, int nsplit, float* scratch, const float* tot_part,
+                     int tot_nsplit, float* csum_out, const void* wd, const RtpConvGeom* g, int ci_real, int co_real,
+                     float* p_out, int* counters, void* stream);
 /* Fixed-order reduction of class-sum partials [n][nsplit][64][c] -> out [n][64][c]. */
 int rtp_class_sums_reduce(const float* scratch, int nsplit, int n, int c, float* out, void* stream);
 

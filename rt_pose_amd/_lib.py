@@ -64,6 +64,7 @@ PROTOTYPES = {
     "rtp_conv_dgrad_fused": [_A, _P, _A, _P, _P, _T, _I, _I, _A, _G, _P, _P],
     "rtp_gn_bwd_p": [_P, _I, _P, _P, _G, _I, _I, _P, _P],
     "rtp_class_sums_boundary": [_A, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P],
+    "rtp_class_sums_p": [_A, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P, _G, _I, _I, _P, _P, _P],
     "rtp_class_sums": [_A, _I, _I, _I, _I, _I, _P, _P, _P],
     "rtp_class_sums_reduce": [_P, _I, _I, _I, _P, _P],
     "rtp_wgrad_fold": [_P, _I, _P, _P, _P, _P, _I, _G, _I, _I, _P, _P, _I, _P],

@@ -12,7 +12,7 @@ import torch
 from . import _lib
 from ._lib import RtpAct, RtpConvGeom, RtpTerm, check
 
-_DT = {"bf16": torch.bfloat16, "f32": torch.float32, "i64": torch.int64, "u8": torch.uint8}
+_DT = {"bf16": torch.bfloat16, "f32": torch.float32, "i64": torch.int64, "u8": torch.uint8, "i32": torch.int32}
 
 
 def _ptr(t):
@@ -159,6 +159,15 @@ class HipBackend:
                 _act(dx), g, _ptr(tot_out))
         keep = (gy, wd, x, coeff, terms, dx, arr, tot_out, gn, gs)
         return lambda s: check(fn(*args, s), "rtp_conv_dgrad_fused") or keep and None
+
+    def class_sums_p(self, gy, nsplit, scratch, tot_part, tot_nsplit, csum_out, wd, geom, ci_real, co_real, p_out):
+        """rtp_class_sums_p: class sums (boundary-only when tot_part is given) + P of the GroupNorm backward, one launch."""
+        fn = self.lib.rtp_class_sums_p
+        counters = self.alloc((gy.n,), "i32")
+        args = (_act(gy), gy.n, gy.d, gy.h, gy.w, nsplit, _ptr(scratch), _ptr(tot_part), tot_nsplit, _ptr(csum_out), _ptr(wd),
+                _geom(geom) if geom is not None else None, ci_real, co_real, _ptr(p_out), _ptr(counters))
+        keep = (gy, scratch, tot_part, csum_out, wd, p_out, counters)
+        return lambda s: check(fn(*args, s), "rtp_class_sums_p") or keep and None
 
     def class_sums_boundary(self, gy, nsplit, scratch, tot_part, tot_nsplit, out):
         fn = self.lib.rtp_class_sums_boundary

@@ -491,36 +491,51 @@ struct GnClsParams {
   float* p_out;   // non-null: write P [n][ci] only (no Q, no coefficients)
 };
 
-__global__ __launch_bounds__(256) void gn_bwd_coeffs_cls_kernel(GnClsParams p) {
-  extern __shared__ __attribute__((aligned(16))) float sh[];
-  const int tid = threadIdx.x, n = blockIdx.x;
-  const int co32 = p.co32, ntap = p.f.ntap, C = p.f.ci_real, cip = p.f.ci_pad;
+// Shared by the coefficient kernel and by the last block of the class-sum scans: reduce class-sum partials of sample n into
+// LDS (csum [64][co32]; `tot` != null: the interior class is the per-channel total minus the boundary classes), optionally
+// store them, then CS[tap][co] = sum over the classes in which `tap` is in bounds, and P[c] = sum_{tap,co} wd * CS
+// (partials left in red[k*C + c], k < 256/C).  256 threads; sh as laid out below.
+__device__ __forceinline__ void reduce_csum_and_p(const float* cls_part, int cls_nsplit, const float* tot, int tot_nsplit,
+                                                  float* csum_out, const bf16_t* wd, const FoldParams& f, int co32, int n,
+                                                  float* sh) {
+  const int tid = threadIdx.x;
+  const int ntap = f.ntap, C = f.ci_real, cip = f.ci_pad;
   float* csum = sh;                       // [64][co32]
   float* CS = csum + 64 * co32;           // [ntap][co32]
   float* red = CS + ntap * co32;          // [256]
-  float* Pq = red + 256;                  // [2][256]: gamma*P, gamma*r*(Q - mu P) per channel
-  float* S12 = Pq + 512;                  // [2][64]
-  unsigned* vm = reinterpret_cast<unsigned*>(S12 + 128);   // [ntap][2]: bit cls set = tap in bounds for that boundary class
+  unsigned* vm = reinterpret_cast<unsigned*>(red + 256 + 512 + 128);   // [ntap][2]: bit cls set = tap in bounds for that class
   for (int i = tid; i < ntap * 2; i += 256) vm[i] = 0u;
   for (int i = tid; i < 64 * co32; i += 256) {
-    const float* src = p.cls_part + (long)n * p.cls_nsplit * 64 * co32 + i;
+    const float* src = cls_part + (long)n * cls_nsplit * 64 * co32 + i;
     float a = 0.f;
     int s_ = 0;
-    for (; s_ + 8 <= p.cls_nsplit; s_ += 8) {   // eight loads in flight
+    for (; s_ + 8 <= cls_nsplit; s_ += 8) {   // eight loads in flight
       float g8[8];
 #pragma unroll
       for (int k = 0; k < 8; ++k) g8[k] = src[(long)(s_ + k) * 64 * co32];
 #pragma unroll
       for (int k = 0; k < 8; ++k) a += g8[k];
     }
-    for (; s_ < p.cls_nsplit; ++s_) a += src[(long)s_ * 64 * co32];
+    for (; s_ < cls_nsplit; ++s_) a += src[(long)s_ * 64 * co32];
     csum[i] = a;
-    if (p.csum_out) p.csum_out[(long)n * 64 * co32 + i] = a;
   }
   __syncthreads();
+  if (tot) {
+    for (int ch = tid; ch < co32; ch += 256) {
+      float t = 0.f;
+      for (int s_ = 0; s_ < tot_nsplit; ++s_) t += tot[((long)n * tot_nsplit + s_) * co32 + ch];
+      float bsum = 0.f;
+      for (int cls = 1; cls < 64; ++cls) bsum += csum[cls * co32 + ch];
+      csum[ch] = t - bsum;
+    }
+    __syncthreads();
+  }
+  if (csum_out)
+    for (int i = tid; i < 64 * co32; i += 256) csum_out[(long)n * 64 * co32 + i] = csum[i];
+  if (!wd) return;
   for (int i = tid; i < ntap * 64; i += 256) {
     const int tap = i >> 6, cls = i & 63;
-    if (tap_inb_class(tap, cls, p.f)) atomicOr(&vm[tap * 2 + (cls >> 5)], 1u << (cls & 31));
+    if (tap_inb_class(tap, cls, f)) atomicOr(&vm[tap * 2 + (cls >> 5)], 1u << (cls & 31));
   }
   __syncthreads();
   for (int i = tid; i < ntap * co32; i += 256) {
@@ -543,7 +558,7 @@ __global__ __launch_bounds__(256) void gn_bwd_coeffs_cls_kernel(GnClsParams p) {
   float pacc = 0.f;
   if (k < np)
     for (int tap = k; tap < ntap; tap += np) {
-      const bf16_t* wr = p.wd + ((long)tap * cip + c) * co32;
+      const bf16_t* wr = wd + ((long)tap * cip + c) * co32;
       const float* cr = CS + tap * co32;
       for (int co = 0; co < co32; co += 8) {
         const bf16x8 w8 = ld_bf16x8(wr + co);
@@ -553,6 +568,18 @@ __global__ __launch_bounds__(256) void gn_bwd_coeffs_cls_kernel(GnClsParams p) {
     }
   red[tid] = pacc;
   __syncthreads();
+}
+static size_t reduce_csum_shm(int co32, int ntap) { return sizeof(float) * ((size_t)64 * co32 + (size_t)ntap * co32 + 256 + 512 + 128 + 64); }
+
+__global__ __launch_bounds__(256) void gn_bwd_coeffs_cls_kernel(GnClsParams p) {
+  extern __shared__ __attribute__((aligned(16))) float sh[];
+  const int tid = threadIdx.x, n = blockIdx.x;
+  const int co32 = p.co32, ntap = p.f.ntap, C = p.f.ci_real, cip = p.f.ci_pad;
+  float* red = sh + 64 * co32 + ntap * co32;   // [256]
+  float* Pq = red + 256;                  // [2][256]: gamma*P, gamma*r*(Q - mu P) per channel
+  float* S12 = Pq + 512;                  // [2][64]
+  const int np = 256 / C;
+  reduce_csum_and_p(p.cls_part, p.cls_nsplit, nullptr, 0, p.csum_out, p.wd, p.f, co32, n, sh);
   float pc = 0.f, qc = 0.f, mu = 0.f, r = 0.f, gam = 0.f;
   if (p.p_out) {
     if (tid < C) {
@@ -603,7 +630,7 @@ extern "C" int rtp_gn_bwd_coeffs_cls(const float* qpart, int q_nsplit, const flo
   if (rc) return rc;
   if (ci_real > 256 || 256 % ci_real || groups > 64 || ci_real % groups || ci_real != p.f.ci_pad) return RTP_ERR_UNSUPPORTED;
   p.co32 = (g->co + 31) / 32 * 32;
-  const size_t shm = sizeof(float) * ((size_t)64 * p.co32 + (size_t)p.f.ntap * p.co32 + 256 + 512 + 128 + 64);
+  const size_t shm = reduce_csum_shm(p.co32, p.f.ntap);
   if (shm > 60 * 1024) return RTP_ERR_UNSUPPORTED;
   p.qpart = qpart; p.q_nsplit = q_nsplit; p.cls_part = cls_part; p.cls_nsplit = cls_nsplit; p.csum_out = csum_out;
   p.wd = (const bf16_t*)wd; p.mr = mr; p.gamma = gamma; p.groups = groups; p.vox = (long)g->di * g->hi * g->wi;
@@ -623,7 +650,7 @@ extern "C" int rtp_gn_bwd_p(const float* cls_part, int cls_nsplit, float* csum_o
   if (rc) return rc;
   if (ci_real > 256 || 256 % ci_real || ci_real != p.f.ci_pad) return RTP_ERR_UNSUPPORTED;
   p.co32 = (g->co + 31) / 32 * 32;
-  const size_t shm = sizeof(float) * ((size_t)64 * p.co32 + (size_t)p.f.ntap * p.co32 + 256 + 512 + 128 + 64);
+  const size_t shm = reduce_csum_shm(p.co32, p.f.ntap);
   if (shm > 60 * 1024) return RTP_ERR_UNSUPPORTED;
   p.qpart = nullptr; p.q_nsplit = 0; p.cls_part = cls_part; p.cls_nsplit = cls_nsplit; p.csum_out = csum_out;
   p.wd = (const bf16_t*)wd; p.mr = nullptr; p.gamma = nullptr; p.groups = 1; p.vox = 1; p.coeff = nullptr; p.part = nullptr;
@@ -860,6 +887,158 @@ __global__ __launch_bounds__(512) void class_sums_final_tot_kernel(const float* 
   __syncthreads();
   for (int i4 = tid; i4 < per_n / 4; i4 += 512)
     *reinterpret_cast<f32x4*>(out + (long)n * per_n + i4 * 4) = *reinterpret_cast<const f32x4*>(shc + i4 * 4);
+}
+
+// One launch for "class sums of gy, and P of the GroupNorm backward from them": the scan blocks write their partials, and
+// the LAST block of each sample to arrive (agent-scope counter) runs the reduction + P -- instead of three dependent launches
+// (scan, reduction, P) between the data gradient that produced gy and the one that needs P.
+struct ClsScanParams {
+  const bf16_t* g; int cs, co, c, D, H, W, nsplit; float* part;
+  int boundary;                     // 1: only boundary voxels are read; the interior class comes from the totals
+  const float* tot; int tot_nsplit;
+  float* csum_out; const bf16_t* wd; FoldParams f; float* p_out;
+  int* counters;                    // [n], zero before the first launch; the last block resets its sample's counter
+};
+
+__global__ __launch_bounds__(256) void class_scan_p_kernel(ClsScanParams p) {
+  extern __shared__ __attribute__((aligned(16))) float sh[];
+  __shared__ int is_last;
+  const int n = blockIdx.y, s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = p.c, D = p.D, H = p.H, W = p.W;
+  float* cls_sum = sh;
+  const long vox = (long)D * H * W;
+  for (int i = tid; i < 64 * c; i += 256) cls_sum[i] = 0.f;
+  __syncthreads();
+  const int cpv = c >> 3, chunk = lane % cpv;
+  const bf16_t* gn = p.g + (long)n * vox * p.cs + p.co;
+  const int gw = s * 4 + wave, NW = p.nsplit * 4;
+  const bool thin = !(D > 2 && H > 2 && W > 2);
+  // rows scanned in full: every row (full scan / thin volume), or the rows of the z and y faces
+  const int nfull = (!p.boundary || thin) ? D * H : 2 * H + 2 * (D - 2);
+  for (int fr = gw; fr < nfull; fr += NW) {
+    int z, y;
+    if (!p.boundary || thin) { z = fr / H; y = fr - z * H; }
+    else if (fr < 2 * H) { z = (fr < H) ? 0 : D - 1; y = fr % H; }
+    else { const int k = fr - 2 * H; z = 1 + (k >> 1); y = (k & 1) ? H - 1 : 0; }
+    const int czy = (z == 0) | ((z == D - 1) << 1) | ((y == 0) << 2) | ((y == H - 1) << 3);
+    float a_in[8], a_f[8], a_l[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a_in[j] = a_f[j] = a_l[j] = 0.f;
+    const bf16_t* row = gn + ((long)z * H + y) * W * p.cs;
+    const int items = W * cpv;
+    for (int i0 = 0; i0 < items; i0 += 64 * 4) {
+      bf16x8 t4[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int i = i0 + k * 64 + lane;
+        t4[k] = (i < items) ? ld_bf16x8(row + (long)(i / cpv) * p.cs + chunk * 8) : zero_bf16x8();
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int i = i0 + k * 64 + lane, x = i / cpv;
+        const bool first = (x == 0), last = (x == W - 1) && W > 1;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float v = bf2f(t4[k][j]);
+          if (first) a_f[j] += v; else if (last) a_l[j] += v; else a_in[j] += v;
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      for (int o = 32; o >= cpv; o >>= 1) {
+        a_in[j] += __shfl_xor(a_in[j], o, 64);
+        a_f[j] += __shfl_xor(a_f[j], o, 64);
+        a_l[j] += __shfl_xor(a_l[j], o, 64);
+      }
+    if (lane < cpv) {
+      const int cf = czy | 16 | ((W == 1) << 5);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        atomicAdd(&cls_sum[czy * c + chunk * 8 + j], a_in[j]);
+        atomicAdd(&cls_sum[cf * c + chunk * 8 + j], a_f[j]);
+        if (W > 1) atomicAdd(&cls_sum[(czy | 32) * c + chunk * 8 + j], a_l[j]);
+      }
+    }
+  }
+  if (p.boundary && !thin) {   // x faces of the interior rows: item = (row, side, chunk)
+    const int per_row = 2 * cpv, nint = (D - 2) * (H - 2);
+    const int rows_per_wave = 64 / per_row;
+    for (int r0 = gw * rows_per_wave; r0 < nint; r0 += NW * rows_per_wave) {
+      const int r = r0 + lane / per_row, side = (lane / cpv) & 1;
+      float a[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a[j] = 0.f;
+      if (r < nint) {
+        const int z = 1 + r / (H - 2), y = 1 + r % (H - 2);
+        const bf16x8 t = ld_bf16x8(gn + (((long)z * H + y) * W + (side ? W - 1 : 0)) * p.cs + chunk * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] = bf2f(t[j]);
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        for (int o = 32; o >= per_row; o >>= 1) a[j] += __shfl_xor(a[j], o, 64);
+      if (lane < per_row) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) atomicAdd(&cls_sum[(side ? 32 : 16) * c + chunk * 8 + j], a[j]);
+      }
+    }
+  }
+  __syncthreads();
+  float* o = p.part + ((long)n * p.nsplit + s) * 64 * c;
+  for (int i = tid; i < 64 * c; i += 256) o[i] = cls_sum[i];
+  // ---- the last block of this sample finishes the job (release: every wave's stores are drained by the barrier, then one
+  // lane's agent-scope read-modify-write; acquire: the same lane, then the barrier, then plain loads)
+  __syncthreads();
+  if (tid == 0) {
+    const int prev = __hip_atomic_fetch_add(p.counters + n, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    is_last = (prev == p.nsplit - 1);
+    if (is_last) __hip_atomic_store(p.counters + n, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  if (!is_last) return;
+  const bool totals = p.boundary && !thin;
+  reduce_csum_and_p(p.part, p.nsplit, totals ? p.tot : nullptr, p.tot_nsplit, p.csum_out, p.wd, p.f, c, n, sh);
+  if (p.wd && p.p_out) {
+    const int C = p.f.ci_real, np = 256 / C;
+    const float* red = sh + 64 * c + p.f.ntap * c;
+    if (tid < C) {
+      float pc = 0.f;
+      for (int kk = 0; kk < np; ++kk) pc += red[kk * C + tid];
+      p.p_out[(long)n * C + tid] = pc;
+    }
+  }
+}
+
+// Class sums of gy [n][64][c] -> csum_out, and (wd != NULL) P [n][ci] of the GroupNorm backward of the conv whose output
+// gradient gy is, in ONE launch.  tot_part != NULL: gy's per-channel totals are known (rtp_conv_dgrad_fused), only the
+// boundary voxels are scanned.  counters: device int [n], zeroed once by the caller (self-resetting).
+extern "C" int rtp_class_sums_p(const RtpAct* gy, int n, int d, int h, int w, int nsplit, float* scratch, const float* tot_part,
+                                int tot_nsplit, float* csum_out, const void* wd, const RtpConvGeom* g, int ci_real, int co_real,
+                                float* p_out, int* counters, void* stream) {
+  if (!gy || !scratch || !csum_out || !counters || nsplit < 1 || (tot_part && tot_nsplit < 1)) return RTP_ERR_SHAPE;
+  if (wd && (!g || !p_out)) return RTP_ERR_SHAPE;
+  const int c = gy->c;
+  if (c % 8 || c > 128 || (64 % (2 * (c / 8)))) return RTP_ERR_UNSUPPORTED;
+  if ((gy->cs % 8) || (gy->co % 8)) return RTP_ERR_ALIGN;
+  ClsScanParams p;
+  memset(&p, 0, sizeof(p));
+  p.f.ntap = 27;
+  if (wd) {
+    int rc = fill_fold(p.f, g, ci_real, co_real);
+    if (rc) return rc;
+    if (ci_real > 256 || 256 % ci_real || ci_real != p.f.ci_pad || (g->co + 31) / 32 * 32 != c) return RTP_ERR_UNSUPPORTED;
+  }
+  p.g = (const bf16_t*)gy->ptr; p.cs = gy->cs; p.co = gy->co; p.c = c; p.D = d; p.H = h; p.W = w; p.nsplit = nsplit;
+  p.part = scratch; p.boundary = tot_part ? 1 : 0; p.tot = tot_part; p.tot_nsplit = tot_nsplit;
+  p.csum_out = csum_out; p.wd = (const bf16_t*)wd; p.p_out = p_out; p.counters = counters;
+  const size_t shm = reduce_csum_shm(c, p.f.ntap);
+  if (shm > 60 * 1024) return RTP_ERR_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  RtpProfScope prof(RTP_FAM_NORM, s);
+  hipLaunchKernelGGL(class_scan_p_kernel, dim3(nsplit, n), dim3(256), shm, s, p);
+  RTP_CHECK_LAUNCH();
+  return RTP_OK;
 }
 
 // rtp_class_sums for a tensor whose per-channel totals are already known (tot_part fp32 [n][tot_nsplit][c], e.g. from

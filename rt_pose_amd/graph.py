@@ -323,6 +323,26 @@ class Graph:
                 self.tail_a.append(("class_reduce", scratch, split, self.n, gy.c, csum))
         return csum
 
+    def class_sums_and_p(self, y: Act, gy: View, lane, name, wd, geom, ci_real, co_real):
+        """class_sums_for(early=True) plus P = sum dxhat of the GroupNorm backward of the conv whose output gradient gy is, as
+        ONE launch on `lane`: -> (csum [n][64][c], P [n][ci])."""
+        be = self.be
+        csum = be.alloc((self.n, 64, gy.c), "f32")
+        pbuf = be.alloc((self.n, geom.ci), "f32")
+        if y.grad is gy and y.grad_cls is not None:      # partials from the grad_combine pass: reduce + P
+            split, scratch = y.grad_cls
+            self.emit_bwd(be.gn_bwd_p(scratch, split, csum, wd, geom, ci_real, co_real, pbuf), lane, [scratch, wd], [csum, pbuf],
+                          "clsp:" + name)
+            return csum, pbuf
+        tot, tsplit = None, 0
+        if y.grad is gy and y.grad_tot is not None:      # totals from the fused data gradient: boundary-only scan
+            tsplit, tot = y.grad_tot
+        split = min(32, cls_split(gy.d, gy.h))
+        scratch = be.alloc((self.n, split, 64, gy.c), "f32")
+        self.emit_bwd(be.class_sums_p(gy, split, scratch, tot, tsplit, csum, wd, geom, ci_real, co_real, pbuf), lane,
+                      [gy, tot, wd], [scratch, csum, pbuf], ("clsbp:" if tot is not None else "clsp:") + name)
+        return csum, pbuf
+
     def build_backward(self):
         assert self.train
         import os
@@ -539,7 +559,13 @@ class ConvOp:
         assert gy.c == co32, (self.name, gy.c, co32)
         ntap = ge.ks ** 3
         # ---- per-boundary-class sums of gy: bias / un-fold need them, and now P does too
-        csum = g.class_sums_for(self.y, gy, wl, self.name, early=bool(self.gn)) if (self.gn or self.bname) else None
+        import os
+        own_kernel = bool(os.environ.get("RTP_GNCOEF_KERNEL"))   # A/B: coefficients by a kernel of their own on the main chain
+        csum = pbuf = None
+        if self.gn and not own_kernel and hasattr(be, "class_sums_p"):
+            csum, pbuf = g.class_sums_and_p(self.y, gy, wl, self.name, self.wd, ge, self.ci_real, self.co_real)
+        elif self.gn or self.bname:
+            csum = g.class_sums_for(self.y, gy, wl, self.name, early=bool(self.gn))
         # ---- weight gradient (for a GroupNorm conv it now precedes the data gradient: its slabs give Q)
         S = be.wgrad_nsplit(ge) if x.cs == 32 and x.co == 0 else 0
         self.tiled_wgrad = S > 0
@@ -547,19 +573,19 @@ class ConvOp:
         gp = be.alloc((g.n, S, ntap, co32, ge.ci), "f32")
         coeff = gnq = None
         if self.gn:
-            import os
             qpart = be.alloc((g.n, S, ge.ci), "f32")
             g.emit_bwd(be.wgrad_q(gy, x, ge, S, gp, self.wd, qpart), lane, [gy, x, self.wd], [gp, qpart], "wgrad:" + self.name)
             coeff = be.alloc((g.n * ge.ci * 5,), "f32")
-            if os.environ.get("RTP_GNCOEF_KERNEL"):   # A/B: coefficients by a kernel of their own on the main chain
+            if own_kernel:
                 g.emit_bwd(be.gn_bwd_coeffs_cls(qpart, S, csum, 1, None, self.wd, self.mr, g.params[self.gn[0]], ge,
                                                 self.ci_real, self.co_real, self.groups, coeff),
                            lane, [qpart, csum, self.wd, self.mr], [coeff], "gncoef:" + self.name)
             else:
                 # P beside the weight gradient (side lane); Q and the coefficients in the data gradient's own prologue
-                pbuf = be.alloc((g.n, ge.ci), "f32")
-                g.emit_bwd(be.gn_bwd_p(csum, 1, None, self.wd, ge, self.ci_real, self.co_real, pbuf), wl, [csum, self.wd], [pbuf],
-                           "gnp:" + self.name)
+                if pbuf is None:
+                    pbuf = be.alloc((g.n, ge.ci), "f32")
+                    g.emit_bwd(be.gn_bwd_p(csum, 1, None, self.wd, ge, self.ci_real, self.co_real, pbuf), wl, [csum, self.wd], [pbuf],
+                               "gnp:" + self.name)
                 gnq = dict(qpart=qpart, q_nsplit=S, p=pbuf, mr=self.mr, gamma=g.params[self.gn[0]], groups=self.groups,
                            coeff_out=coeff)
             g.tail_a.append(("gn_param", coeff, g.n, self.ci_real, g.pgrad[self.gn[0]], g.pgrad[self.gn[1]], 0))

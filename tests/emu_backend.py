@@ -11,7 +11,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-_DT = {"bf16": torch.bfloat16, "f32": torch.float32, "i64": torch.int64, "u8": torch.uint8}
+_DT = {"bf16": torch.bfloat16, "f32": torch.float32, "i64": torch.int64, "u8": torch.uint8, "i32": torch.int32}
 
 
 def _sl(v):
@@ -382,6 +382,18 @@ class EmuBackend:
             part = coeff[n * c * 3:n * c * 5].view(n, c, 2)
             part[:, :, 0] = r * (Q - mu * P)
             part[:, :, 1] = P
+        return run
+
+    def class_sums_p(self, gy, nsplit, scratch, tot_part, tot_nsplit, csum_out, wd, geom, ci_real, co_real, p_out):
+        """rtp_class_sums_p = class sums (via the totals when given) followed by rtp_gn_bwd_p."""
+        a = (self.class_sums_boundary(gy, nsplit, scratch, tot_part, tot_nsplit, csum_out) if tot_part is not None
+             else self.class_sums(gy, nsplit, scratch, csum_out))
+        b = self.gn_bwd_p(csum_out, 1, None, wd, geom, ci_real, co_real, p_out) if wd is not None else None
+
+        def run(s):
+            a(s)
+            if b is not None:
+                b(s)
         return run
 
     def class_sums_boundary(self, gy, nsplit, scratch, tot_part, tot_nsplit, out):

@@ -669,6 +669,23 @@ def test_fused_backward_chain(hip, case):
         pe = torch.zeros(n, ci)
         EMU.gn_bwd_p(cso_e, 1, None, wd.c, geom, ci, co_real, pe)(None)
         assert rel_err(pb.cpu(), pe) < 2e-3
+    # one-launch class sums + P (last-block finalisation), with and without the totals; repeated launches reuse the counters
+    for use_tot in (True, False):
+        cs1, p1 = hip.alloc((n, 64, ci), "f32"), hip.alloc((n, ci), "f32")
+        f1 = hip.class_sums_p(dxg, 4, hip.alloc((n, 4, 64, ci), "f32"), tot if use_tot else None, ts if use_tot else 0, cs1, wd.g,
+                              geom, ci, co_real, p1) if co32 == ci else None
+        if f1 is None:
+            break
+        for rep in range(3):
+            cs1.zero_(); p1.zero_()
+            f1(hip.stream())
+            torch.cuda.synchronize()
+            assert rel_err(cs1[:, 1:].cpu(), full[:, 1:].cpu()) < 1e-6
+            assert (cs1[:, 0] - full[:, 0]).abs().max() <= 2e-4 * max(1.0, float(stored.abs().sum(1).max()))
+            pr = hip.alloc((n, ci), "f32")
+            hip.gn_bwd_p(cs1, 1, None, wd.g, geom, ci, co_real, pr)(hip.stream())
+            torch.cuda.synchronize()
+            assert rel_err(p1.cpu(), pr.cpu()) < 1e-5, "P of the one-launch path (totals=%s, rep %d)" % (use_tot, rep)
     # the same without the second pass through the emulation
     bnd_e = torch.zeros(n, 64, ci)
     tot_e = torch.zeros(n, 2, 32)
