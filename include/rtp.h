@@ -121,9 +121,14 @@ int rtp_wgrad_nsplit(const RtpConvGeom* g);
  *   qpart[n][s][ci] = sum_{tap,co} wd[tap][ci][co] * gp[n][s][tap][co][ci]
  * Summed over s this is Q = sum_v dxhat[v][ci] * x[v][ci] of GroupNorm backward (dxhat = the data gradient), obtained
  * without a pass over dxhat -- so the data gradient can run AFTER its GroupNorm coefficients are known and write the
- * finished gradient (rtp_conv_dgrad_fused). */
+ * finished gradient (rtp_conv_dgrad_fused).
+ * tg (optional, fp32 [n][27][32], ZEROED by the caller): the kernel's loader waves also sum gy over the volume and its faces /
+ * edges / corners (27 subsets: per axis all | first plane | last plane, slot (az*3+ay)*3+ax) and add them with atomics --
+ * what P, the bias gradient and the GroupNorm un-fold need, without a pass over gy. */
 int rtp_wgrad_q(const RtpAct* gy, const RtpAct* x, const RtpConvGeom* g, int nsplit, float* gp, const void* wd,
-                float* qpart, void* stream);
+                float* qpart, float* tg, void* stream);
+/* dst[0..n) = 0 (device fp32), on `stream`: one launch for every accumulate-into buffer of a step. */
+int rtp_zero_f32(float* dst, long n, void* stream);
 
 /* Per boundary-class channel sums of an output-side gradient: out fp32 [n][64][c];
  * scratch fp32 [n][nsplit][64][c] (row-split partials, reduced in fixed order).  out == NULL: partials only. */
@@ -207,7 +212,9 @@ typedef struct RtpTerm {
  * their own between the weight gradient and the data gradient). */
 typedef struct RtpGnBwd {
   const float* qpart; int q_nsplit; /* [n][q_nsplit][32] slab contractions (rtp_wgrad_q): Q = their sum                 */
-  const float* p;                   /* [n][32]  P = sum dxhat, from the class sums (rtp_gn_bwd_p)                        */
+  const float* p;                   /* [n][32]  P = sum dxhat, from the class sums (rtp_gn_bwd_p); or NULL with ...      */
+  const float* tg;                  /* [n][27][32] subset sums of gy accumulated by rtp_wgrad_q: P is computed from them  */
+  float* csum_out;                  /* (with tg) optional [n][64][32]: per-boundary-class sums of gy for rtp_wgrad_fold   */
   const float* mr;                  /* [n][groups][2] (mean, rstd) saved by rtp_fold_fwd                                 */
   const float* gamma; int groups;
   float* coeff_out;                 /* optional [n*32*5]: the coefficients + dgamma/dbeta partials, as rtp_gn_bwd_coeffs */

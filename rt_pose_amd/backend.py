@@ -124,12 +124,17 @@ class HipBackend:
     def wgrad_nsplit(self, geom):
         return self.lib.rtp_wgrad_nsplit(_geom(geom))
 
-    def wgrad_q(self, gy, x, geom, nsplit, gp, wd, qpart):
-        """rtp_wgrad_q: the tiled weight-gradient correlation + each slab's contraction with the data-gradient weights."""
+    def wgrad_q(self, gy, x, geom, nsplit, gp, wd, qpart, tg=None):
+        """rtp_wgrad_q: the tiled weight-gradient correlation + each slab's contraction with the data-gradient weights
+        (+ tg [n][27][32]: subset sums of gy, accumulated with atomics into a buffer the caller zeroes)."""
         fn, g = self.lib.rtp_wgrad_q, _geom(geom)
-        args = (_act(gy), _act(x), g, nsplit, _ptr(gp), _ptr(wd), _ptr(qpart))
-        keep = (gy, x, gp, wd, qpart)
+        args = (_act(gy), _act(x), g, nsplit, _ptr(gp), _ptr(wd), _ptr(qpart), _ptr(tg))
+        keep = (gy, x, gp, wd, qpart, tg)
         return lambda s: check(fn(*args, s), "rtp_wgrad_q") or keep and None
+
+    def zero_f32(self, t):
+        fn, args = self.lib.rtp_zero_f32, (_ptr(t), t.numel())
+        return lambda s: check(fn(*args, s), "rtp_zero_f32") or t is None
 
     def gn_bwd_coeffs_cls(self, qpart, q_nsplit, cls_part, cls_nsplit, csum_out, wd, mr, gamma, geom, ci_real, co_real, groups,
                           coeff):
@@ -153,8 +158,9 @@ class HipBackend:
         arr = self._terms(terms, False) if terms else None
         gs = None
         if gn is not None:
-            gs = _lib.RtpGnBwd(gn["qpart"].data_ptr(), gn["q_nsplit"], gn["p"].data_ptr(), gn["mr"].data_ptr(),
-                               gn["gamma"].data_ptr(), gn["groups"], gn["coeff_out"].data_ptr() if gn.get("coeff_out") is not None else None)
+            dp = lambda k: gn[k].data_ptr() if gn.get(k) is not None else None
+            gs = _lib.RtpGnBwd(dp("qpart"), gn["q_nsplit"], dp("p"), dp("tg"), dp("csum_out"), dp("mr"), dp("gamma"),
+                               gn["groups"], dp("coeff_out"))
         args = (_act(gy), _ptr(wd), _act(x), _ptr(coeff), C.byref(gs) if gs is not None else None, arr, len(terms), int(mask),
                 _act(dx), g, _ptr(tot_out))
         keep = (gy, wd, x, coeff, terms, dx, arr, tot_out, gn, gs)

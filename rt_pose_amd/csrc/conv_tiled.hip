@@ -61,6 +61,10 @@ struct TiledParams {
   // (coef_out [N*32*3] + dgamma/dbeta partials [N*32*2]) for the other consumers of the coefficients.
   const float* qpart; int q_nsplit; const float* gn_p; const float* gn_mr; const float* gn_gamma; int gn_groups; float gn_m;
   float* coef_out;
+  // ... and P itself from the 27 inclusive subset sums of gy the weight-gradient kernel accumulated (tg [N][27][32], see
+  // wgrad_tiled.hip) when gn_p is null; workgroup 0 of a sample then also writes the per-boundary-class sums csum_out
+  // [N][64][32] the deferred weight-gradient fold needs.
+  const float* tg; float* csum_out;
 };
 
 __device__ __forceinline__ int swz(int chunk, int xi) { return ((chunk + 2 * (xi >> 2)) & 3) << 3; }  // bf16 elements
@@ -146,6 +150,74 @@ __global__ __launch_bounds__(512, 2) void conv_tiled_kernel(TiledParams p) {
   }
   if constexpr (FUSE) {   // coefficient table in the (unused) class-bias region: [A0 | Bt | Ct | A1 | A2 | A3][32]
     float gq = 0.f, gp_ = 0.f, gmu = 0.f, gr = 0.f, ggam = 0.f;
+    if (p.qpart && !p.gn_p) {   // P from the subset sums: scratch in team 0's (still unused) brick region
+      float* Ts = reinterpret_cast<float*>(lds + 27 * NT * 16 * 32);   // [27][32] inclusive sums
+      float* CSs = Ts + 27 * 32;                                        // [27 taps][32 co]
+      float* Pp = CSs + 27 * 32;                                        // [16][32] partial P
+      for (int i = tid; i < 27 * 32; i += 512) Ts[i] = p.tg[(long)n * 27 * 32 + i];
+      __syncthreads();
+      // sum of gy over the voxels whose tap (kz,ky,kx) stays in bounds: per axis  all - [k == 0] first - [k == 2] last
+      for (int i = tid; i < 27 * 32; i += 512) {
+        const int tap = i >> 5, co = i & 31;
+        const int kz = tap / 9, ky = (tap / 3) % 3, kx = tap % 3;
+        float v = 0.f;
+#pragma unroll
+        for (int ia = 0; ia < 2; ++ia)
+#pragma unroll
+          for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+            for (int ic = 0; ic < 2; ++ic) {
+              if ((ia && kz == 1) || (ib && ky == 1) || (ic && kx == 1)) continue;
+              const int a = ia ? (kz == 0 ? 1 : 2) : 0, b = ib ? (ky == 0 ? 1 : 2) : 0, c = ic ? (kx == 0 ? 1 : 2) : 0;
+              const float t = Ts[((a * 3 + b) * 3 + c) * 32 + co];
+              v += ((ia + ib + ic) & 1) ? -t : t;
+            }
+        CSs[i] = v;
+      }
+      if (p.csum_out && bid == n * wgs_per_sample) {   // exclusive boundary classes for the deferred fold: 64 x 32
+        for (int i = tid; i < 64 * 32; i += 512) {
+          const int cls = i >> 5, co = i & 31;
+          const int sz = cls & 3, sy = (cls >> 2) & 3, sx = (cls >> 4) & 3;   // per axis: 0 interior, 1 first, 2 last, 3 both (empty)
+          float v = 0.f;
+          if (sz != 3 && sy != 3 && sx != 3) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+              for (int b = 0; b < 3; ++b)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                  // interior = all - first - last ; first = first ; last = last
+                  const float ma = sz == 0 ? (a == 0 ? 1.f : -1.f) : (a == sz ? 1.f : 0.f);
+                  const float mb = sy == 0 ? (b == 0 ? 1.f : -1.f) : (b == sy ? 1.f : 0.f);
+                  const float mc = sx == 0 ? (c == 0 ? 1.f : -1.f) : (c == sx ? 1.f : 0.f);
+                  v += ma * mb * mc * Ts[((a * 3 + b) * 3 + c) * 32 + co];
+                }
+          }
+          p.csum_out[(long)n * 64 * 32 + i] = v;
+        }
+      }
+      __syncthreads();
+      {
+        const int c = tid & 31, k = tid >> 5;   // 16 tap groups
+        float pa = 0.f;
+        for (int tap = k; tap < 27; tap += 16) {
+          const bf16_t* wr = p.w + ((long)tap * 32 + c) * 32;
+#pragma unroll
+          for (int co = 0; co < 32; co += 8) {
+            const bf16x8 w8 = ld_bf16x8(wr + co);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pa += bf2f(w8[j]) * CSs[tap * 32 + co + j];
+          }
+        }
+        Pp[k * 32 + c] = pa;
+      }
+      __syncthreads();
+      if (tid < 32) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) gp_ += Pp[k * 32 + tid];
+      }
+      __syncthreads();   // the brick region is staged into from here on
+    }
     if (p.qpart) {   // workgroup-uniform
       float* scr = bL + 448;   // [256] partial Q, then [2][32] group-sum operands at +256
       if (tid < 256) {
@@ -159,7 +231,7 @@ __global__ __launch_bounds__(512, 2) void conv_tiled_kernel(TiledParams p) {
         const int cg = 32 / p.gn_groups, g = tid / cg;
 #pragma unroll
         for (int k = 0; k < 8; ++k) gq += scr[k * 32 + tid];
-        gp_ = p.gn_p[(long)n * 32 + tid];
+        if (p.gn_p) gp_ = p.gn_p[(long)n * 32 + tid];
         gmu = p.gn_mr[((long)n * p.gn_groups + g) * 2];
         gr = p.gn_mr[((long)n * p.gn_groups + g) * 2 + 1];
         ggam = p.gn_gamma[tid];
@@ -589,6 +661,7 @@ int rtp_conv_tiled_try(const RtpAct* x, const void* wf, int w_per_sample, const 
   p.dbg = dbg;
   p.nextra = 0; p.mask = 0; p.tot_out = nullptr;
   p.qpart = nullptr; p.q_nsplit = 0; p.gn_p = p.gn_mr = p.gn_gamma = nullptr; p.gn_groups = 1; p.gn_m = 1.f; p.coef_out = nullptr;
+  p.tg = nullptr; p.csum_out = nullptr;
   for (int e = 0; e < 4; ++e) p.coef[e] = nullptr;
   for (int e = 0; e < 3; ++e) { p.ex[e] = nullptr; p.ex_cs[e] = p.ex_co[e] = 0; }
   if (fuse) {
@@ -597,7 +670,8 @@ int rtp_conv_tiled_try(const RtpAct* x, const void* wf, int w_per_sample, const 
     p.coef[0] = fuse->coef[0];
     if (fuse->gn) {
       const RtpGnBwd* q = fuse->gn;
-      if (!q->qpart || !q->p || !q->mr || !q->gamma || q->q_nsplit < 1 || q->groups < 1 || 32 % q->groups) return RTP_ERR_SHAPE;
+      if (!q->qpart || (!q->p && !q->tg) || !q->mr || !q->gamma || q->q_nsplit < 1 || q->groups < 1 || 32 % q->groups) return RTP_ERR_SHAPE;
+      p.tg = q->p ? nullptr : q->tg; p.csum_out = q->p ? nullptr : q->csum_out;
       p.qpart = q->qpart; p.q_nsplit = q->q_nsplit; p.gn_p = q->p; p.gn_mr = q->mr; p.gn_gamma = q->gamma;
       p.gn_groups = q->groups; p.gn_m = (float)(32 / q->groups) * (float)((long)g->di * g->hi * g->wi);
       p.coef_out = q->coeff_out;

@@ -81,3 +81,18 @@ extern "C" int rtp_adam_step(float* p, const float* g, float* m, float* v, long 
   RTP_CHECK_LAUNCH();
   return RTP_OK;
 }
+
+__global__ void zero_f32_kernel(float* dst, long n) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) dst[i] = 0.f;
+}
+
+extern "C" int rtp_zero_f32(float* dst, long n, void* stream) {
+  if (!dst || n < 1) return RTP_ERR_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  RtpProfScope prof(RTP_FAM_OPTIM, s);
+  long blocks = (n + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(zero_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, s, dst, n);
+  RTP_CHECK_LAUNCH();
+  return RTP_OK;
+}

@@ -150,17 +150,17 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradParams p) {
 }
 
 int rtp_wgrad_tiled_try(const RtpAct* gy, const RtpAct* x, const RtpConvGeom* g, int nsplit, float* gp, hipStream_t s,
-                        const void* wd, float* qpart);
+                        const void* wd, float* qpart, float* tg);
 
 // rtp_wgrad on the LDS-tiled kernel that also contracts every slab with the data-gradient weights (GroupNorm backward's Q
 // without a pass over dxhat).  Only the tiled kernel's geometries (rtp_wgrad_nsplit(g) > 0, nsplit equal to it).
 extern "C" int rtp_wgrad_q(const RtpAct* gy, const RtpAct* x, const RtpConvGeom* g, int nsplit, float* gp, const void* wd,
-                           float* qpart, void* stream) {
+                           float* qpart, float* tg, void* stream) {
   if (!gy || !x || !g || !gp || !wd || !qpart || nsplit < 1) return RTP_ERR_SHAPE;
   if ((gy->cs % 8) || (gy->co % 8) || (x->cs % 8) || (x->co % 8)) return RTP_ERR_ALIGN;
   if (gy->c < (g->co + 31) / 32 * 32 || x->c < g->ci) return RTP_ERR_SHAPE;
   if (rtp_wgrad_nsplit(g) != nsplit) return RTP_ERR_UNSUPPORTED;
-  const int rc = rtp_wgrad_tiled_try(gy, x, g, nsplit, gp, (hipStream_t)stream, wd, qpart);
+  const int rc = rtp_wgrad_tiled_try(gy, x, g, nsplit, gp, (hipStream_t)stream, wd, qpart, tg);
   return rc > 0 ? RTP_ERR_UNSUPPORTED : rc;
 }
 
@@ -171,7 +171,7 @@ extern "C" int rtp_wgrad(const RtpAct* gy, const RtpAct* x, const RtpConvGeom* g
   if ((gy->cs % 8) || (gy->co % 8) || (x->cs % 8) || (x->co % 8)) return RTP_ERR_ALIGN;
   if (gy->c < (g->co + 31) / 32 * 32 || x->c < g->ci) return RTP_ERR_SHAPE;
   {
-    const int rc = rtp_wgrad_tiled_try(gy, x, g, nsplit, gp, (hipStream_t)stream, nullptr, nullptr);
+    const int rc = rtp_wgrad_tiled_try(gy, x, g, nsplit, gp, (hipStream_t)stream, nullptr, nullptr, nullptr);
     if (rc <= 0) return rc;
   }
   WgradParams p;

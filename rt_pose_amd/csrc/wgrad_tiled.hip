@@ -35,6 +35,11 @@ struct WgTiledParams {
   // optional: contract this workgroup's slab with the data-gradient weights wd[tap][ci][co] (bf16) -> qpart[n][wg][ci] =
   // sum_{tap,co} wd * slab, the slab's share of Q = sum_v dxhat*x of GroupNorm backward (norm_fold.hip, gn_bwd_coeffs_cls)
   const bf16_t* wd; float* qpart;
+  // optional: sums of gy over the volume and its faces / edges / corners (27 "inclusive" subsets: per axis all | first plane
+  // | last plane; slot = (az*3 + ay)*3 + ax), accumulated by the otherwise idle LOADER waves from the staged gy bricks and
+  // added with fp32 atomics to tg[N][27][32] (zeroed by the caller).  They give P = sum dxhat of GroupNorm backward, the
+  // bias gradient and the un-fold term without any pass over gy (conv_tiled.hip, fused data gradient).
+  float* tg;
 };
 
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
@@ -148,6 +153,14 @@ __global__ __launch_bounds__(512, 2) void wgrad_tiled_kernel(WgTiledParams p) {
     }
     const bf16_t* xn = p.x + vox_n * p.x_cs + p.x_co;
     const bf16_t* gn = p.gy + vox_n * p.g_cs + p.g_co;
+    // class-sum bookkeeping: thread = (x segment of 4 voxels, 8-channel chunk, brick row)
+    const int seg = ttid & 7, c8 = (ttid >> 3) & 3, rr = ttid >> 5;
+    float call[8], cedge[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) call[j] = cedge[j] = 0.f;
+    float* T = reinterpret_cast<float*>(lds + 2 * BUF);   // [27][32], only allocated when p.tg
+    if (p.tg)
+      for (int i = ttid; i < 27 * 32; i += 256) T[i] = 0.f;   // (first atomics come after the first barrier)
     for (int k = 0; k <= my_tiles; ++k) {
       if (k < my_tiles) {
         bf16_t* xL = lds + (k & 1) * BUF;
@@ -168,13 +181,68 @@ __global__ __launch_bounds__(512, 2) void wgrad_tiled_kernel(WgTiledParams p) {
           }
         }
       }
+      if (p.tg && k >= 1) {
+        // sums of gy brick k-1 (landed before the previous barrier; the consumers are reading the same buffer now)
+        const int tile = t_begin + k - 1;
+        const int tz = tile % p.tiles_z, tx = (tile / p.tiles_z) % p.tiles_x, ty = tile / (p.tiles_z * p.tiles_x);
+        const int z = tz * TZ + (rr >> 2), y = ty * TY + (rr & 3), x0 = tx * TX;
+        const bf16_t* gb = lds + ((k - 1) & 1) * BUF + HALO_VOX * 32 + (rr * TX + seg * 4) * 32 + (((c8 + seg) & 3) << 3);
+        bf16x8 v4[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v4[j] = ld_bf16x8(gb + j * 32);
+        float sv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sv[j] = (bf2f(v4[0][j]) + bf2f(v4[1][j])) + (bf2f(v4[2][j]) + bf2f(v4[3][j]));
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {   // fold the 8 x segments (lanes seg = lane & 7): every lane ends with the row sum
+          sv[j] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sv[j]), 0xB1, 0xf, 0xf, true));
+          sv[j] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sv[j]), 0x4E, 0xf, 0xf, true));
+          sv[j] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sv[j]), 0x141, 0xf, 0xf, true));
+        }
+        const int bxl = p.W - 1 - x0;   // brick position of the volume's last x (inside this brick iff 0 <= bxl < TX)
+        const int ax = (seg == 0 && x0 == 0) ? 1 : ((bxl >= 0 && bxl < TX && seg == (bxl >> 2)) ? 2 : 0);
+        float ev[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ev[j] = (ax == 1) ? bf2f(v4[0][j]) : (ax == 2) ? bf2f(v4[3][j]) : 0.f;   // W % 4 == 0: bxl & 3 == 3
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { call[j] += sv[j]; cedge[j] += ev[j]; }
+        const int az = (z == 0) ? 1 : (z == p.D - 1) ? 2 : 0, ay = (y == 0) ? 1 : (y == p.H - 1) ? 2 : 0;
+        if (az | ay) {   // a row of a z / y face: also the face (and edge) subsets, straight into the LDS table
+#pragma unroll
+          for (int cmb = 0; cmb < 3; ++cmb) {
+            const int a = (cmb == 1) ? 0 : az, b = (cmb == 0) ? 0 : ay;   // (az,0), (0,ay), (az,ay)
+            const bool on = (cmb == 0) ? (az != 0) : (cmb == 1) ? (ay != 0) : (az != 0 && ay != 0);
+            if (on) {
+              float* ts = T + ((a * 3 + b) * 3) * 32 + c8 * 8;
+              if (seg == 0) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) atomicAdd(ts + j, sv[j]);
+              }
+              if (ax) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) atomicAdd(ts + ax * 32 + j, ev[j]);
+              }
+            }
+          }
+        }
+      }
       __syncthreads();  // (drains the DMA: hipcc emits vmcnt(0) before the barrier)
     }
-    return;
+    if (p.tg) {   // whole-volume subsets (all, all, all | first x | last x) kept in registers until now
+      if (seg == 0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) atomicAdd(T + c8 * 8 + j, call[j]);
+      }
+      const int axr = (seg == 0) ? 1 : 2;   // a thread only ever held one edge role (first x: seg 0; last x: seg 3 or 7)
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (cedge[j] != 0.f) atomicAdd(T + axr * 32 + c8 * 8 + j, cedge[j]);
+    }
   }
 
   // ---- consumers: per-lane fragment addresses for both buffers, accumulators live for the whole kernel
   f32x4 acc[7][2][2];
+  if (!loader) {
 #pragma unroll
   for (int t = 0; t < 7; ++t)
 #pragma unroll
@@ -218,9 +286,20 @@ __global__ __launch_bounds__(512, 2) void wgrad_tiled_kernel(WgTiledParams p) {
       }
     __syncthreads();  // brick k consumed, brick k+1 staged
   }
+  }  // !loader
+  __syncthreads();   // every brick consumed; the loaders' class-sum table is complete
 
-  // ---- one fp32 slab [27][32][32] per workgroup; D[row = co][col = ci]: lane holds rows 4q..4q+3, column lane&15
   const int q = lane >> 4, i = lane & 15;
+  if (loader) {
+    if (p.tg) {
+      const float* T = reinterpret_cast<const float*>(lds + 2 * BUF);
+      for (int k = ttid; k < 27 * 32; k += 256) {
+        const float v = T[k];
+        if (v != 0.f) atomicAdd(p.tg + (long)n * 27 * 32 + k, v);
+      }
+    }
+  } else {
+  // ---- one fp32 slab [27][32][32] per workgroup; D[row = co][col = ci]: lane holds rows 4q..4q+3, column lane&15
   float* out = p.gp + ((long)n * p.wgs_per_sample + wg) * 27 * 32 * 32;
 #pragma unroll
   for (int t = 0; t < 7; ++t) {
@@ -234,9 +313,11 @@ __global__ __launch_bounds__(512, 2) void wgrad_tiled_kernel(WgTiledParams p) {
           for (int r = 0; r < 4; ++r)
             out[(tap * 32 + a * 16 + q * 4 + r) * 32 + b * 16 + i] = acc[t][a][b][r];
   }
-  if (p.qpart) {
+  }
+  if (p.qpart) {   // workgroup-uniform: the two barriers below are reached by all eight waves
     // lane holds slab[tap][co = a*16 + 4q + r][ci = b*16 + i]; wd[tap][ci][co..co+3] is one 8-byte read
     float qs[2] = {0.f, 0.f};
+    if (!loader) {
 #pragma unroll
     for (int t = 0; t < 7; ++t) {
       const int tap = tw + 4 * t;
@@ -255,13 +336,12 @@ __global__ __launch_bounds__(512, 2) void wgrad_tiled_kernel(WgTiledParams p) {
       qs[b] += __shfl_xor(qs[b], 16, 64);
       qs[b] += __shfl_xor(qs[b], 32, 64);
     }
-    // fold the four consumer waves in fixed order through LDS (the staging buffers are idle now; the loader waves have
-    // exited, which the hardware barrier accounts for)
+    }
+    // fold the four consumer waves in fixed order through LDS (the staging buffers are idle now)
     float* red = reinterpret_cast<float*>(lds);
+    if (!loader && q == 0) { red[tw * 32 + i] = qs[0]; red[tw * 32 + 16 + i] = qs[1]; }
     __syncthreads();
-    if (q == 0) { red[tw * 32 + i] = qs[0]; red[tw * 32 + 16 + i] = qs[1]; }
-    __syncthreads();
-    if (tw == 0 && lane < 32)
+    if (!loader && tw == 0 && lane < 32)
       p.qpart[((long)n * p.wgs_per_sample + wg) * 32 + lane] = (red[lane] + red[32 + lane]) + (red[64 + lane] + red[96 + lane]);
   }
 }
@@ -287,7 +367,7 @@ static int wg_tiled_wgs(const RtpConvGeom* g) {
 extern "C" int rtp_wgrad_nsplit(const RtpConvGeom* g) { return (g && wg_tiled_applicable(g)) ? wg_tiled_wgs(g) : 0; }
 
 int rtp_wgrad_tiled_try(const RtpAct* gy, const RtpAct* x, const RtpConvGeom* g, int nsplit, float* gp, hipStream_t s,
-                        const void* wd, float* qpart) {
+                        const void* wd, float* qpart, float* tg) {
   if (!wg_tiled_applicable(g)) return 1;
   if (x->cs % 32 || x->co % 8 || nsplit != wg_tiled_wgs(g)) return 1;   // x may be a 32-channel slice of a wider tensor
   WgTiledParams p;
@@ -299,11 +379,16 @@ int rtp_wgrad_tiled_try(const RtpAct* gy, const RtpAct* x, const RtpConvGeom* g,
   p.wgs_per_sample = nsplit;
   static const int dbg = getenv("RTP_TILED_DBG") ? atoi(getenv("RTP_TILED_DBG")) : 0;
   p.dbg = dbg;
-  p.wd = (const bf16_t*)wd; p.qpart = wd ? qpart : nullptr;
-  const size_t shm = sizeof(bf16_t) * 2 * (size_t)(HALO_VOX + BRICK_VOX) * 32;
+  p.wd = (const bf16_t*)wd; p.qpart = wd ? qpart : nullptr; p.tg = tg;
+  const size_t shm_base = sizeof(bf16_t) * 2 * (size_t)(HALO_VOX + BRICK_VOX) * 32;
+  const size_t shm = shm_base + (tg ? 27 * 32 * sizeof(float) : 0);
   RtpProfScope prof(RTP_FAM_WGRAD_TILED, s);
   static bool attr = false;
-  if (!attr) { (void)hipFuncSetAttribute((const void*)wgrad_tiled_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); attr = true; }
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)wgrad_tiled_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)(shm_base + 27 * 32 * sizeof(float)));
+    attr = true;
+  }
   hipLaunchKernelGGL(wgrad_tiled_kernel, dim3(p.N * nsplit), dim3(512), shm, s, p);
   RTP_CHECK_LAUNCH();
   return RTP_OK;

@@ -323,6 +323,20 @@ class Graph:
                 self.tail_a.append(("class_reduce", scratch, split, self.n, gy.c, csum))
         return csum
 
+    def zero_alloc(self, shape):
+        """fp32 buffer that kernels ACCUMULATE into with atomics: carved from one arena that a single launch at the start of the
+        backward sweep zeroes (build_backward)."""
+        import math
+        size = int(math.prod(shape))
+        if getattr(self, "_zero_arena", None) is None:
+            self._zero_arena = self.be.alloc((64 * self.n * 27 * 32,), "f32")
+            self._zero_used, self._zero_views = 0, []
+        assert self._zero_used + size <= self._zero_arena.numel(), "zero arena exhausted"
+        v = self._zero_arena[self._zero_used:self._zero_used + size].view(shape)
+        self._zero_used += (size + 63) // 64 * 64
+        self._zero_views.append(v)
+        return v
+
     def class_sums_and_p(self, y: Act, gy: View, lane, name, wd, geom, ci_real, co_real):
         """class_sums_for(early=True) plus P = sum dxhat of the GroupNorm backward of the conv whose output gradient gy is, as
         ONE launch on `lane`: -> (csum [n][64][c], P [n][ci])."""
@@ -362,6 +376,8 @@ class Graph:
             if len(self.tail_b) >= self.tail_batch:   # optional early flush on the weight-gradient lane
                 self.emit_tail(L_WG_LOW)
         self.emit_tail(L_FULL)
+        if getattr(self, "_zero_arena", None) is not None and self._zero_used:
+            self.bwd.insert(0, Launch(self.be.zero_f32(self._zero_arena[:self._zero_used]), L_FULL, [], self._zero_views, "zero"))
 
     def emit_tail(self, lane=L_FULL):
         """The deferred items as two launches (stage a: class reductions + GroupNorm parameter sums; stage b: folds)."""
@@ -561,8 +577,14 @@ class ConvOp:
         # ---- per-boundary-class sums of gy: bias / un-fold need them, and now P does too
         import os
         own_kernel = bool(os.environ.get("RTP_GNCOEF_KERNEL"))   # A/B: coefficients by a kernel of their own on the main chain
-        csum = pbuf = None
-        if self.gn and not own_kernel and hasattr(be, "class_sums_p"):
+        # default: the weight-gradient kernel's loader waves sum gy over the volume / faces / edges / corners (tg), from which
+        # the data gradient's prologue derives P and the class sums -- no pass over gy, no launch between the two kernels
+        from_wgrad = bool(self.gn) and not own_kernel and not os.environ.get("RTP_CLS_KERNELS")
+        csum = pbuf = tg = None
+        if from_wgrad:
+            tg = g.zero_alloc((g.n, 27, 32))
+            csum = be.alloc((g.n, 64, gy.c), "f32")
+        elif self.gn and not own_kernel and hasattr(be, "class_sums_p"):
             csum, pbuf = g.class_sums_and_p(self.y, gy, wl, self.name, self.wd, ge, self.ci_real, self.co_real)
         elif self.gn or self.bname:
             csum = g.class_sums_for(self.y, gy, wl, self.name, early=bool(self.gn))
@@ -574,7 +596,7 @@ class ConvOp:
         coeff = gnq = None
         if self.gn:
             qpart = be.alloc((g.n, S, ge.ci), "f32")
-            g.emit_bwd(be.wgrad_q(gy, x, ge, S, gp, self.wd, qpart), lane, [gy, x, self.wd], [gp, qpart], "wgrad:" + self.name)
+            g.emit_bwd(be.wgrad_q(gy, x, ge, S, gp, self.wd, qpart, tg), lane, [gy, x, self.wd], [gp, qpart, tg], "wgrad:" + self.name)
             coeff = be.alloc((g.n * ge.ci * 5,), "f32")
             if own_kernel:
                 g.emit_bwd(be.gn_bwd_coeffs_cls(qpart, S, csum, 1, None, self.wd, self.mr, g.params[self.gn[0]], ge,
@@ -582,12 +604,12 @@ class ConvOp:
                            lane, [qpart, csum, self.wd, self.mr], [coeff], "gncoef:" + self.name)
             else:
                 # P beside the weight gradient (side lane); Q and the coefficients in the data gradient's own prologue
-                if pbuf is None:
+                if pbuf is None and tg is None:
                     pbuf = be.alloc((g.n, ge.ci), "f32")
                     g.emit_bwd(be.gn_bwd_p(csum, 1, None, self.wd, ge, self.ci_real, self.co_real, pbuf), wl, [csum, self.wd], [pbuf],
                                "gnp:" + self.name)
-                gnq = dict(qpart=qpart, q_nsplit=S, p=pbuf, mr=self.mr, gamma=g.params[self.gn[0]], groups=self.groups,
-                           coeff_out=coeff)
+                gnq = dict(qpart=qpart, q_nsplit=S, p=pbuf, tg=tg, csum_out=csum if tg is not None else None, mr=self.mr,
+                           gamma=g.params[self.gn[0]], groups=self.groups, coeff_out=coeff)
             g.tail_a.append(("gn_param", coeff, g.n, self.ci_real, g.pgrad[self.gn[0]], g.pgrad[self.gn[1]], 0))
         else:
             g.emit_bwd(be.wgrad(gy, x, ge, S, gp), wl, [gy, x], [gp], "wgrad:" + self.name)
@@ -605,15 +627,19 @@ class ConvOp:
         reads = [gy, self.wd, x, coeff] + [v for v, _ in terms] + [cf for _, cf in terms]
         # x's producer will want the per-boundary-class sums of this gradient: emit the per-channel totals here
         tot, prod = None, x.producer
-        if isinstance(prod, (ConvOp, SplitConvOp)) and (prod.gn or prod.bname) and hasattr(be, "class_sums_boundary"):
+        import os
+        prod_from_wgrad = (isinstance(prod, ConvOp) and prod.gn and prod.tiled_bwd and g.fused_dgrad
+                           and not os.environ.get("RTP_GNCOEF_KERNEL") and not os.environ.get("RTP_CLS_KERNELS"))
+        if (isinstance(prod, (ConvOp, SplitConvOp)) and (prod.gn or prod.bname) and hasattr(be, "class_sums_boundary")
+                and not prod_from_wgrad):
             ts = be.conv_stats_nsplit(gy, ge, True)
             if ts > 0:
                 tot = be.alloc((g.n, ts, 32), "f32")
                 x.grad_tot = (ts, tot)
         if gnq is not None:
-            reads += [gnq["qpart"], gnq["p"], self.mr]
-            g.emit_bwd(be.conv_dgrad_fused(gy, self.wd, x, None, terms, x.relu, dx, ge, tot, gnq), lane, reads, [dx_buf, tot, coeff],
-                       "dgrad:" + self.name)
+            reads += [gnq["qpart"], gnq["p"], gnq["tg"], self.mr]
+            g.emit_bwd(be.conv_dgrad_fused(gy, self.wd, x, None, terms, x.relu, dx, ge, tot, gnq), lane, reads,
+                       [dx_buf, tot, coeff, gnq["csum_out"]], "dgrad:" + self.name)
         else:
             g.emit_bwd(be.conv_dgrad_fused(gy, self.wd, x, coeff, terms, x.relu, dx, ge, tot), lane, reads, [dx_buf, tot],
                        "dgrad:" + self.name)

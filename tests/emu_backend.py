@@ -345,13 +345,26 @@ class EmuBackend:
                 dbeta.copy_(db)
         return run
 
-    def wgrad_q(self, gy, x, geom, nsplit, gp, wd, qpart):
-        """rtp_wgrad_q: the correlation plus each slab's contraction with the data-gradient weights wd[tap][ci][cok]."""
+    def wgrad_q(self, gy, x, geom, nsplit, gp, wd, qpart, tg=None):
+        """rtp_wgrad_q: the correlation plus each slab's contraction with the data-gradient weights wd[tap][ci][cok], plus
+        (tg, ACCUMULATED into) the 27 inclusive subset sums of gy: per axis all | first plane | last plane."""
         base = self.wgrad(gy, x, geom, nsplit, gp)
 
         def run(s):
             base(s)
             qpart.copy_(torch.einsum("tic,nstci->nsi", wd.float(), gp))
+            if tg is not None:
+                gv = _sl(gy)   # [n,d,h,w,c]
+                sel = lambda t, dim, a: t if a == 0 else t.narrow(dim, 0 if a == 1 else t.shape[dim] - 1, 1)
+                for a in range(3):
+                    for b in range(3):
+                        for c in range(3):
+                            tg.view(gy.n, 27, -1)[:, (a * 3 + b) * 3 + c, :gy.c] += sel(sel(sel(gv, 1, a), 2, b), 3, c).sum((1, 2, 3))
+        return run
+
+    def zero_f32(self, t):
+        def run(s):
+            t.zero_()
         return run
 
     def gn_bwd_coeffs_cls(self, qpart, q_nsplit, cls_part, cls_nsplit, csum_out, wd, mr, gamma, geom, ci_real, co_real, groups,
@@ -431,7 +444,22 @@ class EmuBackend:
                 n, c, groups = g.n, g.ci, gn["groups"]
                 cg = c // groups
                 Q = gn["qpart"].view(n, gn["q_nsplit"], -1).sum(1)[:, :c]
-                P = gn["p"].view(n, -1)[:, :c]
+                if gn.get("p") is not None:
+                    P = gn["p"].view(n, -1)[:, :c]
+                else:   # P (and the exclusive boundary-class sums) from the inclusive subset sums
+                    T = gn["tg"].view(n, 3, 3, 3, -1)
+                    M = torch.tensor([[1.0, -1.0, -1.0], [0.0, 1.0, 0.0], [0.0, 0.0, 1.0]])   # state (int, first, last) x subset (all, first, last)
+                    E = torch.tensor([[1.0, -1.0, 0.0], [1.0, 0.0, 0.0], [1.0, 0.0, -1.0]])   # tap k in {0,1,2} x subset: in-bounds voxels
+                    CS = torch.einsum("za,yb,xc,nabck->nzyxk", E, E, E, T).reshape(n, 27, -1)
+                    P = torch.einsum("tic,ntc->ni", wd.float(), CS)[:, :c]
+                    if gn.get("csum_out") is not None:
+                        ex = torch.einsum("za,yb,xc,nabck->nzyxk", M, M, M, T)   # [n, sz, sy, sx, co]
+                        out = gn["csum_out"].view(n, 64, -1)
+                        out.zero_()
+                        for sz in range(3):
+                            for sy in range(3):
+                                for sx in range(3):
+                                    out[:, sz | (sy << 2) | (sx << 4)] = ex[:, sz, sy, sx]
                 mu = gn["mr"][:, :, 0].repeat_interleave(cg, 1)
                 r = gn["mr"][:, :, 1].repeat_interleave(cg, 1)
                 gam = gn["gamma"].detach().float()

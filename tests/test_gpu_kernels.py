@@ -669,6 +669,28 @@ def test_fused_backward_chain(hip, case):
         pe = torch.zeros(n, ci)
         EMU.gn_bwd_p(cso_e, 1, None, wd.c, geom, ci, co_real, pe)(None)
         assert rel_err(pb.cpu(), pe) < 2e-3
+    if has_gn:
+        # subset sums of gy from the weight-gradient kernel's loader waves -> P, class sums and coefficients in the data
+        # gradient's prologue: no kernel between the two
+        tg = hip.alloc((n, 27, 32), "f32")
+        tg_e = torch.zeros(n, 27, 32)
+        slab3 = hip.alloc((n, S, 27, co32, ci), "f32")
+        qp3 = hip.alloc((n, S, ci), "f32")
+        for rep in range(2):
+            tg.zero_()
+            hip.wgrad_q(gyg, xg, geom, S, slab3, wd.g, qp3, tg)(hip.stream())
+            torch.cuda.synchronize()
+            assert torch.equal(slab3, slab.g) and torch.equal(qp3, qp.g), "the subset sums do not disturb the slabs"
+        EMU.wgrad_q(gyc, xc, geom, Sc, torch.zeros_like(slab_e), wd.c, torch.zeros_like(qp_e), tg_e)(None)
+        assert rel_err(tg.cpu(), tg_e) < 1e-5, "inclusive subset sums of gy"
+        cf3, cs3 = hip.alloc((n * ci * 5,), "f32"), hip.alloc((n, 64, co32), "f32")
+        dx3p, dx3c, dx3g = views(hip, torch.zeros(n, d, h, w, ci, dtype=torch.bfloat16), n, d, h, w)
+        gn3 = dict(qpart=qp.g, q_nsplit=S, p=None, tg=tg, csum_out=cs3, mr=mr.g, gamma=gam.g, groups=groups, coeff_out=cf3)
+        hip.conv_dgrad_fused(gyg, wd.g, xg, None, terms_g, mask, dx3g, geom, None, gn3)(hip.stream())
+        torch.cuda.synchronize()
+        assert rel_err(cs3.cpu(), cso.g.cpu()) < 1e-4, "class sums rebuilt from the subset sums"
+        assert rel_err(cf3.cpu(), cf.g.cpu()) < 1e-4, "coefficients from the subset sums"
+        assert rel_err(dx3g.buf.float().cpu(), dxg.buf.float().cpu()) < 1e-3
     # one-launch class sums + P (last-block finalisation), with and without the totals; repeated launches reuse the counters
     for use_tot in (True, False):
         cs1, p1 = hip.alloc((n, 64, ci), "f32"), hip.alloc((n, ci), "f32")
