@@ -130,7 +130,12 @@ def load():
                            "rt_pose_amd has no CPU fallback." % LIB_PATH)
         lib = C.CDLL(LIB_PATH)
         for name, argtypes in PROTOTYPES.items():
-            fn = getattr(lib, name)  # AttributeError if the symbol is missing
+            try:
+                fn = getattr(lib, name)  # AttributeError if the symbol is missing
+            except AttributeError:
+                if os.environ.get("RTP_LIB"):   # A/B runs against an older build: its missing entry points simply stay unbound
+                    continue
+                raise
             fn.argtypes = argtypes
             fn.restype = _RESTYPE.get(name, C.c_int)
         _lib = lib

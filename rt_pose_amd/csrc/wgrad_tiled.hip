@@ -109,7 +109,9 @@ __device__ __forceinline__ void wg_brick(const LaneAddr& la, f32x4 (&acc)[7][2][
   wg_sched<0, 56>();
 }
 
-__global__ __launch_bounds__(512, 2) void wgrad_tiled_kernel(WgTiledParams p) {
+// (explicit occupancy: with only __launch_bounds__ the scheduler aimed at 3 waves/SIMD once the loader path grew, and squeezed the
+// consumers' software pipeline into 168 VGPRs: +9 us per launch)
+__global__ __attribute__((amdgpu_flat_work_group_size(512, 512), amdgpu_waves_per_eu(2, 2))) void wgrad_tiled_kernel(WgTiledParams p) {
   extern __shared__ __attribute__((aligned(16))) bf16_t lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const bool loader = __builtin_amdgcn_readfirstlane(wave >> 2) == 1;  // waves 4-7 stage, waves 0-3 run the MFMAs
@@ -158,9 +160,14 @@ __global__ __launch_bounds__(512, 2) void wgrad_tiled_kernel(WgTiledParams p) {
     float call[8], cedge[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) call[j] = cedge[j] = 0.f;
-    float* T = reinterpret_cast<float*>(lds + 2 * BUF);   // [27][32], only allocated when p.tg
-    if (p.tg)
+    // [27][32] subset table in LDS (only allocated when p.tg) + a counter: the last loader wave to finish flushes the table to
+    // global memory with atomics and exits -- nobody waits for those atomics (waited for at a barrier they cost +70 us)
+    float* T = reinterpret_cast<float*>(lds + 2 * BUF);
+    int* tcnt = reinterpret_cast<int*>(T + 27 * 32);
+    if (p.tg) {
       for (int i = ttid; i < 27 * 32; i += 256) T[i] = 0.f;   // (first atomics come after the first barrier)
+      if (ttid == 0) *tcnt = 0;
+    }
     for (int k = 0; k <= my_tiles; ++k) {
       if (k < my_tiles) {
         bf16_t* xL = lds + (k & 1) * BUF;
@@ -193,12 +200,6 @@ __global__ __launch_bounds__(512, 2) void wgrad_tiled_kernel(WgTiledParams p) {
         float sv[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) sv[j] = (bf2f(v4[0][j]) + bf2f(v4[1][j])) + (bf2f(v4[2][j]) + bf2f(v4[3][j]));
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {   // fold the 8 x segments (lanes seg = lane & 7): every lane ends with the row sum
-          sv[j] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sv[j]), 0xB1, 0xf, 0xf, true));
-          sv[j] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sv[j]), 0x4E, 0xf, 0xf, true));
-          sv[j] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sv[j]), 0x141, 0xf, 0xf, true));
-        }
         const int bxl = p.W - 1 - x0;   // brick position of the volume's last x (inside this brick iff 0 <= bxl < TX)
         const int ax = (seg == 0 && x0 == 0) ? 1 : ((bxl >= 0 && bxl < TX && seg == (bxl >> 2)) ? 2 : 0);
         float ev[8];
@@ -207,7 +208,13 @@ __global__ __launch_bounds__(512, 2) void wgrad_tiled_kernel(WgTiledParams p) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) { call[j] += sv[j]; cedge[j] += ev[j]; }
         const int az = (z == 0) ? 1 : (z == p.D - 1) ? 2 : 0, ay = (y == 0) ? 1 : (y == p.H - 1) ? 2 : 0;
-        if (az | ay) {   // a row of a z / y face: also the face (and edge) subsets, straight into the LDS table
+        if (az | ay) {   // a row of a z / y face (15 % of the rows): also the face / edge subsets, straight into the LDS table
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {   // fold the 8 x segments (lanes seg = lane & 7): every lane ends with the row sum
+            sv[j] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sv[j]), 0xB1, 0xf, 0xf, true));
+            sv[j] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sv[j]), 0x4E, 0xf, 0xf, true));
+            sv[j] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sv[j]), 0x141, 0xf, 0xf, true));
+          }
 #pragma unroll
           for (int cmb = 0; cmb < 3; ++cmb) {
             const int a = (cmb == 1) ? 0 : az, b = (cmb == 0) ? 0 : ay;   // (az,0), (0,ay), (az,ay)
@@ -229,20 +236,39 @@ __global__ __launch_bounds__(512, 2) void wgrad_tiled_kernel(WgTiledParams p) {
       __syncthreads();  // (drains the DMA: hipcc emits vmcnt(0) before the barrier)
     }
     if (p.tg) {   // whole-volume subsets (all, all, all | first x | last x) kept in registers until now
+      float* Tg = T;   // (the LDS table; flushed below)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {   // call holds this thread's own 4-voxel partials: fold the 8 segments once, here
+        call[j] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, call[j]), 0xB1, 0xf, 0xf, true));
+        call[j] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, call[j]), 0x4E, 0xf, 0xf, true));
+        call[j] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, call[j]), 0x141, 0xf, 0xf, true));
+      }
       if (seg == 0) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) atomicAdd(T + c8 * 8 + j, call[j]);
+        for (int j = 0; j < 8; ++j) atomicAdd(Tg + c8 * 8 + j, call[j]);
       }
       const int axr = (seg == 0) ? 1 : 2;   // a thread only ever held one edge role (first x: seg 0; last x: seg 3 or 7)
 #pragma unroll
       for (int j = 0; j < 8; ++j)
-        if (cedge[j] != 0.f) atomicAdd(T + axr * 32 + c8 * 8 + j, cedge[j]);
+        if (cedge[j] != 0.f) atomicAdd(Tg + axr * 32 + c8 * 8 + j, cedge[j]);
+      // last loader wave out flushes (LDS atomics of a wave are complete once their lgkmcnt drains: the returning add waits)
+      __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0)
+      int last = 0;
+      if (lane == 0) last = (atomicAdd(tcnt, 1) == 3);
+      last = __builtin_amdgcn_readfirstlane(last);
+      if (last) {
+        float* G = p.tg + (long)n * 27 * 32;
+        for (int k = lane; k < 27 * 32; k += 64) {
+          const float v = T[k];
+          if (v != 0.f) atomicAdd(G + k, v);
+        }
+      }
     }
+    return;
   }
 
   // ---- consumers: per-lane fragment addresses for both buffers, accumulators live for the whole kernel
   f32x4 acc[7][2][2];
-  if (!loader) {
 #pragma unroll
   for (int t = 0; t < 7; ++t)
 #pragma unroll
@@ -286,19 +312,8 @@ __global__ __launch_bounds__(512, 2) void wgrad_tiled_kernel(WgTiledParams p) {
       }
     __syncthreads();  // brick k consumed, brick k+1 staged
   }
-  }  // !loader
-  __syncthreads();   // every brick consumed; the loaders' class-sum table is complete
 
   const int q = lane >> 4, i = lane & 15;
-  if (loader) {
-    if (p.tg) {
-      const float* T = reinterpret_cast<const float*>(lds + 2 * BUF);
-      for (int k = ttid; k < 27 * 32; k += 256) {
-        const float v = T[k];
-        if (v != 0.f) atomicAdd(p.tg + (long)n * 27 * 32 + k, v);
-      }
-    }
-  } else {
   // ---- one fp32 slab [27][32][32] per workgroup; D[row = co][col = ci]: lane holds rows 4q..4q+3, column lane&15
   float* out = p.gp + ((long)n * p.wgs_per_sample + wg) * 27 * 32 * 32;
 #pragma unroll
@@ -313,11 +328,9 @@ __global__ __launch_bounds__(512, 2) void wgrad_tiled_kernel(WgTiledParams p) {
           for (int r = 0; r < 4; ++r)
             out[(tap * 32 + a * 16 + q * 4 + r) * 32 + b * 16 + i] = acc[t][a][b][r];
   }
-  }
-  if (p.qpart) {   // workgroup-uniform: the two barriers below are reached by all eight waves
+  if (p.qpart) {
     // lane holds slab[tap][co = a*16 + 4q + r][ci = b*16 + i]; wd[tap][ci][co..co+3] is one 8-byte read
     float qs[2] = {0.f, 0.f};
-    if (!loader) {
 #pragma unroll
     for (int t = 0; t < 7; ++t) {
       const int tap = tw + 4 * t;
@@ -336,12 +349,13 @@ __global__ __launch_bounds__(512, 2) void wgrad_tiled_kernel(WgTiledParams p) {
       qs[b] += __shfl_xor(qs[b], 16, 64);
       qs[b] += __shfl_xor(qs[b], 32, 64);
     }
-    }
-    // fold the four consumer waves in fixed order through LDS (the staging buffers are idle now)
+    // fold the four consumer waves in fixed order through LDS (the staging buffers are idle now; the loader waves have
+    // exited, which the hardware barrier accounts for)
     float* red = reinterpret_cast<float*>(lds);
-    if (!loader && q == 0) { red[tw * 32 + i] = qs[0]; red[tw * 32 + 16 + i] = qs[1]; }
     __syncthreads();
-    if (!loader && tw == 0 && lane < 32)
+    if (q == 0) { red[tw * 32 + i] = qs[0]; red[tw * 32 + 16 + i] = qs[1]; }
+    __syncthreads();
+    if (tw == 0 && lane < 32)
       p.qpart[((long)n * p.wgs_per_sample + wg) * 32 + lane] = (red[lane] + red[32 + lane]) + (red[64 + lane] + red[96 + lane]);
   }
 }
@@ -381,12 +395,12 @@ int rtp_wgrad_tiled_try(const RtpAct* gy, const RtpAct* x, const RtpConvGeom* g,
   p.dbg = dbg;
   p.wd = (const bf16_t*)wd; p.qpart = wd ? qpart : nullptr; p.tg = tg;
   const size_t shm_base = sizeof(bf16_t) * 2 * (size_t)(HALO_VOX + BRICK_VOX) * 32;
-  const size_t shm = shm_base + (tg ? 27 * 32 * sizeof(float) : 0);
+  const size_t shm = shm_base + (tg ? 27 * 32 * sizeof(float) + 16 : 0);
   RtpProfScope prof(RTP_FAM_WGRAD_TILED, s);
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute((const void*)wgrad_tiled_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)(shm_base + 27 * 32 * sizeof(float)));
+                              (int)(shm_base + 27 * 32 * sizeof(float) + 16));
     attr = true;
   }
   hipLaunchKernelGGL(wgrad_tiled_kernel, dim3(p.N * nsplit), dim3(512), shm, s, p);

@@ -22,6 +22,22 @@ def t(f, it=300):
     for _ in range(it): f(s)
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / it * 1e6
 print('dbg', os.environ.get('RTP_TILED_DBG', '0'), 'conv_tiled %.1f us' % t(f_conv), 'wgrad_tiled %.1f us' % t(f_wg))
+if 'full' not in sys.argv:
+    # the fused backward pair: weight gradient + slab contraction (+ subset sums of gy), then the data gradient that writes the
+    # finished gradient (coefficients in its prologue; 0 / 1 / 2 extra terms)
+    wd = mk((27, c, c)) * 0.05
+    qp = torch.zeros(n, S, c, device='cuda'); tg = torch.zeros(n, 27, 32, device='cuda')
+    mr = torch.rand(n, 8, 2, device='cuda') + 0.5; gam = torch.rand(c, device='cuda') + 0.5
+    cf = torch.zeros(n * c * 5, device='cuda'); cs = torch.zeros(n, 64, c, device='cuda')
+    dx = View(mk((n, d, h, w, c)), n, d, h, w, c, 0, c)
+    e1 = View(mk((n, d, h, w, c)), n, d, h, w, c, 0, c); e2 = View(mk((n, d, h, w, c)), n, d, h, w, c, 0, c)
+    gn = dict(qpart=qp, q_nsplit=S, p=None, tg=tg, csum_out=cs, mr=mr, gamma=gam, groups=8, coeff_out=cf)
+    print('wgrad_q %.1f us' % t(be.wgrad_q(y, x, g, S, gp, wd, qp, None)), 'wgrad_q+tg %.1f us' % t(be.wgrad_q(y, x, g, S, gp, wd, qp, tg)))
+    print('dgrad plain+stats %.1f us' % t(be.conv(y, wd, False, None, None, dx, g, False, True, False, (x, torch.zeros(n, 32, c, 2, device='cuda')))),
+          'fused(no gn) %.1f' % t(be.conv_dgrad_fused(y, wd, x, None, [], True, dx, g)),
+          'fused(gn) %.1f' % t(be.conv_dgrad_fused(y, wd, x, None, [], True, dx, g, None, gn)),
+          'fused(gn,+1) %.1f' % t(be.conv_dgrad_fused(y, wd, x, None, [(e1, None)], True, dx, g, None, gn)),
+          'fused(gn,+2) %.1f' % t(be.conv_dgrad_fused(y, wd, x, None, [(e1, None), (e2, None)], True, dx, g, None, gn)))
 if 'full' in sys.argv: sys.exit(0)   # PMC passes: only the full-resolution launches
 # level-1 sized problem (8 x 32 x 80): few bricks per workgroup, ragged W
 d1, h1, w1 = 8, 32, 80
