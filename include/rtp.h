@@ -122,9 +122,9 @@ int rtp_wgrad_nsplit(const RtpConvGeom* g);
  * Summed over s this is Q = sum_v dxhat[v][ci] * x[v][ci] of GroupNorm backward (dxhat = the data gradient), obtained
  * without a pass over dxhat -- so the data gradient can run AFTER its GroupNorm coefficients are known and write the
  * finished gradient (rtp_conv_dgrad_fused).
- * tg (optional, fp32 [n][27][32], ZEROED by the caller): the kernel's loader waves also sum gy over the volume and its faces /
- * edges / corners (27 subsets: per axis all | first plane | last plane, slot (az*3+ay)*3+ax) and add them with atomics --
- * what P, the bias gradient and the GroupNorm un-fold need, without a pass over gy. */
+ * tg (optional, fp32 [n][nsplit][27][32]): the kernel's loader waves also sum gy over the volume and its faces / edges /
+ * corners (27 subsets: per axis all | first plane | last plane, slot (az*3+ay)*3+ax), one partial table per slab, summed in
+ * a fixed order -- what P, the bias gradient and the GroupNorm un-fold need, without a pass over gy. */
 int rtp_wgrad_q(const RtpAct* gy, const RtpAct* x, const RtpConvGeom* g, int nsplit, float* gp, const void* wd,
                 float* qpart, float* tg, void* stream);
 /* dst[0..n) = 0 (device fp32), on `stream`: one launch for every accumulate-into buffer of a step. */
@@ -213,7 +213,7 @@ typedef struct RtpTerm {
 typedef struct RtpGnBwd {
   const float* qpart; int q_nsplit; /* [n][q_nsplit][32] slab contractions (rtp_wgrad_q): Q = their sum                 */
   const float* p;                   /* [n][32]  P = sum dxhat, from the class sums (rtp_gn_bwd_p); or NULL with ...      */
-  const float* tg;                  /* [n][27][32] subset sums of gy accumulated by rtp_wgrad_q: P is computed from them  */
+  const float* tg;                  /* [n][q_nsplit][27][32] subset-sum partials from rtp_wgrad_q: P is computed from them */
   float* csum_out;                  /* (with tg) optional [n][64][32]: per-boundary-class sums of gy for rtp_wgrad_fold   */
   const float* mr;                  /* [n][groups][2] (mean, rstd) saved by rtp_fold_fwd                                 */
   const float* gamma; int groups;

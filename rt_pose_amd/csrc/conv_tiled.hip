@@ -61,7 +61,7 @@ struct TiledParams {
   // (coef_out [N*32*3] + dgamma/dbeta partials [N*32*2]) for the other consumers of the coefficients.
   const float* qpart; int q_nsplit; const float* gn_p; const float* gn_mr; const float* gn_gamma; int gn_groups; float gn_m;
   float* coef_out;
-  // ... and P itself from the 27 inclusive subset sums of gy the weight-gradient kernel accumulated (tg [N][27][32], see
+  // ... and P itself from the 27 inclusive subset sums of gy the weight-gradient kernel accumulated (tg [N][q_nsplit][27][32], see
   // wgrad_tiled.hip) when gn_p is null; workgroup 0 of a sample then also writes the per-boundary-class sums csum_out
   // [N][64][32] the deferred weight-gradient fold needs.
   const float* tg; float* csum_out;
@@ -154,7 +154,20 @@ __global__ __launch_bounds__(512, 2) void conv_tiled_kernel(TiledParams p) {
       float* Ts = reinterpret_cast<float*>(lds + 27 * NT * 16 * 32);   // [27][32] inclusive sums
       float* CSs = Ts + 27 * 32;                                        // [27 taps][32 co]
       float* Pp = CSs + 27 * 32;                                        // [16][32] partial P
-      for (int i = tid; i < 27 * 32; i += 512) Ts[i] = p.tg[(long)n * 27 * 32 + i];
+      for (int i = tid; i < 27 * 32; i += 512) {   // the sample's workgroup partials, in fixed order, eight loads in flight
+        const float* src = p.tg + (long)n * p.q_nsplit * 27 * 32 + i;
+        float a = 0.f;
+        int s_ = 0;
+        for (; s_ + 8 <= p.q_nsplit; s_ += 8) {
+          float g8[8];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) g8[k] = src[(long)(s_ + k) * 27 * 32];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) a += g8[k];
+        }
+        for (; s_ < p.q_nsplit; ++s_) a += src[(long)s_ * 27 * 32];
+        Ts[i] = a;
+      }
       __syncthreads();
       // sum of gy over the voxels whose tap (kz,ky,kx) stays in bounds: per axis  all - [k == 0] first - [k == 2] last
       for (int i = tid; i < 27 * 32; i += 512) {

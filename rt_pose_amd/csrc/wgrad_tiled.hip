@@ -37,8 +37,9 @@ struct WgTiledParams {
   const bf16_t* wd; float* qpart;
   // optional: sums of gy over the volume and its faces / edges / corners (27 "inclusive" subsets: per axis all | first plane
   // | last plane; slot = (az*3 + ay)*3 + ax), accumulated by the otherwise idle LOADER waves from the staged gy bricks and
-  // added with fp32 atomics to tg[N][27][32] (zeroed by the caller).  They give P = sum dxhat of GroupNorm backward, the
-  // bias gradient and the un-fold term without any pass over gy (conv_tiled.hip, fused data gradient).
+  // stored as ONE partial table per workgroup tg[N][wgs_per_sample][27][32] (fixed summation order: reproducible).  They
+  // give P = sum dxhat of GroupNorm backward, the bias gradient and the un-fold term without any pass over gy
+  // (conv_tiled.hip, fused data gradient).
   float* tg;
 };
 
@@ -160,12 +161,13 @@ __global__ __attribute__((amdgpu_flat_work_group_size(512, 512), amdgpu_waves_pe
     float call[8], cedge[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) call[j] = cedge[j] = 0.f;
-    // [27][32] subset table in LDS (only allocated when p.tg) + a counter: the last loader wave to finish flushes the table to
-    // global memory with atomics and exits -- nobody waits for those atomics (waited for at a barrier they cost +70 us)
-    float* T = reinterpret_cast<float*>(lds + 2 * BUF);
-    int* tcnt = reinterpret_cast<int*>(T + 27 * 32);
+    // One [27][32] subset table PER LOADER WAVE in LDS (only allocated when p.tg: no cross-wave add order to vary from run to
+    // run) + a counter: the last loader wave to finish adds the four tables in fixed order and stores the workgroup's partial.
+    float* Tall = reinterpret_cast<float*>(lds + 2 * BUF);
+    float* T = Tall + (wave & 3) * 27 * 32;
+    int* tcnt = reinterpret_cast<int*>(Tall + 4 * 27 * 32);
     if (p.tg) {
-      for (int i = ttid; i < 27 * 32; i += 256) T[i] = 0.f;   // (first atomics come after the first barrier)
+      for (int i = lane; i < 27 * 32; i += 64) T[i] = 0.f;
       if (ttid == 0) *tcnt = 0;
     }
     for (int k = 0; k <= my_tiles; ++k) {
@@ -236,7 +238,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(512, 512), amdgpu_waves_pe
       __syncthreads();  // (drains the DMA: hipcc emits vmcnt(0) before the barrier)
     }
     if (p.tg) {   // whole-volume subsets (all, all, all | first x | last x) kept in registers until now
-      float* Tg = T;   // (the LDS table; flushed below)
+      float* Tg = T;   // (this wave's LDS table; flushed below)
 #pragma unroll
       for (int j = 0; j < 8; ++j) {   // call holds this thread's own 4-voxel partials: fold the 8 segments once, here
         call[j] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, call[j]), 0xB1, 0xf, 0xf, true));
@@ -257,11 +259,9 @@ __global__ __attribute__((amdgpu_flat_work_group_size(512, 512), amdgpu_waves_pe
       if (lane == 0) last = (atomicAdd(tcnt, 1) == 3);
       last = __builtin_amdgcn_readfirstlane(last);
       if (last) {
-        float* G = p.tg + (long)n * 27 * 32;
-        for (int k = lane; k < 27 * 32; k += 64) {
-          const float v = T[k];
-          if (v != 0.f) atomicAdd(G + k, v);
-        }
+        float* G = p.tg + ((long)n * p.wgs_per_sample + wg) * 27 * 32;
+        for (int k = lane; k < 27 * 32; k += 64)
+          G[k] = (Tall[k] + Tall[27 * 32 + k]) + (Tall[2 * 27 * 32 + k] + Tall[3 * 27 * 32 + k]);
       }
     }
     return;
@@ -395,12 +395,12 @@ int rtp_wgrad_tiled_try(const RtpAct* gy, const RtpAct* x, const RtpConvGeom* g,
   p.dbg = dbg;
   p.wd = (const bf16_t*)wd; p.qpart = wd ? qpart : nullptr; p.tg = tg;
   const size_t shm_base = sizeof(bf16_t) * 2 * (size_t)(HALO_VOX + BRICK_VOX) * 32;
-  const size_t shm = shm_base + (tg ? 27 * 32 * sizeof(float) + 16 : 0);
+  const size_t shm = shm_base + (tg ? 4 * 27 * 32 * sizeof(float) + 16 : 0);
   RtpProfScope prof(RTP_FAM_WGRAD_TILED, s);
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute((const void*)wgrad_tiled_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)(shm_base + 27 * 32 * sizeof(float) + 16));
+                              (int)(shm_base + 4 * 27 * 32 * sizeof(float) + 16));
     attr = true;
   }
   hipLaunchKernelGGL(wgrad_tiled_kernel, dim3(p.N * nsplit), dim3(512), shm, s, p);

@@ -582,7 +582,7 @@ class ConvOp:
         from_wgrad = bool(self.gn) and not own_kernel and not os.environ.get("RTP_CLS_KERNELS")
         csum = pbuf = tg = None
         if from_wgrad:
-            tg = g.zero_alloc((g.n, 27, 32))
+            tg = be.alloc((g.n, be.wgrad_nsplit(ge), 27, 32), "f32")   # one partial table per weight-gradient slab
             csum = be.alloc((g.n, 64, gy.c), "f32")
         elif self.gn and not own_kernel and hasattr(be, "class_sums_p"):
             csum, pbuf = g.class_sums_and_p(self.y, gy, wl, self.name, self.wd, ge, self.ci_real, self.co_real)

@@ -347,7 +347,7 @@ class EmuBackend:
 
     def wgrad_q(self, gy, x, geom, nsplit, gp, wd, qpart, tg=None):
         """rtp_wgrad_q: the correlation plus each slab's contraction with the data-gradient weights wd[tap][ci][cok], plus
-        (tg, ACCUMULATED into) the 27 inclusive subset sums of gy: per axis all | first plane | last plane."""
+        (tg [n][nsplit][27][32]) the 27 inclusive subset sums of gy: per axis all | first plane | last plane."""
         base = self.wgrad(gy, x, geom, nsplit, gp)
 
         def run(s):
@@ -355,11 +355,13 @@ class EmuBackend:
             qpart.copy_(torch.einsum("tic,nstci->nsi", wd.float(), gp))
             if tg is not None:
                 gv = _sl(gy)   # [n,d,h,w,c]
+                tgv = tg.view(gy.n, nsplit, 27, -1)   # one partial table per slab; everything in slab 0
+                tgv.zero_()
                 sel = lambda t, dim, a: t if a == 0 else t.narrow(dim, 0 if a == 1 else t.shape[dim] - 1, 1)
                 for a in range(3):
                     for b in range(3):
                         for c in range(3):
-                            tg.view(gy.n, 27, -1)[:, (a * 3 + b) * 3 + c, :gy.c] += sel(sel(sel(gv, 1, a), 2, b), 3, c).sum((1, 2, 3))
+                            tgv[:, 0, (a * 3 + b) * 3 + c, :gy.c] = sel(sel(sel(gv, 1, a), 2, b), 3, c).sum((1, 2, 3))
         return run
 
     def zero_f32(self, t):
@@ -447,7 +449,7 @@ class EmuBackend:
                 if gn.get("p") is not None:
                     P = gn["p"].view(n, -1)[:, :c]
                 else:   # P (and the exclusive boundary-class sums) from the inclusive subset sums
-                    T = gn["tg"].view(n, 3, 3, 3, -1)
+                    T = gn["tg"].view(n, gn["q_nsplit"], 27, -1).sum(1).view(n, 3, 3, 3, -1)
                     M = torch.tensor([[1.0, -1.0, -1.0], [0.0, 1.0, 0.0], [0.0, 0.0, 1.0]])   # state (int, first, last) x subset (all, first, last)
                     E = torch.tensor([[1.0, -1.0, 0.0], [1.0, 0.0, 0.0], [1.0, 0.0, -1.0]])   # tap k in {0,1,2} x subset: in-bounds voxels
                     CS = torch.einsum("za,yb,xc,nabck->nzyxk", E, E, E, T).reshape(n, 27, -1)

@@ -26,7 +26,7 @@ if 'full' not in sys.argv:
     # the fused backward pair: weight gradient + slab contraction (+ subset sums of gy), then the data gradient that writes the
     # finished gradient (coefficients in its prologue; 0 / 1 / 2 extra terms)
     wd = mk((27, c, c)) * 0.05
-    qp = torch.zeros(n, S, c, device='cuda'); tg = torch.zeros(n, 27, 32, device='cuda')
+    qp = torch.zeros(n, S, c, device='cuda'); tg = torch.zeros(n, S, 27, 32, device='cuda')
     mr = torch.rand(n, 8, 2, device='cuda') + 0.5; gam = torch.rand(c, device='cuda') + 0.5
     cf = torch.zeros(n * c * 5, device='cuda'); cs = torch.zeros(n, 64, c, device='cuda')
     dx = View(mk((n, d, h, w, c)), n, d, h, w, c, 0, c)
