@@ -31,7 +31,7 @@ def cpu_baseline(name, seconds_budget=40.0):
     SURVEY.md 8d: B = 2 frames at the native shape, fp32, one warm-up step, median of 3 timed steps, at the host's physical
     core count (stated); plus an 8-thread datapoint (the authoring container's size) and, on hosts with more than 32
     physical cores, a 32-thread datapoint (PyTorch's CPU conv stops scaling well before 100+ threads).  `value` is the best
-    of the datapoints with 3 timed steps."""
+    datapoint."""
     import statistics
     import torch
     from oracle import hrradarpose_ref as O
@@ -49,13 +49,12 @@ def cpu_baseline(name, seconds_budget=40.0):
     phys = max(1, min(phys, avail))
     batch, dims = 2, (16, 64, 160)
     ex = O.synth_example(batch, O.ARCHS[arch]["inplanes"], dims, seed=1234, one_hm=heads["hm"] == 1)
-    t_start = time.perf_counter()
 
-    def run(threads, warm, timed):
+    def run(threads, warm, timed, budget):
         torch.set_num_threads(threads)
         sd = {k: v.requires_grad_(True) for k, v in O.seeded_state_dict(shapes, seed=1).items()}
         opt = O.AdamTrueWD(list(sd.values()))
-        ts = []
+        ts, t_begin = [], time.perf_counter()
         for i in range(warm + timed):
             t0 = time.perf_counter()
             for p in sd.values():
@@ -64,23 +63,25 @@ def cpu_baseline(name, seconds_budget=40.0):
             opt.step(1e-4, 0.95)
             if i >= warm:
                 ts.append(time.perf_counter() - t0)
-            if time.perf_counter() - t_start > seconds_budget and ts:
+            if time.perf_counter() - t_begin > budget and ts:
                 break
         return statistics.median(ts), len(ts)
 
+    # every datapoint has its own time box (a 128-thread host oversubscribes PyTorch's CPU conv: 8.8 s per step there,
+    # 2.3 s with 32 threads), the 8-thread one is a single step; `value` is the best datapoint, `cores` its thread count
     points = {}
-    med, k = run(phys, 1, 3)
-    points[phys] = (med, k)
     if phys > 32:
-        points[32] = run(32, 1, 3)
-    if phys != 8 and avail >= 8:
-        points[8] = run(8, 0, 1)      # bounded: one step, no warm-up (about 15 s)
-    best = min((t for t, (m, k) in points.items() if k >= 2 or len(points) == 1), key=lambda t: points[t][0])
+        points[32] = run(32, 1, 3, seconds_budget * 0.4)
+    points[phys] = run(phys, 1, 3, seconds_budget * 0.4)
+    if 8 not in points and avail >= 8:
+        points[8] = run(8, 0, 1, seconds_budget * 0.2)
+    best = min(points, key=lambda t: points[t][0])
     return dict(value=round(batch / points[best][0], 4), unit="frames/s", cores=best, kind="port",
                 physical_cores=phys,
                 datapoints={str(t): {"frames_per_s": round(batch / m, 4), "timed_steps": k} for t, (m, k) in points.items()},
-                sample="median of %d train steps (1 warm-up) of batch %d at [B,%d,16,64,160], fp32, oracle/hrradarpose_ref.py; "
-                       "8-thread datapoint: one step, no warm-up" % (points[best][1], batch, O.ARCHS[arch]["inplanes"]))
+                sample="train steps of batch %d at [B,%d,16,64,160], fp32, oracle/hrradarpose_ref.py: per thread count 1 warm-up + median of "
+                       "up to 3 timed steps inside a time box (8 threads: one step, no warm-up); value = the best datapoint"
+                       % (batch, O.ARCHS[arch]["inplanes"]))
 
 
 def torch_gpu_child_run(name="hr3d", batch=8, amp=False, steps=3, warm=2, dev="cuda:0"):

@@ -117,6 +117,9 @@ def load_checkpoint(target, filename, map_location="cpu", strict=False, logger=N
         raise RuntimeError("No state_dict found in checkpoint file {}".format(filename))
     if list(sd.keys())[0].startswith("module."):
         sd = {k[7:]: v for k, v in sd.items()}
+    if any(k.endswith(("_offset.weight", "_offset.bias")) for k in sd):   # pre-version-2 DeformConvPack keys (deform_conv.py:298-321)
+        from .dcn import migrate_pre_v2_keys
+        sd = migrate_pre_v2_keys(dict(sd))
     load_state_dict(getattr(target, "flat", target), sd, strict, logger)
     return ckpt
 

@@ -7,7 +7,8 @@ of include/rtp.h section D instead of the pybind module `deform_conv_cuda`.
 
 Error behaviour kept: non-4-D input -> ValueError; CPU tensors -> NotImplementedError (there is no CPU path here
 either); batch not divisible by im2col_step -> AssertionError('im2col step must divide batchsize'); a failing native
-call -> RuntimeError.  fp32 only (the reference also dispatches fp64/fp16; the pose path never uses them).
+call -> RuntimeError.  The kernels compute in fp32; fp16 / bf16 / fp64 tensors (the reference dispatches fp64/fp32/fp16) are
+converted around the native call and results come back in the caller's dtype.
 """
 import ctypes as C
 import math
@@ -37,12 +38,21 @@ def _workspace(x, weight, out_hw, step):
     return torch.empty(nbytes // 4, dtype=torch.float32, device=x.device)
 
 
+_FLOATS = (torch.float32, torch.float16, torch.bfloat16, torch.float64)
+
+
 def _check(x, *others):
     if not x.is_cuda:
         raise NotImplementedError
     for t in (x, *others):
-        if t is not None and t.dtype != torch.float32:
-            raise NotImplementedError("rt_pose_amd.dcn is fp32 (got %s)" % t.dtype)
+        if t is not None and t.dtype not in _FLOATS:
+            raise NotImplementedError("rt_pose_amd.dcn: floating-point tensors only (got %s)" % t.dtype)
+
+
+def _f32(t):
+    """The kernels compute in fp32; half / bfloat16 / double tensors (the reference dispatches fp64/fp32/fp16,
+    deform_conv_cuda_kernel.cu:259) are converted around the call and results returned in the caller's dtype."""
+    return t if t is None or t.dtype == torch.float32 else t.float()
 
 
 class DeformConvFunction(Function):
@@ -55,10 +65,11 @@ class DeformConvFunction(Function):
         ctx.save_for_backward(input, offset, weight)
         _check(input, offset, weight)
         out_size = DeformConvFunction._output_size(input, weight, ctx.padding, ctx.dilation, ctx.stride)
-        output = input.new_empty(out_size)
+        out_dtype = input.dtype
         step = min(ctx.im2col_step, input.shape[0])
         assert (input.shape[0] % step) == 0, "im2col step must divide batchsize"
-        input, offset, weight = input.contiguous(), offset.contiguous(), weight.contiguous()
+        input, offset, weight = _f32(input).contiguous(), _f32(offset).contiguous(), _f32(weight).contiguous()
+        output = input.new_empty(out_size)
         ws = _workspace(input, weight, out_size[2:], step)
         n, c, h, w = input.shape
         rc = _lib.load().rtp_deform_conv_forward(
@@ -67,7 +78,7 @@ class DeformConvFunction(Function):
             ctx.deformable_groups, step, _stream(input))
         if rc != 0:
             raise RuntimeError("rtp_deform_conv_forward failed (%d)" % rc)
-        return output
+        return output if out_dtype == torch.float32 else output.to(out_dtype)
 
     @staticmethod
     @once_differentiable
@@ -79,7 +90,9 @@ class DeformConvFunction(Function):
         step = min(ctx.im2col_step, input.shape[0])
         assert (input.shape[0] % step) == 0, "im2col step must divide batchsize"
         lib = _lib.load()
-        input, offset, weight, grad_output = input.contiguous(), offset.contiguous(), weight.contiguous(), grad_output.contiguous()
+        dts = (input.dtype, offset.dtype, weight.dtype)
+        input, offset, weight, grad_output = (_f32(input).contiguous(), _f32(offset).contiguous(), _f32(weight).contiguous(),
+                                              _f32(grad_output).contiguous())
         ws = _workspace(input, weight, grad_output.shape[2:], step)
         n, c, h, w = input.shape
         geo = (n, c, h, w, weight.size(0), weight.size(3), weight.size(2), ctx.stride[1], ctx.stride[0], ctx.padding[1],
@@ -97,7 +110,8 @@ class DeformConvFunction(Function):
                                                          1.0, step, _stream(input))
             if rc != 0:
                 raise RuntimeError("rtp_deform_conv_backward_parameters failed (%d)" % rc)
-        return (grad_input, grad_offset, grad_weight, None, None, None, None, None, None)
+        cast = lambda g, dt: g if g is None or g.dtype == dt else g.to(dt)
+        return (cast(grad_input, dts[0]), cast(grad_offset, dts[1]), cast(grad_weight, dts[2]), None, None, None, None, None, None)
 
     @staticmethod
     def _output_size(input, weight, padding, dilation, stride):
@@ -124,8 +138,10 @@ class ModulatedDeformConvFunction(Function):
         if weight.requires_grad or mask.requires_grad or offset.requires_grad or input.requires_grad:
             ctx.save_for_backward(input, offset, mask, weight, bias)
         out_shape = ModulatedDeformConvFunction._infer_shape(ctx, input, weight)
+        out_dtype = input.dtype
+        input, offset, mask, weight, bias = (_f32(input).contiguous(), _f32(offset).contiguous(), _f32(mask).contiguous(),
+                                             _f32(weight).contiguous(), _f32(bias).contiguous())
         output = input.new_empty(out_shape)
-        input, offset, mask, weight = input.contiguous(), offset.contiguous(), mask.contiguous(), weight.contiguous()
         ws = _workspace(input, weight, out_shape[2:], 1)
         n, c, h, w = input.shape
         rc = _lib.load().rtp_modulated_deform_conv_forward(
@@ -134,7 +150,7 @@ class ModulatedDeformConvFunction(Function):
             int(ctx.with_bias), _stream(input))
         if rc != 0:
             raise RuntimeError("rtp_modulated_deform_conv_forward failed (%d)" % rc)
-        return output
+        return output if out_dtype == torch.float32 else output.to(out_dtype)
 
     @staticmethod
     @once_differentiable
@@ -142,10 +158,12 @@ class ModulatedDeformConvFunction(Function):
         if not grad_output.is_cuda:
             raise NotImplementedError
         input, offset, mask, weight, bias = ctx.saved_tensors
+        dts = (input.dtype, offset.dtype, mask.dtype, weight.dtype, bias.dtype)
+        input, offset, mask, weight, bias = (_f32(input).contiguous(), _f32(offset).contiguous(), _f32(mask).contiguous(),
+                                             _f32(weight).contiguous(), _f32(bias).contiguous())
         grad_input, grad_offset = torch.zeros_like(input), torch.zeros_like(offset)
         grad_mask, grad_weight, grad_bias = torch.zeros_like(mask), torch.zeros_like(weight), torch.zeros_like(bias)
-        input, offset, mask, weight = input.contiguous(), offset.contiguous(), mask.contiguous(), weight.contiguous()
-        grad_output = grad_output.contiguous()
+        grad_output = _f32(grad_output).contiguous()
         ws = _workspace(input, weight, grad_output.shape[2:], 1)
         n, c, h, w = input.shape
         rc = _lib.load().rtp_modulated_deform_conv_backward(
@@ -157,7 +175,9 @@ class ModulatedDeformConvFunction(Function):
             raise RuntimeError("rtp_modulated_deform_conv_backward failed (%d)" % rc)
         if not ctx.with_bias:
             grad_bias = None
-        return (grad_input, grad_offset, grad_mask, grad_weight, grad_bias, None, None, None, None, None)
+        cast = lambda g, dt: g if g is None or g.dtype == dt else g.to(dt)
+        return (cast(grad_input, dts[0]), cast(grad_offset, dts[1]), cast(grad_mask, dts[2]), cast(grad_weight, dts[3]),
+                cast(grad_bias, dts[4]), None, None, None, None, None)
 
     @staticmethod
     def _infer_shape(ctx, input, weight):
@@ -222,6 +242,17 @@ class DeformConvPack(DeformConv):
         offset = self.conv_offset(x)
         return deform_conv(x, offset, self.weight, self.stride, self.padding, self.dilation, self.groups, self.deformable_groups)
 
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        """Checkpoints written before version 2 name the offset conv '<name>_offset.*' instead of '<name>.conv_offset.*'
+        (deform_conv.py:298-321 / 420-444): move those keys, then load as usual."""
+        version = local_metadata.get("version", None)
+        if version is None or version < 2:
+            for leaf in ("weight", "bias"):
+                new_key, old_key = prefix + "conv_offset." + leaf, prefix[:-1] + "_offset." + leaf
+                if new_key not in state_dict and old_key in state_dict:
+                    state_dict[new_key] = state_dict.pop(old_key)
+        super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs)
+
 
 class ModulatedDeformConv(nn.Module):
     def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1,
@@ -267,3 +298,35 @@ class ModulatedDeformConvPack(ModulatedDeformConv):
         mask = torch.sigmoid(mask)
         return modulated_deform_conv(x, offset, mask, self.weight, self.bias, self.stride, self.padding, self.dilation,
                                      self.groups, self.deformable_groups)
+
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        """Checkpoints written before version 2 name the offset conv '<name>_offset.*' instead of '<name>.conv_offset.*'
+        (deform_conv.py:298-321 / 420-444): move those keys, then load as usual."""
+        version = local_metadata.get("version", None)
+        if version is None or version < 2:
+            for leaf in ("weight", "bias"):
+                new_key, old_key = prefix + "conv_offset." + leaf, prefix[:-1] + "_offset." + leaf
+                if new_key not in state_dict and old_key in state_dict:
+                    state_dict[new_key] = state_dict.pop(old_key)
+        super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs)
+
+
+def migrate_pre_v2_keys(state_dict, module=None):
+    """Rename '<name>_offset.{weight,bias}' to '<name>.conv_offset.{weight,bias}' in a whole checkpoint state dict.
+
+    The reference does this inside DeformConvPack._load_from_state_dict (deform_conv.py:298-321, 420-444), which current
+    PyTorch never reaches with such a key: Module.load_state_dict hands a child only the keys under its own prefix
+    ('conv2.'), and 'conv2_offset.weight' is not one of them.  Call this on the dict before load_state_dict instead
+    (rt_pose_amd.checkpoint.load_checkpoint does).  With `module` given, only names that are Pack modules are touched."""
+    packs = None
+    if module is not None:
+        packs = {n for n, m in module.named_modules() if isinstance(m, (DeformConvPack, ModulatedDeformConvPack))}
+    for k in list(state_dict.keys()):
+        for leaf in ("weight", "bias"):
+            tail = "_offset." + leaf
+            if k.endswith(tail):
+                name = k[:-len(tail)]
+                new = name + ".conv_offset." + leaf
+                if new not in state_dict and (packs is None or name in packs):
+                    state_dict[new] = state_dict.pop(k)
+    return state_dict

@@ -229,6 +229,8 @@ def install_det3d_shim(force=False):
         except Exception:
             real = None
     if real is not None:
+        from . import deform_conv_cuda as _dcc
+        sys.modules.setdefault("det3d.ops.dcn.deform_conv_cuda", _dcc)   # picked up by `from . import deform_conv_cuda`
         for ours, theirs in ((READERS, real.READERS), (BACKBONES, real.BACKBONES), (HEADS, real.HEADS),
                              (DETECTORS, real.DETECTORS)):
             for name, cls in ours.module_dict.items():
@@ -260,6 +262,17 @@ def install_det3d_shim(force=False):
                   "build_feat_transform", "build_detector"):
             setattr(bld, k, getattr(me, k))
             setattr(models, k, getattr(me, k))
+        # native-op seam: `from . import deform_conv_cuda` in det3d/ops/dcn/deform_conv.py:11 resolves to the ctypes binding
+        from . import dcn as _dcn, deform_conv_cuda as _dcc
+        ops = mk("det3d.ops")
+        opd = mk("det3d.ops.dcn")
+        sys.modules["det3d.ops.dcn.deform_conv_cuda"] = _dcc
+        opd.deform_conv_cuda = _dcc
+        for k in ("DeformConv", "DeformConvPack", "ModulatedDeformConv", "ModulatedDeformConvPack", "DeformConvFunction",
+                  "ModulatedDeformConvFunction", "deform_conv", "modulated_deform_conv"):
+            setattr(opd, k, getattr(_dcn, k))
+        sys.modules["det3d.ops.dcn.deform_conv"] = _dcn
+        opd.deform_conv = _dcn.deform_conv
         torchie = mk("det3d.torchie")
         torchie.Config = Config
         torchie.is_str = lambda x: isinstance(x, str)
