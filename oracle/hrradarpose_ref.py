@@ -110,11 +110,34 @@ def hrnet3d(sd, x, final_fuse, p="backbone"):
     return feats
 
 
+def feature_adaption(sd, p, x, deformable_groups=4):
+    """FeatureAdaption.forward -- center_head.py:24-62 -- applied per (frame, z) slice of a 5-D feature (Z folded into the
+    batch; the reference's module is 2-D and its DCNSepHead cannot run on the 5-D feature, appendix 4):
+    offset = Conv2d 1x1 (zero-initialised weight) -> DCNv1 3x3, pad 1, deformable_groups 4 -> ReLU.
+    The deformable convolution is oracle/dcn_ref.py -- PARITY UNPINNED by the reference (see that file's header)."""
+    from . import dcn_ref
+    b, c, d, h, w = x.shape
+    x2 = x.permute(0, 2, 1, 3, 4).reshape(b * d, c, h, w)
+    off = F.conv2d(x2, sd[p + ".conv_offset.weight"], sd[p + ".conv_offset.bias"])
+    y2 = F.relu(dcn_ref.deform_conv2d(x2, off, sd[p + ".conv_adaption.weight"], 1, 1, 1, 1, deformable_groups))
+    return y2.reshape(b, d, c, h, w).permute(0, 2, 1, 3, 4)
+
+
 def sep_head(sd, p, x, heads):
-    """SepHead.forward -- pose_heads/center_head.py:66-109 (final_kernel=3, 2 convs per head)."""
+    """SepHead.forward -- pose_heads/center_head.py:66-109 (final_kernel=3, 2 convs per head).  With the DCN head's
+    parameters present (dcn_head=True, DCNSepHead.forward :156-163) the heat-map tower reads feature_adapt_cls(x) and the
+    other towers feature_adapt_reg(x)."""
     out = {}
+    dcn = (p + ".feature_adapt_cls.conv_adaption.weight") in sd
+    adapted = {}
     for name in heads:
-        t = F.relu(_conv(sd, f"{p}.{name}.0", x, 1, 1))
+        src = x
+        if dcn:
+            which = "cls" if name == "hm" else "reg"
+            if which not in adapted:
+                adapted[which] = feature_adaption(sd, f"{p}.feature_adapt_{which}", x)
+            src = adapted[which]
+        t = F.relu(_conv(sd, f"{p}.{name}.0", src, 1, 1))
         out[name] = _conv(sd, f"{p}.{name}.2", t, 1, 1)
     return out
 
@@ -338,8 +361,9 @@ class AdamTrueWD:
 # ----------------------------------------------------------------------------
 # parameter schema + seeded init recipe (used by golden generation and tests)
 # ----------------------------------------------------------------------------
-def param_shapes(arch, final_in, final_out, head_in, heads):
-    """Names/shapes of the reference module tree (checked against the reference import in gen_golden.py)."""
+def param_shapes(arch, final_in, final_out, head_in, heads, dcn_head=False):
+    """Names/shapes of the reference module tree (checked against the reference import in gen_golden.py).
+    dcn_head: plus the two FeatureAdaption modules of DCNSepHead (center_head.py:44-57, 125-135; 2-D shapes)."""
     a = ARCHS[arch]
     ch = a["channels"]
     sd = OrderedDict()
@@ -378,6 +402,12 @@ def param_shapes(arch, final_in, final_out, head_in, heads):
     if final_in != final_out:
         sd["backbone.final_conv.weight"] = (final_out, final_in, 1, 1, 1)
         sd["backbone.final_conv.bias"] = (final_out,)
+    if dcn_head:
+        for which in ("cls", "reg"):
+            p = f"pose_head.tasks.0.feature_adapt_{which}"
+            sd[p + ".conv_offset.weight"] = (72, head_in, 1, 1)
+            sd[p + ".conv_offset.bias"] = (72,)
+            sd[p + ".conv_adaption.weight"] = (head_in, head_in, 3, 3)
     for name, ncls in heads.items():
         p = f"pose_head.tasks.0.{name}"
         sd[p + ".0.weight"] = (32, head_in, 3, 3, 3)

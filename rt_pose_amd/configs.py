@@ -19,13 +19,17 @@ _TABLE = {
     "hr3d_one_hm_doppler_phase": ("hr_tiny_feat64_zyx_l4_in64", 64, 384, 256, "conat_conv", 1, 45, 0.5, 2e-3, 1),
 }
 NAMES = list(_TABLE)
+# BASELINE config 4: a shipped configuration + `dcn_head=True` (the DCN head of center_head.py:111-163 with Z folded into the
+# batch; the reference's own DCNSepHead cannot run on the 5-D feature, SURVEY appendix 4 -- parity unpinned by construction)
+DCN_VARIANTS = {"hr3d_dcn": "hr3d"}
 
 
 def spec(name):
-    arch, cin, fin, fout, fuse, nhm, nreg, weight, lr_max, batch = _TABLE[name]
+    dcn = name in DCN_VARIANTS
+    arch, cin, fin, fout, fuse, nhm, nreg, weight, lr_max, batch = _TABLE[DCN_VARIANTS.get(name, name)]
     cw = [1.0, 1.5, 2.0] if nreg == 3 else [1.0] * nreg
     return dict(arch=arch, cin=cin, final_conv_in=fin, final_conv_out=fout, final_fuse=fuse,
-                heads=OrderedDict(reg=nreg, hm=nhm), weight=weight, code_weights=cw, lr_max=lr_max, batch=batch)
+                heads=OrderedDict(reg=nreg, hm=nhm), weight=weight, code_weights=cw, lr_max=lr_max, batch=batch, dcn_head=dcn)
 
 
 def model_dict(name):
@@ -38,7 +42,7 @@ def model_dict(name):
                       final_conv_out=s["final_conv_out"], final_fuse=s["final_fuse"], ds_factor=1),
         pose_head=dict(type="CenterHead", tasks=tasks, in_channels=s["final_conv_out"],
                        share_conv_channel=s["final_conv_out"], dataset="cruw_pose", weight=s["weight"],
-                       code_weights=s["code_weights"], common_heads={"reg": (s["heads"]["reg"], 2)}, dcn_head=False),
+                       code_weights=s["code_weights"], common_heads={"reg": (s["heads"]["reg"], 2)}, dcn_head=s["dcn_head"]),
         neck=None)
 
 
@@ -89,6 +93,13 @@ def param_shapes(name):
     if s["final_conv_in"] != s["final_conv_out"]:
         sd["backbone.final_conv.weight"] = (s["final_conv_out"], s["final_conv_in"], 1, 1, 1)
         sd["backbone.final_conv.bias"] = (s["final_conv_out"],)
+    if s["dcn_head"]:   # FeatureAdaption x 2 (center_head.py:44-57, 125-135); before the towers: keeps every view 16-B aligned
+        c = s["final_conv_out"]
+        for which in ("cls", "reg"):
+            p = "pose_head.tasks.0.feature_adapt_%s" % which
+            sd[p + ".conv_offset.weight"] = (4 * 18, c, 1, 1)
+            sd[p + ".conv_offset.bias"] = (4 * 18,)
+            sd[p + ".conv_adaption.weight"] = (c, c, 3, 3)
     for hname, ncls in s["heads"].items():
         p = "pose_head.tasks.0.%s" % hname
         sd[p + ".0.weight"] = (32, s["final_conv_out"], 3, 3, 3)

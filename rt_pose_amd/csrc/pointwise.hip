@@ -759,6 +759,41 @@ __global__ __launch_bounds__(256) void pack_kernel(const float* x, bf16_t* y, in
   }
 }
 
+// y = bf16([relu](x (+ x2))): the hand-off from the fp32 NCHW deformable-convolution operator back to the plan's layout
+__global__ __launch_bounds__(256) void pack_ex_kernel(const float* x, const float* x2, bf16_t* y, int y_cs, int y_co, int n, int c,
+                                                      int cpad, long vox, int relu) {
+  const int cpv = cpad >> 3;
+  const long total = (long)n * vox * cpv;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long v = i % vox;
+    const int ck = (int)((i / vox) % cpv);
+    const int nn = (int)(i / (vox * cpv));
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int ch = ck * 8 + j;
+      float a = 0.f;
+      if (ch < c) {
+        a = x[((long)nn * c + ch) * vox + v];
+        if (x2) a += x2[((long)nn * c + ch) * vox + v];
+        if (relu) a = a > 0.f ? a : 0.f;
+      }
+      o[j] = f2bf(a);
+    }
+    st_bf16x8(y + ((long)nn * vox + v) * y_cs + y_co + ck * 8, o);
+  }
+}
+
+extern "C" int rtp_pack_ncdhw_ex(const float* x, const float* x2, const RtpAct* y, int n, int c, long vox, int relu, void* stream) {
+  if (!x || !y || y->c % 8 || c > y->c || (y->cs % 8) || (y->co % 8)) return RTP_ERR_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  RtpProfScope prof(RTP_FAM_POINTWISE, s);
+  hipLaunchKernelGGL(pack_ex_kernel, dim3(grid_for((long)n * vox * (y->c / 8))), dim3(256), 0, s, x, x2, (bf16_t*)y->ptr,
+                     y->cs, y->co, n, c, y->c, vox, relu);
+  RTP_CHECK_LAUNCH();
+  return RTP_OK;
+}
+
 extern "C" int rtp_pack_ncdhw(const float* x, const RtpAct* y, int n, int c, long vox, void* stream) {
   if (!x || !y || y->c % 8 || c > y->c || (y->cs % 8) || (y->co % 8)) return RTP_ERR_SHAPE;
   hipStream_t s = (hipStream_t)stream;

@@ -248,6 +248,21 @@ class Graph:
         self.emit_fwd(self.be.fuse_sum(terms, None, y, relu), self.lane_of(y), terms, [y], "fuse:" + name)
         return y
 
+    def dcn_adapt(self, name, x: Act, prefix):
+        """FeatureAdaption of the reference's DCN head (center_head.py:24-62) with Z folded into the batch:
+        relu(DeformConv3x3_dg4(x, Conv1x1(x))) per (frame, z) slice.  Parameters: prefix + .conv_offset.{weight,bias},
+        .conv_adaption.weight (2-D shapes, reference names)."""
+        w_off, b_off, w_ad = (self.param(prefix + ".conv_offset.weight"), self.param(prefix + ".conv_offset.bias"),
+                              self.param(prefix + ".conv_adaption.weight"))
+        assert x.c == x.c_real == w_ad.shape[1] and x.cs == x.c and x.co == 0, (name, x.c, x.c_real)
+        y = self.act(name, x.c_real, x.dims, relu=True)
+        op = DcnAdaptOp(self, name, x, y, prefix)
+        y.producer = op
+        self.ops.append(op)
+        op.fwd_fn, op.make_bwd = self.be.dcn_adapt(x, w_off, b_off, w_ad, y)
+        self.emit_fwd(op.fwd_fn, self.lane_of(y), [x, w_off, b_off, w_ad], [y], "dcn:" + name)
+        return y
+
     def forward_list(self):
         """The forward launches, opened by the one launch that packs every activation-independent weight image."""
         if self.head and not self._head_emitted:
@@ -826,6 +841,26 @@ class CoSplitConvOp:
             g.alg_bytes["wgrad_tiled"] += 2 * g.n * (gy.vox * 32 + x.vox * 32) + 4 * g.n * S * 27 * 32 * 32
         g.flops["wgrad"] += self.alg_flops
         g.flops["wgrad_tiled"] += self.alg_flops
+
+
+class DcnAdaptOp:
+    """graph.Graph.dcn_adapt: one forward launch sequence and one backward launch sequence of the native DCN operator."""
+
+    def __init__(self, g, name, x, y, prefix):
+        self.g, self.name, self.x, self.y, self.prefix = g, name, x, y, prefix
+        self.gn = self.bname = None
+
+    def inputs(self):
+        return [self.x]
+
+    def emit_backward(self, gy: View):
+        g, x = self.g, self.x
+        gx_buf = g.be.alloc((g.n, x.d, x.h, x.w, x.c), "bf16")
+        gx = View(gx_buf, g.n, x.d, x.h, x.w, x.c, 0, x.c)
+        pg = [g.pgrad[self.prefix + k] for k in (".conv_offset.weight", ".conv_offset.bias", ".conv_adaption.weight")]
+        g.emit_bwd(self.make_bwd(gy, gx, *pg), g.lane_of(self.y), [gy, x], [gx_buf] + pg, "dcn_bwd:" + self.name)
+        if x.needs_grad:
+            x.contribs.append((gx, None))
 
 
 class FuseOp:

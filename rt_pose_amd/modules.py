@@ -113,9 +113,10 @@ class CenterHead(nn.Module):
     def __init__(self, in_channels=128, tasks=[], dataset="cruw_pose", common_heads=dict(), logger=None, init_bias=-2.19,
                  share_conv_channel=64, num_hm_conv=2, weight=0.1, code_weights=[], dcn_head=False):
         super().__init__()
-        if dcn_head:
-            raise NotImplementedError("dcn_head=True cannot run in the reference either (center_head.py:152 passes bn= into "
-                                      "nn.Module.__init__); the deformable operator is available as rt_pose_amd.dcn")
+        # dcn_head=True: the reference's DCNSepHead (center_head.py:111-163) is 2-D and cannot run on the 5-D feature (its
+        # constructor also raises, :152); here the two FeatureAdaption modules run per (frame, z) slice in front of the
+        # SepHead towers (parity unpinned by construction)
+        self.dcn_head = bool(dcn_head)
         if in_channels != share_conv_channel:
             raise NotImplementedError("shared_conv (in_channels != share_conv_channel) is not used by any shipped config")
         if len(tasks) != 1 or num_hm_conv != 2:
@@ -127,6 +128,12 @@ class CenterHead(nn.Module):
         self.heads = OrderedDict((k, v[0]) for k, v in dict(common_heads).items())
         self.heads["hm"] = self.num_classes[0]
         shapes = OrderedDict()
+        if self.dcn_head:
+            for which in ("cls", "reg"):
+                p = "pose_head.tasks.0.feature_adapt_%s" % which
+                shapes[p + ".conv_offset.weight"] = (72, share_conv_channel, 1, 1)
+                shapes[p + ".conv_offset.bias"] = (72,)
+                shapes[p + ".conv_adaption.weight"] = (share_conv_channel, share_conv_channel, 3, 3)
         for hname, ncls in self.heads.items():
             p = "pose_head.tasks.0.%s" % hname
             shapes[p + ".0.weight"] = (32, share_conv_channel, 3, 3, 3)

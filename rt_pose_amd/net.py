@@ -111,8 +111,16 @@ def build_head(g: Graph, feats, heads, prefix="pose_head"):
         feats = g.conv("shared", feats, prefix + ".shared_conv.1.weight",
                        gn=(prefix + ".shared_conv.0.weight", prefix + ".shared_conv.0.bias"), relu=True)
     out = {}
+    # dcn_head (BASELINE config 4): separate deformable feature adaptions for the heat-map and the regression towers
+    # (DCNSepHead.forward, center_head.py:156-163), each on [B*Z, C, Y, X]
+    adapt = {}
+    if (prefix + ".tasks.0.feature_adapt_cls.conv_adaption.weight") in g.params:
+        adapt = {"hm": g.dcn_adapt("adapt.cls", feats, prefix + ".tasks.0.feature_adapt_cls"),
+                 "reg": g.dcn_adapt("adapt.reg", feats, prefix + ".tasks.0.feature_adapt_reg")}
+    src = feats
     for name in heads:
         p = "%s.tasks.0.%s" % (prefix, name)
+        feats = adapt.get(name, src)
         t = g.conv("head.%s.0" % name, feats, p + ".0.weight", bname=p + ".0.bias", relu=True, want_stats=False)
         out[name] = g.conv("head.%s.2" % name, t, p + ".2.weight", bname=p + ".2.bias", out_fp32=True)
     return out

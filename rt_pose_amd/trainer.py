@@ -27,6 +27,14 @@ def init_state_dict(shapes, seed=0):
     g = torch.Generator().manual_seed(seed)
     sd = OrderedDict()
     for name, shape in shapes.items():
+        if ".feature_adapt_" in name:   # FeatureAdaption (center_head.py:44-57): zero offset weights, default conv init otherwise
+            wshape = shapes[name.rsplit(".", 1)[0] + ".weight"]
+            bound = 1.0 / math.sqrt(wshape[1] * wshape[2] * wshape[3])
+            if name.endswith("conv_offset.weight"):
+                sd[name] = torch.zeros(shape)
+            else:
+                sd[name] = (torch.rand(shape, generator=g) * 2 - 1) * bound
+            continue
         is_gn = len(shapes[name.rsplit(".", 1)[0] + ".weight"]) == 1
         if is_gn:
             sd[name] = torch.ones(shape) if name.endswith(".weight") else torch.zeros(shape)

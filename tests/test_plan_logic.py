@@ -149,3 +149,32 @@ def test_no_tail_switch_keeps_every_deferred_item(monkeypatch):
         assert ntail > 50 if flag else ntail <= 3, ntail
     assert float(grads[None].abs().max()) > 0
     assert torch.equal(grads[None], grads["1"])
+
+
+def test_dcn_head_plan_matches_oracle_composition():
+    """BASELINE config 4 at model level: hr3d + dcn_head (two FeatureAdaption modules per (frame, z) slice in front of the
+    towers) against oracle.hrradarpose_ref composed with oracle.dcn_ref -- plan wiring, parameter gradients of the adaption
+    modules, the extra gradient paths into the feature.  (The DCN arithmetic itself is parity-unpinned: oracle/dcn_ref.py.)"""
+    arch, fin, fout, fuse, heads, weight, cw = O.MODEL_CONFIGS["hr3d"]
+    shapes = O.param_shapes(arch, fin, fout, fout, heads, dcn_head=True)
+    sd = O.seeded_state_dict(shapes, seed=1)
+    be = EmuBackend(exact=True)
+    flat = FlatParams(shapes, be.alloc)
+    flat.load_state_dict(sd)
+    dims = (4, 8, 16)
+    eng = PoseEngine(be, flat.values, arch, fuse, heads, weight, cw, 2, dims, pgrads=flat.grads, test_cfg=TEST_CFG)
+    ex = O.synth_example(2, 1, dims, seed=1234)
+    eng.load_input(ex["rdr"]["rdr_tensor"])
+    eng.load_targets(ex["rdr"])
+    eng.run_forward()
+    eng.run_loss_backward()
+    sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ref = O.radar_pose_net(sdr, ex, fuse, weight, cw)
+    ref["loss"][0].backward()
+    assert abs(float(eng.losses()["loss"]) - float(ref["loss"][0])) < 2e-4 * abs(float(ref["loss"][0]))
+    adapt = [k for k in sd if "feature_adapt" in k]
+    assert len(adapt) == 6 and all(k in eng.live_params for k in adapt)
+    for k in sd:
+        if sdr[k].grad is not None:
+            assert rel_err(flat.grads[k], sdr[k].grad) < 1e-2, (k, rel_err(flat.grads[k], sdr[k].grad))
+    assert float(flat.grads["pose_head.tasks.0.feature_adapt_cls.conv_offset.weight"].abs().max()) > 0
