@@ -308,6 +308,7 @@ int rtp_conv_tiled_try(const RtpAct* x, const void* wf, int w_per_sample, const 
                        const struct TiledFuse* fuse = nullptr);
 int rtp_conv_tiled_stat_slots(const RtpAct* x, const RtpConvGeom* g, int transposed);
 
+
 // tile shape of the generic kernel for a problem: (cout tiles per wave, voxel tiles per wave, blocks per sample)
 static void igemm_shape(int N, int Vo, int Co, int* nt, int* mt, int* bps) {
   static const int force_mt = getenv("RTP_IGEMM_MT") ? atoi(getenv("RTP_IGEMM_MT")) : 0;  // experiments: 1 or 4
@@ -319,6 +320,11 @@ static void igemm_shape(int N, int Vo, int Co, int* nt, int* mt, int* bps) {
   *bps = rtp_div_up(Vo, 4 * *mt * 16);
 }
 
+// dgrad_s2_tiled.hip: the LDS-tiled data gradient of the stride-2 convs that read a full-resolution 32-channel tensor
+struct S2Fuse;
+int rtp_dgrad_s2_stat_slots(const RtpAct* gy, const RtpConvGeom* g);
+int rtp_dgrad_s2_try(const RtpAct* gy, const void* wd, const RtpAct* dx, const RtpConvGeom* g, const RtpAct* stat_x, float* stat_out,
+                     const S2Fuse* fuse, hipStream_t s);
 int rtp_conv_tiled_stat_slots(const RtpAct* x, const RtpConvGeom* g, int transposed);
 /* 1 if this (slice) geometry runs on the LDS-tiled kernel -- the only one that accepts rtp_conv_igemm_acc. */
 extern "C" int rtp_conv_tiled_ok(const RtpAct* x, const RtpConvGeom* g, int transposed) {
@@ -329,6 +335,10 @@ extern "C" int rtp_conv_stats_nsplit(const RtpAct* x, const RtpConvGeom* g, int 
   if (!x || !g) return 0;
   const int tiled = rtp_conv_tiled_stat_slots(x, g, transposed);
   if (tiled > 0) return tiled;
+  if (transposed) {
+    const int s2 = rtp_dgrad_s2_stat_slots(x, g);
+    if (s2 > 0) return s2;
+  }
   if ((g->ks != 1 && g->ks != 3) || (g->stride != 1 && g->stride != 2)) return 0;
   const int Co = transposed ? g->ci : g->co;
   const int Vo = transposed ? g->di * g->hi * g->wi : g->dov * g->ho * g->wo;
@@ -377,6 +387,10 @@ static int conv_dispatch(const RtpAct* x, const void* wf, int w_per_sample, cons
     if (rc <= 0) return rc;  // handled (or failed) by the LDS-tiled kernel
   }
   if (acc32) return RTP_ERR_UNSUPPORTED;  // partial-sum input: only the LDS-tiled kernel (rtp_conv_tiled_ok)
+  if (transposed && g->stride == 2 && !btab && !res && !relu && !y_fp32) {
+    const int rc = rtp_dgrad_s2_try(x, wf, y, g, stat_x, stat_out, nullptr, (hipStream_t)stream);
+    if (rc <= 0) return rc;
+  }
   ConvParams p;
   p.x = (const bf16_t*)x->ptr;
   p.w = (const bf16_t*)wf;

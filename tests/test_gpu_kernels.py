@@ -126,7 +126,9 @@ def test_conv_forward(hip, case):
 @pytest.mark.parametrize("case", [
     (2, (4, 8, 16), 32, 32, 3, 1), (2, (4, 8, 16), 32, 64, 3, 2), (1, (2, 4, 20), 64, 32, 1, 1),
     (2, (4, 8, 8), 32, 15, 3, 1), (1, (1, 2, 4), 64, 64, 3, 2), (1, (5, 6, 7), 32, 32, 3, 2),
-    (2, (4, 8, 32), 32, 32, 3, 1), (1, (2, 16, 64), 32, 15, 3, 1), (2, (8, 32, 80), 32, 32, 3, 1)])  # LDS-tiled kernel, flipped taps
+    (2, (4, 8, 32), 32, 32, 3, 1), (1, (2, 16, 64), 32, 15, 3, 1), (2, (8, 32, 80), 32, 32, 3, 1),  # LDS-tiled kernel, flipped taps
+    # stride-2 data gradients on the parity-class kernel (csrc/dgrad_s2_tiled.hip): output dims = 2 x gy dims, Ho % 2, Wo % 16
+    (2, (4, 8, 32), 32, 32, 3, 2), (3, (8, 16, 64), 32, 32, 3, 2), (1, (2, 4, 32), 32, 32, 3, 2), (8, (16, 64, 160), 32, 32, 3, 2)])
 def test_conv_transposed_is_data_gradient(hip, case):
     n, dims, ci, co_real, ks, stride = case
     d, h, w = dims
