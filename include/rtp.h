@@ -127,6 +127,10 @@ int rtp_wgrad_nsplit(const RtpConvGeom* g);
  * a fixed order -- what P, the bias gradient and the GroupNorm un-fold need, without a pass over gy. */
 int rtp_wgrad_q(const RtpAct* gy, const RtpAct* x, const RtpConvGeom* g, int nsplit, float* gp, const void* wd,
                 float* qpart, float* tg, void* stream);
+/* The slab contraction of rtp_wgrad_q for slabs ANY weight-gradient kernel wrote (the generic kernel's, e.g. the stride-2
+ * layers): qpart[n][s][ci] = sum_{tap,co} wd[tap][ci][co] * gp[n][s][tap][co][ci];  gp fp32 [n][nsplit][ntap][co32][ci]. */
+int rtp_qpart_from_slabs(const float* gp, int n, int nsplit, int ntap, int co32, int ci, const void* wd, float* qpart,
+                         void* stream);
 /* dst[0..n) = 0 (device fp32), on `stream`: one launch for every accumulate-into buffer of a step. */
 int rtp_zero_f32(float* dst, long n, void* stream);
 
@@ -215,6 +219,7 @@ typedef struct RtpGnBwd {
   const float* p;                   /* [n][32]  P = sum dxhat, from the class sums (rtp_gn_bwd_p); or NULL with ...      */
   const float* tg;                  /* [n][q_nsplit][27][32] subset-sum partials from rtp_wgrad_q: P is computed from them */
   float* csum_out;                  /* (with tg) optional [n][64][32]: per-boundary-class sums of gy for rtp_wgrad_fold   */
+  const float* csum;                /* or (stride-2 data gradients): [n][64][32] boundary-class sums of gy (rtp_class_sums)  */
   const float* mr;                  /* [n][groups][2] (mean, rstd) saved by rtp_fold_fwd                                 */
   const float* gamma; int groups;
   float* coeff_out;                 /* optional [n*32*5]: the coefficients + dgamma/dbeta partials, as rtp_gn_bwd_coeffs */
@@ -227,12 +232,16 @@ typedef struct RtpGnBwd {
  * the slab contractions), or both NULL (conv without GroupNorm: A = 1, B = C = 0);
  * terms (host, <= 3): gradient contributions of x's OTHER consumers, already complete -- DIRECT addends or another
  * GroupNorm consumer's dxhat with its coefficients (evaluated like rtp_grad_combine's GN terms).
- * Geometries: rtp_conv_tiled_ok(gy, g, 1); others return RTP_ERR_UNSUPPORTED (use rtp_conv_igemm + rtp_grad_combine).
+ * Geometries: rtp_conv_tiled_ok(gy, g, 1) (stride 1), or the stride-2 convs of csrc/dgrad_s2_tiled.hip (32 -> <= 32 channels,
+ * input dims = 2 x output dims, Ho % 2 == 0, Wo % 16 == 0; gn then carries csum instead of tg); others return
+ * RTP_ERR_UNSUPPORTED (use rtp_conv_igemm + rtp_grad_combine).
  * tot_out (optional): per-channel sums of the stored dx, one fp32 partial per workgroup
  * [n][rtp_conv_stats_nsplit(gy, g, 1)][32], which rtp_class_sums_boundary completes to per-boundary-class sums. */
 int rtp_conv_dgrad_fused(const RtpAct* gy, const void* wd, const RtpAct* x, const float* coeff, const RtpGnBwd* gn /*host*/,
                          const RtpTerm* terms /*host*/, int nterms, int mask, const RtpAct* dx, const RtpConvGeom* g,
                          float* tot_out, void* stream);
+
+int rtp_conv_dgrad_fused_ok(const RtpAct* gy, const RtpConvGeom* g);
 
 /* out = mask(relu_src > 0) * sum_k term_k ; GN terms evaluate A*dxhat + B*x + C.  All same resolution. */
 int rtp_grad_combine(const RtpTerm* terms /*host*/, int nterms, const RtpAct* x, const RtpAct* relu_src,

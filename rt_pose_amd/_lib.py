@@ -32,7 +32,7 @@ class RtpConvGeom(C.Structure):
 
 class RtpGnBwd(C.Structure):
     _fields_ = [("qpart", C.c_void_p), ("q_nsplit", C.c_int), ("p", C.c_void_p), ("tg", C.c_void_p), ("csum_out", C.c_void_p),
-                ("mr", C.c_void_p), ("gamma", C.c_void_p), ("groups", C.c_int), ("coeff_out", C.c_void_p)]
+                ("csum", C.c_void_p), ("mr", C.c_void_p), ("gamma", C.c_void_p), ("groups", C.c_int), ("coeff_out", C.c_void_p)]
 
 
 class RtpTerm(C.Structure):
@@ -61,9 +61,11 @@ PROTOTYPES = {
     "rtp_wgrad_nsplit": [_G],
     "rtp_wgrad_q": [_A, _A, _G, _I, _P, _P, _P, _P, _P],
     "rtp_zero_f32": [_P, _L, _P],
+    "rtp_qpart_from_slabs": [_P, _I, _I, _I, _I, _I, _P, _P, _P],
     "rtp_gn_bwd_coeffs_cls": [_P, _I, _P, _I, _P, _P, _P, _P, _G, _I, _I, _I, _P, _P],
     "rtp_conv_dgrad_fused": [_A, _P, _A, _P, _P, _T, _I, _I, _A, _G, _P, _P],
     "rtp_gn_bwd_p": [_P, _I, _P, _P, _G, _I, _I, _P, _P],
+    "rtp_conv_dgrad_fused_ok": [_A, _G],
     "rtp_class_sums_boundary": [_A, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P],
     "rtp_class_sums_p": [_A, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P, _G, _I, _I, _P, _P, _P],
     "rtp_class_sums": [_A, _I, _I, _I, _I, _I, _P, _P, _P],

@@ -132,6 +132,14 @@ class HipBackend:
         keep = (gy, x, gp, wd, qpart, tg)
         return lambda s: check(fn(*args, s), "rtp_wgrad_q") or keep and None
 
+    def qpart_from_slabs(self, gp, n, nsplit, ntap, co32, ci, wd, qpart):
+        fn, args = self.lib.rtp_qpart_from_slabs, (_ptr(gp), n, nsplit, ntap, co32, ci, _ptr(wd), _ptr(qpart))
+        keep = (gp, wd, qpart)
+        return lambda s: check(fn(*args, s), "rtp_qpart_from_slabs") or keep and None
+
+    def conv_dgrad_fused_ok(self, gy, geom):
+        return bool(self.lib.rtp_conv_dgrad_fused_ok(_act(gy), _geom(geom)))
+
     def zero_f32(self, t):
         fn, args = self.lib.rtp_zero_f32, (_ptr(t), t.numel())
         return lambda s: check(fn(*args, s), "rtp_zero_f32") or t is None
@@ -159,7 +167,7 @@ class HipBackend:
         gs = None
         if gn is not None:
             dp = lambda k: gn[k].data_ptr() if gn.get(k) is not None else None
-            gs = _lib.RtpGnBwd(dp("qpart"), gn["q_nsplit"], dp("p"), dp("tg"), dp("csum_out"), dp("mr"), dp("gamma"),
+            gs = _lib.RtpGnBwd(dp("qpart"), gn["q_nsplit"], dp("p"), dp("tg"), dp("csum_out"), dp("csum"), dp("mr"), dp("gamma"),
                                gn["groups"], dp("coeff_out"))
         args = (_act(gy), _ptr(wd), _act(x), _ptr(coeff), C.byref(gs) if gs is not None else None, arr, len(terms), int(mask),
                 _act(dx), g, _ptr(tot_out))

@@ -645,6 +645,9 @@ int rtp_conv_tiled_stat_slots(const RtpAct* x, const RtpConvGeom* g, int transpo
 
 // Returns RTP_OK if it handled the conv, +1 if the geometry is not this kernel's (caller falls through to the
 // generic gather kernel), or a negative error.
+struct S2Fuse { const float* coef[4]; const RtpAct* ex[3]; int nextra, mask; float* tot_out; const RtpGnBwd* gn; };   // dgrad_s2_tiled.hip
+int rtp_dgrad_s2_try(const RtpAct* gy, const void* wd, const RtpAct* dx, const RtpConvGeom* g, const RtpAct* stat_x, float* stat_out,
+                     const S2Fuse* fuse, hipStream_t s);
 struct TiledFuse { const float* coef[4]; const RtpAct* ex[3]; int nextra, mask; float* tot_out; const RtpGnBwd* gn; };
 
 int rtp_conv_tiled_try(const RtpAct* x, const void* wf, int w_per_sample, const float* btab, const RtpAct* res,
@@ -748,6 +751,14 @@ extern "C" int rtp_conv_dgrad_fused(const RtpAct* gy, const void* wd, const RtpA
                                     const RtpTerm* terms /*host*/, int nterms, int mask, const RtpAct* dx,
                                     const RtpConvGeom* g, float* tot_out, void* stream) {
   if (coeff && gn) return RTP_ERR_SHAPE;
+  if (g->stride == 2) {   // the parity-class kernel (dgrad_s2_tiled.hip)
+    S2Fuse f2;
+    f2.nextra = nterms; f2.mask = mask; f2.tot_out = tot_out; f2.gn = gn;
+    f2.coef[0] = coeff;
+    for (int e = 0; e < 3; ++e) { f2.ex[e] = e < nterms ? &terms[e].t : nullptr; f2.coef[1 + e] = e < nterms ? terms[e].coeff : nullptr; }
+    const int rc2 = rtp_dgrad_s2_try(gy, wd, dx, g, x, nullptr, &f2, (hipStream_t)stream);
+    return rc2 > 0 ? RTP_ERR_UNSUPPORTED : rc2;
+  }
   if (!gy || !wd || !x || !dx || !g || nterms < 0 || nterms > 3 || (nterms && !terms)) return RTP_ERR_SHAPE;
   if ((gy->co % 8) || (gy->cs % 8) || (dx->co % 8) || (dx->cs % 8) || (x->co % 8) || (x->cs % 8)) return RTP_ERR_ALIGN;
   if (x->c < 32 || dx->c < 32) return RTP_ERR_SHAPE;
@@ -757,4 +768,13 @@ extern "C" int rtp_conv_dgrad_fused(const RtpAct* gy, const void* wd, const RtpA
   for (int e = 0; e < 3; ++e) { f.ex[e] = e < nterms ? &terms[e].t : nullptr; f.coef[1 + e] = e < nterms ? terms[e].coeff : nullptr; }
   const int rc = rtp_conv_tiled_try(gy, wd, 0, nullptr, nullptr, dx, g, 0, 1, 0, x, nullptr, nullptr, 0, (hipStream_t)stream, &f);
   return rc > 0 ? RTP_ERR_UNSUPPORTED : rc;
+}
+
+int rtp_dgrad_s2_stat_slots(const RtpAct* gy, const RtpConvGeom* g);
+// 1 if rtp_conv_dgrad_fused has a kernel for this data gradient (gy = output-side gradient view, g = forward geometry)
+extern "C" int rtp_conv_dgrad_fused_ok(const RtpAct* gy, const RtpConvGeom* g) {
+  if (!gy || !g) return 0;
+  int Co;
+  if (g->stride == 2) return rtp_dgrad_s2_stat_slots(gy, g) > 0 ? 1 : 0;
+  return (tiled_geometry_ok(gy, g, 1, &Co) && Co == 32) ? 1 : 0;
 }

@@ -12,7 +12,8 @@
 // contiguous brick runs; weights [27][32][32] resident in LDS; the haloed gy tile (2 x 3 x 17 voxels) double-buffered; a
 // brick = 1 x 2 x 16 gy voxels = 2 x 4 x 32 output voxels; wave w owns parity classes w and 7 - w (1+8 / 2+4 taps).
 // Epilogues = conv_tiled.hip's: either dxhat + the (P, Q) statistics, or the FINISHED gradient
-// [x > 0] (A acc + B x + C + sum other consumers' terms) with the coefficients computed in the prologue.
+// [x > 0] (A acc + B x + C + sum other consumers' terms) with the coefficients computed in the prologue (P from the
+// boundary-class sums of gy, Q from the weight-gradient slabs' contraction).
 #include <stdlib.h>
 #include <string.h>
 
@@ -38,8 +39,8 @@ struct S2Params {
   const bf16_t* ex[3]; int ex_cs[3], ex_co[3];
   int nextra, mask;
   float* tot_out;
-  const float* qpart; int q_nsplit; const float* tg; int t_nsplit; const float* gn_mr; const float* gn_gamma; int gn_groups;
-  float gn_m; float* coef_out; float* csum_out;
+  const float* qpart; int q_nsplit; const float* csum; const float* gn_mr; const float* gn_gamma; int gn_groups;
+  float gn_m; float* coef_out;
 };
 
 __device__ __forceinline__ int swz2(int chunk, int xi) { return ((chunk + 2 * (xi >> 2)) & 3) << 3; }  // bf16 elements
@@ -70,53 +71,22 @@ __global__ __launch_bounds__(256, 2) void dgrad_s2_kernel(S2Params p) {
   if constexpr (FUSE) {
     float gq = 0.f, gp_ = 0.f, gmu = 0.f, gr = 0.f, ggam = 0.f;
     if (p.qpart) {
-      float* Ts = reinterpret_cast<float*>(gL);        // [27][32] inclusive subset sums; the gy buffers are still unused
-      float* CSs = Ts + 27 * 32;                       // (2 x 102 x 64 B = 13 KB: room for 3 x 3.4 KB)
+      float* Cs = reinterpret_cast<float*>(gL);        // [64][32] boundary-class sums of gy; the gy buffers are still unused
+      float* CSs = Cs + 64 * 32;                       // [27][32]   (2 x 102 x 64 B = 13 KB: 8 + 3.4 + 1 KB fit)
       float* Pp = CSs + 27 * 32;                       // [8][32]
-      for (int i = tid; i < 27 * 32; i += 256) {
-        const float* src = p.tg + (long)n * p.t_nsplit * 27 * 32 + i;
-        float a = 0.f;
-        for (int s_ = 0; s_ < p.t_nsplit; ++s_) a += src[(long)s_ * 27 * 32];
-        Ts[i] = a;
-      }
+      for (int i = tid; i < 64 * 32; i += 256) Cs[i] = p.csum[(long)n * 64 * 32 + i];
       __syncthreads();
-      // stride 2, pad 1: tap 0 leaves the volume at the FIRST output plane only (input 2v - 1 < 0); taps 1, 2 never do
+      // sum of gy over the output voxels whose tap stays in bounds.  Stride 2, pad 1, even input size: tap 0 leaves the
+      // volume at the FIRST output plane only (input 2v - 1 < 0); taps 1 and 2 never do
       for (int i = tid; i < 27 * 32; i += 256) {
         const int tap = i >> 5, co = i & 31;
         const int kz = tap / 9, ky = (tap / 3) % 3, kx = tap % 3;
         float vv = 0.f;
-#pragma unroll
-        for (int ia = 0; ia < 2; ++ia)
-#pragma unroll
-          for (int ib = 0; ib < 2; ++ib)
-#pragma unroll
-            for (int ic = 0; ic < 2; ++ic) {
-              if ((ia && kz != 0) || (ib && ky != 0) || (ic && kx != 0)) continue;
-              const float t = Ts[((ia * 3 + ib) * 3 + ic) * 32 + co];   // subset "first plane" has index 1 per axis
-              vv += ((ia + ib + ic) & 1) ? -t : t;
-            }
-        CSs[i] = vv;
-      }
-      if (p.csum_out && wg == 0) {
-        for (int i = tid; i < 64 * 32; i += 256) {
-          const int cls = i >> 5, co = i & 31;
-          const int sz = cls & 3, sy = (cls >> 2) & 3, sx = (cls >> 4) & 3;
-          float vv = 0.f;
-          if (sz != 3 && sy != 3 && sx != 3) {
-#pragma unroll
-            for (int a = 0; a < 3; ++a)
-#pragma unroll
-              for (int b = 0; b < 3; ++b)
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                  const float ma = sz == 0 ? (a == 0 ? 1.f : -1.f) : (a == sz ? 1.f : 0.f);
-                  const float mb = sy == 0 ? (b == 0 ? 1.f : -1.f) : (b == sy ? 1.f : 0.f);
-                  const float mc = sx == 0 ? (c == 0 ? 1.f : -1.f) : (c == sx ? 1.f : 0.f);
-                  vv += ma * mb * mc * Ts[((a * 3 + b) * 3 + c) * 32 + co];
-                }
-          }
-          p.csum_out[(long)n * 64 * 32 + i] = vv;
+        for (int cls = 0; cls < 64; ++cls) {
+          const bool out = (kz == 0 && (cls & 1)) || (ky == 0 && (cls & 4)) || (kx == 0 && (cls & 16));
+          if (!out) vv += Cs[cls * 32 + co];
         }
+        CSs[i] = vv;
       }
       __syncthreads();
       {
@@ -410,7 +380,7 @@ static int s2_wgs_per_sample(const RtpConvGeom* g) {
 int rtp_dgrad_s2_stat_slots(const RtpAct* gy, const RtpConvGeom* g) { return s2_geometry_ok(gy, g) ? s2_wgs_per_sample(g) : 0; }
 
 struct TiledFuse;   // conv_tiled.hip
-struct S2Fuse { const float* coef[4]; const RtpAct* ex[3]; int nextra, mask; float* tot_out; const RtpGnBwd* gn; int t_nsplit; };
+struct S2Fuse { const float* coef[4]; const RtpAct* ex[3]; int nextra, mask; float* tot_out; const RtpGnBwd* gn; };
 
 // +1: not this kernel's geometry; RTP_OK / negative otherwise.  stat_x: the conv's input when statistics or the fused epilogue
 // are requested.
@@ -445,11 +415,10 @@ int rtp_dgrad_s2_try(const RtpAct* gy, const void* wd, const RtpAct* dx, const R
     }
     if (fuse->gn) {
       const RtpGnBwd* q = fuse->gn;
-      if (!q->qpart || !q->tg || !q->mr || !q->gamma || q->q_nsplit < 1 || fuse->t_nsplit < 1 || q->groups < 1 || 32 % q->groups)
-        return RTP_ERR_SHAPE;
-      p.qpart = q->qpart; p.q_nsplit = q->q_nsplit; p.tg = q->tg; p.t_nsplit = fuse->t_nsplit; p.gn_mr = q->mr; p.gn_gamma = q->gamma;
+      if (!q->qpart || !q->csum || !q->mr || !q->gamma || q->q_nsplit < 1 || q->groups < 1 || 32 % q->groups) return RTP_ERR_SHAPE;
+      p.qpart = q->qpart; p.q_nsplit = q->q_nsplit; p.csum = q->csum; p.gn_mr = q->mr; p.gn_gamma = q->gamma;
       p.gn_groups = q->groups; p.gn_m = (float)(32 / q->groups) * (float)((long)g->di * g->hi * g->wi);
-      p.coef_out = q->coeff_out; p.csum_out = q->csum_out;
+      p.coef_out = q->coeff_out;
     }
   }
   const size_t shm = sizeof(bf16_t) * (27 * 32 * 32 + 2 * GVOX * 32) + 864 * sizeof(float);

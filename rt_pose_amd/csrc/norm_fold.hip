@@ -642,6 +642,38 @@ extern "C" int rtp_gn_bwd_coeffs_cls(const float* qpart, int q_nsplit, const flo
   return RTP_OK;
 }
 
+// qpart[n][s][ci] = sum_{tap,co} wd[tap][ci][co] * gp[n][s][tap][co][ci]: one block per slab; thread (ci, k) walks the
+// (tap, co) pairs k, k + 256/ci, ... -- slab reads are contiguous along ci, the weights come from L2.
+__global__ __launch_bounds__(256) void qpart_from_slabs_kernel(const float* gp, int ntap, int co32, int ci, const bf16_t* wd,
+                                                              float* qpart) {
+  __shared__ float red[256];
+  const int tid = threadIdx.x, c = tid % ci, k = tid / ci, np = 256 / ci;
+  const float* slab = gp + (long)blockIdx.x * ntap * co32 * ci;
+  float a = 0.f;
+  for (int r = k; r < ntap * co32; r += np) {
+    const int tap = r / co32, co = r - tap * co32;
+    a += slab[(long)r * ci + c] * bf2f(wd[((long)tap * ci + c) * co32 + co]);
+  }
+  red[tid] = a;
+  __syncthreads();
+  if (tid < ci) {
+    float t = 0.f;
+    for (int kk = 0; kk < np; ++kk) t += red[kk * ci + tid];
+    qpart[(long)blockIdx.x * ci + tid] = t;
+  }
+}
+
+extern "C" int rtp_qpart_from_slabs(const float* gp, int n, int nsplit, int ntap, int co32, int ci, const void* wd, float* qpart,
+                                    void* stream) {
+  if (!gp || !wd || !qpart || n < 1 || nsplit < 1 || ntap < 1) return RTP_ERR_SHAPE;
+  if (ci > 256 || 256 % ci || co32 % 32) return RTP_ERR_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  RtpProfScope prof(RTP_FAM_NORM, s);
+  hipLaunchKernelGGL(qpart_from_slabs_kernel, dim3(n * nsplit), dim3(256), 0, s, gp, ntap, co32, ci, (const bf16_t*)wd, qpart);
+  RTP_CHECK_LAUNCH();
+  return RTP_OK;
+}
+
 extern "C" int rtp_gn_bwd_p(const float* cls_part, int cls_nsplit, float* csum_out, const void* wd, const RtpConvGeom* g,
                             int ci_real, int co_real, float* p_out, void* stream) {
   if (!cls_part || !wd || !g || !p_out || cls_nsplit < 1) return RTP_ERR_SHAPE;

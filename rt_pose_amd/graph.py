@@ -489,6 +489,11 @@ class ConvOp:
         brick = ge.ks == 3 and ge.stride == 1 and ge.di % 2 == 0 and ge.hi % 4 == 0 and ge.wi % 16 == 0
         self.tiled_fwd = brick and ge.ci == 32 and ge.co in (16, 32) and self.x.cs == 32
         self.tiled_bwd = brick and ge.ci == 32 and pad_to(ge.co, 32) == 32
+        # ... and of rtp_dgrad_s2_try (csrc/dgrad_s2_tiled.hip): stride-2 data gradients that write a 32-channel tensor of twice
+        # the output's size
+        self.s2_bwd = (ge.ks == 3 and ge.stride == 2 and ge.ci == 32 and pad_to(ge.co, 32) == 32 and ge.di == 2 * ge.do
+                       and ge.hi == 2 * ge.ho and ge.wi == 2 * ge.wo and ge.ho % 2 == 0 and ge.wo % 16 == 0
+                       and not __import__("os").environ.get("RTP_DISABLE_S2_TILED"))
         g.flops["conv_tiled" if self.tiled_fwd else "conv_generic"] += self.alg_flops
         esz = 4 if self.out_fp32 else 2
         self.bytes_fwd = 2 * g.n * self.x.vox * ge.ci + esz * g.n * self.y.vox * self.y.c + (
@@ -522,10 +527,10 @@ class ConvOp:
             g.emit_bwd(be.conv(gy, wd, False, None, None, dxh, ge, False, True, False, (x, pq) if S else None),
                        lane, [gy, wd, x if S else None], [dxh, pq if S else None], "dgrad:" + self.name)
             g.flops["conv_dgrad"] += self.alg_flops
-            g.flops["conv_tiled" if self.tiled_bwd else "conv_generic"] += self.alg_flops
+            g.flops["conv_tiled" if (self.tiled_bwd or self.s2_bwd) else "conv_generic"] += self.alg_flops
             # data gradient: read gy, write dxhat, (GroupNorm: read x for Q)
             nb = 2 * g.n * (gy.vox * pad_to(ge.co, 32) + x.vox * ge.ci * (2 if self.gn else 1))
-            g.alg_bytes["conv_tiled" if self.tiled_bwd else "conv_generic"] += nb
+            g.alg_bytes["conv_tiled" if (self.tiled_bwd or self.s2_bwd) else "conv_generic"] += nb
             if self.tiled_bwd and ge.ci == 32 and g.n * x.vox >= (1 << 20):   # transposed: the kernel's Cout is the conv's Cin
                 g.flops["conv_tiled_full"] += self.alg_flops
                 g.alg_bytes["conv_tiled_full"] += nb
@@ -570,12 +575,15 @@ class ConvOp:
         """This conv's data gradient can write the FINISHED gradient of x: it runs on the LDS-tiled kernel, it is the last
         contribution to x in the sweep, and x's other contributions fit the kernel's epilogue."""
         g, be, ge, x = self.g, self.g.be, self.geom, self.x
-        if not (g.fused_dgrad and self.tiled_bwd and x.needs_grad and g.first_consumer.get(id(x)) is self):
+        s2 = self.s2_bwd and not __import__("os").environ.get("RTP_NO_FUSED_S2")
+        if not (g.fused_dgrad and (self.tiled_bwd or s2) and x.needs_grad and g.first_consumer.get(id(x)) is self):
             return False
         if self.residual is x or x.c != 32 or x.cs != 32 or x.co != 0 or gy.c < 32:
             return False
         if len(x.contribs) > 3 or any(v.c < 32 or (cf is not None and v.c != 32) for v, cf in x.contribs):
             return False
+        if ge.stride == 2:   # Q from the generic weight-gradient kernel's slabs (rtp_qpart_from_slabs), P from gy's class sums
+            return gy.c == 32 and hasattr(be, "qpart_from_slabs") and be.conv_dgrad_fused_ok(gy, ge)
         if self.gn and not (be.wgrad_nsplit(ge) > 0 and gy.c == 32 and pad_to(ge.co, 32) == 32):
             return False   # Q comes from the tiled weight-gradient kernel's slabs
         return be.conv_tiled_ok(gy, ge, True)
@@ -594,9 +602,11 @@ class ConvOp:
         own_kernel = bool(os.environ.get("RTP_GNCOEF_KERNEL"))   # A/B: coefficients by a kernel of their own on the main chain
         # default: the weight-gradient kernel's loader waves sum gy over the volume / faces / edges / corners (tg), from which
         # the data gradient's prologue derives P and the class sums -- no pass over gy, no launch between the two kernels
-        from_wgrad = bool(self.gn) and not own_kernel and not os.environ.get("RTP_CLS_KERNELS")
+        from_wgrad = bool(self.gn) and not own_kernel and not os.environ.get("RTP_CLS_KERNELS") and ge.stride == 1
         csum = pbuf = tg = None
-        if from_wgrad:
+        if ge.stride == 2:
+            csum = g.class_sums_for(self.y, gy, wl, self.name, early=True) if (self.gn or self.bname) else None
+        elif from_wgrad:
             tg = be.alloc((g.n, be.wgrad_nsplit(ge), 27, 32), "f32")   # one partial table per weight-gradient slab
             csum = be.alloc((g.n, 64, gy.c), "f32")
         elif self.gn and not own_kernel and hasattr(be, "class_sums_p"):
@@ -609,7 +619,18 @@ class ConvOp:
         S = S or wgrad_split(gy.vox)
         gp = be.alloc((g.n, S, ntap, co32, ge.ci), "f32")
         coeff = gnq = None
-        if self.gn:
+        if self.gn and ge.stride == 2:
+            # the generic weight-gradient kernel's slabs, contracted with the weights by a small launch; P in the data gradient's
+            # prologue from gy's boundary-class sums
+            qpart = be.alloc((g.n, S, ge.ci), "f32")
+            g.emit_bwd(be.wgrad(gy, x, ge, S, gp), lane, [gy, x], [gp], "wgrad:" + self.name)
+            g.emit_bwd(be.qpart_from_slabs(gp, g.n, S, ntap, co32, ge.ci, self.wd, qpart), lane, [gp, self.wd], [qpart],
+                       "qslab:" + self.name)
+            coeff = be.alloc((g.n * ge.ci * 5,), "f32")
+            gnq = dict(qpart=qpart, q_nsplit=S, p=None, tg=None, csum_out=None, csum=csum, mr=self.mr, gamma=g.params[self.gn[0]],
+                       groups=self.groups, coeff_out=coeff)
+            g.tail_a.append(("gn_param", coeff, g.n, self.ci_real, g.pgrad[self.gn[0]], g.pgrad[self.gn[1]], 0))
+        elif self.gn:
             qpart = be.alloc((g.n, S, ge.ci), "f32")
             g.emit_bwd(be.wgrad_q(gy, x, ge, S, gp, self.wd, qpart, tg), lane, [gy, x, self.wd], [gp, qpart, tg], "wgrad:" + self.name)
             coeff = be.alloc((g.n * ge.ci * 5,), "f32")
@@ -652,7 +673,7 @@ class ConvOp:
                 tot = be.alloc((g.n, ts, 32), "f32")
                 x.grad_tot = (ts, tot)
         if gnq is not None:
-            reads += [gnq["qpart"], gnq["p"], gnq["tg"], self.mr]
+            reads += [gnq["qpart"], gnq["p"], gnq["tg"], gnq.get("csum"), self.mr]
             g.emit_bwd(be.conv_dgrad_fused(gy, self.wd, x, None, terms, x.relu, dx, ge, tot, gnq), lane, reads,
                        [dx_buf, tot, coeff, gnq["csum_out"]], "dgrad:" + self.name)
         else:

@@ -61,8 +61,11 @@ def build_backbone(g: Graph, x_f32, arch, dims, prefix="backbone.backbone", live
         new = _seq(g, "%s.transition%d.%d.0" % (prefix, stage - 1, stage - 1), ys[-1], "t%d" % (stage - 1), 3, 2, True)
         xs.append(_resblock(g, "%s.branches.%d.0" % (sp, nb - 1), new, "s%d.b%d" % (stage, nb - 1)))
         rows = nb if (stage < 4 or live_rows_last is None) else live_rows_last
-        ys = []
-        for i in range(rows):
+        # rows are CREATED last-to-first: the stride-2 conv that starts a lower row's chain from branch 0 then precedes row 0's
+        # fuse node, i.e. it is the first-created consumer of the branch-0 output and its (tiled) data gradient can absorb the
+        # other gradient contributions to that full-resolution tensor (graph.ConvOp._fusable)
+        ys = [None] * rows
+        for i in reversed(range(rows)):
             terms = []
             for j in range(nb):
                 if j == i:
@@ -76,7 +79,7 @@ def build_backbone(g: Graph, x_f32, arch, dims, prefix="backbone.backbone", live
                         t = _seq(g, "%s.fuse_layers.%d.%d.%d" % (sp, i, j, k), t, "s%d.f%d%d.%d" % (stage, i, j, k), 3, 2,
                                  relu=(k != i - j - 1), want_stats=(k != i - j - 1))
                     terms.append(t)
-            ys.append(g.fuse("s%d.row%d" % (stage, i), terms, relu=True))
+            ys[i] = g.fuse("s%d.row%d" % (stage, i), terms, relu=True)
     return ys
 
 

@@ -364,6 +364,18 @@ class EmuBackend:
                             tgv[:, 0, (a * 3 + b) * 3 + c, :gy.c] = sel(sel(sel(gv, 1, a), 2, b), 3, c).sum((1, 2, 3))
         return run
 
+    def qpart_from_slabs(self, gp, n, nsplit, ntap, co32, ci, wd, qpart):
+        def run(s):
+            qpart.copy_(torch.einsum("tic,nstci->nsi", wd.float(), gp.view(n, nsplit, ntap, co32, ci)))
+        return run
+
+    def conv_dgrad_fused_ok(self, gy, geom):
+        g = geom
+        if g.stride == 2:
+            return bool(g.ks == 3 and g.pad == 1 and g.ci == 32 and (g.co + 31) // 32 * 32 == 32 and g.di == 2 * g.do
+                        and g.hi == 2 * g.ho and g.wi == 2 * g.wo and g.ho % 2 == 0 and g.wo % 16 == 0)
+        return self.conv_tiled_ok(gy, g, True) and g.ci == 32
+
     def zero_f32(self, t):
         def run(s):
             t.zero_()
@@ -448,6 +460,10 @@ class EmuBackend:
                 Q = gn["qpart"].view(n, gn["q_nsplit"], -1).sum(1)[:, :c]
                 if gn.get("p") is not None:
                     P = gn["p"].view(n, -1)[:, :c]
+                elif gn.get("csum") is not None:   # P from the boundary-class sums of gy (stride-2 data gradients)
+                    inb = torch.tensor([[_tap_inb(t, kk, g) for kk in range(64)] for t in range(g.ks ** 3)], dtype=torch.float32)
+                    CS = torch.einsum("tk,nkc->ntc", inb, gn["csum"].view(n, 64, -1))
+                    P = torch.einsum("tic,ntc->ni", wd.float(), CS)[:, :c]
                 else:   # P (and the exclusive boundary-class sums) from the inclusive subset sums
                     T = gn["tg"].view(n, gn["q_nsplit"], 27, -1).sum(1).view(n, 3, 3, 3, -1)
                     M = torch.tensor([[1.0, -1.0, -1.0], [0.0, 1.0, 0.0], [0.0, 0.0, 1.0]])   # state (int, first, last) x subset (all, first, last)
@@ -483,7 +499,8 @@ class EmuBackend:
             cok = (g.co + 31) // 32 * 32
             xin = _ncdhw(gy.buf[..., gy.co:gy.co + cok].float())
             wt = wd.float().reshape(k, k, k, g.ci, cok).permute(4, 3, 0, 1, 2)
-            acc = _ndhwc(F.conv_transpose3d(xin, wt, None, g.stride, g.pad))
+            op = [i - ((o - 1) * g.stride - 2 * g.pad + k) for i, o in zip((g.di, g.hi, g.wi), (g.do, g.ho, g.wo))]
+            acc = _ndhwc(F.conv_transpose3d(xin, wt, None, g.stride, g.pad, output_padding=tuple(op)))
             c = acc.shape[-1]
             xv = _sl(x)[..., :c]
             if coeff is not None:

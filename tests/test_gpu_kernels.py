@@ -719,3 +719,69 @@ def test_fused_backward_chain(hip, case):
     EMU.conv_dgrad_fused(gyc, wd.c, xc, coeff_e, terms_c, mask, dxc, geom, tot_e)(None)
     EMU.class_sums_boundary(dxc, 4, None, tot_e, 2, bnd_e)(None)
     assert rel_err(bnd.cpu(), bnd_e) < 2e-2
+
+
+@pytest.mark.parametrize("case", [(2, (4, 8, 32), ("plain",), True), (3, (8, 16, 64), ("gn", "plain"), True),
+                                  (1, (2, 4, 32), (), False), (8, (8, 32, 80), ("plain",), True)])
+def test_fused_stride2_data_gradient(hip, case):
+    """rtp_qpart_from_slabs + rtp_conv_dgrad_fused on the stride-2 parity-class kernel (csrc/dgrad_s2_tiled.hip): Q from the
+    generic weight-gradient slabs, P from gy's boundary-class sums, the finished gradient of the full-resolution input."""
+    n, dims, extras, mask = case
+    d, h, w = dims
+    do, ho, wo = d // 2, h // 2, w // 2
+    ci = co = 32
+    geom = Geom(n, d, h, w, do, ho, wo, ci, co, 3, 2, 1)
+    xp, xc, xg = views(hip, rnd((n, d, h, w, ci), 1, relu=True), n, d, h, w)
+    gp_, gyc, gyg = views(hip, rnd((n, do, ho, wo, co), 2), n, do, ho, wo)
+    w32 = Pair(hip, rnd((co, ci, 27), 3, torch.float32, scale=0.05))
+    wd = Pair(hip, torch.zeros(27, ci, co, dtype=torch.bfloat16))
+    run(hip, EMU.pack_dgrad_w(w32.c, geom, ci, co, wd.c), hip.pack_dgrad_w(w32.g, geom, ci, co, wd.g))
+    assert hip.conv_dgrad_fused_ok(gyg, geom)
+    S = 3
+    slab = Pair(hip, torch.zeros(n, S, 27, co, ci))
+    run(hip, EMU.wgrad(gyc, xc, geom, S, slab.c), hip.wgrad(gyg, xg, geom, S, slab.g))
+    qp = Pair(hip, torch.zeros(n, S, ci))
+    run(hip, EMU.qpart_from_slabs(slab.c, n, S, 27, co, ci, wd.c, qp.c), hip.qpart_from_slabs(slab.g, n, S, 27, co, ci, wd.g, qp.g))
+    assert rel_err(qp.g.sum(1).cpu(), qp.c.sum(1)) < 3e-3
+    cs = Pair(hip, torch.zeros(n, 64, co))
+    run(hip, EMU.class_sums(gyc, 2, torch.zeros(n, 2, 64, co), cs.c), hip.class_sums(gyg, 2, hip.alloc((n, 2, 64, co), "f32"), cs.g))
+    groups = 8
+    mr = Pair(hip, torch.stack([rnd((n, groups), 5, torch.float32, 0.3), rnd((n, groups), 6, torch.float32, 0.2).abs() + 0.5], -1))
+    gam = Pair(hip, rnd((ci,), 7, torch.float32) + 1.5)
+    terms_c, terms_g = [], []
+    for i, kind in enumerate(extras):
+        ep, ec, eg = views(hip, rnd((n, d, h, w, ci), 20 + i), n, d, h, w)
+        if kind == "gn":
+            k = Pair(hip, torch.cat([rnd((n * ci * 3,), 30 + i, torch.float32, 0.5), torch.zeros(n * ci * 2)]))
+            terms_c.append((ec, k.c)); terms_g.append((eg, k.g))
+        else:
+            terms_c.append((ec, None)); terms_g.append((eg, None))
+    cf = Pair(hip, torch.zeros(n * ci * 5))
+    dxp, dxc, dxg = views(hip, torch.zeros(n, d, h, w, ci, dtype=torch.bfloat16), n, d, h, w)
+    gn_c = dict(qpart=qp.c, q_nsplit=S, p=None, tg=None, csum=cs.c, mr=mr.c, gamma=gam.c, groups=groups, coeff_out=cf.c)
+    gn_g = dict(qpart=qp.g, q_nsplit=S, p=None, tg=None, csum=cs.g, mr=mr.g, gamma=gam.g, groups=groups, coeff_out=cf.g)
+    EMU.conv_dgrad_fused(gyc, wd.c, xc, None, terms_c, mask, dxc, geom, None, gn_c)(None)
+    hip.conv_dgrad_fused(gyg, wd.g, xg, None, terms_g, mask, dxg, geom, None, gn_g)(hip.stream())
+    torch.cuda.synchronize()
+    assert rel_err(cf.g.cpu(), cf.c) < 5e-3, "coefficients"
+    check(dxp, BF, "fused stride-2 data gradient %r" % (case,))
+    # the coefficients equal those of the unfused chain (P, Q as sums over the stored dxhat)
+    dxh = hip.alloc((n, d, h, w, ci), "bf16")
+    dxv = View(dxh, n, d, h, w, ci, 0, ci)
+    Sd = hip.conv_stats_nsplit(gyg, geom, True)
+    pq = hip.alloc((n, Sd, ci, 2), "f32")
+    hip.conv(gyg, wd.g, False, None, None, dxv, geom, False, True, False, (xg, pq))(hip.stream())
+    cf_old = hip.alloc((n * ci * 5,), "f32")
+    hip.gn_bwd_coeffs(pq, Sd, mr.g, gam.g, n, ci, groups, d * h * w, cf_old, None, None, 0)(hip.stream())
+    torch.cuda.synchronize()
+    got, old = cf.g.cpu()[:n * ci * 3].view(n, ci, 3), cf_old.cpu()[:n * ci * 3].view(n, ci, 3)
+    for k, nm in enumerate("ABC"):
+        assert rel_err(got[..., k], old[..., k]) < 2e-2, "coefficient %s vs the dxhat-pass chain" % nm
+    # no-GroupNorm variant with totals
+    ts = hip.conv_stats_nsplit(gyg, geom, True)
+    tot = hip.alloc((n, ts, 32), "f32")
+    hip.conv_dgrad_fused(gyg, wd.g, xg, None, terms_g, mask, dxg, geom, tot)(hip.stream())
+    EMU.conv_dgrad_fused(gyc, wd.c, xc, None, terms_c, mask, dxc, geom)(None)
+    torch.cuda.synchronize()
+    check(dxp, BF, "fused stride-2 data gradient without GroupNorm %r" % (case,))
+    assert rel_err(tot.sum(1).cpu(), dxg.buf.float().reshape(n, -1, ci).sum(1).cpu()) < F32

@@ -178,3 +178,31 @@ def test_dcn_head_plan_matches_oracle_composition():
         if sdr[k].grad is not None:
             assert rel_err(flat.grads[k], sdr[k].grad) < 1e-2, (k, rel_err(flat.grads[k], sdr[k].grad))
     assert float(flat.grads["pose_head.tasks.0.feature_adapt_cls.conv_offset.weight"].abs().max()) > 0
+
+
+def test_fused_stride2_data_gradient_route():
+    """Volumes wide enough for the stride-2 parity-class kernel (Wo % 16 == 0): the first conv of a fuse chain from branch 0
+    is the last gradient contribution to the branch-0 output and writes its finished gradient (weight gradient -> slab
+    contraction -> data gradient); gradients still equal the oracle's."""
+    arch, fin, fout, fuse, heads, weight, cw = O.MODEL_CONFIGS["hr3d"]
+    shapes = O.param_shapes(arch, fin, fout, fout, heads)
+    sd = O.seeded_state_dict(shapes, seed=1)
+    dims = (4, 8, 32)
+    be = EmuBackend(exact=True)
+    flat = FlatParams(shapes, be.alloc)
+    flat.load_state_dict(sd)
+    eng = PoseEngine(be, flat.values, arch, fuse, heads, weight, cw, 2, dims, pgrads=flat.grads)
+    tags = [L.tag for L in eng.bwd]
+    assert "qslab:s2.f10.0" in tags and "qslab:s3.f20.0" in tags, "stride-2 data gradients of the fuse chains take the fused route"
+    assert "combine:s2.b0.c3" not in tags and "combine:s3.b0.c3" not in tags, "no fan-in pass left for the branch-0 outputs"
+    ex = O.synth_example(2, 1, dims, seed=1234)
+    eng.load_input(ex["rdr"]["rdr_tensor"])
+    eng.load_targets(ex["rdr"])
+    eng.run_forward()
+    eng.run_loss_backward()
+    sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ref = O.radar_pose_net(sdr, ex, fuse, weight, cw)
+    ref["loss"][0].backward()
+    for k in sd:
+        if sdr[k].grad is not None:
+            assert rel_err(flat.grads[k], sdr[k].grad) < 1e-2, (k, rel_err(flat.grads[k], sdr[k].grad))
