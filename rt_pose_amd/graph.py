@@ -575,7 +575,11 @@ class ConvOp:
         """This conv's data gradient can write the FINISHED gradient of x: it runs on the LDS-tiled kernel, it is the last
         contribution to x in the sweep, and x's other contributions fit the kernel's epilogue."""
         g, be, ge, x = self.g, self.g.be, self.geom, self.x
-        s2 = self.s2_bwd and not __import__("os").environ.get("RTP_NO_FUSED_S2")
+        # The fused route for the stride-2 data gradients (Q from the generic slabs by rtp_qpart_from_slabs, P from gy's class
+        # sums) is built and tested but OFF by default: measured 6.41 ms/step against 6.31 with the same kernel writing dxhat +
+        # statistics and the fan-in pass kept (the slab contraction and the early class sums cost more than the two passes
+        # they remove), and P inherits the LDS-atomic order of the class-sum scan (1e-6 instead of 1e-9 run to run).
+        s2 = self.s2_bwd and bool(__import__("os").environ.get("RTP_FUSED_S2"))
         if not (g.fused_dgrad and (self.tiled_bwd or s2) and x.needs_grad and g.first_consumer.get(id(x)) is self):
             return False
         if self.residual is x or x.c != 32 or x.cs != 32 or x.co != 0 or gy.c < 32:

@@ -180,7 +180,8 @@ def test_dcn_head_plan_matches_oracle_composition():
     assert float(flat.grads["pose_head.tasks.0.feature_adapt_cls.conv_offset.weight"].abs().max()) > 0
 
 
-def test_fused_stride2_data_gradient_route():
+def test_fused_stride2_data_gradient_route(monkeypatch):
+    monkeypatch.setenv("RTP_FUSED_S2", "1")   # built and tested, off by default (graph.ConvOp._fusable)
     """Volumes wide enough for the stride-2 parity-class kernel (Wo % 16 == 0): the first conv of a fuse chain from branch 0
     is the last gradient contribution to the branch-0 output and writes its finished gradient (weight gradient -> slab
     contraction -> data gradient); gradients still equal the oracle's."""
