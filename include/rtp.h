@@ -273,6 +273,8 @@ int rtp_stem_bwd_blocks(void);
 /* NCDHW fp32 -> channels-last bf16 (network input with Cin in {32,64}) and back (feature export). */
 int rtp_pack_ncdhw(const float* x, const RtpAct* y, int n, int c, long vox, void* stream);
 int rtp_unpack_ncdhw(const RtpAct* x, float* y, int n, int c, long vox, void* stream);
+/* fp32 channels-last [n][vox][x_cs] (channels [x_co, x_co + c)) -> fp32 NC(D)HW [n][c][vox]. */
+int rtp_unpack_ncdhw_f32(const float* x, int x_cs, int x_co, float* y, int n, int c, long vox, void* stream);
 /* y = bf16([relu](x (+ x2))): fp32 NC(D)HW -> channels-last, with an optional second addend and ReLU -- the hand-off from the
  * fp32 deformable-convolution operator (section D) back into the plan (FeatureAdaption: relu(conv_adaption(x, offset)),
  * det3d/models/pose_heads/center_head.py:59-62; backward: grad_input of the two paths summed). */

@@ -321,44 +321,37 @@ class HipBackend:
         return lambda s: check(fn(*args, s), "rtp_unpack_ncdhw") or keep and None
 
     # -------------------------------------------------------------- deformable feature adaption (BASELINE config 4)
-    def dcn_adapt(self, x, w_off, b_off, w_ad, y, dg=4):
-        """FeatureAdaption (center_head.py:24-62) on a 5-D feature with Z folded into the batch:
-        y = relu(DeformConv3x3(x2, offset = Conv1x1(x2))) for x2 = [N*D, C, H, W].  The plan's bf16 channels-last tensors are
-        handed to the fp32 NCHW operator of include/rtp.h section D and back (rtp_unpack_ncdhw / rtp_pack_ncdhw_ex); the 1x1
-        offset conv runs as a modulated deformable conv with zero offsets and unit mask (= an ordinary conv with bias), so the
-        whole node stays inside the native ABI.  Returns (forward closure, make_backward(gy, gx, gw_off, gb_off, gw_ad))."""
+    def dcn_adapt(self, x, off_act, koff, w_ad, y, dg=4):
+        """The deformable half of FeatureAdaption (center_head.py:24-62) on a 5-D feature with Z folded into the batch:
+        y = relu(DeformConv3x3(x2, offset)) for x2 = [N*D, C, H, W].  The offsets are an activation of the plan (the 1x1
+        offset conv runs on the plan's own MFMA conv with fp32 output, channels-last [.., >= koff]); the bf16 channels-last
+        tensors are handed to the fp32 NCHW operator of include/rtp.h section D and back (rtp_unpack_ncdhw[_f32],
+        rtp_pack_ncdhw_ex).  Returns (forward closure, make_backward(gy, gx, goff, gw_ad))."""
         lib = self.lib
         N, C, H, W = x.n * x.d, x.c, x.h, x.w
         vox = H * W
-        koff = w_off.shape[0]
         f32 = lambda *shape: self.alloc(shape, "f32")
         xf, off, yf = f32(N, C, H, W), f32(N, koff, H, W), f32(N, C, H, W)
-        zoff, ones = f32(N, 2, H, W), f32(N, 1, H, W)
-        ones.fill_(1.0)
         step = 64
         while N % step:
             step //= 2
-        ws1 = f32(max(1, lib.rtp_dcn_workspace_bytes(1, C, H, W, koff, 1, 1, H, W) // 4))
         ws3 = f32(max(1, lib.rtp_dcn_workspace_bytes(step, C, H, W, C, 3, 3, H, W) // 4))
         xa, ya = _act(x), _act(y)
-        keep = [x, y, w_off, b_off, w_ad, xf, off, yf, zoff, ones, ws1, ws3]
+        keep = [x, y, off_act, w_ad, xf, off, yf, ws3]
 
         def fwd(s):
             check(lib.rtp_unpack_ncdhw(xa, _ptr(xf), N, C, vox, s), "rtp_unpack_ncdhw")
-            check(lib.rtp_modulated_deform_conv_forward(_ptr(xf), _ptr(w_off), _ptr(b_off), _ptr(zoff), _ptr(ones), _ptr(off),
-                                                        _ptr(ws1), N, C, H, W, koff, 1, 1, 1, 1, 0, 0, 1, 1, 1, 1, 1, s),
-                  "offset conv (rtp_modulated_deform_conv_forward 1x1)")
+            check(lib.rtp_unpack_ncdhw_f32(_ptr(off_act.buf), off_act.cs, off_act.co, _ptr(off), N, koff, vox, s), "rtp_unpack_ncdhw_f32")
             check(lib.rtp_deform_conv_forward(_ptr(xf), _ptr(w_ad), _ptr(off), _ptr(yf), _ptr(ws3), N, C, H, W, C, 3, 3, 1, 1, 1, 1,
                                               1, 1, 1, dg, step, s), "rtp_deform_conv_forward")
             check(lib.rtp_pack_ncdhw_ex(_ptr(yf), None, ya, N, C, vox, 1, s), "rtp_pack_ncdhw_ex")
             return keep and None
 
-        def make_backward(gy, gx, gw_off, gb_off, gw_ad):
-            gyf, gi, goff, gi2 = f32(N, C, H, W), f32(N, C, H, W), f32(N, koff, H, W), f32(N, C, H, W)
-            gz, gm = f32(N, 2, H, W), f32(N, 1, H, W)
-            gya, gxa = _act(gy), _act(gx)
-            zero = [gi, goff, gi2, gz, gm, gw_off, gb_off, gw_ad]
-            keepb = [gy, gx, gyf] + zero
+        def make_backward(gy, gx, goff_v, gw_ad):
+            gyf, gi, goff = f32(N, C, H, W), f32(N, C, H, W), f32(N, koff, H, W)
+            gya, gxa, goa = _act(gy), _act(gx), _act(goff_v)
+            zero = [gi, goff, gw_ad]
+            keepb = [gy, gx, goff_v, gyf] + zero
 
             def bwd(s):
                 for t in zero:   # the operator accumulates into its gradient outputs (deform_conv.py:75-76, 86)
@@ -370,11 +363,8 @@ class HipBackend:
                 check(lib.rtp_deform_conv_backward_parameters(_ptr(xf), _ptr(off), _ptr(gyf), _ptr(gw_ad), _ptr(ws3), N, C, H, W, C,
                                                               3, 3, 1, 1, 1, 1, 1, 1, 1, dg, 1.0, step, s),
                       "rtp_deform_conv_backward_parameters")
-                check(lib.rtp_modulated_deform_conv_backward(_ptr(xf), _ptr(w_off), _ptr(b_off), _ptr(zoff), _ptr(ones), _ptr(gi2),
-                                                             _ptr(gw_off), _ptr(gb_off), _ptr(gz), _ptr(gm), _ptr(goff), _ptr(ws1),
-                                                             N, C, H, W, koff, 1, 1, 1, 1, 0, 0, 1, 1, 1, 1, 1, s),
-                      "offset conv backward (rtp_modulated_deform_conv_backward 1x1)")
-                check(lib.rtp_pack_ncdhw_ex(_ptr(gi), _ptr(gi2), gxa, N, C, vox, 0, s), "rtp_pack_ncdhw_ex")
+                check(lib.rtp_pack_ncdhw_ex(_ptr(gi), None, gxa, N, C, vox, 0, s), "rtp_pack_ncdhw_ex")
+                check(lib.rtp_pack_ncdhw_ex(_ptr(goff), None, goa, N, koff, vox, 0, s), "rtp_pack_ncdhw_ex")
                 return keepb and None
             return bwd
         return fwd, make_backward

@@ -634,6 +634,10 @@ static int tiled_wgs_per_sample(const RtpConvGeom* g) {
   int wgs = total_wgs / g->n;  // workgroups per sample: one workgroup per CU when N divides 256
   if (wgs < 1) wgs = 1;
   if (wgs * 2 > tiles) wgs = (tiles + 1) / 2;
+  // small volumes: a workgroup pays ~6 us of fixed cost (55 KB of weights, pipeline ramp) whatever it computes; with fewer than
+  // `minb` bricks per team that dominates (experiment knob; 0 = off)
+  static const int minb = getenv("RTP_TILED_MIN_BRICKS") ? atoi(getenv("RTP_TILED_MIN_BRICKS")) : 0;
+  if (minb > 0 && wgs * 2 * minb > tiles) { wgs = tiles / (2 * minb); if (wgs < 1) wgs = 1; }
   return wgs;
 }
 

@@ -709,7 +709,9 @@ __global__ __launch_bounds__(256) void class_sums_kernel(const bf16_t* g, int cs
   const long vox = (long)D * H * W;
   for (int i = tid; i < 64 * c; i += 256) cls_sum[i] = 0.f;
   __syncthreads();
-  const int cpv = c >> 3;           // 4, 8, 16 or 32: divides 64
+  const int cpv = c >> 3;           // 4, 8, 16 or 32 divide 64 (shuffle reduction); other widths (96 channels: 12) leave the
+  const bool pow2 = (64 % cpv) == 0;  // last 64 % cpv lanes idle and every lane adds its own sums to the LDS table
+  const int act = pow2 ? 64 : (64 / cpv) * cpv;
   const int chunk = lane % cpv;
   const int rows = D * H;
   const int rps = (rows + nsplit - 1) / nsplit;
@@ -722,7 +724,7 @@ __global__ __launch_bounds__(256) void class_sums_kernel(const bf16_t* g, int cs
     for (int j = 0; j < 8; ++j) a_in[j] = a_f[j] = a_l[j] = 0.f;
     const bf16_t* row = g + ((long)n * vox + (long)r * W) * cs + co;
     const bool edge_only = boundary_only && czy == 0 && W > 2;   // interior row: only its first and last voxel
-    for (int i = lane; i < (edge_only ? 2 : W) * cpv; i += 64) {
+    for (int i = lane; lane < act && i < (edge_only ? 2 : W) * cpv; i += act) {
       const int x = edge_only ? ((i / cpv) ? W - 1 : 0) : i / cpv;
       bf16x8 t = ld_bf16x8(row + (long)x * cs + chunk * 8);
       const bool first = (x == 0), last = (x == W - 1);
@@ -736,14 +738,16 @@ __global__ __launch_bounds__(256) void class_sums_kernel(const bf16_t* g, int cs
       }
     }
     // reduce over lanes that share a chunk (lane, lane+cpv, ...)
+    if (pow2) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j)
-      for (int o = 32; o >= cpv; o >>= 1) {
-        a_in[j] += __shfl_xor(a_in[j], o, 64);
-        a_f[j] += __shfl_xor(a_f[j], o, 64);
-        a_l[j] += __shfl_xor(a_l[j], o, 64);
-      }
-    if (lane < cpv) {
+      for (int j = 0; j < 8; ++j)
+        for (int o = 32; o >= cpv; o >>= 1) {
+          a_in[j] += __shfl_xor(a_in[j], o, 64);
+          a_f[j] += __shfl_xor(a_f[j], o, 64);
+          a_l[j] += __shfl_xor(a_l[j], o, 64);
+        }
+    }
+    if (pow2 ? lane < cpv : lane < act) {
       const int cf = czy | (1 << 4) | ((W == 1) << 5), cl = czy | (1 << 5);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -791,7 +795,7 @@ extern "C" int rtp_class_sums(const RtpAct* gy, int n, int d, int h, int w, int 
                               void* stream) {
   if (!gy || !scratch) return RTP_ERR_SHAPE;
   const int c = gy->c;
-  if (c % 8 || c > 256 || (64 % (c / 8))) return RTP_ERR_UNSUPPORTED;
+  if (c % 8 || c > 256) return RTP_ERR_UNSUPPORTED;
   if ((gy->cs % 8) || (gy->co % 8)) return RTP_ERR_ALIGN;
   hipStream_t s = (hipStream_t)stream;
   RtpProfScope prof(RTP_FAM_NORM, s);

@@ -784,6 +784,27 @@ __global__ __launch_bounds__(256) void pack_ex_kernel(const float* x, const floa
   }
 }
 
+__global__ __launch_bounds__(256) void unpack_f32_kernel(const float* x, int x_cs, int x_co, float* y, int n, int c, long vox) {
+  const long total = (long)n * c * vox;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long v = i % vox;
+    const int ch = (int)((i / vox) % c);
+    const int nn = (int)(i / (vox * c));
+    y[i] = x[((long)nn * vox + v) * x_cs + x_co + ch];
+  }
+}
+
+// fp32 channels-last [n][vox][cs] (channels [co, co + c)) -> fp32 NC(D)HW [n][c][vox]: hands an fp32 conv output of the plan
+// (the offsets of the DCN head) to the NCHW deformable-convolution operator
+extern "C" int rtp_unpack_ncdhw_f32(const float* x, int x_cs, int x_co, float* y, int n, int c, long vox, void* stream) {
+  if (!x || !y || n < 1 || c < 1 || x_co + c > x_cs) return RTP_ERR_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  RtpProfScope prof(RTP_FAM_POINTWISE, s);
+  hipLaunchKernelGGL(unpack_f32_kernel, dim3(grid_for((long)n * vox * c)), dim3(256), 0, s, x, x_cs, x_co, y, n, c, vox);
+  RTP_CHECK_LAUNCH();
+  return RTP_OK;
+}
+
 extern "C" int rtp_pack_ncdhw_ex(const float* x, const float* x2, const RtpAct* y, int n, int c, long vox, int relu, void* stream) {
   if (!x || !y || y->c % 8 || c > y->c || (y->cs % 8) || (y->co % 8)) return RTP_ERR_SHAPE;
   hipStream_t s = (hipStream_t)stream;

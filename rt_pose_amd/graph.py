@@ -250,17 +250,19 @@ class Graph:
 
     def dcn_adapt(self, name, x: Act, prefix):
         """FeatureAdaption of the reference's DCN head (center_head.py:24-62) with Z folded into the batch:
-        relu(DeformConv3x3_dg4(x, Conv1x1(x))) per (frame, z) slice.  Parameters: prefix + .conv_offset.{weight,bias},
-        .conv_adaption.weight (2-D shapes, reference names)."""
-        w_off, b_off, w_ad = (self.param(prefix + ".conv_offset.weight"), self.param(prefix + ".conv_offset.bias"),
-                              self.param(prefix + ".conv_adaption.weight"))
+        relu(DeformConv3x3_dg4(x, Conv1x1(x))) per (frame, z) slice.  The 1x1 offset conv is an ordinary conv node of the plan
+        (MFMA kernel, fp32 output, its own weight / bias / data gradients); the deformable conv is the native operator.
+        Parameters: prefix + .conv_offset.{weight,bias}, .conv_adaption.weight (2-D shapes, reference names)."""
+        w_ad = self.param(prefix + ".conv_adaption.weight")
         assert x.c == x.c_real == w_ad.shape[1] and x.cs == x.c and x.co == 0, (name, x.c, x.c_real)
+        off = self.conv(name + ".off", x, prefix + ".conv_offset.weight", bname=prefix + ".conv_offset.bias", ks=1, out_fp32=True,
+                        want_stats=False)
         y = self.act(name, x.c_real, x.dims, relu=True)
-        op = DcnAdaptOp(self, name, x, y, prefix)
+        op = DcnAdaptOp(self, name, x, off, y, prefix)
         y.producer = op
         self.ops.append(op)
-        op.fwd_fn, op.make_bwd = self.be.dcn_adapt(x, w_off, b_off, w_ad, y)
-        self.emit_fwd(op.fwd_fn, self.lane_of(y), [x, w_off, b_off, w_ad], [y], "dcn:" + name)
+        op.fwd_fn, op.make_bwd = self.be.dcn_adapt(x, off, off.c_real, w_ad, y)
+        self.emit_fwd(op.fwd_fn, self.lane_of(y), [x, off, w_ad], [y], "dcn:" + name)
         return y
 
     def forward_list(self):
@@ -871,21 +873,25 @@ class CoSplitConvOp:
 class DcnAdaptOp:
     """graph.Graph.dcn_adapt: one forward launch sequence and one backward launch sequence of the native DCN operator."""
 
-    def __init__(self, g, name, x, y, prefix):
-        self.g, self.name, self.x, self.y, self.prefix = g, name, x, y, prefix
+    def __init__(self, g, name, x, off, y, prefix):
+        self.g, self.name, self.x, self.off, self.y, self.prefix = g, name, x, off, y, prefix
         self.gn = self.bname = None
 
     def inputs(self):
-        return [self.x]
+        return [self.x, self.off]
 
     def emit_backward(self, gy: View):
-        g, x = self.g, self.x
+        g, x, off = self.g, self.x, self.off
         gx_buf = g.be.alloc((g.n, x.d, x.h, x.w, x.c), "bf16")
         gx = View(gx_buf, g.n, x.d, x.h, x.w, x.c, 0, x.c)
-        pg = [g.pgrad[self.prefix + k] for k in (".conv_offset.weight", ".conv_offset.bias", ".conv_adaption.weight")]
-        g.emit_bwd(self.make_bwd(gy, gx, *pg), g.lane_of(self.y), [gy, x], [gx_buf] + pg, "dcn_bwd:" + self.name)
+        oc = pad_to(pad_to(off.c_real, 16), 32)   # the offset conv's data gradient contracts full 32-channel K steps
+        go_buf = g.be.alloc((g.n, x.d, x.h, x.w, oc), "bf16")
+        go = View(go_buf, g.n, x.d, x.h, x.w, oc, 0, oc)
+        gw = g.pgrad[self.prefix + ".conv_adaption.weight"]
+        g.emit_bwd(self.make_bwd(gy, gx, go, gw), g.lane_of(self.y), [gy, x, off], [gx_buf, go_buf, gw], "dcn_bwd:" + self.name)
         if x.needs_grad:
             x.contribs.append((gx, None))
+        off.contribs.append((go, None))
 
 
 class FuseOp:

@@ -520,34 +520,39 @@ class EmuBackend:
                 tot_out.view(g.n, -1, tot_out.shape[-1])[:, 0, :c] = _sl(dx)[..., :c].reshape(g.n, -1, c).sum(1)
         return run
 
-    def dcn_adapt(self, x, w_off, b_off, w_ad, y, dg=4):
-        """HipBackend.dcn_adapt: FeatureAdaption per (frame, z) slice.  The deformable convolution itself is the oracle's
-        (oracle/dcn_ref.py, parity unpinned) -- this emulation checks the plan wiring and the fp32 <-> bf16 hand-off."""
+    def dcn_adapt(self, x, off_act, koff, w_ad, y, dg=4):
+        """HipBackend.dcn_adapt: the deformable half of FeatureAdaption per (frame, z) slice; the offsets arrive as an fp32
+        channels-last activation.  The deformable convolution itself is the oracle's (oracle/dcn_ref.py, parity unpinned) --
+        this emulation checks the plan wiring and the fp32 <-> bf16 hand-off."""
         from oracle import dcn_ref
         state = {}
 
-        def to2d(v):
+        def to2d(v, c=None):
             t = _sl(v)
-            n, d, h, w, c = t.shape
-            return t.permute(0, 1, 4, 2, 3).reshape(n * d, c, h, w), (n, d, h, w, c)
+            n, d, h, w, cc = t.shape
+            c = c or cc
+            return t[..., :c].permute(0, 1, 4, 2, 3).reshape(n * d, c, h, w), (n, d, h, w, c)
 
         def fwd(s):
             x2, (n, d, h, w, c) = to2d(x)
-            off = F.conv2d(x2, w_off.detach().float(), b_off.detach().float())
-            y2 = F.relu(dcn_ref.deform_conv2d(x2, off, w_ad.detach().float(), 1, 1, 1, 1, dg))
+            off2, _ = to2d(off_act, koff)
+            y2 = F.relu(dcn_ref.deform_conv2d(x2, off2, w_ad.detach().float(), 1, 1, 1, 1, dg))
             _store(y, y2.reshape(n, d, c, h, w).permute(0, 1, 3, 4, 2))
-            state["x2"] = x2
+            state["x2"], state["off2"] = x2, off2
 
-        def make_backward(gy, gx, gw_off, gb_off, gw_ad):
+        def make_backward(gy, gx, goff_v, gw_ad):
             @torch.enable_grad()
             def bwd(s):
                 x2 = state["x2"].detach().clone().requires_grad_(True)
-                wo, bo, wa = [t.detach().float().clone().requires_grad_(True) for t in (w_off, b_off, w_ad)]
-                y2 = dcn_ref.deform_conv2d(x2, F.conv2d(x2, wo, bo), wa, 1, 1, 1, 1, dg)
+                o2 = state["off2"].detach().clone().requires_grad_(True)
+                wa = w_ad.detach().float().clone().requires_grad_(True)
+                y2 = dcn_ref.deform_conv2d(x2, o2, wa, 1, 1, 1, 1, dg)
                 g2, (n, d, h, w, c) = to2d(gy)     # already masked by the adapted feature's ReLU
                 y2.backward(g2)
                 _store(gx, x2.grad.reshape(n, d, c, h, w).permute(0, 1, 3, 4, 2))
-                gw_off.copy_(wo.grad); gb_off.copy_(bo.grad); gw_ad.copy_(wa.grad)
+                goff_v.buf.zero_()
+                _store(goff_v, o2.grad.reshape(n, d, koff, h, w).permute(0, 1, 3, 4, 2))
+                gw_ad.copy_(wa.grad)
             return bwd
         return fwd, make_backward
 
