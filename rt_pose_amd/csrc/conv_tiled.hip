@@ -24,17 +24,48 @@
 #include "rtp_prof.h"
 
 #define TZ 2
-#define TY 4
+#ifndef RTP_TILED_TY
+#define RTP_TILED_TY 4
+#endif
+#define TY RTP_TILED_TY
 #define TX 32
-#define HZ (TZ + 2)
 #define HY (TY + 2)
 #define HX (TX + 2)
-#define HALO_VOX (HZ * HY * HX)          // 816
-#define HALO_ITEMS (HALO_VOX * 4)        // 16-B items
-#define STAGE_BATCH 13
-#define STAGE_ROUNDS 1                   // 13 * 256 = 3328 >= 3264: all of a thread's loads in flight at once
+#define PLANE_VOX (HY * HX)              // haloed voxels of one z-plane
+#define PAIR_VOX (2 * PLANE_VOX)         // the staging unit is a PAIR of z-planes
+#define PAIR_ITEMS (PAIR_VOX * 4)        // sixteen-byte items
+// pairs a team keeps in LDS.  2 (with TY 4: 2 x 26 KB): the two pairs under the MFMAs; the pair the next brick is missing is
+// requested in the team's load phase, into the slot of the pair the finished brick no longer needs.  3 (with TY 2: 3 x 17 KB):
+// one more slot, requested a phase earlier (under the previous brick's MFMAs).
+#define RING (TY == 4 ? 2 : 3)
+#define HALO_VOX (RING * PAIR_VOX)       // 816 voxels x 64 B = 52 KB per team either way
+#ifndef RTP_TILED_DIST
+#define RTP_TILED_DIST 4
+#endif
+#ifndef RTP_TILED_WBUF
+#define RTP_TILED_WBUF 2
+#endif
+#define STAGE_BATCH ((PAIR_ITEMS + 255) / 256)   // a thread's loads of one pair, all in flight at once
 
-__device__ __attribute__((aligned(16))) bf16_t g_zero_line_c[8];  // zero-initialised: source of padding voxels
+__device__ __attribute__((aligned(16))) bf16_t g_zero_line_c[8];
+#ifdef RTP_TILED_PROF
+// Cycle-counter instrumentation (separate build, tools/tiled_prof.sh): per wave of workgroup 0, s_memtime deltas summed over
+// the phases: [0] compute-phase preamble, [1] MFMA loop, [2] barrier after compute, [3] load-phase issue, [4] epilogue,
+// [5] barrier after load, [6] compute phases, [7] load phases
+__device__ long long g_tiled_wg[512][2];   // per workgroup: entry and exit (s_memrealtime, 10-ns ticks)
+extern "C" int rtp_tiled_prof_wgs(long long* host) {
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_tiled_wg), sizeof(long long) * 1024) == hipSuccess ? 0 : -1;
+}
+__device__ long long g_tiled_prof[9][8];   // row 8 (wave 0): kernel entry -> weights staged -> phase loop -> loop end, realtime stamps
+extern "C" int rtp_tiled_prof_read(long long* host) {
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_tiled_prof), sizeof(long long) * 72) == hipSuccess ? 0 : -1;
+}
+#define PROF_T(var) const long long var = __builtin_readcyclecounter()
+#define PROF_ADD(slot, a, b) prof_acc[slot] += (b) - (a)
+#else
+#define PROF_T(var)
+#define PROF_ADD(slot, a, b)
+#endif  // zero-initialised: source of padding voxels
 
 struct TiledParams {
   const bf16_t* x; const bf16_t* w; const float* btab; const bf16_t* res; void* y;  // res: residual (AUX 1) or the statistics' second operand (AUX 2)
@@ -46,6 +77,8 @@ struct TiledParams {
   int x_cs, x_co;          // x may be a 32-channel slice of a wider tensor (channel stride / first channel)
   const float* acc32; int a_cs;  // optional fp32 partial result [N][vox][a_cs] added before bias / ReLU (input-channel split)
   int dbg;  // timing experiments only (RTP_TILED_DBG): bit0 = skip the MFMA loop, bit1 = skip staging, bit2 = skip epilogue
+  int tsync;  // 0: the two teams swap roles at workgroup barriers (lockstep); 1: each team synchronises only its own four waves
+              // (LDS counter), the teams drift freely; 2: as 1, with the MFMA loop of team 0 / 1 at wave priority 3 / 2
   // FUSE: a data gradient that writes the FINISHED gradient of its input tensor x (= p.res, the AUX operand):
   //   y = [x > 0] * (A0 * acc + Bt * x + Ct + sum_e Ae * ex_e)
   // coef[0] = this conv's GroupNorm-backward coefficients [N][32][3] (A, B, C) or null (1, 0, 0); ex_e = gradient terms of
@@ -66,6 +99,25 @@ struct TiledParams {
   // [N][64][32] the deferred weight-gradient fold needs.
   const float* tg; float* csum_out;
 };
+
+// Barrier over the four waves of one team: a monotonic LDS counter (no reset, so no re-use hazard); `target` = 4 x the
+// number of barriers the team has passed including this one.  s_waitcnt 0 first: the team's LDS-DMA writes (vmcnt) and LDS
+// reads of the brick (lgkmcnt) must be complete before the other waves overwrite / read it.
+__device__ __forceinline__ void team_sync(unsigned* cnt, unsigned target, int lane) {
+  __builtin_amdgcn_s_waitcnt(0);
+  if (lane == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+  while (__hip_atomic_load(cnt, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
+}
+
+// One LDS-DMA piece (16 B per lane, wave-linear LDS destination from M0), issued from inline assembly so that the compiler does
+// not model it: hipcc treats the builtin as a FLAT access to both memories, and while one is outstanding it (a) drains vmcnt
+// before the next ds_read of the same address space and (b) turns every counted lgkmcnt wait into lgkmcnt(0) -- which is
+// exactly what a brick requested under the previous brick's MFMA loop must not cost.  The price: the kernel waits for these
+// itself (s_waitcnt 0 before the barrier that hands the brick to the MFMA phase).
+__device__ __forceinline__ void lds_dma16(const bf16_t* src, unsigned lds_wave_base) {
+  const unsigned m0v = __builtin_amdgcn_readfirstlane(lds_wave_base);
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" : : "s"(m0v), "v"(src) : "memory", "m0");
+}
 
 __device__ __forceinline__ int swz(int chunk, int xi) { return ((chunk + 2 * (xi >> 2)) & 3) << 3; }  // bf16 elements
 
@@ -97,8 +149,14 @@ __global__ __launch_bounds__(512, 2) void conv_tiled_kernel(TiledParams p) {
   constexpr int NEX = FUSE ? FUSEX - 1 : 0;
   static_assert(!FUSE || (NT == 2 && !HAS_BTAB && AUX == 2 && !STAT), "fused data-gradient epilogue: 32 channels, x in the AUX slot");
   extern __shared__ __attribute__((aligned(16))) bf16_t lds[];
+  PROF_T(pk0);
+#ifdef RTP_TILED_PROF
+  const long long rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
   bf16_t* wL = lds;                                   // [27][NT*16][32]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // wave index through readfirstlane: everything derived from it (team, brick coordinates, ring slots, row bases) is then
+  // wave-uniform to the compiler and lives on the scalar unit, beside the vector / matrix issue instead of in it
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int team = wave >> 2, tw = wave & 3, ttid = tid & 255;
   bf16_t* xL = lds + 27 * NT * 16 * 32 + team * (HALO_VOX * 32);  // this team's [HZ][HY][HX][32]
   // class-bias table in LDS: 27 reachable classes (per axis: interior / first / last; every axis is >= 2 long here)
@@ -282,6 +340,14 @@ __global__ __launch_bounds__(512, 2) void conv_tiled_kernel(TiledParams p) {
     }
     if (tid < 256) bL[192 + tid] = 0.f;   // per-wave running totals [8 waves][32]
   }
+  PROF_T(pk1);
+  unsigned* tcnt = reinterpret_cast<unsigned*>(bL + 27 * p.Co) + team;
+  unsigned tbar = 0;
+  if (p.tsync) {
+    if (tid < 2) reinterpret_cast<unsigned*>(bL + 27 * p.Co)[tid] = 0u;
+    __syncthreads();   // weights, tables and the counters are in place for both teams
+  }
+#define PHASE_SYNC() do { if (p.tsync) { tbar += 4; team_sync(tcnt, tbar, lane); } else __syncthreads(); } while (0)
   const long vox_n = (long)n * p.D * p.H * p.W;
   // Staging descriptors (brick-independent, computed once): element offset of each of this thread's 13 sixteen-byte
   // items relative to the brick origin, its swizzled LDS slot, and six "on the low/high face of the halo" bits.
@@ -294,10 +360,10 @@ __global__ __launch_bounds__(512, 2) void conv_tiled_kernel(TiledParams p) {
   for (int k = 0; k < STAGE_BATCH; ++k) {
     const int i = ttid + k * 256;
     const int cp = i & 3, hv = i >> 2;
-    const int hx = hv % HX, hy = (hv / HX) % HY, hz = hv / (HX * HY);
+    const int hx = hv % HX, hy = (hv / HX) % HY, hz = hv / (HX * HY);   // hz: 0 / 1 = first / second plane of the pair
     const int ck = (cp - 2 * (hx >> 2)) & 3;
-    s_pk[k] = (hz == 0) | ((hz == HZ - 1) << 1) | ((hy == 0) << 2) | ((hy == HY - 1) << 3) | ((hx == 0) << 4) | (hx << 8);
-    s_rel[k] = (((hz - 1) * p.H + (hy - 1)) * p.W + (hx - 1)) * p.x_cs + ck * 8;
+    s_pk[k] = (hz == 0) | ((hz == 1) << 1) | ((hy == 0) << 2) | ((hy == HY - 1) << 3) | ((hx == 0) << 4) | (hx << 8);
+    s_rel[k] = ((hz * p.H + (hy - 1)) * p.W + (hx - 1)) * p.x_cs + ck * 8;
   }
   const bf16_t* xn = p.x + vox_n * p.x_cs + p.x_co;
   // contiguous, balanced runs of bricks per team, z fastest: consecutive bricks share two of their four haloed z-planes,
@@ -307,6 +373,37 @@ __global__ __launch_bounds__(512, 2) void conv_tiled_kernel(TiledParams p) {
   int max_tiles = (p.tiles_per_sample + p.teams_per_sample - 1) / p.teams_per_sample;  // workgroup-uniform
   const int nphase = 2 * max_tiles + 2;  // every compute phase is followed by a load phase of the same team (its epilogue runs there)
   int load_k = 0, comp_k = 0;
+  // The team's LDS region is a FIFO ring of RING plane pairs.  A brick (2 output z-planes) reads planes z0-1 .. z0+2 = the pair
+  // (z0-1, z0) and the pair (z0+1, z0+2): along a z-column (bricks are dealt z fastest) the upper pair of one brick is the lower
+  // pair of the next, so a brick inside a column stages ONE pair (26 KB) and only a column's first brick stages two.  The pair a
+  // brick is missing is requested at the START of the previous brick's MFMA phase, into the ring slot that phase does not read,
+  // so its HBM latency hides under that whole phase (the second pair of a column's first brick follows in the load phase, into
+  // the slot the finished brick frees).  A brick always computes from the last two pairs staged: slots cur-2, cur-1.
+  int ring_cur = 0;
+  // coordinates of the team's next brick to compute (z fastest), advanced brick by brick: no divisions in the phase loop
+  int c_tz = t_begin % p.tiles_z, c_tx = (t_begin / p.tiles_z) % p.tiles_x, c_ty = t_begin / (p.tiles_z * p.tiles_x);
+  auto issue_pair = [&](int tz, int tx, int ty, int upper) {   // team-uniform arguments
+    const int zp = tz * TZ - 1 + 2 * upper, y0 = ty * TY, x0 = tx * TX;
+    const int org = ((zp * p.H + y0) * p.W + x0) * p.x_cs;
+    const int tflg = (zp < 0) | ((zp + 1 >= p.D) << 1) | ((y0 == 0) << 2) | ((y0 + TY == p.H) << 3) | ((x0 == 0) << 4);
+    const int xlim = (p.W - x0 + 1) << 8;  // haloed x index >= this lies beyond the volume (W need not be a multiple of TX)
+    const unsigned dst_b = (unsigned)(size_t)(__attribute__((address_space(3))) bf16_t*)lds + 2u * (unsigned)((xL - lds) + ring_cur * (PAIR_VOX * 32));
+    const int ring_slot = ring_cur;
+    ring_cur = ring_cur == RING - 1 ? 0 : ring_cur + 1;
+    if (p.dbg & 2) return;
+#pragma unroll
+    for (int k = 0; k < STAGE_BATCH; ++k) {
+      if (k * 256 + ttid < PAIR_ITEMS) {  // (TY 4: the last piece is half a wave -- EXEC masks the other lanes' transfers)
+        const bool oob = (s_pk[k] & tflg & 0xff) || s_pk[k] >= xlim;
+        const bf16_t* src = oob ? g_zero_line_c : xn + org + s_rel[k];
+        if (RING == 3) lds_dma16(src, dst_b + 16u * (unsigned)(k * 256 + (ttid & ~63)));
+        else   // issued and awaited within one load phase: the compiler's own bookkeeping (counted vmcnt for the residual) is right
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                           (__attribute__((address_space(3))) void*)(xL + ring_slot * (PAIR_VOX * 32) + (k * 256 + (ttid & ~63)) * 8), 16, 0, 0);
+      }
+    }
+  };
+  // (a brick stages both pairs when it is the team's first or the first of a z-column)
   // State of the brick whose MFMAs are done but whose epilogue is still pending: the epilogue (bias, residual, ReLU,
   // rounding, stores, statistics) runs at the start of the team's NEXT load phase, right after that phase's global loads
   // have been issued -- it then overlaps both those loads' latency and the OTHER team's MFMA phase, instead of sitting
@@ -322,8 +419,13 @@ __global__ __launch_bounds__(512, 2) void conv_tiled_kernel(TiledParams p) {
 #pragma unroll
   for (int j = 0; j < 4 * NT; ++j) st_p[j] = st_q[j] = 0.f;
 
+#ifdef RTP_TILED_PROF
+  long long prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  PROF_T(pk2);
+#endif
   for (int phase = 0; phase < nphase; ++phase) {
     const bool loading = ((phase + team) & 1) == 0;  // team-uniform (=> wave-uniform)
+    PROF_T(pt0);
     if (loading) {
       bf16x8 exr[NEX > 0 ? NEX : 1][TY];
       if constexpr (NEX > 0) {
@@ -337,23 +439,18 @@ __global__ __launch_bounds__(512, 2) void conv_tiled_kernel(TiledParams p) {
           }
         }
       }
-      if (load_k < my_tiles && !(p.dbg & 2)) {
-        const int tile = t_begin + load_k;
-        const int tz = tile % p.tiles_z, tx = (tile / p.tiles_z) % p.tiles_x, ty = tile / (p.tiles_z * p.tiles_x);  // z fastest
-        const int z0 = tz * TZ, y0 = ty * TY, x0 = tx * TX;
-        const int org = ((z0 * p.H + y0) * p.W + x0) * p.x_cs;
-        const int tflg = (z0 == 0) | ((z0 + TZ == p.D) << 1) | ((y0 == 0) << 2) | ((y0 + TY == p.H) << 3) | ((x0 == 0) << 4);
-        const int xlim = (p.W - x0 + 1) << 8;  // haloed x index >= this lies beyond the volume (W need not be a multiple of TX)
-#pragma unroll
-        for (int k = 0; k < STAGE_BATCH; ++k) {
-          if (k * 256 + (ttid & ~63) < HALO_ITEMS) {  // wave-uniform: 3264 items = 51 waves' worth
-            const bool oob = (s_pk[k] & tflg & 0xff) || s_pk[k] >= xlim;
-            const bf16_t* src = oob ? g_zero_line_c : xn + org + s_rel[k];
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(xL + (k * 256 + (ttid & ~63)) * 8), 16, 0, 0);
-          }
+      if (load_k < my_tiles) {   // brick load_k == the next brick to compute: (c_tz, c_tx, c_ty)
+        const bool col_start = load_k == 0 || c_tz == 0;
+        if (RING == 2) {
+          if (col_start) issue_pair(c_tz, c_tx, c_ty, 0);
+          issue_pair(c_tz, c_tx, c_ty, 1);
+        } else if (col_start) {
+          if (load_k == 0) issue_pair(c_tz, c_tx, c_ty, 0);   // (later columns: the lower pair went out under the previous brick's MFMAs)
+          issue_pair(c_tz, c_tx, c_ty, 1);
         }
       }
+      PROF_T(pt1);
+      PROF_ADD(3, pt0, pt1);
       if (pend) {
         pend = false;
         // ---- epilogue of the previous brick: bias + residual + ReLU in fp32, one rounding, one 16-B store per lane and row
@@ -441,7 +538,11 @@ __global__ __launch_bounds__(512, 2) void conv_tiled_kernel(TiledParams p) {
               bf16x8 o;
 #pragma unroll
               for (int j = 0; j < 8; ++j) o[j] = f2bf(ev[j]);
+#ifdef RTP_EXP_NO_NT
               st_bf16x8(yp, o);
+#else
+              st_bf16x8_nt(yp, o);
+#endif
               if constexpr (FUSE) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) tsum[j] += bf2f(o[j]);   // totals of the stored (rounded) values
@@ -494,12 +595,23 @@ __global__ __launch_bounds__(512, 2) void conv_tiled_kernel(TiledParams p) {
         }
       }
       ++load_k;
+      if (RING == 3) __builtin_amdgcn_s_waitcnt(0);   // this team's LDS-DMA pieces (not modelled by the compiler) have landed
+#ifdef RTP_TILED_PROF
+      PROF_T(pt2);
+      PROF_ADD(4, pt1, pt2);
+      PHASE_SYNC();
+      PROF_T(pt3);
+      PROF_ADD(5, pt2, pt3);
+      prof_acc[7] += 1;
+      continue;
+#endif
     } else if (comp_k < load_k && comp_k < my_tiles) {
-      const int tile = t_begin + comp_k;
       ++comp_k;
-      if (((tile / p.tiles_z) % p.tiles_x) * TX + wx * 16 >= p.W) { __syncthreads(); continue; }  // wave-uniform: this wave's 16-voxel column is padding
-      const int tz = tile % p.tiles_z, tx = (tile / p.tiles_z) % p.tiles_x, ty = tile / (p.tiles_z * p.tiles_x);  // z fastest
-      const int z0 = tz * TZ, y0 = ty * TY, x0 = tx * TX;
+      const int z0 = c_tz * TZ, y0 = c_ty * TY, x0 = c_tx * TX;
+      if (++c_tz == p.tiles_z) { c_tz = 0; if (++c_tx == p.tiles_x) { c_tx = 0; ++c_ty; } }
+      const int slot_a = (ring_cur + RING - 2) % RING, slot_b = (ring_cur + RING - 1) % RING;   // the last two pairs staged
+      if (RING == 3 && comp_k < my_tiles) issue_pair(c_tz, c_tx, c_ty, c_tz == 0 ? 0 : 1);   // next brick's missing pair, into the free slot
+      if (x0 + wx * 16 >= p.W) { PHASE_SYNC(); continue; }  // wave-uniform: this wave's 16-voxel column is padding
 
 #pragma unroll
       for (int t = 0; t < TY; ++t)
@@ -521,27 +633,38 @@ __global__ __launch_bounds__(512, 2) void conv_tiled_kernel(TiledParams p) {
           else pre_r4[t] = *reinterpret_cast<const bf16x4*>(rp);
         }
       }
+      if (p.tsync == 2) { if (team == 0) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(2); }
+      PROF_T(pc1);
+      PROF_ADD(0, pt0, pc1);
       if (!(p.dbg & 1)) {
         // Software pipeline over 54 steps = 9 (dz,dx) tap groups x HY haloed rows.  Step s reads its row fragment three
         // steps early into a 4-deep register ring, and a group's 3*NT weight fragments are read during the previous
         // group (double-buffered); sched_barrier fences pin that order (left alone, hipcc issues each ds_read right
         // before its first use and waits lgkmcnt(0) on it, exposing the LDS latency to the single MFMA wave per SIMD).
-        constexpr int DIST = 3, NSTEP = 9 * HY, CO = NT * 16;
-        bf16x8 fa[2][3][NT], fb[4];
+        constexpr int DIST = RTP_TILED_DIST, FBN = 8, WB = RTP_TILED_WBUF, NSTEP = 9 * HY, CO = NT * 16;
+        bf16x8 fa[WB][3][NT], fb[FBN];   // weights: three (dz,dx) groups in registers, fetched two groups ahead
         // Four per-lane LDS byte addresses serve all 54 + 54 fragment reads; everything else is a compile-time
         // immediate (weights: tap and cout tile; rows: dz and haloed row) -- address registers were the spill source.
         typedef const __attribute__((address_space(3))) bf16x8* lds_frag;
         const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) bf16_t*)lds;
         const unsigned a_base = lds0 + 2u * (v * 32 + swz(q, v));  // swz(q, nt*16+v) == swz(q, v): 8*nt == 0 mod 4
-        unsigned b_base[3];
+        unsigned b_base[3][3];   // [dz][dx]: plane wz + dz of the brick's four = pair (wz + dz) >> 1, plane (wz + dz) & 1 of it
 #pragma unroll
-        for (int dx = 0; dx < 3; ++dx) {
-          const int hx = wx * 16 + v + dx;
-          b_base[dx] = lds0 + 2u * (unsigned)((xL - lds) + (wz * HY * HX + hx) * 32 + swz(q, hx));
+        for (int dz = 0; dz < 3; ++dz) {
+          const int j = wz + dz;
+          const int pv = ((j >> 1) ? slot_b : slot_a) * PAIR_VOX + (j & 1) * PLANE_VOX;
+#pragma unroll
+          for (int dx = 0; dx < 3; ++dx) {
+            const int hx = wx * 16 + v + dx;
+            b_base[dz][dx] = lds0 + 2u * (unsigned)((xL - lds) + (pv + hx) * 32 + swz(q, hx));
+            // opaque VGPR: left visible, hipcc keeps the wave-uniform slot part in an SGPR and spends a v_add per fragment read
+            // instead of folding the row offset into the ds_read's immediate
+            asm volatile("" : "+v"(b_base[dz][dx]));
+          }
         }
         auto row_frag = [&](int s) {
           const int g = s / HY, ry = s - g * HY, dz = g / 3, dx = g - dz * 3;
-          return *(lds_frag)(b_base[dx] + 2u * ((dz * HY + ry) * HX * 32));
+          return *(lds_frag)(b_base[dz][dx] + 2u * (ry * HX * 32));
         };
         auto load_a = [&](int g, bf16x8 (&a)[3][NT]) {
           const int dz = g / 3, dx = g - dz * 3;
@@ -552,32 +675,66 @@ __global__ __launch_bounds__(512, 2) void conv_tiled_kernel(TiledParams p) {
               a[dy][nt] = *(lds_frag)(a_base + 2u * ((((dz * 3 + dy) * 3 + dx) * CO + nt * 16) * 32));
         };
         load_a(0, fa[0]);
+        if (WB == 3) load_a(1, fa[1]);
 #pragma unroll
-        for (int s = 0; s < DIST; ++s) fb[s & 3] = row_frag(s);
+        for (int s = 0; s < DIST; ++s) fb[s % FBN] = row_frag(s);
 #pragma unroll
         for (int s = 0; s < NSTEP; ++s) {
           const int g = s / HY, ry = s - g * HY;
-          if (s + DIST < NSTEP) fb[(s + DIST) & 3] = row_frag(s + DIST);
-          if (ry == 0 && g + 1 < 9) load_a(g + 1, fa[(g + 1) & 1]);
+#ifndef RTP_EXP_NOLDS
+          if (s + DIST < NSTEP) fb[(s + DIST) % FBN] = row_frag(s + DIST);
+          if (ry == 0 && g + WB - 1 < 9) load_a(g + WB - 1, fa[(g + WB - 1) % WB]);
+#endif
+#ifndef RTP_EXP_NOFENCE
           __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
           for (int dy = 0; dy < 3; ++dy) {
             const int t = ry - dy;
             if (t >= 0 && t < TY) {
 #pragma unroll
               for (int nt = 0; nt < NT; ++nt)
-                acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[g & 1][dy][nt], fb[s & 3], acc[t][nt], 0, 0, 0);
+                acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[g % WB][dy][nt], fb[s % FBN], acc[t][nt], 0, 0, 0);
             }
           }
+#ifndef RTP_EXP_NOFENCE
           __builtin_amdgcn_sched_barrier(0);
+#endif
         }
       }
-      if (p.dbg & 4) { __syncthreads(); continue; }
+      if (p.tsync == 2) __builtin_amdgcn_s_setprio(0);
+#ifdef RTP_TILED_PROF
+      __builtin_amdgcn_s_waitcnt(0);   // (MFMA results are not covered by a counter: the delta below is issue time)
+      PROF_T(pc2);
+      PROF_ADD(1, pc1, pc2);
+      if (!(p.dbg & 4)) { pend = true; e_oz = oz; e_ox = ox; e_y0 = y0; e_kzx = kzx; }
+      PHASE_SYNC();
+      PROF_T(pc3);
+      PROF_ADD(2, pc2, pc3);
+      prof_acc[6] += 1;
+      continue;
+#endif
+      if (p.dbg & 4) { PHASE_SYNC(); continue; }
       pend = true;
       e_oz = oz; e_ox = ox; e_y0 = y0; e_kzx = kzx;
     }
-    __syncthreads();
+    PHASE_SYNC();
   }
+#ifdef RTP_TILED_PROF
+  if (tid == 0 && blockIdx.x < 512) { g_tiled_wg[blockIdx.x][0] = rt0; g_tiled_wg[blockIdx.x][1] = __builtin_amdgcn_s_memrealtime(); }
+  if (blockIdx.x == 0 && lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) g_tiled_prof[wave][k] = prof_acc[k];
+    if (wave == 0) {
+      PROF_T(pk3);
+      g_tiled_prof[8][0] = pk1 - pk0; g_tiled_prof[8][1] = pk2 - pk1; g_tiled_prof[8][2] = pk3 - pk2;
+      g_tiled_prof[8][4] = __builtin_amdgcn_s_memrealtime() - rt0;   // in-kernel time of workgroup 0, 10-ns ticks
+      g_tiled_prof[8][3] = __builtin_amdgcn_s_memrealtime();   // 100 MHz: kernel-to-kernel period from successive launches
+    }
+  }
+#endif
+  if (p.tsync) __syncthreads();   // both teams done before the workgroup-wide reductions below
+#undef PHASE_SYNC
   if constexpr (FUSE) {
     if (p.tot_out && tid < 32) {   // (the phase loop ends with a barrier)
       float a = 0.f;
@@ -679,6 +836,8 @@ int rtp_conv_tiled_try(const RtpAct* x, const void* wf, int w_per_sample, const 
   p.teams_per_sample = wgs * 2;
   static const int dbg = getenv("RTP_TILED_DBG") ? atoi(getenv("RTP_TILED_DBG")) : 0;
   p.dbg = dbg;
+  static const int tsync = getenv("RTP_TILED_SYNC") ? atoi(getenv("RTP_TILED_SYNC")) : 0;
+  p.tsync = tsync;
   p.nextra = 0; p.mask = 0; p.tot_out = nullptr;
   p.qpart = nullptr; p.q_nsplit = 0; p.gn_p = p.gn_mr = p.gn_gamma = nullptr; p.gn_groups = 1; p.gn_m = 1.f; p.coef_out = nullptr;
   p.tg = nullptr; p.csum_out = nullptr;
@@ -703,7 +862,7 @@ int rtp_conv_tiled_try(const RtpAct* x, const void* wf, int w_per_sample, const 
     }
   }
   const int nt = Co / 16;
-  const size_t shm = sizeof(bf16_t) * (27 * (size_t)Co * 32 + 2 * (size_t)HALO_VOX * 32) + 27 * (size_t)Co * sizeof(float);
+  const size_t shm = sizeof(bf16_t) * (27 * (size_t)Co * 32 + 2 * (size_t)HALO_VOX * 32) + 27 * (size_t)Co * sizeof(float) + 16;
   RtpProfScope prof((Co == 32 && (long)p.N * p.D * p.H * p.W >= (1L << 20)) ? RTP_FAM_CONV_TILED_FULL : RTP_FAM_CONV_TILED, s);
   using Kern = void (*)(TiledParams);
 #define RTP_TILED_ROW(NT, BT) \

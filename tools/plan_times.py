@@ -15,6 +15,7 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--rep", type=int, default=10)
     ap.add_argument("--top", type=int, default=60)
+    ap.add_argument("--convs", action="store_true")
     a = ap.parse_args()
     from rt_pose_amd import configs, synth
     from rt_pose_amd.trainer import DataParallelTrainer
@@ -57,6 +58,29 @@ def main():
     for t, phase, lane, tag in out:
         lag[(phase, lane)] = lag.get((phase, lane), 0) + t
     print("-- by lane", {k: round(v) for k, v in sorted(lag.items())})
+    if a.convs:
+        # per conv layer: geometry, kernel family, algorithmic GFLOP and the three launches' times / TFLOP/s
+        tm = {(phase, tag): t for t, phase, lane, tag in out}
+        print("-- conv layers (ci -> co, k, stride, input dims; fwd / dgrad / wgrad us and TFLOP/s)")
+        tot3 = [0.0, 0.0, 0.0]
+        for op in tr.engine.graph.ops:
+            ge = getattr(op, "geom", None)
+            if ge is None or not hasattr(op, "alg_flops"):
+                continue
+            f = tm.get(("fwd", "conv:" + op.name), 0.0)
+            d = tm.get(("bwd", "dgrad:" + op.name), 0.0)
+            w = tm.get(("bwd", "wgrad:" + op.name), 0.0)
+            fam = "tiled" if getattr(op, "tiled_fwd", False) else "generic"
+            famb = "tiled" if (getattr(op, "tiled_bwd", False) or getattr(op, "s2_bwd", False)) else "generic"
+            famw = "tiled" if getattr(op, "tiled_wgrad", False) else "generic"
+            gf = op.alg_flops / 1e9
+            tf = lambda t: gf / t * 1e-3 if t else 0.0
+            if fam == "generic": tot3[0] += f
+            if famb == "generic": tot3[1] += d
+            if famw == "generic": tot3[2] += w
+            print("%-16s %3d->%3d k%d s%d [%2d,%3d,%3d] %6.2f GF | %-7s %6.1f us %5.0f TF | %-7s %6.1f us %5.0f TF | %-7s %6.1f us %5.0f TF" % (
+                op.name, ge.ci, ge.co, ge.ks, ge.stride, ge.di, ge.hi, ge.wi, gf, fam, f, tf(f), famb, d, tf(d), famw, w, tf(w)))
+        print("generic totals: fwd %.0f us, dgrad %.0f us, wgrad %.0f us" % tuple(tot3))
     print("-- top launches")
     for t, phase, lane, tag in sorted(out, key=lambda r: -r[0])[:a.top]:
         nb = bybytes.get((phase, tag), 0)
