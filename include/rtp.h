@@ -177,6 +177,9 @@ int rtp_tail_desc_gn_param(const float* coeff, int n, int c, float* dgamma, floa
                            void* desc /*host*/, int* blocks, int* shm_bytes);
 /* Weight packing that needs no activations (a conv without GroupNorm; wf == NULL: only the data-gradient packing wd):
  * batched so one launch at the start of a step serves every layer. */
+/* wt[tap][co_pad][ci] (fp32) = w[co][ci][tap], rows co >= co_real zero: the weight layout rtp_conv_gn_fused reads. */
+int rtp_tail_desc_pack_wt(const float* w, int co_real, int co_pad, int ci, int ntap, float* wt, void* desc /*host*/, int* blocks,
+                          int* shm_bytes);
 int rtp_tail_desc_fold_fwd(const float* w, const float* bias, const float* gamma, const float* beta, const float* stats,
                            int nsplit, int groups, float eps, const RtpConvGeom* g, int ci_real, int co_real, void* wf,
                            float* btab, float* mr, void* wd, void* desc /*host*/, int* blocks, int* shm_bytes);
@@ -242,6 +245,21 @@ int rtp_conv_dgrad_fused(const RtpAct* gy, const void* wd, const RtpAct* x, cons
                          float* tot_out, void* stream);
 
 int rtp_conv_dgrad_fused_ok(const RtpAct* gy, const RtpConvGeom* g);
+
+/* GroupNorm -> Conv3d(3x3x3, stride 1, 32 -> 16|32 channels) -> [+ residual] -> [ReLU] in ONE launch: the fold of the
+ * input's GroupNorm into per-sample weights and the boundary-class bias table (rtp_fold_fwd) happens in the prologue of
+ * every workgroup of the LDS-tiled conv kernel, from the statistics partials the producer of x left behind -- no fold launch
+ * between two convs of a chain (create_conv's 'gcr' order, hr3d.py:58-61,91-93).  Same arithmetic as rtp_fold_fwd followed by
+ * rtp_conv_igemm (fp32 weight * fp32 scale -> one bf16 rounding; group statistics summed in double).
+ * w: the conv's fp32 weights in tap-major order [27][Co][32] (rtp_tail_desc_pack_wt of the master [co_real][32][27]); stats: [n][nsplit][32][2] (sum, sum of squares) of x;
+ * mr (optional out): [n][groups][2] (mean, rstd) for the backward pass; stat_out as rtp_conv_igemm_stats.
+ * Geometries: rtp_conv_tiled_ok(x, g, 0); others RTP_ERR_UNSUPPORTED. */
+typedef struct RtpGnFold {
+  const float* w; const float* bias; const float* gamma; const float* beta; const float* stats;
+  int nsplit, groups, co_real; float eps; float* mr;
+} RtpGnFold;
+int rtp_conv_gn_fused(const RtpAct* x, const RtpGnFold* f /*host*/, const RtpAct* res, const RtpAct* y, const RtpConvGeom* g,
+                      int relu, float* stat_out, void* stream);
 
 /* out = mask(relu_src > 0) * sum_k term_k ; GN terms evaluate A*dxhat + B*x + C.  All same resolution. */
 int rtp_grad_combine(const RtpTerm* terms /*host*/, int nterms, const RtpAct* x, const RtpAct* relu_src,

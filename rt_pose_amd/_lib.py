@@ -35,6 +35,11 @@ class RtpGnBwd(C.Structure):
                 ("csum", C.c_void_p), ("mr", C.c_void_p), ("gamma", C.c_void_p), ("groups", C.c_int), ("coeff_out", C.c_void_p)]
 
 
+class RtpGnFold(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("bias", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p), ("stats", C.c_void_p),
+                ("nsplit", C.c_int), ("groups", C.c_int), ("co_real", C.c_int), ("eps", C.c_float), ("mr", C.c_void_p)]
+
+
 class RtpTerm(C.Structure):
     _fields_ = [("t", RtpAct), ("coeff", C.c_void_p), ("d", C.c_int), ("h", C.c_int), ("w", C.c_int)]
 
@@ -64,6 +69,7 @@ PROTOTYPES = {
     "rtp_qpart_from_slabs": [_P, _I, _I, _I, _I, _I, _P, _P, _P],
     "rtp_gn_bwd_coeffs_cls": [_P, _I, _P, _I, _P, _P, _P, _P, _G, _I, _I, _I, _P, _P],
     "rtp_conv_dgrad_fused": [_A, _P, _A, _P, _P, _T, _I, _I, _A, _G, _P, _P],
+    "rtp_conv_gn_fused": [_A, _P, _A, _A, _G, _I, _P, _P],
     "rtp_gn_bwd_p": [_P, _I, _P, _P, _G, _I, _I, _P, _P],
     "rtp_conv_dgrad_fused_ok": [_A, _G],
     "rtp_class_sums_boundary": [_A, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P],
@@ -76,6 +82,7 @@ PROTOTYPES = {
     "rtp_tail_desc_class_reduce": [_P, _I, _I, _I, _P, _P, C.POINTER(_I), C.POINTER(_I)],
     "rtp_tail_desc_wgrad_fold": [_P, _I, _P, _P, _P, _P, _I, _G, _I, _I, _P, _P, _I, _P, C.POINTER(_I), C.POINTER(_I)],
     "rtp_tail_desc_gn_param": [_P, _I, _I, _P, _P, _I, _P, C.POINTER(_I), C.POINTER(_I)],
+    "rtp_tail_desc_pack_wt": [_P, _I, _I, _I, _I, _P, _P, C.POINTER(_I), C.POINTER(_I)],
     "rtp_tail_desc_fold_fwd": [_P, _P, _P, _P, _P, _I, _I, _F, _G, _I, _I, _P, _P, _P, _P, _P, C.POINTER(_I), C.POINTER(_I)],
     "rtp_tail_launch": [_P, _P, _I, _I, _I, _P],
     "rtp_grad_combine": [_T, _I, _A, _A, _A, _I, _L, _P],

@@ -112,6 +112,16 @@ class HipBackend:
         fn = self.lib.rtp_conv_igemm
         return lambda s: check(fn(*args, s), "rtp_conv_igemm") or keep and None
 
+    def conv_gn_fused(self, x, wt, bias, gamma, beta, stats, nsplit, groups, eps, co_real, mr, res, y, geom, relu, stat_out=None):
+        """rtp_conv_gn_fused: GroupNorm fold in the conv kernel's prologue (no fold launch); the LDS-tiled geometries only.
+        wt: the weights in tap-major fp32 order [27][co_pad][32] (tail item "pack_wt")."""
+        fn, g = self.lib.rtp_conv_gn_fused, _geom(geom)
+        fs = _lib.RtpGnFold(_ptr(wt), _ptr(bias), _ptr(gamma), _ptr(beta), _ptr(stats), int(nsplit), int(groups), int(co_real),
+                            float(eps), _ptr(mr))
+        args = (_act(x), C.byref(fs), _act(res), _act(y), g, int(relu), _ptr(stat_out))
+        keep = (x, wt, bias, gamma, beta, stats, mr, res, y, stat_out, fs)
+        return lambda s: check(fn(*args, s), "rtp_conv_gn_fused") or keep and None
+
     def conv_stats_nsplit(self, x, geom, transposed):
         return self.lib.rtp_conv_stats_nsplit(_act(x), _geom(geom), int(transposed))
 
@@ -218,7 +228,7 @@ class HipBackend:
     def tail(self, items):
         """One launch for a list of independent deferred items (rtp_tail_*): tuples ("class_reduce", scratch, nsplit,
         n, c, out) | ("wgrad_fold", <wgrad_fold args>) | ("gn_param", coeff, n, c, dgamma, dbeta, acc) |
-        ("fold_fwd", <fold_fwd args>)."""
+        ("fold_fwd", <fold_fwd args>) | ("pack_wt", w, co_real, co_pad, ci, ntap, wt)."""
         lib = self.lib
         nb = lib.rtp_tail_desc_bytes()
         host = C.create_string_buffer(nb * len(items))
@@ -239,6 +249,9 @@ class HipBackend:
                 rc = lib.rtp_tail_desc_fold_fwd(_ptr(w), _ptr(bias), _ptr(gamma), _ptr(beta), _ptr(stats), nsplit, groups,
                                                 eps, _geom(geom), ci_real, co_real, _ptr(wf), _ptr(btab), _ptr(mr),
                                                 _ptr(wd), d, C.byref(blocks), C.byref(sb))
+            elif kind == "pack_wt":
+                w, co_real, co_pad, ci, ntap, wt = a
+                rc = lib.rtp_tail_desc_pack_wt(_ptr(w), co_real, co_pad, ci, ntap, _ptr(wt), d, C.byref(blocks), C.byref(sb))
             elif kind == "gn_param":
                 rc = lib.rtp_tail_desc_gn_param(_ptr(a[0]), a[1], a[2], _ptr(a[3]), _ptr(a[4]), int(a[5]), d,
                                                 C.byref(blocks), C.byref(sb))

@@ -305,7 +305,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
 int rtp_conv_tiled_try(const RtpAct* x, const void* wf, int w_per_sample, const float* btab, const RtpAct* res,
                        const RtpAct* y, const RtpConvGeom* g, int relu, int transposed, int y_fp32,
                        const RtpAct* stat_x, float* stat_out, const float* acc32, int acc_cs, hipStream_t s,
-                       const struct TiledFuse* fuse = nullptr);
+                       const struct TiledFuse* fuse = nullptr, const RtpGnFold* fold = nullptr);
 int rtp_conv_tiled_stat_slots(const RtpAct* x, const RtpConvGeom* g, int transposed);
 
 

@@ -98,6 +98,10 @@ struct TiledParams {
   // wgrad_tiled.hip) when gn_p is null; workgroup 0 of a sample then also writes the per-boundary-class sums csum_out
   // [N][64][32] the deferred weight-gradient fold needs.
   const float* tg; float* csum_out;
+  // FOLD (forward): the GroupNorm of the conv's input is folded in the prologue (rtp_conv_gn_fused): fp32 weights in tap-major
+  // order [27][Co][32], the input's statistics partials [N][f_nsplit][32][2]; w / btab are then unused
+  const float* fw; const float* fbias; const float* fgamma; const float* fbeta; const float* fstats;
+  int f_nsplit, f_groups, f_co_real; float f_eps; float* f_mr;
 };
 
 // Barrier over the four waves of one team: a monotonic LDS counter (no reset, so no re-use hazard); `target` = 4 x the
@@ -171,8 +175,98 @@ __global__ __launch_bounds__(512, 2) void conv_tiled_kernel(TiledParams p) {
   const int v = lane & 15, q = lane >> 4;
   const int wz = tw >> 1, wx = tw & 1;
 
+  if (p.fw) {   // kernel-uniform: GroupNorm fold in the prologue (both teams' brick regions are scratch until the phase loop)
+    float* scr = reinterpret_cast<float*>(lds + 27 * NT * 16 * 32);
+    float* sc_l = scr;                                       // [32] gamma * rstd
+    float* sh_l = scr + 32;                                  // [32] beta - mean * gamma * rstd
+    float2* part = reinterpret_cast<float2*>(scr + 64);      // [512] statistics partials
+    float* Tt = scr + 1088;                                  // [27][32]  T[tap][co] = sum_ci w * shift
+    float* mrl = scr + 1952;                                 // [groups][2]
+    // Every global load of the prologue is requested up front (one memory round trip for all of it): the statistics partials,
+    // gamma / beta, and this thread's share of the fp32 weights in tap-major order [27][Co][32] (rtp_tail_desc_pack_wt) --
+    // items (tap, output channel, 8-input-channel chunk) = two coalesced 16-byte loads each, in the order of the LDS image.
+    constexpr int ITEMS = 27 * NT * 16 * 4, NIT = (ITEMS + 511) / 512;
+    float wv[NIT][8];
+#pragma unroll
+    for (int m = 0; m < NIT; ++m) {
+      const int i = tid + m * 512;
+      const f32x4* wr = reinterpret_cast<const f32x4*>(p.fw + (long)(i < ITEMS ? i : 0) * 8);
+      const f32x4 lo = wr[0], hi = wr[1];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { wv[m][j] = lo[j]; wv[m][4 + j] = hi[j]; }
+    }
+    float gam_r = 0.f, bet_r = 0.f;
+    if (tid < 32) { gam_r = p.fgamma[tid]; bet_r = p.fbeta[tid]; }
+    {
+      const int c = tid & 31, pt = tid >> 5;
+      float a0 = 0.f, a1 = 0.f;
+      const float2* q = reinterpret_cast<const float2*>(p.fstats) + ((long)n * p.f_nsplit) * 32 + c;
+      for (int s_ = pt; s_ < p.f_nsplit; s_ += 16) { const float2 v = q[(long)s_ * 32]; a0 += v.x; a1 += v.y; }
+      part[tid] = make_float2(a0, a1);
+    }
+    __syncthreads();
+    const int cg = 32 / p.f_groups;
+    if (tid < p.f_groups) {   // fixed order, in double; reciprocal square root in fp32 (as rtp_fold_fwd)
+      double s0 = 0.0, s1 = 0.0;
+      for (int k = 0; k < 16; ++k)
+        for (int j = 0; j < cg; ++j) { const float2 v = part[k * 32 + tid * cg + j]; s0 += v.x; s1 += v.y; }
+      const double inv = 1.0 / ((double)cg * p.D * p.H * p.W);
+      const double mean = s0 * inv;
+      double var = s1 * inv - mean * mean;
+      if (var < 0.0) var = 0.0;
+      const float rstd = 1.0f / sqrtf((float)var + p.f_eps);
+      mrl[tid * 2] = (float)mean;
+      mrl[tid * 2 + 1] = rstd;
+      if (p.f_mr && bid == n * wgs_per_sample) {
+        p.f_mr[((long)n * p.f_groups + tid) * 2] = (float)mean;
+        p.f_mr[((long)n * p.f_groups + tid) * 2 + 1] = rstd;
+      }
+    }
+    __syncthreads();
+    if (tid < 32) {
+      const float sc = mrl[(tid / cg) * 2 + 1] * gam_r;
+      sc_l[tid] = sc;
+      sh_l[tid] = bet_r - mrl[(tid / cg) * 2] * sc;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < NIT; ++m) {
+      const int i = tid + m * 512;
+      const int ck = i & 3, co = (i >> 2) % (NT * 16), tap = (i >> 2) / (NT * 16);
+      bf16x8 o;
+      float ts = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        o[j] = f2bf(wv[m][j] * sc_l[ck * 8 + j]);
+        ts += wv[m][j] * sh_l[ck * 8 + j];
+      }
+      ts += __shfl_xor(ts, 1, 64);   // the four chunks of a row sit in adjacent lanes
+      ts += __shfl_xor(ts, 2, 64);
+      if (i < ITEMS) {
+        const int dtap = p.flip ? 26 - tap : tap;
+        const int arow = (NT == 2) ? ((co >> 2) & 1) * 16 + (co >> 3) * 4 + (co & 3) : co;
+        st_bf16x8(wL + (dtap * p.Co + arow) * 32 + swz(ck, arow), o);
+        if (ck == 0) Tt[tap * 32 + co] = ts;
+      }
+    }
+    __syncthreads();
+    for (int i = tid; i < 27 * p.Co; i += 512) {   // class bias: bias + the taps that stay inside the volume for that class
+      const int co = i % p.Co, k = i / p.Co;
+      const int cz = k / 9, cy = (k / 3) % 3, cx = k % 3;  // 0 interior, 1 first, 2 last
+      float acc = (p.fbias && co < p.f_co_real) ? p.fbias[co] : 0.f;
+#pragma unroll
+      for (int tap = 0; tap < 27; ++tap) {
+        const int kz = tap / 9, ky = (tap / 3) % 3, kx = tap % 3;
+        const bool ok = !(cz == 1 && kz == 0) && !(cz == 2 && kz == 2) && !(cy == 1 && ky == 0) && !(cy == 2 && ky == 2) &&
+                        !(cx == 1 && kx == 0) && !(cx == 2 && kx == 2);
+        acc += ok ? Tt[tap * 32 + co] : 0.f;
+      }
+      bL[i] = acc;
+    }
+    __syncthreads();   // the scratch is the bricks' from here on
+  }
   // ---- weights -> LDS (once): item = (row = tap*Co + co, chunk)
-  {
+  if (!p.fw) {
     const bf16_t* wsrc = p.w + (p.w_per_sample ? (long)n * 27 * p.Co * 32 : 0);
     const int items = 27 * p.Co * 4;
     for (int i0 = tid; i0 < items; i0 += 512 * 4) {
@@ -198,7 +292,7 @@ __global__ __launch_bounds__(512, 2) void conv_tiled_kernel(TiledParams p) {
     }
   }
 
-  if (HAS_BTAB) {
+  if (HAS_BTAB && !p.fw) {
     for (int i = tid; i < 27 * p.Co; i += 512) {
       const int co = i % p.Co, k = i / p.Co;
       const int cz = k / 9, cy = (k / 3) % 3, cx = k % 3;  // 0 interior, 1 first, 2 last
@@ -814,9 +908,13 @@ struct TiledFuse { const float* coef[4]; const RtpAct* ex[3]; int nextra, mask; 
 int rtp_conv_tiled_try(const RtpAct* x, const void* wf, int w_per_sample, const float* btab, const RtpAct* res,
                        const RtpAct* y, const RtpConvGeom* g, int relu, int transposed, int y_fp32,
                        const RtpAct* stat_x, float* stat_out, const float* acc32, int acc_cs, hipStream_t s,
-                       const TiledFuse* fuse = nullptr) {
+                       const TiledFuse* fuse, const RtpGnFold* fold) {
   int Co;
   if (!tiled_geometry_ok(x, g, transposed, &Co)) return 1;
+  if (fold && (fuse || transposed || acc32 || y_fp32 || wf || btab || !fold->w || !fold->gamma || !fold->beta || !fold->stats ||
+               fold->nsplit < 1 || fold->groups < 1 || fold->groups > 32 || 32 % fold->groups || fold->co_real < 1 ||
+               fold->co_real > Co || g->w_ci_total > 32 || g->w_ci_off))
+    return RTP_ERR_SHAPE;
   if (fuse && (Co != 32 || !transposed || btab || res || !stat_x || stat_out || acc32 || y_fp32 || relu)) return RTP_ERR_UNSUPPORTED;
   if (acc32 && (acc_cs % 4 || acc_cs < Co)) return RTP_ERR_ALIGN;
   if (stat_out && (y_fp32 || (stat_x && res))) return RTP_ERR_UNSUPPORTED;
@@ -841,6 +939,12 @@ int rtp_conv_tiled_try(const RtpAct* x, const void* wf, int w_per_sample, const 
   p.nextra = 0; p.mask = 0; p.tot_out = nullptr;
   p.qpart = nullptr; p.q_nsplit = 0; p.gn_p = p.gn_mr = p.gn_gamma = nullptr; p.gn_groups = 1; p.gn_m = 1.f; p.coef_out = nullptr;
   p.tg = nullptr; p.csum_out = nullptr;
+  p.fw = p.fbias = p.fgamma = p.fbeta = p.fstats = nullptr; p.f_nsplit = p.f_groups = p.f_co_real = 0; p.f_eps = 0.f; p.f_mr = nullptr;
+  if (fold) {
+    p.fw = fold->w; p.fbias = fold->bias; p.fgamma = fold->gamma; p.fbeta = fold->beta; p.fstats = fold->stats;
+    p.f_nsplit = fold->nsplit; p.f_groups = fold->groups; p.f_co_real = fold->co_real; p.f_eps = fold->eps; p.f_mr = fold->mr;
+    p.w_per_sample = 1;
+  }
   for (int e = 0; e < 4; ++e) p.coef[e] = nullptr;
   for (int e = 0; e < 3; ++e) { p.ex[e] = nullptr; p.ex_cs[e] = p.ex_co[e] = 0; }
   if (fuse) {
@@ -898,9 +1002,19 @@ int rtp_conv_tiled_try(const RtpAct* x, const void* wf, int w_per_sample, const 
     RTP_CHECK_LAUNCH();
     return RTP_OK;
   }
-  hipLaunchKernelGGL(table[nt - 1][btab ? 1 : 0][aux][stat_out ? 1 : 0], dim3(p.N * wgs), dim3(512), shm, s, p);
+  hipLaunchKernelGGL(table[nt - 1][(btab || fold) ? 1 : 0][aux][stat_out ? 1 : 0], dim3(p.N * wgs), dim3(512), shm, s, p);
   RTP_CHECK_LAUNCH();
   return RTP_OK;
+}
+
+// GroupNorm -> conv -> (+ residual) -> (ReLU) with the fold in the kernel's prologue (include/rtp.h).
+extern "C" int rtp_conv_gn_fused(const RtpAct* x, const RtpGnFold* f, const RtpAct* res, const RtpAct* y, const RtpConvGeom* g,
+                                 int relu, float* stat_out, void* stream) {
+  if (!x || !f || !y || !g) return RTP_ERR_SHAPE;
+  if ((x->co % 8) || (x->cs % 8) || (y->co % 8) || (y->cs % 8) || (res && ((res->co % 8) || (res->cs % 8)))) return RTP_ERR_ALIGN;
+  const int rc = rtp_conv_tiled_try(x, nullptr, 1, nullptr, res, y, g, relu, 0, 0, nullptr, stat_out, nullptr, 0, (hipStream_t)stream,
+                                    nullptr, f);
+  return rc > 0 ? RTP_ERR_UNSUPPORTED : rc;
 }
 
 // Data gradient of a 3x3x3 stride-1 32 -> <=32-channel conv that writes the FINISHED gradient of the conv's input x:
@@ -929,7 +1043,7 @@ extern "C" int rtp_conv_dgrad_fused(const RtpAct* gy, const void* wd, const RtpA
   f.nextra = nterms; f.mask = mask; f.tot_out = tot_out; f.gn = gn;
   f.coef[0] = coeff;
   for (int e = 0; e < 3; ++e) { f.ex[e] = e < nterms ? &terms[e].t : nullptr; f.coef[1 + e] = e < nterms ? terms[e].coeff : nullptr; }
-  const int rc = rtp_conv_tiled_try(gy, wd, 0, nullptr, nullptr, dx, g, 0, 1, 0, x, nullptr, nullptr, 0, (hipStream_t)stream, &f);
+  const int rc = rtp_conv_tiled_try(gy, wd, 0, nullptr, nullptr, dx, g, 0, 1, 0, x, nullptr, nullptr, 0, (hipStream_t)stream, &f, nullptr);
   return rc > 0 ? RTP_ERR_UNSUPPORTED : rc;
 }
 

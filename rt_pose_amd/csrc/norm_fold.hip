@@ -1260,11 +1260,22 @@ extern "C" int rtp_wgrad_fold(const float* gp, int nsplit, const float* csum, co
 // reductions + GroupNorm parameter sums, then the folds): block -> (descriptor, local block) by binary search.
 // ------------------------------------------------------------------------------------------------
 struct GnParParams { const float* part; float* dgamma; float* dbeta; int n, c, accumulate; };
-enum { TAIL_CLASS_REDUCE = 0, TAIL_WGRAD_FOLD = 1, TAIL_GN_PARAM = 2, TAIL_FOLD_FWD = 3 };
+// tap-major fp32 copy of a conv's master weights: wt[tap][co_pad][ci] = w[co][ci][tap] (rows co >= co_real are zeros) -- what
+// rtp_conv_gn_fused's prologue reads with coalesced 16-byte loads, in the order it writes the LDS image
+struct PackWtParams { const float* w; float* wt; int co_real, co_pad, ci, ntap; };
+enum { TAIL_CLASS_REDUCE = 0, TAIL_WGRAD_FOLD = 1, TAIL_GN_PARAM = 2, TAIL_FOLD_FWD = 3, TAIL_PACK_WT = 4 };
 struct RtpTailDesc {
   int kind, blocks;
-  union { WFoldParams wf; ClsRedParams cr; GnParParams gp; FoldParams ff; } u;
+  union { WFoldParams wf; ClsRedParams cr; GnParParams gp; FoldParams ff; PackWtParams pw; } u;
 };
+
+__device__ __forceinline__ void pack_wt_body(const PackWtParams& p, int bid) {
+  const int i = bid * 256 + threadIdx.x;   // one output element: (tap, co, ci), ci fastest
+  const int total = p.ntap * p.co_pad * p.ci;
+  if (i >= total) return;
+  const int ci = i % p.ci, co = (i / p.ci) % p.co_pad, tap = i / (p.ci * p.co_pad);
+  p.wt[i] = co < p.co_real ? p.w[((long)co * p.ci + ci) * p.ntap + tap] : 0.f;
+}
 
 __device__ __forceinline__ void gn_param_body(const GnParParams& p, int bid) {
   const int t = bid * 256 + threadIdx.x;
@@ -1295,6 +1306,9 @@ __global__ __launch_bounds__(256) void tail_kernel(const RtpTailDesc* descs, con
   } else if (d.kind == TAIL_FOLD_FWD) {
     const FoldParams p = d.u.ff;
     fold_fwd_body(p, b % p.nw, b / p.nw, sh);
+  } else if (d.kind == TAIL_PACK_WT) {
+    const PackWtParams p = d.u.pw;
+    pack_wt_body(p, b);
   } else {
     const GnParParams p = d.u.gp;
     gn_param_body(p, b);
@@ -1366,6 +1380,20 @@ extern "C" int rtp_tail_desc_fold_fwd(const float* w, const float* bias, const f
   memcpy(desc, &d, sizeof(d));
   if (blocks) *blocks = d.blocks;
   if (shm_bytes) *shm_bytes = (int)fold_shm(d.u.ff);
+  return RTP_OK;
+}
+
+extern "C" int rtp_tail_desc_pack_wt(const float* w, int co_real, int co_pad, int ci, int ntap, float* wt, void* desc, int* blocks,
+                                     int* shm_bytes) {
+  if (!desc || !w || !wt || co_real < 1 || co_real > co_pad || ci < 1 || ntap < 1) return RTP_ERR_SHAPE;
+  RtpTailDesc d;
+  memset(&d, 0, sizeof(d));
+  d.kind = TAIL_PACK_WT;
+  d.u.pw.w = w; d.u.pw.wt = wt; d.u.pw.co_real = co_real; d.u.pw.co_pad = co_pad; d.u.pw.ci = ci; d.u.pw.ntap = ntap;
+  d.blocks = (ntap * co_pad * ci + 255) / 256;
+  memcpy(desc, &d, sizeof(d));
+  if (blocks) *blocks = d.blocks;
+  if (shm_bytes) *shm_bytes = 0;
   return RTP_OK;
 }
 

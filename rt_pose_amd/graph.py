@@ -268,7 +268,7 @@ class Graph:
     def forward_list(self):
         """The forward launches, opened by the one launch that packs every activation-independent weight image."""
         if self.head and not self._head_emitted:
-            outs = [t for it in self.head for t in it[13:17] if t is not None]
+            outs = [t for it in self.head for t in (it[13:17] if it[0] == "fold_fwd" else it[-1:]) if t is not None]
             self.fwd.insert(0, Launch(self.be.tail(self.head), L_FULL, [it[1] for it in self.head], outs, "pack_weights"))
             self._head_emitted = True
         return self.fwd
@@ -453,8 +453,14 @@ class ConvOp:
             gamma = beta = stats = None
             nw = 1
         self.groups = GROUPS if self.ci_real >= GROUPS else 1
-        self.wf = be.alloc((nw, ntap, ge.co, ge.ci), "bf16")
-        need_btab = bool(self.gn) or bias is not None
+        # A GroupNorm conv on the LDS-tiled kernel folds the norm in the kernel's own prologue (rtp_conv_gn_fused): no fold launch
+        # between two convs of a chain, no per-sample weight / bias-table buffers (RTP_NO_FUSED_FOLD: the separate launch, A/B)
+        self.fold_fused = bool(self.gn and not self.out_fp32 and ge.ks == 3 and ge.stride == 1 and ge.pad == 1 and ge.ci == 32
+                               and self.ci_real == 32 and ge.co in (16, 32) and self.x.cs == 32 and self.x.co == 0
+                               and ge.di % 2 == 0 and ge.hi % 4 == 0 and ge.wi % 16 == 0 and not ge.w_ci_total
+                               and hasattr(be, "conv_gn_fused") and not __import__("os").environ.get("RTP_NO_FUSED_FOLD"))
+        self.wf = None if self.fold_fused else be.alloc((nw, ntap, ge.co, ge.ci), "bf16")
+        need_btab = (bool(self.gn) or bias is not None) and not self.fold_fused
         self.btab = be.alloc((nw, 64, ge.co), "f32") if need_btab else None
         # training plans also need the data-gradient packing of the same weights
         need_dgrad = g.train and (self.x.needs_grad or bool(self.gn))
@@ -464,9 +470,10 @@ class ConvOp:
         # packing of every conv) is recorded for the ONE launch that opens the step (Graph.forward_list); only the
         # GroupNorm fold, which needs this step's statistics, is a launch of its own in front of its conv.
         if self.gn:
-            g.emit_fwd(be.fold_fwd(w, bias, gamma, beta, stats, self.x.stats_split, self.groups, GN_EPS,
-                                   ge, self.ci_real, self.co_real, self.wf, self.btab, self.mr, None),
-                       lane, [stats], [self.wf, self.btab, self.mr], "fold:" + self.name)
+            if not self.fold_fused:
+                g.emit_fwd(be.fold_fwd(w, bias, gamma, beta, stats, self.x.stats_split, self.groups, GN_EPS,
+                                       ge, self.ci_real, self.co_real, self.wf, self.btab, self.mr, None),
+                           lane, [stats], [self.wf, self.btab, self.mr], "fold:" + self.name)
             if self.wd is not None:
                 g.head.append(("fold_fwd", w, None, None, None, None, 0, self.groups, GN_EPS, ge, self.ci_real,
                                self.co_real, None, None, None, self.wd))
@@ -481,10 +488,18 @@ class ConvOp:
             self.y.stats_split = S
             self.y.stats = be.alloc((g.n, S, self.y.c, 2), "f32")
             fstats = (None, self.y.stats)
-        g.emit_fwd(be.conv(self.x, self.wf, nw > 1, self.btab, self.residual, self.y, ge, self.relu, False,
-                           self.out_fp32, fstats),
-                   lane, [self.x, self.wf, self.btab, self.residual], [self.y, self.y.stats if fstats else None],
-                   "conv:" + self.name)
+        if self.fold_fused:
+            self.wt = be.alloc((ntap, ge.co, ge.ci), "f32")   # tap-major fp32 copy of the master, made by the step's opening launch
+            g.head.append(("pack_wt", w, self.co_real, ge.co, ge.ci, ntap, self.wt))
+            g.emit_fwd(be.conv_gn_fused(self.x, self.wt, bias, gamma, beta, stats, self.x.stats_split, self.groups, GN_EPS, self.co_real,
+                                        self.mr, self.residual, self.y, ge, self.relu, self.y.stats if fstats else None),
+                       lane, [self.x, self.wt, stats, self.residual], [self.y, self.mr, self.y.stats if fstats else None],
+                       "conv:" + self.name)
+        else:
+            g.emit_fwd(be.conv(self.x, self.wf, nw > 1, self.btab, self.residual, self.y, ge, self.relu, False,
+                               self.out_fp32, fstats),
+                       lane, [self.x, self.wf, self.btab, self.residual], [self.y, self.y.stats if fstats else None],
+                       "conv:" + self.name)
         self.alg_flops = 2 * g.n * ge.do * ge.ho * ge.wo * self.co_real * self.ci_real * ntap
         g.flops["conv_fwd"] += self.alg_flops
         # mirrors the dispatch predicate of rtp_conv_tiled_try (csrc/conv_tiled.hip)

@@ -61,6 +61,16 @@ def _split_ranges(vox, nsplit, mult=1):
     return [(min(s * vps, vox), min((s + 1) * vps, vox)) for s in range(nsplit)]
 
 
+class _TapMajor:
+    """Lazy view of a tap-major weight copy wt[tap][co_pad][ci] as the master layout [co_real][ci][tap] (read when the launch runs)."""
+
+    def __init__(self, wt, co_real):
+        self.wt, self.co_real = wt, co_real
+
+    def detach(self):
+        return self.wt[:, :self.co_real].permute(1, 2, 0).contiguous()
+
+
 class EmuBackend:
     name = "emu"
 
@@ -169,6 +179,26 @@ class EmuBackend:
         return bool(g.ks == 3 and g.stride == 1 and ci == 32 and co in (16, 32) and g.di % 2 == 0 and g.hi % 4 == 0
                     and g.wi % 16 == 0 and g.di >= 2 and x.cs % 32 == 0 and x.co % 8 == 0)
 
+    def pack_wt(self, w, co_real, co_pad, ci, ntap, wt):
+        def run(s):
+            wt.zero_()
+            wt[:, :co_real] = w.detach().float().reshape(co_real, ci, ntap).permute(2, 0, 1)
+        return run
+
+    def conv_gn_fused(self, x, wt, bias, gamma, beta, stats, nsplit, groups, eps, co_real, mr, res, y, geom, relu, stat_out=None):
+        """HipBackend.conv_gn_fused = fold_fwd into private per-sample weights / class-bias table, then conv."""
+        ntap = geom.ks ** 3
+        w = _TapMajor(wt, co_real)
+        wf = self.alloc((x.n, ntap, geom.co, geom.ci), "bf16")   # (fp32 in the emulation's exact mode)
+        btab = self.alloc((x.n, 64, geom.co), "f32")
+        fold = self.fold_fwd(w, bias, gamma, beta, stats, nsplit, groups, eps, geom, geom.ci, co_real, wf, btab, mr, None)
+        conv = self.conv(x, wf, True, btab, res, y, geom, relu, False, False, (None, stat_out) if stat_out is not None else None)
+
+        def run(s):
+            fold(s)
+            conv(s)
+        return run
+
     def conv(self, x, wf, per_sample, btab, res, y, geom, relu, transposed, y_fp32, stats=None, acc=None):
         def run(s):
             g = geom
@@ -268,6 +298,8 @@ class EmuBackend:
                 fns.append(self.gn_bwd_param(*a))
             elif kind == "fold_fwd":
                 fns.append(self.fold_fwd(*a))
+            elif kind == "pack_wt":
+                fns.append(self.pack_wt(*a))
             else:
                 raise ValueError(kind)
         return lambda s: [f(s) for f in fns] and None

@@ -124,6 +124,65 @@ def test_conv_forward(hip, case):
 
 
 @pytest.mark.parametrize("case", [
+    # n, dims, co_real, groups, nsplit of the input's statistics, bias, residual, relu
+    (2, (4, 8, 32), 32, 8, 3, False, True, True), (3, (2, 16, 64), 32, 8, 1, True, False, False),
+    (1, (2, 16, 64), 15, 8, 5, True, False, True), (2, (8, 32, 80), 32, 4, 37, False, True, True),
+    (2, (6, 24, 96), 3, 32, 2, True, False, False), (8, (4, 8, 32), 16, 8, 16, False, False, True),
+])
+def test_conv_with_groupnorm_fold_in_the_prologue(hip, case):
+    """rtp_conv_gn_fused (GroupNorm fold inside the LDS-tiled conv kernel) against rtp_fold_fwd + rtp_conv_igemm on the SAME
+    device inputs (same arithmetic: results agree to bf16 rounding of a handful of weights at most), against the emulation,
+    and the (mean, rstd) it saves for the backward pass."""
+    n, dims, co_real, groups, nsplit, has_bias, has_res, relu = case
+    d, h, w = dims
+    ci, co = 32, pad_to(co_real, 16)
+    geom = Geom(n, d, h, w, d, h, w, ci, co, 3, 1, 1)
+    xp, xc, xg = views(hip, rnd((n, d, h, w, ci), 11, relu=True), n, d, h, w)
+    W = Pair(hip, rnd((co_real, ci, 3, 3, 3), 12, torch.float32, scale=0.05))
+    bias = Pair(hip, rnd((co_real,), 13, torch.float32)) if has_bias else None
+    gamma, beta = Pair(hip, rnd((ci,), 14, torch.float32) * 0.2 + 1.0), Pair(hip, rnd((ci,), 15, torch.float32) * 0.2)
+    # the input's statistics as a producer's epilogue leaves them: nsplit partials per sample (any split sums to the totals)
+    xv = xp.c.float().reshape(n, -1, ci)
+    tot = torch.stack([xv.sum(1), (xv * xv).sum(1)], -1)                      # [n, ci, 2]
+    frac = torch.rand(nsplit, generator=torch.Generator().manual_seed(16)) + 0.1
+    st = Pair(hip, (tot[:, None] * (frac / frac.sum())[None, :, None, None]).contiguous())
+    yc_ch = co if co_real % 16 == 0 else pad_to(co_real, 32)
+    yp, yc, yg = views(hip, torch.zeros(n, d, h, w, yc_ch, dtype=torch.bfloat16), n, d, h, w)
+    rc = rg = None
+    if has_res:
+        rp, rc, rg = views(hip, rnd((n, d, h, w, co), 17), n, d, h, w)
+    mr = Pair(hip, torch.zeros(n, groups, 2))
+    b = lambda P: (P.c, P.g) if P is not None else (None, None)
+    wt = Pair(hip, torch.zeros(27, co, ci))
+    EMU.tail([("pack_wt", W.c, co_real, co, ci, 27, wt.c)])(None)
+    hip.tail([("pack_wt", W.g, co_real, co, ci, 27, wt.g)])(hip.stream())
+    torch.cuda.synchronize()
+    assert torch.equal(wt.g.cpu(), wt.c)
+    run(hip, EMU.conv_gn_fused(xc, wt.c, b(bias)[0], gamma.c, beta.c, st.c, nsplit, groups, 1e-5, co_real, mr.c, rc, yc, geom, relu),
+        hip.conv_gn_fused(xg, wt.g, b(bias)[1], gamma.g, beta.g, st.g, nsplit, groups, 1e-5, co_real, mr.g, rg, yg, geom, relu))
+    check(yp, BF, "conv + GroupNorm fold %r" % (case,))
+    assert rel_err(mr.sync_back(), mr.c) < 1e-5
+    # the two-launch route on the device
+    wf = hip.alloc((n, 27, co, ci), "bf16"); bt = hip.alloc((n, 64, co), "f32"); mr2 = hip.alloc((n, groups, 2), "f32")
+    y2 = torch.zeros_like(yp.g)
+    y2v = View(y2, n, d, h, w, yc_ch, 0, yc_ch)
+    hip.fold_fwd(W.g, b(bias)[1], gamma.g, beta.g, st.g, nsplit, groups, 1e-5, geom, ci, co_real, wf, bt, mr2, None)(hip.stream())
+    hip.conv(xg, wf, True, bt, rg, y2v, geom, relu, False, False)(hip.stream())
+    torch.cuda.synchronize()
+    assert rel_err(mr.g.cpu(), mr2.cpu()) < 1e-6
+    assert rel_err(yp.g.float().cpu(), y2.float().cpu()) < 1e-3, "fused fold vs fold + conv"
+    # with the statistics epilogue
+    S = hip.conv_stats_nsplit(xg, geom, False) if co == yc_ch else 0
+    if S:
+        so = hip.alloc((n, S, co, 2), "f32")
+        hip.conv_gn_fused(xg, wt.g, b(bias)[1], gamma.g, beta.g, st.g, nsplit, groups, 1e-5, co_real, mr.g, rg, yg, geom, relu, so)(hip.stream())
+        ref = hip.alloc((n, 3, co, 2), "f32")
+        hip.chan_stats(yg, None, 3, ref)(hip.stream())
+        torch.cuda.synchronize()
+        assert rel_err(so.sum(1).cpu(), ref.sum(1).cpu()) < F32
+
+
+@pytest.mark.parametrize("case", [
     (2, (4, 8, 16), 32, 32, 3, 1), (2, (4, 8, 16), 32, 64, 3, 2), (1, (2, 4, 20), 64, 32, 1, 1),
     (2, (4, 8, 8), 32, 15, 3, 1), (1, (1, 2, 4), 64, 64, 3, 2), (1, (5, 6, 7), 32, 32, 3, 2),
     (2, (4, 8, 32), 32, 32, 3, 1), (1, (2, 16, 64), 32, 15, 3, 1), (2, (8, 32, 80), 32, 32, 3, 1),  # LDS-tiled kernel, flipped taps

@@ -22,6 +22,19 @@ def t(f, it=300):
     for _ in range(it): f(s)
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / it * 1e6
 print('dbg', os.environ.get('RTP_TILED_DBG', '0'), 'conv_tiled %.1f us' % t(f_conv), 'wgrad_tiled %.1f us' % t(f_wg))
+if 'fold' in sys.argv:
+    Wm = torch.randn(c, c, 3, 3, 3, device='cuda') * 0.05
+    gam = torch.rand(c, device='cuda') + 0.5; bet = torch.randn(c, device='cuda') * 0.1
+    st = torch.rand(n, 32, c, 2, device='cuda') * 1e4 + 1e5; st[..., 1] *= 2
+    mr = torch.zeros(n, 8, 2, device='cuda'); so = torch.zeros(n, 32, c, 2, device='cuda')
+    wf2 = mk((n, 27, c, c)); bt2 = torch.zeros(n, 64, c, device='cuda')
+    wt_ = torch.zeros(27, c, c, device='cuda'); be.tail([('pack_wt', Wm, c, c, c, 27, wt_)])(be.stream())
+    f_fused = be.conv_gn_fused(x, wt_, None, gam, bet, st, 32, 8, 1e-5, c, mr, res, y, g, True, so)
+    f_fold = be.fold_fwd(Wm, None, gam, bet, st, 32, 8, 1e-5, g, c, c, wf2, bt2, mr, None)
+    f_plain = be.conv(x, wf2, True, bt2, res, y, g, True, False, False, (None, so))
+    def both(s): f_fold(s); f_plain(s)
+    print('conv+stats %.1f us | fold %.1f us | fold+conv %.1f us | conv with fold in prologue %.1f us' % (t(f_plain), t(f_fold), t(both), t(f_fused)))
+    sys.exit(0)
 if 'full' not in sys.argv:
     # the fused backward pair: weight gradient + slab contraction (+ subset sums of gy), then the data gradient that writes the
     # finished gradient (coefficients in its prologue; 0 / 1 / 2 extra terms)
