@@ -65,7 +65,7 @@ def main():
         tot3 = [0.0, 0.0, 0.0]
         for op in tr.engine.graph.ops:
             ge = getattr(op, "geom", None)
-            if ge is None or not hasattr(op, "alg_flops"):
+            if ge is None or callable(ge) or not hasattr(op, "alg_flops"):
                 continue
             f = tm.get(("fwd", "conv:" + op.name), 0.0)
             d = tm.get(("bwd", "dgrad:" + op.name), 0.0)
@@ -74,7 +74,7 @@ def main():
             famb = "tiled" if (getattr(op, "tiled_bwd", False) or getattr(op, "s2_bwd", False)) else "generic"
             famw = "tiled" if getattr(op, "tiled_wgrad", False) else "generic"
             gf = op.alg_flops / 1e9
-            tf = lambda t: gf / t * 1e-3 if t else 0.0
+            tf = lambda t: gf / t * 1e3 * 1e-3 if t else 0.0   # GFLOP / us = PFLOP/s -> TFLOP/s
             if fam == "generic": tot3[0] += f
             if famb == "generic": tot3[1] += d
             if famw == "generic": tot3[2] += w

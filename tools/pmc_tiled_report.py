@@ -9,7 +9,7 @@ import sys
 
 out = sys.argv[1]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNELS = {"conv_tiled_full": "conv_tiled_kernel<2, true, 1, false>", "wgrad_tiled": "wgrad_tiled_kernel"}
+KERNELS = {"conv_tiled_full": "conv_tiled_kernel<2, true, 1, false", "wgrad_tiled": "wgrad_tiled_kernel"}
 agg = {k: collections.defaultdict(list) for k in KERNELS}
 dur = {k: collections.defaultdict(list) for k in KERNELS}
 for tag in ("f", "w", "s1", "s2", "g"):
