@@ -215,9 +215,33 @@ def lidar_bench(dev, batch, npts=200000, iters=5):
         nv = run()
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / iters * 1e3
-    return {"workload": "%d LiDAR frames x %d points: extrinsic transform + dynamic voxelisation (stable radix sort, in-order means) "
-                        "+ dense scatter (BASELINE config 5 pieces)" % (batch, npts),
-            "ms_per_batch": round(ms, 3), "points_per_s": round(batch * npts / ms * 1e3, 1), "voxels": int(nv)}
+    out = {"workload": "%d LiDAR frames x %d points: extrinsic transform + dynamic voxelisation (stable radix sort, in-order means) "
+                       "+ dense scatter (BASELINE config 5 pieces)" % (batch, npts),
+           "ms_per_batch": round(ms, 3), "points_per_s": round(batch * npts / ms * 1e3, 1), "voxels": int(nv)}
+    # ... and the fused model: hr3d whose head towers read concat(radar feature, dense LiDAR grid) (configs.LIDAR_VARIANTS;
+    # this repo's composition, the reference ships no fusion detector) -- the same train step as the headline, LiDAR grid resident
+    try:
+        from rt_pose_amd import configs, synth
+        from rt_pose_amd.trainer import DataParallelTrainer
+        spec = configs.spec("hr3d_lidar")
+        trf = DataParallelTrainer("hr3d_lidar", batch, configs.NATIVE_DIMS, total_steps=100, device=dev, use_graph=False)
+        trf.load(synth.make_batch(batch, spec["cin"], configs.NATIVE_DIMS, seed=4321, lidar_channels=spec["lidar_channels"]))
+        for _ in range(3):
+            trf.step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        nst = 10
+        for _ in range(nst):
+            trf.step()
+        torch.cuda.synchronize()
+        msf = (time.perf_counter() - t0) / nst * 1e3
+        out["fusion_model"] = {"workload": "hr3d_lidar train step (radar feature ++ %d-channel dense LiDAR grid in front of the towers), "
+                                           "%d frames/GPU" % (spec["lidar_channels"], batch),
+                               "ms_per_step": round(msf, 3), "frames_per_s": round(batch / msf * 1e3, 1)}
+        del trf
+    except Exception as e:   # informational leg
+        out["fusion_model"] = {"error": repr(e)[:200]}
+    return out
 
 
 def main():
@@ -264,7 +288,8 @@ def main():
     spec = configs.spec(args.model)
     tr = DataParallelTrainer(args.model, args.batch, configs.NATIVE_DIMS, total_steps=max(100, args.steps + args.warmup),
                              device=dev, rank=rank, world_size=world, use_graph=args.graph)
-    ex = synth.make_batch(args.batch, spec["cin"], configs.NATIVE_DIMS, seed=1234, one_hm=spec["heads"]["hm"] == 1, rank=rank)
+    ex = synth.make_batch(args.batch, spec["cin"], configs.NATIVE_DIMS, seed=1234, one_hm=spec["heads"]["hm"] == 1, rank=rank,
+                          lidar_channels=spec.get("lidar_channels", 0))
     tr.load(ex)  # inputs resident in HBM before the timed region
     torch.cuda.synchronize()
 

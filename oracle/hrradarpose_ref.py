@@ -142,10 +142,14 @@ def sep_head(sd, p, x, heads):
     return out
 
 
-def center_head(sd, x, heads=("reg", "hm"), p="pose_head"):
-    """CenterHead.forward -- center_head.py:232-238; shared_conv :203-211."""
+def center_head(sd, x, heads=("reg", "hm"), p="pose_head", lidar=None):
+    """CenterHead.forward -- center_head.py:232-238; shared_conv :203-211.
+    lidar (this repo's two-stream fusion, BASELINE config 5 / SURVEY 8f N3; no reference counterpart): the dense LiDAR voxel
+    grid [B, C_l, Z, Y, X] is concatenated with the radar feature along the channels in front of the towers."""
     if (p + ".shared_conv.1.weight") in sd:
         x = F.relu(_conv(sd, p + ".shared_conv.1", _gn(sd, p + ".shared_conv.0", x), 1, 1))
+    if lidar is not None:
+        x = torch.cat([x, lidar.to(x.dtype)], dim=1)
     return [sep_head(sd, p + ".tasks.0", x, heads)], x
 
 
@@ -236,7 +240,7 @@ def radar_pose_net(sd, example, final_fuse, weight, code_weights, return_loss=Tr
     """RadarPoseNet.forward -- detectors/radar_pose_net.py:26-46 (reader is identity, radar_encoder.py:15-17)."""
     ex = dict(example["rdr"])
     feats = hrnet3d(sd, ex["rdr_tensor"], final_fuse)
-    preds, _ = center_head(sd, feats)
+    preds, _ = center_head(sd, feats, lidar=ex.get("lidar_grid"))
     if return_loss:
         return center_head_loss(preds, ex, weight, code_weights)
     return center_head_predict(preds, test_cfg, example.get("meta"))

@@ -22,14 +22,21 @@ NAMES = list(_TABLE)
 # BASELINE config 4: a shipped configuration + `dcn_head=True` (the DCN head of center_head.py:111-163 with Z folded into the
 # batch; the reference's own DCNSepHead cannot run on the 5-D feature, SURVEY appendix 4 -- parity unpinned by construction)
 DCN_VARIANTS = {"hr3d_dcn": "hr3d"}
+# BASELINE config 5 (two-stream fusion): a shipped configuration whose head towers read the radar feature
+# CONCATENATED with the dense-ified LiDAR voxel grid (mean point features per voxel: x, y, z, intensity -- DynamicVoxelEncoder,
+# readers/dynamic_voxel_encoder.py:69-101 -> rt_pose_amd.lidar.DynamicVoxelEncoder.to_dense).  The reference ships no fusion
+# detector (voxelnet.py:47-49 calls a missing backbone), so the composition is this repo's and parity-unpinned by construction.
+LIDAR_VARIANTS = {"hr3d_lidar": ("hr3d", 4)}
 
 
 def spec(name):
     dcn = name in DCN_VARIANTS
-    arch, cin, fin, fout, fuse, nhm, nreg, weight, lr_max, batch = _TABLE[DCN_VARIANTS.get(name, name)]
+    base, lidar_c = LIDAR_VARIANTS.get(name, (name, 0))
+    arch, cin, fin, fout, fuse, nhm, nreg, weight, lr_max, batch = _TABLE[DCN_VARIANTS.get(base, base)]
     cw = [1.0, 1.5, 2.0] if nreg == 3 else [1.0] * nreg
     return dict(arch=arch, cin=cin, final_conv_in=fin, final_conv_out=fout, final_fuse=fuse,
-                heads=OrderedDict(reg=nreg, hm=nhm), weight=weight, code_weights=cw, lr_max=lr_max, batch=batch, dcn_head=dcn)
+                heads=OrderedDict(reg=nreg, hm=nhm), weight=weight, code_weights=cw, lr_max=lr_max, batch=batch, dcn_head=dcn,
+                lidar_channels=lidar_c)
 
 
 def model_dict(name):
@@ -42,7 +49,8 @@ def model_dict(name):
                       final_conv_out=s["final_conv_out"], final_fuse=s["final_fuse"], ds_factor=1),
         pose_head=dict(type="CenterHead", tasks=tasks, in_channels=s["final_conv_out"],
                        share_conv_channel=s["final_conv_out"], dataset="cruw_pose", weight=s["weight"],
-                       code_weights=s["code_weights"], common_heads={"reg": (s["heads"]["reg"], 2)}, dcn_head=s["dcn_head"]),
+                       code_weights=s["code_weights"], common_heads={"reg": (s["heads"]["reg"], 2)}, dcn_head=s["dcn_head"],
+                       lidar_channels=s["lidar_channels"]),
         neck=None)
 
 
@@ -102,7 +110,7 @@ def param_shapes(name):
             sd[p + ".conv_adaption.weight"] = (c, c, 3, 3)
     for hname, ncls in s["heads"].items():
         p = "pose_head.tasks.0.%s" % hname
-        sd[p + ".0.weight"] = (32, s["final_conv_out"], 3, 3, 3)
+        sd[p + ".0.weight"] = (32, s["final_conv_out"] + s["lidar_channels"], 3, 3, 3)
         sd[p + ".0.bias"] = (32,)
         sd[p + ".2.weight"] = (ncls, 32, 3, 3, 3)
         sd[p + ".2.bias"] = (ncls,)

@@ -79,7 +79,7 @@ class PoseEngine:
     """HRRadarPose for a fixed (batch, Cin, dims): buffers + launch lists built once, replayed every step."""
 
     def __init__(self, backend, params, arch, final_fuse, heads, loss_weight, code_weights, batch, dims, train=True,
-                 pgrads=None, test_cfg=None, max_objs=None):
+                 pgrads=None, test_cfg=None, max_objs=None, lidar_channels=0):
         self.be, self.n, self.dims, self.train = backend, batch, tuple(dims), train
         self.heads = OrderedDict(heads)
         self.nreg, self.ncls = self.heads["reg"], self.heads["hm"]
@@ -89,7 +89,13 @@ class PoseEngine:
         g = self.graph = Graph(be, batch, params, train=train, pgrads=pgrads)
         self.x_in = g.input_f32("rdr", cin, dims)
         self.feats = net.build_hrnet3d(g, self.x_in, arch, dims, final_fuse)
-        self.outs = net.build_head(g, self.feats, list(self.heads))
+        # two-stream fusion (BASELINE config 5): the dense LiDAR voxel grid [B, C_l, Z, Y, X] fp32 enters beside the radar feature
+        self.lidar_in = None
+        lidar = None
+        if lidar_channels:
+            self.lidar_in = g.input_f32("lidar", lidar_channels, dims)
+            lidar = (g.pack("lidar", self.lidar_in, lidar_channels, dims), lidar_channels)
+        self.outs = net.build_head(g, self.feats, list(self.heads), lidar=lidar)
         self.fwd = list(g.forward_list())
         self.fwd_plan = LanePlan(be, self.fwd, LANE_MAP)
         self.bwd_plan = None
@@ -132,6 +138,12 @@ class PoseEngine:
     # ------------------------------------------------------------------ data in (plumbing copies)
     def load_input(self, rdr_tensor):
         self.x_in.copy_(rdr_tensor.reshape(self.x_in.shape), non_blocking=True)
+
+    def load_lidar(self, grid):
+        """grid: dense LiDAR voxel grid [B, C_l, Z, Y, X] (fp32; rt_pose_amd.lidar.DynamicVoxelEncoder.to_dense per frame)."""
+        if self.lidar_in is None:
+            raise ValueError("this plan was built without a LiDAR input (lidar_channels=0)")
+        self.lidar_in.copy_(grid.reshape(self.lidar_in.shape), non_blocking=True)
 
     def load_targets(self, ex):
         """ex: the reference's example['rdr'] dict with per-task lists (cruw_pose.py:225-275)."""

@@ -238,6 +238,26 @@ class Graph:
         op.emit_forward()
         return y
 
+    def conv_cat(self, name, xs: List[Act], reals, wname, bname=None, relu=False):
+        """Conv3d(sum(reals), Cout in {16, 32}, 3x3x3, bias) [+ ReLU] over the channel concatenation of `xs` without building
+        it: every source (<= 32 real channels, padded to 32) is one input-channel slice of a SplitConvOp -- the two-stream
+        fusion head (radar feature ++ dense LiDAR grid)."""
+        w = self.param(wname)
+        co_real, ci_total = w.shape[0], w.shape[1]
+        assert ci_total == sum(reals) and all(x.c == 32 and x.cs == 32 and x.co == 0 and r <= 32 for x, r in zip(xs, reals)), name
+        x0 = xs[0]
+        gs = Geom(self.n, x0.d, x0.h, x0.w, x0.d, x0.h, x0.w, 32, pad_to(co_real, 16), 3, 1, 1, ci_total, 0)
+        if not (hasattr(self.be, "conv_tiled_ok") and self.be.conv_tiled_ok(View(x0.buf, x0.n, x0.d, x0.h, x0.w, 32, 0, 32), gs, False)
+                and co_real % 16 == 0):
+            raise NotImplementedError("conv_cat needs the LDS-tiled conv geometry (D % 2, H % 4, W % 16, Cout 16 | 32)")
+        y = self.act(name, co_real, x0.dims, c=co_real, relu=relu)
+        offs = [sum(reals[:k]) for k in range(len(xs))]
+        op = SplitConvOp(self, name, x0, y, gs, wname, bname, relu, ci_total, co_real, sources=list(zip(xs, reals, offs)))
+        y.producer = op
+        self.ops.append(op)
+        op.emit_forward()
+        return y
+
     def fuse(self, name, terms: List[Act], relu=True):
         """HighResolutionModule fuse row (hr3d.py:213-228): terms at other resolutions are upsampled."""
         hi = max(terms, key=lambda t: t.vox)
@@ -717,20 +737,30 @@ class SplitConvOp:
     the bias, applies the ReLU and writes bf16.  Backward: K independent data-gradient launches, each writing its
     32-channel slice of the input gradient, and K weight-gradient launches over the matching slices of x."""
 
-    def __init__(self, g, name, x, y, gs, wname, bname, relu, ci_real, co_real):
+    def __init__(self, g, name, x, y, gs, wname, bname, relu, ci_real, co_real, sources=None):
         self.g, self.name, self.x, self.y, self.gs = g, name, x, y, gs
         self.wname, self.bname, self.relu, self.ci_real, self.co_real = wname, bname, relu, ci_real, co_real
         self.gn = None
-        self.K = ci_real // 32
+        # sources: [(activation, real channels, first weight input channel)] -- separate 32-channel tensors standing in for the
+        # slices of one wide tensor (Graph.conv_cat); None: the K = Cin / 32 slices of x
+        self.sources = sources
+        self.K = len(sources) if sources else ci_real // 32
 
     def inputs(self):
-        return [self.x]
+        return [s[0] for s in self.sources] if self.sources else [self.x]
+
+    def slice_real(self, k):
+        return self.sources[k][1] if self.sources else 32
 
     def slice_geom(self, k):
         s = self.gs
-        return Geom(s.n, s.di, s.hi, s.wi, s.do, s.ho, s.wo, 32, s.co, s.ks, s.stride, s.pad, self.ci_real, 32 * k)
+        off = self.sources[k][2] if self.sources else 32 * k
+        return Geom(s.n, s.di, s.hi, s.wi, s.do, s.ho, s.wo, 32, s.co, s.ks, s.stride, s.pad, self.ci_real, off)
 
     def x_slice(self, k):
+        if self.sources:
+            x = self.sources[k][0]
+            return View(x.buf, x.n, x.d, x.h, x.w, x.cs, 0, 32)
         x = self.x
         return View(x.buf, x.n, x.d, x.h, x.w, x.cs, 32 * k, 32)
 
@@ -739,7 +769,7 @@ class SplitConvOp:
         w = g.param(self.wname)
         bias = g.param(self.bname) if self.bname else None
         ntap = gs.ks ** 3
-        need_dgrad = g.train and self.x.needs_grad
+        need_dgrad = g.train and any(a.needs_grad for a in self.inputs())
         self.wf, self.wd, self.btab = [], [], None
         lane = g.lane_of(self.y)
         acc = be.alloc((g.n, self.y.vox, gs.co), "f32")
@@ -754,15 +784,16 @@ class SplitConvOp:
             self.wd.append(wd)
             if bt is not None:
                 self.btab = bt
-            g.head.append(("fold_fwd", w, bias if bt is not None else None, None, None, None, 0, 1, GN_EPS, gk, 32,
+            g.head.append(("fold_fwd", w, bias if bt is not None else None, None, None, None, 0, 1, GN_EPS, gk, self.slice_real(k),
                            self.co_real, wf, bt, None, wd))
             g.emit_fwd(be.conv(self.x_slice(k), wf, False, bt, None, self.y if last else accv, gk, self.relu and last, False,
                                not last, None, (acc, gs.co) if k > 0 else None),
-                       lane, [self.x, wf, bt, acc if k > 0 else None], [self.y if last else acc], "conv:%s.%d" % (self.name, k))
+                       lane, [self.inputs()[k] if self.sources else self.x, wf, bt, acc if k > 0 else None],
+                       [self.y if last else acc], "conv:%s.%d" % (self.name, k))
         self.alg_flops = 2 * g.n * gs.do * gs.ho * gs.wo * self.co_real * self.ci_real * ntap
         g.flops["conv_fwd"] += self.alg_flops
         g.flops["conv_tiled"] += self.alg_flops
-        nb = 2 * g.n * (self.x.vox * self.ci_real + self.y.vox * self.y.c)
+        nb = 2 * g.n * (self.x.vox * (32 * self.K if self.sources else self.ci_real) + self.y.vox * self.y.c)
         g.alg_bytes["conv_tiled"] += nb
         self.full = gs.co == 32 and g.n * self.y.vox >= (1 << 20)   # the profiling family of these launches (conv_tiled.hip)
         if self.full:
@@ -774,7 +805,19 @@ class SplitConvOp:
         co32 = pad_to(gs.co, 32)
         assert gy.c >= co32, (self.name, gy.c, co32)
         lane = g.lane_of(self.y)
-        if x.needs_grad:
+        if self.sources:   # separate tensors: a data gradient per source that wants one
+            for k, (a, _real, _off) in enumerate(self.sources):
+                if not a.needs_grad:
+                    continue
+                dk_buf = be.alloc((g.n, a.d, a.h, a.w, 32), "bf16")
+                dk = View(dk_buf, g.n, a.d, a.h, a.w, 32, 0, 32)
+                g.emit_bwd(be.conv(gy, self.wd[k], False, None, None, dk, self.slice_geom(k), False, True, False), lane,
+                           [gy, self.wd[k]], [dk_buf], "dgrad:%s.%d" % (self.name, k))
+                a.contribs.append((dk, None))
+            if any(a.needs_grad for a in self.inputs()):
+                g.flops["conv_dgrad"] += self.alg_flops
+                g.flops["conv_tiled"] += self.alg_flops
+        elif x.needs_grad:
             dxb = be.alloc((g.n, x.d, x.h, x.w, self.ci_real), "bf16")
             for k in range(self.K):
                 dk = View(dxb, g.n, x.d, x.h, x.w, self.ci_real, 32 * k, 32)
@@ -794,9 +837,10 @@ class SplitConvOp:
             gk = self.slice_geom(k)
             S = be.wgrad_nsplit(gk) or wgrad_split(gy.vox)
             gp = be.alloc((g.n, S, gs.ks ** 3, co32, 32), "f32")
-            g.emit_bwd(be.wgrad(gy, self.x_slice(k), gk, S, gp), wl, [gy, x], [gp], "wgrad:%s.%d" % (self.name, k))
+            g.emit_bwd(be.wgrad(gy, self.x_slice(k), gk, S, gp), wl, [gy, self.inputs()[k] if self.sources else x], [gp],
+                       "wgrad:%s.%d" % (self.name, k))
             first = k == 0 and self.bname
-            g.tail_b.append(("wgrad_fold", gp, S, csum if first else None, None, None, None, 1, gk, 32, self.co_real,
+            g.tail_b.append(("wgrad_fold", gp, S, csum if first else None, None, None, None, 1, gk, self.slice_real(k), self.co_real,
                              g.pgrad[self.wname], g.pgrad[self.bname] if first else None, 0))
             g.alg_bytes["wgrad_tiled"] += 2 * g.n * (gy.vox * co32 + x.vox * 32) + 4 * g.n * S * gs.ks ** 3 * co32 * 32
         g.flops["wgrad"] += self.alg_flops

@@ -48,6 +48,12 @@ def plan_waits(launches, nlanes=NLANES, lane_of=None):
     """-> (waits, record): waits[i] = indices of earlier launches (on other lanes) launch i must wait for;
     record[j] = launch j's completion needs an event.  lane_of: optional list overriding each launch's lane."""
     lane_of = lane_of if lane_of is not None else [L.lane for L in launches]
+    # Gating (RTP_GATE="1,2,5"): a launch of lane 0 also waits for every launch of the gated lanes that precedes it in list order.
+    # The persistent full-resolution kernels own every CU while they run, so a side lane's chain of small kernels otherwise
+    # advances about one launch per big-kernel boundary; gated, the side chains run (concurrently with each other) in the
+    # window before the next big launch instead.
+    gated = [int(v) for v in os.environ.get("RTP_GATE", "").split(",") if v.strip() != ""]
+    last_on = {}
     last_w, readers = {}, {}
     clock = [[-1] * nlanes for _ in range(nlanes)]  # clock[l][m]: newest launch on lane m known finished before lane l's next
     after = []                                      # clock snapshot implied by the completion of launch i
@@ -64,6 +70,11 @@ def plan_waits(launches, nlanes=NLANES, lane_of=None):
                 deps.add(j)
             deps.update(readers.get(k, ()))
         lane = lane_of[i]
+        if lane == 0:
+            for m in gated:
+                if m in last_on:
+                    deps.add(last_on[m])
+        last_on[lane] = i
         vc = clock[lane]
         need = {}
         for j in deps:

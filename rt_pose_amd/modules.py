@@ -111,8 +111,11 @@ class HRNet3D(nn.Module):
 @HEADS.register_module
 class CenterHead(nn.Module):
     def __init__(self, in_channels=128, tasks=[], dataset="cruw_pose", common_heads=dict(), logger=None, init_bias=-2.19,
-                 share_conv_channel=64, num_hm_conv=2, weight=0.1, code_weights=[], dcn_head=False):
+                 share_conv_channel=64, num_hm_conv=2, weight=0.1, code_weights=[], dcn_head=False, lidar_channels=0):
         super().__init__()
+        # lidar_channels > 0: two-stream fusion (BASELINE config 5; no reference counterpart, configs.LIDAR_VARIANTS): the towers'
+        # first conv reads the radar feature concatenated with the dense LiDAR voxel grid (example["rdr"]["lidar_grid"])
+        self.lidar_channels = int(lidar_channels)
         # dcn_head=True: the reference's DCNSepHead (center_head.py:111-163) is 2-D and cannot run on the 5-D feature (its
         # constructor also raises, :152); here the two FeatureAdaption modules run per (frame, z) slice in front of the
         # SepHead towers (parity unpinned by construction)
@@ -136,7 +139,7 @@ class CenterHead(nn.Module):
                 shapes[p + ".conv_adaption.weight"] = (share_conv_channel, share_conv_channel, 3, 3)
         for hname, ncls in self.heads.items():
             p = "pose_head.tasks.0.%s" % hname
-            shapes[p + ".0.weight"] = (32, share_conv_channel, 3, 3, 3)
+            shapes[p + ".0.weight"] = (32, share_conv_channel + self.lidar_channels, 3, 3, 3)
             shapes[p + ".0.bias"] = (32,)
             shapes[p + ".2.weight"] = (ncls, 32, 3, 3, 3)
             shapes[p + ".2.bias"] = (ncls,)
@@ -309,7 +312,8 @@ class RadarPoseNet(nn.Module):
             bb, hd = self.backbone, self.pose_head
             eng = PoseEngine(be, self.flat.values, bb.backbone_cfg, bb.final_fuse, hd.heads, hd.weight, hd.code_weights,
                              x.shape[0], tuple(x.shape[2:]), train=train, pgrads=self.flat.grads if train else None,
-                             test_cfg=_plain(self.test_cfg) if self.test_cfg else None)
+                             test_cfg=_plain(self.test_cfg) if self.test_cfg else None,
+                             lidar_channels=getattr(hd, "lidar_channels", 0))
             plan = type("Plan", (), {})()
             plan.engine, plan.flat, plan.named = eng, self.flat, self._named
             self._plans[key] = plan
@@ -329,6 +333,8 @@ class RadarPoseNet(nn.Module):
         plan = self._plan(x, bool(return_loss))
         eng = plan.engine
         eng.load_input(x.float())
+        if eng.lidar_in is not None:
+            eng.load_lidar(ex["lidar_grid"].float())
         if return_loss:
             eng.load_targets(ex)
             eng.run_forward()

@@ -108,8 +108,10 @@ def build_hrnet3d(g: Graph, x_f32, arch, dims, final_fuse, prefix="backbone"):
     return g.fuse("final.sum", terms, relu=False)
 
 
-def build_head(g: Graph, feats, heads, prefix="pose_head"):
-    """SepHead with head_conv=32, final_kernel=3 (center_head.py:223): Conv3d(C,32,3)+ReLU -> Conv3d(32,classes,3)."""
+def build_head(g: Graph, feats, heads, prefix="pose_head", lidar=None):
+    """SepHead with head_conv=32, final_kernel=3 (center_head.py:223): Conv3d(C,32,3)+ReLU -> Conv3d(32,classes,3).
+    lidar = (activation, real channels): the dense LiDAR grid of the two-stream fusion variant (configs.LIDAR_VARIANTS); the
+    towers' first conv then reads concat(feats, lidar) -- as two input-channel slices, the concatenation is never built."""
     if (prefix + ".shared_conv.1.weight") in g.params:
         feats = g.conv("shared", feats, prefix + ".shared_conv.1.weight",
                        gn=(prefix + ".shared_conv.0.weight", prefix + ".shared_conv.0.bias"), relu=True)
@@ -124,6 +126,10 @@ def build_head(g: Graph, feats, heads, prefix="pose_head"):
     for name in heads:
         p = "%s.tasks.0.%s" % (prefix, name)
         feats = adapt.get(name, src)
-        t = g.conv("head.%s.0" % name, feats, p + ".0.weight", bname=p + ".0.bias", relu=True, want_stats=False)
+        if lidar is not None:
+            t = g.conv_cat("head.%s.0" % name, [feats, lidar[0]], [feats.c_real, lidar[1]], p + ".0.weight", bname=p + ".0.bias",
+                           relu=True)
+        else:
+            t = g.conv("head.%s.0" % name, feats, p + ".0.weight", bname=p + ".0.bias", relu=True, want_stats=False)
         out[name] = g.conv("head.%s.2" % name, t, p + ".2.weight", bname=p + ".2.bias", out_fp32=True)
     return out

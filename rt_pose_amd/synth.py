@@ -33,7 +33,17 @@ def draw_splat(hm, cz, cy, cx, radius, prof=None):
     return hm
 
 
-def make_batch(batch, cin, dims, seed, one_hm=False, rank=0):
+def lidar_grid(batch, channels, dims, seed, occupancy=0.06):
+    """A dense LiDAR voxel grid [B, C_l, Z, Y, X] of the sparsity a real sweep leaves in the radar ROI: `occupancy` of the voxels
+    hold mean point features (metric x, y, z inside the voxel's range + an intensity), the rest are zeros."""
+    Z, Y, X = dims
+    g = torch.Generator().manual_seed(seed + 77)
+    occ = (torch.rand(batch, 1, Z, Y, X, generator=g) < occupancy).float()
+    feat = torch.rand(batch, channels, Z, Y, X, generator=g) * 2 - 1
+    return feat * occ
+
+
+def make_batch(batch, cin, dims, seed, one_hm=False, rank=0, lidar_channels=0):
     """Returns the reference's collated `example` dict (datasets/cruw_pose.py:225-275) on CPU."""
     Z, Y, X = dims
     g = torch.Generator().manual_seed(seed + rank)
@@ -52,4 +62,6 @@ def make_batch(batch, cin, dims, seed, one_hm=False, rank=0):
     pose = (torch.rand(batch, 1, 45, generator=g) * 16 - 8) if one_hm else torch.rand(batch, 15, 3, generator=g)
     ex = dict(rdr_tensor=rdr, hm=[hm], ind=[ind], mask=[torch.ones(batch, ncls, dtype=torch.uint8)],
               cat=[torch.arange(ncls).repeat(batch, 1)], anno_pose=[pose])
+    if lidar_channels:
+        ex["lidar_grid"] = lidar_grid(batch, lidar_channels, dims, seed + rank)
     return {"rdr": ex, "meta": [{"seq": "synth", "frame": b, "rdr_frame": b} for b in range(batch)]}

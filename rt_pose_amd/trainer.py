@@ -70,7 +70,7 @@ class DataParallelTrainer:
         self.flat.load_state_dict(init_state_dict(self.shapes, seed))
         self.engine = PoseEngine(self.be, self.flat.values, s["arch"], s["final_fuse"], s["heads"], s["weight"],
                                  s["code_weights"], batch_per_gpu, dims, train=True, pgrads=self.flat.grads,
-                                 test_cfg=configs.test_cfg())
+                                 test_cfg=configs.test_cfg(), lidar_channels=s.get("lidar_channels", 0))
         self.opt = FlatAdam(self.be, self.flat, self.engine.live_params)
         self.total_steps, self.lr_max = total_steps, lr_max if lr_max is not None else s["lr_max"]
         self.step_idx = 0
@@ -106,6 +106,8 @@ class DataParallelTrainer:
     def load(self, example):
         with self._on_stream():
             self.engine.load_input(example["rdr"]["rdr_tensor"])
+            if self.engine.lidar_in is not None:
+                self.engine.load_lidar(example["rdr"]["lidar_grid"])
             self.engine.load_targets(example["rdr"])
 
     def _fwd_bwd(self):

@@ -180,6 +180,46 @@ def test_dcn_head_plan_matches_oracle_composition():
     assert float(flat.grads["pose_head.tasks.0.feature_adapt_cls.conv_offset.weight"].abs().max()) > 0
 
 
+def test_lidar_fusion_head_matches_oracle_concat():
+    """BASELINE config 5 at model level (this repo's composition, no reference counterpart): the towers' first conv
+    reads concat(radar feature, dense LiDAR grid).  The plan runs it as two input-channel slices of the LDS-tiled conv (the
+    second slice has 4 real channels) and never builds the concatenation; the oracle concatenates.  Loss, every parameter
+    gradient (including the 36-input-channel tower weights) and the data gradient into the backbone must agree."""
+    from rt_pose_amd import synth
+    arch, fin, fout, fuse, heads, weight, cw = O.MODEL_CONFIGS["hr3d"]
+    C_L = 4
+    shapes = O.param_shapes(arch, fin, fout, fout + C_L, heads)
+    assert shapes["pose_head.tasks.0.hm.0.weight"] == (32, 36, 3, 3, 3)
+    sd = O.seeded_state_dict(shapes, seed=1)
+    be = EmuBackend(exact=True)
+    flat = FlatParams(shapes, be.alloc)
+    flat.load_state_dict(sd)
+    dims = (4, 8, 16)
+    eng = PoseEngine(be, flat.values, arch, fuse, heads, weight, cw, 2, dims, pgrads=flat.grads, test_cfg=TEST_CFG, lidar_channels=C_L)
+    tags = [L.tag for L in eng.fwd]
+    assert "pack:lidar" in tags and "conv:head.hm.0.0" in tags and "conv:head.hm.0.1" in tags
+    ex = O.synth_example(2, 1, dims, seed=1234)
+    ex["rdr"]["lidar_grid"] = synth.lidar_grid(2, C_L, dims, seed=5, occupancy=0.3)
+    eng.load_input(ex["rdr"]["rdr_tensor"])
+    eng.load_lidar(ex["rdr"]["lidar_grid"])
+    eng.load_targets(ex["rdr"])
+    eng.run_forward()
+    eng.run_loss_backward()
+    sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ref = O.radar_pose_net(sdr, ex, fuse, weight, cw)
+    ref["loss"][0].backward()
+    assert abs(float(eng.losses()["loss"]) - float(ref["loss"][0])) < 2e-4 * abs(float(ref["loss"][0]))
+    for k in sd:
+        if sdr[k].grad is not None:
+            assert rel_err(flat.grads[k], sdr[k].grad) < 1e-2, (k, rel_err(flat.grads[k], sdr[k].grad))
+    gw = flat.grads["pose_head.tasks.0.reg.0.weight"]
+    assert float(gw[:, 32:].abs().max()) > 0, "the LiDAR input channels of the tower weights receive gradient"
+    # without the LiDAR stream the result differs (the grid really is read)
+    ex2 = {"rdr": dict(ex["rdr"], lidar_grid=torch.zeros_like(ex["rdr"]["lidar_grid"])), "meta": ex["meta"]}
+    ref2 = O.radar_pose_net(sd, ex2, fuse, weight, cw)
+    assert abs(float(ref2["loss"][0]) - float(ref["loss"][0])) > 1e-6
+
+
 def test_fused_stride2_data_gradient_route(monkeypatch):
     monkeypatch.setenv("RTP_FUSED_S2", "1")   # built and tested, off by default (graph.ConvOp._fusable)
     """Volumes wide enough for the stride-2 parity-class kernel (Wo % 16 == 0): the first conv of a fuse chain from branch 0

@@ -21,7 +21,8 @@ def main():
     from rt_pose_amd.trainer import DataParallelTrainer
     spec = configs.spec(a.model)
     tr = DataParallelTrainer(a.model, a.batch, configs.NATIVE_DIMS, total_steps=100, use_graph=False)
-    ex = synth.make_batch(a.batch, spec["cin"], configs.NATIVE_DIMS, seed=1234, one_hm=spec["heads"]["hm"] == 1)
+    ex = synth.make_batch(a.batch, spec["cin"], configs.NATIVE_DIMS, seed=1234, one_hm=spec["heads"]["hm"] == 1,
+                          lidar_channels=spec.get("lidar_channels", 0))
     tr.load(ex)
     for _ in range(3):
         tr.step()
