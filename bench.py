@@ -368,15 +368,21 @@ def main():
         # (level-1 tensors, 16-channel head outputs); graph.py's conv_tiled totals include both
         rest_f = g.flops["conv_tiled"] - g.flops["conv_tiled_full"]
         rest_b = g.alg_bytes["conv_tiled"] - g.alg_bytes["conv_tiled_full"]
+        fb_f, fb_b = g.flops["conv_tiled_full_bwd"], g.alg_bytes["conv_tiled_full_bwd"]
         fams = {"conv_tiled_kernel<2,...> 32->32ch 3x3x3 at full resolution (fwd+dgrad)":
-                    (_lib.FAM_CONV_TILED_FULL, g.flops["conv_tiled_full"], g.alg_bytes["conv_tiled_full"]),
+                    ((_lib.FAM_CONV_TILED_FULL, _lib.FAM_CONV_TILED_FULL_BWD), g.flops["conv_tiled_full"], g.alg_bytes["conv_tiled_full"]),
+                # the same launches split: forward (class bias / residual / ReLU / statistics epilogue, GroupNorm fold prologue) and
+                # data gradient (most of them the fused variants that also do the gradient fan-in and GroupNorm-backward apply)
+                "  of which forward": (_lib.FAM_CONV_TILED_FULL, g.flops["conv_tiled_full"] - fb_f, g.alg_bytes["conv_tiled_full"] - fb_b),
+                "  of which data gradient": (_lib.FAM_CONV_TILED_FULL_BWD, fb_f, fb_b),
                 "conv_tiled other geometries (level 1, 16-channel outputs)": (_lib.FAM_CONV_TILED, rest_f, rest_b),
                 "conv_igemm generic (fwd+dgrad)": (_lib.FAM_CONV, g.flops["conv_generic"], g.alg_bytes["conv_generic"]),
                 "wgrad_tiled (32ch 3x3x3)": (_lib.FAM_WGRAD_TILED, g.flops["wgrad_tiled"], g.alg_bytes["wgrad_tiled"]),
                 "wgrad generic": (_lib.FAM_WGRAD, g.flops["wgrad_generic"], g.alg_bytes["wgrad_generic"])}
         tr.use_graph = False
         tr.engine.use_lanes = False  # one stream while timing kernels: concurrent side-stream work would inflate the events
-        for fam, _, _ in fams.values():
+        all_fams = sorted({f for fam, _, _ in fams.values() for f in (fam if isinstance(fam, tuple) else (fam,))})
+        for fam in all_fams:
             be.prof_enable(fam, True)
         ksteps = min(args.steps, 5)
         for _ in range(ksteps):
@@ -384,9 +390,13 @@ def main():
         torch.cuda.synchronize()
         best = None
         detail = {}
-        for kname, (fam, flops, nbytes) in fams.items():
-            ms, cnt = be.prof_collect(fam)
+        collected = {}
+        for fam in all_fams:
+            collected[fam] = be.prof_collect(fam)
             be.prof_enable(fam, False)
+        for kname, (fam, flops, nbytes) in fams.items():
+            parts = [collected[f] for f in (fam if isinstance(fam, tuple) else (fam,))]
+            ms, cnt = sum(p_[0] for p_ in parts), sum(p_[1] for p_ in parts)
             if cnt == 0:
                 continue
             tf = flops * ksteps / (ms * 1e-3) / 1e12
@@ -394,7 +404,7 @@ def main():
             detail[kname] = {"launches_per_step": cnt // ksteps, "ms_per_step": round(ms / ksteps, 3),
                              "avg_us_per_launch": round(1e3 * ms / cnt, 2), "tflops": round(tf, 2),
                              "algorithmic_GBps": round(gbps, 1), "hbm_frac": round(gbps / PEAK_HBM_GBPS, 4)}
-            if best is None or ms > best[1]:
+            if not kname.startswith("  ") and (best is None or ms > best[1]):
                 best = (kname, ms, tf, gbps)
         # HBM bytes per launch of the dominant kernel: PMC counters cannot be read inside this process, so the separate
         # rocprofv3 --pmc passes (tools/pmc_tiled.sh: FETCH_SIZE doubled per MI355X_MICROARCH.md, + WRITE_SIZE, B=8

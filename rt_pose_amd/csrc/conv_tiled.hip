@@ -967,7 +967,8 @@ int rtp_conv_tiled_try(const RtpAct* x, const void* wf, int w_per_sample, const 
   }
   const int nt = Co / 16;
   const size_t shm = sizeof(bf16_t) * (27 * (size_t)Co * 32 + 2 * (size_t)HALO_VOX * 32) + 27 * (size_t)Co * sizeof(float) + 16;
-  RtpProfScope prof((Co == 32 && (long)p.N * p.D * p.H * p.W >= (1L << 20)) ? RTP_FAM_CONV_TILED_FULL : RTP_FAM_CONV_TILED, s);
+  RtpProfScope prof((Co == 32 && (long)p.N * p.D * p.H * p.W >= (1L << 20)) ? (transposed ? RTP_FAM_CONV_TILED_FULL_BWD : RTP_FAM_CONV_TILED_FULL)
+                                                                                : RTP_FAM_CONV_TILED, s);
   using Kern = void (*)(TiledParams);
 #define RTP_TILED_ROW(NT, BT) \
   {{conv_tiled_kernel<NT, BT, 0, false>, conv_tiled_kernel<NT, BT, 0, true>}, \

@@ -125,9 +125,10 @@ class Graph:
         self.full_vox = None       # voxels of the first (full-resolution) activation: lanes are assigned by resolution
         # algorithmic FLOPs (2*MACs of real channels) per kernel family, per replay of the lists
         self.flops = {"conv_fwd": 0, "conv_dgrad": 0, "wgrad": 0, "conv_tiled": 0, "conv_generic": 0,
-                      "wgrad_tiled": 0, "wgrad_generic": 0, "conv_tiled_full": 0}
+                      "wgrad_tiled": 0, "wgrad_generic": 0, "conv_tiled_full": 0, "conv_tiled_full_bwd": 0}
         # algorithmic HBM bytes (fused minimum, SURVEY 8d: every operand tensor of a launch read or written once) per family
-        self.alg_bytes = {"conv_tiled": 0, "conv_generic": 0, "wgrad_tiled": 0, "wgrad_generic": 0, "conv_tiled_full": 0}
+        self.alg_bytes = {"conv_tiled": 0, "conv_generic": 0, "wgrad_tiled": 0, "wgrad_generic": 0, "conv_tiled_full": 0,
+                          "conv_tiled_full_bwd": 0}
 
     # ------------------------------------------------------------------ helpers
     def act(self, *a, **k):
@@ -571,6 +572,8 @@ class ConvOp:
             if self.tiled_bwd and ge.ci == 32 and g.n * x.vox >= (1 << 20):   # transposed: the kernel's Cout is the conv's Cin
                 g.flops["conv_tiled_full"] += self.alg_flops
                 g.alg_bytes["conv_tiled_full"] += nb
+                g.flops["conv_tiled_full_bwd"] += self.alg_flops
+                g.alg_bytes["conv_tiled_full_bwd"] += nb
             if self.gn:
                 if not S:
                     S = x.stats_split
@@ -729,6 +732,8 @@ class ConvOp:
         if g.n * x.vox >= (1 << 20):
             g.flops["conv_tiled_full"] += self.alg_flops
             g.alg_bytes["conv_tiled_full"] += nb
+            g.flops["conv_tiled_full_bwd"] += self.alg_flops
+            g.alg_bytes["conv_tiled_full_bwd"] += nb
 
 
 class SplitConvOp:
@@ -831,6 +836,8 @@ class SplitConvOp:
             if g.n * x.vox >= (1 << 20):
                 g.flops["conv_tiled_full"] += self.alg_flops
                 g.alg_bytes["conv_tiled_full"] += nb
+                g.flops["conv_tiled_full_bwd"] += self.alg_flops
+                g.alg_bytes["conv_tiled_full_bwd"] += nb
         wl = g.wg_lane_of(gy)
         csum = g.class_sums_for(self.y, gy, wl, self.name) if self.bname else None
         for k in range(self.K):
@@ -911,6 +918,8 @@ class CoSplitConvOp:
             if self.big:
                 g.flops["conv_tiled_full"] += self.alg_flops
                 g.alg_bytes["conv_tiled_full"] += 2 * g.n * (gy.vox * 64 + x.vox * 32)
+                g.flops["conv_tiled_full_bwd"] += self.alg_flops
+                g.alg_bytes["conv_tiled_full_bwd"] += 2 * g.n * (gy.vox * 64 + x.vox * 32)
         wl = g.wg_lane_of(gy)
         for k, (a, c) in enumerate(self.slices):
             gk = self.geom(c)
