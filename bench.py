@@ -276,8 +276,15 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        # RTP_BENCH_ONE_DEVICE=1 (test rigs with a single GPU): every rank on cuda:0 over gloo -- exercises this file's N > 1
+        # control flow (barriers, max over ranks, rank-0 JSON) where RCCL cannot run; the numbers mean nothing
+        if os.environ.get("RTP_BENCH_ONE_DEVICE"):
+            local = 0
+            torch.cuda.set_device(0)
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     else:
         torch.cuda.set_device(0)
     dev = "cuda:%d" % local
