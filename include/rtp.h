@@ -215,6 +215,15 @@ typedef struct RtpTerm {
   int d, h, w;       /* spatial dims of the term (fuse_sum: low-res terms are upsampled) */
 } RtpTerm;
 
+/* Lazy GroupNorm-backward coefficients of a GN term of rtp_grad_combine_cls_lazy: computed in that kernel's prologue (the
+ * arithmetic of rtp_gn_bwd_coeffs) from the statistics partials the data-gradient launch left behind; the term's `coeff`
+ * buffer ([n*c*5] fp32, as rtp_gn_bwd_coeffs) is then an OUTPUT (coefficients + dgamma/dbeta partials, written once per
+ * sample).  pq == NULL: the term is not lazy. */
+typedef struct RtpGnLazy {
+  const float* pq; int nsplit;     /* [n][nsplit][c][2]: P = sum dxhat, Q = sum dxhat * x */
+  const float* mr; const float* gamma; int groups;
+} RtpGnLazy;
+
 /* GroupNorm-backward inputs from which rtp_conv_dgrad_fused computes its coefficients in its own prologue (no kernel of
  * their own between the weight gradient and the data gradient). */
 typedef struct RtpGnBwd {
@@ -260,6 +269,11 @@ typedef struct RtpGnFold {
 } RtpGnFold;
 int rtp_conv_gn_fused(const RtpAct* x, const RtpGnFold* f /*host*/, const RtpAct* res, const RtpAct* y, const RtpConvGeom* g,
                       int relu, float* stat_out, void* stream);
+
+/* rtp_grad_combine_cls with lazy[k] (host array of nterms, or NULL) describing terms whose coefficients the kernel computes. */
+int rtp_grad_combine_cls_lazy(const RtpTerm* terms /*host*/, int nterms, const RtpGnLazy* lazy /*host*/, const RtpAct* x,
+                              const RtpAct* relu_src, const RtpAct* out, int n, int d, int h, int w, int nsplit,
+                              float* cls_scratch, void* stream);
 
 /* out = mask(relu_src > 0) * sum_k term_k ; GN terms evaluate A*dxhat + B*x + C.  All same resolution. */
 int rtp_grad_combine(const RtpTerm* terms /*host*/, int nterms, const RtpAct* x, const RtpAct* relu_src,

@@ -41,6 +41,10 @@ class RtpGnFold(C.Structure):
                 ("nsplit", C.c_int), ("groups", C.c_int), ("co_real", C.c_int), ("eps", C.c_float), ("mr", C.c_void_p)]
 
 
+class RtpGnLazy(C.Structure):
+    _fields_ = [("pq", C.c_void_p), ("nsplit", C.c_int), ("mr", C.c_void_p), ("gamma", C.c_void_p), ("groups", C.c_int)]
+
+
 class RtpTerm(C.Structure):
     _fields_ = [("t", RtpAct), ("coeff", C.c_void_p), ("d", C.c_int), ("h", C.c_int), ("w", C.c_int)]
 
@@ -88,6 +92,7 @@ PROTOTYPES = {
     "rtp_tail_launch": [_P, _P, _I, _I, _I, _P],
     "rtp_grad_combine": [_T, _I, _A, _A, _A, _I, _L, _P],
     "rtp_grad_combine_cls": [_T, _I, _A, _A, _A, _I, _I, _I, _I, _I, _P, _P],
+    "rtp_grad_combine_cls_lazy": [_T, _I, _P, _A, _A, _A, _I, _I, _I, _I, _I, _P, _P],
     "rtp_fuse_sum": [_T, _I, _P, _A, _I, _I, _I, _I, _I, _P],
     "rtp_upsample_bwd": [_A, _I, _I, _I, _A, _I, _I, _I, _I, _P, _P],
     "rtp_upsample_bwd_scratch_floats": [_I] * 8,

@@ -273,6 +273,7 @@ class HipBackend:
         arr = (RtpTerm * len(terms))()
         for i, t in enumerate(terms):
             v, coeff = t if isinstance(t, tuple) else (t, None)
+            coeff = getattr(coeff, "tensor", coeff)   # graph.LazyCoeff: the buffer the coefficients live in
             arr[i].t = _act(v)
             arr[i].coeff = coeff.data_ptr() if coeff is not None else None
             arr[i].d, arr[i].h, arr[i].w = (v.d, v.h, v.w) if with_dims else (0, 0, 0)
@@ -281,15 +282,26 @@ class HipBackend:
     def grad_combine(self, terms, x, relu_src, out, cls=None):
         """cls = (nsplit, scratch): also emit per-boundary-class partial sums of the result (rtp_grad_combine_cls)."""
         arr = self._terms(terms, False)
+        lazies = [cf for _, cf in terms if hasattr(cf, "pq")]   # graph.LazyCoeff terms still to be computed
         if cls is not None:
-            fn = self.lib.rtp_grad_combine_cls
-            args = (arr, len(terms), _act(x), _act(relu_src), _act(out), out.n, out.d, out.h, out.w, cls[0], _ptr(cls[1]))
-            keep = (terms, x, relu_src, out, cls)
-            return lambda s: check(fn(*args, s), "rtp_grad_combine_cls") or keep and None
+            lz = None
+            if lazies:   # ... by this launch's prologue
+                lz = (_lib.RtpGnLazy * len(terms))()
+                for i, (_, cf) in enumerate(terms):
+                    if hasattr(cf, "pq"):
+                        lz[i].pq, lz[i].nsplit, lz[i].mr, lz[i].gamma, lz[i].groups = (cf.pq.data_ptr(), cf.nsplit, cf.mr.data_ptr(),
+                                                                                      cf.gamma.data_ptr(), cf.groups)
+            fn = self.lib.rtp_grad_combine_cls_lazy
+            args = (arr, len(terms), lz, _act(x), _act(relu_src), _act(out), out.n, out.d, out.h, out.w, cls[0], _ptr(cls[1]))
+            keep = (terms, x, relu_src, out, cls, lz)
+            return lambda s: check(fn(*args, s), "rtp_grad_combine_cls_lazy") or keep and None
+        assert not lazies, "lazy GroupNorm coefficients need the class-sum combine (graph.finalize_grad materialises them otherwise)"
         fn = self.lib.rtp_grad_combine
         args = (arr, len(terms), _act(x), _act(relu_src), _act(out), out.n, out.vox)
         keep = (terms, x, relu_src, out)
         return lambda s: check(fn(*args, s), "rtp_grad_combine") or keep and None
+
+    grad_combine_lazy_ok = True   # rtp_grad_combine_cls_lazy: GroupNorm-backward coefficients in the combine's prologue
 
     @staticmethod
     def grad_combine_cls_ok(c):

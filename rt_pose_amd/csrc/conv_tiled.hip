@@ -504,6 +504,7 @@ __global__ __launch_bounds__(512, 2) void conv_tiled_kernel(TiledParams p) {
   // between two MFMA phases with the matrix pipe idle (measured: MFMA loop alone 52 us, whole kernel 80 us).
   constexpr int CH = 4 * NT;  // channels this lane owns: [c0, c0 + CH)
   const int c0 = q * CH;
+  const unsigned res_lane = (unsigned)(v * p.r_cs + c0);   // lane part of every residual address (element offset)
   f32x4 acc[TY][NT];
   bf16x8 pre_r8[TY];
   bf16x4 pre_r4[TY];
@@ -716,13 +717,14 @@ __global__ __launch_bounds__(512, 2) void conv_tiled_kernel(TiledParams p) {
       // every brick (measured: epilogue 78 us of a 132 us launch).  The class bias comes from the LDS table.
       const int oz = z0 + wz, ox = x0 + wx * 16 + v;
       const int kzx = ((oz == 0) ? 1 : (oz == p.D - 1) ? 2 : 0) * 9 + ((ox == 0) ? 1 : (ox == p.W - 1) ? 2 : 0);
+      // address = wave-uniform 64-bit row base (scalar unit) + this lane's constant 32-bit element offset
+      const bf16_t* res_row = p.res + (vox_n + ((long)oz * p.H + y0) * p.W + x0 + wx * 16) * p.r_cs + p.r_co;
 #pragma unroll
       for (int t = 0; t < TY; ++t) {
-        const long vo = vox_n + ((long)oz * p.H + (y0 + t)) * p.W + ox;
         pre_r8[t] = zero_bf16x8();
         pre_r4[t] = bf16x4{(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
         if constexpr (AUX != 0) {  // compile-time: a runtime select per load makes hipcc branch around each one and wait vmcnt(0) early
-          const bf16_t* rp = p.res + vo * p.r_cs + p.r_co + c0;
+          const bf16_t* rp = res_row + (long)t * p.W * p.r_cs + res_lane;
           if constexpr (NT == 2) pre_r8[t] = ld_bf16x8(rp);
           else pre_r4[t] = *reinterpret_cast<const bf16x4*>(rp);
         }

@@ -7,7 +7,11 @@
 // ------------------------------------------------------------------------------------------------
 // rtp_grad_combine
 // ------------------------------------------------------------------------------------------------
-struct CombTerm { const bf16_t* t; int cs, co; const float* coeff; };
+// lazy (rtp_grad_combine_cls_lazy): the GroupNorm-backward coefficients of a GN term are computed in the kernel's prologue from
+// the statistics partials pq [n][pq_nsplit][c][2] the data-gradient launch left behind (P = sum dxhat, Q = sum dxhat * x) --
+// the arithmetic of rtp_gn_bwd_coeffs, without a launch of its own between the data gradient and the fan-in pass.
+struct CombTerm { const bf16_t* t; int cs, co; const float* coeff;
+                  const float* pq; int pq_nsplit; const float* mr; const float* gamma; int groups; float* coef_out; };
 struct CombParams {
   CombTerm terms[RTP_MAX_TERMS]; int nterms;
   const bf16_t* x; int x_cs, x_co;
@@ -125,7 +129,7 @@ extern "C" int rtp_grad_combine(const RtpTerm* terms, int nterms, const RtpAct* 
   bool need_x = false;
   for (int k = 0; k < nterms; ++k) {
     if (terms[k].t.c != p.c || (terms[k].t.cs % 8) || (terms[k].t.co % 8)) return RTP_ERR_ALIGN;
-    p.terms[k] = CombTerm{(const bf16_t*)terms[k].t.ptr, terms[k].t.cs, terms[k].t.co, terms[k].coeff};
+    p.terms[k] = CombTerm{(const bf16_t*)terms[k].t.ptr, terms[k].t.cs, terms[k].t.co, terms[k].coeff, nullptr, 0, nullptr, nullptr, 1, nullptr};
     need_x |= terms[k].coeff != nullptr;
   }
   if (need_x && (!x || (x->cs % 8) || (x->co % 8))) return RTP_ERR_SHAPE;
@@ -155,9 +159,68 @@ __global__ __launch_bounds__(256) void grad_combine_cls_kernel(CombParams p, int
   const int c = p.c, cpv = c >> 3, chunk = lane % cpv;
   float* mine = cls_lds + wave * 64 * c;
   float* cfs = cls_lds + 4 * 64 * c;
+  for (int k = 0; k < p.nterms; ++k) {
+    const CombTerm& t = p.terms[k];
+    if (t.pq) {   // kernel-uniform: lazy coefficients of this term for sample n (the class-sum region is scratch until zeroed below)
+      float2* part_pq = reinterpret_cast<float2*>(cls_lds);   // [256]
+      float* P = cls_lds + 512;                               // [c]
+      float* Q = P + 64;                                      // [c]
+      float* S1 = Q + 64;                                     // [groups]
+      float* S2 = S1 + 64;
+      const int cg = c / t.groups;
+      const float m = (float)cg * (float)((long)D * H * W);
+      float pc = 0.f, qc = 0.f, mu = 0.f, r = 0.f, gam = 0.f;
+      {
+        const int np = 256 / c, ch = tid % c, pt = tid / c;
+        float2 a = make_float2(0.f, 0.f);
+        if (pt < np)
+          for (int s_ = pt; s_ < t.pq_nsplit; s_ += np) {
+            const float2 q2 = *reinterpret_cast<const float2*>(t.pq + (((long)n * t.pq_nsplit + s_) * c + ch) * 2);
+            a.x += q2.x;
+            a.y += q2.y;
+          }
+        part_pq[tid] = a;
+        __syncthreads();
+        if (tid < c)
+          for (int k2 = 0; k2 < np; ++k2) { pc += part_pq[k2 * c + tid].x; qc += part_pq[k2 * c + tid].y; }
+      }
+      if (tid < c) {
+        const int g = tid / cg;
+        mu = t.mr[((long)n * t.groups + g) * 2];
+        r = t.mr[((long)n * t.groups + g) * 2 + 1];
+        gam = t.gamma[tid];
+        P[tid] = gam * pc;
+        Q[tid] = gam * r * (qc - mu * pc);
+        if (s == 0 && t.coef_out) {   // dgamma / dbeta partials for the deferred parameter sums (rtp_tail_desc_gn_param)
+          float* pt2 = t.coef_out + (long)gridDim.y * c * 3 + ((long)n * c + tid) * 2;
+          pt2[0] = r * (qc - mu * pc);
+          pt2[1] = pc;
+        }
+      }
+      __syncthreads();
+      if (tid < t.groups) {
+        float s1 = 0.f, s2 = 0.f;
+        for (int k2 = tid * cg; k2 < (tid + 1) * cg; ++k2) { s1 += P[k2]; s2 += Q[k2]; }
+        S1[tid] = s1;
+        S2[tid] = s2;
+      }
+      __syncthreads();
+      if (tid < c) {
+        const int g = tid / cg;
+        const float a0 = r * gam, b0 = -r * r * S2[g] / m, c0 = -r * S1[g] / m + r * r * mu * S2[g] / m;
+        float* o = cfs + k * c * 3 + tid * 3;
+        o[0] = a0; o[1] = b0; o[2] = c0;
+        if (s == 0 && t.coef_out) {
+          float* og = t.coef_out + ((long)n * c + tid) * 3;
+          og[0] = a0; og[1] = b0; og[2] = c0;
+        }
+      }
+      __syncthreads();
+    }
+  }
   for (int i = tid; i < 4 * 64 * c; i += 256) cls_lds[i] = 0.f;
   for (int k = 0; k < p.nterms; ++k)
-    if (p.terms[k].coeff)
+    if (p.terms[k].coeff && !p.terms[k].pq)
       for (int i = tid; i < c * 3; i += 256) cfs[k * c * 3 + i] = p.terms[k].coeff[(long)n * c * 3 + i];
   __syncthreads();
   const bool same_rx = p.relu == p.x && p.r_cs == p.x_cs && p.r_co == p.x_co;
@@ -245,7 +308,7 @@ static int comb_params(CombParams& p, const RtpTerm* terms, int nterms, const Rt
   bool need_x = false;
   for (int k = 0; k < nterms; ++k) {
     if (terms[k].t.c != p.c || (terms[k].t.cs % 8) || (terms[k].t.co % 8)) return RTP_ERR_ALIGN;
-    p.terms[k] = CombTerm{(const bf16_t*)terms[k].t.ptr, terms[k].t.cs, terms[k].t.co, terms[k].coeff};
+    p.terms[k] = CombTerm{(const bf16_t*)terms[k].t.ptr, terms[k].t.cs, terms[k].t.co, terms[k].coeff, nullptr, 0, nullptr, nullptr, 1, nullptr};
     need_x |= terms[k].coeff != nullptr;
   }
   if (need_x && (!x || (x->cs % 8) || (x->co % 8))) return RTP_ERR_SHAPE;
@@ -256,12 +319,29 @@ static int comb_params(CombParams& p, const RtpTerm* terms, int nterms, const Rt
   return RTP_OK;
 }
 
+extern "C" int rtp_grad_combine_cls_lazy(const RtpTerm* terms, int nterms, const RtpGnLazy* lazy, const RtpAct* x, const RtpAct* relu_src,
+                                         const RtpAct* out, int n, int d, int h, int w, int nsplit, float* cls_scratch,
+                                         void* stream);
+
 extern "C" int rtp_grad_combine_cls(const RtpTerm* terms, int nterms, const RtpAct* x, const RtpAct* relu_src,
                                     const RtpAct* out, int n, int d, int h, int w, int nsplit, float* cls_scratch,
                                     void* stream) {
+  return rtp_grad_combine_cls_lazy(terms, nterms, nullptr, x, relu_src, out, n, d, h, w, nsplit, cls_scratch, stream);
+}
+
+extern "C" int rtp_grad_combine_cls_lazy(const RtpTerm* terms, int nterms, const RtpGnLazy* lazy, const RtpAct* x, const RtpAct* relu_src,
+                                         const RtpAct* out, int n, int d, int h, int w, int nsplit, float* cls_scratch,
+                                         void* stream) {
   CombParams p;
   int rc = comb_params(p, terms, nterms, x, relu_src, out);
   if (rc != RTP_OK) return rc;
+  for (int k = 0; lazy && k < nterms; ++k) {
+    if (!lazy[k].pq) continue;
+    if (!terms[k].coeff || !lazy[k].mr || !lazy[k].gamma || lazy[k].nsplit < 1 || lazy[k].groups < 1 || p.c % lazy[k].groups || p.c < 8)
+      return RTP_ERR_SHAPE;
+    p.terms[k].pq = lazy[k].pq; p.terms[k].pq_nsplit = lazy[k].nsplit; p.terms[k].mr = lazy[k].mr; p.terms[k].gamma = lazy[k].gamma;
+    p.terms[k].groups = lazy[k].groups; p.terms[k].coef_out = const_cast<float*>(terms[k].coeff);
+  }
   if (!cls_scratch || nsplit < 1) return RTP_ERR_SHAPE;
   if (p.c > 64 || (64 % (p.c / 8))) return RTP_ERR_UNSUPPORTED;
   p.n = n; p.vox = (long)d * h * w;

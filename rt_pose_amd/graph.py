@@ -20,6 +20,7 @@ The `backend` supplies the kernels (rt_pose_amd.backend.HipBackend in the produc
 emulation of each kernel to check this file's plan logic without a GPU).  Every backend method returns a
 closure f(stream) so argument marshalling happens once, at build time.
 """
+import os
 from dataclasses import dataclass, field
 from typing import List, Optional
 
@@ -65,6 +66,28 @@ class View:
     @property
     def dims(self):
         return (self.d, self.h, self.w)
+
+
+class LazyCoeff:
+    """GroupNorm-backward coefficients of one conv's input that no launch has computed yet: the fan-in pass that consumes them
+    (rtp_grad_combine_cls_lazy) does it in its own prologue, from the statistics partials of the data gradient.  `materialise`
+    emits the rtp_gn_bwd_coeffs launch instead, for consumers that need the finished table (fused data-gradient epilogues, the
+    plain combine)."""
+
+    def __init__(self, g, name, lane, pq, nsplit, mr, gamma, n, c, groups, vox, tensor):
+        self.g, self.name, self.lane = g, name, lane
+        self.pq, self.nsplit, self.mr, self.gamma, self.n, self.c, self.groups, self.vox = pq, nsplit, mr, gamma, n, c, groups, vox
+        self.tensor = tensor          # [n*c*5] fp32: coefficients [n][c][3] + dgamma/dbeta partials [n][c][2]
+        self.done = False
+
+    def materialise(self):
+        if not self.done:
+            g = self.g
+            g.emit_bwd(g.be.gn_bwd_coeffs(self.pq, self.nsplit, self.mr, self.gamma, self.n, self.c, self.groups, self.vox,
+                                          self.tensor, None, None, 0),
+                       self.lane, [self.pq, self.mr], [self.tensor], "gncoef:" + self.name)
+            self.done = True
+        return self.tensor
 
 
 class Act(View):
@@ -326,9 +349,23 @@ class Graph:
                 nsplit = cls_split(t.d, t.h)
                 cls = (nsplit, self.be.alloc((self.n, nsplit, 64, c), "f32"))
                 t.grad_cls = cls
+            # coefficients nobody has computed yet: the class-sum combine does it in its prologue, anything else gets the launch
+            lazy_ok = cls is not None and hasattr(self.be, "grad_combine_lazy_ok") and not os.environ.get("RTP_NO_LAZY_COEF")
+            reads, writes = [], []
+            for i, (v, cf) in enumerate(chunk):
+                if isinstance(cf, LazyCoeff):
+                    if cf.done or not lazy_ok:
+                        chunk[i] = (v, cf.materialise())
+                        reads.append(cf.tensor)
+                    else:
+                        cf.done = True          # computed (and written out) by this launch
+                        reads += [cf.pq, cf.mr]
+                        writes.append(cf.tensor)
+                else:
+                    reads.append(cf)
             self.emit_bwd(self.be.grad_combine(chunk, t if need_x else None, t if (t.relu and last) else None, t.grad, cls),
-                          self.lane_of(t), [v for v, _ in chunk] + [cf for _, cf in chunk] + [t],
-                          [t.grad, cls[1] if cls else None], "combine:" + t.name)
+                          self.lane_of(t), [v for v, _ in chunk] + reads + [t],
+                          [t.grad, cls[1] if cls else None] + writes, "combine:" + t.name)
             first = False
         return t.grad
 
@@ -579,12 +616,16 @@ class ConvOp:
                     S = x.stats_split
                     g.emit_bwd(be.chan_stats(dxh, x, S, pq), lane, [dxh, x], [pq], "pq:" + self.name)
                 coeff = be.alloc((g.n * ge.ci * 5,), "f32")  # [n][c][3] coefficients + [n][c][2] scratch
-                g.emit_bwd(be.gn_bwd_coeffs(pq, S, self.mr, g.params[self.gn[0]], g.n, self.ci_real, self.groups,
-                                            x.vox, coeff, None, None, 0),
-                           lane, [pq, self.mr], [coeff], "gncoef:" + self.name)
+                # no launch yet: the fan-in pass of x computes them in its prologue when it can (LazyCoeff); the parameter sums
+                # of the deferred tail read the partials that pass writes
+                lz = LazyCoeff(g, self.name, lane, pq, S, self.mr, g.params[self.gn[0]], g.n, self.ci_real, self.groups, x.vox, coeff)
                 g.tail_a.append(("gn_param", coeff, g.n, self.ci_real, g.pgrad[self.gn[0]], g.pgrad[self.gn[1]], 0))
-                if x.needs_grad:
-                    x.contribs.append((dxh, coeff))
+                if x.needs_grad and ge.ci == self.ci_real:
+                    x.contribs.append((dxh, lz))
+                else:           # nobody downstream will ask for them (or padded channels): compute now for the parameter sums
+                    lz.materialise()
+                    if x.needs_grad:
+                        x.contribs.append((dxh, coeff))
             elif x.needs_grad:
                 x.contribs.append((dxh, None))
         # ---- weight gradient
@@ -701,7 +742,7 @@ class ConvOp:
                          g.params[self.gn[1]] if self.gn else None, self.groups, ge, self.ci_real,
                          self.co_real, g.pgrad[self.wname], g.pgrad[self.bname] if self.bname else None, 0))
         # ---- data gradient -> finished gradient of x
-        terms = list(x.contribs)
+        terms = [(v, cf.materialise() if isinstance(cf, LazyCoeff) else cf) for v, cf in x.contribs]
         dx_buf = be.alloc((g.n, x.d, x.h, x.w, ge.ci), "bf16")
         dx = View(dx_buf, g.n, x.d, x.h, x.w, ge.ci, 0, ge.ci)
         reads = [gy, self.wd, x, coeff] + [v for v, _ in terms] + [cf for _, cf in terms]

@@ -598,8 +598,18 @@ class EmuBackend:
             out.copy_(scratch.view(n, nsplit, 64, c).sum(1))
         return run
 
+    grad_combine_lazy_ok = True
+
     def grad_combine(self, terms, x, relu_src, out, cls=None):
+        lazies = [cf for _, cf in terms if hasattr(cf, "pq")]
+        assert cls is not None or not lazies
+        coefs = [self.gn_bwd_coeffs(cf.pq, cf.nsplit, cf.mr, cf.gamma, cf.n, cf.c, cf.groups, cf.vox, cf.tensor, None, None, 0)
+                 for cf in lazies]
+        terms = [(v, getattr(cf, "tensor", cf)) for v, cf in terms]
+
         def run(s):
+            for f in coefs:   # (the HIP kernel computes them in its prologue)
+                f(s)
             acc = torch.zeros(out.n, out.d, out.h, out.w, out.c)
             for v, cf in terms:
                 if cf is None:

@@ -526,6 +526,44 @@ def test_grad_combine_fuse_upsample(hip):
         check(lp, BF, "upsample_bwd %r" % ((ld, lh, lw),))
 
 
+@pytest.mark.parametrize("dims,ch,groups,S", [((4, 8, 16), 32, 8, 5), ((2, 6, 10), 64, 8, 80), ((3, 5, 80), 32, 4, 1), ((2, 4, 8), 64, 8, 37)])
+def test_grad_combine_with_lazy_groupnorm_coefficients(hip, dims, ch, groups, S):
+    """rtp_grad_combine_cls_lazy: the fan-in pass computes the GroupNorm-backward coefficients of a GN term in its own prologue
+    from the statistics partials (P, Q) of the data gradient.  Must equal rtp_gn_bwd_coeffs + rtp_grad_combine_cls on the same
+    inputs (same arithmetic), write the same coefficient / dgamma-dbeta-partial table, and agree with the emulation."""
+    from rt_pose_amd.graph import LazyCoeff
+    n = 2
+    d, h, w = dims
+    _, xc, xg = views(hip, rnd((n, d, h, w, ch), 330, relu=True), n, d, h, w)
+    _, a1c, a1g = views(hip, rnd((n, d, h, w, ch), 331), n, d, h, w)
+    _, a2c, a2g = views(hip, rnd((n, d, h, w, ch), 332), n, d, h, w)
+    pq = Pair(hip, rnd((n, S, ch, 2), 333, torch.float32))
+    mr = Pair(hip, torch.stack([rnd((n, groups), 334, torch.float32) * 0.1, torch.rand(n, groups) + 0.5], -1).contiguous())
+    gam = Pair(hip, rnd((ch,), 335, torch.float32) * 0.2 + 1.0)
+    vox = d * h * w
+    ns = 3
+    res = {}
+    for mode in ("lazy", "launch"):
+        cf = Pair(hip, torch.zeros(n * ch * 5))
+        op, oc, og = views(hip, torch.zeros(n, d, h, w, ch, dtype=torch.bfloat16), n, d, h, w)
+        sc_c, sc_g = torch.zeros(n, ns, 64, ch), hip.alloc((n, ns, 64, ch), "f32")
+        if mode == "lazy":
+            lzc = LazyCoeff(None, "t", 0, pq.c, S, mr.c, gam.c, n, ch, groups, vox, cf.c)
+            lzg = LazyCoeff(None, "t", 0, pq.g, S, mr.g, gam.g, n, ch, groups, vox, cf.g)
+            run(hip, EMU.grad_combine([(a1c, None), (a2c, lzc)], xc, xc, oc, (ns, sc_c)),
+                hip.grad_combine([(a1g, None), (a2g, lzg)], xg, xg, og, (ns, sc_g)))
+            check(op, BF, "lazy combine vs emulation")
+            assert rel_err(cf.g.cpu(), cf.c) < 1e-4, "coefficient table vs emulation"
+        else:
+            hip.gn_bwd_coeffs(pq.g, S, mr.g, gam.g, n, ch, groups, vox, cf.g, None, None, 0)(hip.stream())
+            hip.grad_combine([(a1g, None), (a2g, cf.g)], xg, xg, og, (ns, sc_g))(hip.stream())
+            torch.cuda.synchronize()
+        res[mode] = (op.g.float().cpu(), cf.g.cpu().clone(), sc_g.cpu().clone())
+    assert rel_err(res["lazy"][1], res["launch"][1]) < 1e-6, "same coefficient / partial table as the stand-alone launch"
+    assert rel_err(res["lazy"][0], res["launch"][0]) < 1e-3
+    assert rel_err(res["lazy"][2].sum(1), res["launch"][2].sum(1)) < 1e-3
+
+
 def test_stem_and_pack(hip):
     n, d, h, w = 2, 4, 8, 16
     x = Pair(hip, torch.relu(rnd((n, 1, d, h, w), 40, torch.float32)))
