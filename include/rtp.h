@@ -288,6 +288,12 @@ int rtp_grad_combine_cls(const RtpTerm* terms /*host*/, int nterms, const RtpAct
  * (hr3d.py:205-229, hrnet3d.py:37-39). bias fp32 [c] or NULL. */
 int rtp_fuse_sum(const RtpTerm* terms /*host*/, int nterms, const float* bias, const RtpAct* out, int n, int d, int h,
                  int w, int relu, void* stream);
+/* The same row that also emits the per-channel statistics of what it stores (sum y, sum y^2; one partial per block,
+ * stat_out fp32 [n][nsplit][c][2] with nsplit = rtp_fuse_stats_nsplit(n, c, d, h, w) > 0) -- the input of the next GroupNorm
+ * without a read pass of its own (rtp_chan_stats). */
+int rtp_fuse_stats_nsplit(int n, int c, int d, int h, int w);
+int rtp_fuse_sum_stats(const RtpTerm* terms /*host*/, int nterms, const float* bias, const RtpAct* out, int n, int d, int h,
+                       int w, int relu, float* stat_out, int nsplit, void* stream);
 
 /* Adjoint of the trilinear upsample: glow[n][dl][hl][wl][c] = up^T(ghi), as three separable 1-D passes;
  * scratch fp32 [rtp_upsample_bwd_scratch_floats(...)]. */

@@ -94,6 +94,8 @@ PROTOTYPES = {
     "rtp_grad_combine_cls": [_T, _I, _A, _A, _A, _I, _I, _I, _I, _I, _P, _P],
     "rtp_grad_combine_cls_lazy": [_T, _I, _P, _A, _A, _A, _I, _I, _I, _I, _I, _P, _P],
     "rtp_fuse_sum": [_T, _I, _P, _A, _I, _I, _I, _I, _I, _P],
+    "rtp_fuse_sum_stats": [_T, _I, _P, _A, _I, _I, _I, _I, _I, _P, _I, _P],
+    "rtp_fuse_stats_nsplit": [_I, _I, _I, _I, _I],
     "rtp_upsample_bwd": [_A, _I, _I, _I, _A, _I, _I, _I, _I, _P, _P],
     "rtp_upsample_bwd_scratch_floats": [_I] * 8,
     "rtp_stem_fwd": [_P, _P, _P, _A, _I, _L, _P],

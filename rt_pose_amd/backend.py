@@ -308,11 +308,17 @@ class HipBackend:
         """Channel counts rtp_grad_combine_cls accepts."""
         return c <= 64 and c % 8 == 0 and 64 % (c // 8) == 0
 
-    def fuse_sum(self, terms, bias, out, relu):
-        fn, arr = self.lib.rtp_fuse_sum, self._terms(terms, True)
-        args = (arr, len(terms), _ptr(bias), _act(out), out.n, out.d, out.h, out.w, int(relu))
-        keep = (terms, bias, out)
-        return lambda s: check(fn(*args, s), "rtp_fuse_sum") or keep and None
+    def fuse_stats_nsplit(self, out):
+        """Statistics partials per sample rtp_fuse_sum_stats writes for this row (0: not offered)."""
+        return int(self.lib.rtp_fuse_stats_nsplit(out.n, out.c, out.d, out.h, out.w))
+
+    def fuse_sum(self, terms, bias, out, relu, stats=None):
+        """stats = (nsplit, fp32 [n, nsplit, c, 2]): the row also emits the statistics of what it stores (rtp_fuse_sum_stats)."""
+        fn, arr = self.lib.rtp_fuse_sum_stats, self._terms(terms, True)
+        args = (arr, len(terms), _ptr(bias), _act(out), out.n, out.d, out.h, out.w, int(relu),
+                _ptr(stats[1]) if stats else None, stats[0] if stats else 0)
+        keep = (terms, bias, out, stats)
+        return lambda s: check(fn(*args, s), "rtp_fuse_sum_stats") or keep and None
 
     def upsample_bwd(self, ghi, glow):
         fn = self.lib.rtp_upsample_bwd

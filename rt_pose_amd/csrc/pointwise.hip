@@ -366,7 +366,26 @@ struct FuseParams {
   FuseTerm terms[RTP_MAX_TERMS]; int nterms;
   const float* bias; bf16_t* out; int o_cs, o_co;
   int c, n, d, h, w, relu;
+  // optional (rtp_fuse_sum_stats): per-channel (sum y, sum y^2) of the stored (rounded) row, one partial per block
+  // [n][stat_blocks][c][2] -- what rtp_chan_stats would compute in a read pass of its own; the grid is then (stat_blocks, n)
+  float* stat_out; int stat_blocks;
 };
+
+// statistics of a thread's items -> one partial per block.  Every item of a thread has the same 8-channel chunk (the index
+// stride is a multiple of 256 and c / 8 divides 256), threads tid = chunk (mod c / 8) own the same channels.
+__device__ __forceinline__ void fuse_stats_flush(const FuseParams& p, int n, const float (&sy)[8], const float (&sq)[8]) {
+  __shared__ float red[256][17];
+  const int tid = threadIdx.x, cpv = p.c >> 3;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { red[tid][j] = sy[j]; red[tid][8 + j] = sq[j]; }
+  __syncthreads();
+  for (int t = tid; t < cpv * 16; t += 256) {
+    const int ck = t >> 4, j = t & 15;
+    float a = 0.f;
+    for (int m = ck; m < 256; m += cpv) a += red[m][j];   // fixed order
+    p.stat_out[(((long)n * p.stat_blocks + blockIdx.x) * p.c + ck * 8 + (j & 7)) * 2 + (j >> 3)] = a;
+  }
+}
 
 __host__ __device__ __forceinline__ float ac_scale(int I, int O) { return (O > 1) ? (float)(I - 1) / (float)(O - 1) : 0.f; }
 
@@ -382,8 +401,11 @@ __device__ __forceinline__ void src_index(int o, int I, int O, float scale, int&
 __global__ __launch_bounds__(256) void fuse_sum_kernel(FuseParams p) {
   const int cpv = p.c >> 3;
   const long vox = (long)p.d * p.h * p.w;
-  const long total = (long)p.n * vox * cpv;
-  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+  const bool per_sample = p.stat_out != nullptr;   // grid (stat_blocks, n): a block stays inside one sample
+  const long total = (per_sample ? 1 : (long)p.n) * vox * cpv, ibase = per_sample ? (long)blockIdx.y * vox * cpv : 0;
+  float sy[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, sq[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (long i_ = blockIdx.x * 256L + threadIdx.x; i_ < total; i_ += (long)gridDim.x * 256) {
+    const long i = ibase + i_;
     const int ck = (int)(i % cpv);
     const long vv = i / cpv;
     const int n = (int)(vv / vox);
@@ -428,7 +450,12 @@ __global__ __launch_bounds__(256) void fuse_sum_kernel(FuseParams p) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) o[j] = f2bf(p.relu ? (acc[j] > 0.f ? acc[j] : 0.f) : acc[j]);
     st_bf16x8(p.out + vv * p.o_cs + p.o_co + ck * 8, o);
+    if (per_sample) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float r = bf2f(o[j]); sy[j] += r; sq[j] += r * r; }
+    }
   }
+  if (per_sample) fuse_stats_flush(p, blockIdx.y, sy, sq);
 }
 
 // Row-run variant: a thread owns FX consecutive output voxels of one x-row (one 8-channel chunk).  For an up-sampled
@@ -439,8 +466,12 @@ __global__ __launch_bounds__(256) void fuse_sum_kernel(FuseParams p) {
 #define FSPAN 5
 __global__ __launch_bounds__(256) void fuse_sum_rows_kernel(FuseParams p) {
   const int cpv = p.c >> 3, runs = p.w / FX;
-  const long total = (long)p.n * p.d * p.h * runs * cpv;
-  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+  const bool per_sample = p.stat_out != nullptr;   // grid (stat_blocks, n): a block stays inside one sample
+  const long per_n = (long)p.d * p.h * runs * cpv;
+  const long total = (per_sample ? 1 : (long)p.n) * per_n, ibase = per_sample ? (long)blockIdx.y * per_n : 0;
+  float sy[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, sq[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (long i_ = blockIdx.x * 256L + threadIdx.x; i_ < total; i_ += (long)gridDim.x * 256) {
+    const long i = ibase + i_;
     const int ck = (int)(i % cpv);
     long r = i / cpv;
     const int xs = (int)(r % runs) * FX;
@@ -545,8 +576,13 @@ __global__ __launch_bounds__(256) void fuse_sum_rows_kernel(FuseParams p) {
 #pragma unroll
       for (int c = 0; c < 8; ++c) o[c] = f2bf(p.relu ? (acc[j][c] > 0.f ? acc[j][c] : 0.f) : acc[j][c]);
       st_bf16x8(p.out + (vv0 + j) * p.o_cs + p.o_co + ck * 8, o);
+      if (per_sample) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) { const float r = bf2f(o[c]); sy[c] += r; sq[c] += r * r; }
+      }
     }
   }
+  if (per_sample) fuse_stats_flush(p, blockIdx.y, sy, sq);
 }
 
 // can every up-sampled term's FX-output run be served from FSPAN source voxels?
@@ -567,10 +603,32 @@ static bool fuse_rows_ok(const FuseParams& p) {
   return true;
 }
 
+// Statistics partials per sample the fused epilogue writes: enough blocks to fill the chip, at most 128 partials to fold later.
+extern "C" int rtp_fuse_stats_nsplit(int n, int c, int d, int h, int w) {
+  if (c < 8 || c % 8 || 256 % (c / 8) || n < 1) return 0;
+  const long items = (long)d * h * ((w % FX) ? w : w / FX) * (c / 8);
+  long s = (items + 255) / 256;          // blocks that would each do one pass
+  s = (s + 3) / 4;                       // ~4 items per thread
+  const long want = (2048 + n - 1) / n;  // ... but >= ~2048 blocks in the launch when the row is that large
+  if (s > want) s = want;
+  if (s > 128) s = 128;
+  return (int)(s < 1 ? 1 : s);
+}
+
+extern "C" int rtp_fuse_sum_stats(const RtpTerm* terms, int nterms, const float* bias, const RtpAct* out, int n, int d, int h,
+                                  int w, int relu, float* stat_out, int nsplit, void* stream);
+
 extern "C" int rtp_fuse_sum(const RtpTerm* terms, int nterms, const float* bias, const RtpAct* out, int n, int d, int h,
                             int w, int relu, void* stream) {
+  return rtp_fuse_sum_stats(terms, nterms, bias, out, n, d, h, w, relu, nullptr, 0, stream);
+}
+
+extern "C" int rtp_fuse_sum_stats(const RtpTerm* terms, int nterms, const float* bias, const RtpAct* out, int n, int d, int h,
+                                  int w, int relu, float* stat_out, int nsplit, void* stream) {
   if (!terms || nterms < 1 || nterms > RTP_MAX_TERMS || !out) return RTP_ERR_SHAPE;
+  if (stat_out && (nsplit < 1 || 256 % (out->c / 8))) return RTP_ERR_SHAPE;
   FuseParams p;
+  p.stat_out = stat_out; p.stat_blocks = stat_out ? nsplit : 0;
   p.nterms = nterms; p.c = out->c;
   if (p.c % 8 || (out->cs % 8) || (out->co % 8)) return RTP_ERR_ALIGN;
   for (int k = 0; k < nterms; ++k) {
@@ -583,10 +641,12 @@ extern "C" int rtp_fuse_sum(const RtpTerm* terms, int nterms, const float* bias,
   p.n = n; p.d = d; p.h = h; p.w = w; p.relu = relu;
   hipStream_t s = (hipStream_t)stream;
   RtpProfScope prof(RTP_FAM_POINTWISE, s);
+  const dim3 grid_rows = stat_out ? dim3(nsplit, n) : dim3(grid_for((long)n * d * h * (w / FX) * (p.c / 8)));
+  const dim3 grid_pts = stat_out ? dim3(nsplit, n) : dim3(grid_for((long)n * d * h * w * (p.c / 8)));
   if (fuse_rows_ok(p))
-    hipLaunchKernelGGL(fuse_sum_rows_kernel, dim3(grid_for((long)n * d * h * (w / FX) * (p.c / 8))), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(fuse_sum_rows_kernel, grid_rows, dim3(256), 0, s, p);
   else
-    hipLaunchKernelGGL(fuse_sum_kernel, dim3(grid_for((long)n * d * h * w * (p.c / 8))), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(fuse_sum_kernel, grid_pts, dim3(256), 0, s, p);
   RTP_CHECK_LAUNCH();
   return RTP_OK;
 }

@@ -282,14 +282,23 @@ class Graph:
         op.emit_forward()
         return y
 
-    def fuse(self, name, terms: List[Act], relu=True):
+    def fuse(self, name, terms: List[Act], relu=True, want_stats=True):
         """HighResolutionModule fuse row (hr3d.py:213-228): terms at other resolutions are upsampled."""
         hi = max(terms, key=lambda t: t.vox)
         y = self.act(name, hi.c_real, hi.dims, c=hi.c, relu=relu)
         op = FuseOp(self, terms, y)
         y.producer = op
         self.ops.append(op)
-        self.emit_fwd(self.be.fuse_sum(terms, None, y, relu), self.lane_of(y), terms, [y], "fuse:" + name)
+        # a fuse row feeds GroupNorm convs of the next stage: it emits the statistics of what it stores (no chan_stats pass)
+        S = self.be.fuse_stats_nsplit(y) if (want_stats and hasattr(self.be, "fuse_stats_nsplit")
+                                            and not os.environ.get("RTP_NO_FUSE_STATS")) else 0
+        st = None
+        if S > 0:
+            y.stats_split = S
+            y.stats = self.be.alloc((self.n, S, y.c, 2), "f32")
+            st = (S, y.stats)
+        self.emit_fwd(self.be.fuse_sum(terms, None, y, relu, st) if st else self.be.fuse_sum(terms, None, y, relu),
+                      self.lane_of(y), terms, [y, y.stats if st else None], "fuse:" + name)
         return y
 
     def dcn_adapt(self, name, x: Act, prefix):
@@ -345,12 +354,17 @@ class Graph:
                 chunk = [(t.grad, None)] + chunk
             last = not terms
             cls = None
-            if last and want_cls and self.be.grad_combine_cls_ok(c):
+            can_lazy = hasattr(self.be, "grad_combine_lazy_ok") and not os.environ.get("RTP_NO_LAZY_COEF")
+            pending = can_lazy and any(isinstance(cf, LazyCoeff) and not cf.done for _, cf in chunk)
+            # the class-sum variant of the combine also when nobody wants the sums but a term's coefficients are still to be
+            # computed: its prologue does that (per-sample blocks), which is cheaper than a coefficient launch in the chain
+            if last and (want_cls or pending) and self.be.grad_combine_cls_ok(c):
                 nsplit = cls_split(t.d, t.h)
                 cls = (nsplit, self.be.alloc((self.n, nsplit, 64, c), "f32"))
-                t.grad_cls = cls
+                if want_cls:
+                    t.grad_cls = cls
             # coefficients nobody has computed yet: the class-sum combine does it in its prologue, anything else gets the launch
-            lazy_ok = cls is not None and hasattr(self.be, "grad_combine_lazy_ok") and not os.environ.get("RTP_NO_LAZY_COEF")
+            lazy_ok = cls is not None and can_lazy
             reads, writes = [], []
             for i, (v, cf) in enumerate(chunk):
                 if isinstance(cf, LazyCoeff):

@@ -79,7 +79,7 @@ def build_backbone(g: Graph, x_f32, arch, dims, prefix="backbone.backbone", live
                         t = _seq(g, "%s.fuse_layers.%d.%d.%d" % (sp, i, j, k), t, "s%d.f%d%d.%d" % (stage, i, j, k), 3, 2,
                                  relu=(k != i - j - 1), want_stats=(k != i - j - 1))
                     terms.append(t)
-            ys[i] = g.fuse("s%d.row%d" % (stage, i), terms, relu=True)
+            ys[i] = g.fuse("s%d.row%d" % (stage, i), terms, relu=True, want_stats=stage < 4)   # (stage-4 rows feed no GroupNorm)
     return ys
 
 
@@ -105,7 +105,8 @@ def build_hrnet3d(g: Graph, x_f32, arch, dims, final_fuse, prefix="backbone"):
                             bname=(prefix + ".final_conv.bias") if j == 0 else None, ks=1,
                             w_ci_total=total, w_ci_off=off, ci_real=ch[j], want_stats=False))
         off += ch[j]
-    return g.fuse("final.sum", terms, relu=False)
+    return g.fuse("final.sum", terms, relu=False,
+                  want_stats=(prefix.replace("backbone", "pose_head") + ".shared_conv.1.weight") in g.params)
 
 
 def build_head(g: Graph, feats, heads, prefix="pose_head", lidar=None):

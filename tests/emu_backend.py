@@ -627,7 +627,10 @@ class EmuBackend:
                 part[:, 0].index_add_(1, _classes(out.d, out.h, out.w).reshape(-1), _sl(out).reshape(out.n, out.vox, out.c))
         return run
 
-    def fuse_sum(self, terms, bias, out, relu):
+    def fuse_stats_nsplit(self, out):
+        return 2
+
+    def fuse_sum(self, terms, bias, out, relu, stats=None):
         def run(s):
             acc = torch.zeros(out.n, out.d, out.h, out.w, out.c)
             if bias is not None:
@@ -640,6 +643,11 @@ class EmuBackend:
             if relu:
                 acc = acc.clamp_min(0)
             _store(out, acc)
+            if stats is not None:   # statistics of the stored (rounded) row, all in partial 0
+                yv = _sl(out).reshape(out.n, out.vox, out.c)
+                stats[1].zero_()
+                stats[1][:, 0, :, 0] = yv.sum(1)
+                stats[1][:, 0, :, 1] = (yv * yv).sum(1)
         return run
 
     def upsample_bwd(self, ghi, glow):

@@ -507,6 +507,17 @@ def test_grad_combine_fuse_upsample(hip):
     for relu in (True, False):
         run(hip, EMU.fuse_sum(tc, None, oc, relu), hip.fuse_sum(tg, None, og, relu))
         check(op, BF, "fuse_sum relu=%s" % relu)
+        # with the statistics epilogue: same row, and the partials sum to a chan_stats pass over the tensor the kernel stored
+        S = hip.fuse_stats_nsplit(og)
+        assert S > 0
+        st = hip.alloc((n, S, c, 2), "f32")
+        before = op.g.clone()
+        hip.fuse_sum(tg, None, og, relu, (S, st))(hip.stream())
+        ref = hip.alloc((n, 3, c, 2), "f32")
+        hip.chan_stats(og, None, 3, ref)(hip.stream())
+        torch.cuda.synchronize()
+        assert torch.equal(op.g, before), "statistics variant stores the same row"
+        assert rel_err(st.sum(1).cpu(), ref.sum(1).cpu()) < F32, "fused fuse-row statistics"
     # native row width (160 <- 80, 40, 20: the row-run kernel) and a width that takes the point-per-thread kernel
     for (dd, hh, ww), lowdims in (((2, 4, 160), [(1, 2, 80), (1, 1, 40), (2, 1, 20)]), ((2, 3, 12), [(1, 2, 6), (1, 1, 5)])):
         _, b0c, b0g = views(hip, rnd((n, dd, hh, ww, c), 230), n, dd, hh, ww)
@@ -518,6 +529,13 @@ def test_grad_combine_fuse_upsample(hip):
             tg2.append(lg)
         run(hip, EMU.fuse_sum(tc2, None, boc, True), hip.fuse_sum(tg2, None, bog, True))
         check(bp, BF, "fuse_sum %r" % ((dd, hh, ww),))
+        S = hip.fuse_stats_nsplit(bog)
+        st = hip.alloc((n, S, c, 2), "f32")
+        hip.fuse_sum(tg2, None, bog, True, (S, st))(hip.stream())
+        ref = hip.alloc((n, 2, c, 2), "f32")
+        hip.chan_stats(bog, None, 2, ref)(hip.stream())
+        torch.cuda.synchronize()
+        assert rel_err(st.sum(1).cpu(), ref.sum(1).cpu()) < F32, "fused fuse-row statistics %r" % ((dd, hh, ww),)
     # upsample adjoint for x2, x4, x8 and a non-integer ratio
     for (ld, lh, lw), ch in (((2, 4, 8), 32), ((1, 2, 4), 64), ((1, 1, 2), 128), ((3, 5, 7), 32)):
         _, gc, gg = views(hip, rnd((n, d, h, w, ch), 38), n, d, h, w)
