@@ -86,7 +86,9 @@ def test_hr3d_plan_hazards_are_covered():
     eng = PoseEngine(be, flat.values, s["arch"], s["final_fuse"], s["heads"], s["weight"], s["code_weights"], 1,
                      (8, 16, 32), train=True, pgrads=flat.grads)
     assert {L.lane for L in eng.fwd} >= {lanes.L_FULL, lanes.L_MID, lanes.L_LOW}
-    assert {L.lane for L in eng.bwd} >= {lanes.L_FULL, lanes.L_MID, lanes.L_LOW, lanes.L_WG, lanes.L_WG_LOW}
+    # (the full-resolution weight-gradient lane L_WG is issued on the main lane by default: graph.Graph.emit_bwd, RTP_DEFER_WG)
+    assert {L.lane for L in eng.bwd} >= {lanes.L_FULL, lanes.L_MID, lanes.L_LOW, lanes.L_WG_LOW}
+    assert any(L.tag.startswith("wgrad:head.") and L.lane == lanes.L_FULL for L in eng.bwd)
     nf, nb = _check(eng.fwd), _check(eng.bwd)
     # and under the default lane -> stream mapping the engine replays with
     assert eng.fwd_plan.waits == plan_waits(eng.fwd, lanes.NLANES, eng.fwd_plan.lane_of)[0]
