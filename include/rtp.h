@@ -335,6 +335,12 @@ int rtp_focal_blocks(void);
 int rtp_reg_loss(const float* reg, int cpad, const float* target, const long long* ind, const unsigned char* mask,
                  const float* code_w, int n, int nreg, long vox, int m, float gscale, float* out,
                  const RtpAct* greg, void* stream);
+/* rtp_reg_loss without the zero fill of greg: prev_ind (device int64 [n*m], initialised to -1; greg zero-initialised once and
+ * written by nothing else) remembers the voxels of the previous call, the only non-zero ones: they are cleared, this call's are
+ * written and recorded. */
+int rtp_reg_loss_sparse(const float* reg, int cpad, const float* target, const long long* ind, const unsigned char* mask,
+                        const float* code_w, int n, int nreg, long vox, int m, float gscale, float* out, const RtpAct* greg,
+                        long long* prev_ind, void* stream);
 
 /* sigmoid -> per-channel first-index argmax -> offset decode (center_head.py:272-360).
  *   scale_xyz / origin_xyz: HOST fp32[3] = (out_size_factor*voxel_size, pc_range) per x,y,z

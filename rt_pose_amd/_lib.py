@@ -108,6 +108,7 @@ PROTOTYPES = {
     "rtp_focal_loss": [_P, _I, _P, _P, _P, _P, _I, _I, _L, _I, _F, _P, _P, _A, _P],
     "rtp_focal_blocks": [],
     "rtp_reg_loss": [_P, _I, _P, _P, _P, _P, _I, _I, _L, _I, _F, _P, _A, _P],
+    "rtp_reg_loss_sparse": [_P, _I, _P, _P, _P, _P, _I, _I, _L, _I, _F, _P, _A, _P, _P],
     "rtp_decode": [_P, _I, _P, _I, _I, _I, _I, _I, _I, _I, C.POINTER(_F), C.POINTER(_F), _P, _P, _P],
     "rtp_decode_scratch_floats": [_I, _I],
     "rtp_cube_prep": [_P, _L, _I, _I, _I, C.POINTER(_I), _F, _F, _I, _P, _P],

@@ -412,12 +412,17 @@ class HipBackend:
         keep = (logits, target, ind, mask, cat, scratch, out_loss, ghm)
         return lambda s: check(fn(*args, s), "rtp_focal_loss") or keep and None
 
-    def reg_loss(self, reg, target, ind, mask, code_w, nreg, gscale, out, greg):
-        fn = self.lib.rtp_reg_loss
+    def reg_loss(self, reg, target, ind, mask, code_w, nreg, gscale, out, greg, prev=None):
+        """prev (int64 [n, m], initialised to -1; greg zero-initialised and written by nothing else): rtp_reg_loss_sparse -- only
+        the previous call's voxels are cleared instead of zero-filling the gradient tensor."""
         n, vox, m = reg.n, reg.vox, ind.shape[1]
         args = (_ptr(reg.buf), reg.cs, _ptr(target), _ptr(ind), _ptr(mask), _ptr(code_w), n, nreg, vox, m,
                 float(gscale), _ptr(out), _act(greg))
-        keep = (reg, target, ind, mask, code_w, out, greg)
+        keep = (reg, target, ind, mask, code_w, out, greg, prev)
+        if prev is not None:
+            fn, args = self.lib.rtp_reg_loss_sparse, args + (_ptr(prev),)
+            return lambda s: check(fn(*args, s), "rtp_reg_loss_sparse") or keep and None
+        fn = self.lib.rtp_reg_loss
         return lambda s: check(fn(*args, s), "rtp_reg_loss") or keep and None
 
     def decode_scratch(self, n, ncls):

@@ -143,37 +143,63 @@ struct RegParams {
   int n, nreg, m; long vox; float gscale; float* out; bf16_t* g; int g_cs, g_co;
 };
 
-__global__ __launch_bounds__(256) void reg_loss_kernel(RegParams p) {
-  __shared__ float s_msum;
+// One block.  Rows (sample, object) are spread over the threads and reduced through LDS in fixed order (a single thread walking
+// the 120 rows paid one global-load latency per row: 60 us of a 75 us launch).  prev (optional, device, [n*m]): the voxels this
+// kernel wrote in the previous step -- only those are cleared instead of zero-filling the whole gradient tensor (it is zero
+// everywhere else by construction: nothing else writes it), then this step's voxels are recorded there.
+__global__ __launch_bounds__(256) void reg_loss_kernel(RegParams p, long long* prev) {
+  __shared__ float s_red[256];
   __shared__ float s_loss[64];
-  const int tid = threadIdx.x;
-  if (tid == 0) {
-    float ms = 0.f;
-    for (int i = 0; i < p.n * p.m; ++i) ms += p.mask[i] ? 1.f : 0.f;
-    s_msum = ms;
-  }
-  __syncthreads();
-  const float inv = 1.f / (s_msum + 1e-4f);
-  // per-channel loss: thread per channel (nreg <= 64)
-  if (tid < p.nreg) {
-    float acc = 0.f;
-    for (int r = 0; r < p.n * p.m; ++r) {
-      const int n = r / p.m;
-      const float mk = p.mask[r] ? 1.f : 0.f;
-      const float pred = p.reg[((long)n * p.vox + p.ind[r]) * p.cpad + tid];
-      acc += fabsf(pred * mk - p.target[(long)r * p.nreg + tid] * mk) * inv;
+  __shared__ float s_msum;
+  const int tid = threadIdx.x, rows = p.n * p.m;
+  if (prev) {   // clear last step's voxels (-1: nothing recorded yet)
+    for (int i = tid; i < rows * p.nreg; i += 256) {
+      const int c = i % p.nreg, r = i / p.nreg, n = r / p.m;
+      const long long v = prev[r];
+      if (v >= 0) p.g[((long)n * p.vox + v) * p.g_cs + p.g_co + c] = f2bf(0.f);
     }
-    s_loss[tid] = acc;
-    p.out[tid] = acc;
   }
-  __syncthreads();
+  {
+    float ms = 0.f;
+    for (int r = tid; r < rows; r += 256) ms += p.mask[r] ? 1.f : 0.f;
+    s_red[tid] = ms;
+    __syncthreads();
+    if (tid == 0) {
+      float a = 0.f;
+      for (int k = 0; k < 256; ++k) a += s_red[k];
+      s_msum = a;
+    }
+    __syncthreads();
+  }
+  const float inv = 1.f / (s_msum + 1e-4f);
+  // per-channel loss: 256 / 64 row groups x up to 64 channels, partial sums folded in fixed order
+  {
+    const int c = tid & 63, grp = tid >> 6;
+    float acc = 0.f;
+    if (c < p.nreg)
+      for (int r = grp; r < rows; r += 4) {
+        const int n = r / p.m;
+        const float mk = p.mask[r] ? 1.f : 0.f;
+        const float pred = p.reg[((long)n * p.vox + p.ind[r]) * p.cpad + c];
+        acc += fabsf(pred * mk - p.target[(long)r * p.nreg + c] * mk) * inv;
+      }
+    s_red[tid] = acc;
+    __syncthreads();
+    if (tid < p.nreg) {
+      const float a = (s_red[tid] + s_red[64 + tid]) + (s_red[128 + tid] + s_red[192 + tid]);
+      s_loss[tid] = a;
+      p.out[tid] = a;
+    }
+    __syncthreads();
+  }
   if (tid == 0) {
     float loc = 0.f;
     for (int c = 0; c < p.nreg; ++c) loc += s_loss[c] * p.cw[c];
     p.out[p.nreg] = loc;
   }
+  __syncthreads();   // (the clears above are ordered before the writes below: same thread set, barrier in between)
   // gradient scatter: the first row of each (sample, voxel) group sums its duplicates
-  for (int i = tid; i < p.n * p.m * p.nreg; i += 256) {
+  for (int i = tid; i < rows * p.nreg; i += 256) {
     const int c = i % p.nreg, r = i / p.nreg, n = r / p.m;
     bool first = true;
     for (int r2 = n * p.m; r2 < r; ++r2) first = first && (p.ind[r2] != p.ind[r]);
@@ -189,20 +215,40 @@ __global__ __launch_bounds__(256) void reg_loss_kernel(RegParams p) {
     }
     p.g[((long)n * p.vox + p.ind[r]) * p.g_cs + p.g_co + c] = f2bf(p.gscale * p.cw[c] * inv * gsum);
   }
+  if (prev) {
+    __syncthreads();
+    for (int r = tid; r < rows; r += 256) prev[r] = p.ind[r];
+  }
+}
+
+static int reg_loss_launch(const float* reg, int cpad, const float* target, const long long* ind, const unsigned char* mask,
+                           const float* code_w, int n, int nreg, long vox, int m, float gscale, float* out, const RtpAct* greg,
+                           long long* prev, void* stream) {
+  if (!reg || !target || !greg || nreg > 64 || nreg > cpad || nreg > greg->c) return RTP_ERR_SHAPE;
+  if (greg->co != 0 || greg->cs != greg->c) return RTP_ERR_SHAPE;  // zero-filled as one contiguous buffer
+  hipStream_t s = (hipStream_t)stream;
+  RtpProfScope prof(RTP_FAM_LOSS, s);
+  if (!prev && hipMemsetAsync(greg->ptr, 0, (size_t)n * vox * greg->cs * sizeof(bf16_t), s) != hipSuccess) return RTP_ERR_LAUNCH;
+  RegParams p{reg, cpad, target, ind, mask, code_w, n, nreg, m, vox, gscale, out, (bf16_t*)greg->ptr, greg->cs, greg->co};
+  hipLaunchKernelGGL(reg_loss_kernel, dim3(1), dim3(256), 0, s, p, prev);
+  RTP_CHECK_LAUNCH();
+  return RTP_OK;
 }
 
 extern "C" int rtp_reg_loss(const float* reg, int cpad, const float* target, const long long* ind,
                             const unsigned char* mask, const float* code_w, int n, int nreg, long vox, int m,
                             float gscale, float* out, const RtpAct* greg, void* stream) {
-  if (!reg || !target || !greg || nreg > 64 || nreg > cpad || nreg > greg->c) return RTP_ERR_SHAPE;
-  if (greg->co != 0 || greg->cs != greg->c) return RTP_ERR_SHAPE;  // zero-filled as one contiguous buffer
-  hipStream_t s = (hipStream_t)stream;
-  RtpProfScope prof(RTP_FAM_LOSS, s);
-  if (hipMemsetAsync(greg->ptr, 0, (size_t)n * vox * greg->cs * sizeof(bf16_t), s) != hipSuccess) return RTP_ERR_LAUNCH;
-  RegParams p{reg, cpad, target, ind, mask, code_w, n, nreg, m, vox, gscale, out, (bf16_t*)greg->ptr, greg->cs, greg->co};
-  hipLaunchKernelGGL(reg_loss_kernel, dim3(1), dim3(256), 0, s, p);
-  RTP_CHECK_LAUNCH();
-  return RTP_OK;
+  return reg_loss_launch(reg, cpad, target, ind, mask, code_w, n, nreg, vox, m, gscale, out, greg, nullptr, stream);
+}
+
+// The same with a state buffer instead of the zero fill: prev_ind (device, int64 [n*m], initialised to -1 by the caller; greg
+// zero-initialised once) holds the voxels written by the previous call, which are the only non-zero ones -- a call clears them,
+// writes this step's and records them.  greg must not be written by anything else.
+extern "C" int rtp_reg_loss_sparse(const float* reg, int cpad, const float* target, const long long* ind,
+                                   const unsigned char* mask, const float* code_w, int n, int nreg, long vox, int m,
+                                   float gscale, float* out, const RtpAct* greg, long long* prev_ind, void* stream) {
+  if (!prev_ind) return RTP_ERR_SHAPE;
+  return reg_loss_launch(reg, cpad, target, ind, mask, code_w, n, nreg, vox, m, gscale, out, greg, prev_ind, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -13,6 +13,8 @@ Data parallel: one process per GPU, batch sharded by rank, ONE all-reduce of the
 import math
 from collections import OrderedDict
 
+import os
+
 import torch
 
 from . import net
@@ -126,8 +128,19 @@ class PoseEngine:
             scratch = be.focal_scratch(batch)
             self.loss_launches.append(be.focal_loss(hm, self.tgt_hm, self.tgt_ind, self.tgt_mask, self.tgt_cat,
                                                     self.ncls, 1.0, scratch, self.loss_hm, self.ghm))
-            self.loss_launches.append(be.reg_loss(reg, self.tgt_pose, self.tgt_ind, self.tgt_mask, self.code_w,
-                                                  self.nreg, self.loss_weight, self.loss_reg, self.greg))
+            # the regression gradient is non-zero at <= m voxels per frame: instead of zero-filling its 84 MB every step the
+            # loss kernel clears the voxels it wrote last time (state: reg_prev; the buffer starts zeroed, nothing else writes it)
+            self.reg_prev = be.alloc((batch, self.m), "i64")
+            self.reg_prev.fill_(-1)
+            try:
+                if os.environ.get("RTP_REG_DENSE"):   # A/B: zero fill every step
+                    raise TypeError
+                rl = be.reg_loss(reg, self.tgt_pose, self.tgt_ind, self.tgt_mask, self.code_w, self.nreg, self.loss_weight,
+                                 self.loss_reg, self.greg, self.reg_prev)
+            except TypeError:   # (a backend without the stateful variant)
+                rl = be.reg_loss(reg, self.tgt_pose, self.tgt_ind, self.tgt_mask, self.code_w, self.nreg, self.loss_weight,
+                                 self.loss_reg, self.greg)
+            self.loss_launches.append(rl)
             g.seed_grad(hm, self.ghm)
             g.seed_grad(reg, self.greg)
             g.build_backward()

@@ -147,6 +147,8 @@ class Graph:
         self._defer_wg = [int(v) for v in os.environ.get("RTP_DEFER_WG", "3").split(",") if v.strip() != ""]
         self._defer_keep = int(os.environ.get("RTP_DEFER_KEEP", "4"))
         self._defer_tags = tuple(v for v in os.environ.get("RTP_DEFER_TAGS", "").split(",") if v)
+        # (the stem's weight gradient is the sweep's last launch: nothing left to wait for, it stays beside the tail on its lane)
+        self._defer_skip = set(v for v in os.environ.get("RTP_DEFER_SKIP", "stem_bwd").split(",") if v)
         self._deferred = []
         self.head, self._head_emitted = [], False   # activation-independent weight packing (forward_list)
         self.full_vox = None       # voxels of the first (full-resolution) activation: lanes are assigned by resolution
@@ -183,7 +185,7 @@ class Graph:
         # only time-share the CUs and stretch the critical chain -- but are queued and issued ON the main lane where it is about
         # to wait for the side lanes anyway: in front of the second fan-in of a full-resolution block output (RTP_DEFER_WG="3"
         # default, "" = off; only lanes whose results nothing but the tail reads may be listed: measured 6.30 -> 6.22 ms/step)
-        if (self._defer_wg and lane in self._defer_wg) or (self._defer_tags and tag.startswith(self._defer_tags)):
+        if ((self._defer_wg and lane in self._defer_wg) or (self._defer_tags and tag.startswith(self._defer_tags))) and tag not in self._defer_skip:
             self._deferred.append(Launch(fn, L_FULL, reads, writes, tag))
             return
         self.bwd.append(Launch(fn, lane, reads, writes, tag))

@@ -633,6 +633,24 @@ def test_losses_and_decode(hip, ncls, nreg):
         hip.reg_loss(rg, pose.g, ind.g, mask.g, cw.g, nreg, 0.2, lr.g, grg))
     check(lr, 1e-4, "reg loss values")
     check(grp, BF, "reg grad")
+    # the stateful variant (no zero fill: only the previous call's voxels are cleared), three calls with moving objects, against
+    # the zero-filling kernel on the same inputs -- bit for bit, values and the whole gradient tensor
+    g2 = torch.zeros(n, d, h, w, gr_c, dtype=torch.bfloat16, device=hip.device)
+    g2v = View(g2, n, d, h, w, gr_c, 0, gr_c)
+    prev = torch.full((n, m), -1, dtype=torch.int64, device=hip.device)
+    lr2 = torch.zeros(nreg + 1, device=hip.device)
+    gen = torch.Generator().manual_seed(7)
+    for it in range(3):
+        ind_i = ind.c.clone() if it == 0 else torch.randint(0, d * h * w, (n, m), generator=gen)
+        if it == 2 and m > 1:
+            ind_i[:, 1] = ind_i[:, 0]           # duplicate voxels within a frame (their gradients add, like gather's backward)
+        ind_g = ind_i.to(hip.device)
+        hip.reg_loss(rg, pose.g, ind_g, mask.g, cw.g, nreg, 0.2, lr.g, grg)(hip.stream())
+        hip.reg_loss(rg, pose.g, ind_g, mask.g, cw.g, nreg, 0.2, lr2, g2v, prev)(hip.stream())
+        torch.cuda.synchronize()
+        assert torch.equal(lr2.cpu(), lr.g.cpu()), it
+        assert torch.equal(g2.cpu(), grp.g.cpu()), "stateful reg-loss gradient tensor, call %d" % it
+        assert torch.equal(prev.cpu(), ind_i)
     out = Pair(hip, torch.zeros(n, ncls, 2 + nreg))
     sc, og = (0.05, 0.15, 0.36), (0.77, -5.0, -1.1)
     run(hip, EMU.decode(hc, rc, ncls, nreg, sc, og, None, out.c),
