@@ -326,6 +326,11 @@ int rtp_pack_ncdhw_ex(const float* x, const float* x2, const RtpAct* y, int n, i
 int rtp_focal_loss(const float* logits, int cpad, const float* target, const long long* ind, const unsigned char* mask,
                    const long long* cat, int n, int ncls, long vox, int m, float gscale, float* scratch,
                    float* out_loss, const RtpAct* ghm, void* stream);
+/* write_pad == 0: padding channels past the last class chunk of the gradient rows are not stored (buffer zeroed once, written by
+ * nothing else). */
+int rtp_focal_loss_ex(const float* logits, int cpad, const float* target, const long long* ind, const unsigned char* mask,
+                      const long long* cat, int n, int ncls, long vox, int m, float gscale, float* scratch, float* out_loss,
+                      const RtpAct* ghm, int write_pad, void* stream);
 int rtp_focal_blocks(void);
 
 /* RegLoss forward+backward (centernet_loss.py:17-24, center_head.py:252-258).

@@ -106,6 +106,7 @@ PROTOTYPES = {
     "rtp_pack_ncdhw_ex": [_P, _P, _A, _I, _I, _L, _I, _P],
     "rtp_unpack_ncdhw_f32": [_P, _I, _I, _P, _I, _I, _L, _P],
     "rtp_focal_loss": [_P, _I, _P, _P, _P, _P, _I, _I, _L, _I, _F, _P, _P, _A, _P],
+    "rtp_focal_loss_ex": [_P, _I, _P, _P, _P, _P, _I, _I, _L, _I, _F, _P, _P, _A, _I, _P],
     "rtp_focal_blocks": [],
     "rtp_reg_loss": [_P, _I, _P, _P, _P, _P, _I, _I, _L, _I, _F, _P, _A, _P],
     "rtp_reg_loss_sparse": [_P, _I, _P, _P, _P, _P, _I, _I, _L, _I, _F, _P, _A, _P, _P],

@@ -404,13 +404,14 @@ class HipBackend:
     def focal_scratch(self, n):
         return self.alloc((n * self.lib.rtp_focal_blocks() * 2,), "f32")
 
-    def focal_loss(self, logits, target, ind, mask, cat, ncls, gscale, scratch, out_loss, ghm):
-        fn = self.lib.rtp_focal_loss
+    def focal_loss(self, logits, target, ind, mask, cat, ncls, gscale, scratch, out_loss, ghm, write_pad=True):
+        """write_pad=False: the gradient rows' padding channels are not stored (ghm zeroed once, written by nothing else)."""
+        fn = self.lib.rtp_focal_loss_ex
         n, vox, m = logits.n, logits.vox, ind.shape[1]
         args = (_ptr(logits.buf), logits.cs, _ptr(target), _ptr(ind), _ptr(mask), _ptr(cat), n, ncls, vox, m,
-                float(gscale), _ptr(scratch), _ptr(out_loss), _act(ghm))
+                float(gscale), _ptr(scratch), _ptr(out_loss), _act(ghm), int(write_pad))
         keep = (logits, target, ind, mask, cat, scratch, out_loss, ghm)
-        return lambda s: check(fn(*args, s), "rtp_focal_loss") or keep and None
+        return lambda s: check(fn(*args, s), "rtp_focal_loss_ex") or keep and None
 
     def reg_loss(self, reg, target, ind, mask, code_w, nreg, gscale, out, greg, prev=None):
         """prev (int64 [n, m], initialised to -1; greg zero-initialised and written by nothing else): rtp_reg_loss_sparse -- only

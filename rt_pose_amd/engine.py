@@ -126,8 +126,13 @@ class PoseEngine:
             self.ghm = View(be.alloc((batch, d, h, w, ghm_c), "bf16"), batch, d, h, w, ghm_c, 0, ghm_c)
             self.greg = View(be.alloc((batch, d, h, w, greg_c), "bf16"), batch, d, h, w, greg_c, 0, greg_c)
             scratch = be.focal_scratch(batch)
-            self.loss_launches.append(be.focal_loss(hm, self.tgt_hm, self.tgt_ind, self.tgt_mask, self.tgt_cat,
-                                                    self.ncls, 1.0, scratch, self.loss_hm, self.ghm))
+            try:   # ghm is zeroed at allocation and written by this kernel only: its padding channels need no store
+                fl = be.focal_loss(hm, self.tgt_hm, self.tgt_ind, self.tgt_mask, self.tgt_cat, self.ncls, 1.0, scratch, self.loss_hm,
+                                   self.ghm, False)
+            except TypeError:
+                fl = be.focal_loss(hm, self.tgt_hm, self.tgt_ind, self.tgt_mask, self.tgt_cat, self.ncls, 1.0, scratch, self.loss_hm,
+                                   self.ghm)
+            self.loss_launches.append(fl)
             # the regression gradient is non-zero at <= m voxels per frame: instead of zero-filling its 84 MB every step the
             # loss kernel clears the voxels it wrote last time (state: reg_prev; the buffer starts zeroed, nothing else writes it)
             self.reg_prev = be.alloc((batch, self.m), "i64")

@@ -629,6 +629,13 @@ def test_losses_and_decode(hip, ncls, nreg):
         hip.focal_loss(hg, tgt.g, ind.g, mask.g, cat.g, ncls, 1.0, hip.focal_scratch(n), lh.g, ghg))
     check(lh, 1e-4, "focal loss value")
     check(ghp, BF, "focal grad")
+    # without the padding stores: identical class channels, padding channels left as they were
+    g3 = torch.full((n, d, h, w, gh_c), 7.0, dtype=torch.bfloat16, device=hip.device)
+    lh3 = torch.zeros(1, device=hip.device)
+    hip.focal_loss(hg, tgt.g, ind.g, mask.g, cat.g, ncls, 1.0, hip.focal_scratch(n), lh3, View(g3, n, d, h, w, gh_c, 0, gh_c), False)(hip.stream())
+    torch.cuda.synchronize()
+    wr = (ncls + 7) // 8 * 8
+    assert torch.equal(g3[..., :wr].cpu(), ghp.g[..., :wr].cpu()) and bool((g3[..., wr:] == 7.0).all()) and torch.equal(lh3.cpu(), lh.g.cpu())
     run(hip, EMU.reg_loss(rc, pose.c, ind.c, mask.c, cw.c, nreg, 0.2, lr.c, grc),
         hip.reg_loss(rg, pose.g, ind.g, mask.g, cw.g, nreg, 0.2, lr.g, grg))
     check(lr, 1e-4, "reg loss values")
