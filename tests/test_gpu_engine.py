@@ -196,3 +196,40 @@ def test_graph_replay_equals_eager_lane_mode(tmp_path):
     (l0, p0), (l1, p1) = out
     assert np.allclose(l0, l1, rtol=1e-4), (l0, l1)
     assert rel_err(p1, p0) < 1e-4
+
+
+@pytest.mark.parametrize("env", [{"RTP_DEFER_WG": ""}, {"RTP_NO_LAZY_COEF": "1"}, {"RTP_NO_FUSE_STATS": "1", "RTP_NO_FUSED_FOLD": "1"}])
+def test_schedule_and_fusion_switches_do_not_change_the_result(hip, env, monkeypatch):
+    """The plan-level choices of round 2 only move work between launches or change where a launch is issued: the weight-gradient
+    lane on the main lane (RTP_DEFER_WG), GroupNorm-backward coefficients in the combine's prologue (RTP_NO_LAZY_COEF),
+    statistics from the fuse rows and the fold inside the tiled conv (RTP_NO_FUSE_STATS, RTP_NO_FUSED_FOLD).  One train step
+    with each switch flipped must give the default plan's loss and parameter gradients up to summation-order noise."""
+    name, dims, batch = "hr3d", (8, 16, 32), 2
+    arch, fin, fout, fuse, heads, weight, cw = O.MODEL_CONFIGS[name]
+    shapes = O.param_shapes(arch, fin, fout, fout, heads)
+    sd = O.seeded_state_dict(shapes, seed=1)
+    ex = O.synth_example(batch, 1, dims, seed=1234)
+
+    def one():
+        flat = FlatParams(shapes, hip.alloc)
+        flat.load_state_dict(sd)
+        eng = PoseEngine(hip, flat.values, arch, fuse, heads, weight, cw, batch, dims, pgrads=flat.grads)
+        eng.load_input(ex["rdr"]["rdr_tensor"])
+        eng.load_targets(ex["rdr"])
+        eng.run_forward()
+        eng.run_loss_backward()
+        torch.cuda.synchronize()
+        return float(eng.losses()["loss"]), flat.g.detach().float().cpu().clone(), [L.tag for L in eng.bwd], [L.tag for L in eng.fwd]
+
+    l0, g0, bwd0, fwd0 = one()
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    l1, g1, bwd1, fwd1 = one()
+    assert (bwd0, fwd0) != (bwd1, fwd1), "the switch changes the launch lists"
+    assert abs(l0 - l1) <= 2e-3 * abs(l0), (l0, l1)       # (forward switches re-round a few weights / statistics)
+    if "RTP_DEFER_WG" in env or "RTP_NO_LAZY_COEF" in env:      # backward-only: same operands, same arithmetic
+        assert rel_err(g1, g0) < 1e-5, rel_err(g1, g0)
+    else:   # forward statistics summed in another order: a few folded weights move by a bf16 ulp, ReLU masks of single voxels
+            # flip -- the same gate as two bf16 evaluations of one plan elsewhere in this file
+        cos = float(torch.dot(g0, g1) / (g0.norm() * g1.norm()))
+        assert cos > 0.98 and abs(float(g1.norm() / g0.norm()) - 1) < 0.05, (cos, rel_err(g1, g0))
