@@ -232,4 +232,5 @@ def test_schedule_and_fusion_switches_do_not_change_the_result(hip, env, monkeyp
     else:   # forward statistics summed in another order: a few folded weights move by a bf16 ulp, ReLU masks of single voxels
             # flip -- the same gate as two bf16 evaluations of one plan elsewhere in this file
         cos = float(torch.dot(g0, g1) / (g0.norm() * g1.norm()))
+        print("\nforward switches: gradient cosine %.5f, norm ratio %.4f, loss %.6f vs %.6f" % (cos, float(g1.norm() / g0.norm()), l1, l0))
         assert cos > 0.98 and abs(float(g1.norm() / g0.norm()) - 1) < 0.05, (cos, rel_err(g1, g0))
