@@ -924,6 +924,28 @@ __global__ __launch_bounds__(256) void pack_ex_kernel(const float* x, const floa
   }
 }
 
+// fp32 channels-last -> NC(D)HW through an LDS tile of 64 voxels x all channels: 16-byte reads along the channels, 256-byte
+// rows along the voxels on the way out (the per-element version read with a 320-byte stride: 0.9 TB/s on the DCN head's
+// 72-channel offsets).  x_cs % 4 == 0, x_co % 4 == 0.
+__global__ __launch_bounds__(256) void unpack_f32_tile_kernel(const float* x, int x_cs, int x_co, float* y, int c, long vox) {
+  extern __shared__ float ut_lds[];   // [c4 * 4][65]
+  const int tid = threadIdx.x, c4 = (c + 3) >> 2;
+  const long v0 = (long)blockIdx.x * 64;
+  const int nn = blockIdx.y;
+  const int nv = (vox - v0 < 64) ? (int)(vox - v0) : 64;
+  for (int i = tid; i < nv * c4; i += 256) {
+    const int k = i % c4, v = i / c4;
+    const f32x4 t = *reinterpret_cast<const f32x4*>(x + ((long)nn * vox + v0 + v) * x_cs + x_co + k * 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ut_lds[(k * 4 + j) * 65 + v] = t[j];
+  }
+  __syncthreads();
+  for (int i = tid; i < c * 64; i += 256) {
+    const int v = i & 63, ch = i >> 6;
+    if (v < nv) y[((long)nn * c + ch) * vox + v0 + v] = ut_lds[ch * 65 + v];
+  }
+}
+
 __global__ __launch_bounds__(256) void unpack_f32_kernel(const float* x, int x_cs, int x_co, float* y, int n, int c, long vox) {
   const long total = (long)n * c * vox;
   for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
@@ -940,6 +962,12 @@ extern "C" int rtp_unpack_ncdhw_f32(const float* x, int x_cs, int x_co, float* y
   if (!x || !y || n < 1 || c < 1 || x_co + c > x_cs) return RTP_ERR_SHAPE;
   hipStream_t s = (hipStream_t)stream;
   RtpProfScope prof(RTP_FAM_POINTWISE, s);
+  if (x_cs % 4 == 0 && x_co % 4 == 0 && x_co + ((c + 3) / 4) * 4 <= x_cs && c <= 256 && (vox + 63) / 64 < (1L << 31) && n < 65536) {
+    const size_t lds = sizeof(float) * ((c + 3) / 4) * 4 * 65;
+    hipLaunchKernelGGL(unpack_f32_tile_kernel, dim3((unsigned)((vox + 63) / 64), n), dim3(256), lds, s, x, x_cs, x_co, y, c, vox);
+    RTP_CHECK_LAUNCH();
+    return RTP_OK;
+  }
   hipLaunchKernelGGL(unpack_f32_kernel, dim3(grid_for((long)n * vox * c)), dim3(256), 0, s, x, x_cs, x_co, y, n, c, vox);
   RTP_CHECK_LAUNCH();
   return RTP_OK;

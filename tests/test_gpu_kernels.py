@@ -582,6 +582,19 @@ def test_grad_combine_with_lazy_groupnorm_coefficients(hip, dims, ch, groups, S)
     assert rel_err(res["lazy"][2].sum(1), res["launch"][2].sum(1)) < 1e-3
 
 
+@pytest.mark.parametrize("n,c,cs,co,vox", [(2, 72, 80, 0, 64 * 160), (3, 5, 16, 4, 777), (1, 32, 32, 0, 63), (2, 7, 12, 4, 65)])
+def test_unpack_f32_channels_last_to_ncdhw(hip, n, c, cs, co, vox):
+    """rtp_unpack_ncdhw_f32 (the DCN head's offsets: fp32 channels-last conv output -> the operator's NCHW): exact copy, channel
+    slices, ragged voxel counts, channel counts that are not a multiple of 4."""
+    import ctypes as C
+    x = torch.randn(n, vox, cs, device=hip.device)
+    y = torch.full((n, c, vox), -7.0, device=hip.device)
+    rc = hip.lib.rtp_unpack_ncdhw_f32(C.c_void_p(x.data_ptr()), cs, co, C.c_void_p(y.data_ptr()), n, c, vox, hip.stream())
+    torch.cuda.synchronize()
+    assert rc == 0
+    assert torch.equal(y.cpu(), x[:, :, co:co + c].permute(0, 2, 1).contiguous().cpu())
+
+
 def test_stem_and_pack(hip):
     n, d, h, w = 2, 4, 8, 16
     x = Pair(hip, torch.relu(rnd((n, 1, d, h, w), 40, torch.float32)))
