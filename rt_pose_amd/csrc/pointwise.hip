@@ -973,10 +973,63 @@ extern "C" int rtp_unpack_ncdhw_f32(const float* x, int x_cs, int x_co, float* y
   return RTP_OK;
 }
 
+// The two hand-offs around the NCHW operator through an LDS tile of 64 voxels x all channels (256-byte rows on the NCHW side,
+// 16-byte chunks on the channels-last side) instead of one strided element / chunk per thread.
+__global__ __launch_bounds__(256) void pack_ex_tile_kernel(const float* x, const float* x2, bf16_t* y, int y_cs, int y_co, int c,
+                                                           int cpad, long vox, int relu) {
+  extern __shared__ float pt_lds[];   // [cpad][65]
+  const int tid = threadIdx.x, nn = blockIdx.y;
+  const long v0 = (long)blockIdx.x * 64;
+  const int nv = (vox - v0 < 64) ? (int)(vox - v0) : 64;
+  for (int i = tid; i < cpad * 64; i += 256) {
+    const int v = i & 63, ch = i >> 6;
+    float a = 0.f;
+    if (ch < c && v < nv) {
+      a = x[((long)nn * c + ch) * vox + v0 + v];
+      if (x2) a += x2[((long)nn * c + ch) * vox + v0 + v];
+      if (relu) a = a > 0.f ? a : 0.f;
+    }
+    pt_lds[ch * 65 + v] = a;
+  }
+  __syncthreads();
+  const int cpv = cpad >> 3;
+  for (int i = tid; i < nv * cpv; i += 256) {
+    const int ck = i % cpv, v = i / cpv;
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = f2bf(pt_lds[(ck * 8 + j) * 65 + v]);
+    st_bf16x8(y + ((long)nn * vox + v0 + v) * y_cs + y_co + ck * 8, o);
+  }
+}
+
+__global__ __launch_bounds__(256) void unpack_tile_kernel(const bf16_t* x, int x_cs, int x_co, float* y, int c, long vox) {
+  extern __shared__ float pt_lds[];   // [c8 * 8][65]
+  const int tid = threadIdx.x, nn = blockIdx.y, c8 = (c + 7) >> 3;
+  const long v0 = (long)blockIdx.x * 64;
+  const int nv = (vox - v0 < 64) ? (int)(vox - v0) : 64;
+  for (int i = tid; i < nv * c8; i += 256) {
+    const int k = i % c8, v = i / c8;
+    const bf16x8 t = ld_bf16x8(x + ((long)nn * vox + v0 + v) * x_cs + x_co + k * 8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) pt_lds[(k * 8 + j) * 65 + v] = bf2f(t[j]);
+  }
+  __syncthreads();
+  for (int i = tid; i < c * 64; i += 256) {
+    const int v = i & 63, ch = i >> 6;
+    if (v < nv) y[((long)nn * c + ch) * vox + v0 + v] = pt_lds[ch * 65 + v];
+  }
+}
+
 extern "C" int rtp_pack_ncdhw_ex(const float* x, const float* x2, const RtpAct* y, int n, int c, long vox, int relu, void* stream) {
   if (!x || !y || y->c % 8 || c > y->c || (y->cs % 8) || (y->co % 8)) return RTP_ERR_SHAPE;
   hipStream_t s = (hipStream_t)stream;
   RtpProfScope prof(RTP_FAM_POINTWISE, s);
+  if (y->c <= 128 && n < 65536) {
+    hipLaunchKernelGGL(pack_ex_tile_kernel, dim3((unsigned)((vox + 63) / 64), n), dim3(256), sizeof(float) * y->c * 65, s, x, x2,
+                       (bf16_t*)y->ptr, y->cs, y->co, c, y->c, vox, relu);
+    RTP_CHECK_LAUNCH();
+    return RTP_OK;
+  }
   hipLaunchKernelGGL(pack_ex_kernel, dim3(grid_for((long)n * vox * (y->c / 8))), dim3(256), 0, s, x, x2, (bf16_t*)y->ptr,
                      y->cs, y->co, n, c, y->c, vox, relu);
   RTP_CHECK_LAUNCH();
@@ -1008,6 +1061,12 @@ extern "C" int rtp_unpack_ncdhw(const RtpAct* x, float* y, int n, int c, long vo
   if (!x || !y || c > x->c) return RTP_ERR_SHAPE;
   hipStream_t s = (hipStream_t)stream;
   RtpProfScope prof(RTP_FAM_POINTWISE, s);
+  if ((x->cs % 8) == 0 && (x->co % 8) == 0 && x->co + ((c + 7) / 8) * 8 <= x->cs && c <= 128 && n < 65536) {
+    hipLaunchKernelGGL(unpack_tile_kernel, dim3((unsigned)((vox + 63) / 64), n), dim3(256), sizeof(float) * ((c + 7) / 8) * 8 * 65, s,
+                       (const bf16_t*)x->ptr, x->cs, x->co, y, c, vox);
+    RTP_CHECK_LAUNCH();
+    return RTP_OK;
+  }
   hipLaunchKernelGGL(unpack_kernel, dim3(grid_for((long)n * vox * c)), dim3(256), 0, s, (const bf16_t*)x->ptr, x->cs,
                      x->co, y, n, c, vox);
   RTP_CHECK_LAUNCH();

@@ -595,6 +595,34 @@ def test_unpack_f32_channels_last_to_ncdhw(hip, n, c, cs, co, vox):
     assert torch.equal(y.cpu(), x[:, :, co:co + c].permute(0, 2, 1).contiguous().cpu())
 
 
+@pytest.mark.parametrize("n,c,cpad,cs,co,vox,relu,two", [(2, 72, 96, 96, 0, 64 * 160, False, False), (3, 32, 32, 64, 32, 777, True, True),
+                                                         (1, 5, 8, 16, 8, 63, False, True), (2, 32, 32, 32, 0, 65, True, False)])
+def test_pack_ex_and_unpack_through_lds_tiles(hip, n, c, cpad, cs, co, vox, relu, two):
+    """rtp_pack_ncdhw_ex (fp32 NC(D)HW [+ second addend] [ReLU] -> bf16 channels-last slice, padding channels zero) and
+    rtp_unpack_ncdhw (bf16 channels-last slice -> fp32 NC(D)HW): exact against torch on ragged voxel counts and channel slices."""
+    import ctypes as C
+    from rt_pose_amd.backend import _act
+    x = torch.randn(n, c, vox, device=hip.device)
+    x2 = torch.randn(n, c, vox, device=hip.device) if two else None
+    y = torch.full((n, vox, cs), 3.0, dtype=torch.bfloat16, device=hip.device)
+    yv = View(y, n, 1, 1, vox, cs, co, cpad)
+    rc = hip.lib.rtp_pack_ncdhw_ex(C.c_void_p(x.data_ptr()), C.c_void_p(x2.data_ptr()) if two else None, _act(yv), n, c, vox, int(relu), hip.stream())
+    torch.cuda.synchronize()
+    assert rc == 0
+    ref = x + x2 if two else x.clone()
+    if relu:
+        ref = ref.clamp_min(0)
+    want = torch.full((n, vox, cs), 3.0, dtype=torch.bfloat16)
+    want[:, :, co:co + cpad] = 0
+    want[:, :, co:co + c] = ref.permute(0, 2, 1).to(torch.bfloat16).cpu()
+    assert torch.equal(y.cpu(), want)
+    back = torch.full((n, c, vox), -1.0, device=hip.device)
+    rc = hip.lib.rtp_unpack_ncdhw(_act(View(y, n, 1, 1, vox, cs, co, cpad)), C.c_void_p(back.data_ptr()), n, c, vox, hip.stream())
+    torch.cuda.synchronize()
+    assert rc == 0
+    assert torch.equal(back.cpu(), want[:, :, co:co + c].float().permute(0, 2, 1).contiguous())
+
+
 def test_stem_and_pack(hip):
     n, d, h, w = 2, 4, 8, 16
     x = Pair(hip, torch.relu(rnd((n, 1, d, h, w), 40, torch.float32)))
