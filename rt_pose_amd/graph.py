@@ -146,6 +146,9 @@ class Graph:
         self.tail_batch = int(os.environ.get("RTP_TAIL_BATCH", "1000000"))
         self._defer_wg = [int(v) for v in os.environ.get("RTP_DEFER_WG", "3").split(",") if v.strip() != ""]
         self._defer_keep = int(os.environ.get("RTP_DEFER_KEEP", "4"))
+        # at most this many launches move (the two 32-channel head towers of hr3d: 8; the wide heads of the one-heat-map configs
+        # queue 20+ launches there, more than the waits absorb: measured 11.20 ms/step without the move, 11.45 with all of it)
+        self._defer_max, self._ndeferred = int(os.environ.get("RTP_DEFER_MAX", "8")), 0
         self._defer_tags = tuple(v for v in os.environ.get("RTP_DEFER_TAGS", "").split(",") if v)
         # (the stem's weight gradient is the sweep's last launch: nothing left to wait for, it stays beside the tail on its lane)
         self._defer_skip = set(v for v in os.environ.get("RTP_DEFER_SKIP", "stem_bwd").split(",") if v)
@@ -185,7 +188,9 @@ class Graph:
         # only time-share the CUs and stretch the critical chain -- but are queued and issued ON the main lane where it is about
         # to wait for the side lanes anyway: in front of the second fan-in of a full-resolution block output (RTP_DEFER_WG="3"
         # default, "" = off; only lanes whose results nothing but the tail reads may be listed: measured 6.30 -> 6.22 ms/step)
-        if ((self._defer_wg and lane in self._defer_wg) or (self._defer_tags and tag.startswith(self._defer_tags))) and tag not in self._defer_skip:
+        if (((self._defer_wg and lane in self._defer_wg) or (self._defer_tags and tag.startswith(self._defer_tags)))
+                and tag not in self._defer_skip and self._ndeferred < self._defer_max):
+            self._ndeferred += 1
             self._deferred.append(Launch(fn, L_FULL, reads, writes, tag))
             return
         self.bwd.append(Launch(fn, lane, reads, writes, tag))
@@ -484,6 +489,10 @@ class Graph:
         for op in self.ops:
             for t in op.inputs():
                 self.first_consumer.setdefault(id(t), op)
+        # (the move of the weight-gradient lane onto the main lane pays for the two 32-channel towers of hr3d; the wide heads of
+        # the one-heat-map configs -- slice ops -- queue more work there than the waits absorb: 11.3 vs 11.5 ms/step, so not by default)
+        if "RTP_DEFER_WG" not in os.environ and any(isinstance(op, (SplitConvOp, CoSplitConvOp)) for op in self.ops):
+            self._defer_wg = []
         for op in reversed(self.ops):
             gy = self.finalize_grad(op.y, isinstance(op, (ConvOp, SplitConvOp, CoSplitConvOp)) and bool(op.gn or op.bname))
             if gy is None:
