@@ -63,8 +63,35 @@ def step(db, full):
     print("device busy (union) %.1f us" % (tot / 1e3))
 
 
+def tiled(db, steps):
+    """The persistent tiled kernels split by geometry (the same template instantiation serves the full-resolution tensors and the
+    level-1 ones: per-name averages mix them) -- the rows bench.py's `roofline.families` are to be compared with."""
+    cls = {}
+    for r in rows(db):
+        n, d = r["name"].replace("void ", ""), (r["end"] - r["start"]) / 1e3
+        if n.startswith("conv_tiled_kernel<2"):
+            key = ("conv_tiled_kernel<2,...> " + ("data gradient (fused variants)" if "<2, false, 2, false" in n else "forward / plain"),
+                   "full resolution" if d >= 45 else "level 1")
+        elif n.startswith("wgrad_tiled_kernel"):
+            key = ("wgrad_tiled_kernel", "full resolution" if d >= 40 else "level 1")
+        else:
+            continue
+        cls.setdefault(key, []).append(d)
+    out = ["", "## The tiled kernels by geometry (same trace; launches >= 45 / 40 us are the full-resolution tensors)", "",
+           "| kernel | tensors | launches/step | avg us | ms/step |", "|---|---|---|---|---|"]
+    for k, v in sorted(cls.items()):
+        out.append("| `%s` | %s | %.1f | %.1f | %.3f |" % (k[0], k[1], len(v) / steps, sum(v) / len(v), sum(v) / steps / 1e3))
+    full = [d for k, v in cls.items() if k[0].startswith("conv_tiled") and k[1] == "full resolution" for d in v]
+    if full:
+        out.append("| **conv_tiled, full resolution, all** (bench.py: `roofline.families`, first row; its HIP-event timing also "
+                   "contains the launch boundary) | | %.1f | **%.1f** | %.3f |" % (len(full) / steps, sum(full) / len(full), sum(full) / steps / 1e3))
+    print("\n".join(out))
+
+
 if __name__ == "__main__":
-    if sys.argv[1] == "stats":
+    if sys.argv[1] == "tiled":
+        tiled(sys.argv[2], int(sys.argv[3]))
+    elif sys.argv[1] == "stats":
         stats(sys.argv[2], int(sys.argv[3]), sys.argv[4] if len(sys.argv) > 4 else "kernel stats")
     else:
         step(sys.argv[2], "--full" in sys.argv)
