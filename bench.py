@@ -424,7 +424,8 @@ def main():
                     tdata = json.load(f)
                 key = "conv_tiled_full" if best[0].startswith("conv_tiled_kernel") else "wgrad_tiled" if best[0].startswith("wgrad_tiled") else None
                 if key in tdata.get("bytes_per_launch", {}):
-                    traffic, traffic_src = tdata["bytes_per_launch"][key], "profiles/pmc_traffic.json (%s)" % tdata.get("source", "")
+                    traffic = tdata["bytes_per_launch"][key]
+                    traffic_src = "profiles/pmc_traffic.json, recorded %s (%s)" % (tdata.get("recorded", "round 2"), tdata.get("source", ""))
             except Exception:
                 pass
         # The 32-channel 3x3x3 layers sit at the ridge (288-431 algorithmic flop/B against 2500/8 = 312): the MFMA bound is

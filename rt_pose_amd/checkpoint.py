@@ -117,10 +117,13 @@ def load_checkpoint(target, filename, map_location="cpu", strict=False, logger=N
         raise RuntimeError("No state_dict found in checkpoint file {}".format(filename))
     if list(sd.keys())[0].startswith("module."):
         sd = {k[7:]: v for k, v in sd.items()}
-    if any(k.endswith(("_offset.weight", "_offset.bias")) for k in sd):   # pre-version-2 DeformConvPack keys (deform_conv.py:298-321)
+    flat = getattr(target, "flat", target)
+    # pre-version-2 DeformConvPack keys (deform_conv.py:298-321): '<name>_offset.*' -- not the current '<name>.conv_offset.*'
+    if any(k.endswith(("_offset.weight", "_offset.bias")) and not k.endswith((".conv_offset.weight", ".conv_offset.bias"))
+           for k in sd):
         from .dcn import migrate_pre_v2_keys
-        sd = migrate_pre_v2_keys(dict(sd))
-    load_state_dict(getattr(target, "flat", target), sd, strict, logger)
+        sd = migrate_pre_v2_keys(dict(sd), target_keys=set(flat.values))
+    load_state_dict(flat, sd, strict, logger)
     return ckpt
 
 

@@ -1030,7 +1030,11 @@ extern "C" int rtp_conv_gn_fused(const RtpAct* x, const RtpGnFold* f, const RtpA
 extern "C" int rtp_conv_dgrad_fused(const RtpAct* gy, const void* wd, const RtpAct* x, const float* coeff, const RtpGnBwd* gn,
                                     const RtpTerm* terms /*host*/, int nterms, int mask, const RtpAct* dx,
                                     const RtpConvGeom* g, float* tot_out, void* stream) {
+  if (!gy || !wd || !x || !dx || !g || nterms < 0 || nterms > 3 || (nterms && !terms)) return RTP_ERR_SHAPE;
   if (coeff && gn) return RTP_ERR_SHAPE;
+  if ((gy->co % 8) || (gy->cs % 8) || (dx->co % 8) || (dx->cs % 8) || (x->co % 8) || (x->cs % 8)) return RTP_ERR_ALIGN;
+  if (x->c < 32 || dx->c < 32) return RTP_ERR_SHAPE;
+  if (gn && gn->groups != 8 && gn->groups != 1) return RTP_ERR_UNSUPPORTED;
   if (g->stride == 2) {   // the parity-class kernel (dgrad_s2_tiled.hip)
     S2Fuse f2;
     f2.nextra = nterms; f2.mask = mask; f2.tot_out = tot_out; f2.gn = gn;
@@ -1039,9 +1043,6 @@ extern "C" int rtp_conv_dgrad_fused(const RtpAct* gy, const void* wd, const RtpA
     const int rc2 = rtp_dgrad_s2_try(gy, wd, dx, g, x, nullptr, &f2, (hipStream_t)stream);
     return rc2 > 0 ? RTP_ERR_UNSUPPORTED : rc2;
   }
-  if (!gy || !wd || !x || !dx || !g || nterms < 0 || nterms > 3 || (nterms && !terms)) return RTP_ERR_SHAPE;
-  if ((gy->co % 8) || (gy->cs % 8) || (dx->co % 8) || (dx->cs % 8) || (x->co % 8) || (x->cs % 8)) return RTP_ERR_ALIGN;
-  if (x->c < 32 || dx->c < 32) return RTP_ERR_SHAPE;
   TiledFuse f;
   f.nextra = nterms; f.mask = mask; f.tot_out = tot_out; f.gn = gn;
   f.coef[0] = coeff;

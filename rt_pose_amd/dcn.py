@@ -311,22 +311,25 @@ class ModulatedDeformConvPack(ModulatedDeformConv):
         super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs)
 
 
-def migrate_pre_v2_keys(state_dict, module=None):
+def migrate_pre_v2_keys(state_dict, module=None, target_keys=None):
     """Rename '<name>_offset.{weight,bias}' to '<name>.conv_offset.{weight,bias}' in a whole checkpoint state dict.
 
     The reference does this inside DeformConvPack._load_from_state_dict (deform_conv.py:298-321, 420-444), which current
     PyTorch never reaches with such a key: Module.load_state_dict hands a child only the keys under its own prefix
     ('conv2.'), and 'conv2_offset.weight' is not one of them.  Call this on the dict before load_state_dict instead
-    (rt_pose_amd.checkpoint.load_checkpoint does).  With `module` given, only names that are Pack modules are touched."""
+    (rt_pose_amd.checkpoint.load_checkpoint does).  With `module` given, only names that are Pack modules are touched;
+    with `target_keys` (the destination's parameter names), only renames whose NEW key the destination has.
+    Current-format keys -- '<pack>.conv_offset.weight', which also END in '_offset.weight' -- are never touched."""
     packs = None
     if module is not None:
         packs = {n for n, m in module.named_modules() if isinstance(m, (DeformConvPack, ModulatedDeformConvPack))}
     for k in list(state_dict.keys()):
         for leaf in ("weight", "bias"):
             tail = "_offset." + leaf
-            if k.endswith(tail):
+            if k.endswith(tail) and not k.endswith(".conv_offset." + leaf):
                 name = k[:-len(tail)]
                 new = name + ".conv_offset." + leaf
-                if new not in state_dict and (packs is None or name in packs):
+                if (new not in state_dict and (packs is None or name in packs)
+                        and (target_keys is None or (new in target_keys and k not in target_keys))):
                     state_dict[new] = state_dict.pop(k)
     return state_dict

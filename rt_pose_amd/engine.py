@@ -126,25 +126,17 @@ class PoseEngine:
             self.ghm = View(be.alloc((batch, d, h, w, ghm_c), "bf16"), batch, d, h, w, ghm_c, 0, ghm_c)
             self.greg = View(be.alloc((batch, d, h, w, greg_c), "bf16"), batch, d, h, w, greg_c, 0, greg_c)
             scratch = be.focal_scratch(batch)
-            try:   # ghm is zeroed at allocation and written by this kernel only: its padding channels need no store
-                fl = be.focal_loss(hm, self.tgt_hm, self.tgt_ind, self.tgt_mask, self.tgt_cat, self.ncls, 1.0, scratch, self.loss_hm,
-                                   self.ghm, False)
-            except TypeError:
-                fl = be.focal_loss(hm, self.tgt_hm, self.tgt_ind, self.tgt_mask, self.tgt_cat, self.ncls, 1.0, scratch, self.loss_hm,
-                                   self.ghm)
+            # ghm is zeroed at allocation and written by this kernel only: its padding channels need no store
+            fl = be.focal_loss(hm, self.tgt_hm, self.tgt_ind, self.tgt_mask, self.tgt_cat, self.ncls, 1.0, scratch, self.loss_hm,
+                               self.ghm, False)
             self.loss_launches.append(fl)
             # the regression gradient is non-zero at <= m voxels per frame: instead of zero-filling its 84 MB every step the
             # loss kernel clears the voxels it wrote last time (state: reg_prev; the buffer starts zeroed, nothing else writes it)
             self.reg_prev = be.alloc((batch, self.m), "i64")
             self.reg_prev.fill_(-1)
-            try:
-                if os.environ.get("RTP_REG_DENSE"):   # A/B: zero fill every step
-                    raise TypeError
-                rl = be.reg_loss(reg, self.tgt_pose, self.tgt_ind, self.tgt_mask, self.code_w, self.nreg, self.loss_weight,
-                                 self.loss_reg, self.greg, self.reg_prev)
-            except TypeError:   # (a backend without the stateful variant)
-                rl = be.reg_loss(reg, self.tgt_pose, self.tgt_ind, self.tgt_mask, self.code_w, self.nreg, self.loss_weight,
-                                 self.loss_reg, self.greg)
+            dense = bool(os.environ.get("RTP_REG_DENSE"))   # A/B: zero fill every step
+            rl = be.reg_loss(reg, self.tgt_pose, self.tgt_ind, self.tgt_mask, self.code_w, self.nreg, self.loss_weight,
+                             self.loss_reg, self.greg, None if dense else self.reg_prev)
             self.loss_launches.append(rl)
             g.seed_grad(hm, self.ghm)
             g.seed_grad(reg, self.greg)

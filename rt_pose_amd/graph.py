@@ -193,7 +193,16 @@ class Graph:
             self._ndeferred += 1
             self._deferred.append(Launch(fn, L_FULL, reads, writes, tag))
             return
-        self.bwd.append(Launch(fn, lane, reads, writes, tag))
+        L = Launch(fn, lane, reads, writes, tag)
+        # List order must stay a valid serial order: a launch that reads (or overwrites) what a still-queued launch writes, or
+        # overwrites what one reads, goes behind it -- the queue is issued first (the fused backward puts producers
+        # of the data gradient's prologue inputs on the deferred lane in the A/B modes)
+        if self._deferred:
+            dw = set(k for D in self._deferred for k in D.writes)
+            dr = set(k for D in self._deferred for k in D.reads)
+            if dw.intersection(L.reads) or dw.intersection(L.writes) or dr.intersection(L.writes):
+                self.flush_deferred()
+        self.bwd.append(L)
 
     def flush_deferred(self, keep=0):
         """Issue the queued weight-gradient launches on the main lane (all but the newest `keep`)."""
@@ -444,20 +453,6 @@ class Graph:
                 self.tail_a.append(("class_reduce", scratch, split, self.n, gy.c, csum))
         return csum
 
-    def zero_alloc(self, shape):
-        """fp32 buffer that kernels ACCUMULATE into with atomics: carved from one arena that a single launch at the start of the
-        backward sweep zeroes (build_backward)."""
-        import math
-        size = int(math.prod(shape))
-        if getattr(self, "_zero_arena", None) is None:
-            self._zero_arena = self.be.alloc((64 * self.n * 27 * 32,), "f32")
-            self._zero_used, self._zero_views = 0, []
-        assert self._zero_used + size <= self._zero_arena.numel(), "zero arena exhausted"
-        v = self._zero_arena[self._zero_used:self._zero_used + size].view(shape)
-        self._zero_used += (size + 63) // 64 * 64
-        self._zero_views.append(v)
-        return v
-
     def class_sums_and_p(self, y: Act, gy: View, lane, name, wd, geom, ci_real, co_real):
         """class_sums_for(early=True) plus P = sum dxhat of the GroupNorm backward of the conv whose output gradient gy is, as
         ONE launch on `lane`: -> (csum [n][64][c], P [n][ci])."""
@@ -501,8 +496,6 @@ class Graph:
             if len(self.tail_b) >= self.tail_batch:   # optional early flush on the weight-gradient lane
                 self.emit_tail(L_WG_LOW)
         self.emit_tail(L_FULL)
-        if getattr(self, "_zero_arena", None) is not None and self._zero_used:
-            self.bwd.insert(0, Launch(self.be.zero_f32(self._zero_arena[:self._zero_used]), L_FULL, [], self._zero_views, "zero"))
 
     def emit_tail(self, lane=L_FULL):
         """The deferred items as two launches (stage a: class reductions + GroupNorm parameter sums; stage b: folds)."""
@@ -715,6 +708,8 @@ class ConvOp:
         if not (g.fused_dgrad and (self.tiled_bwd or s2) and x.needs_grad and g.first_consumer.get(id(x)) is self):
             return False
         if self.residual is x or x.c != 32 or x.cs != 32 or x.co != 0 or gy.c < 32:
+            return False
+        if self.gn and (self.ci_real != 32 or ge.ci != self.ci_real):   # the fused prologue's GroupNorm algebra is 32 real channels
             return False
         if len(x.contribs) > 3 or any(v.c < 32 or (cf is not None and v.c != 32) for v, cf in x.contribs):
             return False

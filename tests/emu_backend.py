@@ -695,7 +695,7 @@ class EmuBackend:
     def focal_scratch(self, n):
         return torch.zeros(2)
 
-    def focal_loss(self, logits, target, ind, mask, cat, ncls, gscale, scratch, out_loss, ghm):
+    def focal_loss(self, logits, target, ind, mask, cat, ncls, gscale, scratch, out_loss, ghm, write_pad=True):
         @torch.enable_grad()
         def run(s):
             z = logits.buf[..., :ncls].detach().clone().requires_grad_(True)  # [n,d,h,w,ncls]
@@ -716,7 +716,7 @@ class EmuBackend:
             _store(ghm, g)
         return run
 
-    def reg_loss(self, reg, target, ind, mask, code_w, nreg, gscale, out, greg):
+    def reg_loss(self, reg, target, ind, mask, code_w, nreg, gscale, out, greg, prev=None):
         @torch.enable_grad()
         def run(s):
             r = reg.buf[..., :nreg].detach().clone().requires_grad_(True)

@@ -73,3 +73,44 @@ def test_loads_ddp_prefixed_checkpoint_non_strict(tmp_path, capsys):
         ck.load_checkpoint(tr, p)
     with pytest.raises(TypeError):
         ck.save_checkpoint(tr, p, meta=[1])
+
+
+def test_dcn_head_checkpoint_round_trip_keeps_current_format_offset_keys(tmp_path):
+    """'<pack>.conv_offset.weight' also ends in '_offset.weight'; the pre-v2 migration must not rename it."""
+    from rt_pose_amd.engine import FlatParams
+    shapes = configs.param_shapes("hr3d_dcn")
+    offs = [k for k in shapes if ".conv_offset." in k]
+    assert len(offs) == 4, offs
+    alloc = lambda shape, dt: torch.zeros(shape, dtype=torch.float32)
+    src, dst = FlatParams(shapes, alloc), FlatParams(shapes, alloc)
+    g = torch.Generator().manual_seed(3)
+    src.p.copy_(torch.randn(src.numel, generator=g))
+    p = os.path.join(tmp_path, "dcn.pth")
+    torch.save({"meta": {"epoch": 1, "iter": 5}, "state_dict": ck.model_state_dict(src)}, p)   # what save_checkpoint writes
+    unexpected, missing, mismatched = ck.load_state_dict(dst, torch.load(p, weights_only=False)["state_dict"])
+    assert not unexpected and not missing and not mismatched
+    dst.p.zero_()
+    ck.load_checkpoint(dst, p, strict=True)
+    assert torch.equal(dst.p, src.p)
+    for k in offs:
+        assert torch.equal(dst.values[k], src.values[k]) and float(dst.values[k].abs().sum()) > 0
+
+
+def test_pre_v2_offset_keys_are_migrated_only_onto_existing_targets(tmp_path):
+    from rt_pose_amd.dcn import migrate_pre_v2_keys
+    from rt_pose_amd.engine import FlatParams
+    shapes = configs.param_shapes("hr3d_dcn")
+    alloc = lambda shape, dt: torch.zeros(shape, dtype=torch.float32)
+    src, dst = FlatParams(shapes, alloc), FlatParams(shapes, alloc)
+    src.p.copy_(torch.randn(src.numel, generator=torch.Generator().manual_seed(4)))
+    sd = OrderedDict()
+    for k, v in src.state_dict().items():      # write the DCN packs' offset convs under their pre-version-2 names
+        sd[k.replace(".conv_offset.", "_offset.") if ".conv_offset." in k else k] = v
+    assert not any(".conv_offset." in k for k in sd)
+    sd["something_offset.weight"] = torch.zeros(2)          # no such pack in the target: must stay as it is (unexpected key)
+    p = os.path.join(tmp_path, "old.pth")
+    torch.save({"meta": {"epoch": 0, "iter": 0}, "state_dict": sd}, p)
+    ck.load_checkpoint(dst, p)
+    assert torch.equal(dst.p, src.p)
+    out = migrate_pre_v2_keys(dict(sd), target_keys=set(dst.values))
+    assert "something_offset.weight" in out and all(k in out for k in shapes)

@@ -6,7 +6,7 @@
 #   pass s1: SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_INSTS_MFMA
 #   pass s2: SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INSTS_VALU SQ_INSTS_SALU
 #   pass g : GRBM_GUI_ACTIVE                    (effective clock = GRBM_GUI_ACTIVE / 8 / kernel time)
-# Writes profiles/pmc_traffic.json (bench.py quotes it as roofline.traffic) and prints the table for profiles/r02_pmc_tiled.md.
+# Writes gpurun_out/pmc_traffic.json (copy it to profiles/pmc_traffic.json: bench.py quotes that file as roofline.traffic, with its `recorded` stamp) and prints the table for profiles/r02_pmc_tiled.md.
 export TMPDIR=/tmp
 out=gpurun_out/pmc_tiled
 mkdir -p $out

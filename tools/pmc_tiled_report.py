@@ -1,6 +1,7 @@
 """Summarise the PMC passes of tools/pmc_tiled.sh: per kernel mean counter values per launch, derived MFMA-busy %, LDS
 figures, HBM traffic (FETCH_SIZE doubled per MI355X_MICROARCH.md for 16-B-per-lane streaming reads on gfx950, + WRITE_SIZE;
-counter unit KiB), effective clock.  Writes profiles/pmc_traffic.json for bench.py."""
+counter unit KiB), effective clock.  Writes gpurun_out/pmc_traffic.json (the only directory that travels back from the GPU box); copy it to
+profiles/pmc_traffic.json, which bench.py quotes together with the file's `recorded` stamp."""
 import collections
 import csv
 import json
@@ -54,7 +55,8 @@ for k in KERNELS:
 print(json.dumps(res, indent=1))
 if os.path.exists(out + "/unprofiled.txt"):
     print(open(out + "/unprofiled.txt").read())
-tj = {"source": "tools/pmc_tiled.sh (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over tools/microbench_tiled.py full, B=8 [8,16,64,160,32])",
+import time
+tj = {"recorded": time.strftime("%Y-%m-%dT%H:%M:%SZ", time.gmtime()), "source": "tools/pmc_tiled.sh (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over tools/microbench_tiled.py full, B=8 [8,16,64,160,32])",
       "bytes_per_launch": {k: v["hbm_bytes_per_launch"] for k, v in res.items() if "hbm_bytes_per_launch" in v}, "detail": res}
 if tj["bytes_per_launch"]:
     with open(os.path.join(ROOT, "gpurun_out", "pmc_traffic.json"), "w") as f:
