@@ -95,6 +95,19 @@ int rtp_conv_igemm(const RtpAct* x, const void* wf, int w_per_sample, const floa
 int rtp_conv_igemm_stats(const RtpAct* x, const void* wf, int w_per_sample, const float* btab, const RtpAct* res,
                          const RtpAct* y, const RtpConvGeom* g, int relu, int transposed, int y_fp32,
                          const RtpAct* stat_x, float* stat_out, void* stream);
+
+/* Wide 3x3x3 stride-1 convs (Cin = 32 K, Cout = 32 J, K * J > 1: the 64- and 128-channel layers of the feat64 backbone,
+ * det3d/models/backbones/hrnet3D_config.py:149-177, hr_util/common.py:98-148) as K x J launches of the LDS-tiled 32 -> 32
+ * kernel over channel slices, the partial sums carried in the caller's fp32 workspace; stride-2 forward convs of those widths
+ * (hr_util/hr3d.py:162-197, 297-305) likewise on the LDS-tiled stride-2 kernel (csrc/conv_s2_tiled.hip).
+ * rtp_conv_sliced_ok: 1 if rtp_conv_igemm_ws runs (x, g, transposed) that way.
+ * rtp_conv_igemm_ws: rtp_conv_igemm / rtp_conv_igemm_stats (stat_x / stat_out may be NULL) with ws = n * (output voxels) * 32
+ * floats of scratch; geometries that are not sliced ignore ws.  rtp_conv_stats_nsplit gives the partial count either way. */
+int rtp_conv_sliced_ok(const RtpAct* x, const RtpConvGeom* g, int transposed);
+int rtp_conv_stats_nsplit_ws(const RtpAct* x, const RtpConvGeom* g, int transposed);   /* partial count of rtp_conv_igemm_ws */
+int rtp_conv_igemm_ws(const RtpAct* x, const void* wf, int w_per_sample, const float* btab, const RtpAct* res,
+                      const RtpAct* y, const RtpConvGeom* g, int relu, int transposed, int y_fp32,
+                      const RtpAct* stat_x, float* stat_out, float* ws, void* stream);
 int rtp_conv_stats_nsplit(const RtpAct* x, const RtpConvGeom* g, int transposed);
 
 /* Contraction split of a wide conv (head towers, center_head.py:86-93): each 32-channel slice of the contracted tensor

@@ -90,11 +90,24 @@ class HipBackend:
     def conv_tiled_ok(self, x, geom, transposed):
         return bool(self.lib.rtp_conv_tiled_ok(_act(x), _geom(geom), int(transposed)))
 
-    def conv(self, x, wf, per_sample, btab, res, y, geom, relu, transposed, y_fp32, stats=None, acc=None):
+    def conv_sliced_ok(self, x, geom, transposed):
+        """A wide 3x3x3 stride-1 conv (Cin = 32 K, Cout = 32 J) that rtp_conv_igemm_ws runs as channel slices of the LDS-tiled kernel."""
+        return bool(self.lib.rtp_conv_sliced_ok(_act(x), _geom(geom), int(transposed)))
+
+    def conv(self, x, wf, per_sample, btab, res, y, geom, relu, transposed, y_fp32, stats=None, acc=None, ws=None):
         """stats = (stat_x | None, out [n, S, cout, 2]) with S = conv_stats_nsplit(...) > 0: the conv also emits the
         per-channel statistics of y (rtp_conv_igemm_stats).
-        acc = (fp32 [n, vox, acc_cs], acc_cs): partial result of earlier input-channel slices (rtp_conv_igemm_acc)."""
+        acc = (fp32 [n, vox, acc_cs], acc_cs): partial result of earlier input-channel slices (rtp_conv_igemm_acc).
+        ws = fp32 [n * output voxels * 32] scratch: conv_sliced_ok geometries run as channel slices (rtp_conv_igemm_ws)."""
         g = _geom(geom)
+        if ws is not None:
+            assert acc is None
+            fn = self.lib.rtp_conv_igemm_ws
+            args = (_act(x), _ptr(wf), int(per_sample), _ptr(btab), _act(res), _act(y), g, int(relu), int(transposed),
+                    int(y_fp32), _act(stats[0]) if stats is not None else None, _ptr(stats[1]) if stats is not None else None,
+                    _ptr(ws))
+            keep = (x, wf, btab, res, y, stats, ws)
+            return lambda s: check(fn(*args, s), "rtp_conv_igemm_ws") or keep and None
         if acc is not None:
             assert stats is None
             fn = self.lib.rtp_conv_igemm_acc
@@ -122,8 +135,10 @@ class HipBackend:
         keep = (x, wt, bias, gamma, beta, stats, mr, res, y, stat_out, fs)
         return lambda s: check(fn(*args, s), "rtp_conv_gn_fused") or keep and None
 
-    def conv_stats_nsplit(self, x, geom, transposed):
-        return self.lib.rtp_conv_stats_nsplit(_act(x), _geom(geom), int(transposed))
+    def conv_stats_nsplit(self, x, geom, transposed, ws=False):
+        """ws: the conv will be launched with a slice workspace (conv(..., ws=...))."""
+        fn = self.lib.rtp_conv_stats_nsplit_ws if ws else self.lib.rtp_conv_stats_nsplit
+        return fn(_act(x), _geom(geom), int(transposed))
 
     def wgrad(self, gy, x, geom, nsplit, gp):
         fn, g = self.lib.rtp_wgrad, _geom(geom)

@@ -305,8 +305,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
 int rtp_conv_tiled_try(const RtpAct* x, const void* wf, int w_per_sample, const float* btab, const RtpAct* res,
                        const RtpAct* y, const RtpConvGeom* g, int relu, int transposed, int y_fp32,
                        const RtpAct* stat_x, float* stat_out, const float* acc32, int acc_cs, hipStream_t s,
-                       const struct TiledFuse* fuse = nullptr, const RtpGnFold* fold = nullptr);
+                       const struct TiledFuse* fuse = nullptr, const RtpGnFold* fold = nullptr, const struct TiledSlice* slice = nullptr);
+struct TiledSlice { long w_sample_stride; int w_tap_stride, w_row_stride, bt_cs, st_cs; };   // conv_tiled.hip
 int rtp_conv_tiled_stat_slots(const RtpAct* x, const RtpConvGeom* g, int transposed);
+// conv_s2_tiled.hip: the LDS-tiled forward stride-2 conv (32 -> 32 channels per launch)
+int rtp_conv_s2_fwd_stat_slots(const RtpAct* x, const RtpConvGeom* g);
+int rtp_conv_s2_fwd_try(const RtpAct* x, const void* wf, int w_per_sample, const float* btab, const RtpAct* res, const RtpAct* y,
+                        const RtpConvGeom* g, int relu, int y_fp32, float* stat_out, const float* acc32, int acc_cs, hipStream_t s,
+                        const TiledSlice* slice);
 
 
 // tile shape of the generic kernel for a problem: (cout tiles per wave, voxel tiles per wave, blocks per sample)
@@ -326,6 +332,78 @@ int rtp_dgrad_s2_stat_slots(const RtpAct* gy, const RtpConvGeom* g);
 int rtp_dgrad_s2_try(const RtpAct* gy, const void* wd, const RtpAct* dx, const RtpConvGeom* g, const RtpAct* stat_x, float* stat_out,
                      const S2Fuse* fuse, hipStream_t s);
 int rtp_conv_tiled_stat_slots(const RtpAct* x, const RtpConvGeom* g, int transposed);
+// ---- wide 3x3x3 stride-1 convs (Cin = 32 K, Cout = 32 J, K * J > 1) as K x J launches of the LDS-tiled 32 -> 32 kernel
+// (the 64- and 128-channel layers of the feat64 backbone, hrnet3D_config.py:149-177): output slice j is the sum over the
+// input slices k of a 32 x 32 window of the SAME weight image (fold output [n][27][Co][Ci] / data-gradient packing
+// [27][ci][cok]); the partial sum travels through the caller's fp32 workspace ws [n][voxels][32] in place, the last slice
+// of a chain adds class bias / residual / ReLU, rounds once and emits the statistics partials of its 32 channels.
+static void slice_geom(const RtpConvGeom* g, int transposed, RtpConvGeom* gs, int* K, int* J) {
+  *gs = *g;
+  const int Ci = transposed ? (g->co + 31) / 32 * 32 : g->ci, Co = transposed ? g->ci : g->co;
+  *K = Ci / 32; *J = Co / 32;
+  gs->ci = 32; gs->co = 32; gs->w_ci_total = 0; gs->w_ci_off = 0;
+}
+
+static int sliced_stat_slots(const RtpAct* x, const RtpConvGeom* g, int transposed) {
+  static const bool disabled = getenv("RTP_DISABLE_SLICED") != nullptr || getenv("RTP_DISABLE_TILED") != nullptr;
+  if (disabled || !x || !g) return 0;
+  if (g->ks != 3 || g->pad != 1 || (g->stride != 1 && !(g->stride == 2 && !transposed))) return 0;
+  const int Ci = transposed ? (g->co + 31) / 32 * 32 : g->ci, Co = transposed ? g->ci : g->co;
+  if (Ci % 32 || Co % 32 || Ci * Co <= 32 * 32 || Ci > 256 || Co > 256) return 0;
+  if (!transposed && (g->co % 32)) return 0;
+  RtpConvGeom gs; int K, J;
+  slice_geom(g, transposed, &gs, &K, &J);
+  RtpAct xs = *x; xs.c = 32;
+  // stride 2: every slice launch streams its 32-channel window of x again, which pays for the volumes that fill the chip only
+  // (measured at B = 8: 64 -> 64 from [4,16,40], four launches 25 us against 16 on the generic kernel)
+  if (g->stride == 2 && K > 1 && (long)g->n * g->dov * g->ho * g->wo < 65536) return 0;
+  return g->stride == 2 ? rtp_conv_s2_fwd_stat_slots(&xs, &gs) : rtp_conv_tiled_stat_slots(&xs, &gs, transposed);
+}
+static bool conv_sliced_geometry(const RtpAct* x, const RtpConvGeom* g, int transposed) { return sliced_stat_slots(x, g, transposed) > 0; }
+
+/* 1 if rtp_conv_igemm_ws runs this conv as slices of the LDS-tiled kernel (a workspace of n * output voxels * 32 floats). */
+extern "C" int rtp_conv_sliced_ok(const RtpAct* x, const RtpConvGeom* g, int transposed) {
+  return conv_sliced_geometry(x, g, transposed) ? 1 : 0;
+}
+
+static int conv_sliced(const RtpAct* x, const void* wf, int w_per_sample, const float* btab, const RtpAct* res,
+                       const RtpAct* y, const RtpConvGeom* g, int relu, int transposed, int y_fp32,
+                       const RtpAct* stat_x, float* stat_out, float* ws, hipStream_t s) {
+  RtpConvGeom gs; int K, J;
+  slice_geom(g, transposed, &gs, &K, &J);
+  const int Ci = 32 * K, Co = 32 * J;
+  if (x->c < Ci || y->c < Co || (res && res->c < Co) || (stat_x && stat_x->c < Co)) return RTP_ERR_SHAPE;
+  if (stat_out && y_fp32) return RTP_ERR_UNSUPPORTED;
+  TiledSlice sl;
+  // forward: wf [n][27][Co][Ci] (rows = output channels); transposed: wd [27][conv ci = Co here][cok = Ci here]
+  sl.w_row_stride = Ci; sl.w_tap_stride = Co * Ci; sl.w_sample_stride = 27L * Co * Ci; sl.bt_cs = Co; sl.st_cs = Co;
+  RtpAct wsa; wsa.ptr = ws; wsa.cs = 32; wsa.co = 0; wsa.c = 32;
+  for (int j = 0; j < J; ++j)
+    for (int k = 0; k < K; ++k) {
+      const bool last = k == K - 1;
+      RtpAct xs = *x; xs.co = x->co + 32 * k; xs.c = 32;
+      RtpAct ys = *y; ys.co = y->co + 32 * j; ys.c = 32;
+      RtpAct rs, sx;
+      if (res) { rs = *res; rs.co = res->co + 32 * j; rs.c = 32; }
+      if (stat_x) { sx = *stat_x; sx.co = stat_x->co + 32 * j; sx.c = 32; }
+      const bf16_t* wjk = (const bf16_t*)wf + (long)(32 * j) * Ci + 32 * k;
+      int rc;
+      if (g->stride == 2) {
+        if (stat_x) return RTP_ERR_UNSUPPORTED;
+        rc = rtp_conv_s2_fwd_try(&xs, wjk, w_per_sample, (last && btab) ? btab + 32 * j : nullptr, (last && res) ? &rs : nullptr,
+                                 last ? &ys : &wsa, &gs, last ? relu : 0,
+                                 last ? y_fp32 : 1, (last && stat_out) ? stat_out + 2 * 32 * j : nullptr, k > 0 ? ws : nullptr, 32, s, &sl);
+      } else {
+        rc = rtp_conv_tiled_try(&xs, wjk, w_per_sample, (last && btab) ? btab + 32 * j : nullptr, (last && res) ? &rs : nullptr,
+                                last ? &ys : &wsa, &gs, last ? relu : 0, transposed, last ? y_fp32 : 1,
+                                (last && stat_out && stat_x) ? &sx : nullptr, (last && stat_out) ? stat_out + 2 * 32 * j : nullptr,
+                                k > 0 ? ws : nullptr, 32, s, nullptr, nullptr, &sl);
+      }
+      if (rc != RTP_OK) return rc > 0 ? RTP_ERR_UNSUPPORTED : rc;
+    }
+  return RTP_OK;
+}
+
 /* 1 if this (slice) geometry runs on the LDS-tiled kernel -- the only one that accepts rtp_conv_igemm_acc. */
 extern "C" int rtp_conv_tiled_ok(const RtpAct* x, const RtpConvGeom* g, int transposed) {
   return (x && g && rtp_conv_tiled_stat_slots(x, g, transposed) > 0) ? 1 : 0;
@@ -335,6 +413,11 @@ extern "C" int rtp_conv_stats_nsplit(const RtpAct* x, const RtpConvGeom* g, int 
   if (!x || !g) return 0;
   const int tiled = rtp_conv_tiled_stat_slots(x, g, transposed);
   if (tiled > 0) return tiled;
+  if (!transposed) {
+    const int s2 = rtp_conv_s2_fwd_stat_slots(x, g);
+    if (s2 > 0) return s2;
+  }
+
   if (transposed) {
     const int s2 = rtp_dgrad_s2_stat_slots(x, g);
     if (s2 > 0) return s2;
@@ -351,6 +434,29 @@ extern "C" int rtp_conv_stats_nsplit(const RtpAct* x, const RtpConvGeom* g, int 
 static int conv_dispatch(const RtpAct* x, const void* wf, int w_per_sample, const float* btab, const RtpAct* res,
                          const RtpAct* y, const RtpConvGeom* g, int relu, int transposed, int y_fp32,
                          const RtpAct* stat_x, float* stat_out, void* stream, const float* acc32 = nullptr, int acc_cs = 0);
+
+/* Statistics partials per sample that rtp_conv_igemm_ws (called WITH a workspace) writes: the sliced route's count where
+ * rtp_conv_sliced_ok, rtp_conv_stats_nsplit otherwise. */
+extern "C" int rtp_conv_stats_nsplit_ws(const RtpAct* x, const RtpConvGeom* g, int transposed) {
+  const int sl = sliced_stat_slots(x, g, transposed);
+  return sl > 0 ? sl : rtp_conv_stats_nsplit(x, g, transposed);
+}
+
+/* rtp_conv_igemm / rtp_conv_igemm_stats (stat_out may be NULL) with a caller-owned fp32 workspace ws of
+ * n * (output voxels) * 32 floats: convs with rtp_conv_sliced_ok(x, g, transposed) run as channel slices of the LDS-tiled
+ * kernel; every other geometry ignores ws and takes the usual route. */
+extern "C" int rtp_conv_igemm_ws(const RtpAct* x, const void* wf, int w_per_sample, const float* btab, const RtpAct* res,
+                                 const RtpAct* y, const RtpConvGeom* g, int relu, int transposed, int y_fp32,
+                                 const RtpAct* stat_x, float* stat_out, float* ws, void* stream) {
+  if (!x || !y || !wf || !g) return RTP_ERR_SHAPE;
+  if ((x->co % 8) || (x->cs % 8) || (y->co % 8) || (y->cs % 8)) return RTP_ERR_ALIGN;
+  if (res && ((res->co % 8) || (res->cs % 8))) return RTP_ERR_ALIGN;
+  if (stat_x && ((stat_x->cs % 8) || (stat_x->co % 8))) return RTP_ERR_ALIGN;
+  if (stat_x && !stat_out) return RTP_ERR_SHAPE;
+  if (ws && conv_sliced_geometry(x, g, transposed))
+    return conv_sliced(x, wf, w_per_sample, btab, res, y, g, relu, transposed, y_fp32, stat_x, stat_out, ws, (hipStream_t)stream);
+  return conv_dispatch(x, wf, w_per_sample, btab, res, y, g, relu, transposed, y_fp32, stat_x, stat_out, stream);
+}
 
 extern "C" int rtp_conv_igemm_acc(const RtpAct* x, const void* wf, int w_per_sample, const float* btab, const RtpAct* res,
                                   const RtpAct* y, const RtpConvGeom* g, int relu, int transposed, int y_fp32,
@@ -386,7 +492,11 @@ static int conv_dispatch(const RtpAct* x, const void* wf, int w_per_sample, cons
                                       acc32, acc_cs, (hipStream_t)stream);
     if (rc <= 0) return rc;  // handled (or failed) by the LDS-tiled kernel
   }
-  if (acc32) return RTP_ERR_UNSUPPORTED;  // partial-sum input: only the LDS-tiled kernel (rtp_conv_tiled_ok)
+  if (!transposed && g->stride == 2 && !stat_x) {
+    const int rc = rtp_conv_s2_fwd_try(x, wf, w_per_sample, btab, res, y, g, relu, y_fp32, stat_out, acc32, acc_cs, (hipStream_t)stream, nullptr);
+    if (rc <= 0) return rc;
+  }
+  if (acc32) return RTP_ERR_UNSUPPORTED;  // partial-sum input: only the LDS-tiled kernels (rtp_conv_tiled_ok)
   if (transposed && g->stride == 2 && !btab && !res && !relu && !y_fp32) {
     const int rc = rtp_dgrad_s2_try(x, wf, y, g, stat_x, stat_out, nullptr, (hipStream_t)stream);
     if (rc <= 0) return rc;

@@ -102,6 +102,10 @@ struct TiledParams {
   // order [27][Co][32], the input's statistics partials [N][f_nsplit][32][2]; w / btab are then unused
   const float* fw; const float* fbias; const float* fgamma; const float* fbeta; const float* fstats;
   int f_nsplit, f_groups, f_co_real; float f_eps; float* f_mr;
+  // SLICE: this launch is one (output-channel slice, input-channel slice) pair of a wider conv (rtp_conv_igemm_ws): the weights
+  // are a 32 x 32 window of a wider image [sample][27][Co_total][Ci_total] (element strides), the class-bias table and the
+  // statistics partials are 32-channel windows of tables that are bt_cs / st_cs channels wide.  Dense defaults otherwise.
+  long w_sample_stride; int w_tap_stride, w_row_stride, bt_cs, st_cs;
 };
 
 // Barrier over the four waves of one team: a monotonic LDS counter (no reset, so no re-use hazard); `target` = 4 x the
@@ -267,14 +271,17 @@ __global__ __launch_bounds__(512, 2) void conv_tiled_kernel(TiledParams p) {
   }
   // ---- weights -> LDS (once): item = (row = tap*Co + co, chunk)
   if (!p.fw) {
-    const bf16_t* wsrc = p.w + (p.w_per_sample ? (long)n * 27 * p.Co * 32 : 0);
+    const bf16_t* wsrc = p.w + (p.w_per_sample ? (long)n * p.w_sample_stride : 0);
     const int items = 27 * p.Co * 4;
     for (int i0 = tid; i0 < items; i0 += 512 * 4) {
       bf16x8 val[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const int i = i0 + k * 512;
-        if (i < items) val[k] = ld_bf16x8(wsrc + (long)(i >> 2) * 32 + (i & 3) * 8);
+        if (i < items) {
+          const int row = i >> 2, tap = row / p.Co, co = row - tap * p.Co;
+          val[k] = ld_bf16x8(wsrc + (long)tap * p.w_tap_stride + (long)co * p.w_row_stride + (i & 3) * 8);
+        }
       }
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
@@ -297,7 +304,7 @@ __global__ __launch_bounds__(512, 2) void conv_tiled_kernel(TiledParams p) {
       const int co = i % p.Co, k = i / p.Co;
       const int cz = k / 9, cy = (k / 3) % 3, cx = k % 3;  // 0 interior, 1 first, 2 last
       const int cls = (cz == 1) | ((cz == 2) << 1) | ((cy == 1) << 2) | ((cy == 2) << 3) | ((cx == 1) << 4) | ((cx == 2) << 5);
-      bL[i] = p.btab[((long)(p.w_per_sample ? n : 0) * 64 + cls) * p.Co + co];
+      bL[i] = p.btab[((long)(p.w_per_sample ? n : 0) * 64 + cls) * p.bt_cs + co];
     }
   }
   if constexpr (FUSE) {   // coefficient table in the (unused) class-bias region: [A0 | Bt | Ct | A1 | A2 | A3][32]
@@ -863,7 +870,7 @@ __global__ __launch_bounds__(512, 2) void conv_tiled_kernel(TiledParams p) {
       float a = 0.f;
 #pragma unroll
       for (int w8 = 0; w8 < 8; ++w8) a += red[w8 * p.Co * 2 + i];
-      p.stat_out[((long)bid * p.Co) * 2 + i] = a;  // bid = n * workgroups_per_sample + workgroup
+      p.stat_out[((long)bid * p.st_cs) * 2 + i] = a;  // bid = n * workgroups_per_sample + workgroup
     }
   }
 }
@@ -906,13 +913,15 @@ struct S2Fuse { const float* coef[4]; const RtpAct* ex[3]; int nextra, mask; flo
 int rtp_dgrad_s2_try(const RtpAct* gy, const void* wd, const RtpAct* dx, const RtpConvGeom* g, const RtpAct* stat_x, float* stat_out,
                      const S2Fuse* fuse, hipStream_t s);
 struct TiledFuse { const float* coef[4]; const RtpAct* ex[3]; int nextra, mask; float* tot_out; const RtpGnBwd* gn; };
+struct TiledSlice { long w_sample_stride; int w_tap_stride, w_row_stride, bt_cs, st_cs; };
 
 int rtp_conv_tiled_try(const RtpAct* x, const void* wf, int w_per_sample, const float* btab, const RtpAct* res,
                        const RtpAct* y, const RtpConvGeom* g, int relu, int transposed, int y_fp32,
                        const RtpAct* stat_x, float* stat_out, const float* acc32, int acc_cs, hipStream_t s,
-                       const TiledFuse* fuse, const RtpGnFold* fold) {
+                       const TiledFuse* fuse, const RtpGnFold* fold, const TiledSlice* slice) {
   int Co;
   if (!tiled_geometry_ok(x, g, transposed, &Co)) return 1;
+  if (slice && (fuse || fold)) return RTP_ERR_UNSUPPORTED;
   if (fold && (fuse || transposed || acc32 || y_fp32 || wf || btab || !fold->w || !fold->gamma || !fold->beta || !fold->stats ||
                fold->nsplit < 1 || fold->groups < 1 || fold->groups > 32 || 32 % fold->groups || fold->co_real < 1 ||
                fold->co_real > Co || g->w_ci_total > 32 || g->w_ci_off))
@@ -942,6 +951,12 @@ int rtp_conv_tiled_try(const RtpAct* x, const void* wf, int w_per_sample, const 
   p.qpart = nullptr; p.q_nsplit = 0; p.gn_p = p.gn_mr = p.gn_gamma = nullptr; p.gn_groups = 1; p.gn_m = 1.f; p.coef_out = nullptr;
   p.tg = nullptr; p.csum_out = nullptr;
   p.fw = p.fbias = p.fgamma = p.fbeta = p.fstats = nullptr; p.f_nsplit = p.f_groups = p.f_co_real = 0; p.f_eps = 0.f; p.f_mr = nullptr;
+  p.w_sample_stride = 27L * Co * 32; p.w_tap_stride = Co * 32; p.w_row_stride = 32; p.bt_cs = Co; p.st_cs = Co;
+  if (slice) {
+    p.w_sample_stride = slice->w_sample_stride; p.w_tap_stride = slice->w_tap_stride; p.w_row_stride = slice->w_row_stride;
+    p.bt_cs = slice->bt_cs; p.st_cs = slice->st_cs;
+    if (p.w_row_stride % 8 || p.w_tap_stride % 8 || p.w_sample_stride % 8) return RTP_ERR_ALIGN;
+  }
   if (fold) {
     p.fw = fold->w; p.fbias = fold->bias; p.fgamma = fold->gamma; p.fbeta = fold->beta; p.fstats = fold->stats;
     p.f_nsplit = fold->nsplit; p.f_groups = fold->groups; p.f_co_real = fold->co_real; p.f_eps = fold->eps; p.f_mr = fold->mr;
@@ -1016,7 +1031,7 @@ extern "C" int rtp_conv_gn_fused(const RtpAct* x, const RtpGnFold* f, const RtpA
   if (!x || !f || !y || !g) return RTP_ERR_SHAPE;
   if ((x->co % 8) || (x->cs % 8) || (y->co % 8) || (y->cs % 8) || (res && ((res->co % 8) || (res->cs % 8)))) return RTP_ERR_ALIGN;
   const int rc = rtp_conv_tiled_try(x, nullptr, 1, nullptr, res, y, g, relu, 0, 0, nullptr, stat_out, nullptr, 0, (hipStream_t)stream,
-                                    nullptr, f);
+                                    nullptr, f, nullptr);
   return rc > 0 ? RTP_ERR_UNSUPPORTED : rc;
 }
 
@@ -1047,7 +1062,7 @@ extern "C" int rtp_conv_dgrad_fused(const RtpAct* gy, const void* wd, const RtpA
   f.nextra = nterms; f.mask = mask; f.tot_out = tot_out; f.gn = gn;
   f.coef[0] = coeff;
   for (int e = 0; e < 3; ++e) { f.ex[e] = e < nterms ? &terms[e].t : nullptr; f.coef[1 + e] = e < nterms ? terms[e].coeff : nullptr; }
-  const int rc = rtp_conv_tiled_try(gy, wd, 0, nullptr, nullptr, dx, g, 0, 1, 0, x, nullptr, nullptr, 0, (hipStream_t)stream, &f, nullptr);
+  const int rc = rtp_conv_tiled_try(gy, wd, 0, nullptr, nullptr, dx, g, 0, 1, 0, x, nullptr, nullptr, 0, (hipStream_t)stream, &f, nullptr, nullptr);
   return rc > 0 ? RTP_ERR_UNSUPPORTED : rc;
 }
 

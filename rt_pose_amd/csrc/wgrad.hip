@@ -7,6 +7,8 @@
 // Block = 4 waves; the 27 taps are dealt round-robin to the waves (<= 7 each, 16 acc regs per tap), every
 // wave gathers its own shifted x chunk for the tap it is working on.  Output: fp32 partial slabs per
 // (sample, voxel split) -- reduced deterministically by rtp_wgrad_fold (no atomics).
+#include <stdlib.h>
+
 #include "rtp_common.h"
 #include "rtp_prof.h"
 
@@ -149,8 +151,82 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradParams p) {
   }
 }
 
+// 1x1x1 convs (the fuse rows' channel matchers and the concat-free final conv, hr3d.py:147-155, hrnet3d.py:37-41): one tap, so
+// the tap-per-wave deal above leaves three of four waves idle and every (output tile, input tile) block re-reads both
+// tensors.  Here a block stages a 64-voxel chunk of ALL channels of gy and x once ([tile][voxel][32] images) and its four
+// waves split the (co tile, ci tile) pairs, <= 4 each: every byte of both tensors is read once per launch (HBM-bound).
+#define W1_VB 64
+__global__ __launch_bounds__(256) void wgrad_1x1_kernel(WgradParams p) {
+  extern __shared__ __attribute__((aligned(16))) bf16_t lds1[];
+  const int cotiles = p.co32 >> 5, tiles = cotiles * p.citiles;
+  bf16_t* gyL = lds1;                               // [cotiles][W1_VB][32]
+  bf16_t* xL = lds1 + cotiles * W1_VB * 32;         // [citiles][W1_VB][32]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int s = blockIdx.x, n = blockIdx.y;
+  const int v_begin = s * p.vps;
+  const int v_end = (v_begin + p.vps < p.Vo) ? v_begin + p.vps : p.Vo;
+  f32x4 acc[4][2][2];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) acc[t][a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const long vox_n = (long)n * p.Vo;   // stride 1, no padding: input voxel == output voxel
+  const int gck = p.co32 >> 3, xck = p.ci_pad >> 3;
+  for (int vc = v_begin; vc < v_end; vc += W1_VB) {
+    __syncthreads();
+    for (int item = tid; item < W1_VB * gck; item += 256) {
+      const int vox = item / gck, ck = item - vox * gck;
+      bf16x8 val = zero_bf16x8();
+      if (vc + vox < v_end) val = ld_bf16x8(p.gy + (vox_n + vc + vox) * p.g_cs + p.g_co + ck * 8);
+      st_bf16x8(&gyL[((ck >> 2) * W1_VB + vox) * 32 + (ck & 3) * 8], val);
+    }
+    for (int item = tid; item < W1_VB * xck; item += 256) {
+      const int vox = item / xck, ck = item - vox * xck;
+      bf16x8 val = zero_bf16x8();
+      if (vc + vox < v_end) val = ld_bf16x8(p.x + (vox_n + vc + vox) * p.x_cs + p.x_co + ck * 8);
+      st_bf16x8(&xL[((ck >> 2) * W1_VB + vox) * 32 + (ck & 3) * 8], val);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int tile = wave + 4 * t;
+      if (tile >= tiles) break;   // wave-uniform
+      const int cot = tile / p.citiles, cit = tile - cot * p.citiles;
+#pragma unroll
+      for (int ks = 0; ks < W1_VB / 32; ++ks) {
+        bf16x8 a0 = tr_frag(gyL + cot * W1_VB * 32, ks, 0, lane), a1 = tr_frag(gyL + cot * W1_VB * 32, ks, 1, lane);
+        bf16x8 b0 = tr_frag(xL + cit * W1_VB * 32, ks, 0, lane), b1 = tr_frag(xL + cit * W1_VB * 32, ks, 1, lane);
+        acc[t][0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b0, acc[t][0][0], 0, 0, 0);
+        acc[t][0][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b1, acc[t][0][1], 0, 0, 0);
+        acc[t][1][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b0, acc[t][1][0], 0, 0, 0);
+        acc[t][1][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1, acc[t][1][1], 0, 0, 0);
+      }
+    }
+  }
+  const int q = lane >> 4, i = lane & 15;
+  float* out = p.gp + ((long)n * p.nsplit + s) * p.co32 * p.ci_pad;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int tile = wave + 4 * t;
+    if (tile >= tiles) continue;
+    const int cot = tile / p.citiles, cit = tile - cot * p.citiles;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          out[((long)cot * 32 + a * 16 + q * 4 + r) * p.ci_pad + cit * 32 + b * 16 + i] = acc[t][a][b][r];
+  }
+}
+
 int rtp_wgrad_tiled_try(const RtpAct* gy, const RtpAct* x, const RtpConvGeom* g, int nsplit, float* gp, hipStream_t s,
-                        const void* wd, float* qpart, float* tg);
+                        const void* wd, float* qpart, float* tg, int slab_rows = 0, int slab_cols = 0);
+
+int rtp_wgrad_s2_try(const RtpAct* gy, const RtpAct* x, const RtpConvGeom* g, int nsplit, float* gp, hipStream_t s, int slab_rows,
+                     int slab_cols);   // wgrad_s2_tiled.hip
 
 // rtp_wgrad on the LDS-tiled kernel that also contracts every slab with the data-gradient weights (GroupNorm backward's Q
 // without a pass over dxhat).  Only the tiled kernel's geometries (rtp_wgrad_nsplit(g) > 0, nsplit equal to it).
@@ -174,6 +250,10 @@ extern "C" int rtp_wgrad(const RtpAct* gy, const RtpAct* x, const RtpConvGeom* g
     const int rc = rtp_wgrad_tiled_try(gy, x, g, nsplit, gp, (hipStream_t)stream, nullptr, nullptr, nullptr);
     if (rc <= 0) return rc;
   }
+  {
+    const int rc = rtp_wgrad_s2_try(gy, x, g, nsplit, gp, (hipStream_t)stream, 0, 0);
+    if (rc <= 0) return rc;
+  }
   WgradParams p;
   p.gy = (const bf16_t*)gy->ptr; p.x = (const bf16_t*)x->ptr; p.gp = gp;
   p.N = g->n; p.Di = g->di; p.Hi = g->hi; p.Wi = g->wi; p.Do = g->dov; p.Ho = g->ho; p.Wo = g->wo;
@@ -189,6 +269,18 @@ extern "C" int rtp_wgrad(const RtpAct* gy, const RtpAct* x, const RtpConvGeom* g
   p.vps = rtp_div_up(rtp_div_up(p.Vo, nsplit), WG_VB) * WG_VB;
   hipStream_t s = (hipStream_t)stream;
   RtpProfScope prof(RTP_FAM_WGRAD, s);
+  static const bool no_1x1 = getenv("RTP_DISABLE_WGRAD_1X1") != nullptr;
+  if (!no_1x1 && p.ks == 1 && p.stride == 1 && p.pad == 0 && (p.co32 / 32) * p.citiles <= 16) {
+    const size_t shm = sizeof(bf16_t) * (size_t)(p.co32 / 32 + p.citiles) * W1_VB * 32;
+    static bool attr = false;
+    if (!attr) {
+      (void)hipFuncSetAttribute((const void*)wgrad_1x1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr = true;
+    }
+    hipLaunchKernelGGL(wgrad_1x1_kernel, dim3(nsplit, p.N), dim3(256), shm, s, p);
+    RTP_CHECK_LAUNCH();
+    return RTP_OK;
+  }
   dim3 grid(nsplit, p.N, (p.co32 / 32) * p.citiles);
   hipLaunchKernelGGL(wgrad_kernel, grid, dim3(256), 0, s, p);
   RTP_CHECK_LAUNCH();

@@ -41,6 +41,10 @@ struct WgTiledParams {
   // give P = sum dxhat of GroupNorm backward, the bias gradient and the un-fold term without any pass over gy
   // (conv_tiled.hip, fused data gradient).
   float* tg;
+  // slab geometry: a workgroup's slab is a 32 x 32 window (rows co, columns ci) of [27][slab_rows][slab_cols] floats --
+  // dense [27][32][32] for a 32 -> 32 layer; for a wider conv run as (output slice, input slice) launches every launch fills
+  // its window of the SAME [27][Co][Ci] slabs, which rtp_wgrad_fold then reads like the generic kernel's
+  int slab_rows, slab_cols;
 };
 
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
@@ -315,7 +319,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(512, 512), amdgpu_waves_pe
 
   const int q = lane >> 4, i = lane & 15;
   // ---- one fp32 slab [27][32][32] per workgroup; D[row = co][col = ci]: lane holds rows 4q..4q+3, column lane&15
-  float* out = p.gp + ((long)n * p.wgs_per_sample + wg) * 27 * 32 * 32;
+  float* out = p.gp + ((long)n * p.wgs_per_sample + wg) * 27 * p.slab_rows * p.slab_cols;
 #pragma unroll
   for (int t = 0; t < 7; ++t) {
     const int tap = tw + 4 * t;
@@ -326,7 +330,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(512, 512), amdgpu_waves_pe
         for (int b = 0; b < 2; ++b)
 #pragma unroll
           for (int r = 0; r < 4; ++r)
-            out[(tap * 32 + a * 16 + q * 4 + r) * 32 + b * 16 + i] = acc[t][a][b][r];
+            out[(tap * p.slab_rows + a * 16 + q * 4 + r) * p.slab_cols + b * 16 + i] = acc[t][a][b][r];
   }
   if (p.qpart) {
     // lane holds slab[tap][co = a*16 + 4q + r][ci = b*16 + i]; wd[tap][ci][co..co+3] is one 8-byte read
@@ -360,11 +364,16 @@ __global__ __attribute__((amdgpu_flat_work_group_size(512, 512), amdgpu_waves_pe
   }
 }
 
+// 32 -> <=32 channels: one launch.  Cin = 32 K, Cout = 32 J (K * J > 1, the feat64 backbone's layers): K x J launches, each
+// filling its 32 x 32 window of the [27][Co][Ci] slabs.
 static bool wg_tiled_applicable(const RtpConvGeom* g) {
   static const bool disabled = getenv("RTP_DISABLE_TILED") != nullptr;
+  static const bool no_slices = getenv("RTP_DISABLE_SLICED") != nullptr;
   if (disabled) return false;
-  return g->ks == 3 && g->stride == 1 && g->pad == 1 && g->ci == 32 && (g->co + 31) / 32 * 32 == 32 &&
-         g->di % TZ == 0 && g->hi % TY == 0 && g->wi % 16 == 0;
+  const int co32 = (g->co + 31) / 32 * 32;
+  if (!(g->ks == 3 && g->stride == 1 && g->pad == 1 && g->di % TZ == 0 && g->hi % TY == 0 && g->wi % 16 == 0)) return false;
+  if (g->ci == 32 && co32 == 32) return true;
+  return !no_slices && g->ci % 32 == 0 && g->ci <= 256 && co32 <= 256 && g->co % 32 == 0;
 }
 
 static int wg_tiled_wgs(const RtpConvGeom* g) {
@@ -378,14 +387,36 @@ static int wg_tiled_wgs(const RtpConvGeom* g) {
 
 // Number of slabs rtp_wgrad will write per sample for this geometry if the caller lets it choose (0 = generic kernel,
 // any nsplit accepted).
-extern "C" int rtp_wgrad_nsplit(const RtpConvGeom* g) { return (g && wg_tiled_applicable(g)) ? wg_tiled_wgs(g) : 0; }
+int rtp_wgrad_s2_nsplit(const RtpConvGeom* g);   // wgrad_s2_tiled.hip: the stride-2 convs
+extern "C" int rtp_wgrad_nsplit(const RtpConvGeom* g) {
+  if (!g) return 0;
+  if (wg_tiled_applicable(g)) return wg_tiled_wgs(g);
+  return rtp_wgrad_s2_nsplit(g);
+}
 
 int rtp_wgrad_tiled_try(const RtpAct* gy, const RtpAct* x, const RtpConvGeom* g, int nsplit, float* gp, hipStream_t s,
-                        const void* wd, float* qpart, float* tg) {
+                        const void* wd, float* qpart, float* tg, int slab_rows, int slab_cols) {
   if (!wg_tiled_applicable(g)) return 1;
   if (x->cs % 32 || x->co % 8 || nsplit != wg_tiled_wgs(g)) return 1;   // x may be a 32-channel slice of a wider tensor
+  const int K = g->ci / 32, J = (g->co + 31) / 32;
+  if (K * J > 1) {   // channel slices: independent launches into windows of the wide slabs
+    if (wd || qpart || tg) return RTP_ERR_UNSUPPORTED;
+    if (gy->cs % 32 || gy->co % 8) return 1;
+    RtpConvGeom gs = *g;
+    gs.ci = 32; gs.co = 32; gs.w_ci_total = 0; gs.w_ci_off = 0;
+    for (int j = 0; j < J; ++j)
+      for (int k = 0; k < K; ++k) {
+        RtpAct gj = *gy; gj.co = gy->co + 32 * j; gj.c = 32;
+        RtpAct xk = *x; xk.co = x->co + 32 * k; xk.c = 32;
+        const int rc = rtp_wgrad_tiled_try(&gj, &xk, &gs, nsplit, gp + (long)(32 * j) * g->ci + 32 * k, s, nullptr, nullptr, nullptr,
+                                           32 * J, g->ci);
+        if (rc != RTP_OK) return rc > 0 ? RTP_ERR_UNSUPPORTED : rc;
+      }
+    return RTP_OK;
+  }
   WgTiledParams p;
   p.gy = (const bf16_t*)gy->ptr; p.x = (const bf16_t*)x->ptr; p.gp = gp;
+  p.slab_rows = slab_rows > 0 ? slab_rows : 32; p.slab_cols = slab_cols > 0 ? slab_cols : 32;
   p.x_cs = x->cs; p.x_co = x->co;
   p.N = g->n; p.D = g->di; p.H = g->hi; p.W = g->wi; p.g_cs = gy->cs; p.g_co = gy->co;
   p.tiles_y = p.H / TY; p.tiles_x = (p.W + TX - 1) / TX; p.tiles_z = p.D / TZ;

@@ -223,6 +223,14 @@ class Graph:
                 self.pgrad[name] = self.be.alloc(tuple(p.shape), "f32")
         return p
 
+    def slice_ws(self, lane, floats):
+        """fp32 scratch of the channel-sliced convs (backend.conv(ws=...)), one buffer per lane: launches of one lane are
+        stream-ordered anyway, and a shared buffer would tie the lanes together through false dependencies."""
+        d = self.__dict__.setdefault("_slice_ws", {})
+        if (lane, floats) not in d:
+            d[(lane, floats)] = self.be.alloc((floats,), "f32")
+        return d[(lane, floats)]
+
     def ensure_stats(self, x: Act):
         if x.stats is None:
             x.stats_split = stats_split(x.vox)
@@ -585,7 +593,11 @@ class ConvOp:
         # Convs on the LDS-tiled kernel also emit (sum y, sum y^2) per channel from their epilogue, so a GroupNorm
         # consumer of y needs no statistics pass (ensure_stats finds them)
         fstats = None
-        S = 0 if (self.out_fp32 or ge.co != self.y.c or not self.want_stats) else be.conv_stats_nsplit(self.x, ge, False)
+        # wide 3x3x3 convs (64 / 128 channels: the feat64 backbone; stride 1 and the stride-2 forward) run as channel slices of the
+        # LDS-tiled kernels, the partial sums carried in an fp32 workspace (rtp_conv_igemm_ws)
+        self.sliced_fwd = (not self.fold_fused) and hasattr(be, "conv_sliced_ok") and be.conv_sliced_ok(self.x, ge, False)
+        skw = dict(ws=True) if self.sliced_fwd else {}
+        S = 0 if (self.out_fp32 or ge.co != self.y.c or not self.want_stats) else be.conv_stats_nsplit(self.x, ge, False, **skw)
         if S > 0:
             self.y.stats_split = S
             self.y.stats = be.alloc((g.n, S, self.y.c, 2), "f32")
@@ -598,15 +610,19 @@ class ConvOp:
                        lane, [self.x, self.wt, stats, self.residual], [self.y, self.mr, self.y.stats if fstats else None],
                        "conv:" + self.name)
         else:
+            kw = dict(ws=g.slice_ws(lane, g.n * self.y.vox * 32)) if self.sliced_fwd else {}
             g.emit_fwd(be.conv(self.x, self.wf, nw > 1, self.btab, self.residual, self.y, ge, self.relu, False,
-                               self.out_fp32, fstats),
-                       lane, [self.x, self.wf, self.btab, self.residual], [self.y, self.y.stats if fstats else None],
-                       "conv:" + self.name)
+                               self.out_fp32, fstats, **kw),
+                       lane, [self.x, self.wf, self.btab, self.residual, kw.get("ws")],
+                       [self.y, self.y.stats if fstats else None, kw.get("ws")], "conv:" + self.name)
         self.alg_flops = 2 * g.n * ge.do * ge.ho * ge.wo * self.co_real * self.ci_real * ntap
         g.flops["conv_fwd"] += self.alg_flops
         # mirrors the dispatch predicate of rtp_conv_tiled_try (csrc/conv_tiled.hip)
         brick = ge.ks == 3 and ge.stride == 1 and ge.di % 2 == 0 and ge.hi % 4 == 0 and ge.wi % 16 == 0
-        self.tiled_fwd = brick and ge.ci == 32 and ge.co in (16, 32) and self.x.cs == 32
+        s2_fwd = (ge.ks == 3 and ge.stride == 2 and ge.ci == 32 and ge.co == 32 and ge.di == 2 * ge.do and ge.hi == 2 * ge.ho
+                  and ge.wi == 2 * ge.wo and ge.ho % 2 == 0 and min(ge.do, ge.ho, ge.wo) >= 2 and self.x.cs % 32 == 0
+                  and hasattr(be, "conv_sliced_ok"))   # mirrors rtp_conv_s2_fwd_try (csrc/conv_s2_tiled.hip)
+        self.tiled_fwd = (brick and ge.ci == 32 and ge.co in (16, 32) and self.x.cs == 32) or self.sliced_fwd or s2_fwd
         self.tiled_bwd = brick and ge.ci == 32 and pad_to(ge.co, 32) == 32
         # ... and of rtp_dgrad_s2_try (csrc/dgrad_s2_tiled.hip): stride-2 data gradients that write a 32-channel tensor of twice
         # the output's size
@@ -640,12 +656,16 @@ class ConvOp:
             dxh = View(dxh_buf, g.n, x.d, x.h, x.w, ge.ci, 0, ge.ci)
             # GroupNorm backward needs P = sum dxhat and Q = sum dxhat*x per (sample, channel): the tiled kernel
             # accumulates them in its epilogue, otherwise a chan_stats pass over (dxhat, x) follows
-            S = be.conv_stats_nsplit(gy, ge, True) if self.gn else 0
+            self.sliced_bwd = hasattr(be, "conv_sliced_ok") and be.conv_sliced_ok(gy, ge, True)
+            S = be.conv_stats_nsplit(gy, ge, True, **(dict(ws=True) if self.sliced_bwd else {})) if self.gn else 0
             pq = be.alloc((g.n, S or x.stats_split, ge.ci, 2), "f32") if self.gn else None
             lane = g.lane_of(self.y)   # a stride-2 conv's data gradient runs with the LOWER-resolution group
-            g.emit_bwd(be.conv(gy, wd, False, None, None, dxh, ge, False, True, False, (x, pq) if S else None),
-                       lane, [gy, wd, x if S else None], [dxh, pq if S else None], "dgrad:" + self.name)
+            kw = dict(ws=g.slice_ws(lane, g.n * x.vox * 32)) if self.sliced_bwd else {}
+            g.emit_bwd(be.conv(gy, wd, False, None, None, dxh, ge, False, True, False, (x, pq) if S else None, **kw),
+                       lane, [gy, wd, x if S else None, kw.get("ws")], [dxh, pq if S else None, kw.get("ws")], "dgrad:" + self.name)
             g.flops["conv_dgrad"] += self.alg_flops
+            if self.sliced_bwd:
+                self.tiled_bwd = True
             g.flops["conv_tiled" if (self.tiled_bwd or self.s2_bwd) else "conv_generic"] += self.alg_flops
             # data gradient: read gy, write dxhat, (GroupNorm: read x for Q)
             nb = 2 * g.n * (gy.vox * pad_to(ge.co, 32) + x.vox * ge.ci * (2 if self.gn else 1))
@@ -673,7 +693,7 @@ class ConvOp:
             elif x.needs_grad:
                 x.contribs.append((dxh, None))
         # ---- weight gradient
-        S = be.wgrad_nsplit(ge) if x.cs == 32 and x.co == 0 else 0
+        S = be.wgrad_nsplit(ge) if (x.cs % 32 == 0 and x.co % 8 == 0 and gy.cs % 32 == 0 and (ge.ci > 32 or (x.cs == 32 and x.co == 0))) else 0
         self.tiled_wgrad = S > 0
         S = S or wgrad_split(gy.vox)
         co32 = pad_to(ge.co, 32)

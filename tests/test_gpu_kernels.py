@@ -228,8 +228,14 @@ def test_conv_transposed_is_data_gradient(hip, case):
 @pytest.mark.parametrize("case", [
     (2, (4, 8, 16), 32, 32, 3, 1, 3), (2, (8, 8, 16), 32, 64, 3, 2, 2), (1, (2, 4, 20), 64, 32, 1, 1, 1),
     (2, (4, 8, 8), 32, 15, 3, 1, 3), (1, (3, 5, 7), 128, 128, 3, 1, 1), (1, (1, 2, 4), 64, 64, 3, 2, 1),
+    # 1x1x1: the all-channels-per-block kernel (wgrad_1x1_kernel)
+    (2, (4, 8, 16), 64, 256, 1, 1, 3), (1, (3, 5, 7), 128, 64, 1, 1, 2), (2, (4, 8, 16), 32, 32, 1, 1, 4), (3, (2, 4, 20), 32, 45, 1, 1, 1),
+    (1, (4, 16, 40), 64, 32, 1, 1, 10),
     # nsplit=None: geometries of the LDS-tiled kernel (csrc/wgrad_tiled.hip), which picks its own slab count
-    (2, (4, 8, 32), 32, 32, 3, 1, None), (1, (2, 16, 64), 32, 15, 3, 1, None), (3, (6, 12, 96), 32, 32, 3, 1, None), (2, (8, 32, 80), 32, 32, 3, 1, None), (1, (2, 4, 16), 32, 32, 3, 1, None)])
+    (2, (4, 8, 32), 32, 32, 3, 1, None), (1, (2, 16, 64), 32, 15, 3, 1, None), (3, (6, 12, 96), 32, 32, 3, 1, None), (2, (8, 32, 80), 32, 32, 3, 1, None), (1, (2, 4, 16), 32, 32, 3, 1, None),
+    # stride 2 on the LDS-tiled kernel (csrc/wgrad_s2_tiled.hip): 32 -> 32, ragged Wo, wide convs as slices (>= 65536 output voxels)
+    (2, (4, 8, 32), 32, 32, 3, 2, None), (1, (8, 16, 64), 32, 32, 3, 2, None), (3, (4, 4, 80), 32, 15, 3, 2, None), (2, (4, 8, 40), 32, 32, 3, 2, None),
+    (2, (2, 4, 8), 32, 32, 3, 2, None), (8, (16, 32, 128), 64, 64, 3, 2, None), (2, (8, 32, 80), 32, 64, 3, 2, None)])
 def test_wgrad(hip, case):
     n, dims, ci, co_real, ks, stride, nsplit = case
     d, h, w = dims
@@ -966,3 +972,110 @@ def test_fused_stride2_data_gradient(hip, case):
     torch.cuda.synchronize()
     check(dxp, BF, "fused stride-2 data gradient without GroupNorm %r" % (case,))
     assert rel_err(tot.sum(1).cpu(), dxg.buf.float().reshape(n, -1, ci).sum(1).cpu()) < F32
+
+
+@pytest.mark.parametrize("case", [
+    # n, dims, ci, co, per-sample weights + class bias (GroupNorm fold output), residual, relu
+    (2, (4, 8, 32), 64, 64, True, True, True), (1, (2, 8, 48), 128, 64, True, False, False),
+    (2, (2, 4, 16), 64, 128, False, True, True), (3, (4, 8, 80), 128, 128, True, False, True),
+    (2, (4, 8, 32), 32, 64, True, False, True), (1, (2, 4, 32), 64, 32, False, True, False),
+])
+def test_wide_convs_as_channel_slices_of_the_tiled_kernel(hip, case):
+    """rtp_conv_igemm_ws / rtp_wgrad on Cin = 32 K, Cout = 32 J (the feat64 backbone's 64- and 128-channel layers,
+    hrnet3D_config.py:149-177): K x J launches of the LDS-tiled 32 -> 32 kernel over windows of ONE weight image, the partial
+    sums in an fp32 workspace -- forward (+ class bias, residual, ReLU, statistics), data gradient (+ P / Q statistics) and
+    weight gradient, each against the emulation of the whole wide conv."""
+    n, dims, ci, co, per_sample, has_res, relu = case
+    d, h, w = dims
+    geom = Geom(n, d, h, w, d, h, w, ci, co, 3, 1, 1)
+    xp, xc, xg = views(hip, rnd((n, d, h, w, ci), 401, relu=True), n, d, h, w)
+    assert hip.conv_sliced_ok(xg, geom, False)
+    nw = n if per_sample else 1
+    wf = Pair(hip, rnd((nw, 27, co, ci), 402, scale=0.05))
+    bt = Pair(hip, rnd((nw, 64, co), 403, torch.float32))
+    yp, yc, yg = views(hip, torch.zeros(n, d, h, w, co, dtype=torch.bfloat16), n, d, h, w)
+    rc = rg = None
+    if has_res:
+        rp, rc, rg = views(hip, rnd((n, d, h, w, co), 404), n, d, h, w)
+    S = hip.conv_stats_nsplit(xg, geom, False, ws=True)
+    assert S > 0
+    st = hip.alloc((n, S, co, 2), "f32")
+    ws = hip.alloc((n * d * h * w * 32,), "f32")
+    run(hip, EMU.conv(xc, wf.c, per_sample, bt.c, rc, yc, geom, relu, False, False),
+        hip.conv(xg, wf.g, per_sample, bt.g, rg, yg, geom, relu, False, False, (None, st), ws=ws))
+    check(yp, BF, "sliced conv forward %r" % (case,))
+    ref = hip.alloc((n, 3, co, 2), "f32")
+    hip.chan_stats(yg, None, 3, ref)(hip.stream())
+    torch.cuda.synchronize()
+    assert rel_err(st.sum(1).cpu(), ref.sum(1).cpu()) < F32, "sliced conv statistics %r" % (case,)
+    # the same launch without statistics / with an fp32 output
+    y32p, y32c, y32g = views(hip, torch.zeros(n, d, h, w, co), n, d, h, w)
+    run(hip, EMU.conv(xc, wf.c, per_sample, bt.c, rc, y32c, geom, relu, False, True),
+        hip.conv(xg, wf.g, per_sample, bt.g, rg, y32g, geom, relu, False, True, ws=ws))
+    check(y32p, F32 * 5, "sliced conv forward, fp32 output %r" % (case,))
+    # data gradient: contraction over the conv's output channels, P / Q statistics against the conv's input
+    gyp, gyc, gyg = views(hip, rnd((n, d, h, w, co), 405), n, d, h, w)
+    assert hip.conv_sliced_ok(gyg, geom, True)
+    wd = Pair(hip, rnd((27, ci, co), 406, scale=0.05))
+    dxp, dxc, dxg = views(hip, torch.zeros(n, d, h, w, ci, dtype=torch.bfloat16), n, d, h, w)
+    Sb = hip.conv_stats_nsplit(gyg, geom, True, ws=True)
+    assert Sb > 0
+    pq = hip.alloc((n, Sb, ci, 2), "f32")
+    run(hip, EMU.conv(gyc, wd.c, False, None, None, dxc, geom, False, True, False),
+        hip.conv(gyg, wd.g, False, None, None, dxg, geom, False, True, False, (xg, pq), ws=ws))
+    check(dxp, BF, "sliced data gradient %r" % (case,))
+    refq = hip.alloc((n, 3, ci, 2), "f32")
+    hip.chan_stats(dxg, xg, 3, refq)(hip.stream())
+    torch.cuda.synchronize()
+    assert rel_err(pq.sum(1).cpu(), refq.sum(1).cpu()) < F32 * 5, "sliced data gradient P / Q %r" % (case,)
+    # weight gradient: every (output slice, input slice) launch fills its window of the wide slabs
+    Sw = hip.wgrad_nsplit(geom)
+    assert Sw > 0
+    gp = Pair(hip, torch.full((n, Sw, 27, co, ci), 7.0))
+    run(hip, EMU.wgrad(gyc, xc, geom, Sw, gp.c), hip.wgrad(gyg, xg, geom, Sw, gp.g))
+    assert rel_err(gp.sync_back().sum(1), gp.c.sum(1)) < F32 * 5, "sliced weight gradient %r" % (case,)
+
+
+@pytest.mark.parametrize("case", [
+    # n, dims (input), ci, co, per-sample weights + class bias, residual, relu
+    (2, (4, 8, 32), 32, 32, True, False, True), (1, (8, 16, 64), 32, 32, False, True, False), (3, (4, 4, 80), 32, 32, True, False, True),
+    (2, (4, 8, 40), 32, 32, True, False, True),       # Wo = 20: the second brick column is three quarters padding
+    (2, (8, 32, 80), 32, 64, True, False, True),      # the level-1 -> level-2 down-sampling convs: two output slices
+    (1, (4, 8, 32), 64, 64, True, False, True), (2, (4, 8, 32), 64, 128, False, True, False), (1, (4, 4, 32), 128, 128, True, False, True),
+    (8, (16, 32, 128), 64, 64, True, False, True),   # input-channel slices through the fp32 workspace (>= 65536 output voxels)
+])
+def test_stride2_forward_on_the_tiled_kernel(hip, case):
+    """csrc/conv_s2_tiled.hip (32 -> 32 per launch; wider convs as channel slices through rtp_conv_igemm_ws) against the emulation:
+    output, statistics epilogue, fp32 output."""
+    n, dims, ci, co, per_sample, has_res, relu = case
+    d, h, w = dims
+    do, ho, wo = d // 2, h // 2, w // 2
+    geom = Geom(n, d, h, w, do, ho, wo, ci, co, 3, 2, 1)
+    xp, xc, xg = views(hip, rnd((n, d, h, w, ci), 501, relu=True), n, d, h, w)
+    wide = ci * co > 1024
+    # (input-channel slices re-stream x per launch: only volumes that fill the chip take that route, the rest stay generic)
+    sliced = hip.conv_sliced_ok(xg, geom, False)
+    assert sliced == (wide and (ci == 32 or n * do * ho * wo >= 65536))
+    nw = n if per_sample else 1
+    wf = Pair(hip, rnd((nw, 27, co, ci), 502, scale=0.05))
+    bt = Pair(hip, rnd((nw, 64, co), 503, torch.float32))
+    yp, yc, yg = views(hip, torch.zeros(n, do, ho, wo, co, dtype=torch.bfloat16), n, do, ho, wo)
+    rc = rg = None
+    if has_res:
+        rp, rc, rg = views(hip, rnd((n, do, ho, wo, co), 504), n, do, ho, wo)
+    kw = dict(ws=hip.alloc((n * do * ho * wo * 32,), "f32")) if sliced else {}
+    S = hip.conv_stats_nsplit(xg, geom, False, ws=sliced)
+    if sliced or not wide:
+        assert S == min(256 // n, do * (ho // 2) * ((wo + 15) // 16)), "expected the tiled stride-2 kernel's partial count"
+    st = hip.alloc((n, S, co, 2), "f32")
+    run(hip, EMU.conv(xc, wf.c, per_sample, bt.c, rc, yc, geom, relu, False, False),
+        hip.conv(xg, wf.g, per_sample, bt.g, rg, yg, geom, relu, False, False, (None, st), **kw))
+    check(yp, BF, "stride-2 forward %r" % (case,))
+    ref = hip.alloc((n, 3, co, 2), "f32")
+    hip.chan_stats(yg, None, 3, ref)(hip.stream())
+    torch.cuda.synchronize()
+    assert rel_err(st.sum(1).cpu(), ref.sum(1).cpu()) < F32, "stride-2 forward statistics %r" % (case,)
+    y32p, y32c, y32g = views(hip, torch.zeros(n, do, ho, wo, co), n, do, ho, wo)
+    run(hip, EMU.conv(xc, wf.c, per_sample, bt.c, rc, y32c, geom, relu, False, True),
+        hip.conv(xg, wf.g, per_sample, bt.g, rg, y32g, geom, relu, False, True, **kw))
+    check(y32p, F32 * 5, "stride-2 forward, fp32 output %r" % (case,))
