@@ -81,7 +81,7 @@ class PoseEngine:
     """HRRadarPose for a fixed (batch, Cin, dims): buffers + launch lists built once, replayed every step."""
 
     def __init__(self, backend, params, arch, final_fuse, heads, loss_weight, code_weights, batch, dims, train=True,
-                 pgrads=None, test_cfg=None, max_objs=None, lidar_channels=0):
+                 pgrads=None, test_cfg=None, max_objs=None, lidar_channels=0, early_flush=False):
         self.be, self.n, self.dims, self.train = backend, batch, tuple(dims), train
         self.heads = OrderedDict(heads)
         self.nreg, self.ncls = self.heads["reg"], self.heads["hm"]
@@ -89,6 +89,7 @@ class PoseEngine:
         cin = net.ARCH_TABLES[arch]["inplanes"]
         be = backend
         g = self.graph = Graph(be, batch, params, train=train, pgrads=pgrads)
+        g.early_flush = bool(early_flush)   # two gradient buckets (trainer): one early flush of the deferred tail
         self.x_in = g.input_f32("rdr", cin, dims)
         self.feats = net.build_hrnet3d(g, self.x_in, arch, dims, final_fuse)
         # two-stream fusion (BASELINE config 5): the dense LiDAR voxel grid [B, C_l, Z, Y, X] fp32 enters beside the radar feature

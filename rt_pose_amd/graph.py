@@ -154,6 +154,13 @@ class Graph:
         self._defer_skip = set(v for v in os.environ.get("RTP_DEFER_SKIP", "stem_bwd").split(",") if v)
         self._deferred = []
         self.head, self._head_emitted = [], False   # activation-independent weight packing (forward_list)
+        self._lazy_by_coeff = {}   # coefficient tensor -> its LazyCoeff (an early tail flush has to materialise pending ones)
+        # Data-parallel training with TWO gradient buckets (trainer.DataParallelTrainer(ar_buckets=2)): the deferred tail is
+        # flushed once early -- when the reversed sweep leaves stage 3 -- so that the gradients of transition2 .. pose_head (a
+        # contiguous suffix of the flat buffer, state_dict order) are final while stage 2 / layer 1 are still being swept, and
+        # their all-reduce runs beside the rest of the backward pass.  early_tail_index: position of that flush in self.bwd.
+        self.early_flush = False
+        self.early_tail_index = None
         self.full_vox = None       # voxels of the first (full-resolution) activation: lanes are assigned by resolution
         # algorithmic FLOPs (2*MACs of real channels) per kernel family, per replay of the lists
         self.flops = {"conv_fwd": 0, "conv_dgrad": 0, "wgrad": 0, "conv_tiled": 0, "conv_generic": 0,
@@ -497,6 +504,15 @@ class Graph:
         if "RTP_DEFER_WG" not in os.environ and any(isinstance(op, (SplitConvOp, CoSplitConvOp)) for op in self.ops):
             self._defer_wg = []
         for op in reversed(self.ops):
+            if self.early_flush and self.early_tail_index is None and op.y.name.startswith(("l1.", "t1", "s2.")):
+                # (coefficients a later fan-in pass would have computed in its prologue are needed by the GroupNorm parameter
+                # sums of this flush: their launches are emitted now)
+                for it in self.tail_a:
+                    lz = self._lazy_by_coeff.get(it[1].data_ptr()) if it[0] == "gn_param" else None
+                    if lz is not None:
+                        lz.materialise()
+                self.emit_tail(L_WG_LOW)
+                self.early_tail_index = len(self.bwd) - 1
             gy = self.finalize_grad(op.y, isinstance(op, (ConvOp, SplitConvOp, CoSplitConvOp)) and bool(op.gn or op.bname))
             if gy is None:
                 continue
@@ -683,6 +699,7 @@ class ConvOp:
                 # no launch yet: the fan-in pass of x computes them in its prologue when it can (LazyCoeff); the parameter sums
                 # of the deferred tail read the partials that pass writes
                 lz = LazyCoeff(g, self.name, lane, pq, S, self.mr, g.params[self.gn[0]], g.n, self.ci_real, self.groups, x.vox, coeff)
+                g._lazy_by_coeff[coeff.data_ptr()] = lz
                 g.tail_a.append(("gn_param", coeff, g.n, self.ci_real, g.pgrad[self.gn[0]], g.pgrad[self.gn[1]], 0))
                 if x.needs_grad and ge.ci == self.ci_real:
                     x.contribs.append((dxh, lz))

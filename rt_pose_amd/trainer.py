@@ -61,16 +61,29 @@ def init_state_dict(shapes, seed=0):
 
 class DataParallelTrainer:
     def __init__(self, name="hr3d", batch_per_gpu=8, dims=configs.NATIVE_DIMS, total_steps=1000, lr_max=None,
-                 device="cuda:0", rank=0, world_size=1, use_graph=True, seed=0, backend=None, process_group=None):
+                 device="cuda:0", rank=0, world_size=1, use_graph=True, seed=0, backend=None, process_group=None, ar_buckets=None):
         self.spec = s = configs.spec(name)
         self.name, self.rank, self.world = name, rank, world_size
         self.be = backend if backend is not None else HipBackend(device)
         self.shapes = configs.param_shapes(name)
         self.flat = FlatParams(self.shapes, self.be.alloc)
         self.flat.load_state_dict(init_state_dict(self.shapes, seed))
+        # Gradient all-reduce in ONE bucket (the whole flat buffer after the backward sweep) or in TWO (RTP_AR_BUCKETS=2 / ar_buckets=2,
+        # multi-rank eager mode only): the reference's DDP overlaps bucketed all-reduces with the tail of backward
+        # (det3d/torchie/apis/train.py:284-291); here the deferred tail is flushed once early (graph.Graph.early_flush) so that
+        # the gradients of transition2 .. pose_head -- a contiguous suffix of the flat buffer -- are reduced on the process
+        # group's stream while stage 2 / layer 1 are still being swept.  One bucket stays the default (A/B: `allreduce_buckets`
+        # in the bench line); with 8-33 MB of gradients per step the collective is a few percent of the step either way.
+        if ar_buckets is None:
+            ar_buckets = int(os.environ.get("RTP_AR_BUCKETS", "1"))
+        self.ar_buckets = 2 if (ar_buckets == 2 and world_size > 1 and not (use_graph and self.be.name == "hip")) else 1
         self.engine = PoseEngine(self.be, self.flat.values, s["arch"], s["final_fuse"], s["heads"], s["weight"],
                                  s["code_weights"], batch_per_gpu, dims, train=True, pgrads=self.flat.grads,
-                                 test_cfg=configs.test_cfg(), lidar_channels=s.get("lidar_channels", 0))
+                                 test_cfg=configs.test_cfg(), lidar_channels=s.get("lidar_channels", 0),
+                                 early_flush=self.ar_buckets == 2)
+        self._ar_pending = None
+        if self.ar_buckets == 2:
+            self._install_early_bucket()
         self.opt = FlatAdam(self.be, self.flat, self.engine.live_params)
         self.total_steps, self.lr_max = total_steps, lr_max if lr_max is not None else s["lr_max"]
         self.step_idx = 0
@@ -97,6 +110,36 @@ class DataParallelTrainer:
             self._step_done = torch.cuda.Event()
             self._ar_events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(64)]
             self._ar_count = 0
+
+    def _install_early_bucket(self):
+        """Split the flat gradient buffer at the first parameter the early tail flush finalises and queue that suffix's all-reduce
+        as a launch of the backward list, right behind the flush (same lane: stream order makes it wait for exactly that flush)."""
+        from .lanes import LANE_MAP, LanePlan, Launch, L_WG_LOW
+        eng, g = self.engine, self.engine.graph
+        idx = g.early_tail_index
+        if idx is None:
+            self.ar_buckets = 1
+            return
+        ptr2name = {t.data_ptr(): k for k, t in self.flat.grads.items()}
+        early = {ptr2name[w] for L in eng.bwd[:idx + 1] for w in L.writes if w in ptr2name}
+        late = {ptr2name[w] for L in eng.bwd[idx + 1:] for w in L.writes if w in ptr2name}
+        assert early and not (early & late), "a parameter gradient is written on both sides of the early flush"
+        split = min(self.flat.offsets[k] for k in early)
+        assert all(self.flat.offsets[k] < split for k in late), "the early bucket is not a suffix of the flat gradient buffer"
+        self.ar_split = split
+        bucket = self.flat.g[split:]
+        grads = [self.flat.grads[k] for k in early]
+
+        def kick(stream_ptr):
+            import torch.distributed as dist
+            if stream_ptr is not None and self.be.name == "hip":
+                ext = torch.cuda.ExternalStream(stream_ptr.value if hasattr(stream_ptr, "value") else int(stream_ptr), device=self.be.device)
+                with torch.cuda.stream(ext):   # the collective is ordered behind this lane's work and runs on the group's own stream
+                    self._ar_pending = dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+            else:
+                self._ar_pending = dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+        eng.bwd.insert(idx + 1, Launch(kick, L_WG_LOW, grads, grads, "allreduce:early"))
+        eng.bwd_plan = LanePlan(self.be, eng.bwd, LANE_MAP)
 
     # ------------------------------------------------------------------ one step
     def _on_stream(self):
@@ -149,7 +192,13 @@ class DataParallelTrainer:
             if timed:
                 e0, e1 = self._ar_events[self.step_idx % len(self._ar_events)]
                 e0.record(self.stream)
-            dist.all_reduce(self.flat.g, op=dist.ReduceOp.SUM, group=self.pg)
+            if self.ar_buckets == 2:   # the suffix is already on its way (queued behind the early tail flush); now the prefix
+                dist.all_reduce(self.flat.g[:self.ar_split], op=dist.ReduceOp.SUM, group=self.pg)
+                if self._ar_pending is not None:
+                    self._ar_pending.wait()   # (stream-ordered on the GPU: the step stream waits for the early bucket)
+                    self._ar_pending = None
+            else:
+                dist.all_reduce(self.flat.g, op=dist.ReduceOp.SUM, group=self.pg)
             if timed:
                 e1.record(self.stream)
                 self._ar_count += 1

@@ -13,7 +13,8 @@ are compared: argmax-voxel agreement rate, metric shift of the decoded key-point
 synthetic ground truth (so the number the north star cares about -- the MPJPE DIFFERENCE caused by bf16 -- is measured).
 
 This module lives under tests/ because it uses the oracle as the checker.  `python -m tests.keypoint_agreement` writes
-profiles/r02_keypoint_agreement.json, which bench.py attaches to its JSON line (it does not import this module).
+gpurun_out/keypoint_agreement.json; copied to profiles/r03_keypoint_agreement.json it is what bench.py quotes as
+`keypoint_agreement_artefact` (bench.py does not import this module).
 """
 import json
 import os
@@ -155,9 +156,30 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--eval-batches", type=int, default=2)
-    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r02_keypoint_agreement.json"))
+    ap.add_argument("--seeds", type=int, default=1, help="independent trainings (weights seed 0..n-1); the artefact carries every run and their pooled figures")
+    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "keypoint_agreement.json"),
+                    help="(gpurun_out/ is the directory that travels back from the GPU box; copy the file to profiles/)")
     a = ap.parse_args()
-    res = run(steps=a.steps, eval_batches=a.eval_batches, log=lambda s: print(s, flush=True))
+    runs = [run(steps=a.steps, eval_batches=a.eval_batches, seed=sd, log=lambda s: print(s, flush=True)) for sd in range(a.seeds)]
+    res = dict(runs[0])
+    if len(runs) > 1:   # pooled over the seeds: frame-weighted means, worst-case maxima
+        w = np.array([r["frames"] for r in runs], dtype=np.float64)
+        wm = lambda f: float((np.array([f(r) for r in runs]) * w).sum() / w.sum())
+        res.update({
+            "seeds": len(runs), "frames": int(w.sum()), "joints": int(sum(r["joints"] for r in runs)),
+            "argmax_agreement": round(wm(lambda r: r["argmax_agreement"]), 4),
+            "argmax_within_1_voxel": round(wm(lambda r: r["argmax_within_1_voxel"]), 4),
+            "argmax_max_voxel_distance": max(r["argmax_max_voxel_distance"] for r in runs),
+            "keypoint_shift_cm": {"mean": round(wm(lambda r: r["keypoint_shift_cm"]["mean"]), 4),
+                                  "p95": max(r["keypoint_shift_cm"]["p95"] for r in runs), "max": max(r["keypoint_shift_cm"]["max"] for r in runs)},
+            "mpjpe_cm": {k: round(wm(lambda r: r["mpjpe_cm"][k]), 4) for k in ("hip_bf16", "oracle_fp32", "delta")},
+            "abs_mpjpe_cm": {k: round(wm(lambda r: r["abs_mpjpe_cm"][k]), 4) for k in ("hip_bf16", "oracle_fp32", "delta")},
+            "mean_peak_score": {k: round(wm(lambda r: r["mean_peak_score"][k]), 4) for k in ("hip_bf16", "oracle_fp32")},
+            "worst_seed_abs_mpjpe_delta_cm": max(abs(r["mpjpe_cm"]["delta"]) for r in runs),
+            "per_seed": [{k: r[k] for k in ("frames", "argmax_agreement", "argmax_within_1_voxel", "keypoint_shift_cm", "mpjpe_cm",
+                                            "mean_peak_score", "train_seconds")} for r in runs]})
+        res.pop("loss_history", None)
+    os.makedirs(os.path.dirname(a.out), exist_ok=True)
     with open(a.out, "w") as f:
         json.dump(res, f, indent=1)
     print(json.dumps(res))

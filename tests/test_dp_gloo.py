@@ -66,3 +66,39 @@ def test_two_rank_step_matches_manual_average(tmp_path):
     d = (trs[0].flat.p - r0["p"]).abs()
     frac = float((d > 1e-6).float().mean())
     assert frac < 1e-3, ("fraction of parameters off by more than 1e-6", frac, float(d.max()))
+
+
+def _worker_buckets(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    res = {}
+    for nb in (1, 2):
+        tr = DataParallelTrainer("hr3d", B, DIMS, total_steps=10, rank=rank, world_size=world, backend=EmuBackend(exact=True), seed=0,
+                                 ar_buckets=nb)
+        assert tr.ar_buckets == nb
+        if nb == 2:
+            tags = [L.tag for L in tr.engine.bwd]
+            i = tags.index("allreduce:early")
+            assert tags[i - 1] == "tail" and tags[-1] == "tail" and 0 < tr.ar_split < tr.flat.numel
+            # the early bucket is exactly transition2 .. pose_head: everything the sweep has finished when it leaves stage 3
+            first = [k for k, o in tr.flat.offsets.items() if o == tr.ar_split][0]
+            assert first.startswith("backbone.backbone.transition2."), first
+        for step in range(STEPS):
+            tr.step(synth.make_batch(B, 1, DIMS, seed=100 + step, rank=rank))
+        res[nb] = tr.flat.p.clone()
+    torch.save(res, os.path.join(out, "rank%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_two_gradient_buckets_equal_one(tmp_path):
+    """ar_buckets=2 (early tail flush + all-reduce of the transition2 .. pose_head suffix queued inside the backward list, the rest
+    after the sweep) trains exactly like the single all-reduce: same parameters on both ranks after two steps."""
+    world = 2
+    mp.spawn(_worker_buckets, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r0, r1 = [torch.load(os.path.join(tmp_path, "rank%d.pt" % r)) for r in range(world)]
+    assert torch.equal(r0[2], r1[2]), "replicas diverged with two buckets"
+    d = (r0[1] - r0[2]).abs()
+    assert float((d > 1e-6).float().mean()) < 1e-3, ("two buckets vs one", float(d.max()))

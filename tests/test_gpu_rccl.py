@@ -22,7 +22,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, buckets=1):
     import torch.distributed as dist
     from rt_pose_amd import synth
     from rt_pose_amd.trainer import DataParallelTrainer
@@ -30,7 +30,8 @@ def _worker(rank, world, port, out):
     torch.cuda.set_device(rank)
     dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
     tr = DataParallelTrainer("hr3d", B, DIMS, total_steps=10, device="cuda:%d" % rank, rank=rank, world_size=world,
-                             use_graph=False, seed=0)
+                             use_graph=False, seed=0, ar_buckets=buckets)
+    assert tr.ar_buckets == buckets
     grads = []
     for step in range(STEPS):
         tr.step(synth.make_batch(B, 1, DIMS, seed=100 + step, rank=rank))
@@ -43,7 +44,10 @@ def _worker(rank, world, port, out):
 
 
 @pytest.mark.timeout(900)
-def test_two_rank_rccl_step_matches_manual_average(tmp_path):
+@pytest.mark.parametrize("buckets", [1, 2])
+def test_two_rank_rccl_step_matches_manual_average(tmp_path, buckets):
+    """buckets=2: the transition2 .. pose_head gradients are all-reduced from inside the backward list (behind the early tail
+    flush, overlapping the rest of the sweep), the others after it -- same result as the single collective."""
     if torch.cuda.device_count() < 2:
         pytest.skip("needs >= 2 GPUs (the driver's 8-GPU scaling run exercises the same path)")
     import torch.multiprocessing as mp
@@ -51,7 +55,7 @@ def test_two_rank_rccl_step_matches_manual_average(tmp_path):
     from rt_pose_amd.engine import one_cycle
     from rt_pose_amd.trainer import DataParallelTrainer
     world = 2
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), buckets), nprocs=world, join=True)
     r0, r1 = [torch.load(os.path.join(tmp_path, "rank%d.pt" % r)) for r in range(world)]
     assert torch.equal(r0["p"], r1["p"]), "replicas diverged"
     assert all(torch.equal(a, b) for a, b in zip(r0["g"], r1["g"])), "all-reduced gradients differ between ranks"

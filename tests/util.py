@@ -26,3 +26,26 @@ def rel_err(a, b):
     a = a.detach().double().cpu() if torch.is_tensor(a) else torch.as_tensor(a, dtype=torch.float64)
     b = b.detach().double().cpu() if torch.is_tensor(b) else torch.as_tensor(b, dtype=torch.float64)
     return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def check_golden_like_emulation(golden, key, got, emu, slack=1.5):
+    """`got` (the HIP kernels' bf16 result) against the golden entry `key` (the reference's fp32 values), with bounds DERIVED from
+    what bf16 storage costs: `emu` is the emulated plan's result (tests/emu_backend.py: the same rounding points, fp32 CPU
+    arithmetic in between), so emu - golden is the error distribution the precision choice itself produces, and the kernels may
+    differ from it by summation order only.  Norm-wise: rms(got - golden) <= slack * rms(emu - golden).  Per element: no outlier
+    beyond the emulated plan's own worst case (slack * max|emu - golden| + 4 rms), and |got - emu| <= 8 rms(emu - golden)."""
+    a = np.asarray(got.detach().float().cpu().numpy() if torch.is_tensor(got) else got, np.float64).reshape(-1)
+    e = np.asarray(emu.detach().float().cpu().numpy() if torch.is_tensor(emu) else emu, np.float64).reshape(-1)
+    if key in golden.files:
+        g = np.asarray(golden[key], np.float64).reshape(-1)
+    else:
+        g = np.asarray(golden[key + "#samples"], np.float64)
+        idx = sample_index(a.size, g.shape[0])
+        a, e = a[idx], e[idx]
+    d_e, d_h = e - g, a - g
+    rms_e = float(np.sqrt(np.mean(d_e ** 2))) + 1e-7
+    rms_h = float(np.sqrt(np.mean(d_h ** 2)))
+    assert rms_h <= slack * rms_e, (key, "norm-wise", rms_h, rms_e)
+    assert float(np.abs(d_h).max()) <= slack * float(np.abs(d_e).max()) + 4 * rms_e, (key, "per element", float(np.abs(d_h).max()), float(np.abs(d_e).max()), rms_e)
+    assert float(np.abs(a - e).max()) <= 8 * rms_e, (key, "kernels vs emulated plan", float(np.abs(a - e).max()), rms_e)
+    return rms_h, rms_e
