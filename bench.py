@@ -451,7 +451,9 @@ def main():
         line["other_models"] = {}
         for oname in ("hr3d_one_hm_doppler", "hr3d_one_hm_doppler_phase"):
             ospec = configs.spec(oname)
-            otr = DataParallelTrainer(oname, args.batch, configs.NATIVE_DIMS, total_steps=100, device=dev, use_graph=False)
+            # (same backend object and step stream as the headline model: the lanes keep their streams / hardware queues)
+            otr = DataParallelTrainer(oname, args.batch, configs.NATIVE_DIMS, total_steps=100, device=dev, use_graph=False,
+                                      backend=tr.be, stream=tr.stream)
             otr.load(synth.make_batch(args.batch, ospec["cin"], configs.NATIVE_DIMS, seed=1234, one_hm=ospec["heads"]["hm"] == 1))
             for _ in range(3):
                 otr.step()

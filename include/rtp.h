@@ -140,6 +140,8 @@ int rtp_wgrad_nsplit(const RtpConvGeom* g);
  * a fixed order -- what P, the bias gradient and the GroupNorm un-fold need, without a pass over gy. */
 int rtp_wgrad_q(const RtpAct* gy, const RtpAct* x, const RtpConvGeom* g, int nsplit, float* gp, const void* wd,
                 float* qpart, float* tg, void* stream);
+/* rtp_wgrad on the LDS-tiled kernel that also emits the subset sums of gy (tg [n][nsplit][27][32]) and nothing else. */
+int rtp_wgrad_tg(const RtpAct* gy, const RtpAct* x, const RtpConvGeom* g, int nsplit, float* gp, float* tg, void* stream);
 /* The slab contraction of rtp_wgrad_q for slabs ANY weight-gradient kernel wrote (the generic kernel's, e.g. the stride-2
  * layers): qpart[n][s][ci] = sum_{tap,co} wd[tap][ci][co] * gp[n][s][tap][co][ci];  gp fp32 [n][nsplit][ntap][co32][ci]. */
 int rtp_qpart_from_slabs(const float* gp, int n, int nsplit, int ntap, int co32, int ci, const void* wd, float* qpart,
@@ -185,6 +187,10 @@ int rtp_tail_desc_class_reduce(const float* scratch, int nsplit, int n, int c, f
 int rtp_tail_desc_wgrad_fold(const float* gp, int nsplit, const float* csum, const float* mr, const float* gamma,
                              const float* beta, int groups, const RtpConvGeom* g, int ci_real, int co_real, float* dw,
                              float* dbias, int accumulate, void* desc /*host*/, int* blocks, int* shm_bytes);
+/* ... for a conv with bias and without GroupNorm whose weight gradient came from rtp_wgrad_tg: dbias from the subset-sum
+ * partials tg [n][nsplit][27][32] (slot 0 = whole-volume sums of gy) -- no class-sum pass over gy (center_head.py:86-93 towers) */
+int rtp_tail_desc_wgrad_fold_tg(const float* gp, int nsplit, const float* tg, const RtpConvGeom* g, int ci_real, int co_real,
+                                float* dw, float* dbias, int accumulate, void* desc, int* blocks, int* shm_bytes);
 /* coeff: the buffer rtp_gn_bwd_coeffs(..., dgamma = NULL, dbeta = NULL, ...) wrote. */
 int rtp_tail_desc_gn_param(const float* coeff, int n, int c, float* dgamma, float* dbeta, int accumulate,
                            void* desc /*host*/, int* blocks, int* shm_bytes);

@@ -73,6 +73,7 @@ PROTOTYPES = {
     "rtp_wgrad": [_A, _A, _G, _I, _P, _P],
     "rtp_wgrad_nsplit": [_G],
     "rtp_wgrad_q": [_A, _A, _G, _I, _P, _P, _P, _P, _P],
+    "rtp_wgrad_tg": [_A, _A, _G, _I, _P, _P, _P],
     "rtp_zero_f32": [_P, _L, _P],
     "rtp_qpart_from_slabs": [_P, _I, _I, _I, _I, _I, _P, _P, _P],
     "rtp_gn_bwd_coeffs_cls": [_P, _I, _P, _I, _P, _P, _P, _P, _G, _I, _I, _I, _P, _P],
@@ -89,6 +90,7 @@ PROTOTYPES = {
     "rtp_tail_desc_bytes": [],
     "rtp_tail_desc_class_reduce": [_P, _I, _I, _I, _P, _P, C.POINTER(_I), C.POINTER(_I)],
     "rtp_tail_desc_wgrad_fold": [_P, _I, _P, _P, _P, _P, _I, _G, _I, _I, _P, _P, _I, _P, C.POINTER(_I), C.POINTER(_I)],
+    "rtp_tail_desc_wgrad_fold_tg": [_P, _I, _P, _G, _I, _I, _P, _P, _I, _P, C.POINTER(_I), C.POINTER(_I)],
     "rtp_tail_desc_gn_param": [_P, _I, _I, _P, _P, _I, _P, C.POINTER(_I), C.POINTER(_I)],
     "rtp_tail_desc_pack_wt": [_P, _I, _I, _I, _I, _P, _P, C.POINTER(_I), C.POINTER(_I)],
     "rtp_tail_desc_fold_fwd": [_P, _P, _P, _P, _P, _I, _I, _F, _G, _I, _I, _P, _P, _P, _P, _P, C.POINTER(_I), C.POINTER(_I)],

@@ -56,7 +56,17 @@ class HipBackend:
             import os
             # stream priority per side lane (0 = default, -1 = high); RTP_LANE_PRIORITIES="p1,p2,..." for experiments
             pr = [int(v) for v in os.environ.get("RTP_LANE_PRIORITIES", "").split(",") if v.strip() != ""]
-            self._lanes = [torch.cuda.Stream(self.device, priority=(pr[i] if i < len(pr) else 0)) for i in range(n - 1)]
+            # HIP deals streams onto GPU_MAX_HW_QUEUES (4) hardware queues in creation order, and which lanes share a queue decides
+            # how their kernels interleave with the main lane's persistent ones (measured: 4 queues 6.1 ms/step, 3: 6.4, 5+: 9.0).
+            # Experiment knobs: RTP_DUMMY_STREAMS=k creates k unused streams first (shifts the deal), RTP_LANE_ORDER="3,1,2,5,4"
+            # creates the side lanes' streams in that order.
+            self._dummies = [torch.cuda.Stream(self.device) for _ in range(int(os.environ.get("RTP_DUMMY_STREAMS", "0")))]
+            order = [int(v) for v in os.environ.get("RTP_LANE_ORDER", "").split(",") if v.strip() != ""] or list(range(1, n))
+            assert sorted(order) == list(range(1, n)), "RTP_LANE_ORDER must be a permutation of 1..%d" % (n - 1)
+            made = {}
+            for lane in order:
+                made[lane] = torch.cuda.Stream(self.device, priority=(pr[lane - 1] if lane - 1 < len(pr) else 0))
+            self._lanes = [made[i] for i in range(1, n)]
         streams = [cur] + self._lanes[:n - 1]
         return streams, [C.c_void_p(st.cuda_stream) for st in streams]
 
@@ -145,6 +155,13 @@ class HipBackend:
         args = (_act(gy), _act(x), g, nsplit, _ptr(gp))
         keep = (gy, x, gp)
         return lambda s: check(fn(*args, s), "rtp_wgrad") or keep and None
+
+    def wgrad_tg(self, gy, x, geom, nsplit, gp, tg):
+        """rtp_wgrad on the tiled kernel + the subset sums of gy (tg [n, nsplit, 27, 32]): bias gradients without a class-sum pass."""
+        fn, g = self.lib.rtp_wgrad_tg, _geom(geom)
+        args = (_act(gy), _act(x), g, nsplit, _ptr(gp), _ptr(tg))
+        keep = (gy, x, gp, tg)
+        return lambda s: check(fn(*args, s), "rtp_wgrad_tg") or keep and None
 
     def wgrad_nsplit(self, geom):
         return self.lib.rtp_wgrad_nsplit(_geom(geom))
@@ -254,8 +271,13 @@ class HipBackend:
             kind, a = it[0], it[1:]
             if kind == "class_reduce":
                 rc = lib.rtp_tail_desc_class_reduce(_ptr(a[0]), a[1], a[2], a[3], _ptr(a[4]), d, C.byref(blocks), C.byref(sb))
+            elif kind == "wgrad_fold" and len(a) == 14 and a[13] is not None:   # bias from the weight-gradient kernel's subset sums
+                gp, nsplit, csum, mr, gamma, beta, groups, geom, ci_real, co_real, dw, dbias, acc, tg = a
+                assert csum is None and mr is None
+                rc = lib.rtp_tail_desc_wgrad_fold_tg(_ptr(gp), nsplit, _ptr(tg), _geom(geom), ci_real, co_real, _ptr(dw), _ptr(dbias),
+                                                     int(acc), d, C.byref(blocks), C.byref(sb))
             elif kind == "wgrad_fold":
-                gp, nsplit, csum, mr, gamma, beta, groups, geom, ci_real, co_real, dw, dbias, acc = a
+                gp, nsplit, csum, mr, gamma, beta, groups, geom, ci_real, co_real, dw, dbias, acc = a[:13]
                 rc = lib.rtp_tail_desc_wgrad_fold(_ptr(gp), nsplit, _ptr(csum), _ptr(mr), _ptr(gamma), _ptr(beta), groups,
                                                   _geom(geom), ci_real, co_real, _ptr(dw), _ptr(dbias), int(acc), d,
                                                   C.byref(blocks), C.byref(sb))

@@ -1115,6 +1115,7 @@ extern "C" int rtp_class_sums_reduce(const float* scratch, int nsplit, int n, in
 struct WFoldParams {
   const float* gp; int nsplit; const float* csum; const float* mr; const float* gamma; const float* beta;
   int groups, n; FoldParams f; int co32, csum_c; float* dw; float* dbias; int accumulate;
+  const float* tg;   // optional (bias-only convs): subset-sum partials [n][nsplit][27][32] of gy from rtp_wgrad_tg; dbias = sum of slot 0
 };
 
 __host__ __device__ __forceinline__ int wfold_rows(int ci_pad) { return 256 / ci_pad; }  // rows a wave covers with one 1-KB read
@@ -1169,8 +1170,13 @@ __device__ __forceinline__ void wgrad_fold_body(const WFoldParams& p, int bid, f
     for (int r = wave; r < R; r += 4) {
       const int co = rg * R + r;
       float v = 0.f;
-      if (co < co_real)
-        for (int n = 0; n < p.n; ++n) v += p.csum[((long)n * 64 + lane) * p.csum_c + co];
+      if (co < co_real) {
+        if (p.tg) {   // whole-volume sums (slot 0) of every workgroup partial, lanes over (sample, partial)
+          for (int i = lane; i < p.n * p.nsplit; i += 64) v += p.tg[(long)i * 27 * 32 + co];
+        } else {
+          for (int n = 0; n < p.n; ++n) v += p.csum[((long)n * 64 + lane) * p.csum_c + co];
+        }
+      }
       v = wave_sum(v);
       if (lane == 0 && co < co_real) {
         if (p.accumulate) p.dbias[co] += v; else p.dbias[co] = v;
@@ -1230,6 +1236,7 @@ static int fill_wfold(WFoldParams& p, const float* gp, int nsplit, const float* 
   int rc = fill_fold(p.f, g, ci_real, co_real);
   if (rc) return rc;
   if (!gp || !dw || nsplit < 1) return RTP_ERR_SHAPE;
+  p.tg = nullptr;
   if ((mr || dbias) && !csum) return RTP_ERR_SHAPE;
   if (mr && (!gamma || !beta || groups < 1 || ci_real % groups)) return RTP_ERR_SHAPE;
   p.gp = gp; p.nsplit = nsplit; p.csum = csum; p.mr = mr; p.gamma = gamma; p.beta = beta;
@@ -1342,6 +1349,26 @@ extern "C" int rtp_tail_desc_wgrad_fold(const float* gp, int nsplit, const float
   d.kind = TAIL_WGRAD_FOLD;
   int rc = fill_wfold(d.u.wf, gp, nsplit, csum, mr, gamma, beta, groups, g, ci_real, co_real, dw, dbias, accumulate);
   if (rc) return rc;
+  d.blocks = wfold_blocks(d.u.wf);
+  memcpy(desc, &d, sizeof(d));
+  if (blocks) *blocks = d.blocks;
+  if (shm_bytes) *shm_bytes = (int)wfold_shm(d.u.wf);
+  return RTP_OK;
+}
+
+/* rtp_tail_desc_wgrad_fold for a conv with bias and WITHOUT GroupNorm whose weight gradient came from rtp_wgrad_tg: the bias
+ * gradient is read off the subset-sum partials tg [n][nsplit][27][32] (slot 0 = the whole volume) instead of class sums. */
+extern "C" int rtp_tail_desc_wgrad_fold_tg(const float* gp, int nsplit, const float* tg, const RtpConvGeom* g, int ci_real, int co_real,
+                                           float* dw, float* dbias, int accumulate, void* desc, int* blocks, int* shm_bytes) {
+  if (!desc || !tg || !dbias || !g) return RTP_ERR_SHAPE;
+  if ((g->co + 31) / 32 * 32 != 32) return RTP_ERR_UNSUPPORTED;
+  RtpTailDesc d;
+  memset(&d, 0, sizeof(d));
+  d.kind = TAIL_WGRAD_FOLD;
+  int rc = fill_wfold(d.u.wf, gp, nsplit, nullptr, nullptr, nullptr, nullptr, 1, g, ci_real, co_real, dw, nullptr, accumulate);
+  if (rc) return rc;
+  d.u.wf.dbias = dbias;
+  d.u.wf.tg = tg;
   d.blocks = wfold_blocks(d.u.wf);
   memcpy(desc, &d, sizeof(d));
   if (blocks) *blocks = d.blocks;

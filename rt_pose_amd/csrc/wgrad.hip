@@ -240,6 +240,18 @@ extern "C" int rtp_wgrad_q(const RtpAct* gy, const RtpAct* x, const RtpConvGeom*
   return rc > 0 ? RTP_ERR_UNSUPPORTED : rc;
 }
 
+// rtp_wgrad on the LDS-tiled kernel whose loader waves also sum gy over the volume and its faces / edges / corners (tg
+// [n][nsplit][27][32], see wgrad_tiled.hip): the bias gradient of a conv WITHOUT GroupNorm is the sum of slot 0 over the
+// partials (rtp_tail_desc_wgrad_fold_tg), so no class-sum pass reads gy a second time.  Tiled geometries with 32 channels only.
+extern "C" int rtp_wgrad_tg(const RtpAct* gy, const RtpAct* x, const RtpConvGeom* g, int nsplit, float* gp, float* tg, void* stream) {
+  if (!gy || !x || !g || !gp || !tg || nsplit < 1) return RTP_ERR_SHAPE;
+  if ((gy->cs % 8) || (gy->co % 8) || (x->cs % 8) || (x->co % 8)) return RTP_ERR_ALIGN;
+  if (gy->c < 32 || x->c < 32 || g->ci != 32 || (g->co + 31) / 32 * 32 != 32) return RTP_ERR_UNSUPPORTED;
+  if (rtp_wgrad_nsplit(g) != nsplit || g->stride != 1) return RTP_ERR_UNSUPPORTED;
+  const int rc = rtp_wgrad_tiled_try(gy, x, g, nsplit, gp, (hipStream_t)stream, nullptr, nullptr, tg);
+  return rc > 0 ? RTP_ERR_UNSUPPORTED : rc;
+}
+
 extern "C" int rtp_wgrad(const RtpAct* gy, const RtpAct* x, const RtpConvGeom* g, int nsplit, float* gp,
                          void* stream) {
   if (!gy || !x || !g || !gp || nsplit < 1) return RTP_ERR_SHAPE;

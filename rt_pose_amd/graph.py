@@ -161,6 +161,7 @@ class Graph:
         # their all-reduce runs beside the rest of the backward pass.  early_tail_index: position of that flush in self.bwd.
         self.early_flush = False
         self.early_tail_index = None
+        self.group = None          # (block, row) tag the ops created from now on carry (net.build_backbone: fuse rows)
         self.full_vox = None       # voxels of the first (full-resolution) activation: lanes are assigned by resolution
         # algorithmic FLOPs (2*MACs of real channels) per kernel family, per replay of the lists
         self.flops = {"conv_fwd": 0, "conv_dgrad": 0, "wgrad": 0, "conv_tiled": 0, "conv_generic": 0,
@@ -170,6 +171,42 @@ class Graph:
                           "conv_tiled_full_bwd": 0}
 
     # ------------------------------------------------------------------ helpers
+    def _add_op(self, op):
+        op.group = self.group
+        self.ops.append(op)
+
+    def sweep_order(self):
+        """Order in which build_backward processes the ops: reverse creation order, except that inside one fuse block
+        (HighResolutionModule.forward's rows, hr3d.py:205-229) the ROW GROUPS are taken lowest resolution first (row 2, row 1, row 0)
+        instead of row 0 first.  Every lane is a FIFO stream that executes its launches in list order: with row 0 first, the
+        level-1 lane queues row 0's up-sampling adjoint -- which waits for the main lane's newest gradient -- in FRONT of the
+        stride-2 data gradients of rows 1 and 2, whose inputs are long finished and whose outputs the main lane needs next
+        (head-of-line blocking at every stage boundary).  Rows of a block only meet at the branch outputs they all contribute
+        to, so any row order is a valid reverse-topological order.  RTP_ROW_ORDER=0 restores plain reverse creation order."""
+        rev = list(reversed(self.ops))
+        # (RTP_FUSED_S2, the A/B route where a row's stride-2 data gradient absorbs the fan-in of the branch-0 output, needs that
+        # conv to be the last contributor: plain reverse creation order)
+        if os.environ.get("RTP_ROW_ORDER", "1") == "0" or os.environ.get("RTP_FUSED_S2"):
+            return rev
+        out, i = [], 0
+        while i < len(rev):
+            gi = getattr(rev[i], "group", None)
+            if gi is None:
+                out.append(rev[i])
+                i += 1
+                continue
+            j, chunks = i, []
+            while j < len(rev) and getattr(rev[j], "group", None) is not None and rev[j].group[0] == gi[0]:
+                k = j
+                while k < len(rev) and getattr(rev[k], "group", None) == rev[j].group:
+                    k += 1
+                chunks.append(rev[j:k])
+                j = k
+            for ch in reversed(chunks):
+                out.extend(ch)
+            i = j
+        return out
+
     def act(self, *a, **k):
         t = Act(self, *a, **k)
         self.acts.append(t)
@@ -257,7 +294,7 @@ class Graph:
         y = self.act(name, w.shape[0], dims)
         op = StemOp(self, x_f32, y, wname, bname)
         y.producer = op
-        self.ops.append(op)
+        self._add_op(op)
         self.emit_fwd(self.be.stem_fwd(x_f32, w, b, y), self.lane_of(y), [x_f32], [y], "stem:" + name)
         return y
 
@@ -286,7 +323,7 @@ class Graph:
                 y = self.act(name, co_real, (do, ho, wo), c=co_pad, dtype="f32", relu=relu)
                 op = CoSplitConvOp(self, name, x, y, wname, bname, relu, co_real)
                 y.producer = op
-                self.ops.append(op)
+                self._add_op(op)
                 op.emit_forward()
                 return y
         if (gn is None and ks == 3 and stride == 1 and residual is None and not out_fp32 and ci_real > 32 and ci_real % 32 == 0
@@ -297,7 +334,7 @@ class Graph:
                 y = self.act(name, co_real, (do, ho, wo), c=co_real, relu=relu)
                 op = SplitConvOp(self, name, x, y, gs, wname, bname, relu, ci_real, co_real)
                 y.producer = op
-                self.ops.append(op)
+                self._add_op(op)
                 op.emit_forward()
                 return y
         geom = Geom(self.n, x.d, x.h, x.w, do, ho, wo, pad_to(ci_real, 32), co_pad, ks, stride, pad,
@@ -308,7 +345,7 @@ class Graph:
         op = ConvOp(self, name, x, y, geom, wname, bname, gn, relu, residual, out_fp32, ci_real, co_real)
         op.want_stats = want_stats
         y.producer = op
-        self.ops.append(op)
+        self._add_op(op)
         op.emit_forward()
         return y
 
@@ -328,7 +365,7 @@ class Graph:
         offs = [sum(reals[:k]) for k in range(len(xs))]
         op = SplitConvOp(self, name, x0, y, gs, wname, bname, relu, ci_total, co_real, sources=list(zip(xs, reals, offs)))
         y.producer = op
-        self.ops.append(op)
+        self._add_op(op)
         op.emit_forward()
         return y
 
@@ -338,7 +375,7 @@ class Graph:
         y = self.act(name, hi.c_real, hi.dims, c=hi.c, relu=relu)
         op = FuseOp(self, terms, y)
         y.producer = op
-        self.ops.append(op)
+        self._add_op(op)
         # a fuse row feeds GroupNorm convs of the next stage: it emits the statistics of what it stores (no chan_stats pass)
         S = self.be.fuse_stats_nsplit(y) if (want_stats and hasattr(self.be, "fuse_stats_nsplit")
                                             and not os.environ.get("RTP_NO_FUSE_STATS")) else 0
@@ -363,9 +400,13 @@ class Graph:
         y = self.act(name, x.c_real, x.dims, relu=True)
         op = DcnAdaptOp(self, name, x, off, y, prefix)
         y.producer = op
-        self.ops.append(op)
+        self._add_op(op)
         op.fwd_fn, op.make_bwd = self.be.dcn_adapt(x, off, off.c_real, w_ad, y)
-        self.emit_fwd(op.fwd_fn, self.lane_of(y), [x, off, w_ad], [y], "dcn:" + name)
+        # The two feature adaptions (heat-map / regression) are independent and their operator's kernels are ordinary grids, not
+        # chip-filling persistent ones: the regression one runs on the level-1 lane beside the heat-map one's (RTP_DCN_ONE_LANE=1:
+        # both on the main lane, A/B)
+        op.lane = L_MID if (name.endswith(".reg") and not os.environ.get("RTP_DCN_ONE_LANE")) else self.lane_of(y)
+        self.emit_fwd(op.fwd_fn, op.lane, [x, off, w_ad], [y], "dcn:" + name)
         return y
 
     def forward_list(self):
@@ -496,14 +537,15 @@ class Graph:
         # (all other contributions + GroupNorm backward + ReLU mask) and writes the finished gradient (ConvOp.emit_backward).
         self.first_consumer = {}
         self.fused_dgrad = not os.environ.get("RTP_NO_FUSED_DGRAD") and hasattr(self.be, "conv_dgrad_fused")
-        for op in self.ops:
+        order = self.sweep_order()
+        for op in order:   # ("first consumer" = the consumer the sweep reaches LAST: its contribution completes the tensor's gradient)
             for t in op.inputs():
-                self.first_consumer.setdefault(id(t), op)
+                self.first_consumer[id(t)] = op
         # (the move of the weight-gradient lane onto the main lane pays for the two 32-channel towers of hr3d; the wide heads of
         # the one-heat-map configs -- slice ops -- queue more work there than the waits absorb: 11.3 vs 11.5 ms/step, so not by default)
         if "RTP_DEFER_WG" not in os.environ and any(isinstance(op, (SplitConvOp, CoSplitConvOp)) for op in self.ops):
             self._defer_wg = []
-        for op in reversed(self.ops):
+        for op in order:
             if self.early_flush and self.early_tail_index is None and op.y.name.startswith(("l1.", "t1", "s2.")):
                 # (coefficients a later fan-in pass would have computed in its prologue are needed by the GroupNorm parameter
                 # sums of this flush: their launches are emitted now)
@@ -719,17 +761,31 @@ class ConvOp:
         # The weight-gradient chain (wgrad -> class sums -> un-fold) only feeds the optimiser, so it runs on its own
         # lane beside the rest of the backward sweep.
         wl = g.wg_lane_of(gy)
-        g.emit_bwd(be.wgrad(gy, x, ge, S, gp), wl, [gy, x], [gp], "wgrad:" + self.name)
+        # a conv with bias and without GroupNorm on the tiled weight-gradient kernel: its loader waves sum gy as a by-product (tg),
+        # the bias gradient is read off those sums in the tail -- no class-sum pass over gy (the head towers: 84 MB each)
+        tg = self._bias_tg(S) if self.tiled_wgrad else None
+        if tg is not None:
+            g.emit_bwd(be.wgrad_tg(gy, x, ge, S, gp, tg), wl, [gy, x], [gp, tg], "wgrad:" + self.name)
+        else:
+            g.emit_bwd(be.wgrad(gy, x, ge, S, gp), wl, [gy, x], [gp], "wgrad:" + self.name)
         g.flops["wgrad"] += self.alg_flops
         g.flops["wgrad_tiled" if self.tiled_wgrad else "wgrad_generic"] += self.alg_flops
         g.alg_bytes["wgrad_tiled" if self.tiled_wgrad else "wgrad_generic"] += 2 * g.n * (gy.vox * co32 + x.vox * ge.ci) + (
             4 * g.n * S * ge.ks ** 3 * co32 * ge.ci)
         # Everything after the correlation itself (class-sum reduction, slab fold + GroupNorm un-fold) only feeds the
         # optimiser: recorded here, run once for all layers at the end of the sweep (Graph.emit_tail).
-        csum = g.class_sums_for(self.y, gy, wl, self.name) if (self.gn or self.bname) else None
+        csum = g.class_sums_for(self.y, gy, wl, self.name) if ((self.gn or self.bname) and tg is None) else None
         g.tail_b.append(("wgrad_fold", gp, S, csum, self.mr, g.params[self.gn[0]] if self.gn else None,
                          g.params[self.gn[1]] if self.gn else None, self.groups, ge, self.ci_real,
-                         self.co_real, g.pgrad[self.wname], g.pgrad[self.bname] if self.bname else None, 0))
+                         self.co_real, g.pgrad[self.wname], g.pgrad[self.bname] if self.bname else None, 0, tg))
+
+    def _bias_tg(self, S):
+        """Subset-sum buffer for rtp_wgrad_tg when this conv qualifies (bias, no GroupNorm, 32 -> <= 32 channels, stride 1, tiled)."""
+        g, be, ge = self.g, self.g.be, self.geom
+        if (self.gn or not self.bname or not hasattr(be, "wgrad_tg") or ge.ci != 32 or pad_to(ge.co, 32) != 32 or ge.stride != 1
+                or ge.ks != 3 or self.x.cs != 32 or self.x.co != 0 or os.environ.get("RTP_NO_BIAS_TG")):
+            return None
+        return be.alloc((g.n, S, 27, 32), "f32")
 
 
     # ------------------------------------------------------------------ fused backward (no fan-in pass)
@@ -779,12 +835,13 @@ class ConvOp:
             csum = be.alloc((g.n, 64, gy.c), "f32")
         elif self.gn and not own_kernel and hasattr(be, "class_sums_p"):
             csum, pbuf = g.class_sums_and_p(self.y, gy, wl, self.name, self.wd, ge, self.ci_real, self.co_real)
-        elif self.gn or self.bname:
-            csum = g.class_sums_for(self.y, gy, wl, self.name, early=bool(self.gn))
-        # ---- weight gradient (for a GroupNorm conv it now precedes the data gradient: its slabs give Q)
         S = be.wgrad_nsplit(ge) if x.cs == 32 and x.co == 0 else 0
         self.tiled_wgrad = S > 0
         S = S or wgrad_split(gy.vox)
+        btg = self._bias_tg(S) if (self.tiled_wgrad and not self.gn and ge.stride == 1) else None
+        if csum is None and pbuf is None and tg is None and (self.gn or self.bname) and btg is None:
+            csum = g.class_sums_for(self.y, gy, wl, self.name, early=bool(self.gn))
+        # ---- weight gradient (for a GroupNorm conv it now precedes the data gradient: its slabs give Q)
         gp = be.alloc((g.n, S, ntap, co32, ge.ci), "f32")
         coeff = gnq = None
         if self.gn and ge.stride == 2:
@@ -815,6 +872,8 @@ class ConvOp:
                 gnq = dict(qpart=qpart, q_nsplit=S, p=pbuf, tg=tg, csum_out=csum if tg is not None else None, mr=self.mr,
                            gamma=g.params[self.gn[0]], groups=self.groups, coeff_out=coeff)
             g.tail_a.append(("gn_param", coeff, g.n, self.ci_real, g.pgrad[self.gn[0]], g.pgrad[self.gn[1]], 0))
+        elif btg is not None:
+            g.emit_bwd(be.wgrad_tg(gy, x, ge, S, gp, btg), wl, [gy, x], [gp, btg], "wgrad:" + self.name)
         else:
             g.emit_bwd(be.wgrad(gy, x, ge, S, gp), wl, [gy, x], [gp], "wgrad:" + self.name)
         g.flops["wgrad"] += self.alg_flops
@@ -823,7 +882,7 @@ class ConvOp:
             4 * g.n * S * ntap * co32 * ge.ci)
         g.tail_b.append(("wgrad_fold", gp, S, csum, self.mr, g.params[self.gn[0]] if self.gn else None,
                          g.params[self.gn[1]] if self.gn else None, self.groups, ge, self.ci_real,
-                         self.co_real, g.pgrad[self.wname], g.pgrad[self.bname] if self.bname else None, 0))
+                         self.co_real, g.pgrad[self.wname], g.pgrad[self.bname] if self.bname else None, 0, btg))
         # ---- data gradient -> finished gradient of x
         terms = [(v, cf.materialise() if isinstance(cf, LazyCoeff) else cf) for v, cf in x.contribs]
         dx_buf = be.alloc((g.n, x.d, x.h, x.w, ge.ci), "bf16")
@@ -1080,7 +1139,8 @@ class DcnAdaptOp:
         go_buf = g.be.alloc((g.n, x.d, x.h, x.w, oc), "bf16")
         go = View(go_buf, g.n, x.d, x.h, x.w, oc, 0, oc)
         gw = g.pgrad[self.prefix + ".conv_adaption.weight"]
-        g.emit_bwd(self.make_bwd(gy, gx, go, gw), g.lane_of(self.y), [gy, x, off], [gx_buf, go_buf, gw], "dcn_bwd:" + self.name)
+        g.emit_bwd(self.make_bwd(gy, gx, go, gw), getattr(self, "lane", g.lane_of(self.y)), [gy, x, off], [gx_buf, go_buf, gw],
+                   "dcn_bwd:" + self.name)
         if x.needs_grad:
             x.contribs.append((gx, None))
         off.contribs.append((go, None))

@@ -66,6 +66,7 @@ def build_backbone(g: Graph, x_f32, arch, dims, prefix="backbone.backbone", live
         # other gradient contributions to that full-resolution tensor (graph.ConvOp._fusable)
         ys = [None] * rows
         for i in reversed(range(rows)):
+            g.group = ("fuse%d" % stage, i)   # (graph.Graph.build_backward may sweep a fuse block's rows in another order)
             terms = []
             for j in range(nb):
                 if j == i:
@@ -80,6 +81,7 @@ def build_backbone(g: Graph, x_f32, arch, dims, prefix="backbone.backbone", live
                                  relu=(k != i - j - 1), want_stats=(k != i - j - 1))
                     terms.append(t)
             ys[i] = g.fuse("s%d.row%d" % (stage, i), terms, relu=True, want_stats=stage < 4)   # (stage-4 rows feed no GroupNorm)
+        g.group = None
     return ys
 
 

@@ -293,7 +293,7 @@ class EmuBackend:
             if kind == "class_reduce":
                 fns.append(self.class_sums_reduce(*a))
             elif kind == "wgrad_fold":
-                fns.append(self.wgrad_fold(*a))
+                fns.append(self.wgrad_fold(*a[:13]))   # (a[13]: the HIP backend's subset-sum route for bias gradients, never set here)
             elif kind == "gn_param":
                 fns.append(self.gn_bwd_param(*a))
             elif kind == "fold_fwd":

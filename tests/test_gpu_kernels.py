@@ -1079,3 +1079,31 @@ def test_stride2_forward_on_the_tiled_kernel(hip, case):
     run(hip, EMU.conv(xc, wf.c, per_sample, bt.c, rc, y32c, geom, relu, False, True),
         hip.conv(xg, wf.g, per_sample, bt.g, rg, y32g, geom, relu, False, True, **kw))
     check(y32p, F32 * 5, "stride-2 forward, fp32 output %r" % (case,))
+
+
+def test_bias_gradient_from_weight_gradient_subset_sums(hip):
+    """rtp_wgrad_tg + rtp_tail_desc_wgrad_fold_tg (bias gradient of a conv without GroupNorm read off the weight-gradient kernel's
+    sums of gy) against the class-sum route (rtp_class_sums + rtp_tail_desc_wgrad_fold) and against plain sums of gy."""
+    n, d, h, w, co_real = 3, 4, 8, 48, 15
+    geom = Geom(n, d, h, w, d, h, w, 32, 16, 3, 1, 1)
+    gt = rnd((n, d, h, w, 32), 601)
+    gt[..., co_real:] = 0
+    _, gc, gg = views(hip, gt, n, d, h, w)
+    _, xc, xg = views(hip, rnd((n, d, h, w, 32), 602, relu=True), n, d, h, w)
+    S = hip.wgrad_nsplit(geom)
+    assert S > 0
+    gp1, gp2 = hip.alloc((n, S, 27, 32, 32), "f32"), hip.alloc((n, S, 27, 32, 32), "f32")
+    tg = hip.alloc((n, S, 27, 32), "f32")
+    dw1, dw2 = hip.alloc((co_real, 32, 3, 3, 3), "f32"), hip.alloc((co_real, 32, 3, 3, 3), "f32")
+    db1, db2 = hip.alloc((co_real,), "f32"), hip.alloc((co_real,), "f32")
+    s = hip.stream()
+    hip.wgrad_tg(gg, xg, geom, S, gp1, tg)(s)
+    hip.tail([("wgrad_fold", gp1, S, None, None, None, None, 1, geom, 32, co_real, dw1, db1, 0, tg)])(s)
+    cs = hip.alloc((n, 64, 32), "f32")
+    hip.wgrad(gg, xg, geom, S, gp2)(s)
+    hip.class_sums(gg, 3, hip.alloc((n, 3, 64, 32), "f32"), cs)(s)
+    hip.tail([("wgrad_fold", gp2, S, cs, None, None, None, 1, geom, 32, co_real, dw2, db2, 0, None)])(s)
+    torch.cuda.synchronize()
+    assert torch.equal(gp1, gp2) and torch.equal(dw1, dw2)
+    want = gt.float().reshape(-1, 32)[:, :co_real].sum(0)
+    assert rel_err(db1.cpu(), want) < F32 * 5 and rel_err(db2.cpu(), want) < F32 * 5

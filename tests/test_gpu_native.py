@@ -34,23 +34,24 @@ NATIVE = configs.NATIVE_DIMS
 # (tests/emu_backend.py: same rounding points as the kernels, fp32 CPU arithmetic in between -- differs from the HIP path
 # only by summation order and the ReLU / L1-sign decisions that a last-bit difference flips).
 #   hr3d: measured worst tensor 0.094 / 0.067 (transition1 / layer1.conv2, round 2).
-#   hr3d_one_hm_doppler: the regression target is 45 offsets in U(-8, 8) under an L1 loss at ONE voxel per frame, so
-#   the gradient signal is a sum of +-1 signs; a sign decided differently in bf16 is a discontinuity no precision removes.
-#   The emulated plan itself (no HIP code involved) sits 0.20-0.27 from fp32 autograd on layer1 / stage2 tensors
-#   (measured on CPU at B=2), so the oracle gate is loose here and the emulated-plan gate is the sharp one.
-#   "<name>+far": the same configuration with the 45 regression targets moved AWAY from the predictions (|pred - target| >= 1 at
-#   the supervised voxel, computed from the oracle's own forward): no L1 sign can flip under bf16 rounding, so the HIP backward of
-#   the 45-channel regression tower and everything below it is gated as tightly as hr3d's (round-2 review, item 6).
+#   hr3d_one_hm_doppler (and the other one-heat-map configurations): ONE supervised voxel per frame (1 heat-map class + 45 L1
+#   offsets there), so the whole gradient field grows out of 8 voxels per batch: no averaging over voxels, a ReLU decided
+#   differently near one of them moves a layer-1 tensor by percents.  Measured at B = 8 (round 3): worst tensor 0.28 vs the
+#   oracle, 0.195 vs the emulated plan (layer1 / stage2 GroupNorm weights), median 0.022 / 0.016, global cosine 0.9999.
+#   Round 2 blamed L1 sign flips at ties; the "+far" variant refutes that: with every regression target moved >= 1.0 away from
+#   the oracle's own prediction (far_targets: no sign can flip) the same tensors are off by the same amounts (0.283 / 0.193).
+#   What "+far" does gate tightly is the regression tower and the head itself (HEAD_REL): the tensors next to the loss.
 GATES = {"hr3d": {"oracle": (0.13, 0.991), "emu": (0.10, 0.994)},
-         "hr3d_one_hm": {"oracle": (0.40, 0.93), "emu": (0.20, 0.98)},
-         "hr3d_one_hm_doppler": {"oracle": (0.40, 0.93), "emu": (0.20, 0.98)},
-         "hr3d_one_hm_doppler+far": {"oracle": (0.13, 0.991), "emu": (0.10, 0.994)},
-         "hr3d_one_hm_doppler_phase": {"oracle": (0.40, 0.93), "emu": (0.20, 0.98)},
-         "hr3d_one_hm_doppler_phase+far": {"oracle": (0.13, 0.991), "emu": (0.10, 0.994)}}
+         "hr3d_one_hm": {"oracle": (0.18, 0.985), "emu": (0.13, 0.99)},          # measured 0.135 / 0.097 (Cin = 1: dense radar input)
+         "hr3d_one_hm_doppler": {"oracle": (0.35, 0.94), "emu": (0.25, 0.97)},   # measured 0.283 / 0.195
+         "hr3d_one_hm_doppler+far": {"oracle": (0.35, 0.94), "emu": (0.25, 0.97)},
+         "hr3d_one_hm_doppler_phase": {"oracle": (0.35, 0.94), "emu": (0.25, 0.97)},   # measured 0.260 at B = 2
+         "hr3d_one_hm_doppler_phase+far": {"oracle": (0.35, 0.94), "emu": (0.25, 0.97)}}
+HEAD_REL = 0.10   # "+far": every pose_head.* tensor within 10 % of the oracle's fp32 autograd
 GATE_ABS = 2e-3   # of the model's largest per-tensor gradient norm (tensors whose own norm is tiny)
-MEDIAN_REL = {"hr3d": (0.04, 0.04), "hr3d_one_hm": (0.08, 0.06), "hr3d_one_hm_doppler": (0.08, 0.06), "hr3d_one_hm_doppler+far": (0.04, 0.04),
-              "hr3d_one_hm_doppler_phase": (0.08, 0.06), "hr3d_one_hm_doppler_phase+far": (0.04, 0.04)}
-COSINES = {"hr3d": (0.997, 0.995), "hr3d_one_hm_doppler+far": (0.997, 0.995), "hr3d_one_hm_doppler_phase+far": (0.997, 0.995)}   # (emu, oracle); others (0.985, 0.96)
+MEDIAN_REL = {"hr3d": (0.04, 0.04), "hr3d_one_hm": (0.08, 0.06), "hr3d_one_hm_doppler": (0.08, 0.06), "hr3d_one_hm_doppler+far": (0.08, 0.06),
+              "hr3d_one_hm_doppler_phase": (0.08, 0.06), "hr3d_one_hm_doppler_phase+far": (0.08, 0.06)}
+COSINES = {"hr3d": (0.997, 0.995)}   # global cosine (emu, oracle); the one-heat-map configurations: (0.985, 0.96)
 
 
 @pytest.fixture(scope="module")
@@ -275,6 +276,10 @@ def test_native_b8_train_step_per_tensor(hip, name, b, far):
     print("median rel: oracle %.4f emu %.4f; global cosine: oracle %.5f emu %.5f; norm ratio %.4f"
           % (med_o, med_e, cos(gh, gr), cos(gh, ge), float(gh.norm() / gr.norm())))
     assert not (bad_o + bad_e), "tensors outside the per-tensor gates:\n" + "\n".join(bad_o + bad_e)
+    if far:   # the regression tower and the rest of the head: next to the loss, no sign flips possible -> a tight gate
+        rows = tensor_report(got, {k: sdr[k].grad for k in live}, [k for k in live if k.startswith("pose_head.")])
+        print("head tensors vs oracle (worst 3):\n" + "\n".join("   %-50s rel=%.4f cos=%.5f" % (r[0], r[3], r[4]) for r in rows[:3]))
+        assert rows and rows[0][3] <= HEAD_REL, rows[0]
     assert med_o < MEDIAN_REL[name][0] and med_e < MEDIAN_REL[name][1], (med_o, med_e)
     ce, co = COSINES.get(name, (0.985, 0.96))
     assert cos(gh, ge) > ce and cos(gh, gr) > co
