@@ -21,6 +21,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "4")   # (rt_pose_amd/__init__.py: the lane plan's measured optimum, HIP's default)
 
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA, MI355X_MICROARCH.md chip table
 PEAK_HBM_GBPS = 8000.0     # HBM3E peak (same guide; ~6.3 TB/s achievable)

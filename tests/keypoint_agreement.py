@@ -139,6 +139,8 @@ def run(steps=300, batch=8, eval_batches=2, seed=0, dims=configs.NATIVE_DIMS, na
         "loss_history": [[i, round(l, 4)] for i, l in hist],
         "frames": int(agree.shape[0]), "joints": int(agree.size),
         "argmax_agreement": round(float(agree.mean()), 4),
+        "root_argmax_disagreements": int((~agree[:, 0]).sum()),   # frames whose ROOT joint (pelvis) decodes to another voxel: MPJPE is
+                                                                  # root-relative, so each of them shifts all 14 other joints of its frame
         "argmax_max_voxel_distance": int(vox_d.max()),
         "argmax_within_1_voxel": round(float((vox_d <= 1).mean()), 4),
         "keypoint_shift_cm": {"mean": round(float(shifts.mean()) * 100, 4), "p95": round(float(np.percentile(shifts, 95)) * 100, 4),
@@ -167,6 +169,7 @@ def main():
         wm = lambda f: float((np.array([f(r) for r in runs]) * w).sum() / w.sum())
         res.update({
             "seeds": len(runs), "frames": int(w.sum()), "joints": int(sum(r["joints"] for r in runs)),
+            "root_argmax_disagreements": int(sum(r.get("root_argmax_disagreements", 0) for r in runs)),
             "argmax_agreement": round(wm(lambda r: r["argmax_agreement"]), 4),
             "argmax_within_1_voxel": round(wm(lambda r: r["argmax_within_1_voxel"]), 4),
             "argmax_max_voxel_distance": max(r["argmax_max_voxel_distance"] for r in runs),
