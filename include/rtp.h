@@ -464,6 +464,14 @@ int rtp_deform_conv_backward_parameters(const float* input, const float* offset,
                                         float* gradWeight, void* ws, int n, int c, int h, int w, int co, int kW, int kH,
                                         int dW, int dH, int padW, int padH, int dilW, int dilH, int group,
                                         int deformable_group, float scale, int im2col_step, void* stream);
+/* Both halves of DeformConvFunction.backward (det3d/ops/dcn/deform_conv.py:62-98: deform_conv_backward_input_cuda, then
+ * deform_conv_backward_parameters_cuda on the same tensors) in one call.  For the DCN head's geometry (3x3, stride 1, pad 1,
+ * 32 channels in 4 deformable groups, <= 32 output channels) one kernel produces all three gradients without a column matrix;
+ * any other geometry runs the two entry points above one after the other.  Same accumulate-into-outputs contract. */
+int rtp_deform_conv_backward(const float* input, const float* offset, const float* gradOutput, float* gradInput,
+                             float* gradOffset, const float* weight, float* gradWeight, void* ws, int n, int c, int h,
+                             int w, int co, int kW, int kH, int dW, int dH, int padW, int padH, int dilW, int dilH,
+                             int group, int deformable_group, float scale, int im2col_step, void* stream);
 int rtp_modulated_deform_conv_forward(const float* input, const float* weight, const float* bias, const float* offset,
                                       const float* mask, float* output, void* ws, int n, int c, int h, int w, int co,
                                       int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw, int group,

@@ -570,6 +570,7 @@ static void sgemm(hipStream_t s, MatView A, MatView B, MatView C, int M, int N, 
 // (cog <= 64 output channels, cg * K = 288 column rows): HBM-bound (755 MB of columns written / read), which the
 // 64x64x16 VALU tile kernel above does not reach (0.87 ms each).  Both run on v_mfma_f32_32x32x2_f32 (exact fp32).
 typedef float dcn_f32x16 __attribute__((ext_vector_type(16)));
+typedef float dcn_f32x4 __attribute__((ext_vector_type(4)));
 
 // columns[r][n] = sum_co W[co][r] * gO[b0 + n / P][co][n % P]      (r < ck = cg * K, n < step * P)
 // A = W^T from LDS ([co][r], one ds_read_b32 per MFMA), B = gO straight from global memory (a half-wave reads 32
@@ -1419,11 +1420,18 @@ static int dcn_forward(const float* input, const float* weight, const float* bia
   return RTP_OK;
 }
 
+static bool dcn_bwd_fused_ok(const DcnGeom& g, int step);
+static int dcn_backward_fused(const float* input, const float* offset, const float* gradOutput, float* gradInput,
+                              float* gradOffset, const float* weight, float* gradWeight, float* ws, DcnGeom g, float scale,
+                              hipStream_t s);
+
 static int dcn_backward_input(const float* input, const float* offset, const float* mask, const float* gradOutput,
                               float* gradInput, float* gradOffset, float* gradMask, const float* weight, float* ws,
                               DcnGeom g, int step, hipStream_t s) {
   const int P = g.ho * g.wo, K = g.kh * g.kw;
   const int cg = g.c / g.group, cog = g.co / g.group;
+  if (!mask && !gradMask && dcn_bwd_fused_ok(g, step))   // one pass, no column gradient in HBM
+    return dcn_backward_fused(input, offset, gradOutput, gradInput, gradOffset, weight, nullptr, ws, g, 1.f, s);
   RtpProfScope prof(RTP_FAM_DCN, s);
   for (int b0 = 0; b0 < g.n; b0 += step) {
     for (int gi = 0; gi < g.group; ++gi) {
@@ -1474,11 +1482,582 @@ static int dcn_backward_input(const float* input, const float* offset, const flo
   return RTP_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// Weight gradient WITHOUT the column matrix (round 3): gradW[co][c*K + t] += scale * sum_p gO[co][p] * col[c*K + t][p], with the
+// deformable samples produced on chip.  The contraction runs over POSITIONS, but a coalesced gather has its lanes on positions
+// (64 consecutive output pixels of one channel plane hit two or three cache lines; lanes on (channel, tap) columns hit 64), so a
+// wave -- one deformable group of 8 channels -- gathers its 72 columns x 64 positions the im2col way (sample set-up once per
+// (position, tap), corner pairs as 8-byte buffer loads) into a wave-private LDS tile [72][64 + 4] and reads it back TRANSPOSED as
+// the B operand of v_mfma_f32_32x32x2_f32 (lane = column, four consecutive positions per ds_read_b128; the row pad of 4 floats
+// makes the 16 rows of a lane group hit 16 different 4-bank groups).  A = gO rows straight from global memory, lane-half h taking
+// positions 32h .. 32h + 31 of its row as eight 16-byte loads (the summation order over positions is free).  3 column tiles x 16
+// accumulator registers per wave, kept across all of the wave's tiles, added to gradW with fp32 atomics at the end (as
+// dcn_gradw_mfma_kernel does).  No 755-MB columns write + read per 64-image chunk: im2col 0.45 + GEMM 0.38 ms -> one launch.
+// Geometry: one group, 8 channels per deformable group, 3 x 3 taps, <= 32 output channels, Ho * Wo a multiple of 64.
+#define DCN_GF_ROW 68   // floats per LDS row: 64 positions + 4 pad
+__global__ __launch_bounds__(256, 2) void dcn_gradw_fused_kernel(const float* x, const float* offset, const float* mask, const float* go,
+                                                                 float* gw, DcnGeom g, float scale, int tiles_per_block) {
+  extern __shared__ __attribute__((aligned(16))) float gf_lds[];
+  const int lane = threadIdx.x & 63, dgi = threadIdx.x >> 6;   // wave = deformable group (g.dg == 4 waves)
+  const int half = lane >> 5, l32 = lane & 31;
+  float* colL = gf_lds + dgi * (72 * DCN_GF_ROW);
+  const int P = g.ho * g.wo, K = 9, HW = g.h * g.w;
+  const long tiles = (long)g.n * (P / 64);
+  dcn_f32x16 acc[3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  const long t0 = (long)blockIdx.x * tiles_per_block;
+  for (long tile = t0; tile < t0 + tiles_per_block && tile < tiles; ++tile) {
+    const int b = (int)(tile / (P / 64)), p0 = (int)(tile - (long)b * (P / 64)) * 64;
+    // ---- gather: lane = position p0 + lane, this wave's group: 9 taps x 8 channels -> colL[cc * 9 + t][lane]
+    {
+      const int p = p0 + lane;
+      const int wo = p % g.wo, ho = p / g.wo;
+      const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(x + (long)b * g.c * HW), 0, g.c * HW * 4, 0x00020000);
+      const float* off = offset + ((long)b * g.dg + dgi) * 2 * K * P + p;
+      const float* mk = mask ? mask + ((long)b * g.dg + dgi) * K * P + p : nullptr;
+      const int h_in = ho * g.sh - g.ph, w_in = wo * g.sw - g.pw;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int i = t / 3, j = t - i * 3;
+        const float hi = h_in + i * g.dh + off[(long)(2 * t) * P];
+        const float wi = w_in + j * g.dw + off[(long)(2 * t + 1) * P];
+        const float m = mk ? mk[(long)t * P] : 1.f;
+        const bool in = hi > -1.f && wi > -1.f && hi < g.h && wi < g.w;
+        const float hf = floorf(hi), wf = floorf(wi);
+        const int h_low = (int)hf, w_low = (int)wf;
+        const float lh = hi - hf, lw = wi - wf, hh = 1.f - lh, hw = 1.f - lw;
+        const bool c0 = w_low >= 0, c1 = w_low + 1 <= g.w - 1;
+        const float w1 = c0 ? hh * hw : 0.f, w2 = c1 ? hh * lw : 0.f, w3 = c0 ? lh * hw : 0.f, w4 = c1 ? lh * lw : 0.f;
+        const int xs = w_low < 0 ? 0 : (c1 ? w_low : g.w - 2);
+        const int base = (h_low * g.w + xs) * 4;
+        const int a0 = (in && h_low >= 0) ? base : DCN_OOB;
+        const int a1 = (in && h_low + 1 <= g.h - 1) ? base + g.w * 4 : DCN_OOB;
+#pragma unroll
+        for (int cc = 0; cc < 8; ++cc) {
+          const int coff = (dgi * 8 + cc) * HW * 4;
+          const dcn_u32x2 q0 = __builtin_amdgcn_raw_buffer_load_b64(rx, a0 + coff, 0, 0);
+          const dcn_u32x2 q1 = __builtin_amdgcn_raw_buffer_load_b64(rx, a1 + coff, 0, 0);
+          const float v1 = __uint_as_float(c1 ? q0.x : q0.y), v2 = __uint_as_float(c0 ? q0.y : q0.x);
+          const float v3 = __uint_as_float(c1 ? q1.x : q1.y), v4 = __uint_as_float(c0 ? q1.y : q1.x);
+          float v = w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4;
+          if (mk) v *= m;
+          colL[(cc * 9 + t) * DCN_GF_ROW + lane] = v;
+        }
+      }
+    }
+    // ---- gO rows (A operand): lane (co = l32, half) holds positions 32 half .. 32 half + 31 of its row
+    float4 a4[8];
+    {
+      const float* src = go + ((long)b * g.co + l32) * P + p0 + 32 * half;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a4[j] = l32 < g.co ? *(const float4*)(src + 4 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    // (the tile is this wave's own: the LDS pipe keeps a wave's writes and reads in order, no barrier)
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      const int row = t * 32 + l32;
+      const float* src = colL + (row < 72 ? row : 0) * DCN_GF_ROW + 32 * half;
+      float4 b4[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        b4[j] = *(const float4*)(src + 4 * j);
+        if (row >= 72) b4[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j].x, b4[j].x, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j].y, b4[j].y, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j].z, b4[j].z, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j].w, b4[j].w, acc[t], 0, 0, 0);
+      }
+    }
+  }
+  // D[m = co][n = column]: lane l, register i -> n = l % 32, m = 8 * (i / 4) + 4 * (l / 32) + i % 4; column -> gradW column
+  // (dgi * 8 + cc) * 9 + t = dgi * 72 + (cc * 9 + t)
+  const int ck_total = g.c * K;
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    const int r = t * 32 + l32;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int co = 8 * (i >> 2) + 4 * half + (i & 3);
+      if (co < g.co && r < 72) atomicAdd(gw + (long)co * ck_total + dgi * 72 + r, scale * acc[t][i]);
+    }
+  }
+}
+
+static bool dcn_gradw_fused_ok(const DcnGeom& g) {
+  const char* e = getenv("RTP_DCN_NO_FUSED_GRADW");
+  if (e && atoi(e)) return false;
+  return g.group == 1 && g.dg == 4 && g.c == 32 && g.kh == 3 && g.kw == 3 && g.co <= 32 && (g.ho * g.wo) % 64 == 0 && g.w >= 2;
+}
+
+static void dcn_gradw_fused_launch(const float* input, const float* offset, const float* mask, const float* gradOutput,
+                                   float* gradWeight, const DcnGeom& g, float scale, hipStream_t s) {
+  const long tiles = (long)g.n * (g.ho * g.wo / 64);
+  int tpb = (int)((tiles + 511) / 512);   // two 4-wave blocks per CU
+  if (tpb < 1) tpb = 1;
+  const size_t lds = sizeof(float) * 4 * 72 * DCN_GF_ROW;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)dcn_gradw_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr = true;
+  }
+  hipLaunchKernelGGL(dcn_gradw_fused_kernel, dim3((unsigned)((tiles + tpb - 1) / tpb)), dim3(256), lds, s, input, offset, mask,
+                     gradOutput, gradWeight, g, scale, tpb);
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// The WHOLE backward in one pass over the output rows (round 3): column gradient, coordinate gradient, input gradient and
+// (WITH_GW) weight gradient without any column matrix in HBM.  3 x 3 taps, stride 1, dilation 1, padding 1 (Ho = H, Wo = W),
+// 8 channels per deformable group, <= 32 output channels, no mask.
+//
+// A wave owns one deformable group of a strip of 64 consecutive output columns of one image and marches down its rows; lane =
+// column.  Per row:
+//   (1) column gradient G[(c, tap)][column] = W^T . gO for the wave's 72 column rows x 64 positions on v_mfma_f32_32x32x2_f32
+//       (A = the group's weights, held in registers for the whole march; B = gO of the row, lane = position) -> wave-private LDS
+//       tile [72][64 + 4], so that each lane reads its own position's values back;
+//   (2) per tap: the sample is set up once (as dcn_im2col_group_kernel does) and each of the 8 channels gathers its corner pairs
+//       ONCE for three consumers: the column value (written over G in the same LDS slot: the B operand of the weight gradient),
+//       the coordinate gradient (bottom - top and right - left differences of the same corners) and -- no gather, no atomics --
+//   (3) the INPUT gradient: a sample whose offsets lie in [-2, 2) lands in a 5 x 5 neighbourhood of its undeformed tap position,
+//       so its four bilinear weights are two separable 5-vectors (two non-zeros each) and the scatter becomes 25 FMAs into a
+//       STATICALLY indexed register patch; the three taps of a tap row share a 5 x 7 patch, which is reduced across lanes with six
+//       DPP wave shifts per row (lane x receives what lanes x-6 .. x contributed to output column x0 + x - 3) and added to a ring of
+//       7 output-row accumulators per channel; the ring's oldest row is complete after every position row and is stored (each
+//       grad_input element is written by exactly one wave: bit-reproducible).  Strips advance by 56 columns (7 lanes of overlap
+//       recompute the neighbours' column gradients, nothing else); row segments carry 3 halo rows either side for the same reason;
+//   (4) weight gradient: LDS tile read back transposed (lane = column row), A = gO rows as 16-byte loads, accumulators kept for
+//       the whole march, fp32 atomics at the end.
+// Samples with an offset component outside [-2, 2) -- rare at any sane offset scale -- are left to dcn_bwd_outlier_rows_kernel:
+// the wave appends (image, group, row, strip) to a list in the workspace, and that kernel recomputes the few column gradients
+// it needs (32 MACs per channel) and scatters them with global atomics after this kernel has finished.  Replaces, per 64-image
+// chunk at [.,32,64,160]: colgrad 0.23 + coord 0.45 + gather 0.78 + outliers 0.09 + im2col 0.45 + weight GEMM 0.38 ms and
+// 3 x 755 MB of column traffic.
+#define DCN_FB_ROW 68   // floats per LDS row
+#define DCN_FB_XO 56    // output columns / owned positions per strip
+__device__ __forceinline__ float dcn_wave_shr1(float v) {   // lane x <- lane x - 1, lane 0 <- 0
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true));
+}
+
+template <bool WITH_GW, int OCC>   // OCC: waves per SIMD the register budget is set for (2: 256 registers, 1: 512)
+__global__ __launch_bounds__(256, OCC) void dcn_bwd_fused_kernel(const float* __restrict__ x, const float* __restrict__ offset,
+                                                               const float* __restrict__ go, const float* __restrict__ w,
+                                                               float* gin, float* goff, float* gw, unsigned* rec, DcnGeom g,
+                                                               float scale, int strips, int segs, int seg_rows) {
+  extern __shared__ __attribute__((aligned(16))) float fb_lds[];
+  const int lane = threadIdx.x & 63, half = lane >> 5, l32 = lane & 31;
+  const int dgi = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: the buffer resources below depend on it
+  float* T = fb_lds + dgi * (72 * DCN_FB_ROW);
+  const int H = g.h, W = g.w, HW = H * W;
+  int bid = blockIdx.x;
+  const int k = bid % strips; bid /= strips;
+  const int sg = bid % segs;
+  const int b = bid / segs;
+  const int x0 = DCN_FB_XO * k - 4;
+  const int wo = x0 + lane;
+  const bool pos_x = wo >= 0 && wo < W;
+  const bool own_x = lane >= 4 && lane < 4 + DCN_FB_XO && wo < W;
+  const int oc = wo - 3;
+  const bool st_x = lane >= 7 && lane < 7 + DCN_FB_XO && oc < W;
+  const int r0 = sg * seg_rows, r1 = min(H, r0 + seg_rows);
+  const int hs = max(r0 - 3, 0), he = min(r1 + 3, H);
+  // every global stream goes through a buffer resource with 32-bit offsets (per-lane part + uniform part): 64-bit pointers per
+  // stream would cost two registers each for ~80 streams; a lane that must not load / store passes an out-of-range offset
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(x + (long)b * g.c * HW), 0, g.c * HW * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rgo = __builtin_amdgcn_make_buffer_rsrc((void*)(go + (long)b * g.co * HW), 0, g.co * HW * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rof =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(offset + ((long)(b * 4 + dgi) * 18) * HW), 0, 18 * HW * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rgf =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(goff + ((long)(b * 4 + dgi) * 18) * HW), 0, 18 * HW * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rgi =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(gin + ((long)b * g.c + dgi * 8) * HW), 0, 8 * HW * 4, 0x00020000);
+
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, g.co * g.c * 9 * 4, 0x00020000);
+  float ring[8][7];
+#pragma unroll
+  for (int cc = 0; cc < 8; ++cc)
+#pragma unroll
+    for (int q = 0; q < 7; ++q) ring[cc][q] = 0.f;
+  dcn_f32x16 gacc[3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) gacc[t][r] = 0.f;
+
+  // Software pipeline (two waves per SIMD cannot hide HBM latency by themselves): the row's gO operands and offsets are loaded one
+  // row ahead into the registers their predecessors just left, the old grad_input row is fetched before the taps, weights one
+  // MFMA tile ahead, corner pairs two channels ahead.
+  float bv[2][16];   // B operand of the column gradient: gO[co = 2 kk + half][position 32 nt + l32] of the row
+  float ofs[18];     // the position's 18 offsets of the row
+#define DCN_FB_LOAD_BV(ROW_)                                                                                                   \
+  _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) {                                                                           \
+    const int won = x0 + 32 * nt + l32;                                                                                        \
+    const int vo = (won >= 0 && won < W && (ROW_) < he) ? (half * HW + (ROW_) * W + won) * 4 : DCN_OOB;                        \
+    _Pragma("unroll") for (int kk = 0; kk < 16; ++kk)                                                                          \
+        bv[nt][kk] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rgo, vo + kk * (2 * HW * 4), 0, 0));               \
+  }
+  DCN_FB_LOAD_BV(hs)
+  {
+    const int vof = pos_x ? (hs * W + wo) * 4 : DCN_OOB;
+#pragma unroll
+    for (int q = 0; q < 18; ++q) ofs[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rof, vof, q * HW * 4, 0));
+  }
+
+  for (int ho = hs; ho < he; ++ho) {
+    const bool own_row = ho >= r0 && ho < r1;   // wave-uniform: halo rows only feed the input-gradient ring
+    // ---- (1) column gradient of the row -> T[(cc, tap)][lane].  A = W[co = 2 kk + half][group column 32 mt + l32], re-read per
+    // row (48 dwords per lane, L1-resident: holding them would cost 48 registers for the whole march)
+    {
+      float wa[2][16];
+#define DCN_FB_LOAD_WA(MT_)                                                                                                    \
+  {                                                                                                                            \
+    const int m = 32 * (MT_) + l32;                                                                                            \
+    int vw = m < 72 ? (half * (g.c * 9) + dgi * 72 + m) * 4 : DCN_OOB;                                                         \
+    asm volatile("" : "+v"(vw)); /* not loop-invariant as far as the compiler can tell: it would hoist all 48 loads */         \
+    _Pragma("unroll") for (int kk = 0; kk < 16; ++kk)                                                                          \
+        wa[(MT_) & 1][kk] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rw, vw + kk * (2 * g.c * 9 * 4), 0, 0));     \
+  }
+      DCN_FB_LOAD_WA(0)
+#pragma unroll
+      for (int mt = 0; mt < 3; ++mt) {
+        if (mt < 2) DCN_FB_LOAD_WA(mt + 1)
+        dcn_f32x16 d[2];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) d[nt][r] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk)
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt) d[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[mt & 1][kk], bv[nt][kk], d[nt], 0, 0, 0);
+        // D[m][n]: lane l, register i -> n = l % 32, m = 8 (i / 4) + 4 (l / 32) + i % 4
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            if (mt == 2 && i >= 4) continue;   // rows 72 .. 95 do not exist
+            const int mr = 32 * mt + 8 * (i >> 2) + 4 * half + (i & 3);
+            T[mr * DCN_FB_ROW + 32 * nt + l32] = d[nt][i];
+          }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    DCN_FB_LOAD_BV(ho + 1)
+    // the grad_input row this position row completes (accumulate contract: read-modify-write), fetched now, stored after the taps
+    const int orow = ho - 3;
+    const int vg = (orow >= r0 && orow < r1 && st_x) ? (orow * W + oc) * 4 : DCN_OOB;
+    float gold[8];
+#pragma unroll
+    for (int cc = 0; cc < 8; ++cc) gold[cc] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rgi, vg, cc * HW * 4, 0));
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- (2) + (3): taps
+    const bool own = own_row && own_x;
+    const int vof1 = (pos_x && ho + 1 < he) ? ((ho + 1) * W + wo) * 4 : DCN_OOB, vgf = own ? (ho * W + wo) * 4 : DCN_OOB;
+    bool outl = false;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      int a0[3], a1[3];
+      bool c0[3], c1[3];
+      float lh[3], lw[3], wh[3][5], ww[3][5], gh[3], gwc[3];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int t = 3 * i + j;
+        const float oh = ofs[2 * t], ow = ofs[2 * t + 1];
+        const int nh = ho - 1 + i, nw = wo - 1 + j;
+        const float hi = (float)nh + oh, wi = (float)nw + ow;
+        const bool in = hi > -1.f && wi > -1.f && hi < (float)H && wi < (float)W;
+        const float hf = floorf(hi), wf = floorf(wi);
+        const int h_low = (int)hf, w_low = (int)wf;
+        lh[j] = hi - hf; lw[j] = wi - wf;
+        const float hh = 1.f - lh[j], hw = 1.f - lw[j];
+        const int ia = h_low - nh + 2, ib = w_low - nw + 2;   // patch row / column of the top-left corner
+        const bool inpatch = pos_x && (unsigned)ia < 4u && (unsigned)ib < 4u;
+        outl = outl || (own && in && !inpatch);
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+          wh[j][q] = inpatch ? ((q == ia ? hh : 0.f) + (q == ia + 1 ? lh[j] : 0.f)) : 0.f;
+          ww[j][q] = (q == ib ? hw : 0.f) + (q == ib + 1 ? lw[j] : 0.f);
+        }
+        c0[j] = w_low >= 0; c1[j] = w_low + 1 <= W - 1;
+        const int xs = w_low < 0 ? 0 : (c1[j] ? w_low : W - 2);
+        const int base = (h_low * W + xs) * 4;
+        const bool act = own && in;
+        a0[j] = (act && h_low >= 0) ? base : DCN_OOB;
+        a1[j] = (act && h_low + 1 <= H - 1) ? base + W * 4 : DCN_OOB;
+        gh[j] = 0.f; gwc[j] = 0.f;
+      }
+      // corner pairs of channels cc + 1, cc + 2 are in flight while channel cc is consumed (halo rows / lanes that do not own
+      // their position pass out-of-range addresses: zeros, no memory access)
+      dcn_u32x2 qa[3][3], qb[3][3];   // [stage = channel % 3][tap]
+#define DCN_FB_GATHER(CH_)                                                                                                     \
+  _Pragma("unroll") for (int j = 0; j < 3; ++j) {                                                                              \
+    qa[(CH_) % 3][j] = __builtin_amdgcn_raw_buffer_load_b64(rx, a0[j] + (dgi * 8 + (CH_)) * HW * 4, 0, 0);                    \
+    qb[(CH_) % 3][j] = __builtin_amdgcn_raw_buffer_load_b64(rx, a1[j] + (dgi * 8 + (CH_)) * HW * 4, 0, 0);                    \
+  }
+      DCN_FB_GATHER(0)
+      DCN_FB_GATHER(1)
+      // this tap row's offsets are consumed: their registers take the next row's
+#pragma unroll
+      for (int q = 6 * i; q < 6 * i + 6; ++q) ofs[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rof, vof1, q * HW * 4, 0));
+#pragma unroll
+      for (int cc = 0; cc < 8; ++cc) {
+        if (cc < 6) DCN_FB_GATHER(cc + 2)
+        float L[5][7];
+#pragma unroll
+        for (int a = 0; a < 5; ++a)
+#pragma unroll
+          for (int q = 0; q < 7; ++q) L[a][q] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          const int m = cc * 9 + 3 * i + j;
+          const float gv = T[m * DCN_FB_ROW + lane];
+          {
+            const dcn_u32x2 q0 = qa[cc % 3][j], q1 = qb[cc % 3][j];
+            const float v1 = c0[j] ? __uint_as_float(c1[j] ? q0.x : q0.y) : 0.f, v2 = c1[j] ? __uint_as_float(c0[j] ? q0.y : q0.x) : 0.f;
+            const float v3 = c0[j] ? __uint_as_float(c1[j] ? q1.x : q1.y) : 0.f, v4 = c1[j] ? __uint_as_float(c0[j] ? q1.y : q1.x) : 0.f;
+            const float d21 = v2 - v1, d43 = v4 - v3;
+            const float top = v1 + lw[j] * d21, bot = v3 + lw[j] * d43;
+            const float dv = bot - top;                        // d sample / d h
+            if (WITH_GW) T[m * DCN_FB_ROW + lane] = top + lh[j] * dv;   // the sample (0 for positions this wave does not own)
+            gh[j] += gv * dv;
+            gwc[j] += gv * (d21 + lh[j] * (d43 - d21));         // d sample / d w
+          }
+          float sx[5];
+#pragma unroll
+          for (int q = 0; q < 5; ++q) sx[q] = ww[j][q] * gv;
+#pragma unroll
+          for (int a = 0; a < 5; ++a)
+#pragma unroll
+            for (int q = 0; q < 5; ++q) L[a][j + q] += wh[j][a] * sx[q];
+        }
+#pragma unroll
+        for (int a = 0; a < 5; ++a) {
+          float acc = L[a][6];
+#pragma unroll
+          for (int q = 5; q >= 0; --q) acc = dcn_wave_shr1(acc) + L[a][q];
+          ring[cc][i + a] += acc;
+        }
+        // pin the order: without this the compiler sinks all 48 gathers of the tap row below the patch arithmetic (and spills
+        // the 24 column-gradient values they are multiplied with)
+        asm volatile("" : "+v"(gh[0]), "+v"(gh[1]), "+v"(gh[2]), "+v"(gwc[0]), "+v"(gwc[1]), "+v"(gwc[2]));
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(gh[j]), rgf, vgf, (2 * (3 * i + j)) * HW * 4, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(gwc[j]), rgf, vgf, (2 * (3 * i + j) + 1) * HW * 4, 0);
+      }
+    }
+    if (own_row) {
+      if (__builtin_amdgcn_ballot_w64(outl) != 0 && lane == 0) {
+        const unsigned idx = atomicAdd(rec, 1u);
+        rec[2 + 2 * idx] = (unsigned)b;
+        rec[3 + 2 * idx] = ((unsigned)ho << 16) | ((unsigned)k << 8) | (unsigned)dgi;
+      }
+      // ---- (4) weight gradient of the row: gacc[t][co][column row] += gO[co][pos] * sample[column row][pos]
+      if (WITH_GW) {
+        dcn_f32x4 a4[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int w4 = x0 + 32 * half + 4 * j;   // 4-aligned group, W % 4 == 0: wholly inside or wholly outside the row
+          const int va = (w4 >= 0 && w4 < W) ? (l32 * HW + ho * W + w4) * 4 : DCN_OOB;
+          a4[j] = __builtin_bit_cast(dcn_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rgo, va, 0, 0));
+        }
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+          const int row = t * 32 + l32;
+          const float* bs = T + (row < 72 ? row : 0) * DCN_FB_ROW + 32 * half;
+          float4 b4[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            b4[j] = *(const float4*)(bs + 4 * j);
+            if (row >= 72) b4[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+          }
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            gacc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j].x, b4[j].x, gacc[t], 0, 0, 0);
+            gacc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j].y, b4[j].y, gacc[t], 0, 0, 0);
+            gacc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j].z, b4[j].z, gacc[t], 0, 0, 0);
+            gacc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j].w, b4[j].w, gacc[t], 0, 0, 0);
+          }
+        }
+      }
+    }
+    // ---- output row ho - 3 is complete
+    {
+#pragma unroll
+      for (int cc = 0; cc < 8; ++cc)
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(gold[cc] + ring[cc][0]), rgi, vg, cc * HW * 4, 0);
+#pragma unroll
+      for (int cc = 0; cc < 8; ++cc) {
+#pragma unroll
+        for (int q = 0; q < 6; ++q) ring[cc][q] = ring[cc][q + 1];
+        ring[cc][6] = 0.f;
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 3; ++e) {   // the rows below the last position row (bottom of the image)
+    const int orow = he - 3 + e;
+    if (orow >= r0 && orow < r1) {
+      const int vg = st_x ? (orow * W + oc) * 4 : DCN_OOB;
+#pragma unroll
+      for (int cc = 0; cc < 8; ++cc) {
+        const float old = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rgi, vg, cc * HW * 4, 0));
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(old + ring[cc][e]), rgi, vg, cc * HW * 4, 0);
+      }
+    }
+  }
+  if (WITH_GW) {
+    const int ck_total = g.c * 9;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      const int r = t * 32 + l32;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int co = 8 * (i >> 2) + 4 * half + (i & 3);
+        if (co < g.co && r < 72) atomicAdd(gw + (long)co * ck_total + dgi * 72 + r, scale * gacc[t][i]);
+      }
+    }
+  }
+}
+
+// The rows dcn_bwd_fused_kernel listed: samples with an offset component outside [-2, 2).  One wave per listed (image, group,
+// row, strip); the column gradient of such a sample is recomputed from W and gO (co MACs per channel) and scattered to its live
+// corners with fp32 atomics, as dcn_col2im_outlier_kernel does.
+__global__ __launch_bounds__(64) void dcn_bwd_outlier_rows_kernel(const float* offset, const float* go, const float* w,
+                                                                  float* gin, const unsigned* rec, DcnGeom g) {
+  const unsigned count = rec[0];
+  const int lane = threadIdx.x, H = g.h, W = g.w, HW = H * W;
+  const int cc = lane >> 3, part = lane & 7;   // while a sample is served: lane = (channel of the group, eighth of the co sum)
+  for (unsigned r = blockIdx.x; r < count; r += gridDim.x) {
+    const int b = (int)rec[2 + 2 * r];
+    const unsigned v = rec[3 + 2 * r];
+    const int ho = (int)(v >> 16), k = (int)((v >> 8) & 255u), dgi = (int)(v & 255u);
+    const int wo = DCN_FB_XO * k - 4 + lane;
+    const bool own = lane >= 4 && lane < 4 + DCN_FB_XO && wo < W;
+    const float* offp = offset + ((long)(b * g.dg + dgi) * 18) * HW + (long)ho * W + wo;
+    const float* gop = go + ((long)b * g.co * H + ho) * W;
+    float* gim = gin + ((long)b * g.c + dgi * 8 + cc) * HW;
+    for (int t = 0; t < 9; ++t) {
+      const int i = t / 3, j = t - 3 * i;
+      const float oh = own ? offp[(long)(2 * t) * HW] : 0.f, ow = own ? offp[(long)(2 * t + 1) * HW] : 0.f;
+      const int nh = ho - 1 + i, nw = wo - 1 + j;
+      const float hi = (float)nh + oh, wi = (float)nw + ow;
+      const float hf = floorf(hi), wf = floorf(wi);
+      const int h_low = (int)hf, w_low = (int)wf;
+      const int ia = h_low - nh + 2, ib = w_low - nw + 2;
+      const bool flag = own && hi > -1.f && wi > -1.f && hi < (float)H && wi < (float)W && !((unsigned)ia < 4u && (unsigned)ib < 4u);
+      const float lh = hi - hf, lw = wi - wf;
+      unsigned long long todo = __builtin_amdgcn_ballot_w64(flag);
+      while (todo) {   // wave-uniform loop over the row's outlier samples of this tap; the whole wave serves one sample
+        const int src = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        const int s_h = __shfl(h_low, src), s_w = __shfl(w_low, src), s_wo = __shfl(wo, src);
+        const float s_lh = __shfl(lh, src), s_lw = __shfl(lw, src);
+        float cv = 0.f;
+        for (int co = part; co < g.co; co += 8)
+          cv += w[(long)co * (g.c * 9) + (dgi * 8 + cc) * 9 + t] * gop[(long)co * HW + s_wo];
+        cv += __shfl_xor(cv, 1); cv += __shfl_xor(cv, 2); cv += __shfl_xor(cv, 4);
+        if (part < 4) {   // one live corner each
+          const int dy = part >> 1, dx = part & 1;
+          const int yy = s_h + dy, xx = s_w + dx;
+          const float wgt = (dy ? s_lh : 1.f - s_lh) * (dx ? s_lw : 1.f - s_lw);
+          if (yy >= 0 && yy <= H - 1 && xx >= 0 && xx <= W - 1 && wgt != 0.f) atomicAdd(gim + yy * W + xx, wgt * cv);
+        }
+      }
+    }
+  }
+}
+
+static bool dcn_bwd_fused_ok(const DcnGeom& g, int step) {
+  const char* e = getenv("RTP_DCN_NO_FUSED_BWD");
+  if (e && atoi(e)) return false;
+  if (!(g.group == 1 && g.dg == 4 && g.c == 32 && g.kh == 3 && g.kw == 3 && g.sh == 1 && g.sw == 1 && g.dh == 1 && g.dw == 1 &&
+        g.ph == 1 && g.pw == 1 && g.co <= 32 && g.w % 4 == 0 && g.w >= 4 && g.h < 65536))
+    return false;
+  const long strips = (g.w + DCN_FB_XO - 1) / DCN_FB_XO;
+  if (strips > 255 || (long)g.c * g.h * g.w * 4 >= (1L << 31) - (1L << 20)) return false;
+  // the row list lives in the caller's workspace (sized for `step` images of columns, rtp_dcn_workspace_bytes)
+  const long rec_bytes = 8 + 8 * (long)g.n * g.dg * strips * g.h;
+  return rec_bytes <= (long)g.c * 9 * step * g.h * g.w * 4;
+}
+
+// gradWeight == nullptr: input / offset gradients only
+static int dcn_backward_fused(const float* input, const float* offset, const float* gradOutput, float* gradInput,
+                              float* gradOffset, const float* weight, float* gradWeight, float* ws, DcnGeom g, float scale,
+                              hipStream_t s) {
+  RtpProfScope prof(RTP_FAM_DCN, s);
+  const int strips = (g.w + DCN_FB_XO - 1) / DCN_FB_XO;
+  // row segments: one block per CU at a time (512 registers per lane), so the march takes ceil(blocks / CUs) rounds of
+  // seg_rows + halo rows each; the segment count with the fewest rows on the critical path wins (128 images x 3 strips on 256 CUs:
+  // two segments -> 3 rounds x 35 rows instead of 2 x 64)
+  int segs = 1;
+  const char* e = getenv("RTP_DCN_SEGS");
+  if (e && atoi(e) > 0) segs = atoi(e);
+  else {
+    static int cus = 0;
+    if (!cus) {
+      int dev = 0;
+      hipDeviceProp_t prop;
+      if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+      if (cus < 1) cus = 256;
+    }
+    long best = -1;
+    for (int sgs = 1; sgs <= 8 && sgs <= g.h; ++sgs) {
+      const int rows = (g.h + sgs - 1) / sgs;
+      const long rounds = ((long)g.n * strips * sgs + cus - 1) / cus;
+      const long cost = rounds * (rows + (sgs == 1 ? 0 : sgs == 2 ? 3 : 6));
+      if (best < 0 || cost < best) { best = cost; segs = sgs; }
+    }
+  }
+  if (segs > g.h) segs = g.h;
+  const int seg_rows = (g.h + segs - 1) / segs;
+  segs = (g.h + seg_rows - 1) / seg_rows;
+  unsigned* rec = (unsigned*)ws;
+  if (hipMemsetAsync(rec, 0, 8, s) != hipSuccess) return RTP_ERR_LAUNCH;
+  const size_t lds = sizeof(float) * 4 * 72 * DCN_FB_ROW;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)dcn_bwd_fused_kernel<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)dcn_bwd_fused_kernel<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)dcn_bwd_fused_kernel<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)dcn_bwd_fused_kernel<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr = true;
+  }
+  const char* oe = getenv("RTP_DCN_OCC");
+  const int occ = oe && atoi(oe) == 2 ? 2 : 1;
+  const char* se = getenv("RTP_DCN_SPLIT_GW");   // weight gradient by dcn_gradw_fused_kernel (its own gather pass)
+  const bool split = gradWeight && se && atoi(se) && dcn_gradw_fused_ok(g);
+  float* gwk = split ? nullptr : gradWeight;
+  const dim3 grid((unsigned)((long)g.n * segs * strips));
+#define DCN_FB_LAUNCH(GW_, OCC_)                                                                                            \
+  hipLaunchKernelGGL((dcn_bwd_fused_kernel<GW_, OCC_>), grid, dim3(256), lds, s, input, offset, gradOutput, weight, gradInput, \
+                     gradOffset, gwk, rec, g, scale, strips, segs, seg_rows)
+  if (gwk) { if (occ == 2) DCN_FB_LAUNCH(true, 2); else DCN_FB_LAUNCH(true, 1); }
+  else { if (occ == 2) DCN_FB_LAUNCH(false, 2); else DCN_FB_LAUNCH(false, 1); }
+  if (split) dcn_gradw_fused_launch(input, offset, nullptr, gradOutput, gradWeight, g, scale, s);
+  hipLaunchKernelGGL(dcn_bwd_outlier_rows_kernel, dim3(1024), dim3(64), 0, s, offset, gradOutput, weight, gradInput, rec, g);
+  RTP_CHECK_LAUNCH();
+  return RTP_OK;
+}
+
+
 static int dcn_backward_params(const float* input, const float* offset, const float* mask, const float* gradOutput,
                                float* gradWeight, float* ws, DcnGeom g, float scale, int step, hipStream_t s) {
   const int P = g.ho * g.wo, K = g.kh * g.kw;
   const int cg = g.c / g.group, cog = g.co / g.group;
   RtpProfScope prof(RTP_FAM_DCN, s);
+  if (dcn_gradw_fused_ok(g)) {   // no column matrix: gather -> LDS transpose -> MFMA in one launch over all images (ws unused)
+    dcn_gradw_fused_launch(input, offset, mask, gradOutput, gradWeight, g, scale, s);
+    RTP_CHECK_LAUNCH();
+    return RTP_OK;
+  }
   for (int b0 = 0; b0 < g.n; b0 += step) {
     dcn_im2col(s, input, offset, mask, ws, g, b0, step);
     for (int gi = 0; gi < g.group; ++gi) {
@@ -1528,6 +2107,27 @@ extern "C" int rtp_deform_conv_backward_parameters(const float* input, const flo
   if (!input || !offset || !gradOutput || !gradWeight || !ws) return RTP_ERR_SHAPE;
   DCN_GEOM_V1();
   const int rc = dcn_check(g, im2col_step);
+  if (rc) return rc;
+  return dcn_backward_params(input, offset, nullptr, gradOutput, gradWeight, (float*)ws, g, scale, im2col_step,
+                             (hipStream_t)stream);
+}
+
+// Both halves of DeformConvFunction.backward (deform_conv.py:62-98 calls deform_conv_backward_input_cuda and then
+// deform_conv_backward_parameters_cuda on the same tensors) in one call, so that the geometry of the DCN head runs the one-pass
+// kernel with the weight gradient on board; other geometries run the two halves one after the other.
+extern "C" int rtp_deform_conv_backward(const float* input, const float* offset, const float* gradOutput, float* gradInput,
+                                        float* gradOffset, const float* weight, float* gradWeight, void* ws, int n, int c,
+                                        int h, int w, int co, int kW, int kH, int dW, int dH, int padW, int padH, int dilW,
+                                        int dilH, int group, int deformable_group, float scale, int im2col_step, void* stream) {
+  if (!input || !offset || !gradOutput || !gradInput || !gradOffset || !weight || !gradWeight || !ws) return RTP_ERR_SHAPE;
+  DCN_GEOM_V1();
+  int rc = dcn_check(g, im2col_step);
+  if (rc) return rc;
+  if (dcn_bwd_fused_ok(g, im2col_step))
+    return dcn_backward_fused(input, offset, gradOutput, gradInput, gradOffset, weight, gradWeight, (float*)ws, g, scale,
+                              (hipStream_t)stream);
+  rc = dcn_backward_input(input, offset, nullptr, gradOutput, gradInput, gradOffset, nullptr, weight, (float*)ws, g,
+                          im2col_step, (hipStream_t)stream);
   if (rc) return rc;
   return dcn_backward_params(input, offset, nullptr, gradOutput, gradWeight, (float*)ws, g, scale, im2col_step,
                              (hipStream_t)stream);

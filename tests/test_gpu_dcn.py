@@ -24,6 +24,11 @@ CASES = [
     (2, 8, 16, 16, 8, 3, 1, 1, 1, 1, 2, 2),        # P = 256: the MFMA weight-gradient GEMM (needs P % 64 == 0, <= 32 output channels)
     (2, 40, 8, 8, 24, 3, 1, 1, 1, 1, 4, 1),        # 360 column rows: two row chunks in both MFMA GEMMs of the backward
     (3, 12, 33, 41, 40, 3, 1, 1, 1, 1, 2, 3),      # ragged: P = 1353 is no multiple of the 256-position block, co = 40 -> two MFMA row tiles
+    # the fused weight gradient (dcn_gradw_fused_kernel: 32 channels in 4 deformable groups, 3x3, <= 32 output channels, P % 64 == 0)
+    (3, 32, 8, 16, 32, 3, 1, 1, 1, 1, 4, 1),
+    (2, 32, 16, 24, 20, 3, 1, 1, 1, 1, 4, 2),
+    (2, 32, 16, 16, 32, 3, 2, 1, 1, 1, 4, 64),     # stride 2: P = 64
+    (1, 32, 12, 20, 32, 3, 1, 2, 2, 1, 4, 64),     # dilation 2: P = 240 -> not fused (P % 64), the column route on the same channels
 ]
 
 
@@ -268,6 +273,67 @@ def test_dcn_random_geometries(seed):
     assert rel_err(wg.grad.cpu(), wt.grad) < TOL, case
     if scale > 0 or float(off.grad.abs().max()) > 0:
         assert rel_err(og.grad.cpu(), off.grad) < TOL, case
+
+
+FUSED_BWD = [
+    # n, h, w, co, offset scale, row segments (RTP_DCN_SEGS; 0 = the launcher's choice), weight gradient in the same call
+    (2, 8, 16, 32, 0.5, 0, True),
+    (1, 12, 60, 32, 0.5, 1, True),       # two strips (56 owned columns each), the second one ragged
+    (2, 9, 160, 32, 0.5, 0, True),       # the head's row width: three strips
+    (1, 20, 64, 20, 1.0, 3, True),       # co < 32, three row segments with halo rows, some samples beyond the 5 x 5 patch
+    (2, 7, 8, 32, 0.0, 1, True),         # zero offsets: a plain convolution
+    (1, 16, 120, 32, 3.0, 2, True),      # most samples are outliers: the listed-row scatter kernel
+    (1, 33, 36, 8, 12.0, 4, True),       # nearly every sample leaves the image
+    (2, 10, 116, 32, 0.7, 2, False),     # input / offset gradients alone (rtp_deform_conv_backward_input), weights by their own entry
+]
+
+
+@pytest.mark.parametrize("case", FUSED_BWD)
+def test_dcn_one_pass_backward(case, monkeypatch):
+    """dcn_bwd_fused_kernel (+ dcn_bwd_outlier_rows_kernel): the geometry of the DCN head -- 3x3, stride 1, pad 1, 32 channels in
+    4 deformable groups -- takes the one-pass backward; strips, ragged last strip, row segments with halo rows, co < 32, samples
+    outside the register patch and outside the image, against the oracle and against the column route of the same library."""
+    from rt_pose_amd.dcn import deform_conv
+    n, h, w, co, scale, segs, together = case
+    monkeypatch.delenv("RTP_DCN_NO_FUSED_BWD", raising=False)
+    if segs:
+        monkeypatch.setenv("RTP_DCN_SEGS", str(segs))
+    else:
+        monkeypatch.delenv("RTP_DCN_SEGS", raising=False)
+    x = rnd(n, 32, h, w, seed=11).requires_grad_(True)
+    wt = rnd(co, 32, 3, 3, seed=12, scale=0.2).requires_grad_(True)
+    off = rnd(n, 72, h, w, seed=13, scale=scale).requires_grad_(True)
+    ref = deform_conv2d(x, off, wt, 1, 1, 1, 1, 4)
+    gy = rnd(*ref.shape, seed=14)
+    ref.backward(gy)
+
+    def run():
+        xg, wg, og = [t.detach().cuda().requires_grad_(True) for t in (x, wt, off)]
+        out = deform_conv(xg, og, wg, 1, 1, 1, 1, 4, 64)
+        if together:
+            out.backward(gy.cuda())
+        else:
+            gx, go = torch.autograd.grad(out, (xg, og), gy.cuda(), retain_graph=True)
+            gw, = torch.autograd.grad(out, (wg,), gy.cuda())
+            xg.grad, og.grad, wg.grad = gx, go, gw
+        torch.cuda.synchronize()
+        return xg.grad.cpu(), wg.grad.cpu(), og.grad.cpu()
+
+    gx, gw, go = run()
+    assert rel_err(gx, x.grad) < TOL, case
+    assert rel_err(gw, wt.grad) < TOL, case
+    if scale > 0:
+        assert rel_err(go, off.grad) < TOL, case
+    else:
+        assert rel_err(go, off.grad) < TOL or float(off.grad.abs().max()) == 0
+    monkeypatch.setenv("RTP_DCN_NO_FUSED_BWD", "1")      # the column route (im2col / GEMM / gather kernels) on the same inputs
+    cx, cw, co_ = run()
+    assert rel_err(gx, cx) < TOL and rel_err(gw, cw) < TOL and rel_err(go, co_) < TOL, case
+    # offsets within the patch everywhere: the input gradient has no atomics -> bit-reproducible
+    if scale <= 0.5:
+        monkeypatch.delenv("RTP_DCN_NO_FUSED_BWD", raising=False)
+        rx, _, ro = run()
+        assert torch.equal(rx, gx) and torch.equal(ro, go), case
 
 
 @pytest.mark.parametrize("mode", list(MODES))
