@@ -571,6 +571,7 @@ static void sgemm(hipStream_t s, MatView A, MatView B, MatView C, int M, int N, 
 // 64x64x16 VALU tile kernel above does not reach (0.87 ms each).  Both run on v_mfma_f32_32x32x2_f32 (exact fp32).
 typedef float dcn_f32x16 __attribute__((ext_vector_type(16)));
 typedef float dcn_f32x4 __attribute__((ext_vector_type(4)));
+typedef float dcn_f32x2 __attribute__((ext_vector_type(2)));
 
 // columns[r][n] = sum_co W[co][r] * gO[b0 + n / P][co][n % P]      (r < ck = cg * K, n < step * P)
 // A = W^T from LDS ([co][r], one ds_read_b32 per MFMA), B = gO straight from global memory (a half-wave reads 32
@@ -1644,8 +1645,8 @@ __device__ __forceinline__ float dcn_wave_shr1(float v) {   // lane x <- lane x 
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true));
 }
 
-template <bool WITH_GW, int OCC>   // OCC: waves per SIMD the register budget is set for (2: 256 registers, 1: 512)
-__global__ __launch_bounds__(256, OCC) void dcn_bwd_fused_kernel(const float* __restrict__ x, const float* __restrict__ offset,
+template <bool WITH_GW>   // one block per CU: 512 registers per lane (two waves per SIMD at 256 spilled and ran 2x slower)
+__global__ __launch_bounds__(256, 1) void dcn_bwd_fused_kernel(const float* __restrict__ x, const float* __restrict__ offset,
                                                                const float* __restrict__ go, const float* __restrict__ w,
                                                                float* gin, float* goff, float* gw, unsigned* rec, DcnGeom g,
                                                                float scale, int strips, int segs, int seg_rows) {
@@ -1678,92 +1679,88 @@ __global__ __launch_bounds__(256, OCC) void dcn_bwd_fused_kernel(const float* __
       __builtin_amdgcn_make_buffer_rsrc((void*)(gin + ((long)b * g.c + dgi * 8) * HW), 0, 8 * HW * 4, 0x00020000);
 
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, g.co * g.c * 9 * 4, 0x00020000);
-  float ring[8][7];
+  // ring of 7 output-row accumulators per channel, in LDS behind the tiles ([channel][slot][lane], slot = output row mod 7): in
+  // registers it cost 56 VGPRs and 48 moves per row to rotate
+  float* R = fb_lds + 4 * (72 * DCN_FB_ROW) + dgi * (8 * 7 * 64) + lane;
 #pragma unroll
-  for (int cc = 0; cc < 8; ++cc)
-#pragma unroll
-    for (int q = 0; q < 7; ++q) ring[cc][q] = 0.f;
+  for (int q = 0; q < 56; ++q) R[q * 64] = 0.f;
   dcn_f32x16 gacc[3];
 #pragma unroll
   for (int t = 0; t < 3; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) gacc[t][r] = 0.f;
 
-  // Software pipeline (two waves per SIMD cannot hide HBM latency by themselves): the row's gO operands and offsets are loaded one
-  // row ahead into the registers their predecessors just left, the old grad_input row is fetched before the taps, weights one
-  // MFMA tile ahead, corner pairs two channels ahead.
-  float bv[2][16];   // B operand of the column gradient: gO[co = 2 kk + half][position 32 nt + l32] of the row
-  float ofs[18];     // the position's 18 offsets of the row
-#define DCN_FB_LOAD_BV(ROW_)                                                                                                   \
+  // Software pipeline of the march (one wave per SIMD: nothing else hides latency).  Column rows are ordered tap row first
+  // (row 24 i + 3 cc + j for tap (i, j) of channel cc), so a tap row is one MFMA tile (24 of 32 rows used): while tap row i of
+  // position row ho runs on the vector ALU, the matrix core computes tile i of the NEXT row's column gradient, four MFMAs per
+  // channel iteration, into the accumulators tile i of this row just left (they were written to the LDS tile right before the
+  // tap row started).  gO operands are loaded two rows ahead, offsets one row ahead into the registers their predecessors
+  // leave, corner pairs two channels ahead, the old grad_input row before the taps; the weights stay in registers.
+  float wa[3][16];    // A operand of tile i: W[co = 2 kk + half][group column of local row l32]
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int vw = l32 < 24 ? (half * (g.c * 9) + dgi * 72 + (l32 / 3) * 9 + 3 * i + l32 % 3) * 4 : DCN_OOB;
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk)
+      wa[i][kk] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rw, vw + kk * (2 * g.c * 9 * 4), 0, 0));
+  }
+  float bvA[2][16], bvB[2][16];   // B operand gO[co = 2 kk + half][position 32 nt + l32]: of the row whose column gradient is being computed / the one after
+  float ofs[18];                  // the position's 18 offsets of the row
+#define DCN_FB_LOAD_BV(DST_, ROW_)                                                                                             \
   _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) {                                                                           \
     const int won = x0 + 32 * nt + l32;                                                                                        \
     const int vo = (won >= 0 && won < W && (ROW_) < he) ? (half * HW + (ROW_) * W + won) * 4 : DCN_OOB;                        \
     _Pragma("unroll") for (int kk = 0; kk < 16; ++kk)                                                                          \
-        bv[nt][kk] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rgo, vo + kk * (2 * HW * 4), 0, 0));               \
+        DST_[nt][kk] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rgo, vo + kk * (2 * HW * 4), 0, 0));             \
   }
-  DCN_FB_LOAD_BV(hs)
+  DCN_FB_LOAD_BV(bvA, hs)
   {
     const int vof = pos_x ? (hs * W + wo) * 4 : DCN_OOB;
 #pragma unroll
     for (int q = 0; q < 18; ++q) ofs[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rof, vof, q * HW * 4, 0));
   }
+  dcn_f32x16 d[3][2];   // column gradient tiles [tap row][position half]
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) d[i][nt][r] = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk) d[i][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[i][kk], bvA[nt][kk], d[i][nt], 0, 0, 0);
+    }
+  DCN_FB_LOAD_BV(bvA, hs + 1)
+  DCN_FB_LOAD_BV(bvB, hs + 2)
 
   for (int ho = hs; ho < he; ++ho) {
     const bool own_row = ho >= r0 && ho < r1;   // wave-uniform: halo rows only feed the input-gradient ring
-    // ---- (1) column gradient of the row -> T[(cc, tap)][lane].  A = W[co = 2 kk + half][group column 32 mt + l32], re-read per
-    // row (48 dwords per lane, L1-resident: holding them would cost 48 registers for the whole march)
-    {
-      float wa[2][16];
-#define DCN_FB_LOAD_WA(MT_)                                                                                                    \
-  {                                                                                                                            \
-    const int m = 32 * (MT_) + l32;                                                                                            \
-    int vw = m < 72 ? (half * (g.c * 9) + dgi * 72 + m) * 4 : DCN_OOB;                                                         \
-    asm volatile("" : "+v"(vw)); /* not loop-invariant as far as the compiler can tell: it would hoist all 48 loads */         \
-    _Pragma("unroll") for (int kk = 0; kk < 16; ++kk)                                                                          \
-        wa[(MT_) & 1][kk] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rw, vw + kk * (2 * g.c * 9 * 4), 0, 0));     \
-  }
-      DCN_FB_LOAD_WA(0)
+    int rs[7];   // ring slot (x 64 floats) of output row ho - 3 + q
 #pragma unroll
-      for (int mt = 0; mt < 3; ++mt) {
-        if (mt < 2) DCN_FB_LOAD_WA(mt + 1)
-        dcn_f32x16 d[2];
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) d[nt][r] = 0.f;
-#pragma unroll
-        for (int kk = 0; kk < 16; ++kk)
-#pragma unroll
-          for (int nt = 0; nt < 2; ++nt) d[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[mt & 1][kk], bv[nt][kk], d[nt], 0, 0, 0);
-        // D[m][n]: lane l, register i -> n = l % 32, m = 8 (i / 4) + 4 (l / 32) + i % 4
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-          for (int i = 0; i < 16; ++i) {
-            if (mt == 2 && i >= 4) continue;   // rows 72 .. 95 do not exist
-            const int mr = 32 * mt + 8 * (i >> 2) + 4 * half + (i & 3);
-            T[mr * DCN_FB_ROW + 32 * nt + l32] = d[nt][i];
-          }
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    DCN_FB_LOAD_BV(ho + 1)
+    for (int q = 0; q < 7; ++q) rs[q] = ((ho + 4 + q) % 7) * 64;
     // the grad_input row this position row completes (accumulate contract: read-modify-write), fetched now, stored after the taps
     const int orow = ho - 3;
     const int vg = (orow >= r0 && orow < r1 && st_x) ? (orow * W + oc) * 4 : DCN_OOB;
     float gold[8];
 #pragma unroll
     for (int cc = 0; cc < 8; ++cc) gold[cc] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rgi, vg, cc * HW * 4, 0));
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- (2) + (3): taps
     const bool own = own_row && own_x;
     const int vof1 = (pos_x && ho + 1 < he) ? ((ho + 1) * W + wo) * 4 : DCN_OOB, vgf = own ? (ho * W + wo) * 4 : DCN_OOB;
     bool outl = false;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
+      // ---- (1) tile i of this row's column gradient -> T[24 i + (cc, j)][lane]; D[m][n]: lane l, register r -> n = l % 32,
+      // m = 8 (r / 4) + 4 (l / 32) + r % 4 (rows 24 .. 31 do not exist); the accumulators start the next row's tile
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+#pragma unroll
+        for (int r = 0; r < 12; ++r) T[(24 * i + 8 * (r >> 2) + 4 * half + (r & 3)) * DCN_FB_ROW + 32 * nt + l32] = d[i][nt][r];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) d[i][nt][r] = 0.f;
+      }
+      // ---- (2) + (3): the tap row
       int a0[3], a1[3];
-      bool c0[3], c1[3];
-      float lh[3], lw[3], wh[3][5], ww[3][5], gh[3], gwc[3];
+      float lh[3], wh[3][5], ww[3][5], gh[3], gwc[3];
+      dcn_f32x2 wxy[3], exy[3];   // what the loaded column pair contributes to the row's sample / to d sample / d w
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
         const int t = 3 * i + j;
@@ -1773,18 +1770,23 @@ __global__ __launch_bounds__(256, OCC) void dcn_bwd_fused_kernel(const float* __
         const bool in = hi > -1.f && wi > -1.f && hi < (float)H && wi < (float)W;
         const float hf = floorf(hi), wf = floorf(wi);
         const int h_low = (int)hf, w_low = (int)wf;
-        lh[j] = hi - hf; lw[j] = wi - wf;
-        const float hh = 1.f - lh[j], hw = 1.f - lw[j];
+        lh[j] = hi - hf;
+        const float lw = wi - wf;
+        const float hh = 1.f - lh[j], hw = 1.f - lw;
         const int ia = h_low - nh + 2, ib = w_low - nw + 2;   // patch row / column of the top-left corner
         const bool inpatch = pos_x && (unsigned)ia < 4u && (unsigned)ib < 4u;
         outl = outl || (own && in && !inpatch);
 #pragma unroll
         for (int q = 0; q < 5; ++q) {
           wh[j][q] = inpatch ? ((q == ia ? hh : 0.f) + (q == ia + 1 ? lh[j] : 0.f)) : 0.f;
-          ww[j][q] = (q == ib ? hw : 0.f) + (q == ib + 1 ? lw[j] : 0.f);
+          ww[j][q] = (q == ib ? hw : 0.f) + (q == ib + 1 ? lw : 0.f);
         }
-        c0[j] = w_low >= 0; c1[j] = w_low + 1 <= W - 1;
-        const int xs = w_low < 0 ? 0 : (c1[j] ? w_low : W - 2);
+        // the 8-byte load covers columns (xs, xs + 1), clamped into the row: at the left / right edge one of the two is the live
+        // corner and the other one does not exist; per-tap weights on the pair replace per-channel selects
+        const bool c0 = w_low >= 0, c1 = w_low + 1 <= W - 1;
+        const int xs = w_low < 0 ? 0 : (c1 ? w_low : W - 2);
+        wxy[j] = c0 ? (c1 ? dcn_f32x2{hw, lw} : dcn_f32x2{0.f, hw}) : dcn_f32x2{lw, 0.f};
+        exy[j] = c0 ? (c1 ? dcn_f32x2{-1.f, 1.f} : dcn_f32x2{0.f, -1.f}) : dcn_f32x2{1.f, 0.f};
         const int base = (h_low * W + xs) * 4;
         const bool act = own && in;
         a0[j] = (act && h_low >= 0) ? base : DCN_OOB;
@@ -1807,41 +1809,59 @@ __global__ __launch_bounds__(256, OCC) void dcn_bwd_fused_kernel(const float* __
 #pragma unroll
       for (int cc = 0; cc < 8; ++cc) {
         if (cc < 6) DCN_FB_GATHER(cc + 2)
-        float L[5][7];
+        float rv[5];
 #pragma unroll
-        for (int a = 0; a < 5; ++a)
+        for (int a = 0; a < 5; ++a) rv[a] = R[cc * 448 + rs[i + a]];
+        // 5 x 7 patch of the tap row as packed pairs (v_pk_fma_f32): columns (0,1) (2,3) (4,5) 6
+        dcn_f32x2 L01[5], L23[5], L45[5];
+        float L6[5];
 #pragma unroll
-          for (int q = 0; q < 7; ++q) L[a][q] = 0.f;
+        for (int a = 0; a < 5; ++a) { L01[a] = dcn_f32x2{0.f, 0.f}; L23[a] = dcn_f32x2{0.f, 0.f}; L45[a] = dcn_f32x2{0.f, 0.f}; L6[a] = 0.f; }
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-          const int m = cc * 9 + 3 * i + j;
+          const int m = 24 * i + 3 * cc + j;
           const float gv = T[m * DCN_FB_ROW + lane];
           {
             const dcn_u32x2 q0 = qa[cc % 3][j], q1 = qb[cc % 3][j];
-            const float v1 = c0[j] ? __uint_as_float(c1[j] ? q0.x : q0.y) : 0.f, v2 = c1[j] ? __uint_as_float(c0[j] ? q0.y : q0.x) : 0.f;
-            const float v3 = c0[j] ? __uint_as_float(c1[j] ? q1.x : q1.y) : 0.f, v4 = c1[j] ? __uint_as_float(c0[j] ? q1.y : q1.x) : 0.f;
-            const float d21 = v2 - v1, d43 = v4 - v3;
-            const float top = v1 + lw[j] * d21, bot = v3 + lw[j] * d43;
-            const float dv = bot - top;                        // d sample / d h
-            if (WITH_GW) T[m * DCN_FB_ROW + lane] = top + lh[j] * dv;   // the sample (0 for positions this wave does not own)
+            const dcn_f32x2 px = {__uint_as_float(q0.x), __uint_as_float(q1.x)}, py = {__uint_as_float(q0.y), __uint_as_float(q1.y)};
+            const dcn_f32x2 tb = wxy[j].x * px + wxy[j].y * py;   // (top, bottom) row samples
+            const dcn_f32x2 dd = exy[j].x * px + exy[j].y * py;   // their d / d w
+            const float dv = tb.y - tb.x;                        // d sample / d h
+            if (WITH_GW) T[m * DCN_FB_ROW + lane] = tb.x + lh[j] * dv;   // the sample (0 for positions this wave does not own)
             gh[j] += gv * dv;
-            gwc[j] += gv * (d21 + lh[j] * (d43 - d21));         // d sample / d w
+            gwc[j] += gv * (dd.x + lh[j] * (dd.y - dd.x));
           }
-          float sx[5];
+          const float s0 = ww[j][0] * gv, s1 = ww[j][1] * gv, s2 = ww[j][2] * gv, s3 = ww[j][3] * gv, s4 = ww[j][4] * gv;
 #pragma unroll
-          for (int q = 0; q < 5; ++q) sx[q] = ww[j][q] * gv;
-#pragma unroll
-          for (int a = 0; a < 5; ++a)
-#pragma unroll
-            for (int q = 0; q < 5; ++q) L[a][j + q] += wh[j][a] * sx[q];
+          for (int a = 0; a < 5; ++a) {
+            const float h = wh[j][a];
+            if (j == 0) { L01[a] += h * dcn_f32x2{s0, s1}; L23[a] += h * dcn_f32x2{s2, s3}; L45[a].x += h * s4; }
+            if (j == 1) { L01[a].y += h * s0; L23[a] += h * dcn_f32x2{s1, s2}; L45[a] += h * dcn_f32x2{s3, s4}; }
+            if (j == 2) { L23[a] += h * dcn_f32x2{s0, s1}; L45[a] += h * dcn_f32x2{s2, s3}; L6[a] += h * s4; }
+          }
+          // the matrix core's share of this iteration: k steps 2 cc, 2 cc + 1 of tile i of the next row's column gradient
+          if (j < 2) {
+            const int kk = 2 * cc + j;
+            d[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[i][kk], bvA[0][kk], d[i][0], 0, 0, 0);
+            d[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[i][kk], bvA[1][kk], d[i][1], 0, 0, 0);
+          }
         }
+        // x reduction, the five patch rows' chains interleaved: a DPP read of a register the previous instruction wrote costs
+        // two wait states (the chain-by-chain order stalled 8 cycles per shift: a quarter of the kernel)
+        float acc[5];
 #pragma unroll
-        for (int a = 0; a < 5; ++a) {
-          float acc = L[a][6];
+        for (int a = 0; a < 5; ++a) acc[a] = L6[a];
+#define DCN_FB_SHIFT_ADD(SRC_)                                                                                                 \
+  _Pragma("unroll") for (int a = 0; a < 5; ++a) acc[a] = dcn_wave_shr1(acc[a]) + SRC_;                                         \
+  asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]));
+        DCN_FB_SHIFT_ADD(L45[a].y)
+        DCN_FB_SHIFT_ADD(L45[a].x)
+        DCN_FB_SHIFT_ADD(L23[a].y)
+        DCN_FB_SHIFT_ADD(L23[a].x)
+        DCN_FB_SHIFT_ADD(L01[a].y)
+        DCN_FB_SHIFT_ADD(L01[a].x)
 #pragma unroll
-          for (int q = 5; q >= 0; --q) acc = dcn_wave_shr1(acc) + L[a][q];
-          ring[cc][i + a] += acc;
-        }
+        for (int a = 0; a < 5; ++a) R[cc * 448 + rs[i + a]] = rv[a] + acc[a];
         // pin the order: without this the compiler sinks all 48 gathers of the tap row below the patch arithmetic (and spills
         // the 24 column-gradient values they are multiplied with)
         asm volatile("" : "+v"(gh[0]), "+v"(gh[1]), "+v"(gh[2]), "+v"(gwc[0]), "+v"(gwc[1]), "+v"(gwc[2]));
@@ -1853,13 +1873,19 @@ __global__ __launch_bounds__(256, OCC) void dcn_bwd_fused_kernel(const float* __
         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(gwc[j]), rgf, vgf, (2 * (3 * i + j) + 1) * HW * 4, 0);
       }
     }
+    // gO: the next row's operands move up, the row after them is requested
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk) bvA[nt][kk] = bvB[nt][kk];
+    DCN_FB_LOAD_BV(bvB, ho + 3)
     if (own_row) {
       if (__builtin_amdgcn_ballot_w64(outl) != 0 && lane == 0) {
         const unsigned idx = atomicAdd(rec, 1u);
         rec[2 + 2 * idx] = (unsigned)b;
         rec[3 + 2 * idx] = ((unsigned)ho << 16) | ((unsigned)k << 8) | (unsigned)dgi;
       }
-      // ---- (4) weight gradient of the row: gacc[t][co][column row] += gO[co][pos] * sample[column row][pos]
+      // ---- (4) weight gradient of the row: gacc[t][co][local column row] += gO[co][pos] * sample[24 t + local row][pos]
       if (WITH_GW) {
         dcn_f32x4 a4[8];
 #pragma unroll
@@ -1870,13 +1896,12 @@ __global__ __launch_bounds__(256, OCC) void dcn_bwd_fused_kernel(const float* __
         }
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
-          const int row = t * 32 + l32;
-          const float* bs = T + (row < 72 ? row : 0) * DCN_FB_ROW + 32 * half;
+          const float* bs = T + (24 * t + (l32 < 24 ? l32 : 0)) * DCN_FB_ROW + 32 * half;
           float4 b4[8];
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
             b4[j] = *(const float4*)(bs + 4 * j);
-            if (row >= 72) b4[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (l32 >= 24) b4[j] = make_float4(0.f, 0.f, 0.f, 0.f);
           }
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
@@ -1891,13 +1916,9 @@ __global__ __launch_bounds__(256, OCC) void dcn_bwd_fused_kernel(const float* __
     // ---- output row ho - 3 is complete
     {
 #pragma unroll
-      for (int cc = 0; cc < 8; ++cc)
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(gold[cc] + ring[cc][0]), rgi, vg, cc * HW * 4, 0);
-#pragma unroll
       for (int cc = 0; cc < 8; ++cc) {
-#pragma unroll
-        for (int q = 0; q < 6; ++q) ring[cc][q] = ring[cc][q + 1];
-        ring[cc][6] = 0.f;
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(gold[cc] + R[cc * 448 + rs[0]]), rgi, vg, cc * HW * 4, 0);
+        R[cc * 448 + rs[0]] = 0.f;   // the slot is output row ho + 4 from the next position row on
       }
     }
   }
@@ -1909,7 +1930,7 @@ __global__ __launch_bounds__(256, OCC) void dcn_bwd_fused_kernel(const float* __
 #pragma unroll
       for (int cc = 0; cc < 8; ++cc) {
         const float old = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rgi, vg, cc * HW * 4, 0));
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(old + ring[cc][e]), rgi, vg, cc * HW * 4, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(old + R[cc * 448 + ((orow + 7) % 7) * 64]), rgi, vg, cc * HW * 4, 0);
       }
     }
   }
@@ -1917,11 +1938,11 @@ __global__ __launch_bounds__(256, OCC) void dcn_bwd_fused_kernel(const float* __
     const int ck_total = g.c * 9;
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
-      const int r = t * 32 + l32;
+      const int col = dgi * 72 + (l32 / 3) * 9 + 3 * t + l32 % 3;   // local row l32 = 3 cc + j of tap row t
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int co = 8 * (i >> 2) + 4 * half + (i & 3);
-        if (co < g.co && r < 72) atomicAdd(gw + (long)co * ck_total + dgi * 72 + r, scale * gacc[t][i]);
+        if (co < g.co && l32 < 24) atomicAdd(gw + (long)co * ck_total + col, scale * gacc[t][i]);
       }
     }
   }
@@ -2021,26 +2042,23 @@ static int dcn_backward_fused(const float* input, const float* offset, const flo
   segs = (g.h + seg_rows - 1) / seg_rows;
   unsigned* rec = (unsigned*)ws;
   if (hipMemsetAsync(rec, 0, 8, s) != hipSuccess) return RTP_ERR_LAUNCH;
-  const size_t lds = sizeof(float) * 4 * 72 * DCN_FB_ROW;
+  const size_t lds = sizeof(float) * 4 * (72 * DCN_FB_ROW + 8 * 7 * 64);   // tiles + rings: 135 680 B, one block per CU
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)dcn_bwd_fused_kernel<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute((const void*)dcn_bwd_fused_kernel<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute((const void*)dcn_bwd_fused_kernel<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute((const void*)dcn_bwd_fused_kernel<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)dcn_bwd_fused_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)dcn_bwd_fused_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr = true;
   }
-  const char* oe = getenv("RTP_DCN_OCC");
-  const int occ = oe && atoi(oe) == 2 ? 2 : 1;
   const char* se = getenv("RTP_DCN_SPLIT_GW");   // weight gradient by dcn_gradw_fused_kernel (its own gather pass)
   const bool split = gradWeight && se && atoi(se) && dcn_gradw_fused_ok(g);
   float* gwk = split ? nullptr : gradWeight;
   const dim3 grid((unsigned)((long)g.n * segs * strips));
-#define DCN_FB_LAUNCH(GW_, OCC_)                                                                                            \
-  hipLaunchKernelGGL((dcn_bwd_fused_kernel<GW_, OCC_>), grid, dim3(256), lds, s, input, offset, gradOutput, weight, gradInput, \
-                     gradOffset, gwk, rec, g, scale, strips, segs, seg_rows)
-  if (gwk) { if (occ == 2) DCN_FB_LAUNCH(true, 2); else DCN_FB_LAUNCH(true, 1); }
-  else { if (occ == 2) DCN_FB_LAUNCH(false, 2); else DCN_FB_LAUNCH(false, 1); }
+  if (gwk)
+    hipLaunchKernelGGL(dcn_bwd_fused_kernel<true>, grid, dim3(256), lds, s, input, offset, gradOutput, weight, gradInput,
+                       gradOffset, gwk, rec, g, scale, strips, segs, seg_rows);
+  else
+    hipLaunchKernelGGL(dcn_bwd_fused_kernel<false>, grid, dim3(256), lds, s, input, offset, gradOutput, weight, gradInput,
+                       gradOffset, gwk, rec, g, scale, strips, segs, seg_rows);
   if (split) dcn_gradw_fused_launch(input, offset, nullptr, gradOutput, gradWeight, g, scale, s);
   hipLaunchKernelGGL(dcn_bwd_outlier_rows_kernel, dim3(1024), dim3(64), 0, s, offset, gradOutput, weight, gradInput, rec, g);
   RTP_CHECK_LAUNCH();

@@ -1,20 +1,18 @@
 #!/bin/bash
 cd "$(dirname "$0")/.." && mkdir -p gpurun_out
 timeout 900 python3 -m pytest tests/test_gpu_dcn.py -x -q -k "one_pass" 2>&1 | tail -5 > gpurun_out/r03_dcn_tests.txt
-RTP_DCN_OCC=2 timeout 900 python3 -m pytest tests/test_gpu_dcn.py -x -q -k "one_pass" 2>&1 | tail -5 >> gpurun_out/r03_dcn_tests.txt
 {
-for occ in 1 2; do for split in 0 1; do for segs in 1 2 3; do
-  echo "== occ=$occ split=$split segs=$segs"; RTP_DCN_OCC=$occ RTP_DCN_SPLIT_GW=$split RTP_DCN_SEGS=$segs timeout 300 python3 tools/bench_dcn.py 2>/dev/null | head -1
-done; done; done
+for split in 0 1; do for segs in 0 1 2 3; do
+  echo "== split=$split segs=$segs"; RTP_DCN_SPLIT_GW=$split RTP_DCN_SEGS=$segs timeout 300 python3 tools/bench_dcn.py 2>/dev/null | head -1
+done; done
 } > gpurun_out/r03_dcn_bench.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
-RTP_DCN_SEGS=2 timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof_dcn -o run -- python3 $GRAFT_REPO_ROOT/tools/bench_dcn.py > /dev/null 2>&1
-RTP_DCN_SEGS=2 RTP_DCN_SPLIT_GW=1 timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof_dcn_split -o run -- python3 $GRAFT_REPO_ROOT/tools/bench_dcn.py > /dev/null 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof_dcn -o run -- python3 $GRAFT_REPO_ROOT/tools/bench_dcn.py > /dev/null 2>&1
 cd $GRAFT_REPO_ROOT
 cat gpurun_out/r03_dcn_tests.txt gpurun_out/r03_dcn_bench.txt
 python3 - <<'PY'
 import sqlite3,glob
-for d in ("prof_dcn","prof_dcn_split"):
+for d in ("prof_dcn",):
     db=glob.glob('gpurun_out/%s/*.db'%d)[0]
     c=sqlite3.connect(db)
     tabs=[r[0] for r in c.execute("select name from sqlite_master where type='table'")]
