@@ -1690,12 +1690,13 @@ __global__ __launch_bounds__(256, 1) void dcn_bwd_fused_kernel(const float* __re
 #pragma unroll
     for (int r = 0; r < 16; ++r) gacc[t][r] = 0.f;
 
-  // Software pipeline of the march (one wave per SIMD: nothing else hides latency).  Column rows are ordered tap row first
-  // (row 24 i + 3 cc + j for tap (i, j) of channel cc), so a tap row is one MFMA tile (24 of 32 rows used): while tap row i of
-  // position row ho runs on the vector ALU, the matrix core computes tile i of the NEXT row's column gradient, four MFMAs per
-  // channel iteration, into the accumulators tile i of this row just left (they were written to the LDS tile right before the
-  // tap row started).  gO operands are loaded two rows ahead, offsets one row ahead into the registers their predecessors
-  // leave, corner pairs two channels ahead, the old grad_input row before the taps; the weights stay in registers.
+  // Software pipeline of the march (one wave per SIMD: nothing else hides latency; a wave cannot run its own MFMAs under its own
+  // vector instructions either -- tools/ubench/issue_rates: 2 MFMA + 32 FMA interleaved take the sum of both -- so the column
+  // gradient is simply computed at the start of the row).  Column rows are ordered tap row first (row 24 i + 3 cc + j for tap
+  // (i, j) of channel cc), so a tap row is one MFMA tile (24 of 32 rows used).  gO operands and offsets are loaded one row ahead
+  // into the registers their predecessors leave, a tap row's addresses and first corner pairs during the previous tap row, corner
+  // pairs two channels ahead, the old grad_input row and the weight gradient's gO rows before the taps; the weights stay in
+  // registers.
   float wa[3][16];    // A operand of tile i: W[co = 2 kk + half][group column of local row l32]
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
@@ -1704,7 +1705,7 @@ __global__ __launch_bounds__(256, 1) void dcn_bwd_fused_kernel(const float* __re
     for (int kk = 0; kk < 16; ++kk)
       wa[i][kk] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rw, vw + kk * (2 * g.c * 9 * 4), 0, 0));
   }
-  float bvA[2][16], bvB[2][16];   // B operand gO[co = 2 kk + half][position 32 nt + l32]: of the row whose column gradient is being computed / the one after
+  float bvA[2][16];   // B operand gO[co = 2 kk + half][position 32 nt + l32] of the row
   float ofs[18];                  // the position's 18 offsets of the row
 #define DCN_FB_LOAD_BV(DST_, ROW_)                                                                                             \
   _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) {                                                                           \
@@ -1719,21 +1720,60 @@ __global__ __launch_bounds__(256, 1) void dcn_bwd_fused_kernel(const float* __re
 #pragma unroll
     for (int q = 0; q < 18; ++q) ofs[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rof, vof, q * HW * 4, 0));
   }
-  dcn_f32x16 d[3][2];   // column gradient tiles [tap row][position half]
-#pragma unroll
-  for (int i = 0; i < 3; ++i)
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) d[i][nt][r] = 0.f;
-#pragma unroll
-      for (int kk = 0; kk < 16; ++kk) d[i][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[i][kk], bvA[nt][kk], d[i][nt], 0, 0, 0);
-    }
-  DCN_FB_LOAD_BV(bvA, hs + 1)
-  DCN_FB_LOAD_BV(bvB, hs + 2)
+  // Gather addresses of a tap row and the corner pairs of its first two channels, requested while the PREVIOUS tap row's last
+  // channels are in work (its offsets are in the registers already): a tap row used to start by waiting for its first gathers
+  int na0[3], na1[3];
+  dcn_u32x2 nqa[2][3], nqb[2][3];
+#define DCN_FB_NEXT_TAP_ROW(I_, HO_, OWN_)                                                                                     \
+  _Pragma("unroll") for (int j = 0; j < 3; ++j) {                                                                              \
+    const float hi = (float)((HO_) - 1 + (I_)) + ofs[2 * (3 * (I_) + j)], wi = (float)(wo - 1 + j) + ofs[2 * (3 * (I_) + j) + 1]; \
+    const bool in = hi > -1.f && wi > -1.f && hi < (float)H && wi < (float)W;                                                  \
+    const int h_low = (int)floorf(hi), w_low = (int)floorf(wi);                                                                \
+    const int xs = w_low < 0 ? 0 : (w_low + 1 <= W - 1 ? w_low : W - 2);                                                       \
+    const int base = (h_low * W + xs) * 4;                                                                                     \
+    const bool act = (OWN_) && in;                                                                                             \
+    na0[j] = (act && h_low >= 0) ? base : DCN_OOB;                                                                             \
+    na1[j] = (act && h_low + 1 <= H - 1) ? base + W * 4 : DCN_OOB;                                                             \
+    nqa[0][j] = __builtin_amdgcn_raw_buffer_load_b64(rx, na0[j] + (dgi * 8) * HW * 4, 0, 0);                                   \
+    nqb[0][j] = __builtin_amdgcn_raw_buffer_load_b64(rx, na1[j] + (dgi * 8) * HW * 4, 0, 0);                                   \
+    nqa[1][j] = __builtin_amdgcn_raw_buffer_load_b64(rx, na0[j] + (dgi * 8 + 1) * HW * 4, 0, 0);                               \
+    nqb[1][j] = __builtin_amdgcn_raw_buffer_load_b64(rx, na1[j] + (dgi * 8 + 1) * HW * 4, 0, 0);                               \
+  }
+  DCN_FB_NEXT_TAP_ROW(0, hs, (hs >= r0 && hs < r1 && own_x))
 
   for (int ho = hs; ho < he; ++ho) {
     const bool own_row = ho >= r0 && ho < r1;   // wave-uniform: halo rows only feed the input-gradient ring
+    const bool own_next = ho + 1 >= r0 && ho + 1 < r1 && ho + 1 < he && own_x;
+    // gO rows of the weight gradient (A operand, lane = output channel): requested now, used after the taps
+    dcn_f32x4 a4[8];
+    if (WITH_GW) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int w4 = x0 + 32 * half + 4 * j;   // 4-aligned group, W % 4 == 0: wholly inside or wholly outside the row
+        const int va = (own_row && w4 >= 0 && w4 < W) ? (l32 * HW + ho * W + w4) * 4 : DCN_OOB;
+        a4[j] = __builtin_bit_cast(dcn_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rgo, va, 0, 0));
+      }
+    }
+    // ---- (1) the row's column gradient, tile i -> T[24 i + (cc, j)][lane]; D[m][n]: lane l, register r -> n = l % 32,
+    // m = 8 (r / 4) + 4 (l / 32) + r % 4 (rows 24 .. 31 do not exist)
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      dcn_f32x16 d[2];
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) d[nt][r] = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) d[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[i][kk], bvA[nt][kk], d[nt], 0, 0, 0);
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int r = 0; r < 12; ++r) T[(24 * i + 8 * (r >> 2) + 4 * half + (r & 3)) * DCN_FB_ROW + 32 * nt + l32] = d[nt][r];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    DCN_FB_LOAD_BV(bvA, ho + 1)   // consumed: the registers take the next row's
     int rs[7];   // ring slot (x 64 floats) of output row ho - 3 + q
 #pragma unroll
     for (int q = 0; q < 7; ++q) rs[q] = ((ho + 4 + q) % 7) * 64;
@@ -1748,19 +1788,11 @@ __global__ __launch_bounds__(256, 1) void dcn_bwd_fused_kernel(const float* __re
     bool outl = false;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-      // ---- (1) tile i of this row's column gradient -> T[24 i + (cc, j)][lane]; D[m][n]: lane l, register r -> n = l % 32,
-      // m = 8 (r / 4) + 4 (l / 32) + r % 4 (rows 24 .. 31 do not exist); the accumulators start the next row's tile
-#pragma unroll
-      for (int nt = 0; nt < 2; ++nt) {
-#pragma unroll
-        for (int r = 0; r < 12; ++r) T[(24 * i + 8 * (r >> 2) + 4 * half + (r & 3)) * DCN_FB_ROW + 32 * nt + l32] = d[i][nt][r];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) d[i][nt][r] = 0.f;
-      }
       // ---- (2) + (3): the tap row
       int a0[3], a1[3];
       float lh[3], wh[3][5], ww[3][5], gh[3], gwc[3];
       dcn_f32x2 wxy[3], exy[3];   // what the loaded column pair contributes to the row's sample / to d sample / d w
+      bool wide = false;
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
         const int t = 3 * i + j;
@@ -1776,6 +1808,7 @@ __global__ __launch_bounds__(256, 1) void dcn_bwd_fused_kernel(const float* __re
         const int ia = h_low - nh + 2, ib = w_low - nw + 2;   // patch row / column of the top-left corner
         const bool inpatch = pos_x && (unsigned)ia < 4u && (unsigned)ib < 4u;
         outl = outl || (own && in && !inpatch);
+        wide = wide || (inpatch && ((unsigned)(ia - 1) > 1u || (unsigned)(ib - 1) > 1u));   // leaves the inner 3 x 3 footprint
 #pragma unroll
         for (int q = 0; q < 5; ++q) {
           wh[j][q] = inpatch ? ((q == ia ? hh : 0.f) + (q == ia + 1 ? lh[j] : 0.f)) : 0.f;
@@ -1787,10 +1820,7 @@ __global__ __launch_bounds__(256, 1) void dcn_bwd_fused_kernel(const float* __re
         const int xs = w_low < 0 ? 0 : (c1 ? w_low : W - 2);
         wxy[j] = c0 ? (c1 ? dcn_f32x2{hw, lw} : dcn_f32x2{0.f, hw}) : dcn_f32x2{lw, 0.f};
         exy[j] = c0 ? (c1 ? dcn_f32x2{-1.f, 1.f} : dcn_f32x2{0.f, -1.f}) : dcn_f32x2{1.f, 0.f};
-        const int base = (h_low * W + xs) * 4;
-        const bool act = own && in;
-        a0[j] = (act && h_low >= 0) ? base : DCN_OOB;
-        a1[j] = (act && h_low + 1 <= H - 1) ? base + W * 4 : DCN_OOB;
+        a0[j] = na0[j]; a1[j] = na1[j];   // computed (and the first two channels requested) during the previous tap row
         gh[j] = 0.f; gwc[j] = 0.f;
       }
       // corner pairs of channels cc + 1, cc + 2 are in flight while channel cc is consumed (halo rows / lanes that do not own
@@ -1801,71 +1831,116 @@ __global__ __launch_bounds__(256, 1) void dcn_bwd_fused_kernel(const float* __re
     qa[(CH_) % 3][j] = __builtin_amdgcn_raw_buffer_load_b64(rx, a0[j] + (dgi * 8 + (CH_)) * HW * 4, 0, 0);                    \
     qb[(CH_) % 3][j] = __builtin_amdgcn_raw_buffer_load_b64(rx, a1[j] + (dgi * 8 + (CH_)) * HW * 4, 0, 0);                    \
   }
-      DCN_FB_GATHER(0)
-      DCN_FB_GATHER(1)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) { qa[0][j] = nqa[0][j]; qb[0][j] = nqb[0][j]; qa[1][j] = nqa[1][j]; qb[1][j] = nqb[1][j]; }
       // this tap row's offsets are consumed: their registers take the next row's
 #pragma unroll
       for (int q = 6 * i; q < 6 * i + 6; ++q) ofs[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rof, vof1, q * HW * 4, 0));
+      // what every tap of every channel does whatever the patch: column gradient value, the gathered pair -> sample, coordinate
+      // gradient
+#define DCN_FB_TAP(J_)                                                                                                         \
+  const int m = 24 * i + 3 * cc + (J_);                                                                                        \
+  const float gv = T[m * DCN_FB_ROW + lane];                                                                                   \
+  {                                                                                                                            \
+    const dcn_u32x2 q0 = qa[cc % 3][J_], q1 = qb[cc % 3][J_];                                                                  \
+    const dcn_f32x2 px = {__uint_as_float(q0.x), __uint_as_float(q1.x)}, py = {__uint_as_float(q0.y), __uint_as_float(q1.y)}; \
+    const dcn_f32x2 tb = wxy[J_].x * px + wxy[J_].y * py; /* (top, bottom) row samples */                                      \
+    const dcn_f32x2 dd = exy[J_].x * px + exy[J_].y * py; /* their d / d w */                                                  \
+    const float dv = tb.y - tb.x;                         /* d sample / d h */                                                 \
+    if (WITH_GW) T[m * DCN_FB_ROW + lane] = tb.x + lh[J_] * dv; /* the sample (0 for positions this wave does not own) */      \
+    gh[J_] += gv * dv;                                                                                                         \
+    gwc[J_] += gv * (dd.x + lh[J_] * (dd.y - dd.x));                                                                           \
+  }
+      // pin the order of a channel iteration: without this the compiler sinks all 48 gathers of the tap row below the patch
+      // arithmetic (and spills the 24 column-gradient values they are multiplied with)
+#define DCN_FB_PIN()                                                                                                           \
+  asm volatile("" : "+v"(gh[0]), "+v"(gh[1]), "+v"(gh[2]), "+v"(gwc[0]), "+v"(gwc[1]), "+v"(gwc[2]));                          \
+  __builtin_amdgcn_sched_barrier(0);
+      if (__builtin_amdgcn_ballot_w64(wide) == 0) {
+        // every sample of the tap row within one pixel of its undeformed position (wave-uniform; always so while the offset
+        // conv is near its zero initialisation): 3 x 3 footprints, a 3 x 5 patch (rows 1 .. 3, columns 1 .. 5 of the general
+        // one, as pairs (1,2) (3,4) 5), five shifts per row
 #pragma unroll
-      for (int cc = 0; cc < 8; ++cc) {
-        if (cc < 6) DCN_FB_GATHER(cc + 2)
-        float rv[5];
+        for (int cc = 0; cc < 8; ++cc) {
+          if (cc < 6) DCN_FB_GATHER(cc + 2)
+          if (cc == 5) { if (i < 2) { DCN_FB_NEXT_TAP_ROW(i + 1, ho, own) } else { DCN_FB_NEXT_TAP_ROW(0, ho + 1, own_next) } }
+          float rv[3];
 #pragma unroll
-        for (int a = 0; a < 5; ++a) rv[a] = R[cc * 448 + rs[i + a]];
-        // 5 x 7 patch of the tap row as packed pairs (v_pk_fma_f32): columns (0,1) (2,3) (4,5) 6
-        dcn_f32x2 L01[5], L23[5], L45[5];
-        float L6[5];
+          for (int a = 0; a < 3; ++a) rv[a] = R[cc * 448 + rs[i + 1 + a]];
+          dcn_f32x2 N12[3], N34[3];
+          float N5[3];
 #pragma unroll
-        for (int a = 0; a < 5; ++a) { L01[a] = dcn_f32x2{0.f, 0.f}; L23[a] = dcn_f32x2{0.f, 0.f}; L45[a] = dcn_f32x2{0.f, 0.f}; L6[a] = 0.f; }
+          for (int a = 0; a < 3; ++a) { N12[a] = dcn_f32x2{0.f, 0.f}; N34[a] = dcn_f32x2{0.f, 0.f}; N5[a] = 0.f; }
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-          const int m = 24 * i + 3 * cc + j;
-          const float gv = T[m * DCN_FB_ROW + lane];
-          {
-            const dcn_u32x2 q0 = qa[cc % 3][j], q1 = qb[cc % 3][j];
-            const dcn_f32x2 px = {__uint_as_float(q0.x), __uint_as_float(q1.x)}, py = {__uint_as_float(q0.y), __uint_as_float(q1.y)};
-            const dcn_f32x2 tb = wxy[j].x * px + wxy[j].y * py;   // (top, bottom) row samples
-            const dcn_f32x2 dd = exy[j].x * px + exy[j].y * py;   // their d / d w
-            const float dv = tb.y - tb.x;                        // d sample / d h
-            if (WITH_GW) T[m * DCN_FB_ROW + lane] = tb.x + lh[j] * dv;   // the sample (0 for positions this wave does not own)
-            gh[j] += gv * dv;
-            gwc[j] += gv * (dd.x + lh[j] * (dd.y - dd.x));
+          for (int j = 0; j < 3; ++j) {
+            DCN_FB_TAP(j)
+            const float s1 = ww[j][1] * gv, s2 = ww[j][2] * gv, s3 = ww[j][3] * gv;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+              const float h = wh[j][a + 1];
+              if (j == 0) { N12[a] += h * dcn_f32x2{s1, s2}; N34[a].x += h * s3; }
+              if (j == 1) { N12[a].y += h * s1; N34[a] += h * dcn_f32x2{s2, s3}; }
+              if (j == 2) { N34[a] += h * dcn_f32x2{s1, s2}; N5[a] += h * s3; }
+            }
           }
-          const float s0 = ww[j][0] * gv, s1 = ww[j][1] * gv, s2 = ww[j][2] * gv, s3 = ww[j][3] * gv, s4 = ww[j][4] * gv;
+          float acc[3];
 #pragma unroll
-          for (int a = 0; a < 5; ++a) {
-            const float h = wh[j][a];
-            if (j == 0) { L01[a] += h * dcn_f32x2{s0, s1}; L23[a] += h * dcn_f32x2{s2, s3}; L45[a].x += h * s4; }
-            if (j == 1) { L01[a].y += h * s0; L23[a] += h * dcn_f32x2{s1, s2}; L45[a] += h * dcn_f32x2{s3, s4}; }
-            if (j == 2) { L23[a] += h * dcn_f32x2{s0, s1}; L45[a] += h * dcn_f32x2{s2, s3}; L6[a] += h * s4; }
-          }
-          // the matrix core's share of this iteration: k steps 2 cc, 2 cc + 1 of tile i of the next row's column gradient
-          if (j < 2) {
-            const int kk = 2 * cc + j;
-            d[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[i][kk], bvA[0][kk], d[i][0], 0, 0, 0);
-            d[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[i][kk], bvA[1][kk], d[i][1], 0, 0, 0);
-          }
+          for (int a = 0; a < 3; ++a) acc[a] = N5[a];
+#define DCN_FB_SHIFT_ADD3(SRC_)                                                                                                \
+  _Pragma("unroll") for (int a = 0; a < 3; ++a) acc[a] = dcn_wave_shr1(acc[a]) + SRC_;                                         \
+  asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]));
+          DCN_FB_SHIFT_ADD3(N34[a].y)
+          DCN_FB_SHIFT_ADD3(N34[a].x)
+          DCN_FB_SHIFT_ADD3(N12[a].y)
+          DCN_FB_SHIFT_ADD3(N12[a].x)
+          DCN_FB_SHIFT_ADD3(0.f)   // column 0 of the general patch is empty
+#pragma unroll
+          for (int a = 0; a < 3; ++a) R[cc * 448 + rs[i + 1 + a]] = rv[a] + acc[a];
+          DCN_FB_PIN()
         }
-        // x reduction, the five patch rows' chains interleaved: a DPP read of a register the previous instruction wrote costs
-        // two wait states (the chain-by-chain order stalled 8 cycles per shift: a quarter of the kernel)
-        float acc[5];
+      } else {
 #pragma unroll
-        for (int a = 0; a < 5; ++a) acc[a] = L6[a];
+        for (int cc = 0; cc < 8; ++cc) {
+          if (cc < 6) DCN_FB_GATHER(cc + 2)
+          if (cc == 5) { if (i < 2) { DCN_FB_NEXT_TAP_ROW(i + 1, ho, own) } else { DCN_FB_NEXT_TAP_ROW(0, ho + 1, own_next) } }
+          float rv[5];
+#pragma unroll
+          for (int a = 0; a < 5; ++a) rv[a] = R[cc * 448 + rs[i + a]];
+          // 5 x 7 patch of the tap row as packed pairs (v_pk_fma_f32): columns (0,1) (2,3) (4,5) 6
+          dcn_f32x2 L01[5], L23[5], L45[5];
+          float L6[5];
+#pragma unroll
+          for (int a = 0; a < 5; ++a) { L01[a] = dcn_f32x2{0.f, 0.f}; L23[a] = dcn_f32x2{0.f, 0.f}; L45[a] = dcn_f32x2{0.f, 0.f}; L6[a] = 0.f; }
+#pragma unroll
+          for (int j = 0; j < 3; ++j) {
+            DCN_FB_TAP(j)
+            const float s0 = ww[j][0] * gv, s1 = ww[j][1] * gv, s2 = ww[j][2] * gv, s3 = ww[j][3] * gv, s4 = ww[j][4] * gv;
+#pragma unroll
+            for (int a = 0; a < 5; ++a) {
+              const float h = wh[j][a];
+              if (j == 0) { L01[a] += h * dcn_f32x2{s0, s1}; L23[a] += h * dcn_f32x2{s2, s3}; L45[a].x += h * s4; }
+              if (j == 1) { L01[a].y += h * s0; L23[a] += h * dcn_f32x2{s1, s2}; L45[a] += h * dcn_f32x2{s3, s4}; }
+              if (j == 2) { L23[a] += h * dcn_f32x2{s0, s1}; L45[a] += h * dcn_f32x2{s2, s3}; L6[a] += h * s4; }
+            }
+          }
+          // x reduction, the five patch rows' chains interleaved: a DPP read of a register the previous instruction wrote costs
+          // two wait states (the chain-by-chain order stalled 8 cycles per shift)
+          float acc[5];
+#pragma unroll
+          for (int a = 0; a < 5; ++a) acc[a] = L6[a];
 #define DCN_FB_SHIFT_ADD(SRC_)                                                                                                 \
   _Pragma("unroll") for (int a = 0; a < 5; ++a) acc[a] = dcn_wave_shr1(acc[a]) + SRC_;                                         \
   asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]));
-        DCN_FB_SHIFT_ADD(L45[a].y)
-        DCN_FB_SHIFT_ADD(L45[a].x)
-        DCN_FB_SHIFT_ADD(L23[a].y)
-        DCN_FB_SHIFT_ADD(L23[a].x)
-        DCN_FB_SHIFT_ADD(L01[a].y)
-        DCN_FB_SHIFT_ADD(L01[a].x)
+          DCN_FB_SHIFT_ADD(L45[a].y)
+          DCN_FB_SHIFT_ADD(L45[a].x)
+          DCN_FB_SHIFT_ADD(L23[a].y)
+          DCN_FB_SHIFT_ADD(L23[a].x)
+          DCN_FB_SHIFT_ADD(L01[a].y)
+          DCN_FB_SHIFT_ADD(L01[a].x)
 #pragma unroll
-        for (int a = 0; a < 5; ++a) R[cc * 448 + rs[i + a]] = rv[a] + acc[a];
-        // pin the order: without this the compiler sinks all 48 gathers of the tap row below the patch arithmetic (and spills
-        // the 24 column-gradient values they are multiplied with)
-        asm volatile("" : "+v"(gh[0]), "+v"(gh[1]), "+v"(gh[2]), "+v"(gwc[0]), "+v"(gwc[1]), "+v"(gwc[2]));
-        __builtin_amdgcn_sched_barrier(0);
+          for (int a = 0; a < 5; ++a) R[cc * 448 + rs[i + a]] = rv[a] + acc[a];
+          DCN_FB_PIN()
+        }
       }
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
@@ -1873,12 +1948,6 @@ __global__ __launch_bounds__(256, 1) void dcn_bwd_fused_kernel(const float* __re
         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(gwc[j]), rgf, vgf, (2 * (3 * i + j) + 1) * HW * 4, 0);
       }
     }
-    // gO: the next row's operands move up, the row after them is requested
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-      for (int kk = 0; kk < 16; ++kk) bvA[nt][kk] = bvB[nt][kk];
-    DCN_FB_LOAD_BV(bvB, ho + 3)
     if (own_row) {
       if (__builtin_amdgcn_ballot_w64(outl) != 0 && lane == 0) {
         const unsigned idx = atomicAdd(rec, 1u);
@@ -1887,13 +1956,6 @@ __global__ __launch_bounds__(256, 1) void dcn_bwd_fused_kernel(const float* __re
       }
       // ---- (4) weight gradient of the row: gacc[t][co][local column row] += gO[co][pos] * sample[24 t + local row][pos]
       if (WITH_GW) {
-        dcn_f32x4 a4[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int w4 = x0 + 32 * half + 4 * j;   // 4-aligned group, W % 4 == 0: wholly inside or wholly outside the row
-          const int va = (w4 >= 0 && w4 < W) ? (l32 * HW + ho * W + w4) * 4 : DCN_OOB;
-          a4[j] = __builtin_bit_cast(dcn_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rgo, va, 0, 0));
-        }
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
           const float* bs = T + (24 * t + (l32 < 24 ? l32 : 0)) * DCN_FB_ROW + 32 * half;
