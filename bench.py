@@ -171,8 +171,7 @@ def dcn_op_bench(dev, batch, iters=10):
             v.grad = None
         fwd().backward(gy)
 
-    out = {}
-    for name, f in (("forward_ms", fwd), ("forward_backward_ms", fb)):
+    def timed(f):
         for _ in range(3):
             f()
         torch.cuda.synchronize()
@@ -180,7 +179,16 @@ def dcn_op_bench(dev, batch, iters=10):
         for _ in range(iters):
             f()
         torch.cuda.synchronize()
-        out[name] = round((time.perf_counter() - t0) / iters * 1e3, 3)
+        return round((time.perf_counter() - t0) / iters * 1e3, 3)
+
+    out = {"forward_ms": timed(fwd), "forward_backward_ms": timed(fb)}
+    out["backward_ms"] = round(out["forward_backward_ms"] - out["forward_ms"], 3)
+    # the same call with every sample within a pixel of its tap (what the DCN head's zero-initialised offset conv produces): the
+    # one-pass backward takes its 3 x 3-footprint branch
+    with torch.no_grad():
+        off.mul_(0.4)
+    out["offsets_within_a_pixel"] = {"offset_sigma_px": 0.2, "forward_ms": timed(fwd), "forward_backward_ms": timed(fb)}
+    out["offset_sigma_px"] = 0.5
     alg = (x.numel() + off.numel() + gy.numel()) * 4
     out.update(workload="DCNv1 3x3 [%d,%d,%d,%d] -> %d, deformable_groups 4, im2col_step 64, fp32 (BASELINE config 4, op level)" % (n, c, h, w, co),
                forward_algorithmic_GBps=round(alg / out["forward_ms"] / 1e6, 1),
