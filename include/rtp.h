@@ -472,6 +472,11 @@ int rtp_deform_conv_backward(const float* input, const float* offset, const floa
                              float* gradOffset, const float* weight, float* gradWeight, void* ws, int n, int c, int h,
                              int w, int co, int kW, int kH, int dW, int dH, int padW, int padH, int dilW, int dilH,
                              int group, int deformable_group, float scale, int im2col_step, void* stream);
+/* The same for callers that own fresh gradient buffers: the three outputs are OVERWRITTEN (no zero-initialisation needed). */
+int rtp_deform_conv_backward_overwrite(const float* input, const float* offset, const float* gradOutput, float* gradInput,
+                                       float* gradOffset, const float* weight, float* gradWeight, void* ws, int n, int c,
+                                       int h, int w, int co, int kW, int kH, int dW, int dH, int padW, int padH, int dilW,
+                                       int dilH, int group, int deformable_group, float scale, int im2col_step, void* stream);
 int rtp_modulated_deform_conv_forward(const float* input, const float* weight, const float* bias, const float* offset,
                                       const float* mask, float* output, void* ws, int n, int c, int h, int w, int co,
                                       int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw, int group,

@@ -133,6 +133,7 @@ PROTOTYPES = {
     "rtp_deform_conv_backward_input": [_P, _P, _P, _P, _P, _P, _P] + [_I] * 16 + [_P],
     "rtp_deform_conv_backward_parameters": [_P, _P, _P, _P, _P] + [_I] * 15 + [_F, _I, _P],
     "rtp_deform_conv_backward": [_P] * 8 + [_I] * 15 + [_F, _I, _P],
+    "rtp_deform_conv_backward_overwrite": [_P] * 8 + [_I] * 15 + [_F, _I, _P],
     "rtp_modulated_deform_conv_forward": [_P, _P, _P, _P, _P, _P, _P] + [_I] * 16 + [_P],
     "rtp_modulated_deform_conv_backward": [_P] * 12 + [_I] * 16 + [_P],
     "rtp_prof_enable": [_I, _I],

@@ -422,12 +422,13 @@ class HipBackend:
             keepb = [gy, gx, goff_v, gyf] + zero
 
             def bwd(s):
-                for t in zero:   # the operator accumulates into its gradient outputs (deform_conv.py:75-76, 86)
-                    check(lib.rtp_zero_f32(_ptr(t), t.numel(), s), "rtp_zero_f32")
+                # the plan owns the three gradient buffers: the overwriting entry (no zero fills; the reference's wrapper
+                # allocates zeros and accumulates, deform_conv.py:75-76, 86)
                 check(lib.rtp_unpack_ncdhw(gya, _ptr(gyf), N, C, vox, s), "rtp_unpack_ncdhw")
-                check(lib.rtp_deform_conv_backward(_ptr(xf), _ptr(off), _ptr(gyf), _ptr(gi), _ptr(goff), _ptr(w_ad), _ptr(gw_ad),
-                                                   _ptr(ws3), N, C, H, W, C, 3, 3, 1, 1, 1, 1, 1, 1, 1, dg, 1.0, step, s),
-                      "rtp_deform_conv_backward")
+                check(lib.rtp_deform_conv_backward_overwrite(_ptr(xf), _ptr(off), _ptr(gyf), _ptr(gi), _ptr(goff), _ptr(w_ad),
+                                                             _ptr(gw_ad), _ptr(ws3), N, C, H, W, C, 3, 3, 1, 1, 1, 1, 1, 1, 1, dg,
+                                                             1.0, step, s),
+                      "rtp_deform_conv_backward_overwrite")
                 check(lib.rtp_pack_ncdhw_ex(_ptr(gi), None, gxa, N, C, vox, 0, s), "rtp_pack_ncdhw_ex")
                 check(lib.rtp_pack_ncdhw_ex(_ptr(goff), None, goa, N, koff, vox, 0, s), "rtp_pack_ncdhw_ex")
                 return keepb and None

@@ -98,11 +98,12 @@ class DeformConvFunction(Function):
         geo = (n, c, h, w, weight.size(0), weight.size(3), weight.size(2), ctx.stride[1], ctx.stride[0], ctx.padding[1],
                ctx.padding[0], ctx.dilation[1], ctx.dilation[0], ctx.groups, ctx.deformable_groups)
         if (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]) and ctx.needs_input_grad[2]:
-            grad_input, grad_offset, grad_weight = torch.zeros_like(input), torch.zeros_like(offset), torch.zeros_like(weight)
-            rc = lib.rtp_deform_conv_backward(_p(input), _p(offset), _p(grad_output), _p(grad_input), _p(grad_offset), _p(weight),
-                                              _p(grad_weight), _p(ws), *geo, 1.0, step, _stream(input))
+            # fresh buffers: the overwriting entry needs no zeros (deform_conv.py:75-76 allocates zeros and accumulates)
+            grad_input, grad_offset, grad_weight = torch.empty_like(input), torch.empty_like(offset), torch.empty_like(weight)
+            rc = lib.rtp_deform_conv_backward_overwrite(_p(input), _p(offset), _p(grad_output), _p(grad_input), _p(grad_offset),
+                                                        _p(weight), _p(grad_weight), _p(ws), *geo, 1.0, step, _stream(input))
             if rc != 0:
-                raise RuntimeError("rtp_deform_conv_backward failed (%d)" % rc)
+                raise RuntimeError("rtp_deform_conv_backward_overwrite failed (%d)" % rc)
             cast = lambda g, dt: g if g is None or g.dtype == dt else g.to(dt)
             return (cast(grad_input, dts[0]), cast(grad_offset, dts[1]), cast(grad_weight, dts[2]), None, None, None, None, None, None)
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:

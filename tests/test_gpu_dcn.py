@@ -326,9 +326,30 @@ def test_dcn_one_pass_backward(case, monkeypatch):
         assert rel_err(go, off.grad) < TOL, case
     else:
         assert rel_err(go, off.grad) < TOL or float(off.grad.abs().max()) == 0
+    monkeypatch.setenv("RTP_DCN_FP32_MFMA", "1")         # the two products on v_mfma_f32_32x32x2_f32 instead of the bf16 (hi, lo) split
+    fx, fw, fo = run()
+    monkeypatch.delenv("RTP_DCN_FP32_MFMA")
+    assert rel_err(fx, x.grad) < TOL and rel_err(fw, wt.grad) < TOL and rel_err(fo, go) < TOL, case
     monkeypatch.setenv("RTP_DCN_NO_FUSED_BWD", "1")      # the column route (im2col / GEMM / gather kernels) on the same inputs
     cx, cw, co_ = run()
     assert rel_err(gx, cx) < TOL and rel_err(gw, cw) < TOL and rel_err(go, co_) < TOL, case
+    # the accumulating entry (the reference's contract: the caller's buffers are added to) on buffers that hold ones
+    if together:
+        import ctypes as C
+        from rt_pose_amd import _lib
+        monkeypatch.delenv("RTP_DCN_NO_FUSED_BWD", raising=False)
+        lib = _lib.load()
+        xg, wg, og, gyg = [t.detach().cuda().contiguous() for t in (x, wt, off, gy)]
+        bi, bo, bw = torch.ones_like(xg), torch.ones_like(og), torch.ones_like(wg)
+        ws = torch.empty(lib.rtp_dcn_workspace_bytes(n, 32, h, w, co, 3, 3, h, w) // 4, device="cuda")
+        pv = lambda t: C.c_void_p(t.data_ptr())
+        rc = lib.rtp_deform_conv_backward(pv(xg), pv(og), pv(gyg), pv(bi), pv(bo), pv(wg), pv(bw), pv(ws), n, 32, h, w, co, 3, 3,
+                                          1, 1, 1, 1, 1, 1, 1, 4, 1.0, n, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        torch.cuda.synchronize()
+        assert rc == 0
+        assert rel_err(bi.cpu() - 1, x.grad) < 5 * TOL and rel_err(bw.cpu() - 1, wt.grad) < 5 * TOL, case
+        # grad_offset is assigned by both routes (deformable_col2im_coord writes, it does not add)
+        assert rel_err(bo.cpu(), off.grad) < TOL or (scale == 0 and float(off.grad.abs().max()) == 0), case
     # offsets within the patch everywhere: the input gradient has no atomics -> bit-reproducible
     if scale <= 0.5:
         monkeypatch.delenv("RTP_DCN_NO_FUSED_BWD", raising=False)

@@ -2,8 +2,9 @@
 cd "$(dirname "$0")/.." && mkdir -p gpurun_out
 timeout 900 python3 -m pytest tests/test_gpu_dcn.py tests/test_gpu_dcn_head.py -x -q -k "one_pass or head" 2>&1 | tail -5 > gpurun_out/r03_dcn_tests.txt
 {
-for sc in 0.5 0.2 0.0; do
+for sc in 0.5 0.2; do
   RTP_BENCH_DCN_OFF_SCALE=$sc timeout 300 python3 tools/bench_dcn.py 2>/dev/null | head -1
+  RTP_DCN_FP32_MFMA=1 RTP_BENCH_DCN_OFF_SCALE=$sc timeout 300 python3 tools/bench_dcn.py 2>/dev/null | head -1
 done
 } > gpurun_out/r03_dcn_bench.txt 2>&1
 B="--model hr3d_dcn --steps 20 --warmup 5 --no-cpu-baseline --no-torch-gpu --no-lidar --no-dcn --no-forward --no-roofline --no-other-models"
