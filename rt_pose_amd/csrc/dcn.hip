@@ -1641,6 +1641,7 @@ static void dcn_gradw_fused_launch(const float* input, const float* offset, cons
 // 3 x 755 MB of column traffic.
 #define DCN_FB_ROW 68   // floats per LDS row
 #define DCN_FB_XO 56    // output columns / owned positions per strip
+#define DCN_FB_PF 2      // corner pairs are requested this many channels ahead (3: register spills, no gain)
 typedef __bf16 dcn_bf16x8 __attribute__((ext_vector_type(8)));
 // x = hi + lo + O(2^-17 x) with hi, lo in bf16: an fp32 product on the bf16 matrix core as hi*hi + hi*lo + lo*hi (the dropped
 // lo*lo term is 2^-16 relative; tools/ubench/mfma_bf16x3: 3.9e-6 norm-wise at K = 32, a third of the fp32 MFMA's cycles)
@@ -1752,7 +1753,7 @@ __global__ __launch_bounds__(256, 1) void dcn_bwd_fused_kernel(const float* __re
   // Gather addresses of a tap row and the corner pairs of its first two channels, requested while the PREVIOUS tap row's last
   // channels are in work (its offsets are in the registers already): a tap row used to start by waiting for its first gathers
   int na0[3], na1[3];
-  dcn_u32x2 nqa[2][3], nqb[2][3];
+  dcn_u32x2 nqa[DCN_FB_PF][3], nqb[DCN_FB_PF][3];
 #define DCN_FB_NEXT_TAP_ROW(I_, HO_, OWN_)                                                                                     \
   _Pragma("unroll") for (int j = 0; j < 3; ++j) {                                                                              \
     const float hi = (float)((HO_) - 1 + (I_)) + ofs[2 * (3 * (I_) + j)], wi = (float)(wo - 1 + j) + ofs[2 * (3 * (I_) + j) + 1]; \
@@ -1763,10 +1764,10 @@ __global__ __launch_bounds__(256, 1) void dcn_bwd_fused_kernel(const float* __re
     const bool act = (OWN_) && in;                                                                                             \
     na0[j] = (act && h_low >= 0) ? base : DCN_OOB;                                                                             \
     na1[j] = (act && h_low + 1 <= H - 1) ? base + W * 4 : DCN_OOB;                                                             \
-    nqa[0][j] = __builtin_amdgcn_raw_buffer_load_b64(rx, na0[j] + (dgi * 8) * HW * 4, 0, 0);                                   \
-    nqb[0][j] = __builtin_amdgcn_raw_buffer_load_b64(rx, na1[j] + (dgi * 8) * HW * 4, 0, 0);                                   \
-    nqa[1][j] = __builtin_amdgcn_raw_buffer_load_b64(rx, na0[j] + (dgi * 8 + 1) * HW * 4, 0, 0);                               \
-    nqb[1][j] = __builtin_amdgcn_raw_buffer_load_b64(rx, na1[j] + (dgi * 8 + 1) * HW * 4, 0, 0);                               \
+    _Pragma("unroll") for (int ch = 0; ch < DCN_FB_PF; ++ch) {                                                                 \
+      nqa[ch][j] = __builtin_amdgcn_raw_buffer_load_b64(rx, na0[j] + (dgi * 8 + ch) * HW * 4, 0, 0);                           \
+      nqb[ch][j] = __builtin_amdgcn_raw_buffer_load_b64(rx, na1[j] + (dgi * 8 + ch) * HW * 4, 0, 0);                           \
+    }                                                                                                                          \
   }
   DCN_FB_NEXT_TAP_ROW(0, hs, (hs >= r0 && hs < r1 && own_x))
 
@@ -1871,16 +1872,18 @@ __global__ __launch_bounds__(256, 1) void dcn_bwd_fused_kernel(const float* __re
         a0[j] = na0[j]; a1[j] = na1[j];   // computed (and the first two channels requested) during the previous tap row
         gh[j] = 0.f; gwc[j] = 0.f;
       }
-      // corner pairs of channels cc + 1, cc + 2 are in flight while channel cc is consumed (halo rows / lanes that do not own
+      // corner pairs of channels cc + 1 .. cc + DCN_FB_PF are in flight while channel cc is consumed (halo rows / lanes that do not own
       // their position pass out-of-range addresses: zeros, no memory access)
-      dcn_u32x2 qa[3][3], qb[3][3];   // [stage = channel % 3][tap]
+      dcn_u32x2 qa[DCN_FB_PF + 1][3], qb[DCN_FB_PF + 1][3];   // [stage = channel % (DCN_FB_PF + 1)][tap]
 #define DCN_FB_GATHER(CH_)                                                                                                     \
   _Pragma("unroll") for (int j = 0; j < 3; ++j) {                                                                              \
-    qa[(CH_) % 3][j] = __builtin_amdgcn_raw_buffer_load_b64(rx, a0[j] + (dgi * 8 + (CH_)) * HW * 4, 0, 0);                    \
-    qb[(CH_) % 3][j] = __builtin_amdgcn_raw_buffer_load_b64(rx, a1[j] + (dgi * 8 + (CH_)) * HW * 4, 0, 0);                    \
+    qa[(CH_) % (DCN_FB_PF + 1)][j] = __builtin_amdgcn_raw_buffer_load_b64(rx, a0[j] + (dgi * 8 + (CH_)) * HW * 4, 0, 0);      \
+    qb[(CH_) % (DCN_FB_PF + 1)][j] = __builtin_amdgcn_raw_buffer_load_b64(rx, a1[j] + (dgi * 8 + (CH_)) * HW * 4, 0, 0);      \
   }
 #pragma unroll
-      for (int j = 0; j < 3; ++j) { qa[0][j] = nqa[0][j]; qb[0][j] = nqb[0][j]; qa[1][j] = nqa[1][j]; qb[1][j] = nqb[1][j]; }
+      for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int ch = 0; ch < DCN_FB_PF; ++ch) { qa[ch][j] = nqa[ch][j]; qb[ch][j] = nqb[ch][j]; }
       // this tap row's offsets are consumed: their registers take the next row's
 #pragma unroll
       for (int q = 6 * i; q < 6 * i + 6; ++q) ofs[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rof, vof1, q * HW * 4, 0));
@@ -1890,7 +1893,7 @@ __global__ __launch_bounds__(256, 1) void dcn_bwd_fused_kernel(const float* __re
   const int m = 24 * i + 3 * cc + (J_);                                                                                        \
   const float gv = T[m * DCN_FB_ROW + lane];                                                                                   \
   {                                                                                                                            \
-    const dcn_u32x2 q0 = qa[cc % 3][J_], q1 = qb[cc % 3][J_];                                                                  \
+    const dcn_u32x2 q0 = qa[cc % (DCN_FB_PF + 1)][J_], q1 = qb[cc % (DCN_FB_PF + 1)][J_];                                      \
     const dcn_f32x2 px = {__uint_as_float(q0.x), __uint_as_float(q1.x)}, py = {__uint_as_float(q0.y), __uint_as_float(q1.y)}; \
     const dcn_f32x2 tb = wxy[J_].x * px + wxy[J_].y * py; /* (top, bottom) row samples */                                      \
     const dcn_f32x2 dd = exy[J_].x * px + exy[J_].y * py; /* their d / d w */                                                  \
@@ -1910,8 +1913,8 @@ __global__ __launch_bounds__(256, 1) void dcn_bwd_fused_kernel(const float* __re
         // one, as pairs (1,2) (3,4) 5), five shifts per row
 #pragma unroll
         for (int cc = 0; cc < 8; ++cc) {
-          if (cc < 6) DCN_FB_GATHER(cc + 2)
-          if (cc == 5) { if (i < 2) { DCN_FB_NEXT_TAP_ROW(i + 1, ho, own) } else { DCN_FB_NEXT_TAP_ROW(0, ho + 1, own_next) } }
+          if (cc < 8 - DCN_FB_PF) DCN_FB_GATHER(cc + DCN_FB_PF)
+          if (cc == 8 - DCN_FB_PF) { if (i < 2) { DCN_FB_NEXT_TAP_ROW(i + 1, ho, own) } else { DCN_FB_NEXT_TAP_ROW(0, ho + 1, own_next) } }
           float rv[3];
 #pragma unroll
           for (int a = 0; a < 3; ++a) rv[a] = R[cc * 448 + rs[i + 1 + a]];
@@ -1949,8 +1952,8 @@ __global__ __launch_bounds__(256, 1) void dcn_bwd_fused_kernel(const float* __re
       } else {
 #pragma unroll
         for (int cc = 0; cc < 8; ++cc) {
-          if (cc < 6) DCN_FB_GATHER(cc + 2)
-          if (cc == 5) { if (i < 2) { DCN_FB_NEXT_TAP_ROW(i + 1, ho, own) } else { DCN_FB_NEXT_TAP_ROW(0, ho + 1, own_next) } }
+          if (cc < 8 - DCN_FB_PF) DCN_FB_GATHER(cc + DCN_FB_PF)
+          if (cc == 8 - DCN_FB_PF) { if (i < 2) { DCN_FB_NEXT_TAP_ROW(i + 1, ho, own) } else { DCN_FB_NEXT_TAP_ROW(0, ho + 1, own_next) } }
           float rv[5];
 #pragma unroll
           for (int a = 0; a < 5; ++a) rv[a] = R[cc * 448 + rs[i + a]];
