@@ -285,6 +285,9 @@ FUSED_BWD = [
     (1, 16, 120, 32, 3.0, 2, True),      # most samples are outliers: the listed-row scatter kernel
     (1, 33, 36, 8, 12.0, 4, True),       # nearly every sample leaves the image
     (2, 10, 116, 32, 0.7, 2, False),     # input / offset gradients alone (rtp_deform_conv_backward_input), weights by their own entry
+    (3, 1, 4, 32, 0.6, 1, True),         # a single row, the narrowest row the path takes: the ring only ever flushes
+    (2, 2, 8, 32, 1.2, 2, True),         # two rows in two segments (each segment is all halo but one row)
+    (1, 3, 12, 5, 0.3, 3, True),         # three rows, three segments, 5 output channels
 ]
 
 
