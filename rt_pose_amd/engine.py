@@ -100,6 +100,9 @@ class PoseEngine:
             lidar = (g.pack("lidar", self.lidar_in, lidar_channels, dims), lidar_channels)
         self.outs = net.build_head(g, self.feats, list(self.heads), lidar=lidar)
         self.fwd = list(g.forward_list())
+        if os.environ.get("RTP_FWD_ROW0_FIRST", "0") == "1":   # A/B: the main lane's fuse-row feeders ahead of the other rows' chains
+            from .lanes import main_row_first
+            self.fwd = main_row_first(self.fwd)
         self.fwd_plan = LanePlan(be, self.fwd, LANE_MAP)
         self.bwd_plan = None
         self.use_lanes = True      # False: replay everything on the caller's stream in list order

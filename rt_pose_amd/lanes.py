@@ -154,6 +154,69 @@ def reorder_critical_path(launches):
     return [launches[i] for i in order]
 
 
+def _order_preds(launches):
+    """Read-after-write / write-after-read / write-after-write predecessors of every launch in the list's own order."""
+    last_w, readers = {}, {}
+    preds = [set() for _ in launches]
+    for i, L in enumerate(launches):
+        for k in L.reads:
+            j = last_w.get(k)
+            if j is not None:
+                preds[i].add(j)
+        for k in L.writes:
+            j = last_w.get(k)
+            if j is not None:
+                preds[i].add(j)
+            preds[i].update(readers.get(k, ()))
+        for k in L.writes:
+            last_w[k] = i
+            readers[k] = []
+        for k in L.reads:
+            if k not in L.writes:
+                readers.setdefault(k, []).append(i)
+        preds[i].discard(i)
+    return preds
+
+
+def main_row_first(launches):
+    """Forward list: inside every fuse block, the launches that feed the MAIN lane's fuse row (row 0: the 1x1x1 convs `sN.f0j` of
+    the lower branches, with their weight folds) are issued before the other rows' chains.
+
+    Rows are created last-to-first (net.build_backbone: the backward's fusable-consumer rule wants that creation order), so on
+    the side lanes -- FIFO streams -- the cheap feeders of row 0 used to sit behind the stride-2 chains of rows 2 and 1, and the
+    main lane waited for them after its own convolutions (0.33 / 0.16 / 0.15 ms in front of the three `fuse:sN.row0` launches,
+    profiles/r03_main_lane_trace.txt).  Only launches of one block are permuted, groups keep their internal order, and the
+    result is checked against the dependency relations of the original order (any violation: the original list is returned)."""
+    import re
+    n = len(launches)
+    preds = _order_preds(launches)
+    order = list(range(n))
+    pos = 0
+    out = []
+    stage_of = lambda tag: (re.search(r"[:.]s(\d)\.(f\d\d|row\d)", tag) or [None, None])[1]
+    i = 0
+    while i < n:
+        st = stage_of(launches[i].tag)
+        if st is None:
+            out.append(i)
+            i += 1
+            continue
+        j = i
+        while j < n and stage_of(launches[j].tag) == st:   # the block's launches are contiguous
+            j += 1
+        blk = list(range(i, j))
+        feed0 = [k for k in blk if re.search(r"s\d\.f0\d", launches[k].tag)]
+        row0 = [k for k in blk if launches[k].tag.endswith("s%s.row0" % st)]
+        rest = [k for k in blk if k not in feed0 and k not in row0]
+        out += feed0 + row0 + rest
+        i = j
+    where = {k: p for p, k in enumerate(out)}
+    for k in range(n):
+        if any(where[q] > where[k] for q in preds[k]):
+            return launches
+    return [launches[k] for k in out]
+
+
 class LanePlan:
     """A launch list bound to a backend, replayable on one stream or on one stream per lane."""
 

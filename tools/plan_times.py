@@ -16,6 +16,7 @@ def main():
     ap.add_argument("--rep", type=int, default=10)
     ap.add_argument("--top", type=int, default=60)
     ap.add_argument("--convs", action="store_true")
+    ap.add_argument("--order", action="store_true", help="also print every launch in list order (phase, lane, tag, us)")
     a = ap.parse_args()
     from rt_pose_amd import configs, synth
     from rt_pose_amd.trainer import DataParallelTrainer
@@ -46,6 +47,10 @@ def main():
     nbytes = {id(L): sum(BUF_BYTES.get(k, 0) for k in set(L.reads) | set(L.writes)) for _, L in launches}
     out = [(e0.elapsed_time(e1) * 1e3 / a.rep, phase, L.lane, L.tag) for phase, L, e0, e1 in rows]
     bybytes = {(phase, L.tag): nbytes[id(L)] for phase, L, _, _ in rows}
+    if a.order:
+        print("-- list order")
+        for t, phase, lane, tag in out:
+            print("   %s lane %d  %-34s %7.1f us" % (phase, lane, tag, t))
     tot = sum(t for t, *_ in out)
     print("serial total %.2f ms over %d launches" % (tot / 1e3, len(out)))
     agg = {}
