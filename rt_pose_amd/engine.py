@@ -146,6 +146,12 @@ class PoseEngine:
             g.seed_grad(reg, self.greg)
             g.build_backward()
             self.bwd = list(g.bwd)
+            if os.environ.get("RTP_BWD_F10_FIRST", "1") == "1":
+                # stage 3's row-1 stride-2 data gradient (level-1 lane) is issued ahead of the row-2 chain it does not depend on:
+                # the main lane's fan-in `combine:s3.b0.c3` waits for both, and the level-1 lane used to start this one only after
+                # the level-2 lane's chain had arrived (-1 % on the step; RTP_BWD_F10_FIRST=0: creation order)
+                from .lanes import hoist_tagged
+                self.bwd = hoist_tagged(self.bwd, r":s3\.f10\.0$", r":s3\.(row2|f2)")
             self.bwd_plan = LanePlan(be, self.bwd, LANE_MAP)
         self.live_params = set(g.used_params)
 

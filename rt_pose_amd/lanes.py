@@ -217,6 +217,24 @@ def main_row_first(launches):
     return [launches[k] for k in out]
 
 
+def hoist_tagged(launches, pattern, before):
+    """Moves the launches whose tag matches `pattern` (kept in order) in front of the first launch whose tag matches `before`,
+    provided that respects the dependency relations of the original order (otherwise the list is returned unchanged)."""
+    import re
+    idx = [i for i, L in enumerate(launches) if re.search(pattern, L.tag)]
+    tgt = next((i for i, L in enumerate(launches) if re.search(before, L.tag)), None)
+    if not idx or tgt is None or idx[0] < tgt:
+        return launches
+    moved = set(idx)
+    out = [i for i in range(tgt) if i not in moved] + idx + [i for i in range(tgt, len(launches)) if i not in moved]
+    preds = _order_preds(launches)
+    where = {k: p for p, k in enumerate(out)}
+    for k in range(len(launches)):
+        if any(where[q] > where[k] for q in preds[k]):
+            return launches
+    return [launches[k] for k in out]
+
+
 class LanePlan:
     """A launch list bound to a backend, replayable on one stream or on one stream per lane."""
 
