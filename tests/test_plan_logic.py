@@ -247,3 +247,44 @@ def test_fused_stride2_data_gradient_route(monkeypatch):
     for k in sd:
         if sdr[k].grad is not None:
             assert rel_err(flat.grads[k], sdr[k].grad) < 1e-2, (k, rel_err(flat.grads[k], sdr[k].grad))
+
+
+def test_launch_list_reorderings_keep_dependencies_and_results(monkeypatch):
+    """lanes.main_row_first / lanes.hoist_tagged permute a launch list only inside the read/write relations of the original
+    order (checked here with an independent walk), refuse a permutation that would break one, and the plan computes the same
+    losses and gradients with the forward list re-ordered (RTP_FWD_ROW0_FIRST=1) and with the backward hoist switched off."""
+    from rt_pose_amd.lanes import Launch, _order_preds, hoist_tagged, main_row_first
+
+    def respects(orig, new):
+        pos = {id(L): i for i, L in enumerate(new)}
+        preds = _order_preds(orig)
+        return len(new) == len(orig) and all(pos[id(orig[q])] < pos[id(orig[k])] for k in range(len(orig)) for q in preds[k])
+
+    eng, flat, sd, ex, _ = make("hr3d", exact=True)
+    fwd2 = main_row_first(eng.fwd)
+    assert [L.tag for L in fwd2] != [L.tag for L in eng.fwd] and respects(eng.fwd, fwd2)
+    tags = [L.tag for L in fwd2]
+    assert tags.index("conv:s3.f01") < tags.index("fuse:s3.row0") < tags.index("conv:s3.f20.0")
+    # a hoist across a true dependency is refused: b reads what a writes
+    bx, by, bz = torch.zeros(1), torch.zeros(1), torch.zeros(1)
+    a, b, c = Launch(None, 0, [], [bx], "w:a"), Launch(None, 1, [bx], [by], "r:b"), Launch(None, 2, [], [bz], "o:c")
+    assert hoist_tagged([a, c, b], r"r:b", r"w:a") == [a, c, b]
+    assert [L.tag for L in hoist_tagged([a, c, b], r"r:b", r"o:c")] == ["w:a", "r:b", "o:c"]
+
+    def run(env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        e, f, _, x, _ = make("hr3d", exact=True)
+        e.load_input(x["rdr"]["rdr_tensor"])
+        e.load_targets(x["rdr"])
+        e.run_forward()
+        e.run_loss_backward()
+        for k in env:
+            monkeypatch.delenv(k)
+        return e.losses()["loss"].clone(), {k: v.clone() for k, v in f.grads.items()}
+
+    l0, g0 = run({})
+    for env in ({"RTP_FWD_ROW0_FIRST": "1"}, {"RTP_BWD_F10_FIRST": "0"}):
+        l1, g1 = run(env)
+        assert torch.equal(l0, l1), env
+        assert all(torch.equal(g0[k], g1[k]) for k in g0), env
