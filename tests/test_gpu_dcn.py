@@ -360,6 +360,38 @@ def test_dcn_one_pass_backward(case, monkeypatch):
         assert torch.equal(rx, gx) and torch.equal(ro, go), case
 
 
+@pytest.mark.parametrize("seed", range(16))
+def test_dcn_one_pass_backward_random_shapes(seed, monkeypatch):
+    """Random image sizes (rows 1 .. 40, widths 4 .. 200 in steps of 4: one to four strips, ragged last strips), output channel
+    counts, offset scales and row-segment counts through the one-pass backward: all three gradients against the oracle."""
+    import numpy as np
+    from rt_pose_amd.dcn import deform_conv
+    rs = np.random.RandomState(4000 + seed)
+    n, h, w = int(rs.randint(1, 4)), int(rs.randint(1, 41)), 4 * int(rs.randint(1, 51))
+    co = int(rs.choice([1, 7, 16, 31, 32]))
+    scale = float(rs.choice([0.0, 0.2, 0.5, 0.9, 1.5, 2.5, 6.0]))
+    segs = int(rs.randint(0, 6))
+    monkeypatch.delenv("RTP_DCN_NO_FUSED_BWD", raising=False)
+    if segs:
+        monkeypatch.setenv("RTP_DCN_SEGS", str(segs))
+    else:
+        monkeypatch.delenv("RTP_DCN_SEGS", raising=False)
+    x = rnd(n, 32, h, w, seed=seed * 5 + 1).requires_grad_(True)
+    wt = rnd(co, 32, 3, 3, seed=seed * 5 + 2, scale=0.2).requires_grad_(True)
+    off = rnd(n, 72, h, w, seed=seed * 5 + 3, scale=scale).requires_grad_(True)
+    ref = deform_conv2d(x, off, wt, 1, 1, 1, 1, 4)
+    gy = rnd(*ref.shape, seed=seed * 5 + 4)
+    ref.backward(gy)
+    xg, wg, og = [t.detach().cuda().requires_grad_(True) for t in (x, wt, off)]
+    deform_conv(xg, og, wg, 1, 1, 1, 1, 4, 64).backward(gy.cuda())
+    torch.cuda.synchronize()
+    case = (n, h, w, co, scale, segs)
+    assert rel_err(xg.grad.cpu(), x.grad) < TOL, case
+    assert rel_err(wg.grad.cpu(), wt.grad) < TOL, case
+    if float(off.grad.abs().max()) > 0:
+        assert rel_err(og.grad.cpu(), off.grad) < TOL, case
+
+
 @pytest.mark.parametrize("mode", list(MODES))
 def test_small_fixed_case_on_the_gpu(mode, monkeypatch):
     """The HIP operator (through the C ABI) on the small fixed case of tests/golden/dcn_known_answer.json, whose expected
