@@ -21,7 +21,8 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "4")   # (rt_pose_amd/__init__.py: the lane plan's measured optimum, HIP's default)
+from rt_pose_amd import pin_hw_queues  # noqa: E402
+HW_QUEUES = pin_hw_queues()   # the lane plan's measured optimum (HIP's default), pinned before torch initialises HIP
 
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA, MI355X_MICROARCH.md chip table
 PEAK_HBM_GBPS = 8000.0     # HBM3E peak (same guide; ~6.3 TB/s achievable)
@@ -318,20 +319,28 @@ def main():
 
     for _ in range(args.warmup):
         tr.step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        tr.step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    rank_ms = None
-    if world > 1:
-        # every rank's own clock around the same K steps: the job's time is the slowest rank's; the spread is reported so that a
-        # scaling run checks itself (a straggler GPU, or a rank that never joined the collective, shows here)
-        ts = [torch.zeros(1, device=dev) for _ in range(world)]
-        dist.all_gather(ts, torch.tensor([elapsed], device=dev))
-        rank_ms = [round(1e3 * float(x) / args.steps, 3) for x in ts]
-        elapsed = max(float(x) for x in ts)
+    # THREE consecutive timed segments of exactly --steps steps each, every one bracketed by barrier + synchronize on both sides; the
+    # line reports the MEDIAN segment (box-to-box and run-to-run spread of a 0.1-s region is a few percent) and
+    # lists all three.  Multi-rank: a segment's time is the slowest rank's.
+    seg_s, seg_rank_ms = [], []
+    for _seg in range(3):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            tr.step()
+        barrier()
+        el = time.perf_counter() - t0
+        if world > 1:
+            # every rank's own clock around the same K steps: the job's time is the slowest rank's; the spread is reported so that a
+            # scaling run checks itself (a straggler GPU, or a rank that never joined the collective, shows here)
+            ts = [torch.zeros(1, device=dev, dtype=torch.float64) for _ in range(world)]
+            dist.all_gather(ts, torch.tensor([el], device=dev, dtype=torch.float64))
+            seg_rank_ms.append([round(1e3 * float(x) / args.steps, 3) for x in ts])
+            el = max(float(x) for x in ts)
+        seg_s.append(el)
+    mid = sorted(range(3), key=lambda i: seg_s[i])[1]
+    elapsed = seg_s[mid]
+    rank_ms = seg_rank_ms[mid] if world > 1 else None
     loss = float(tr.losses()["loss"])
     frames = world * args.batch * args.steps
     g = tr.engine.graph
@@ -343,12 +352,14 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": "%s train step (fwd+loss+bwd+allreduce+clip+Adam), %d frames/GPU of [%d,16,64,160], "
                                "random-init weights" % (args.model, args.batch, spec["cin"]),
-                   "global_batch": world * args.batch, "parallelism": "dp%d" % world, "hip_graph": bool(args.graph)},
+                   "global_batch": world * args.batch, "parallelism": "dp%d" % world, "hip_graph": bool(args.graph),
+                   "hw_queues": HW_QUEUES},
         "allreduce_ms": (round(tr.allreduce_ms(), 4) if world > 1 else None),   # flat fp32 gradient all-reduce, events on the step stream
         "allreduce_MB": round(tr.flat.numel * 4 / 1e6, 2),
         "allreduce_buckets": getattr(tr, "ar_buckets", 1),
         "collective": ({"backend": dist.get_backend(), "ranks": dist.get_world_size(),
                         "ms_per_step_by_rank": rank_ms, "rank_spread_ms": round(max(rank_ms) - min(rank_ms), 3)} if world > 1 else None),
+        "segments_ms_per_step": [round(1e3 * x / args.steps, 3) for x in seg_s],   # three timed segments of `steps` steps; ms_per_step = their median
         "final_loss": round(loss, 5),
         "train_gflop_per_frame": round(train_flops_per_frame / 1e9, 2),
         "mfma_frac_whole_step": round(frames / elapsed * train_flops_per_frame / (world * PEAK_BF16_TFLOPS * 1e12), 4),

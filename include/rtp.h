@@ -467,7 +467,14 @@ int rtp_deform_conv_backward_parameters(const float* input, const float* offset,
 /* Both halves of DeformConvFunction.backward (det3d/ops/dcn/deform_conv.py:62-98: deform_conv_backward_input_cuda, then
  * deform_conv_backward_parameters_cuda on the same tensors) in one call.  For the DCN head's geometry (3x3, stride 1, pad 1,
  * 32 channels in 4 deformable groups, <= 32 output channels) one kernel produces all three gradients without a column matrix;
- * any other geometry runs the two entry points above one after the other.  Same accumulate-into-outputs contract. */
+ * any other geometry runs the two entry points above one after the other.
+ * Outputs: gradInput and gradWeight are ACCUMULATED into (the reference's contract: the caller zero-fills them, deform_conv.py:77-80);
+ * gradOffset is ASSIGNED -- every element is written exactly once, nothing is read back (the reference zero-fills it and its
+ * col2im_coord kernel then assigns it too, deform_conv_cuda_kernel.cu:436-507, so callers see the same values).
+ * Precision of the one-kernel route: its two matrix products (W^T * gradOutput and gradOutput * columns^T) run on the bf16 matrix
+ * core with both operands split into (hi, lo) bf16 pairs and the lo * lo product dropped: 3.9e-6 norm-wise against the exact fp32
+ * products of the reference operator and of the two-call route -- not bit-equal to either.  RTP_DCN_FP32_MFMA=1 (environment, read
+ * once) selects the fp32 matrix instruction instead (exact fp32 products, 1.4x the time); RTP_DCN_NO_FUSED_BWD=1 the two-call route. */
 int rtp_deform_conv_backward(const float* input, const float* offset, const float* gradOutput, float* gradInput,
                              float* gradOffset, const float* weight, float* gradWeight, void* ws, int n, int c, int h,
                              int w, int co, int kW, int kH, int dW, int dH, int padW, int padH, int dilW, int dilH,
@@ -492,6 +499,10 @@ int rtp_modulated_deform_conv_backward(const float* input, const float* weight, 
 int rtp_prof_enable(int family, int on);
 int rtp_prof_collect(int family, float* total_ms, int* launches); /* synchronises the recorded events */
 const char* rtp_version(void);
+/* Dynamic work claiming of the persistent LDS-tiled kernels (csrc/rtp_claim.h): 32-bit words of the per-GPU counter pool handed
+ * out so far on the current device (every launch owns a slot keyed by its output pointer); -1 on error.  the claiming is opt-in: RTP_CLAIM=1
+ * (environment, read once); the default is the static deal of bricks to workgroups. */
+int rtp_claim_slots_in_use(void);
 
 #ifdef __cplusplus
 }

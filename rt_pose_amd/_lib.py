@@ -139,6 +139,7 @@ PROTOTYPES = {
     "rtp_prof_enable": [_I, _I],
     "rtp_prof_collect": [_I, C.POINTER(_F), C.POINTER(_I)],
     "rtp_version": [],
+    "rtp_claim_slots_in_use": [],
 }
 _RESTYPE = {"rtp_version": C.c_char_p, "rtp_dcn_workspace_bytes": C.c_long, "rtp_voxelize_workspace_bytes": C.c_long,
             "rtp_upsample_bwd_scratch_floats": C.c_long}

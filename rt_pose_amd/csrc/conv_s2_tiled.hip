@@ -306,11 +306,10 @@ int rtp_conv_s2_fwd_try(const RtpAct* x, const void* wf, int w_per_sample, const
   using Kern = void (*)(S2FwdParams);
   static const Kern tab[2][2] = {{conv_s2_fwd_kernel<false, false>, conv_s2_fwd_kernel<false, true>},
                                  {conv_s2_fwd_kernel<true, false>, conv_s2_fwd_kernel<true, true>}};
-  static bool attr = false;
-  if (!attr) {
+  static bool attr[RTP_MAX_DEVICES] = {};
+  if (rtp_once_per_device(attr)) {
     for (int a = 0; a < 2; ++a)
       for (int b = 0; b < 2; ++b) (void)hipFuncSetAttribute((const void*)tab[a][b], hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-    attr = true;
   }
   hipLaunchKernelGGL(tab[btab ? 1 : 0][stat_out ? 1 : 0], dim3(p.N * p.wgs_per_sample), dim3(512), shm, s, p);
   RTP_CHECK_LAUNCH();

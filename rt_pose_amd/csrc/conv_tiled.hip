@@ -20,6 +20,7 @@
 // workgroup, which removes a separate read pass over the tensor.
 #include <stdlib.h>
 
+#include "rtp_claim.h"
 #include "rtp_common.h"
 #include "rtp_prof.h"
 
@@ -34,10 +35,10 @@
 #define PLANE_VOX (HY * HX)              // haloed voxels of one z-plane
 #define PAIR_VOX (2 * PLANE_VOX)         // the staging unit is a PAIR of z-planes
 #define PAIR_ITEMS (PAIR_VOX * 4)        // sixteen-byte items
-// pairs a team keeps in LDS.  2 (with TY 4: 2 x 26 KB): the two pairs under the MFMAs; the pair the next brick is missing is
-// requested in the team's load phase, into the slot of the pair the finished brick no longer needs.  3 (with TY 2: 3 x 17 KB):
-// one more slot, requested a phase earlier (under the previous brick's MFMAs).
-#define RING (TY == 4 ? 2 : 3)
+// pairs a team keeps in LDS: the two pairs under the MFMAs; the pair the next brick is missing is requested in the team's load
+// phase, into the slot of the pair the finished brick no longer needs.  (A three-slot ring at half the brick height, requested a
+// phase earlier, was measured slower in round 2 and is gone.)
+#define RING 2
 #define HALO_VOX (RING * PAIR_VOX)       // 816 voxels x 64 B = 52 KB per team either way
 #ifndef RTP_TILED_DIST
 #define RTP_TILED_DIST 4
@@ -77,8 +78,14 @@ struct TiledParams {
   int x_cs, x_co;          // x may be a 32-channel slice of a wider tensor (channel stride / first channel)
   const float* acc32; int a_cs;  // optional fp32 partial result [N][vox][a_cs] added before bias / ReLU (input-channel split)
   int dbg;  // timing experiments only (RTP_TILED_DBG): bit0 = skip the MFMA loop, bit1 = skip staging, bit2 = skip epilogue
-  int tsync;  // 0: the two teams swap roles at workgroup barriers (lockstep); 1: each team synchronises only its own four waves
-              // (LDS counter), the teams drift freely; 2: as 1, with the MFMA loop of team 0 / 1 at wave priority 3 / 2
+  // Dynamic brick claiming (rtp_claim.h).  claim != null: a team takes UNITS of `unit` consecutive bricks (z fastest) from the
+  // counters claim[n * ranges + r]; a sample's bricks are cut into `ranges` contiguous ranges (one per XCD that serves the sample:
+  // neighbouring bricks keep meeting in one L2), a team starts in its home range and moves on to the others when it is empty.
+  // claim == null: the static deal (contiguous, balanced runs per team).
+  // A range's bricks are cut into units handed out by INDEX (the counter counts units): the first `nbig` units have `ubig` bricks,
+  // the rest `usmall` -- big units first keep the staging cheap (inside a unit a brick stages one z-plane pair instead of two),
+  // the small ones at the end keep the workgroups' finishing times within a brick or two of each other.
+  int* claim; int ranges, total_wgs, nbig, ubig, usmall;
   // FUSE: a data gradient that writes the FINISHED gradient of its input tensor x (= p.res, the AUX operand):
   //   y = [x > 0] * (A0 * acc + Bt * x + Ct + sum_e Ae * ex_e)
   // coef[0] = this conv's GroupNorm-backward coefficients [N][32][3] (A, B, C) or null (1, 0, 0); ex_e = gradient terms of
@@ -107,15 +114,6 @@ struct TiledParams {
   // statistics partials are 32-channel windows of tables that are bt_cs / st_cs channels wide.  Dense defaults otherwise.
   long w_sample_stride; int w_tap_stride, w_row_stride, bt_cs, st_cs;
 };
-
-// Barrier over the four waves of one team: a monotonic LDS counter (no reset, so no re-use hazard); `target` = 4 x the
-// number of barriers the team has passed including this one.  s_waitcnt 0 first: the team's LDS-DMA writes (vmcnt) and LDS
-// reads of the brick (lgkmcnt) must be complete before the other waves overwrite / read it.
-__device__ __forceinline__ void team_sync(unsigned* cnt, unsigned target, int lane) {
-  __builtin_amdgcn_s_waitcnt(0);
-  if (lane == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-  while (__hip_atomic_load(cnt, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
-}
 
 // One LDS-DMA piece (16 B per lane, wave-linear LDS destination from M0), issued from inline assembly so that the compiler does
 // not model it: hipcc treats the builtin as a FLAT access to both memories, and while one is outstanding it (a) drains vmcnt
@@ -178,6 +176,11 @@ __global__ __launch_bounds__(512, 2) void conv_tiled_kernel(TiledParams p) {
   const int team_id = (bid - n * wgs_per_sample) * 2 + team;  // team index within the sample
   const int v = lane & 15, q = lane >> 4;
   const int wz = tw >> 1, wx = tw & 1;
+  // dynamic brick claiming (below, "work distribution")
+  const bool dyn = p.claim != nullptr;                                          // kernel-uniform
+  const bool claimer = tw == 0 && lane == 0;                                    // the one lane per team that talks to the counters
+  int rng = dyn ? ((bid - n * wgs_per_sample) * p.ranges) / wgs_per_sample : 0;   // claimer's current range (home range first)
+  int nfail = 0;   // ranges this claimer has found empty
 
   if (p.fw) {   // kernel-uniform: GroupNorm fold in the prologue (both teams' brick regions are scratch until the phase loop)
     float* scr = reinterpret_cast<float*>(lds + 27 * NT * 16 * 32);
@@ -442,13 +445,61 @@ __global__ __launch_bounds__(512, 2) void conv_tiled_kernel(TiledParams p) {
     if (tid < 256) bL[192 + tid] = 0.f;   // per-wave running totals [8 waves][32]
   }
   PROF_T(pk1);
-  unsigned* tcnt = reinterpret_cast<unsigned*>(bL + 27 * p.Co) + team;
-  unsigned tbar = 0;
-  if (p.tsync) {
-    if (tid < 2) reinterpret_cast<unsigned*>(bL + 27 * p.Co)[tid] = 0u;
-    __syncthreads();   // weights, tables and the counters are in place for both teams
+  // ---- work distribution.  A team works through UNITS of consecutive bricks (z fastest) of its sample.  Static deal (p.claim
+  // null): one unit per team, its balanced contiguous run.  Dynamic (rtp_claim.h): units of 4 then 2 bricks taken from the sample's
+  // counters, so a workgroup that starts late -- its CU was still busy with another stream's kernel -- takes fewer bricks
+  // instead of stretching the launch.  One lane per team (the CLAIMER) talks to the counters; the team's other waves learn the
+  // next unit from LDS after the phase barrier.  ctl[2 * team + {0, 1}] = next unit (first brick or -1, end);
+  // ctl[4 + 2 * (phase & 3) + team] = "this team has nothing left" as of the end of that phase.
+  int* ctl = reinterpret_cast<int*>(bL + 27 * p.Co);
+  auto range_lo = [&](int r) { return (int)((long)r * p.tiles_per_sample / p.ranges); };
+  // claimer only: turn a unit index of range `rng` into the team's next unit.  A team's FIRST unit of its home range is its own
+  // (index = the team's number within the range, drawn = false: no counter involved -- 64 teams asking one address at kernel start
+  // cost the last of them 5 us); every later one is drawn from the range's counter (index = teams of the range + the counter's
+  // answer).  While the current range is exhausted the claimer moves on through the others, cyclically from its home range
+  // (only at the tail of a launch: one atomic round trip per further range).
+  auto claim_finish = [&](int u, bool drawn) {
+    int s0 = -1, s1 = 0;
+    const int teams_r = p.teams_per_sample / p.ranges;
+    for (;;) {
+      const int lo = range_lo(rng), len = range_lo(rng + 1) - lo;
+      const int units = p.nbig + (len - p.nbig * p.ubig + p.usmall - 1) / p.usmall;
+      // (every team of the sample ends with exactly one failed draw on every range's counter)
+      if (drawn) rtp_claim_reset_if_last(p.claim + n * p.ranges + rng, u, units > teams_r ? units - teams_r : 0, p.teams_per_sample);
+      const int idx = drawn ? teams_r + u : u;
+      const int b = idx < p.nbig ? idx * p.ubig : p.nbig * p.ubig + (idx - p.nbig) * p.usmall;
+      if (b < len) {
+        const int e = b + (idx < p.nbig ? p.ubig : p.usmall);
+        s0 = lo + b; s1 = lo + (e < len ? e : len);
+        break;
+      }
+      if (drawn) {
+        if (++nfail >= p.ranges) break;   // (ranges are visited cyclically from the home range: a failed one is never asked again)
+        rng = rng + 1 == p.ranges ? 0 : rng + 1;
+      }
+      u = rtp_claim_take(p.claim + n * p.ranges + rng, 1);   // (after a missing own unit: this range's counter, which fails as well)
+      drawn = true;
+    }
+    ctl[2 * team] = s0;
+    ctl[2 * team + 1] = s1;
+  };
+  if (claimer) {
+    if (dyn) {
+      claim_finish(team_id - rng * (p.teams_per_sample / p.ranges), false);
+    } else {   // contiguous, balanced runs of bricks per team: consecutive bricks share two of their four haloed z-planes
+      const int t_begin = (int)((long)team_id * p.tiles_per_sample / p.teams_per_sample);
+      const int t_end = (int)((long)(team_id + 1) * p.tiles_per_sample / p.teams_per_sample);
+      ctl[2 * team] = t_end > t_begin ? t_begin : -1;
+      ctl[2 * team + 1] = t_end;
+    }
   }
-#define PHASE_SYNC() do { if (p.tsync) { tbar += 4; team_sync(tcnt, tbar, lane); } else __syncthreads(); } while (0)
+  if (tid < 8) ctl[4 + tid] = 0;
+  __syncthreads();   // weights, tables and the first units are in place for both teams
+  int both_done = 0;
+#define PHASE_SYNC() do { \
+    if (claimer) ctl[4 + 2 * (phase & 3) + team] = (finished && !pend && !staged) ? 1 : 0; \
+    both_done = __builtin_amdgcn_readfirstlane(fl[0] & fl[1]); \
+    __syncthreads(); } while (0)
   const long vox_n = (long)n * p.D * p.H * p.W;
   // Staging descriptors (brick-independent, computed once): element offset of each of this thread's 13 sixteen-byte
   // items relative to the brick origin, its swizzled LDS slot, and six "on the low/high face of the halo" bits.
@@ -467,13 +518,10 @@ __global__ __launch_bounds__(512, 2) void conv_tiled_kernel(TiledParams p) {
     s_rel[k] = ((hz * p.H + (hy - 1)) * p.W + (hx - 1)) * p.x_cs + ck * 8;
   }
   const bf16_t* xn = p.x + vox_n * p.x_cs + p.x_co;
-  // contiguous, balanced runs of bricks per team, z fastest: consecutive bricks share two of their four haloed z-planes,
-  // which the second read then finds in this XCD's L2 (PMC: 1.5x over-fetch with the interleaved deal)
-  const int t_begin = (int)((long)team_id * p.tiles_per_sample / p.teams_per_sample);
-  const int my_tiles = (int)((long)(team_id + 1) * p.tiles_per_sample / p.teams_per_sample) - t_begin;
-  int max_tiles = (p.tiles_per_sample + p.teams_per_sample - 1) / p.teams_per_sample;  // workgroup-uniform
-  const int nphase = 2 * max_tiles + 2;  // every compute phase is followed by a load phase of the same team (its epilogue runs there)
-  int load_k = 0, comp_k = 0;
+  // the team's current unit [u_cur, u_end) (u_cur = its next brick to stage), whether a brick is staged and waiting for its MFMA
+  // phase, and whether the team has been told there is no further unit -- all team-uniform
+  int u_cur = 0, u_end = 0;
+  bool staged = false, finished = false;
   // The team's LDS region is a FIFO ring of RING plane pairs.  A brick (2 output z-planes) reads planes z0-1 .. z0+2 = the pair
   // (z0-1, z0) and the pair (z0+1, z0+2): along a z-column (bricks are dealt z fastest) the upper pair of one brick is the lower
   // pair of the next, so a brick inside a column stages ONE pair (26 KB) and only a column's first brick stages two.  The pair a
@@ -481,14 +529,13 @@ __global__ __launch_bounds__(512, 2) void conv_tiled_kernel(TiledParams p) {
   // so its HBM latency hides under that whole phase (the second pair of a column's first brick follows in the load phase, into
   // the slot the finished brick frees).  A brick always computes from the last two pairs staged: slots cur-2, cur-1.
   int ring_cur = 0;
-  // coordinates of the team's next brick to compute (z fastest), advanced brick by brick: no divisions in the phase loop
-  int c_tz = t_begin % p.tiles_z, c_tx = (t_begin / p.tiles_z) % p.tiles_x, c_ty = t_begin / (p.tiles_z * p.tiles_x);
+  // coordinates of the team's next brick (z fastest), set at the start of a unit and advanced brick by brick
+  int c_tz = 0, c_tx = 0, c_ty = 0;
   auto issue_pair = [&](int tz, int tx, int ty, int upper) {   // team-uniform arguments
     const int zp = tz * TZ - 1 + 2 * upper, y0 = ty * TY, x0 = tx * TX;
     const int org = ((zp * p.H + y0) * p.W + x0) * p.x_cs;
     const int tflg = (zp < 0) | ((zp + 1 >= p.D) << 1) | ((y0 == 0) << 2) | ((y0 + TY == p.H) << 3) | ((x0 == 0) << 4);
     const int xlim = (p.W - x0 + 1) << 8;  // haloed x index >= this lies beyond the volume (W need not be a multiple of TX)
-    const unsigned dst_b = (unsigned)(size_t)(__attribute__((address_space(3))) bf16_t*)lds + 2u * (unsigned)((xL - lds) + ring_cur * (PAIR_VOX * 32));
     const int ring_slot = ring_cur;
     ring_cur = ring_cur == RING - 1 ? 0 : ring_cur + 1;
     if (p.dbg & 2) return;
@@ -497,10 +544,9 @@ __global__ __launch_bounds__(512, 2) void conv_tiled_kernel(TiledParams p) {
       if (k * 256 + ttid < PAIR_ITEMS) {  // (TY 4: the last piece is half a wave -- EXEC masks the other lanes' transfers)
         const bool oob = (s_pk[k] & tflg & 0xff) || s_pk[k] >= xlim;
         const bf16_t* src = oob ? g_zero_line_c : xn + org + s_rel[k];
-        if (RING == 3) lds_dma16(src, dst_b + 16u * (unsigned)(k * 256 + (ttid & ~63)));
-        else   // issued and awaited within one load phase: the compiler's own bookkeeping (counted vmcnt for the residual) is right
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                           (__attribute__((address_space(3))) void*)(xL + ring_slot * (PAIR_VOX * 32) + (k * 256 + (ttid & ~63)) * 8), 16, 0, 0);
+        // issued and awaited within one load phase: the compiler's own bookkeeping (counted vmcnt for the residual) is right
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(xL + ring_slot * (PAIR_VOX * 32) + (k * 256 + (ttid & ~63)) * 8), 16, 0, 0);
       }
     }
   };
@@ -525,8 +571,13 @@ __global__ __launch_bounds__(512, 2) void conv_tiled_kernel(TiledParams p) {
   long long prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   PROF_T(pk2);
 #endif
-  for (int phase = 0; phase < nphase; ++phase) {
+  // Every compute phase of a team is followed by a load phase of the same team (its epilogue runs there).  The loop ends one
+  // phase after both teams have reported "nothing left": the flags are read a phase late so that the LDS read's latency sits
+  // under the phase's own work instead of in front of it.
+  for (int phase = 0; !both_done; ++phase) {
     const bool loading = ((phase + team) & 1) == 0;  // team-uniform (=> wave-uniform)
+    typedef int i32x2 __attribute__((ext_vector_type(2)));
+    const i32x2 fl = phase > 0 ? *reinterpret_cast<const volatile i32x2*>(ctl + 4 + 2 * ((phase - 1) & 3)) : i32x2{0, 0};
     PROF_T(pt0);
     if (loading) {
       bf16x8 exr[NEX > 0 ? NEX : 1][TY];
@@ -541,14 +592,23 @@ __global__ __launch_bounds__(512, 2) void conv_tiled_kernel(TiledParams p) {
           }
         }
       }
-      if (load_k < my_tiles) {   // brick load_k == the next brick to compute: (c_tz, c_tx, c_ty)
-        const bool col_start = load_k == 0 || c_tz == 0;
-        if (RING == 2) {
-          if (col_start) issue_pair(c_tz, c_tx, c_ty, 0);
+      if (!finished) {
+        bool fresh = false;   // first brick of a unit: nothing of it is in the ring yet
+        if (u_cur == u_end) {
+          const int s0 = __builtin_amdgcn_readfirstlane(ctl[2 * team]);
+          if (s0 < 0) {
+            finished = true;
+          } else {
+            u_cur = s0;
+            u_end = __builtin_amdgcn_readfirstlane(ctl[2 * team + 1]);
+            c_tz = s0 % p.tiles_z; c_tx = (s0 / p.tiles_z) % p.tiles_x; c_ty = s0 / (p.tiles_z * p.tiles_x);
+            fresh = true;
+          }
+        }
+        if (!finished) {   // stage brick u_cur = (c_tz, c_tx, c_ty); both pairs when it opens a unit or a z-column
+          if (fresh || c_tz == 0) issue_pair(c_tz, c_tx, c_ty, 0);
           issue_pair(c_tz, c_tx, c_ty, 1);
-        } else if (col_start) {
-          if (load_k == 0) issue_pair(c_tz, c_tx, c_ty, 0);   // (later columns: the lower pair went out under the previous brick's MFMAs)
-          issue_pair(c_tz, c_tx, c_ty, 1);
+          staged = true;
         }
       }
       PROF_T(pt1);
@@ -696,8 +756,6 @@ __global__ __launch_bounds__(512, 2) void conv_tiled_kernel(TiledParams p) {
           }
         }
       }
-      ++load_k;
-      if (RING == 3) __builtin_amdgcn_s_waitcnt(0);   // this team's LDS-DMA pieces (not modelled by the compiler) have landed
 #ifdef RTP_TILED_PROF
       PROF_T(pt2);
       PROF_ADD(4, pt1, pt2);
@@ -707,13 +765,17 @@ __global__ __launch_bounds__(512, 2) void conv_tiled_kernel(TiledParams p) {
       prof_acc[7] += 1;
       continue;
 #endif
-    } else if (comp_k < load_k && comp_k < my_tiles) {
-      ++comp_k;
+    } else if (staged) {
+      staged = false;
       const int z0 = c_tz * TZ, y0 = c_ty * TY, x0 = c_tx * TX;
       if (++c_tz == p.tiles_z) { c_tz = 0; if (++c_tx == p.tiles_x) { c_tx = 0; ++c_ty; } }
+      // the unit's last brick: the claimer asks for the next unit NOW -- the counter's answer travels under this phase's MFMAs
+      // and is published (LDS) at its end, for the team's next load phase
+      const bool unit_ends = ++u_cur == u_end;
+      int take = 0;
+      if (unit_ends && claimer && dyn) take = rtp_claim_take(p.claim + n * p.ranges + rng, 1);
       const int slot_a = (ring_cur + RING - 2) % RING, slot_b = (ring_cur + RING - 1) % RING;   // the last two pairs staged
-      if (RING == 3 && comp_k < my_tiles) issue_pair(c_tz, c_tx, c_ty, c_tz == 0 ? 0 : 1);   // next brick's missing pair, into the free slot
-      if (x0 + wx * 16 >= p.W) { PHASE_SYNC(); continue; }  // wave-uniform: this wave's 16-voxel column is padding
+      if (x0 + wx * 16 >= p.W) { PHASE_SYNC(); continue; }  // wave-uniform: this wave's 16-voxel column is padding (never the claimer's: wx = 0)
 
 #pragma unroll
       for (int t = 0; t < TY; ++t)
@@ -736,7 +798,6 @@ __global__ __launch_bounds__(512, 2) void conv_tiled_kernel(TiledParams p) {
           else pre_r4[t] = *reinterpret_cast<const bf16x4*>(rp);
         }
       }
-      if (p.tsync == 2) { if (team == 0) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(2); }
       PROF_T(pc1);
       PROF_ADD(0, pt0, pc1);
       if (!(p.dbg & 1)) {
@@ -805,7 +866,10 @@ __global__ __launch_bounds__(512, 2) void conv_tiled_kernel(TiledParams p) {
 #endif
         }
       }
-      if (p.tsync == 2) __builtin_amdgcn_s_setprio(0);
+      if (unit_ends && claimer) {
+        if (dyn) claim_finish(take, true);
+        else ctl[2 * team] = -1;
+      }
 #ifdef RTP_TILED_PROF
       __builtin_amdgcn_s_waitcnt(0);   // (MFMA results are not covered by a counter: the delta below is issue time)
       PROF_T(pc2);
@@ -836,7 +900,6 @@ __global__ __launch_bounds__(512, 2) void conv_tiled_kernel(TiledParams p) {
     }
   }
 #endif
-  if (p.tsync) __syncthreads();   // both teams done before the workgroup-wide reductions below
 #undef PHASE_SYNC
   if constexpr (FUSE) {
     if (p.tot_out && tid < 32) {   // (the phase loop ends with a barrier)
@@ -891,7 +954,11 @@ static bool tiled_geometry_ok(const RtpAct* x, const RtpConvGeom* g, int transpo
 static int tiled_wgs_per_sample(const RtpConvGeom* g) {
   const int tiles = (g->di / TZ) * (g->hi / TY) * ((g->wi + TX - 1) / TX);
   static const int total_wgs = getenv("RTP_TILED_WGS") ? atoi(getenv("RTP_TILED_WGS")) : 256;  // experiments: leave CUs to other streams
-  int wgs = total_wgs / g->n;  // workgroups per sample: one workgroup per CU when N divides 256
+  // launches of the lower levels (fewer than 2048 bricks in all: the level-1 tensors at the native shape) can be kept NARROW --
+  // fewer workgroups with more bricks each -- so that they run beside the main lane's kernels instead of taking every CU for a
+  // launch that leaves most of them idle (RTP_TILED_WGS_SMALL; 0 = as the large ones)
+  static const int small_wgs = getenv("RTP_TILED_WGS_SMALL") ? atoi(getenv("RTP_TILED_WGS_SMALL")) : 0;
+  int wgs = ((small_wgs > 0 && (long)tiles * g->n < 2048) ? small_wgs : total_wgs) / g->n;  // workgroups per sample: one workgroup per CU when N divides 256
   if (wgs < 1) wgs = 1;
   if (wgs * 2 > tiles) wgs = (tiles + 1) / 2;
   // small volumes: a workgroup pays ~6 us of fixed cost (55 KB of weights, pipeline ramp) whatever it computes; with fewer than
@@ -945,8 +1012,24 @@ int rtp_conv_tiled_try(const RtpAct* x, const void* wf, int w_per_sample, const 
   p.teams_per_sample = wgs * 2;
   static const int dbg = getenv("RTP_TILED_DBG") ? atoi(getenv("RTP_TILED_DBG")) : 0;
   p.dbg = dbg;
-  static const int tsync = getenv("RTP_TILED_SYNC") ? atoi(getenv("RTP_TILED_SYNC")) : 0;
-  p.tsync = tsync;
+  // dynamic brick claiming (rtp_claim.h; RTP_CLAIM=1 switches it on; default: the static deal, RTP_TILED_UNIT: bricks per claim)
+  p.claim = nullptr; p.ranges = 1; p.total_wgs = p.N * wgs; p.nbig = 0; p.ubig = 4; p.usmall = 2;
+  if (rtp_claim_enabled()) {
+    // one range per XCD that serves a sample (the kernel's workgroup permutation gives XCD k the k-th eighth of the grid)
+    int ranges = 1;
+    const int grid = p.N * wgs;
+    if (grid % 8 == 0 && p.N < 8 && 8 % p.N == 0 && wgs % (8 / p.N) == 0 && p.tiles_per_sample >= 8 * (8 / p.N)) ranges = 8 / p.N;
+    p.claim = rtp_claim_slot((const char*)y->ptr + 2 * (size_t)y->co, p.N * ranges);
+    p.ranges = p.claim ? ranges : 1;
+    // unit schedule of a range (RTP_TILED_UBIG / RTP_TILED_USMALL / RTP_TILED_BIGPCT: experiments): ~80 % of its bricks in big
+    // units, a whole number of them per team, the rest in small ones
+    static const int ubig = getenv("RTP_TILED_UBIG") ? atoi(getenv("RTP_TILED_UBIG")) : 4;
+    static const int usmall = getenv("RTP_TILED_USMALL") ? atoi(getenv("RTP_TILED_USMALL")) : 2;
+    static const int bigpct = getenv("RTP_TILED_BIGPCT") ? atoi(getenv("RTP_TILED_BIGPCT")) : 80;
+    p.ubig = ubig < 1 ? 1 : ubig; p.usmall = usmall < 1 ? 1 : usmall;
+    const int len = p.tiles_per_sample / p.ranges, teams = 2 * wgs / p.ranges;
+    p.nbig = (int)((long)len * bigpct / 100 / p.ubig) / teams * teams;
+  }
   p.nextra = 0; p.mask = 0; p.tot_out = nullptr;
   p.qpart = nullptr; p.q_nsplit = 0; p.gn_p = p.gn_mr = p.gn_gamma = nullptr; p.gn_groups = 1; p.gn_m = 1.f; p.coef_out = nullptr;
   p.tg = nullptr; p.csum_out = nullptr;
@@ -983,7 +1066,7 @@ int rtp_conv_tiled_try(const RtpAct* x, const void* wf, int w_per_sample, const 
     }
   }
   const int nt = Co / 16;
-  const size_t shm = sizeof(bf16_t) * (27 * (size_t)Co * 32 + 2 * (size_t)HALO_VOX * 32) + 27 * (size_t)Co * sizeof(float) + 16;
+  const size_t shm = sizeof(bf16_t) * (27 * (size_t)Co * 32 + 2 * (size_t)HALO_VOX * 32) + 27 * (size_t)Co * sizeof(float) + 64;
   RtpProfScope prof((Co == 32 && (long)p.N * p.D * p.H * p.W >= (1L << 20)) ? (transposed ? RTP_FAM_CONV_TILED_FULL_BWD : RTP_FAM_CONV_TILED_FULL)
                                                                                 : RTP_FAM_CONV_TILED, s);
   using Kern = void (*)(TiledParams);
@@ -994,27 +1077,25 @@ int rtp_conv_tiled_try(const RtpAct* x, const void* wf, int w_per_sample, const 
   static const Kern table[2][2][3][2] = {{RTP_TILED_ROW(1, false), RTP_TILED_ROW(1, true)},
                                          {RTP_TILED_ROW(2, false), RTP_TILED_ROW(2, true)}};
 #undef RTP_TILED_ROW
-  static bool attr_done = false;
-  if (!attr_done) {
-    const int big = (int)(sizeof(bf16_t) * (27 * (size_t)32 * 32 + 2 * (size_t)HALO_VOX * 32) + 27 * 32 * sizeof(float));
+  static bool attr_done[RTP_MAX_DEVICES] = {};
+  if (rtp_once_per_device(attr_done)) {
+    const int big = (int)(sizeof(bf16_t) * (27 * (size_t)32 * 32 + 2 * (size_t)HALO_VOX * 32) + 27 * 32 * sizeof(float) + 64);
     for (int a = 0; a < 2; ++a)
       for (int b = 0; b < 2; ++b)
         for (int c = 0; c < 3; ++c)
           for (int d = 0; d < 2; ++d)
             if (table[a][b][c][d])
               (void)hipFuncSetAttribute((const void*)table[a][b][c][d], hipFuncAttributeMaxDynamicSharedMemorySize, big);
-    attr_done = true;
   }
   const int aux = stat_x ? 2 : (res ? 1 : 0);
   if (fuse) {
     static const Kern ftab[4] = {conv_tiled_kernel<2, false, 2, false, 1>, conv_tiled_kernel<2, false, 2, false, 2>,
                                  conv_tiled_kernel<2, false, 2, false, 3>, conv_tiled_kernel<2, false, 2, false, 4>};
-    static bool fattr = false;
-    if (!fattr) {
+    static bool fattr[RTP_MAX_DEVICES] = {};
+    if (rtp_once_per_device(fattr)) {
       for (int e = 0; e < 4; ++e)
         (void)hipFuncSetAttribute((const void*)ftab[e], hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)(sizeof(bf16_t) * (27 * (size_t)32 * 32 + 2 * (size_t)HALO_VOX * 32) + 27 * 32 * sizeof(float)));
-      fattr = true;
+                                  (int)(sizeof(bf16_t) * (27 * (size_t)32 * 32 + 2 * (size_t)HALO_VOX * 32) + 27 * 32 * sizeof(float) + 64));
     }
     hipLaunchKernelGGL(ftab[p.nextra], dim3(p.N * wgs), dim3(512), shm, s, p);
     RTP_CHECK_LAUNCH();

@@ -1597,19 +1597,22 @@ static bool dcn_gradw_fused_ok(const DcnGeom& g) {
   return g.group == 1 && g.dg == 4 && g.c == 32 && g.kh == 3 && g.kw == 3 && g.co <= 32 && (g.ho * g.wo) % 64 == 0 && g.w >= 2;
 }
 
-static void dcn_gradw_fused_launch(const float* input, const float* offset, const float* mask, const float* gradOutput,
+static int dcn_gradw_fused_launch(const float* input, const float* offset, const float* mask, const float* gradOutput,
                                    float* gradWeight, const DcnGeom& g, float scale, hipStream_t s) {
   const long tiles = (long)g.n * (g.ho * g.wo / 64);
   int tpb = (int)((tiles + 511) / 512);   // two 4-wave blocks per CU
   if (tpb < 1) tpb = 1;
   const size_t lds = sizeof(float) * 4 * 72 * DCN_GF_ROW;
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute((const void*)dcn_gradw_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr = true;
+  static bool attr[RTP_MAX_DEVICES] = {};
+  if (rtp_once_per_device(attr)) {
+    if (hipFuncSetAttribute((const void*)dcn_gradw_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+      attr[rtp_device_index()] = false;
+      return RTP_ERR_LAUNCH;
+    }
   }
   hipLaunchKernelGGL(dcn_gradw_fused_kernel, dim3((unsigned)((tiles + tpb - 1) / tpb)), dim3(256), lds, s, input, offset, mask,
                      gradOutput, gradWeight, g, scale, tpb);
+  return RTP_OK;
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
@@ -2157,13 +2160,14 @@ static int dcn_backward_fused(const float* input, const float* offset, const flo
   const char* e = getenv("RTP_DCN_SEGS");
   if (e && atoi(e) > 0) segs = atoi(e);
   else {
-    static int cus = 0;
-    if (!cus) {
-      int dev = 0;
+    static int cus_dev[RTP_MAX_DEVICES] = {};   // CU count, per device
+    const int dev = rtp_device_index();
+    if (!cus_dev[dev]) {
       hipDeviceProp_t prop;
-      if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-      if (cus < 1) cus = 256;
+      if (hipGetDeviceProperties(&prop, dev) == hipSuccess) cus_dev[dev] = prop.multiProcessorCount;
+      if (cus_dev[dev] < 1) cus_dev[dev] = 256;
     }
+    const int cus = cus_dev[dev];
     long best = -1;
     for (int sgs = 1; sgs <= 8 && sgs <= g.h; ++sgs) {
       const int rows = (g.h + sgs - 1) / sgs;
@@ -2178,13 +2182,13 @@ static int dcn_backward_fused(const float* input, const float* offset, const flo
   unsigned* rec = (unsigned*)ws;
   if (hipMemsetAsync(rec, 0, 8, s) != hipSuccess) return RTP_ERR_LAUNCH;
   const size_t lds = sizeof(float) * 4 * (72 * DCN_FB_ROW + 8 * 7 * 64);   // tiles + rings: 135 680 B, one block per CU
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute((const void*)dcn_bwd_fused_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute((const void*)dcn_bwd_fused_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute((const void*)dcn_bwd_fused_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute((const void*)dcn_bwd_fused_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr = true;
+  static bool attr[RTP_MAX_DEVICES] = {};
+  if (rtp_once_per_device(attr)) {   // 135 KB of LDS: above the default limit, the launch fails without the attribute
+    bool ok = hipFuncSetAttribute((const void*)dcn_bwd_fused_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
+    ok = ok && hipFuncSetAttribute((const void*)dcn_bwd_fused_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
+    ok = ok && hipFuncSetAttribute((const void*)dcn_bwd_fused_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
+    ok = ok && hipFuncSetAttribute((const void*)dcn_bwd_fused_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
+    if (!ok) { attr[rtp_device_index()] = false; return RTP_ERR_LAUNCH; }
   }
   const char* se = getenv("RTP_DCN_SPLIT_GW");   // weight gradient by dcn_gradw_fused_kernel (its own gather pass)
   const bool split = gradWeight && se && atoi(se) && dcn_gradw_fused_ok(g);
@@ -2197,7 +2201,7 @@ static int dcn_backward_fused(const float* input, const float* offset, const flo
                      gradOffset, gwk, rec, g, scale, strips, segs, seg_rows, overwrite)
   if (gwk) { if (x3) DCN_FB_LAUNCH(true, true); else DCN_FB_LAUNCH(true, false); }
   else { if (x3) DCN_FB_LAUNCH(false, true); else DCN_FB_LAUNCH(false, false); }
-  if (split) dcn_gradw_fused_launch(input, offset, nullptr, gradOutput, gradWeight, g, scale, s);
+  if (split && dcn_gradw_fused_launch(input, offset, nullptr, gradOutput, gradWeight, g, scale, s) != RTP_OK) return RTP_ERR_LAUNCH;
   hipLaunchKernelGGL(dcn_bwd_outlier_rows_kernel, dim3(1024), dim3(64), 0, s, offset, gradOutput, weight, gradInput, rec, g);
   RTP_CHECK_LAUNCH();
   return RTP_OK;
@@ -2210,7 +2214,7 @@ static int dcn_backward_params(const float* input, const float* offset, const fl
   const int cg = g.c / g.group, cog = g.co / g.group;
   RtpProfScope prof(RTP_FAM_DCN, s);
   if (dcn_gradw_fused_ok(g)) {   // no column matrix: gather -> LDS transpose -> MFMA in one launch over all images (ws unused)
-    dcn_gradw_fused_launch(input, offset, mask, gradOutput, gradWeight, g, scale, s);
+    if (dcn_gradw_fused_launch(input, offset, mask, gradOutput, gradWeight, g, scale, s) != RTP_OK) return RTP_ERR_LAUNCH;
     RTP_CHECK_LAUNCH();
     return RTP_OK;
   }

@@ -424,10 +424,9 @@ int rtp_dgrad_s2_try(const RtpAct* gy, const void* wd, const RtpAct* dx, const R
   const size_t shm = sizeof(bf16_t) * (27 * 32 * 32 + 2 * GVOX * 32) + 864 * sizeof(float);
   using Kern = void (*)(S2Params);
   static const Kern tab[5] = {dgrad_s2_kernel<0>, dgrad_s2_kernel<1>, dgrad_s2_kernel<2>, dgrad_s2_kernel<3>, dgrad_s2_kernel<4>};
-  static bool attr = false;
-  if (!attr) {
+  static bool attr[RTP_MAX_DEVICES] = {};
+  if (rtp_once_per_device(attr)) {
     for (int i = 0; i < 5; ++i) (void)hipFuncSetAttribute((const void*)tab[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-    attr = true;
   }
   RtpProfScope prof(RTP_FAM_CONV_TILED, s);
   hipLaunchKernelGGL(tab[mode], dim3(p.N * p.wgs_per_sample), dim3(256), shm, s, p);

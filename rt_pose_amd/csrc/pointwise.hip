@@ -348,10 +348,9 @@ extern "C" int rtp_grad_combine_cls_lazy(const RtpTerm* terms, int nterms, const
   hipStream_t s = (hipStream_t)stream;
   RtpProfScope prof(RTP_FAM_POINTWISE, s);
   const size_t lds = sizeof(float) * (4 * 64 * p.c + RTP_MAX_TERMS * p.c * 3);
-  static bool attr_done = false;
-  if (!attr_done) {
+  static bool attr_done[RTP_MAX_DEVICES] = {};
+  if (rtp_once_per_device(attr_done)) {
     (void)hipFuncSetAttribute((const void*)grad_combine_cls_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-    attr_done = true;
   }
   hipLaunchKernelGGL(grad_combine_cls_kernel, dim3(nsplit, n), dim3(256), lds, s, p, d, h, w, nsplit, cls_scratch);
   RTP_CHECK_LAUNCH();

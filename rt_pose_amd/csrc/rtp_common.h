@@ -76,3 +76,19 @@ __host__ __device__ __forceinline__ bool tap_inb_1d(int k, int first, int last, 
   } while (0)
 
 static inline int rtp_div_up(long a, long b) { return (int)((a + b - 1) / b); }
+
+// One-time per-DEVICE set-up (hipFuncSetAttribute and cached device properties are per device: a process-wide `static bool`
+// would leave a second GPU of the same process without its LDS limit).  `flags` is a static bool[RTP_MAX_DEVICES]; true exactly
+// once per device.
+#define RTP_MAX_DEVICES 16
+static inline int rtp_device_index() {
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= RTP_MAX_DEVICES) d = 0;
+  return d;
+}
+static inline bool rtp_once_per_device(bool* flags) {
+  const int d = rtp_device_index();
+  if (flags[d]) return false;
+  flags[d] = true;
+  return true;
+}

@@ -284,10 +284,9 @@ extern "C" int rtp_wgrad(const RtpAct* gy, const RtpAct* x, const RtpConvGeom* g
   static const bool no_1x1 = getenv("RTP_DISABLE_WGRAD_1X1") != nullptr;
   if (!no_1x1 && p.ks == 1 && p.stride == 1 && p.pad == 0 && (p.co32 / 32) * p.citiles <= 16) {
     const size_t shm = sizeof(bf16_t) * (size_t)(p.co32 / 32 + p.citiles) * W1_VB * 32;
-    static bool attr = false;
-    if (!attr) {
+    static bool attr[RTP_MAX_DEVICES] = {};
+    if (rtp_once_per_device(attr)) {
       (void)hipFuncSetAttribute((const void*)wgrad_1x1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      attr = true;
     }
     hipLaunchKernelGGL(wgrad_1x1_kernel, dim3(nsplit, p.N), dim3(256), shm, s, p);
     RTP_CHECK_LAUNCH();

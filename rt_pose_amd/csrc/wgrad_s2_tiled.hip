@@ -260,10 +260,9 @@ int rtp_wgrad_s2_try(const RtpAct* gy, const RtpAct* x, const RtpConvGeom* g, in
   p.wgs_per_sample = nsplit;
   const size_t shm = sizeof(bf16_t) * (size_t)W2_RING * W2_SLOT;
   RtpProfScope prof(RTP_FAM_WGRAD_TILED, s);
-  static bool attr = false;
-  if (!attr) {
+  static bool attr[RTP_MAX_DEVICES] = {};
+  if (rtp_once_per_device(attr)) {
     (void)hipFuncSetAttribute((const void*)wgrad_s2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-    attr = true;
   }
   hipLaunchKernelGGL(wgrad_s2_kernel, dim3(p.N * nsplit), dim3(512), shm, s, p);
   RTP_CHECK_LAUNCH();

@@ -11,6 +11,7 @@
 // LDS images rotate the 16-B chunk index by (x>>2) -- conflict-free for the tr-read lane groups (voxels v and v+8).
 #include <stdlib.h>
 
+#include "rtp_claim.h"
 #include "rtp_common.h"
 #include "rtp_prof.h"
 
@@ -45,7 +46,14 @@ struct WgTiledParams {
   // dense [27][32][32] for a 32 -> 32 layer; for a wider conv run as (output slice, input slice) launches every launch fills
   // its window of the SAME [27][Co][Ci] slabs, which rtp_wgrad_fold then reads like the generic kernel's
   int slab_rows, slab_cols;
+  // Dynamic brick claiming (rtp_claim.h).  claim != null: a workgroup's first brick is fixed (its index within its home range), every
+  // further one is taken from the counters claim[n * ranges + r] -- a sample's bricks are cut into `ranges` contiguous ranges, one per
+  // XCD that serves the sample; a workgroup moves on to the other ranges when its own is empty.  claim == null: the static deal.
+  // Claims are UNITS of `unit` consecutive bricks (1 or 2), by index: the counter's answer is asked for at a unit's first brick and
+  // needed only after its last one.
+  int* claim; int ranges, total_wgs, unit;
 };
+#define WG_NONE 0x3fffffff
 
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
@@ -127,9 +135,21 @@ __global__ __attribute__((amdgpu_flat_work_group_size(512, 512), amdgpu_waves_pe
   const int n = bid / p.wgs_per_sample;
   const int wg = bid - n * p.wgs_per_sample;
   const long vox_n = (long)n * p.D * p.H * p.W;
-  const int t_begin = (int)((long)wg * p.tiles_per_sample / p.wgs_per_sample);  // contiguous run, z fastest (L2 reuse of shared z-planes)
-  const int my_tiles = (int)((long)(wg + 1) * p.tiles_per_sample / p.wgs_per_sample) - t_begin;
   constexpr int BUF = (HALO_VOX + BRICK_VOX) * 32;  // elements per staged brick (x halo + gy)
+  // ---- which bricks: iteration k of the workgroup works on brick tile_k.  Static deal: a contiguous run, z fastest (L2 reuse of
+  // shared z-planes).  Dynamic: the first brick is the workgroup's own, the others are claimed one at a time, an iteration ahead
+  // (the counter's answer travels under the staging of the current brick); ctl[k & 3] = tile_k, published by the claimer (first
+  // loader thread) before the barrier that ends iteration k - 1.
+  const bool dyn = p.claim != nullptr;
+  int* ctl = reinterpret_cast<int*>(lds + 2 * BUF);
+  const int wgs_r = p.wgs_per_sample / p.ranges;       // workgroups per home range (dyn: ranges divides the workgroups)
+  int rng = dyn ? wg / wgs_r : 0;
+  auto range_lo = [&](int r) { return (int)((long)r * p.tiles_per_sample / p.ranges); };
+  // the workgroup's first unit: its own (index within the home range) / static: its whole run
+  const int t_begin = dyn ? range_lo(rng) + p.unit * (wg - rng * wgs_r) : (int)((long)wg * p.tiles_per_sample / p.wgs_per_sample);
+  const int t_lim = dyn ? range_lo(rng + 1) : (int)((long)(wg + 1) * p.tiles_per_sample / p.wgs_per_sample);
+  const int t_end = dyn ? (t_begin + p.unit < t_lim ? t_begin + p.unit : t_lim) : t_lim;
+  const int first = t_begin < t_end ? t_begin : WG_NONE;
 
   if (loader) {
     // ---- producer: brick k -> buffer k&1, one brick ahead of the consumers.
@@ -167,17 +187,22 @@ __global__ __attribute__((amdgpu_flat_work_group_size(512, 512), amdgpu_waves_pe
     for (int j = 0; j < 8; ++j) call[j] = cedge[j] = 0.f;
     // One [27][32] subset table PER LOADER WAVE in LDS (only allocated when p.tg: no cross-wave add order to vary from run to
     // run) + a counter: the last loader wave to finish adds the four tables in fixed order and stores the workgroup's partial.
-    float* Tall = reinterpret_cast<float*>(lds + 2 * BUF);
+    float* Tall = reinterpret_cast<float*>(lds + 2 * BUF) + 8;   // (behind the four brick words)
     float* T = Tall + (wave & 3) * 27 * 32;
     int* tcnt = reinterpret_cast<int*>(Tall + 4 * 27 * 32);
     if (p.tg) {
       for (int i = lane; i < 27 * 32; i += 64) T[i] = 0.f;
       if (ttid == 0) *tcnt = 0;
     }
-    for (int k = 0; k <= my_tiles; ++k) {
-      if (k < my_tiles) {
+    int prev_tile = WG_NONE;
+    int c_end = t_end, take = 0, nfail = 0;   // claimer (first loader thread): end of the current unit, the outstanding answer for the next one
+    bool c_first = true;
+    for (int k = 0;; ++k) {
+      const int tile = k == 0 ? first : __builtin_amdgcn_readfirstlane(ctl[k & 3]);
+      const bool have = tile < WG_NONE;
+      if (dyn && have && ttid == 0 && c_first) take = rtp_claim_take(p.claim + n * p.ranges + rng, 1);   // the NEXT unit: asked for now
+      if (have) {
         bf16_t* xL = lds + (k & 1) * BUF;
-        const int tile = t_begin + k;
         const int tz = tile % p.tiles_z, tx = (tile / p.tiles_z) % p.tiles_x, ty = tile / (p.tiles_z * p.tiles_x);  // z fastest
         const int z0 = tz * TZ, y0 = ty * TY, x0 = tx * TX;
         const int org = (z0 * p.H + y0) * p.W + x0;  // brick origin voxel (scalar)
@@ -196,8 +221,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(512, 512), amdgpu_waves_pe
       }
       if (p.tg && k >= 1) {
         // sums of gy brick k-1 (landed before the previous barrier; the consumers are reading the same buffer now)
-        const int tile = t_begin + k - 1;
-        const int tz = tile % p.tiles_z, tx = (tile / p.tiles_z) % p.tiles_x, ty = tile / (p.tiles_z * p.tiles_x);
+        const int tz = prev_tile % p.tiles_z, tx = (prev_tile / p.tiles_z) % p.tiles_x, ty = prev_tile / (p.tiles_z * p.tiles_x);
         const int z = tz * TZ + (rr >> 2), y = ty * TY + (rr & 3), x0 = tx * TX;
         const bf16_t* gb = lds + ((k - 1) & 1) * BUF + HALO_VOX * 32 + (rr * TX + seg * 4) * 32 + (((c8 + seg) & 3) << 3);
         bf16x8 v4[4];
@@ -239,7 +263,30 @@ __global__ __attribute__((amdgpu_flat_work_group_size(512, 512), amdgpu_waves_pe
           }
         }
       }
+      if (ttid == 0 && have) {   // publish brick k + 1
+        int nxt = WG_NONE;
+        if (tile + 1 < c_end) {
+          nxt = tile + 1;
+          c_first = false;
+        } else if (dyn) {   // the unit is done: the next one, from the answer asked for at its first brick
+          int u = take;
+          for (;;) {   // home range empty: the other ranges (cyclically, each at most once), one round trip each
+            const int lo = range_lo(rng), len = range_lo(rng + 1) - lo, b = p.unit * (wgs_r + u);
+            // (every workgroup of the sample ends with exactly one failed take on every range's counter; the first wgs_r units
+            // of a range are never asked for)
+            rtp_claim_reset_if_last(p.claim + n * p.ranges + rng, u, (len + p.unit - 1) / p.unit - wgs_r, p.wgs_per_sample);
+            if (b < len) { nxt = lo + b; c_end = lo + (b + p.unit < len ? b + p.unit : len); break; }
+            if (++nfail >= p.ranges) break;
+            rng = rng + 1 == p.ranges ? 0 : rng + 1;
+            u = rtp_claim_take(p.claim + n * p.ranges + rng, 1);
+          }
+          c_first = true;
+        }
+        ctl[(k + 1) & 3] = nxt;
+      }
+      prev_tile = tile;
       __syncthreads();  // (drains the DMA: hipcc emits vmcnt(0) before the barrier)
+      if (!have) break;
     }
     if (p.tg) {   // whole-volume subsets (all, all, all | first x | last x) kept in registers until now
       float* Tg = T;   // (this wave's LDS table; flushed below)
@@ -302,7 +349,9 @@ __global__ __attribute__((amdgpu_flat_work_group_size(512, 512), amdgpu_waves_pe
     }
   }
   __syncthreads();  // brick 0 staged
-  for (int k = 0; k < my_tiles; ++k) {
+  for (int k = 0;; ++k) {
+    const int tile = k == 0 ? first : __builtin_amdgcn_readfirstlane(ctl[k & 3]);
+    if (tile >= WG_NONE) break;
     if (!(p.dbg & 1)) wg_brick(la, acc);
     // flip every fragment address to the other staging buffer (in place: no second address set stays live)
     const unsigned delta = (k & 1) ? (unsigned)(-(int)(2u * BUF)) : 2u * BUF;
@@ -379,7 +428,8 @@ static bool wg_tiled_applicable(const RtpConvGeom* g) {
 static int wg_tiled_wgs(const RtpConvGeom* g) {
   const int tiles = (g->di / TZ) * (g->hi / TY) * ((g->wi + TX - 1) / TX);
   static const int total_wgs = getenv("RTP_WGRAD_TILED_WGS") ? atoi(getenv("RTP_WGRAD_TILED_WGS")) : 256;  // experiments: fewer slabs / CUs left to other streams
-  int wgs = total_wgs / g->n;
+  static const int small_wgs = getenv("RTP_WGRAD_WGS_SMALL") ? atoi(getenv("RTP_WGRAD_WGS_SMALL")) : 0;   // (conv_tiled.hip: narrow launches for the lower levels)
+  int wgs = ((small_wgs > 0 && (long)tiles * g->n < 2048) ? small_wgs : total_wgs) / g->n;
   if (wgs < 1) wgs = 1;
   if (wgs > tiles) wgs = tiles;
   return wgs;
@@ -425,14 +475,24 @@ int rtp_wgrad_tiled_try(const RtpAct* gy, const RtpAct* x, const RtpConvGeom* g,
   static const int dbg = getenv("RTP_TILED_DBG") ? atoi(getenv("RTP_TILED_DBG")) : 0;
   p.dbg = dbg;
   p.wd = (const bf16_t*)wd; p.qpart = wd ? qpart : nullptr; p.tg = tg;
-  const size_t shm_base = sizeof(bf16_t) * 2 * (size_t)(HALO_VOX + BRICK_VOX) * 32;
+  // dynamic brick claiming (rtp_claim.h; RTP_CLAIM=1 switches it on; default: the static deal)
+  p.claim = nullptr; p.ranges = 1; p.total_wgs = p.N * nsplit; p.unit = 1;
+  if (rtp_claim_enabled()) {
+    int ranges = 1;
+    const int grid = p.N * nsplit;
+    if (grid % 8 == 0 && p.N < 8 && 8 % p.N == 0 && nsplit % (8 / p.N) == 0 && p.tiles_per_sample >= 8 * (8 / p.N)) ranges = 8 / p.N;
+    p.claim = rtp_claim_slot(gp, p.N * ranges);
+    p.ranges = p.claim ? ranges : 1;
+    static const int unit = getenv("RTP_WGRAD_UNIT") ? atoi(getenv("RTP_WGRAD_UNIT")) : 2;
+    p.unit = (unit >= 2 && p.tiles_per_sample / p.ranges >= 4 * (nsplit / p.ranges)) ? 2 : 1;
+  }
+  const size_t shm_base = sizeof(bf16_t) * 2 * (size_t)(HALO_VOX + BRICK_VOX) * 32 + 32;
   const size_t shm = shm_base + (tg ? 4 * 27 * 32 * sizeof(float) + 16 : 0);
   RtpProfScope prof(RTP_FAM_WGRAD_TILED, s);
-  static bool attr = false;
-  if (!attr) {
+  static bool attr[RTP_MAX_DEVICES] = {};
+  if (rtp_once_per_device(attr)) {
     (void)hipFuncSetAttribute((const void*)wgrad_tiled_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)(shm_base + 4 * 27 * 32 * sizeof(float) + 16));
-    attr = true;
   }
   hipLaunchKernelGGL(wgrad_tiled_kernel, dim3(p.N * nsplit), dim3(512), shm, s, p);
   RTP_CHECK_LAUNCH();

@@ -161,6 +161,7 @@ class Graph:
         # their all-reduce runs beside the rest of the backward pass.  early_tail_index: position of that flush in self.bwd.
         self.early_flush = False
         self.early_tail_index = None
+        self.early_tail_launch = None
         self.group = None          # (block, row) tag the ops created from now on carry (net.build_backbone: fuse rows)
         self.full_vox = None       # voxels of the first (full-resolution) activation: lanes are assigned by resolution
         # algorithmic FLOPs (2*MACs of real channels) per kernel family, per replay of the lists
@@ -555,6 +556,7 @@ class Graph:
                         lz.materialise()
                 self.emit_tail(L_WG_LOW)
                 self.early_tail_index = len(self.bwd) - 1
+                self.early_tail_launch = self.bwd[-1]   # the Launch object itself: list positions do not survive re-orderings
             gy = self.finalize_grad(op.y, isinstance(op, (ConvOp, SplitConvOp, CoSplitConvOp)) and bool(op.gn or op.bname))
             if gy is None:
                 continue

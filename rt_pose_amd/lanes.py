@@ -111,25 +111,7 @@ def reorder_critical_path(launches):
     have all been issued, the one with the largest bottom level (its own estimated duration + the longest chain behind it) goes
     next.  Durations are estimated from the bytes of the buffers a launch names (3 TB/s) plus 4 us."""
     n = len(launches)
-    last_w, readers = {}, {}
-    preds = [set() for _ in range(n)]
-    for i, L in enumerate(launches):
-        for k in L.reads:
-            j = last_w.get(k)
-            if j is not None:
-                preds[i].add(j)
-        for k in L.writes:
-            j = last_w.get(k)
-            if j is not None:
-                preds[i].add(j)
-            preds[i].update(readers.get(k, ()))
-        for k in L.writes:
-            last_w[k] = i
-            readers[k] = []
-        for k in L.reads:
-            if k not in L.writes:
-                readers.setdefault(k, []).append(i)
-        preds[i].discard(i)
+    preds = _order_preds(launches)
     succs = [[] for _ in range(n)]
     for i in range(n):
         for j in preds[i]:

@@ -65,6 +65,9 @@ class DataParallelTrainer:
                  stream=None):
         self.spec = s = configs.spec(name)
         self.name, self.rank, self.world = name, rank, world_size
+        if backend is None and str(device).startswith("cuda"):
+            from . import pin_hw_queues
+            self.hw_queues = pin_hw_queues()   # before the HIP runtime initialises (no effect, and a warning, afterwards)
         self.be = backend if backend is not None else HipBackend(device)
         self.shapes = configs.param_shapes(name)
         self.flat = FlatParams(self.shapes, self.be.alloc)
@@ -120,10 +123,14 @@ class DataParallelTrainer:
         as a launch of the backward list, right behind the flush (same lane: stream order makes it wait for exactly that flush)."""
         from .lanes import LANE_MAP, LanePlan, Launch, L_WG_LOW
         eng, g = self.engine, self.engine.graph
-        idx = g.early_tail_index
-        if idx is None:
+        # the flush is looked up by identity AFTER every re-ordering of the list (engine.py hoists launches by tag): its creation
+        # index (g.early_tail_index) is a position in Graph.bwd, not in eng.bwd
+        tail = getattr(g, "early_tail_launch", None)
+        if tail is None or not any(L is tail for L in eng.bwd):
             self.ar_buckets = 1
             return
+        idx = next(i for i, L in enumerate(eng.bwd) if L is tail)
+        assert eng.bwd[idx].tag.startswith("tail"), "the early bucket must sit right behind a tail flush, found %r" % eng.bwd[idx].tag
         ptr2name = {t.data_ptr(): k for k, t in self.flat.grads.items()}
         early = {ptr2name[w] for L in eng.bwd[:idx + 1] for w in L.writes if w in ptr2name}
         late = {ptr2name[w] for L in eng.bwd[idx + 1:] for w in L.writes if w in ptr2name}
@@ -137,7 +144,8 @@ class DataParallelTrainer:
         def kick(stream_ptr):
             import torch.distributed as dist
             if stream_ptr is not None and self.be.name == "hip":
-                ext = torch.cuda.ExternalStream(stream_ptr.value if hasattr(stream_ptr, "value") else int(stream_ptr), device=self.be.device)
+                raw = stream_ptr.value if hasattr(stream_ptr, "value") else int(stream_ptr)   # c_void_p(0).value is None: the null stream
+                ext = torch.cuda.ExternalStream(raw or 0, device=self.be.device)
                 with torch.cuda.stream(ext):   # the collective is ordered behind this lane's work and runs on the group's own stream
                     self._ar_pending = dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
             else:
