@@ -68,6 +68,14 @@ extern "C" int rtp_tiled_prof_read(long long* host) {
 #define PROF_ADD(slot, a, b)
 #endif  // zero-initialised: source of padding voxels
 
+// RTP_TILED_DBG (environment; phase skipping for timing experiments, results wrong) only exists in builds made with
+// -DRTP_TILED_DBGFLAGS: in the product build the flag tests are compile-time false and cost no control flow.
+#ifdef RTP_TILED_DBGFLAGS
+#define RTP_DBG(bit) (p.dbg & (bit))
+#else
+#define RTP_DBG(bit) false
+#endif
+
 struct TiledParams {
   const bf16_t* x; const bf16_t* w; const float* btab; const bf16_t* res; void* y;  // res: residual (AUX 1) or the statistics' second operand (AUX 2)
   float* stat_out;  // [N][workgroups per sample][Co][2] or null
@@ -149,9 +157,13 @@ __device__ __forceinline__ void cv_sched() {
 // AUX: 0 none, 1 residual added in the epilogue, 2 second operand of the statistics (not added).  STAT: emit statistics.
 // FUSEX: 0 = plain epilogue; 1 + NEX = fused data-gradient epilogue with NEX (0..3) extra gradient terms (compile-time: the
 // terms' prefetch registers exist only in the variant that needs them -- the kernel sits at the 256-VGPR limit).
-template <int NT, bool HAS_BTAB, int AUX, bool STAT, int FUSEX = 0>
+// GEN: the launch also takes an fp32 partial sum in (acc32) and / or writes fp32 (y_fp32): the channel-slice chains and the head's
+// logits.  Compile-time, so that the common bf16-in / bf16-out epilogue carries neither their branches nor the register copies
+// the merge points cost.
+template <int NT, bool HAS_BTAB, int AUX, bool STAT, int FUSEX = 0, bool GEN = false>
 __global__ __launch_bounds__(512, 2) void conv_tiled_kernel(TiledParams p) {
   constexpr bool FUSE = FUSEX > 0;
+  static_assert(!(FUSE && GEN), "the fused data-gradient epilogue is bf16 in / bf16 out");
   constexpr int NEX = FUSE ? FUSEX - 1 : 0;
   static_assert(!FUSE || (NT == 2 && !HAS_BTAB && AUX == 2 && !STAT), "fused data-gradient epilogue: 32 channels, x in the AUX slot");
   extern __shared__ __attribute__((aligned(16))) bf16_t lds[];
@@ -538,7 +550,7 @@ __global__ __launch_bounds__(512, 2) void conv_tiled_kernel(TiledParams p) {
     const int xlim = (p.W - x0 + 1) << 8;  // haloed x index >= this lies beyond the volume (W need not be a multiple of TX)
     const int ring_slot = ring_cur;
     ring_cur = ring_cur == RING - 1 ? 0 : ring_cur + 1;
-    if (p.dbg & 2) return;
+    if (RTP_DBG(2)) return;
 #pragma unroll
     for (int k = 0; k < STAGE_BATCH; ++k) {
       if (k * 256 + ttid < PAIR_ITEMS) {  // (TY 4: the last piece is half a wave -- EXEC masks the other lanes' transfers)
@@ -557,12 +569,51 @@ __global__ __launch_bounds__(512, 2) void conv_tiled_kernel(TiledParams p) {
   // between two MFMA phases with the matrix pipe idle (measured: MFMA loop alone 52 us, whole kernel 80 us).
   constexpr int CH = 4 * NT;  // channels this lane owns: [c0, c0 + CH)
   const int c0 = q * CH;
-  const unsigned res_lane = (unsigned)(v * p.r_cs + c0);   // lane part of every residual address (element offset)
+  // Every global address of the epilogue = a wave-uniform 64-bit ROW base (scalar unit) + this lane's constant 32-bit BYTE offset:
+  // the loads and stores take the scalar-base form (global_* v_off, data, s[base]) and no vector instruction is spent on
+  // addresses inside the row loop (they were 5 per access: two 32-bit multiplies, a 64-bit multiply-add, an add3, a shift-add).
+  const unsigned res_lane_b = 2u * (unsigned)(v * p.r_cs + c0);
+  const unsigned y_lane_b = ((GEN && p.y_fp32) ? 4u : 2u) * (unsigned)(v * p.y_cs + c0);
+  const unsigned a_lane_b = 4u * (unsigned)(v * p.a_cs + c0);
+  unsigned ex_lane_b[NEX > 0 ? NEX : 1];
+#pragma unroll
+  for (int e = 0; e < (NEX > 0 ? NEX : 1); ++e) ex_lane_b[e] = NEX > 0 ? 2u * (unsigned)(v * p.ex_cs[e] + c0) : 0u;
+  // The residual joins the accumulators through ONE MFMA per tile with an identity-like A operand (32 -> 32 channels): the
+  // prefetched residual row (voxel v, channels 8q .. 8q+7) IS a B fragment, and A[m][k] = 1 where k is the channel that MFMA row m
+  // of tile nt stands for (row 4q'+r <- channel 8q' + 4nt + r, the weight image's row permutation), so D += residual exactly
+  // (1.0 x bf16 in fp32) -- 8 MFMAs per brick instead of 32 unpacks + 32 adds in the epilogue.
+  const float relu_lo = p.relu ? 0.f : -__builtin_inff();
+  bf16x8 idf[NT];
+  if constexpr (AUX == 1 && NT == 2) {
+    const bool on = (lane >> 4) == ((lane & 15) >> 2);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) idf[nt][j] = (bf16_t)((on && j == 4 * nt + (lane & 3)) ? 1.0f : 0.0f);
+  }
   f32x4 acc[TY][NT];
   bf16x8 pre_r8[TY];
   bf16x4 pre_r4[TY];
+  // MFMA-phase operands that do not depend on the staged brick's DATA are prepared at the END of the team's load phase, which
+  // waits ~3 000 cycles at the barrier for the other team's MFMAs anyway (in-kernel stamps: load phase = 1 200 issue + 1 100
+  // epilogue + 3 000 waiting; MFMA phase = 1 100-1 450 preamble + 4 400 loop): accumulators initialised with the class bias,
+  // the nine row-fragment base addresses, the first tap group's weight fragments.
+  constexpr int WBUF = RTP_TILED_WBUF, COT = NT * 16;
+  typedef const __attribute__((address_space(3))) bf16x8* lds_frag;
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) bf16_t*)lds;
+  const unsigned a_base = lds0 + 2u * (v * 32 + swz(q, v));  // swz(q, nt*16+v) == swz(q, v): 8*nt == 0 mod 4
+  bf16x8 fa[WBUF][3][NT];   // weights: (dz,dx) tap groups in registers, fetched a group (or two) ahead
+  unsigned b_base[3][3];    // [dz][dx]: plane wz + dz of the brick's four = pair (wz + dz) >> 1, plane (wz + dz) & 1 of it
+  auto load_a = [&](int g, bf16x8 (&a)[3][NT]) {
+    const int dz = g / 3, dx = g - dz * 3;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        a[dy][nt] = *(lds_frag)(a_base + 2u * ((((dz * 3 + dy) * 3 + dx) * COT + nt * 16) * 32));
+  };
   bool pend = false;
-  int e_oz = 0, e_ox = 0, e_y0 = 0, e_kzx = 0;
+  int e_oz = 0, e_xb = 0, e_y0 = 0;   // pending brick: plane, first x of this wave's 16-voxel column, first row (all wave-uniform)
   float st_p[4 * NT], st_q[4 * NT];  // running per-lane statistics of this lane's 4*NT channels (STAT)
 #pragma unroll
   for (int j = 0; j < 4 * NT; ++j) st_p[j] = st_q[j] = 0.f;
@@ -588,7 +639,8 @@ __global__ __launch_bounds__(512, 2) void conv_tiled_kernel(TiledParams p) {
           for (int e = 0; e < NEX; ++e) {
 #pragma unroll
             for (int t = 0; t < TY; ++t)
-              exr[e][t] = ld_bf16x8(p.ex[e] + (vox_n + ((long)e_oz * p.H + (e_y0 + t)) * p.W + e_ox) * p.ex_cs[e] + p.ex_co[e] + c0);
+              exr[e][t] = ld_bf16x8(reinterpret_cast<const bf16_t*>(
+                  reinterpret_cast<const char*>(p.ex[e] + (vox_n + ((long)e_oz * p.H + (e_y0 + t)) * p.W + e_xb) * p.ex_cs[e] + p.ex_co[e]) + ex_lane_b[e]));
           }
         }
       }
@@ -616,7 +668,7 @@ __global__ __launch_bounds__(512, 2) void conv_tiled_kernel(TiledParams p) {
       if (pend) {
         pend = false;
         // ---- epilogue of the previous brick: bias + residual + ReLU in fp32, one rounding, one 16-B store per lane and row
-        const int oz = e_oz, ox = e_ox, y0 = e_y0, kzx = e_kzx;
+        const int oz = e_oz, xb = e_xb, y0 = e_y0;
         float tsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         float ka[CH], kb[CH], kc[CH], ke[NEX > 0 ? NEX : 1][CH];
         if constexpr (FUSE) {
@@ -637,37 +689,32 @@ __global__ __launch_bounds__(512, 2) void conv_tiled_kernel(TiledParams p) {
 #pragma unroll
         for (int t = 0; t < TY; ++t) {
           const int oy = y0 + t;
-          const long vo = vox_n + ((long)oz * p.H + oy) * p.W + ox;
+          const long rs = vox_n + ((long)oz * p.H + oy) * p.W + xb;   // first voxel of this wave's row segment (scalar)
           float ev[CH];
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) ev[nt * 4 + j] = acc[t][nt][j];
-          if (p.acc32) {   // kernel-uniform
-            const float* ap = p.acc32 + vo * p.a_cs + c0;
+            for (int j = 0; j < 4; ++j) ev[nt * 4 + j] = acc[t][nt][j];   // (the class bias is already in: accumulator init)
+          if constexpr (GEN) {
+            if (p.acc32) {   // kernel-uniform
+              const float* ap = reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.acc32 + rs * p.a_cs) + a_lane_b);
 #pragma unroll
-            for (int k = 0; k < CH; k += 4) {
-              const f32x4 aa = *reinterpret_cast<const f32x4*>(ap + k);
+              for (int k = 0; k < CH; k += 4) {
+                const f32x4 aa = *reinterpret_cast<const f32x4*>(ap + k);
 #pragma unroll
-              for (int j = 0; j < 4; ++j) ev[k + j] += aa[j];
-            }
-          }
-          if constexpr (HAS_BTAB) {
-            const float* bp = bL + (kzx + ((oy == 0) ? 3 : (oy == p.H - 1) ? 6 : 0)) * p.Co + c0;
-#pragma unroll
-            for (int k = 0; k < CH; k += 4) {
-              const f32x4 bb = *reinterpret_cast<const f32x4*>(bp + k);
-#pragma unroll
-              for (int j = 0; j < 4; ++j) ev[k + j] += bb[j];
+                for (int j = 0; j < 4; ++j) ev[k + j] += aa[j];
+              }
             }
           }
           float aux[CH];
-          if constexpr (NT == 2) {
+          if constexpr (AUX == 2 || (AUX == 1 && NT == 1)) {
+            if constexpr (NT == 2) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) aux[j] = bf2f(pre_r8[t][j]);
-          } else {
+              for (int j = 0; j < 8; ++j) aux[j] = bf2f(pre_r8[t][j]);
+            } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) aux[j] = bf2f(pre_r4[t][j]);
+              for (int j = 0; j < 4; ++j) aux[j] = bf2f(pre_r4[t][j]);
+            }
           }
           if constexpr (FUSE) {
 #pragma unroll
@@ -682,20 +729,25 @@ __global__ __launch_bounds__(512, 2) void conv_tiled_kernel(TiledParams p) {
               for (int j = 0; j < CH; ++j) ev[j] = aux[j] > 0.f ? ev[j] : 0.f;
             }
           }
-          if constexpr (AUX == 1) {
+          if constexpr (AUX == 1 && NT == 1) {   // (32 -> 32 channels: the residual went in through the matrix pipe)
 #pragma unroll
             for (int j = 0; j < CH; ++j) ev[j] += aux[j];
           }
-          if (p.relu) {
+          if constexpr (!FUSE) {   // ReLU without a branch: max with 0 or with -inf (a branch costs a register copy per value at its merge)
 #pragma unroll
-            for (int j = 0; j < CH; ++j) ev[j] = ev[j] > 0.f ? ev[j] : 0.f;
+            for (int j = 0; j < CH; ++j) asm("v_max_f32 %0, %1, %2" : "=v"(ev[j]) : "s"(relu_lo), "v"(ev[j]));
           }
-          if (p.y_fp32) {
-            float* yp = (float*)p.y + vo * p.y_cs + p.y_co + c0;
+          bool stored = false;
+          if constexpr (GEN) {
+            if (p.y_fp32) {
+              float* yp = reinterpret_cast<float*>(reinterpret_cast<char*>((float*)p.y + rs * p.y_cs + p.y_co) + y_lane_b);
 #pragma unroll
-            for (int k = 0; k < CH; k += 4) *reinterpret_cast<f32x4*>(yp + k) = f32x4{ev[k], ev[k + 1], ev[k + 2], ev[k + 3]};
-          } else {
-            bf16_t* yp = (bf16_t*)p.y + vo * p.y_cs + p.y_co + c0;
+              for (int k = 0; k < CH; k += 4) *reinterpret_cast<f32x4*>(yp + k) = f32x4{ev[k], ev[k + 1], ev[k + 2], ev[k + 3]};
+              stored = true;
+            }
+          }
+          if (!stored) {
+            bf16_t* yp = reinterpret_cast<bf16_t*>(reinterpret_cast<char*>((bf16_t*)p.y + rs * p.y_cs + p.y_co) + y_lane_b);
             if constexpr (NT == 2) {
               bf16x8 o;
 #pragma unroll
@@ -756,6 +808,53 @@ __global__ __launch_bounds__(512, 2) void conv_tiled_kernel(TiledParams p) {
           }
         }
       }
+      {   // ---- operands of the brick just staged that do not need its data (see the declarations above).  UNCONDITIONAL: were
+          // it skipped when nothing was staged, the old values would have to survive the whole loop body (the compiler cannot
+          // know that an MFMA phase always follows a load phase that staged) -- 33 registers held across the epilogue; computed
+          // from whatever the coordinates are, the few wasted instructions of the last phases read valid LDS addresses.
+        const int z0 = c_tz * TZ, y0 = c_ty * TY, x0 = c_tx * TX;
+        const int slot_a = (ring_cur + RING - 2) % RING, slot_b = (ring_cur + RING - 1) % RING;   // the last two pairs staged
+        {
+          // Accumulators start from the CLASS BIAS of their output voxel (LDS table, 27 classes x Co floats): the epilogue adds
+          // nothing.  The class is (z class, x class) of the lane's voxel -- a per-lane row of the table -- plus the y class of the
+          // row, which only the brick's first / last row can have (a scalar select for t = 0 and t = TY - 1).
+          const int oz = z0 + wz, xb = x0 + wx * 16, ox = xb + v;
+          if constexpr (HAS_BTAB) {
+            typedef const __attribute__((address_space(3))) f32x4* lds_f4;
+            const int kzx = ((oz == 0) ? 1 : (oz == p.D - 1) ? 2 : 0) * 9 + ((ox == 0) ? 1 : (ox == p.W - 1) ? 2 : 0);
+            const unsigned bb = (unsigned)(size_t)(__attribute__((address_space(3))) float*)bL + 4u * (unsigned)(kzx * p.Co + c0);
+#pragma unroll
+            for (int t = 0; t < TY; ++t) {
+              const int oy = y0 + t;
+              const unsigned ycls = (t == 0 && oy == 0) ? 3u : (t == TY - 1 && oy == p.H - 1) ? 6u : 0u;   // (H >= 2: never both)
+              const unsigned rb = bb + ycls * (4u * (unsigned)p.Co);
+#pragma unroll
+              for (int nt = 0; nt < NT; ++nt) acc[t][nt] = *(lds_f4)(rb + 16u * nt);
+            }
+          } else {
+#pragma unroll
+            for (int t = 0; t < TY; ++t)
+#pragma unroll
+              for (int nt = 0; nt < NT; ++nt) acc[t][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+          }
+
+#pragma unroll
+          for (int dz = 0; dz < 3; ++dz) {
+            const int j = wz + dz;
+            const int pv = ((j >> 1) ? slot_b : slot_a) * PAIR_VOX + (j & 1) * PLANE_VOX;
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+              const int hx = wx * 16 + v + dx;
+              b_base[dz][dx] = lds0 + 2u * (unsigned)((xL - lds) + (pv + hx) * 32 + swz(q, hx));
+              // opaque VGPR: left visible, hipcc keeps the wave-uniform slot part in an SGPR and spends a v_add per fragment read
+              // instead of folding the row offset into the ds_read's immediate
+              asm volatile("" : "+v"(b_base[dz][dx]));
+            }
+          }
+          load_a(0, fa[0]);
+          if (WBUF == 3) load_a(1, fa[1]);
+        }
+      }
 #ifdef RTP_TILED_PROF
       PROF_T(pt2);
       PROF_ADD(4, pt1, pt2);
@@ -774,72 +873,39 @@ __global__ __launch_bounds__(512, 2) void conv_tiled_kernel(TiledParams p) {
       const bool unit_ends = ++u_cur == u_end;
       int take = 0;
       if (unit_ends && claimer && dyn) take = rtp_claim_take(p.claim + n * p.ranges + rng, 1);
-      const int slot_a = (ring_cur + RING - 2) % RING, slot_b = (ring_cur + RING - 1) % RING;   // the last two pairs staged
-      if (x0 + wx * 16 >= p.W) { PHASE_SYNC(); continue; }  // wave-uniform: this wave's 16-voxel column is padding (never the claimer's: wx = 0)
+      const bool live = x0 + wx * 16 < p.W;  // wave-uniform: otherwise this wave's 16-voxel column is padding (never the claimer's: wx = 0).
+                                             // No early `continue`: every extra path through the loop body costs register copies where
+                                             // the paths meet (32 accumulator + 16 residual registers were being shuffled per phase).
 
-#pragma unroll
-      for (int t = 0; t < TY; ++t)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[t][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-
+      const int oz = z0 + wz, xb = x0 + wx * 16;   // (accumulators, fragment bases, first weights: prepared in the load phase)
       // The residual is fetched NOW, under the MFMA loop: loaded after it, its HBM latency sat on the critical path of
-      // every brick (measured: epilogue 78 us of a 132 us launch).  The class bias comes from the LDS table.
-      const int oz = z0 + wz, ox = x0 + wx * 16 + v;
-      const int kzx = ((oz == 0) ? 1 : (oz == p.D - 1) ? 2 : 0) * 9 + ((ox == 0) ? 1 : (ox == p.W - 1) ? 2 : 0);
-      // address = wave-uniform 64-bit row base (scalar unit) + this lane's constant 32-bit element offset
-      const bf16_t* res_row = p.res + (vox_n + ((long)oz * p.H + y0) * p.W + x0 + wx * 16) * p.r_cs + p.r_co;
+      // every brick (measured: epilogue 78 us of a 132 us launch).  (Not in the load phase: its barrier drains every outstanding
+      // vector-memory operation of the wave, so the rows' HBM latency would sit in front of it.)
+      // address = wave-uniform 64-bit row base (scalar unit) + this lane's constant 32-bit byte offset
+      const bf16_t* res_row = p.res + (vox_n + ((long)oz * p.H + y0) * p.W + (live ? xb : 0)) * p.r_cs + p.r_co;   // (padding wave: any in-bounds row)
 #pragma unroll
       for (int t = 0; t < TY; ++t) {
         pre_r8[t] = zero_bf16x8();
         pre_r4[t] = bf16x4{(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
         if constexpr (AUX != 0) {  // compile-time: a runtime select per load makes hipcc branch around each one and wait vmcnt(0) early
-          const bf16_t* rp = res_row + (long)t * p.W * p.r_cs + res_lane;
+          const bf16_t* rp = reinterpret_cast<const bf16_t*>(reinterpret_cast<const char*>(res_row + (long)t * p.W * p.r_cs) + res_lane_b);
           if constexpr (NT == 2) pre_r8[t] = ld_bf16x8(rp);
           else pre_r4[t] = *reinterpret_cast<const bf16x4*>(rp);
         }
       }
       PROF_T(pc1);
       PROF_ADD(0, pt0, pc1);
-      if (!(p.dbg & 1)) {
+      if (live && !RTP_DBG(1)) {
         // Software pipeline over 54 steps = 9 (dz,dx) tap groups x HY haloed rows.  Step s reads its row fragment three
         // steps early into a 4-deep register ring, and a group's 3*NT weight fragments are read during the previous
         // group (double-buffered); sched_barrier fences pin that order (left alone, hipcc issues each ds_read right
         // before its first use and waits lgkmcnt(0) on it, exposing the LDS latency to the single MFMA wave per SIMD).
-        constexpr int DIST = RTP_TILED_DIST, FBN = 8, WB = RTP_TILED_WBUF, NSTEP = 9 * HY, CO = NT * 16;
-        bf16x8 fa[WB][3][NT], fb[FBN];   // weights: three (dz,dx) groups in registers, fetched two groups ahead
-        // Four per-lane LDS byte addresses serve all 54 + 54 fragment reads; everything else is a compile-time
-        // immediate (weights: tap and cout tile; rows: dz and haloed row) -- address registers were the spill source.
-        typedef const __attribute__((address_space(3))) bf16x8* lds_frag;
-        const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) bf16_t*)lds;
-        const unsigned a_base = lds0 + 2u * (v * 32 + swz(q, v));  // swz(q, nt*16+v) == swz(q, v): 8*nt == 0 mod 4
-        unsigned b_base[3][3];   // [dz][dx]: plane wz + dz of the brick's four = pair (wz + dz) >> 1, plane (wz + dz) & 1 of it
-#pragma unroll
-        for (int dz = 0; dz < 3; ++dz) {
-          const int j = wz + dz;
-          const int pv = ((j >> 1) ? slot_b : slot_a) * PAIR_VOX + (j & 1) * PLANE_VOX;
-#pragma unroll
-          for (int dx = 0; dx < 3; ++dx) {
-            const int hx = wx * 16 + v + dx;
-            b_base[dz][dx] = lds0 + 2u * (unsigned)((xL - lds) + (pv + hx) * 32 + swz(q, hx));
-            // opaque VGPR: left visible, hipcc keeps the wave-uniform slot part in an SGPR and spends a v_add per fragment read
-            // instead of folding the row offset into the ds_read's immediate
-            asm volatile("" : "+v"(b_base[dz][dx]));
-          }
-        }
+        constexpr int DIST = RTP_TILED_DIST, FBN = 8, WB = WBUF, NSTEP = 9 * HY;
+        bf16x8 fb[FBN];
         auto row_frag = [&](int s) {
           const int g = s / HY, ry = s - g * HY, dz = g / 3, dx = g - dz * 3;
           return *(lds_frag)(b_base[dz][dx] + 2u * (ry * HX * 32));
         };
-        auto load_a = [&](int g, bf16x8 (&a)[3][NT]) {
-          const int dz = g / 3, dx = g - dz * 3;
-#pragma unroll
-          for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-              a[dy][nt] = *(lds_frag)(a_base + 2u * ((((dz * 3 + dy) * 3 + dx) * CO + nt * 16) * 32));
-        };
-        load_a(0, fa[0]);
-        if (WB == 3) load_a(1, fa[1]);
 #pragma unroll
         for (int s = 0; s < DIST; ++s) fb[s % FBN] = row_frag(s);
 #pragma unroll
@@ -866,6 +932,12 @@ __global__ __launch_bounds__(512, 2) void conv_tiled_kernel(TiledParams p) {
 #endif
         }
       }
+      if (AUX == 1 && NT == 2 && live) {   // + residual, through the matrix pipe (its rows have had the whole loop to arrive)
+#pragma unroll
+        for (int t = 0; t < TY; ++t)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(idf[nt], pre_r8[t], acc[t][nt], 0, 0, 0);
+      }
       if (unit_ends && claimer) {
         if (dyn) claim_finish(take, true);
         else ctl[2 * team] = -1;
@@ -874,16 +946,14 @@ __global__ __launch_bounds__(512, 2) void conv_tiled_kernel(TiledParams p) {
       __builtin_amdgcn_s_waitcnt(0);   // (MFMA results are not covered by a counter: the delta below is issue time)
       PROF_T(pc2);
       PROF_ADD(1, pc1, pc2);
-      if (!(p.dbg & 4)) { pend = true; e_oz = oz; e_ox = ox; e_y0 = y0; e_kzx = kzx; }
+      if (live && !RTP_DBG(4)) { pend = true; e_oz = oz; e_xb = xb; e_y0 = y0; }
       PHASE_SYNC();
       PROF_T(pc3);
       PROF_ADD(2, pc2, pc3);
       prof_acc[6] += 1;
       continue;
 #endif
-      if (p.dbg & 4) { PHASE_SYNC(); continue; }
-      pend = true;
-      e_oz = oz; e_ox = ox; e_y0 = y0; e_kzx = kzx;
+      if (live && !RTP_DBG(4)) { pend = true; e_oz = oz; e_xb = xb; e_y0 = y0; }
     }
     PHASE_SYNC();
   }
@@ -1070,13 +1140,15 @@ int rtp_conv_tiled_try(const RtpAct* x, const void* wf, int w_per_sample, const 
   RtpProfScope prof((Co == 32 && (long)p.N * p.D * p.H * p.W >= (1L << 20)) ? (transposed ? RTP_FAM_CONV_TILED_FULL_BWD : RTP_FAM_CONV_TILED_FULL)
                                                                                 : RTP_FAM_CONV_TILED, s);
   using Kern = void (*)(TiledParams);
+#define RTP_TILED_CELL(NT, BT, AUX, ST) {conv_tiled_kernel<NT, BT, AUX, ST, 0, false>, conv_tiled_kernel<NT, BT, AUX, ST, 0, true>}
 #define RTP_TILED_ROW(NT, BT) \
-  {{conv_tiled_kernel<NT, BT, 0, false>, conv_tiled_kernel<NT, BT, 0, true>}, \
-   {conv_tiled_kernel<NT, BT, 1, false>, conv_tiled_kernel<NT, BT, 1, true>}, \
-   {nullptr, conv_tiled_kernel<NT, BT, 2, true>}}
-  static const Kern table[2][2][3][2] = {{RTP_TILED_ROW(1, false), RTP_TILED_ROW(1, true)},
-                                         {RTP_TILED_ROW(2, false), RTP_TILED_ROW(2, true)}};
+  {{RTP_TILED_CELL(NT, BT, 0, false), RTP_TILED_CELL(NT, BT, 0, true)}, \
+   {RTP_TILED_CELL(NT, BT, 1, false), RTP_TILED_CELL(NT, BT, 1, true)}, \
+   {{nullptr, nullptr}, RTP_TILED_CELL(NT, BT, 2, true)}}
+  static const Kern table[2][2][3][2][2] = {{RTP_TILED_ROW(1, false), RTP_TILED_ROW(1, true)},
+                                            {RTP_TILED_ROW(2, false), RTP_TILED_ROW(2, true)}};   // [nt][class bias][aux][statistics][fp32 in/out]
 #undef RTP_TILED_ROW
+#undef RTP_TILED_CELL
   static bool attr_done[RTP_MAX_DEVICES] = {};
   if (rtp_once_per_device(attr_done)) {
     const int big = (int)(sizeof(bf16_t) * (27 * (size_t)32 * 32 + 2 * (size_t)HALO_VOX * 32) + 27 * 32 * sizeof(float) + 64);
@@ -1084,8 +1156,9 @@ int rtp_conv_tiled_try(const RtpAct* x, const void* wf, int w_per_sample, const 
       for (int b = 0; b < 2; ++b)
         for (int c = 0; c < 3; ++c)
           for (int d = 0; d < 2; ++d)
-            if (table[a][b][c][d])
-              (void)hipFuncSetAttribute((const void*)table[a][b][c][d], hipFuncAttributeMaxDynamicSharedMemorySize, big);
+            for (int e = 0; e < 2; ++e)
+              if (table[a][b][c][d][e])
+                (void)hipFuncSetAttribute((const void*)table[a][b][c][d][e], hipFuncAttributeMaxDynamicSharedMemorySize, big);
   }
   const int aux = stat_x ? 2 : (res ? 1 : 0);
   if (fuse) {
@@ -1101,7 +1174,7 @@ int rtp_conv_tiled_try(const RtpAct* x, const void* wf, int w_per_sample, const 
     RTP_CHECK_LAUNCH();
     return RTP_OK;
   }
-  hipLaunchKernelGGL(table[nt - 1][(btab || fold) ? 1 : 0][aux][stat_out ? 1 : 0], dim3(p.N * wgs), dim3(512), shm, s, p);
+  hipLaunchKernelGGL(table[nt - 1][(btab || fold) ? 1 : 0][aux][stat_out ? 1 : 0][(acc32 || y_fp32) ? 1 : 0], dim3(p.N * wgs), dim3(512), shm, s, p);
   RTP_CHECK_LAUNCH();
   return RTP_OK;
 }
