@@ -94,6 +94,9 @@ struct TiledParams {
   // the rest `usmall` -- big units first keep the staging cheap (inside a unit a brick stages one z-plane pair instead of two),
   // the small ones at the end keep the workgroups' finishing times within a brick or two of each other.
   int* claim; int ranges, total_wgs, nbig, ubig, usmall;
+  // freerun: the two teams synchronise only WITHIN themselves (LDS-counter barriers over their four waves) and drift freely
+  // against each other, instead of swapping roles at workgroup barriers; prio: wave priority of a team's MFMA phase.
+  int freerun, prio;
   // FUSE: a data gradient that writes the FINISHED gradient of its input tensor x (= p.res, the AUX operand):
   //   y = [x > 0] * (A0 * acc + Bt * x + Ct + sum_e Ae * ex_e)
   // coef[0] = this conv's GroupNorm-backward coefficients [N][32][3] (A, B, C) or null (1, 0, 0); ex_e = gradient terms of
@@ -122,6 +125,15 @@ struct TiledParams {
   // statistics partials are 32-channel windows of tables that are bt_cs / st_cs channels wide.  Dense defaults otherwise.
   long w_sample_stride; int w_tap_stride, w_row_stride, bt_cs, st_cs;
 };
+
+// Barrier over the four waves of one team: a monotonic LDS counter (no reset, so no re-use hazard); `target` = 4 x the number of
+// barriers the team has passed including this one.  s_waitcnt 0 first: the wave's LDS-DMA writes (vmcnt) and its LDS reads of the
+// brick (lgkmcnt) must be complete before the team's other waves read / overwrite it.
+__device__ __forceinline__ void team_sync(unsigned* cnt, unsigned target, int lane) {
+  __builtin_amdgcn_s_waitcnt(0);
+  if (lane == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+  while (__hip_atomic_load(cnt, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
+}
 
 // One LDS-DMA piece (16 B per lane, wave-linear LDS destination from M0), issued from inline assembly so that the compiler does
 // not model it: hipcc treats the builtin as a FLAT access to both memories, and while one is outstanding it (a) drains vmcnt
@@ -505,13 +517,24 @@ __global__ __launch_bounds__(512, 2) void conv_tiled_kernel(TiledParams p) {
       ctl[2 * team + 1] = t_end;
     }
   }
-  if (tid < 8) ctl[4 + tid] = 0;
+  if (tid < 10) ctl[4 + tid] = 0;   // flags, and the two team-barrier counters ctl[12 + team]
   __syncthreads();   // weights, tables and the first units are in place for both teams
   int both_done = 0;
+  const bool fr = p.freerun != 0;   // kernel-uniform
+  unsigned* tcnt = reinterpret_cast<unsigned*>(ctl + 12 + team);
+  unsigned tbar = 0;
+  // Lock-step: the teams swap roles at a workgroup barrier per phase and leave together, one phase after both have reported
+  // "nothing left".  Free-running: a team barrier per phase; a team leaves after a load phase that staged nothing (its pending
+  // epilogue has run there).
 #define PHASE_SYNC() do { \
-    if (claimer) ctl[4 + 2 * (phase & 3) + team] = (finished && !pend && !staged) ? 1 : 0; \
-    both_done = __builtin_amdgcn_readfirstlane(fl[0] & fl[1]); \
-    __syncthreads(); } while (0)
+    if (fr) { \
+      if (loading && !staged) both_done = 1; \
+      tbar += 4; team_sync(tcnt, tbar, lane); \
+    } else { \
+      if (claimer) ctl[4 + 2 * (phase & 3) + team] = (finished && !pend && !staged) ? 1 : 0; \
+      both_done = __builtin_amdgcn_readfirstlane(fl[0] & fl[1]); \
+      __syncthreads(); \
+    } } while (0)
   const long vox_n = (long)n * p.D * p.H * p.W;
   // Staging descriptors (brick-independent, computed once): element offset of each of this thread's 13 sixteen-byte
   // items relative to the brick origin, its swizzled LDS slot, and six "on the low/high face of the halo" bits.
@@ -626,9 +649,9 @@ __global__ __launch_bounds__(512, 2) void conv_tiled_kernel(TiledParams p) {
   // phase after both teams have reported "nothing left": the flags are read a phase late so that the LDS read's latency sits
   // under the phase's own work instead of in front of it.
   for (int phase = 0; !both_done; ++phase) {
-    const bool loading = ((phase + team) & 1) == 0;  // team-uniform (=> wave-uniform)
+    const bool loading = ((phase + (fr ? 0 : team)) & 1) == 0;  // team-uniform (=> wave-uniform)
     typedef int i32x2 __attribute__((ext_vector_type(2)));
-    const i32x2 fl = phase > 0 ? *reinterpret_cast<const volatile i32x2*>(ctl + 4 + 2 * ((phase - 1) & 3)) : i32x2{0, 0};
+    const i32x2 fl = (!fr && phase > 0) ? *reinterpret_cast<const volatile i32x2*>(ctl + 4 + 2 * ((phase - 1) & 3)) : i32x2{0, 0};
     PROF_T(pt0);
     if (loading) {
       bf16x8 exr[NEX > 0 ? NEX : 1][TY];
@@ -895,6 +918,7 @@ __global__ __launch_bounds__(512, 2) void conv_tiled_kernel(TiledParams p) {
       }
       PROF_T(pc1);
       PROF_ADD(0, pt0, pc1);
+      if (p.prio) __builtin_amdgcn_s_setprio(2);
       if (live && !RTP_DBG(1)) {
         // Software pipeline over 54 steps = 9 (dz,dx) tap groups x HY haloed rows.  Step s reads its row fragment three
         // steps early into a 4-deep register ring, and a group's 3*NT weight fragments are read during the previous
@@ -932,6 +956,7 @@ __global__ __launch_bounds__(512, 2) void conv_tiled_kernel(TiledParams p) {
 #endif
         }
       }
+      if (p.prio) __builtin_amdgcn_s_setprio(0);
       if (AUX == 1 && NT == 2 && live) {   // + residual, through the matrix pipe (its rows have had the whole loop to arrive)
 #pragma unroll
         for (int t = 0; t < TY; ++t)
@@ -971,6 +996,7 @@ __global__ __launch_bounds__(512, 2) void conv_tiled_kernel(TiledParams p) {
   }
 #endif
 #undef PHASE_SYNC
+  if (fr) __syncthreads();   // both teams done before the workgroup-wide reductions below
   if constexpr (FUSE) {
     if (p.tot_out && tid < 32) {   // (the phase loop ends with a barrier)
       float a = 0.f;
@@ -1100,6 +1126,9 @@ int rtp_conv_tiled_try(const RtpAct* x, const void* wf, int w_per_sample, const 
     const int len = p.tiles_per_sample / p.ranges, teams = 2 * wgs / p.ranges;
     p.nbig = (int)((long)len * bigpct / 100 / p.ubig) / teams * teams;
   }
+  static const int freerun = getenv("RTP_TILED_FREERUN") ? atoi(getenv("RTP_TILED_FREERUN")) : 0;
+  static const int prio = getenv("RTP_TILED_PRIO") ? atoi(getenv("RTP_TILED_PRIO")) : 0;
+  p.freerun = freerun; p.prio = prio;
   p.nextra = 0; p.mask = 0; p.tot_out = nullptr;
   p.qpart = nullptr; p.q_nsplit = 0; p.gn_p = p.gn_mr = p.gn_gamma = nullptr; p.gn_groups = 1; p.gn_m = 1.f; p.coef_out = nullptr;
   p.tg = nullptr; p.csum_out = nullptr;

@@ -57,6 +57,21 @@ struct WgTiledParams {
 
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
+#ifdef RTP_WGT_PROF
+// Cycle stamps of workgroup 0 (separate build, tools/wgt_prof.py): [0] consumer: MFMA code of a brick, [1] consumer: wait at the
+// brick barrier, [2] bricks; [4] loader: DMA issue, [5] loader: subset sums, [6] loader: wait at the barrier, [7] iterations;
+// [8] kernel cycles, [9] kernel time in 10-ns ticks
+__device__ long long g_wgt_prof[16];
+extern "C" int rtp_wgt_prof_read(long long* host) {
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_wgt_prof), sizeof(long long) * 16) == hipSuccess ? 0 : -1;
+}
+#define WPROF_T(var) const long long var = __builtin_readcyclecounter()
+#define WPROF_ADD(slot, a, b) wprof[slot] += (b) - (a)
+#else
+#define WPROF_T(var)
+#define WPROF_ADD(slot, a, b)
+#endif
+
 __device__ __attribute__((aligned(16))) bf16_t g_zero_line[8];  // zero-initialised: source of padding voxels
 
 __device__ __forceinline__ int rot(int chunk, int xi) { return ((chunk + (xi >> 2)) & 3) << 3; }  // bf16 elements
@@ -67,6 +82,10 @@ __device__ __forceinline__ int rot(int chunk, int xi) { return ((chunk + (xi >> 
 // ALL rows/taps share 12 (+4) address registers.
 template <int OFF>
 __device__ __forceinline__ bf16x8 tr_pair(unsigned lo, unsigned hi) {
+#ifdef WGT_EXP_NOREAD   // timing experiment: no LDS reads (results wrong)
+  s16x8 z = {(short)lo, (short)hi, 1, 2, 3, 4, 5, 6};
+  return __builtin_bit_cast(bf16x8, z);
+#endif
   s16x4 l = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lo + OFF));
   s16x4 h = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(hi + OFF));
   s16x8 r = {l[0], l[1], l[2], l[3], h[0], h[1], h[2], h[3]};
@@ -86,6 +105,10 @@ __device__ __forceinline__ void wg_tap(const LaneAddr& la, const bf16x8& a0, con
   constexpr int off = (rz * HY + ry) * HX * 64;  // bytes (< 64 KB): folds into the ds_read immediate
   const bf16x8 b0 = tr_pair<off>(la.x[T][0][0], la.x[T][0][1]);
   const bf16x8 b1 = tr_pair<off>(la.x[T][1][0], la.x[T][1][1]);
+#ifdef WGT_EXP_NOMFMA   // timing experiment: the reads without the MFMAs (results wrong)
+  asm volatile("" : : "v"(b0), "v"(b1), "v"(a0), "v"(a1));
+  return;
+#endif
   acc[T][0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b0, acc[T][0][0], 0, 0, 0);
   acc[T][0][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b1, acc[T][0][1], 0, 0, 0);
   acc[T][1][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b0, acc[T][1][0], 0, 0, 0);
@@ -104,7 +127,9 @@ __device__ __forceinline__ void wg_row(const LaneAddr& la, f32x4 (&acc)[7][2][2]
 
 // Issue-order plan for the whole (fully unrolled, branch-free) brick: a software pipeline with the LDS reads of
 // stage s+WG_DIST issued before the MFMAs of stage s.  Without it the scheduler front-loads hundreds of reads and spills.
+#ifndef WG_DIST
 #define WG_DIST 3  // prefetch distance in stages (8 fragment VGPRs each)
+#endif
 template <int S, int TOTAL>
 __device__ __forceinline__ void wg_sched() {
   if constexpr (S < TOTAL) {
@@ -127,6 +152,10 @@ __device__ __forceinline__ void wg_brick(const LaneAddr& la, f32x4 (&acc)[7][2][
 __global__ __attribute__((amdgpu_flat_work_group_size(512, 512), amdgpu_waves_per_eu(2, 2))) void wgrad_tiled_kernel(WgTiledParams p) {
   extern __shared__ __attribute__((aligned(16))) bf16_t lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef RTP_WGT_PROF
+  long long wprof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const long long wk0 = __builtin_readcyclecounter(), wr0 = __builtin_amdgcn_s_memrealtime();
+#endif
   const bool loader = __builtin_amdgcn_readfirstlane(wave >> 2) == 1;  // waves 4-7 stage, waves 0-3 run the MFMAs
   const int tw = __builtin_amdgcn_readfirstlane(wave & 3);
   const int ttid = tid & 255;
@@ -200,6 +229,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(512, 512), amdgpu_waves_pe
     for (int k = 0;; ++k) {
       const int tile = k == 0 ? first : __builtin_amdgcn_readfirstlane(ctl[k & 3]);
       const bool have = tile < WG_NONE;
+      WPROF_T(l0);
       if (dyn && have && ttid == 0 && c_first) take = rtp_claim_take(p.claim + n * p.ranges + rng, 1);   // the NEXT unit: asked for now
       if (have) {
         bf16_t* xL = lds + (k & 1) * BUF;
@@ -219,6 +249,8 @@ __global__ __attribute__((amdgpu_flat_work_group_size(512, 512), amdgpu_waves_pe
           }
         }
       }
+      WPROF_T(l1);
+      WPROF_ADD(4, l0, l1);
       if (p.tg && k >= 1) {
         // sums of gy brick k-1 (landed before the previous barrier; the consumers are reading the same buffer now)
         const int tz = prev_tile % p.tiles_z, tx = (prev_tile / p.tiles_z) % p.tiles_x, ty = prev_tile / (p.tiles_z * p.tiles_x);
@@ -285,9 +317,19 @@ __global__ __attribute__((amdgpu_flat_work_group_size(512, 512), amdgpu_waves_pe
         ctl[(k + 1) & 3] = nxt;
       }
       prev_tile = tile;
+      WPROF_T(l2);
+      WPROF_ADD(5, l1, l2);
       __syncthreads();  // (drains the DMA: hipcc emits vmcnt(0) before the barrier)
+      WPROF_T(l3);
+      WPROF_ADD(6, l2, l3);
+#ifdef RTP_WGT_PROF
+      wprof[7] += 1;
+#endif
       if (!have) break;
     }
+#ifdef RTP_WGT_PROF
+    if (blockIdx.x == 0 && tid == 256) { for (int i = 4; i < 8; ++i) g_wgt_prof[i] = wprof[i]; }
+#endif
     if (p.tg) {   // whole-volume subsets (all, all, all | first x | last x) kept in registers until now
       float* Tg = T;   // (this wave's LDS table; flushed below)
 #pragma unroll
@@ -352,7 +394,13 @@ __global__ __attribute__((amdgpu_flat_work_group_size(512, 512), amdgpu_waves_pe
   for (int k = 0;; ++k) {
     const int tile = k == 0 ? first : __builtin_amdgcn_readfirstlane(ctl[k & 3]);
     if (tile >= WG_NONE) break;
+    WPROF_T(c0);
     if (!(p.dbg & 1)) wg_brick(la, acc);
+#ifdef RTP_WGT_PROF
+    __builtin_amdgcn_s_waitcnt(0);
+#endif
+    WPROF_T(c1);
+    WPROF_ADD(0, c0, c1);
     // flip every fragment address to the other staging buffer (in place: no second address set stays live)
     const unsigned delta = (k & 1) ? (unsigned)(-(int)(2u * BUF)) : 2u * BUF;
 #pragma unroll
@@ -364,7 +412,19 @@ __global__ __attribute__((amdgpu_flat_work_group_size(512, 512), amdgpu_waves_pe
         for (int t = 0; t < 7; ++t) la.x[t][sub][h] += delta;
       }
     __syncthreads();  // brick k consumed, brick k+1 staged
+    WPROF_T(c2);
+    WPROF_ADD(1, c1, c2);
+#ifdef RTP_WGT_PROF
+    wprof[2] += 1;
+#endif
   }
+#ifdef RTP_WGT_PROF
+  if (blockIdx.x == 0 && tid == 0) {
+    for (int i = 0; i < 4; ++i) g_wgt_prof[i] = wprof[i];
+    g_wgt_prof[8] = __builtin_readcyclecounter() - wk0;
+    g_wgt_prof[9] = __builtin_amdgcn_s_memrealtime() - wr0;
+  }
+#endif
 
   const int q = lane >> 4, i = lane & 15;
   // ---- one fp32 slab [27][32][32] per workgroup; D[row = co][col = ci]: lane holds rows 4q..4q+3, column lane&15

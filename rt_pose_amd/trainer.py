@@ -241,6 +241,12 @@ class DataParallelTrainer:
     def losses(self):
         return self.engine.losses()
 
+    def log_vars(self):
+        """(loss, log_vars) of the last step under the reference's log key names (rt_pose_amd.train_log.parse_losses:
+        loss, hm_loss, loc_loss, coor_{x,y,z}_offset_<joint>, num_positive) -- feed them to train_log.TextLogger.  One host sync."""
+        from .train_log import engine_losses_as_lists, parse_losses
+        return parse_losses(engine_losses_as_lists(self.losses()))
+
     def allreduce_ms(self):
         """Mean duration of the gradient all-reduce over the last (up to 64) steps, by events on the step stream; None when
         single-rank.  Synchronises the device."""
