@@ -74,13 +74,24 @@ class _TapMajor:
 class EmuBackend:
     name = "emu"
 
-    def __init__(self, exact=False, fast=False):
+    def __init__(self, exact=False, fast=False, noise=0.0, seed=0):
         """exact=True keeps every 'bf16' buffer in fp32: isolates plan-logic errors from rounding.
         fast=True: the weight-gradient emulation puts the whole correlation into slab 0 (one pass per sample instead of one
-        per slab; the slabs' sum -- all the plan consumes -- is the same) for native-shape comparisons."""
+        per slab; the slabs' sum -- all the plan consumes -- is the same) for native-shape comparisons.
+        noise > 0: a model of ANOTHER SUMMATION ORDER.  Every fp32 value is multiplied by (1 + noise * N(0, 1)) right before it is
+        rounded into a bf16 activation / gradient buffer -- what re-associating a 864-term fp32 dot product does to its result
+        (relative 1e-7 .. 1e-6) -- so two emulated runs with different seeds differ exactly where two correct implementations of
+        the same plan may differ: in the bf16 roundings (and ReLU / sign decisions) that sit within that distance of a tie."""
         self.bytes = 0
         self.exact = exact
         self.fast = fast
+        self.noise = float(noise)
+        self._gen = torch.Generator().manual_seed(seed) if noise else None
+
+    def _store(self, v, val):
+        if self.noise and v.buf.dtype == torch.bfloat16:
+            val = val * (1.0 + self.noise * torch.randn(val.shape, generator=self._gen, dtype=val.dtype))
+        _store(v, val)
 
     def alloc(self, shape, dtype):
         if self.exact and dtype == "bf16":
@@ -229,7 +240,7 @@ class EmuBackend:
                 out = out + _sl(res)[..., :out.shape[-1]]
             if relu:
                 out = out.clamp_min(0)
-            _store(y, out)
+            self._store(y, out)
             if stats is not None:   # statistics of the stored values; everything in partial 0
                 sx, so = stats
                 yv = _sl(y).reshape(y.n, y.vox, -1)[..., :so.shape[2]]
@@ -546,7 +557,7 @@ class EmuBackend:
                     acc = acc + k2[..., 0] * _sl(v)[..., :c] + k2[..., 1] * xv + k2[..., 2]
             if mask:
                 acc = torch.where(xv > 0, acc, torch.zeros(()))
-            _store(dx, acc)
+            self._store(dx, acc)
             if tot_out is not None:   # totals of the stored (rounded) values, everything in partial 0
                 tot_out.zero_()
                 tot_out.view(g.n, -1, tot_out.shape[-1])[:, 0, :c] = _sl(dx)[..., :c].reshape(g.n, -1, c).sum(1)
@@ -569,7 +580,7 @@ class EmuBackend:
             x2, (n, d, h, w, c) = to2d(x)
             off2, _ = to2d(off_act, koff)
             y2 = F.relu(dcn_ref.deform_conv2d(x2, off2, w_ad.detach().float(), 1, 1, 1, 1, dg))
-            _store(y, y2.reshape(n, d, c, h, w).permute(0, 1, 3, 4, 2))
+            self._store(y, y2.reshape(n, d, c, h, w).permute(0, 1, 3, 4, 2))
             state["x2"], state["off2"] = x2, off2
 
         def make_backward(gy, gx, goff_v, gw_ad):
@@ -581,9 +592,9 @@ class EmuBackend:
                 y2 = dcn_ref.deform_conv2d(x2, o2, wa, 1, 1, 1, 1, dg)
                 g2, (n, d, h, w, c) = to2d(gy)     # already masked by the adapted feature's ReLU
                 y2.backward(g2)
-                _store(gx, x2.grad.reshape(n, d, c, h, w).permute(0, 1, 3, 4, 2))
+                self._store(gx, x2.grad.reshape(n, d, c, h, w).permute(0, 1, 3, 4, 2))
                 goff_v.buf.zero_()
-                _store(goff_v, o2.grad.reshape(n, d, koff, h, w).permute(0, 1, 3, 4, 2))
+                self._store(goff_v, o2.grad.reshape(n, d, koff, h, w).permute(0, 1, 3, 4, 2))
                 gw_ad.copy_(wa.grad)
             return bwd
         return fwd, make_backward
@@ -619,7 +630,7 @@ class EmuBackend:
                     acc += c[..., 0] * _sl(v) + c[..., 1] * _sl(x)[..., :out.c] + c[..., 2]
             if relu_src is not None:
                 acc = torch.where(_sl(relu_src)[..., :out.c] > 0, acc, torch.zeros(()))
-            _store(out, acc)
+            self._store(out, acc)
             if cls is not None:   # class sums of the stored (rounded) result, all in split 0
                 nsplit, scratch = cls
                 part = scratch.view(out.n, nsplit, 64, out.c)
@@ -642,7 +653,7 @@ class EmuBackend:
                 acc += v
             if relu:
                 acc = acc.clamp_min(0)
-            _store(out, acc)
+            self._store(out, acc)
             if stats is not None:   # statistics of the stored (rounded) row, all in partial 0
                 yv = _sl(out).reshape(out.n, out.vox, out.c)
                 stats[1].zero_()
@@ -656,13 +667,13 @@ class EmuBackend:
             z = torch.zeros(glow.n, glow.c, glow.d, glow.h, glow.w, requires_grad=True)
             up = F.interpolate(z, size=(ghi.d, ghi.h, ghi.w), mode="trilinear", align_corners=True)
             up.backward(_ncdhw(_sl(ghi)))
-            _store(glow, _ndhwc(z.grad))
+            self._store(glow, _ndhwc(z.grad))
         return run
 
     def stem_fwd(self, x, w, b, y):
         def run(s):
             out = x.reshape(y.n, y.d, y.h, y.w, 1).float() * w.detach().reshape(-1).float() + b.detach().float()
-            _store(y, out)
+            self._store(y, out)
         return run
 
     def stem_bwd(self, x, gy, scratch, dw, db, acc):
@@ -683,7 +694,7 @@ class EmuBackend:
         def run(s):
             out = torch.zeros(y.n, y.d, y.h, y.w, y.c)
             out[..., :c] = _ndhwc(x.float())
-            _store(y, out)
+            self._store(y, out)
         return run
 
     def unpack_ncdhw(self, x, y, c):
@@ -713,7 +724,7 @@ class EmuBackend:
             out_loss[0] = loss.detach()
             g = torch.zeros(ghm.n, ghm.d, ghm.h, ghm.w, ghm.c)
             g[..., :ncls] = z.grad
-            _store(ghm, g)
+            self._store(ghm, g)
         return run
 
     def reg_loss(self, reg, target, ind, mask, code_w, nreg, gscale, out, greg, prev=None):

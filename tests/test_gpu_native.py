@@ -41,6 +41,11 @@ NATIVE = configs.NATIVE_DIMS
 #   Round 2 blamed L1 sign flips at ties; the "+far" variant refutes that: with every regression target moved >= 1.0 away from
 #   the oracle's own prediction (far_targets: no sign can flip) the same tensors are off by the same amounts (0.283 / 0.193).
 #   What "+far" does gate tightly is the regression tower and the head itself (HEAD_REL): the tensors next to the loss.
+#   Round 4: the spread is MEASURED (test_one_heat_map_gate_is_summation_order_spread): two runs of the emulated plan that differ only
+#   by fp32 noise of another summation order (5e-7 relative in front of every bf16 rounding) are 0.1765 apart on the worst tensor
+#   (median 0.0169) -- the same tensors, the same size as HIP-vs-emulation (0.1774 / 0.0181) -- and eight supervised voxels per frame
+#   do not shrink it.  The fixed bounds below (0.25 vs the emulated plan = 1.4 x that spread) stay as coarse guards; the derived
+#   gates (1.5 x the spread measured in the same run) are the sharp ones.
 GATES = {"hr3d": {"oracle": (0.13, 0.991), "emu": (0.10, 0.994)},
          "hr3d_one_hm": {"oracle": (0.18, 0.985), "emu": (0.13, 0.99)},          # measured 0.135 / 0.097 (Cin = 1: dense radar input)
          "hr3d_one_hm_doppler": {"oracle": (0.35, 0.94), "emu": (0.25, 0.97)},   # measured 0.283 / 0.195
@@ -306,3 +311,105 @@ def test_keypoint_agreement_bf16_vs_fp32_on_trained_weights():
     # else (profiles/r03_keypoint_agreement.json: 0.06 cm over 256 frames)
     slack = r["root_argmax_disagreements"] * max(r["voxel_size_cm"]) * 14.0 / 15.0 / r["frames"]
     assert abs(r["mpjpe_cm"]["delta"]) < 0.5 + slack, (r["mpjpe_cm"], r["root_argmax_disagreements"])
+
+
+# ------------------------------------------------------------------------------------------------ the one-heat-map gate, measured
+def multi_pose_batch(batch, cin, dims, seed, poses):
+    """synth.make_batch for the one-heat-map heads with `poses` people per frame (the reference's max_poses > 1 label layout,
+    datasets/pipelines/pose.py:407-451: ind / mask / cat / anno_pose of shape [B, max_poses(, 45)], every centre splatted into the one
+    heat-map): `poses` supervised voxels per frame instead of one."""
+    Z, Y, X = dims
+    g = torch.Generator().manual_seed(seed)
+    rdr = torch.relu(torch.randn(batch, cin, Z, Y, X, generator=g) * 0.5 + 0.1)
+    prof = synth.splat_profile(2)
+    hm = torch.zeros(batch, 1, Z, Y, X)
+    ind = torch.zeros(batch, poses, dtype=torch.int64)
+    for b in range(batch):
+        seen = set()
+        for m in range(poses):
+            while True:
+                cz, cy, cx = (int(torch.randint(0, n, (1,), generator=g)) for n in (Z, Y, X))
+                if (cz, cy, cx) not in seen:
+                    break
+            seen.add((cz, cy, cx))
+            synth.draw_splat(hm[b, 0], cz, cy, cx, 2, prof)
+            ind[b, m] = (cz * Y + cy) * X + cx
+    ex = dict(rdr_tensor=rdr, hm=[hm], ind=[ind], mask=[torch.ones(batch, poses, dtype=torch.uint8)],
+              cat=[torch.zeros(batch, poses, dtype=torch.int64)], anno_pose=[torch.rand(batch, poses, 45, generator=g) * 16 - 8])
+    return {"rdr": ex, "meta": [{"seq": "synth", "frame": b, "rdr_frame": b} for b in range(batch)]}
+
+
+def _plan_grads(be, name, sd, ex, b, max_objs=None):
+    arch, fin, fout, fuse, heads, weight, cw = O.MODEL_CONFIGS[name]
+    shapes = O.param_shapes(arch, fin, fout, fout, heads)
+    flat = FlatParams(shapes, be.alloc)
+    flat.load_state_dict(sd)
+    eng = PoseEngine(be, flat.values, arch, fuse, heads, weight, cw, b, NATIVE, pgrads=flat.grads, max_objs=max_objs)
+    eng.load_input(ex["rdr"]["rdr_tensor"])
+    eng.load_targets(ex["rdr"])
+    eng.run_forward()
+    eng.run_loss_backward()
+    if getattr(be, "name", "") == "hip":
+        torch.cuda.synchronize()
+    return eng, flat
+
+
+SUM_ORDER_NOISE = 5e-7   # relative fp32 noise that stands for another summation order of a ~10^3-term fp32 dot product (~sqrt(864) * 2^-24 / 3)
+
+
+@pytest.mark.parametrize("poses", [1, 8])
+def test_one_heat_map_gate_is_summation_order_spread(hip, poses):
+    """hr3d_one_hm_doppler, B = 8: is the 15-20 % worst-tensor distance between the HIP kernels and the emulated plan "summation
+    order only"?  Measured instead of asserted by hand: the emulated plan is run TWICE with fp32 noise of
+    another summation order in front of every bf16 rounding (EmuBackend(noise=...), two seeds).  Two correct implementations of one
+    plan may differ by exactly that spread, so the gates are DERIVED from it: HIP-vs-emulation per tensor <= 1.5 x the worst
+    emulation-vs-emulation distance (+ 1 %), medians likewise, and HIP-vs-oracle <= 1.5 x emulation-vs-oracle.
+    poses = 1: the shipped label layout, one supervised voxel per frame.  poses = 8: eight people per frame (64 supervised voxels per
+    batch, the reference's max_poses > 1 layout) -- round 3 blamed the ONE supervised voxel for the wide spread; the measurement
+    says otherwise: with eight the emulation differs from itself by almost as much (the sensitivity belongs to this configuration's
+    dense 32-channel input path, layer1 / stage2 tensors), and the kernels stay inside that spread either way.
+    Measured (round 4): poses 1: emu-emu worst 0.1765 / median 0.0169, HIP-emu 0.1774 / 0.0181, the same five tensors on top."""
+    name, b = "hr3d_one_hm_doppler", 8
+    arch, fin, fout, fuse, heads, weight, cw = O.MODEL_CONFIGS[name]
+    spec = configs.spec(name)
+    sd = O.seeded_state_dict(O.param_shapes(arch, fin, fout, fout, heads), seed=1)
+    ex = synth.make_batch(b, spec["cin"], NATIVE, seed=1234, one_hm=True) if poses == 1 else multi_pose_batch(b, spec["cin"], NATIVE, 4321, poses)
+    mo = None if poses == 1 else poses
+    eng, flat = _plan_grads(hip, name, sd, ex, b, max_objs=mo)
+    sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ref = O.radar_pose_net(sdr, ex, fuse, weight, cw)
+    ref["loss"][0].backward()
+    live = [k for k in sd if sdr[k].grad is not None]
+    assert set(live) == eng.live_params
+    losses = {k: v.detach().float().cpu() for k, v in eng.losses().items()}
+    for k in ("loss", "hm_loss", "loc_loss"):
+        want = float(ref[k][0].detach())
+        assert abs(float(losses[k].sum()) - want) < 2e-2 * abs(want) + 1e-4, (k, float(losses[k].sum()), want)
+    assert float(losses["num_positive"]) == float(ref["num_positive"][0]) == b * poses
+    got = OrderedDict((k, flat.grads[k].detach().float().cpu()) for k in live)
+    orc = OrderedDict((k, sdr[k].grad) for k in live)
+    emu = []
+    for seed in (11, 22):
+        _, fl = _plan_grads(EmuBackend(fast=True, noise=SUM_ORDER_NOISE, seed=seed), name, sd, ex, b, max_objs=mo)
+        emu.append(OrderedDict((k, fl.grads[k].detach().float().clone()) for k in live))
+    r_ee = tensor_report(emu[0], emu[1], live)
+    r_he = [tensor_report(got, e, live) for e in emu]
+    r_ho, r_eo = tensor_report(got, orc, live), [tensor_report(e, orc, live) for e in emu]
+    top = max(r[2] for r in r_ee)
+    sig = lambda rows: [r for r in rows if r[5] > GATE_ABS * top]          # tensors that are not tiny-norm
+    worst = lambda rows: max(r[3] for r in sig(rows))
+    med = lambda rows: float(np.median([r[3] for r in rows]))
+    worst_ee, med_ee = worst(r_ee), med(r_ee)
+    worst_he, med_he = max(worst(rows) for rows in r_he), max(med(rows) for rows in r_he)
+    worst_ho, worst_eo = worst(r_ho), max(worst(rows) for rows in r_eo)
+    fmt = "   %-62s n=%-7d |g|=%.3e rel=%.4f cos=%.5f"
+    print("\n[%d pose(s) per frame] emulation (seed 11) vs emulation (seed 22), noise %.0e -- worst 5:\n%s"
+          % (poses, SUM_ORDER_NOISE, "\n".join(fmt % r[:5] for r in r_ee[:5])))
+    print("HIP vs emulation (seed 11) -- worst 5:\n%s" % "\n".join(fmt % r[:5] for r in r_he[0][:5]))
+    print("HIP vs oracle -- worst 3:\n%s" % "\n".join(fmt % r[:5] for r in r_ho[:3]))
+    print("worst tensor: emu-emu %.4f  hip-emu %.4f  emu-oracle %.4f  hip-oracle %.4f ; median: emu-emu %.4f  hip-emu %.4f"
+          % (worst_ee, worst_he, worst_eo, worst_ho, med_ee, med_he))
+    assert worst_he <= 1.5 * worst_ee + 0.01, ("HIP differs from the emulated plan by more than two emulations differ from each other",
+                                              worst_he, worst_ee)
+    assert med_he <= 1.5 * med_ee + 0.005, (med_he, med_ee)
+    assert worst_ho <= 1.5 * worst_eo + 0.01, (worst_ho, worst_eo)
