@@ -1050,10 +1050,11 @@ static bool tiled_geometry_ok(const RtpAct* x, const RtpConvGeom* g, int transpo
 static int tiled_wgs_per_sample(const RtpConvGeom* g) {
   const int tiles = (g->di / TZ) * (g->hi / TY) * ((g->wi + TX - 1) / TX);
   static const int total_wgs = getenv("RTP_TILED_WGS") ? atoi(getenv("RTP_TILED_WGS")) : 256;  // experiments: leave CUs to other streams
-  // launches of the lower levels (fewer than 2048 bricks in all: the level-1 tensors at the native shape) can be kept NARROW --
-  // fewer workgroups with more bricks each -- so that they run beside the main lane's kernels instead of taking every CU for a
-  // launch that leaves most of them idle (RTP_TILED_WGS_SMALL; 0 = as the large ones)
-  static const int small_wgs = getenv("RTP_TILED_WGS_SMALL") ? atoi(getenv("RTP_TILED_WGS_SMALL")) : 0;
+  // launches of the lower levels (fewer than 2048 bricks in all: the level-1 tensors at the native shape) are kept NARROW -- 128
+  // workgroups with twice the bricks each: the 55 KB of weights (and the GroupNorm fold) a workgroup pays before its first brick are
+  // amortised over 3 bricks per team instead of 1.5, and half the CUs stay free for the other lanes' kernels (hr3d B = 8 step:
+  // -0.7 ... -2.3 % depending on the box; 64 / 96 / 160 / 192 workgroups within 0.5 % of it; RTP_TILED_WGS_SMALL, 0 = as the large ones)
+  static const int small_wgs = getenv("RTP_TILED_WGS_SMALL") ? atoi(getenv("RTP_TILED_WGS_SMALL")) : 128;
   int wgs = ((small_wgs > 0 && (long)tiles * g->n < 2048) ? small_wgs : total_wgs) / g->n;  // workgroups per sample: one workgroup per CU when N divides 256
   if (wgs < 1) wgs = 1;
   if (wgs * 2 > tiles) wgs = (tiles + 1) / 2;

@@ -672,10 +672,48 @@ __device__ __forceinline__ void support(int il, int I, int O, int& lo, int& hi) 
   if (hi > O - 1) hi = O - 1;
 }
 
+// Tap table of the adjoint along one axis, built once per block in LDS: for every low-resolution index il the high-resolution
+// positions o with a NON-ZERO weight (ascending) and their weights.  The kernels below used to recompute support() and adj_w()
+// (floorf / ceilf, an int<->float round trip and two compares per candidate tap) for every tap of every output: ~30 vector
+// instructions per 16-byte load -- the passes ran at 1.6 TB/s of a streaming read, VALU-bound.  Same taps, same order, same
+// weights (a round's padding taps add 0 x value): results equal the on-the-fly form, which is kept as the fall-back for axes that
+// do not fit the table.
+#define ADJ_MAXI 96
+#define ADJ_MAXT 24
+struct AdjTab {
+  float w[ADJ_MAXI][ADJ_MAXT];
+  short o[ADJ_MAXI][ADJ_MAXT];
+  short cnt[ADJ_MAXI];
+  short ok;   // 0: an index has more than ADJ_MAXT taps -> callers fall back
+};
+
+__device__ __forceinline__ void adj_tab_build(AdjTab& t, int I, int O) {   // whole block; __syncthreads() inside
+  if (threadIdx.x == 0) t.ok = (I <= ADJ_MAXI) ? 1 : 0;
+  __syncthreads();
+  if (I <= ADJ_MAXI) {
+    for (int il = threadIdx.x; il < I; il += blockDim.x) {
+      int lo, hi, k = 0;
+      support(il, I, O, lo, hi);
+      for (int o = lo; o <= hi; ++o) {
+        const float wgt = adj_w(o, il, I, O);
+        if (wgt == 0.f) continue;
+        if (k < ADJ_MAXT) { t.w[il][k] = wgt; t.o[il][k] = (short)o; }
+        ++k;
+      }
+      t.cnt[il] = (short)(k <= ADJ_MAXT ? k : 0);
+      if (k > ADJ_MAXT) t.ok = 0;
+    }
+  }
+  __syncthreads();
+}
+
 // out[outer][il][inner][c] = sum_o w(o -> il) * in[outer][o][inner][c]   (channels-last, 8 channels per lane)
 template <typename TIN, typename TOUT>
 __global__ __launch_bounds__(256) void adjoint_axis_kernel(const TIN* in, int in_cs, int in_co, TOUT* out, int out_cs,
                                                            int out_co, int c, long outer, int I, int O, long inner) {
+  __shared__ AdjTab tab;
+  adj_tab_build(tab, I, O);
+  const bool fast = tab.ok != 0;   // block-uniform
   const int cpv = c >> 3;
   const long total = outer * I * inner * cpv;
   for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
@@ -684,17 +722,39 @@ __global__ __launch_bounds__(256) void adjoint_axis_kernel(const TIN* in, int in
     const long in_i = r % inner; r /= inner;
     const int il = (int)(r % I);
     const long ou = r / I;
-    int lo, hi;
-    support(il, I, O, lo, hi);
     float acc[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-    for (int o = lo; o <= hi; ++o) {
-      const float wgt = adj_w(o, il, I, O);
-      if (wgt == 0.f) continue;
-      const TIN* src = in + ((ou * O + o) * inner + in_i) * in_cs + in_co + ck * 8;
+    if (fast) {
+      // four taps per round, all four loads issued before the first use (one load in flight per thread left these passes
+      // parked on s_waitcnt 75-85 % of the time); a round's missing taps re-read the last one with weight 0
+      const int cnt = tab.cnt[il];
+      const TIN* base = in + (ou * O * inner + in_i) * in_cs + in_co + ck * 8;
+      typedef TIN tin8 __attribute__((ext_vector_type(8)));
+      for (int k0 = 0; k0 < cnt; k0 += 4) {
+        tin8 v[4];
+        float wg[4];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) acc[j] += wgt * (float)src[j];
+        for (int u = 0; u < 4; ++u) {
+          const int k = k0 + u < cnt ? k0 + u : cnt - 1;
+          wg[u] = k0 + u < cnt ? tab.w[il][k] : 0.f;
+          v[u] = *reinterpret_cast<const tin8*>(base + (long)tab.o[il][k] * inner * in_cs);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc[j] += wg[u] * (float)v[u][j];
+      }
+    } else {
+      int lo, hi;
+      support(il, I, O, lo, hi);
+      for (int o = lo; o <= hi; ++o) {
+        const float wgt = adj_w(o, il, I, O);
+        if (wgt == 0.f) continue;
+        const TIN* src = in + ((ou * O + o) * inner + in_i) * in_cs + in_co + ck * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += wgt * (float)src[j];
+      }
     }
     TOUT* dst = out + ((ou * I + il) * inner + in_i) * out_cs + out_co + ck * 8;
 #pragma unroll
@@ -708,6 +768,10 @@ __global__ __launch_bounds__(256) void adjoint_axis_kernel(const TIN* in, int in
 // level-1 -> level-0 adjoint.  Neighbouring outputs share their (2/scale + 2)^2 inputs through L1.
 __global__ __launch_bounds__(256) void adjoint_xy_kernel(const bf16_t* in, int in_cs, int in_co, float* out, int c, long outer,
                                                          int HL, int H, int WL, int W) {
+  __shared__ AdjTab taby, tabx;
+  adj_tab_build(taby, HL, H);
+  adj_tab_build(tabx, WL, W);
+  const bool fast = taby.ok != 0 && tabx.ok != 0;   // block-uniform
   const int cpv = c >> 3;
   const long total = outer * HL * WL * cpv;
   for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
@@ -716,28 +780,84 @@ __global__ __launch_bounds__(256) void adjoint_xy_kernel(const bf16_t* in, int i
     const int xl = (int)(r % WL); r /= WL;
     const int yl = (int)(r % HL);
     const long ou = r / HL;
-    int ylo, yhi, xlo, xhi;
-    support(yl, HL, H, ylo, yhi);
-    support(xl, WL, W, xlo, xhi);
     float acc[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-    for (int oy = ylo; oy <= yhi; ++oy) {
-      const float wy = adj_w(oy, yl, HL, H);
-      if (wy == 0.f) continue;
-      float row[8];
+    if (fast && tabx.cnt[xl] <= 5) {
+      // the x taps of a row (at most 5 for the x2 adjoints) are loaded together, and the NEXT row's loads are issued before this
+      // row's arithmetic: up to ten 16-byte loads in flight per thread instead of one
+      const int ny = taby.cnt[yl], nx = tabx.cnt[xl];
+      long xo[5];
+      float wx[5];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) row[j] = 0.f;
-      const bf16_t* srow = in + ((ou * H + oy) * W) * in_cs + in_co + ck * 8;
-      for (int ox = xlo; ox <= xhi; ++ox) {
-        const float wx = adj_w(ox, xl, WL, W);
-        if (wx == 0.f) continue;
-        const bf16_t* src = srow + (long)ox * in_cs;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) row[j] += wx * (float)src[j];
+      for (int u = 0; u < 5; ++u) {
+        const int k = u < nx ? u : nx - 1;
+        xo[u] = (long)tabx.o[xl][k] * in_cs;
+        wx[u] = u < nx ? tabx.w[xl][k] : 0.f;
       }
+      const bf16_t* plane = in + (ou * H * W) * in_cs + in_co + ck * 8;
+      bf16x8 cur[5], nxt[5];
+      {
+        const bf16_t* srow = plane + (long)taby.o[yl][0] * W * in_cs;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) acc[j] += wy * row[j];
+        for (int u = 0; u < 5; ++u) cur[u] = ld_bf16x8(srow + xo[u]);
+      }
+      for (int ky = 0; ky < ny; ++ky) {
+        const float wy = taby.w[yl][ky];
+        const int kn = ky + 1 < ny ? ky + 1 : ky;
+        const bf16_t* srow = plane + (long)taby.o[yl][kn] * W * in_cs;
+#pragma unroll
+        for (int u = 0; u < 5; ++u) nxt[u] = ld_bf16x8(srow + xo[u]);
+        float row[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) row[j] = 0.f;
+#pragma unroll
+        for (int u = 0; u < 5; ++u)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) row[j] += wx[u] * bf2f(cur[u][j]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += wy * row[j];
+#pragma unroll
+        for (int u = 0; u < 5; ++u) cur[u] = nxt[u];
+      }
+    } else if (fast) {
+      const int ny = taby.cnt[yl], nx = tabx.cnt[xl];
+      for (int ky = 0; ky < ny; ++ky) {
+        const float wy = taby.w[yl][ky];
+        float row[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) row[j] = 0.f;
+        const bf16_t* srow = in + ((ou * H + taby.o[yl][ky]) * W) * in_cs + in_co + ck * 8;
+        for (int kx = 0; kx < nx; ++kx) {
+          const float wx = tabx.w[xl][kx];
+          const bf16_t* src = srow + (long)tabx.o[xl][kx] * in_cs;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) row[j] += wx * (float)src[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += wy * row[j];
+      }
+    } else {
+      int ylo, yhi, xlo, xhi;
+      support(yl, HL, H, ylo, yhi);
+      support(xl, WL, W, xlo, xhi);
+      for (int oy = ylo; oy <= yhi; ++oy) {
+        const float wy = adj_w(oy, yl, HL, H);
+        if (wy == 0.f) continue;
+        float row[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) row[j] = 0.f;
+        const bf16_t* srow = in + ((ou * H + oy) * W) * in_cs + in_co + ck * 8;
+        for (int ox = xlo; ox <= xhi; ++ox) {
+          const float wx = adj_w(ox, xl, WL, W);
+          if (wx == 0.f) continue;
+          const bf16_t* src = srow + (long)ox * in_cs;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) row[j] += wx * (float)src[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += wy * row[j];
+      }
     }
     float* dst = out + ((ou * HL + yl) * WL + xl) * c + ck * 8;
 #pragma unroll
