@@ -191,7 +191,10 @@ def dcn_op_bench(dev, batch, iters=10):
     out["offsets_within_a_pixel"] = {"offset_sigma_px": 0.2, "forward_ms": timed(fwd), "forward_backward_ms": timed(fb)}
     out["offset_sigma_px"] = 0.5
     alg = (x.numel() + off.numel() + gy.numel()) * 4
-    out.update(workload="DCNv1 3x3 [%d,%d,%d,%d] -> %d, deformable_groups 4, im2col_step 64, fp32 (BASELINE config 4, op level)" % (n, c, h, w, co),
+    out.update(workload="DCNv1 3x3 [%d,%d,%d,%d] -> %d, deformable_groups 4, im2col_step 64; fp32 tensors in / out; forward: exact fp32 MFMA; "
+                        "backward (one-pass kernel): both matrix products on the bf16 matrix core with (hi, lo) operand splits, lo x lo "
+                        "dropped = 3.9e-6 norm-wise (RTP_DCN_FP32_MFMA=1: exact fp32 products) (BASELINE config 4, op level)" % (n, c, h, w, co),
+               arithmetic={"forward": "fp32 (v_mfma_f32_32x32x2_f32)", "backward": "bf16x3 split products, fp32 accumulation"},
                forward_algorithmic_GBps=round(alg / out["forward_ms"] / 1e6, 1),
                forward_tflops_fp32=round(2.0 * n * h * w * co * c * 9 / out["forward_ms"] / 1e9, 2))
     return out
@@ -508,7 +511,7 @@ def main():
         line["torch_gpu_baseline"] = torch_gpu_baseline(args.model, args.batch)
     # MPJPE proxy: an ARTEFACT of tests/keypoint_agreement.py (run on an MI355X with the oracle as the checker, which this
     # process may only use for cpu_baseline) -- quoted with its file name, not measured by this run
-    for kname in ("r03_keypoint_agreement.json", "r02_keypoint_agreement.json"):
+    for kname in ("r04_keypoint_agreement.json", "r03_keypoint_agreement.json", "r02_keypoint_agreement.json"):
         kj = os.path.join(ROOT, "profiles", kname)
         if world == 1 and os.path.exists(kj):
             try:
@@ -519,7 +522,8 @@ def main():
                 pass
             break
     # whole-step HBM traffic from the separate PMC passes (tools/pmc_step.sh), against the fused-minimum algorithmic bytes
-    pj = os.path.join(ROOT, "profiles", "r03_pmc_step_traffic.json")
+    pj = next((q for q in (os.path.join(ROOT, "profiles", f) for f in ("r04_pmc_step_traffic.json", "r03_pmc_step_traffic.json")) if os.path.exists(q)),
+              os.path.join(ROOT, "profiles", "r03_pmc_step_traffic.json"))
     if world == 1 and "roofline" in line and os.path.exists(pj) and args.model == "hr3d" and args.batch == 8:
         try:
             with open(pj) as f:
@@ -527,7 +531,7 @@ def main():
             fused_min = 3 * 553e6 * args.batch   # 553 MB per frame and pass, three passes
             line["roofline"]["whole_step_traffic_GB"] = round(pt["bytes_per_step"] / 1e9, 2)
             line["roofline"]["whole_step_traffic_ratio"] = round(pt["bytes_per_step"] / fused_min, 3)
-            line["roofline"]["whole_step_traffic_source"] = "profiles/r03_pmc_step_traffic.json (recorded %s)" % pt.get("recorded", "?")
+            line["roofline"]["whole_step_traffic_source"] = "profiles/%s (recorded %s)" % (os.path.basename(pj), pt.get("recorded", "?"))
         except Exception:
             pass
     if world == 1 and rank == 0 and not args.no_cpu_baseline:

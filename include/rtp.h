@@ -499,6 +499,21 @@ int rtp_modulated_deform_conv_backward(const float* input, const float* weight, 
 int rtp_prof_enable(int family, int on);
 int rtp_prof_collect(int family, float* total_ms, int* launches); /* synchronises the recorded events */
 const char* rtp_version(void);
+/* Several independent launches of ONE LDS-tiled kernel variant as one launch (csrc/rtp_multi.h; round 4).  HRNet's branches run the
+ * same block structure side by side: the full-resolution conv of a stage and the level-1 conv of the same position are launches
+ * of the same kernel on eight samples each, and alone the small one occupies every CU for a ninth of the work.
+ *   rtp_multi_begin();  <call the ordinary entry points of the launches to merge: rtp_conv_gn_fused / rtp_conv_igemm* /
+ *   rtp_conv_dgrad_fused / rtp_wgrad* on the tiled kernels -- they validate and RECORD instead of launching>;  rtp_multi_end(&h);
+ *   then rtp_multi_launch(h, stream) per step.  Results and buffers are those of the separate launches (a problem merely runs on
+ *   its share of every XCD's workgroups).  rtp_multi_end returns RTP_ERR_UNSUPPORTED when the recorded launches cannot share one
+ *   (different kernels or variants, batch != 8, a generic-kernel geometry): the caller keeps the separate launches. */
+int rtp_multi_begin(void);
+int rtp_multi_end(int* handle_out);
+int rtp_multi_abort(void);
+int rtp_multi_launch(int handle, void* stream);
+/* Width hint: the LDS-tiled launch whose output buffer starts at `key` (conv / data gradient: y->ptr + 2 * y->co bytes; weight
+ * gradient: the slab buffer) runs on total_wgs workgroups instead of one per CU; 0 removes the hint.  Results do not change. */
+int rtp_tiled_width_hint(const void* key, int total_wgs);
 /* Dynamic work claiming of the persistent LDS-tiled kernels (csrc/rtp_claim.h): 32-bit words of the per-GPU counter pool handed
  * out so far on the current device (every launch owns a slot keyed by its output pointer); -1 on error.  the claiming is opt-in: RTP_CLAIM=1
  * (environment, read once); the default is the static deal of bricks to workgroups. */

@@ -140,6 +140,8 @@ PROTOTYPES = {
     "rtp_prof_collect": [_I, C.POINTER(_F), C.POINTER(_I)],
     "rtp_version": [],
     "rtp_claim_slots_in_use": [],
+    "rtp_tiled_width_hint": [_P, _I],
+    "rtp_multi_begin": [], "rtp_multi_end": [C.POINTER(_I)], "rtp_multi_abort": [], "rtp_multi_launch": [_I, _P],
 }
 _RESTYPE = {"rtp_version": C.c_char_p, "rtp_dcn_workspace_bytes": C.c_long, "rtp_voxelize_workspace_bytes": C.c_long,
             "rtp_upsample_bwd_scratch_floats": C.c_long}

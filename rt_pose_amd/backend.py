@@ -97,6 +97,24 @@ class HipBackend:
         keep = (w, wd)
         return lambda s: check(fn(*args, s), "rtp_pack_dgrad_w") or keep and None
 
+    def multi(self, fns):
+        """fns: launch closures of this backend that each issue ONE stride-1 LDS-tiled kernel launch of the same variant on eight
+        samples (conv_gn_fused / conv / conv_dgrad_fused, or wgrad / wgrad_q / wgrad_tg).  -> ONE closure that issues them as a
+        shared launch (include/rtp.h: rtp_multi_*), or None when they cannot share one (the callers keep the separate launches)."""
+        lib = self.lib
+        check(lib.rtp_multi_begin(), "rtp_multi_begin")
+        try:
+            for f in fns:
+                f(None)          # recorded by the entry points, not launched
+        except _lib.RtpError:
+            lib.rtp_multi_abort()
+            return None
+        h = C.c_int(-1)
+        if lib.rtp_multi_end(C.byref(h)) != 0 or h.value < 0:
+            return None
+        hv, keep = h.value, tuple(fns)
+        return lambda s: check(lib.rtp_multi_launch(hv, s), "rtp_multi_launch") or keep and None
+
     def conv_tiled_ok(self, x, geom, transposed):
         return bool(self.lib.rtp_conv_tiled_ok(_act(x), _geom(geom), int(transposed)))
 

@@ -59,3 +59,23 @@ extern "C" int rtp_claim_slots_in_use(void) {
   std::lock_guard<std::mutex> lk(g_mu);
   return g_pool[dev].next;
 }
+
+// ---- per-launch width hints -------------------------------------------------------------------------------------------------
+// rtp_tiled_width_hint(key, total_wgs): the LDS-tiled launch whose OUTPUT buffer (conv / data gradient: y + channel offset; weight
+// gradient: the slab buffer) starts at `key` runs on total_wgs workgroups instead of one per CU (0 removes the hint).  The launch
+// plan uses it to keep a few CUs free for the other lanes' dependent chains exactly where the main lane would otherwise wait for them
+// (rt_pose_amd/engine.py); per-workgroup partial buffers keep their size (the upper slots stay zero).
+namespace {
+std::mutex g_wmu;
+std::unordered_map<const void*, int> g_width;
+}
+extern "C" int rtp_tiled_width_hint(const void* key, int total_wgs) {
+  std::lock_guard<std::mutex> lk(g_wmu);
+  if (total_wgs > 0) g_width[key] = total_wgs; else g_width.erase(key);
+  return RTP_OK;
+}
+int rtp_tiled_width_for(const void* key) {
+  std::lock_guard<std::mutex> lk(g_wmu);
+  auto it = g_width.find(key);
+  return it == g_width.end() ? 0 : it->second;
+}

@@ -10,6 +10,7 @@
 #include <stdlib.h>
 
 #include "rtp_common.h"
+#include "rtp_multi.h"
 #include "rtp_prof.h"
 
 struct ConvParams {
@@ -369,6 +370,7 @@ extern "C" int rtp_conv_sliced_ok(const RtpAct* x, const RtpConvGeom* g, int tra
 static int conv_sliced(const RtpAct* x, const void* wf, int w_per_sample, const float* btab, const RtpAct* res,
                        const RtpAct* y, const RtpConvGeom* g, int relu, int transposed, int y_fp32,
                        const RtpAct* stat_x, float* stat_out, float* ws, hipStream_t s) {
+  if (rtp_multi_capture()) return RTP_ERR_UNSUPPORTED;   // (chains of launches cannot be recorded for a shared launch)
   RtpConvGeom gs; int K, J;
   slice_geom(g, transposed, &gs, &K, &J);
   const int Ci = 32 * K, Co = 32 * J;
@@ -492,6 +494,7 @@ static int conv_dispatch(const RtpAct* x, const void* wf, int w_per_sample, cons
                                       acc32, acc_cs, (hipStream_t)stream);
     if (rc <= 0) return rc;  // handled (or failed) by the LDS-tiled kernel
   }
+  if (rtp_multi_capture()) return RTP_ERR_UNSUPPORTED;   // only the stride-1 LDS-tiled kernel can be recorded for a shared launch
   if (!transposed && g->stride == 2 && !stat_x) {
     const int rc = rtp_conv_s2_fwd_try(x, wf, w_per_sample, btab, res, y, g, relu, y_fp32, stat_out, acc32, acc_cs, (hipStream_t)stream, nullptr);
     if (rc <= 0) return rc;

@@ -19,9 +19,11 @@
 // P = sum dxhat, Q = sum dxhat * x), accumulated in registers over the workgroup's bricks and written as one partial per
 // workgroup, which removes a separate read pass over the tensor.
 #include <stdlib.h>
+#include <string.h>
 
 #include "rtp_claim.h"
 #include "rtp_common.h"
+#include "rtp_multi.h"
 #include "rtp_prof.h"
 
 #define TZ 2
@@ -97,6 +99,10 @@ struct TiledParams {
   // freerun: the two teams synchronise only WITHIN themselves (LDS-counter barriers over their four waves) and drift freely
   // against each other, instead of swapping roles at workgroup barriers; prio: wave priority of a team's MFMA phase.
   int freerun, prio;
+  // Per-workgroup partial outputs (statistics, totals) go to slot n * part_stride + wg: part_stride = workgroups per sample of a
+  // plain launch; a launch that shares the grid with other problems (conv_tiled_multi_kernel) runs on fewer workgroups per sample
+  // than the buffers were sized for and leaves the upper slots untouched (they are zero: nothing else writes them).
+  int part_stride;
   // FUSE: a data gradient that writes the FINISHED gradient of its input tensor x (= p.res, the AUX operand):
   //   y = [x > 0] * (A0 * acc + Bt * x + Ct + sum_e Ae * ex_e)
   // coef[0] = this conv's GroupNorm-backward coefficients [N][32][3] (A, B, C) or null (1, 0, 0); ex_e = gradient terms of
@@ -173,7 +179,7 @@ __device__ __forceinline__ void cv_sched() {
 // logits.  Compile-time, so that the common bf16-in / bf16-out epilogue carries neither their branches nor the register copies
 // the merge points cost.
 template <int NT, bool HAS_BTAB, int AUX, bool STAT, int FUSEX = 0, bool GEN = false>
-__global__ __launch_bounds__(512, 2) void conv_tiled_kernel(TiledParams p) {
+__device__ __forceinline__ void conv_tiled_body(const TiledParams& p, const int n, const int wg_in_sample) {
   constexpr bool FUSE = FUSEX > 0;
   static_assert(!(FUSE && GEN), "the fused data-gradient epilogue is bf16 in / bf16 out");
   constexpr int NEX = FUSE ? FUSEX - 1 : 0;
@@ -192,18 +198,15 @@ __global__ __launch_bounds__(512, 2) void conv_tiled_kernel(TiledParams p) {
   // class-bias table in LDS: 27 reachable classes (per axis: interior / first / last; every axis is >= 2 long here)
   float* bL = reinterpret_cast<float*>(lds + 27 * NT * 16 * 32 + 2 * (HALO_VOX * 32));  // [27][Co]
   const int wgs_per_sample = p.teams_per_sample >> 1;
-  // XCD-aware placement: workgroups are dealt round-robin over the 8 XCDs (b and b + 8 share an L2), so the logical
-  // workgroup index is permuted to give every XCD one contiguous run of bricks -- haloes shared with the y/x neighbour
-  // columns then hit that XCD's L2 instead of being re-read from HBM (PMC: x fetched 2.4x with the identity map).
-  const int bid = (gridDim.x % 8 == 0) ? (int)(blockIdx.x % 8) * (int)(gridDim.x / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
-  const int n = bid / wgs_per_sample;
-  const int team_id = (bid - n * wgs_per_sample) * 2 + team;  // team index within the sample
+  // (sample and workgroup-within-sample come from the kernel wrapper below: XCD-aware placement)
+  const int bid = n * p.part_stride + wg_in_sample;             // this workgroup's slot in the per-workgroup partial outputs
+  const int team_id = wg_in_sample * 2 + team;  // team index within the sample
   const int v = lane & 15, q = lane >> 4;
   const int wz = tw >> 1, wx = tw & 1;
   // dynamic brick claiming (below, "work distribution")
   const bool dyn = p.claim != nullptr;                                          // kernel-uniform
   const bool claimer = tw == 0 && lane == 0;                                    // the one lane per team that talks to the counters
-  int rng = dyn ? ((bid - n * wgs_per_sample) * p.ranges) / wgs_per_sample : 0;   // claimer's current range (home range first)
+  int rng = dyn ? (wg_in_sample * p.ranges) / wgs_per_sample : 0;   // claimer's current range (home range first)
   int nfail = 0;   // ranges this claimer has found empty
 
   if (p.fw) {   // kernel-uniform: GroupNorm fold in the prologue (both teams' brick regions are scratch until the phase loop)
@@ -248,7 +251,7 @@ __global__ __launch_bounds__(512, 2) void conv_tiled_kernel(TiledParams p) {
       const float rstd = 1.0f / sqrtf((float)var + p.f_eps);
       mrl[tid * 2] = (float)mean;
       mrl[tid * 2 + 1] = rstd;
-      if (p.f_mr && bid == n * wgs_per_sample) {
+      if (p.f_mr && wg_in_sample == 0) {
         p.f_mr[((long)n * p.f_groups + tid) * 2] = (float)mean;
         p.f_mr[((long)n * p.f_groups + tid) * 2 + 1] = rstd;
       }
@@ -296,32 +299,27 @@ __global__ __launch_bounds__(512, 2) void conv_tiled_kernel(TiledParams p) {
     }
     __syncthreads();   // the scratch is the bricks' from here on
   }
-  // ---- weights -> LDS (once): item = (row = tap*Co + co, chunk)
+  // ---- weights -> LDS (once), by LDS-DMA: all of a thread's (up to 7) sixteen-byte pieces are in flight at once and land while
+  // the set-up below runs (registers + two dependent rounds of loads and LDS stores cost 3.2 us per launch in front of it).  A wave
+  // instruction's LDS destination is linear, so -- as for the bricks -- the layout is applied on the SOURCE side: the lane whose slot
+  // is (tap position dtap, MFMA row arow, rotated chunk) fetches output channel co(arow) of tap dtap (flipped for a data gradient),
+  // logical chunk (rotated chunk - 2 * (arow >> 2)) & 3.
+  // MFMA row (nt, 4q+r) <- output channel 8q + 4nt + r: lane (voxel, q) then owns channels 8q..8q+7, one 16-B chunk, and a wave's
+  // store instruction covers 16 voxels x 64 B = 1 KB of contiguous output.
   if (!p.fw) {
     const bf16_t* wsrc = p.w + (p.w_per_sample ? (long)n * p.w_sample_stride : 0);
-    const int items = 27 * p.Co * 4;
-    for (int i0 = tid; i0 < items; i0 += 512 * 4) {
-      bf16x8 val[4];
+    constexpr int CO_T = NT * 16, ITEMS = 27 * CO_T * 4, NPIECE = (ITEMS + 511) / 512;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int i = i0 + k * 512;
-        if (i < items) {
-          const int row = i >> 2, tap = row / p.Co, co = row - tap * p.Co;
-          val[k] = ld_bf16x8(wsrc + (long)tap * p.w_tap_stride + (long)co * p.w_row_stride + (i & 3) * 8);
-        }
-      }
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int i = i0 + k * 512;
-        if (i < items) {
-          const int ck = i & 3, row = i >> 2;
-          const int tap = row / p.Co, co = row - tap * p.Co;
-          const int dtap = p.flip ? 26 - tap : tap;
-          // MFMA row (nt, 4q+r) <- output channel 8q + 4nt + r: lane (voxel, q) then owns channels 8q..8q+7, one 16-B
-          // chunk, and a wave's store instruction covers 16 voxels x 64 B = 1 KB of contiguous output
-          const int arow = (NT == 2) ? ((co >> 2) & 1) * 16 + (co >> 3) * 4 + (co & 3) : co;
-          st_bf16x8(wL + (dtap * p.Co + arow) * 32 + swz(ck, arow), val[k]);
-        }
+    for (int k = 0; k < NPIECE; ++k) {
+      const int d = k * 512 + tid;
+      if (d < ITEMS) {
+        const int cpos = d & 3, row = d >> 2, dtap = row / CO_T, arow = row - dtap * CO_T;
+        const int ck = (cpos - 2 * (arow >> 2)) & 3;
+        const int co = (NT == 2) ? ((arow >> 2) & 3) * 8 + (arow >> 4) * 4 + (arow & 3) : arow;
+        const int tap = p.flip ? 26 - dtap : dtap;
+        const bf16_t* src = wsrc + (long)tap * p.w_tap_stride + (long)co * p.w_row_stride + ck * 8;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(wL + (k * 512 + (tid & ~63)) * 8), 16, 0, 0);
       }
     }
   }
@@ -373,7 +371,7 @@ __global__ __launch_bounds__(512, 2) void conv_tiled_kernel(TiledParams p) {
             }
         CSs[i] = v;
       }
-      if (p.csum_out && bid == n * wgs_per_sample) {   // exclusive boundary classes for the deferred fold: 64 x 32
+      if (p.csum_out && wg_in_sample == 0) {   // exclusive boundary classes for the deferred fold: 64 x 32
         for (int i = tid; i < 64 * 32; i += 512) {
           const int cls = i >> 5, co = i & 31;
           const int sz = cls & 3, sy = (cls >> 2) & 3, sx = (cls >> 4) & 3;   // per axis: 0 interior, 1 first, 2 last, 3 both (empty)
@@ -450,7 +448,7 @@ __global__ __launch_bounds__(512, 2) void conv_tiled_kernel(TiledParams p) {
         a0 = gr * ggam;
         bt = -gr * gr * s2 / p.gn_m;
         ct = -gr * s1 / p.gn_m + gr * gr * gmu * s2 / p.gn_m;
-        if (p.coef_out && bid == n * wgs_per_sample) {
+        if (p.coef_out && wg_in_sample == 0) {
           float* o = p.coef_out + ((long)n * 32 + tid) * 3;
           o[0] = a0; o[1] = bt; o[2] = ct;
           float* pt = p.coef_out + (long)p.N * 32 * 3 + ((long)n * 32 + tid) * 2;
@@ -511,8 +509,10 @@ __global__ __launch_bounds__(512, 2) void conv_tiled_kernel(TiledParams p) {
     if (dyn) {
       claim_finish(team_id - rng * (p.teams_per_sample / p.ranges), false);
     } else {   // contiguous, balanced runs of bricks per team: consecutive bricks share two of their four haloed z-planes
-      const int t_begin = (int)((long)team_id * p.tiles_per_sample / p.teams_per_sample);
-      const int t_end = (int)((long)(team_id + 1) * p.tiles_per_sample / p.teams_per_sample);
+      // (32-bit: team index x bricks of a sample stays far below 2^31 -- rtp_conv_tiled_try checks -- and a 64-bit division is
+      // ~150 instructions on this chip)
+      const int t_begin = (int)((unsigned)team_id * (unsigned)p.tiles_per_sample / (unsigned)p.teams_per_sample);
+      const int t_end = (int)((unsigned)(team_id + 1) * (unsigned)p.tiles_per_sample / (unsigned)p.teams_per_sample);
       ctl[2 * team] = t_end > t_begin ? t_begin : -1;
       ctl[2 * team + 1] = t_end;
     }
@@ -1034,6 +1034,36 @@ __global__ __launch_bounds__(512, 2) void conv_tiled_kernel(TiledParams p) {
   }
 }
 
+// One problem per launch.  XCD-aware placement: workgroups are dealt round-robin over the 8 XCDs (b and b + 8 share an L2), so the
+// logical workgroup index is permuted to give every XCD one contiguous run of bricks -- haloes shared with the y/x neighbour columns
+// then hit that XCD's L2 instead of being re-read from HBM (PMC: x fetched 2.4x with the identity map).
+template <int NT, bool HAS_BTAB, int AUX, bool STAT, int FUSEX = 0, bool GEN = false>
+__global__ __launch_bounds__(512, 2) void conv_tiled_kernel(TiledParams p) {
+  const int wgs_per_sample = p.teams_per_sample >> 1;
+  const int bid = (gridDim.x % 8 == 0) ? (int)(blockIdx.x % 8) * (int)(gridDim.x / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
+  const int n = bid / wgs_per_sample;
+  conv_tiled_body<NT, HAS_BTAB, AUX, STAT, FUSEX, GEN>(p, n, bid - n * wgs_per_sample);
+}
+
+// SEVERAL problems of one kernel variant share a launch (horizontal fusion, round 4): HRNet's branches run the same block structure
+// side by side, so the full-resolution conv of a stage and the level-1 conv of the same position are independent launches of the
+// same variant -- alone, the level-1 one occupied all 256 CUs for 1.5 bricks per team (26 us for a ninth of the work), and the two
+// serialised.  Here the eight samples keep their XCDs and each XCD's 32 workgroups are split between the problems in proportion to
+// their bricks (28 + 4 for full resolution + level 1: 11.4 and 12 bricks per team).  jobs[j] = the problem's parameters (built by
+// the host exactly as for a plain launch, teams_per_sample = 2 x its share), split[j] = first workgroup of problem j within an XCD.
+#define RTP_MULTI_MAX 4
+struct TiledMulti { const TiledParams* jobs; int njobs; int split[RTP_MULTI_MAX + 1]; };
+template <int NT, bool HAS_BTAB, int AUX, bool STAT, int FUSEX = 0>
+__global__ __launch_bounds__(512, 2) void conv_tiled_multi_kernel(TiledMulti m) {
+  const int xcd = (int)(blockIdx.x % 8), l = (int)(blockIdx.x / 8);   // grid = 8 x workgroups per XCD; sample = XCD
+  int j = 0;
+#pragma unroll
+  for (int k = 1; k < RTP_MULTI_MAX; ++k) j += (k < m.njobs && l >= m.split[k]) ? 1 : 0;
+  j = __builtin_amdgcn_readfirstlane(j);
+  const TiledParams p = m.jobs[j];   // (uniform address: scalar loads)
+  conv_tiled_body<NT, HAS_BTAB, AUX, STAT, FUSEX, false>(p, xcd, l - m.split[j]);
+}
+
 static bool tiled_geometry_ok(const RtpAct* x, const RtpConvGeom* g, int transposed, int* Co_out) {
   static const bool disabled = getenv("RTP_DISABLE_TILED") != nullptr;
   if (disabled) return false;
@@ -1050,11 +1080,11 @@ static bool tiled_geometry_ok(const RtpAct* x, const RtpConvGeom* g, int transpo
 static int tiled_wgs_per_sample(const RtpConvGeom* g) {
   const int tiles = (g->di / TZ) * (g->hi / TY) * ((g->wi + TX - 1) / TX);
   static const int total_wgs = getenv("RTP_TILED_WGS") ? atoi(getenv("RTP_TILED_WGS")) : 256;  // experiments: leave CUs to other streams
-  // launches of the lower levels (fewer than 2048 bricks in all: the level-1 tensors at the native shape) are kept NARROW -- 128
-  // workgroups with twice the bricks each: the 55 KB of weights (and the GroupNorm fold) a workgroup pays before its first brick are
-  // amortised over 3 bricks per team instead of 1.5, and half the CUs stay free for the other lanes' kernels (hr3d B = 8 step:
-  // -0.7 ... -2.3 % depending on the box; 64 / 96 / 160 / 192 workgroups within 0.5 % of it; RTP_TILED_WGS_SMALL, 0 = as the large ones)
-  static const int small_wgs = getenv("RTP_TILED_WGS_SMALL") ? atoi(getenv("RTP_TILED_WGS_SMALL")) : 128;
+  // launches of the lower levels (fewer than 2048 bricks in all: the level-1 tensors at the native shape) are kept NARROW -- 64
+  // workgroups with four times the bricks each: the 55 KB of weights (and the GroupNorm fold) a workgroup pays before its first brick
+  // are amortised over 6 bricks per team instead of 1.5, and they fit on the CUs the hinted main-lane launches leave free (hr3d B = 8
+  // step: -0.7 ... -2.3 % depending on the box for 128, another -0.5 % for 64 beside the width hints; RTP_TILED_WGS_SMALL, 0 = as the large ones)
+  static const int small_wgs = getenv("RTP_TILED_WGS_SMALL") ? atoi(getenv("RTP_TILED_WGS_SMALL")) : 64;
   int wgs = ((small_wgs > 0 && (long)tiles * g->n < 2048) ? small_wgs : total_wgs) / g->n;  // workgroups per sample: one workgroup per CU when N divides 256
   if (wgs < 1) wgs = 1;
   if (wgs * 2 > tiles) wgs = (tiles + 1) / 2;
@@ -1105,8 +1135,14 @@ int rtp_conv_tiled_try(const RtpAct* x, const void* wf, int w_per_sample, const 
   p.relu = relu; p.y_fp32 = y_fp32; p.flip = transposed; p.w_per_sample = w_per_sample;
   p.tiles_y = p.H / TY; p.tiles_x = (p.W + TX - 1) / TX; p.tiles_z = p.D / TZ;
   p.tiles_per_sample = (p.D / TZ) * p.tiles_y * p.tiles_x;
-  const int wgs = tiled_wgs_per_sample(g);
+  int wgs = tiled_wgs_per_sample(g);
+  p.part_stride = wgs;   // (the partial buffers are sized for the un-hinted launch)
+  if (const int hint = rtp_tiled_width_for((const char*)y->ptr + 2 * (size_t)y->co)) {   // fewer workgroups: CUs left to other lanes
+    const int hw = hint / g->n;
+    if (hw >= 1 && hw < wgs) wgs = hw;
+  }
   p.teams_per_sample = wgs * 2;
+  if ((long)p.tiles_per_sample * (p.teams_per_sample + 1) >= (1L << 31)) return RTP_ERR_SHAPE;
   static const int dbg = getenv("RTP_TILED_DBG") ? atoi(getenv("RTP_TILED_DBG")) : 0;
   p.dbg = dbg;
   // dynamic brick claiming (rtp_claim.h; RTP_CLAIM=1 switches it on; default: the static deal, RTP_TILED_UNIT: bricks per claim)
@@ -1167,6 +1203,19 @@ int rtp_conv_tiled_try(const RtpAct* x, const void* wf, int w_per_sample, const 
   }
   const int nt = Co / 16;
   const size_t shm = sizeof(bf16_t) * (27 * (size_t)Co * 32 + 2 * (size_t)HALO_VOX * 32) + 27 * (size_t)Co * sizeof(float) + 64;
+  if (std::vector<RtpMultiJob>* cap = rtp_multi_capture()) {   // recorded for a shared launch (rtp_multi.h), not issued
+    const int aux_c = stat_x ? 2 : (res ? 1 : 0);
+    if (nt != 2 || acc32 || y_fp32 || slice) return RTP_ERR_UNSUPPORTED;
+    RtpMultiJob job;
+    job.kind = RTP_MULTI_CONV_TILED;
+    job.variant = fuse ? (100 + p.nextra) : (((btab || fold) ? 1 : 0) * 8 + aux_c * 2 + (stat_out ? 1 : 0));
+    job.tiles_per_sample = p.tiles_per_sample; job.n = p.N; job.slots_per_sample = p.part_stride; job.shm = shm;
+    job.fam = transposed ? RTP_FAM_CONV_TILED_FULL_BWD : RTP_FAM_CONV_TILED_FULL;
+    p.claim = nullptr; p.ranges = 1;   // the static deal inside a shared launch
+    job.params.assign((const char*)&p, (const char*)&p + sizeof(p));
+    cap->push_back(job);
+    return RTP_OK;
+  }
   RtpProfScope prof((Co == 32 && (long)p.N * p.D * p.H * p.W >= (1L << 20)) ? (transposed ? RTP_FAM_CONV_TILED_FULL_BWD : RTP_FAM_CONV_TILED_FULL)
                                                                                 : RTP_FAM_CONV_TILED, s);
   using Kern = void (*)(TiledParams);
@@ -1235,6 +1284,7 @@ extern "C" int rtp_conv_dgrad_fused(const RtpAct* gy, const void* wd, const RtpA
   if (x->c < 32 || dx->c < 32) return RTP_ERR_SHAPE;
   if (gn && gn->groups != 8 && gn->groups != 1) return RTP_ERR_UNSUPPORTED;
   if (g->stride == 2) {   // the parity-class kernel (dgrad_s2_tiled.hip)
+    if (rtp_multi_capture()) return RTP_ERR_UNSUPPORTED;
     S2Fuse f2;
     f2.nextra = nterms; f2.mask = mask; f2.tot_out = tot_out; f2.gn = gn;
     f2.coef[0] = coeff;
@@ -1257,4 +1307,59 @@ extern "C" int rtp_conv_dgrad_fused_ok(const RtpAct* gy, const RtpConvGeom* g) {
   int Co;
   if (g->stride == 2) return rtp_dgrad_s2_stat_slots(gy, g) > 0 ? 1 : 0;
   return (tiled_geometry_ok(gy, g, 1, &Co) && Co == 32) ? 1 : 0;
+}
+
+// ---- shared launches (rtp_multi.h)
+namespace {
+struct ConvMultiLauncher { void (*kern)(TiledMulti); TiledMulti m; size_t shm; };
+using MKern = void (*)(TiledMulti);
+MKern conv_multi_kernel_for(int variant) {
+  switch (variant) {
+    case 0 * 8 + 0 * 2 + 0: return conv_tiled_multi_kernel<2, false, 0, false>;
+    case 0 * 8 + 0 * 2 + 1: return conv_tiled_multi_kernel<2, false, 0, true>;
+    case 0 * 8 + 1 * 2 + 0: return conv_tiled_multi_kernel<2, false, 1, false>;
+    case 0 * 8 + 1 * 2 + 1: return conv_tiled_multi_kernel<2, false, 1, true>;
+    case 0 * 8 + 2 * 2 + 1: return conv_tiled_multi_kernel<2, false, 2, true>;
+    case 1 * 8 + 0 * 2 + 0: return conv_tiled_multi_kernel<2, true, 0, false>;
+    case 1 * 8 + 0 * 2 + 1: return conv_tiled_multi_kernel<2, true, 0, true>;
+    case 1 * 8 + 1 * 2 + 0: return conv_tiled_multi_kernel<2, true, 1, false>;
+    case 1 * 8 + 1 * 2 + 1: return conv_tiled_multi_kernel<2, true, 1, true>;
+    case 1 * 8 + 2 * 2 + 1: return conv_tiled_multi_kernel<2, true, 2, true>;
+    case 100: return conv_tiled_multi_kernel<2, false, 2, false, 1>;
+    case 101: return conv_tiled_multi_kernel<2, false, 2, false, 2>;
+    case 102: return conv_tiled_multi_kernel<2, false, 2, false, 3>;
+    case 103: return conv_tiled_multi_kernel<2, false, 2, false, 4>;
+    default: return nullptr;
+  }
+}
+}  // namespace
+
+int rtp_conv_tiled_multi_finish(std::vector<RtpMultiJob>& jobs, const int* share, void* dev_params, void** launcher) {
+  MKern k = conv_multi_kernel_for(jobs[0].variant);
+  if (!k) return RTP_ERR_UNSUPPORTED;
+  if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)jobs[0].shm) != hipSuccess) return RTP_ERR_LAUNCH;
+  std::vector<TiledParams> host(jobs.size());
+  ConvMultiLauncher* L = new ConvMultiLauncher();
+  L->kern = k; L->shm = jobs[0].shm;
+  L->m.jobs = (const TiledParams*)dev_params; L->m.njobs = (int)jobs.size();
+  int at = 0;
+  for (size_t j = 0; j < jobs.size(); ++j) {
+    if (jobs[j].params.size() != sizeof(TiledParams)) { delete L; return RTP_ERR_SHAPE; }
+    memcpy(&host[j], jobs[j].params.data(), sizeof(TiledParams));
+    host[j].teams_per_sample = 2 * share[j];   // (part_stride keeps the slots the problem's partial buffers were sized for)
+    host[j].total_wgs = 8 * share[j];
+    L->m.split[j] = at;
+    at += share[j];
+  }
+  for (size_t j = jobs.size(); j <= RTP_MULTI_MAX; ++j) L->m.split[j] = at;
+  if (hipMemcpy(dev_params, host.data(), host.size() * sizeof(TiledParams), hipMemcpyHostToDevice) != hipSuccess) { delete L; return RTP_ERR_LAUNCH; }
+  *launcher = L;
+  return RTP_OK;
+}
+
+int rtp_conv_tiled_multi_launch(void* launcher, hipStream_t s) {
+  ConvMultiLauncher* L = (ConvMultiLauncher*)launcher;
+  hipLaunchKernelGGL(L->kern, dim3(256), dim3(512), L->shm, s, L->m);
+  RTP_CHECK_LAUNCH();
+  return RTP_OK;
 }

@@ -33,3 +33,6 @@ __device__ __forceinline__ int rtp_claim_take(int* ctr, int unit) {
 __device__ __forceinline__ void rtp_claim_reset_if_last(int* ctr, int drawn, int units, int claimers) {
   if (drawn == units + claimers - 1) __hip_atomic_store(ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+
+// per-launch width hint for the output buffer `key` (claim.hip); 0 = none
+int rtp_tiled_width_for(const void* key);

@@ -10,6 +10,7 @@
 #include <stdlib.h>
 
 #include "rtp_common.h"
+#include "rtp_multi.h"
 #include "rtp_prof.h"
 
 #define WG_VB 128  // voxels per staged chunk (41 KB of LDS per block: three blocks per CU overlap each other's gathers)
@@ -262,6 +263,7 @@ extern "C" int rtp_wgrad(const RtpAct* gy, const RtpAct* x, const RtpConvGeom* g
     const int rc = rtp_wgrad_tiled_try(gy, x, g, nsplit, gp, (hipStream_t)stream, nullptr, nullptr, nullptr);
     if (rc <= 0) return rc;
   }
+  if (rtp_multi_capture()) return RTP_ERR_UNSUPPORTED;   // only the stride-1 LDS-tiled kernel can be recorded for a shared launch
   {
     const int rc = rtp_wgrad_s2_try(gy, x, g, nsplit, gp, (hipStream_t)stream, 0, 0);
     if (rc <= 0) return rc;

@@ -11,8 +11,11 @@
 // LDS images rotate the 16-B chunk index by (x>>2) -- conflict-free for the tr-read lane groups (voxels v and v+8).
 #include <stdlib.h>
 
+#include <string.h>
+
 #include "rtp_claim.h"
 #include "rtp_common.h"
+#include "rtp_multi.h"
 #include "rtp_prof.h"
 
 #define TZ 2
@@ -71,6 +74,9 @@ struct WgTiledParams {
   // Claims are UNITS of `unit` consecutive bricks (1 or 2), by index: the counter's answer is asked for at a unit's first brick and
   // needed only after its last one.
   int* claim; int ranges, total_wgs, unit;
+  // per-workgroup outputs (slab, Q partial, subset sums) go to slot n * part_stride + wg: the workgroups per sample of a plain
+  // launch; in a shared launch (wgrad_tiled_multi_kernel) a problem runs on fewer and leaves the upper slots untouched (zero)
+  int part_stride;
 };
 #define WG_NONE 0x3fffffff
 
@@ -174,7 +180,9 @@ __device__ __forceinline__ void wg_brick(const LaneAddr& la, f32x4 (&acc)[WG_NTS
 
 // (explicit occupancy: with only __launch_bounds__ the scheduler aimed at 3 waves/SIMD once the loader path grew, and squeezed the
 // consumers' software pipeline into 168 VGPRs: +9 us per launch)
-__global__ __attribute__((amdgpu_flat_work_group_size(WG_THREADS, WG_THREADS), amdgpu_waves_per_eu(WG_THREADS / 256, WG_THREADS / 256))) void wgrad_tiled_kernel(WgTiledParams p) {
+__global__ __attribute__((amdgpu_flat_work_group_size(WG_THREADS, WG_THREADS), amdgpu_waves_per_eu(WG_THREADS / 256, WG_THREADS / 256))) void wgrad_tiled_kernel(WgTiledParams p);
+
+__device__ __forceinline__ void wgrad_tiled_body(const WgTiledParams& p, const int n, const int wg) {
   extern __shared__ __attribute__((aligned(16))) bf16_t lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #ifdef RTP_WGT_PROF
@@ -184,10 +192,6 @@ __global__ __attribute__((amdgpu_flat_work_group_size(WG_THREADS, WG_THREADS), a
   const bool loader = __builtin_amdgcn_readfirstlane(wave) >= WG_NCW;  // the last four waves stage, the others run the MFMAs
   const int tw = __builtin_amdgcn_readfirstlane(wave);                  // MFMA wave index (taps tw, tw + WG_NCW, ...)
   const int ttid = tid - WG_NCW * 64;                                   // loader thread index 0 .. 255
-  // XCD-aware placement (see conv_tiled.hip): one contiguous run of bricks per XCD
-  const int bid = (gridDim.x % 8 == 0) ? (int)(blockIdx.x % 8) * (int)(gridDim.x / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
-  const int n = bid / p.wgs_per_sample;
-  const int wg = bid - n * p.wgs_per_sample;
   const long vox_n = (long)n * p.D * p.H * p.W;
   constexpr int BUF = (HALO_VOX + BRICK_VOX) * 32;  // elements per staged brick (x halo + gy)
   // ---- which bricks: iteration k of the workgroup works on brick tile_k.  Static deal: a contiguous run, z fastest (L2 reuse of
@@ -381,7 +385,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(WG_THREADS, WG_THREADS), a
       if (lane == 0) last = (atomicAdd(tcnt, 1) == 3);
       last = __builtin_amdgcn_readfirstlane(last);
       if (last) {
-        float* G = p.tg + ((long)n * p.wgs_per_sample + wg) * 27 * 32;
+        float* G = p.tg + ((long)n * p.part_stride + wg) * 27 * 32;
         for (int k = lane; k < 27 * 32; k += 64)
           G[k] = (Tall[k] + Tall[27 * 32 + k]) + (Tall[2 * 27 * 32 + k] + Tall[3 * 27 * 32 + k]);
       }
@@ -457,7 +461,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(WG_THREADS, WG_THREADS), a
 
   const int q = lane >> 4, i = lane & 15;
   // ---- one fp32 slab [27][32][32] per workgroup; D[row = co][col = ci]: lane holds rows 4q..4q+3, column lane&15
-  float* out = p.gp + ((long)n * p.wgs_per_sample + wg) * 27 * p.slab_rows * p.slab_cols;
+  float* out = p.gp + ((long)n * p.part_stride + wg) * 27 * p.slab_rows * p.slab_cols;
 #pragma unroll
   for (int t = 0; t < WG_NTS; ++t) {
     const int tap = tw + WG_NCW * t;
@@ -502,9 +506,32 @@ __global__ __attribute__((amdgpu_flat_work_group_size(WG_THREADS, WG_THREADS), a
       float a = 0.f;
 #pragma unroll
       for (int w8 = 0; w8 < WG_NCW; ++w8) a += red[w8 * 32 + lane];
-      p.qpart[((long)n * p.wgs_per_sample + wg) * 32 + lane] = a;
+      p.qpart[((long)n * p.part_stride + wg) * 32 + lane] = a;
     }
   }
+}
+
+// One problem per launch; XCD-aware placement (see conv_tiled.hip): one contiguous run of bricks per XCD.
+__global__ __attribute__((amdgpu_flat_work_group_size(WG_THREADS, WG_THREADS), amdgpu_waves_per_eu(WG_THREADS / 256, WG_THREADS / 256)))
+void wgrad_tiled_kernel(WgTiledParams p) {
+  const int bid = (gridDim.x % 8 == 0) ? (int)(blockIdx.x % 8) * (int)(gridDim.x / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
+  const int n = bid / p.wgs_per_sample;
+  wgrad_tiled_body(p, n, bid - n * p.wgs_per_sample);
+}
+
+// Several weight gradients in one launch (rtp_multi.h, conv_tiled.hip's conv_tiled_multi_kernel): sample = XCD, every XCD's 32
+// workgroups split between the problems in proportion to their bricks.
+#define RTP_MULTI_MAX 4
+struct WgMulti { const WgTiledParams* jobs; int njobs; int split[RTP_MULTI_MAX + 1]; };
+__global__ __attribute__((amdgpu_flat_work_group_size(WG_THREADS, WG_THREADS), amdgpu_waves_per_eu(WG_THREADS / 256, WG_THREADS / 256)))
+void wgrad_tiled_multi_kernel(WgMulti m) {
+  const int xcd = (int)(blockIdx.x % 8), l = (int)(blockIdx.x / 8);
+  int j = 0;
+#pragma unroll
+  for (int k = 1; k < RTP_MULTI_MAX; ++k) j += (k < m.njobs && l >= m.split[k]) ? 1 : 0;
+  j = __builtin_amdgcn_readfirstlane(j);
+  const WgTiledParams p = m.jobs[j];
+  wgrad_tiled_body(p, xcd, l - m.split[j]);
 }
 
 // 32 -> <=32 channels: one launch.  Cin = 32 K, Cout = 32 J (K * J > 1, the feat64 backbone's layers): K x J launches, each
@@ -544,6 +571,7 @@ int rtp_wgrad_tiled_try(const RtpAct* gy, const RtpAct* x, const RtpConvGeom* g,
   if (x->cs % 32 || x->co % 8 || nsplit != wg_tiled_wgs(g)) return 1;   // x may be a 32-channel slice of a wider tensor
   const int K = g->ci / 32, J = (g->co + 31) / 32;
   if (K * J > 1) {   // channel slices: independent launches into windows of the wide slabs
+    if (rtp_multi_capture()) return RTP_ERR_UNSUPPORTED;
     if (wd || qpart || tg) return RTP_ERR_UNSUPPORTED;
     if (gy->cs % 32 || gy->co % 8) return 1;
     RtpConvGeom gs = *g;
@@ -565,7 +593,11 @@ int rtp_wgrad_tiled_try(const RtpAct* gy, const RtpAct* x, const RtpConvGeom* g,
   p.N = g->n; p.D = g->di; p.H = g->hi; p.W = g->wi; p.g_cs = gy->cs; p.g_co = gy->co;
   p.tiles_y = p.H / TY; p.tiles_x = (p.W + TX - 1) / TX; p.tiles_z = p.D / TZ;
   p.tiles_per_sample = (p.D / TZ) * p.tiles_y * p.tiles_x;
-  p.wgs_per_sample = nsplit;
+  p.wgs_per_sample = nsplit; p.part_stride = nsplit;
+  if (const int hint = rtp_tiled_width_for(gp)) {   // fewer workgroups than slabs (the upper slabs stay zero): CUs left to other lanes
+    const int hw = hint / g->n;
+    if (hw >= 1 && hw < nsplit) p.wgs_per_sample = hw;
+  }
   static const int dbg = getenv("RTP_TILED_DBG") ? atoi(getenv("RTP_TILED_DBG")) : 0;
   p.dbg = dbg;
   p.wd = (const bf16_t*)wd; p.qpart = wd ? qpart : nullptr; p.tg = tg;
@@ -582,13 +614,58 @@ int rtp_wgrad_tiled_try(const RtpAct* gy, const RtpAct* x, const RtpConvGeom* g,
   }
   const size_t shm_base = sizeof(bf16_t) * 2 * (size_t)(HALO_VOX + BRICK_VOX) * 32 + 32;
   const size_t shm = shm_base + (tg ? 4 * 27 * 32 * sizeof(float) + 16 : 0);
+  if (std::vector<RtpMultiJob>* cap = rtp_multi_capture()) {   // recorded for a shared launch (rtp_multi.h), not issued
+    RtpMultiJob job;
+    job.kind = RTP_MULTI_WGRAD_TILED;
+    job.variant = tg ? 1 : 0;   // (the subset-sum tables change the LDS size)
+    job.tiles_per_sample = p.tiles_per_sample; job.n = p.N; job.slots_per_sample = nsplit; job.shm = shm;
+    job.fam = RTP_FAM_WGRAD_TILED;
+    p.claim = nullptr; p.ranges = 1; p.unit = 1;
+    job.params.assign((const char*)&p, (const char*)&p + sizeof(p));
+    cap->push_back(job);
+    return RTP_OK;
+  }
   RtpProfScope prof(RTP_FAM_WGRAD_TILED, s);
   static bool attr[RTP_MAX_DEVICES] = {};
   if (rtp_once_per_device(attr)) {
     (void)hipFuncSetAttribute((const void*)wgrad_tiled_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)(shm_base + 4 * 27 * 32 * sizeof(float) + 16));
   }
-  hipLaunchKernelGGL(wgrad_tiled_kernel, dim3(p.N * nsplit), dim3(WG_THREADS), shm, s, p);
+  hipLaunchKernelGGL(wgrad_tiled_kernel, dim3(p.N * p.wgs_per_sample), dim3(WG_THREADS), shm, s, p);
+  RTP_CHECK_LAUNCH();
+  return RTP_OK;
+}
+
+// ---- shared launches (rtp_multi.h)
+namespace {
+struct WgMultiLauncher { WgMulti m; size_t shm; };
+}
+
+int rtp_wgrad_tiled_multi_finish(std::vector<RtpMultiJob>& jobs, const int* share, void* dev_params, void** launcher) {
+  if (hipFuncSetAttribute((const void*)wgrad_tiled_multi_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)jobs[0].shm) != hipSuccess)
+    return RTP_ERR_LAUNCH;
+  std::vector<WgTiledParams> host(jobs.size());
+  WgMultiLauncher* L = new WgMultiLauncher();
+  L->shm = jobs[0].shm;
+  L->m.jobs = (const WgTiledParams*)dev_params; L->m.njobs = (int)jobs.size();
+  int at = 0;
+  for (size_t j = 0; j < jobs.size(); ++j) {
+    if (jobs[j].params.size() != sizeof(WgTiledParams)) { delete L; return RTP_ERR_SHAPE; }
+    memcpy(&host[j], jobs[j].params.data(), sizeof(WgTiledParams));
+    host[j].wgs_per_sample = share[j];   // (part_stride keeps the slots the slab / partial buffers were sized for)
+    host[j].total_wgs = 8 * share[j];
+    L->m.split[j] = at;
+    at += share[j];
+  }
+  for (size_t j = jobs.size(); j <= RTP_MULTI_MAX; ++j) L->m.split[j] = at;
+  if (hipMemcpy(dev_params, host.data(), host.size() * sizeof(WgTiledParams), hipMemcpyHostToDevice) != hipSuccess) { delete L; return RTP_ERR_LAUNCH; }
+  *launcher = L;
+  return RTP_OK;
+}
+
+int rtp_wgrad_tiled_multi_launch(void* launcher, hipStream_t s) {
+  WgMultiLauncher* L = (WgMultiLauncher*)launcher;
+  hipLaunchKernelGGL(wgrad_tiled_multi_kernel, dim3(256), dim3(WG_THREADS), L->shm, s, L->m);
   RTP_CHECK_LAUNCH();
   return RTP_OK;
 }

@@ -77,6 +77,19 @@ class FlatParams:
         return [tuple(r) for r in out]
 
 
+# Main-lane launches that give up a quarter of the CUs (192 workgroups instead of 256) while the side lanes' dependent chains are
+# the critical path.  Measured (hr3d, B = 8, round 4): every LDS-tiled launch asks for all 256 CUs with all their LDS, so the lanes'
+# kernels serialise as whole kernels and a side lane's chain of 8-20 small dependent launches advances ONE launch per main-kernel
+# boundary -- the main lane then waits 150-440 us in front of each fuse row / fan-in for chains whose kernels add up to a fraction of
+# that.  The tiled kernels are power- and bandwidth-limited rather than CU-limited (a full-resolution conv on 128 workgroups takes
+# 91 us against 78 on 256), so leaving 64 CUs free costs them 5 % and lets the chains run BESIDE them: 5.77-5.88 -> 5.62-5.66 ms per
+# step (-2.5 ... -3.5 %, five same-box pairs).  Forward convs and weight gradients of the full-resolution branch in stages 2-4, the
+# conv3 data gradients of stages 3-4; data gradients elsewhere, 208 / 176 / 160 workgroups, the head and layer1: no better or worse.
+# Results do not change (include/rtp.h: rtp_tiled_width_hint).  RTP_WIDTH_HINTS="" switches them off, any other value replaces them.
+DEFAULT_WIDTH_HINTS = ";".join(["conv:s%d.b0=192" % s for s in (2, 3, 4)] + ["wgrad:s%d.b0=192" % s for s in (2, 3, 4)]
+                               + ["dgrad:s4.b0.c3=192", "dgrad:s3.b0.c3=192"])
+
+
 class PoseEngine:
     """HRRadarPose for a fixed (batch, Cin, dims): buffers + launch lists built once, replayed every step."""
 
@@ -103,6 +116,18 @@ class PoseEngine:
         if os.environ.get("RTP_FWD_ROW0_FIRST", "0") == "1":   # A/B: the main lane's fuse-row feeders ahead of the other rows' chains
             from .lanes import main_row_first
             self.fwd = main_row_first(self.fwd)
+        # Horizontal fusion (lanes.merge_launches, RTP_MERGE=1): the level-1 branch's convs of a stage join the full-resolution convs
+        # of the same position in ONE launch -- alone they occupy every CU for a ninth of the work.  Measured (hr3d, B = 8): the merged
+        # launches cost 83-89 us against 72 + 27 separately and the serial kernel total drops, but in LANE mode the step gets 0.7-1 %
+        # SLOWER (5.77 -> 5.81-5.83 ms): the main lane is the critical path, and work moved onto it from a side lane lengthens it by
+        # more than the side lane's (largely hidden) launches cost.  Off by default; the one-stream replay is where it pays.
+        self.merged = []
+        self._merge = os.environ.get("RTP_MERGE", "0") == "1" and hasattr(be, "multi") and batch == 8
+        if self._merge:
+            from .lanes import merge_launches
+            pairs = [("conv:s%d.b0.%s" % (st, c), "conv:s%d.b1.%s" % (st, c)) for st in (2, 3, 4) for c in ("c2", "c3")]
+            self.fwd, done = merge_launches(self.fwd, be, pairs)
+            self._account_merged(done, "conv_tiled_full", None)
         self.fwd_plan = LanePlan(be, self.fwd, LANE_MAP)
         self.bwd_plan = None
         self.use_lanes = True      # False: replay everything on the caller's stream in list order
@@ -152,8 +177,44 @@ class PoseEngine:
                 # the level-2 lane's chain had arrived (-1 % on the step; RTP_BWD_F10_FIRST=0: creation order)
                 from .lanes import hoist_tagged
                 self.bwd = hoist_tagged(self.bwd, r":s3\.f10\.0$", r":s3\.(row2|f2)")
+            if self._merge:
+                from .lanes import merge_launches
+                kinds = ("wgrad", "dgrad") if not os.environ.get("RTP_NO_MERGE_WGRAD") else ("dgrad",)
+                pairs = [("%s:s%d.b0.%s" % (k, st, c), "%s:s%d.b1.%s" % (k, st, c)) for st in (4, 3, 2) for c in ("c3", "c2") for k in kinds]
+                self.bwd, done = merge_launches(self.bwd, be, pairs)
+                self._account_merged([d for d in done if d[0].startswith("dgrad:")], "conv_tiled_full", "conv_tiled_full_bwd")
             self.bwd_plan = LanePlan(be, self.bwd, LANE_MAP)
         self.live_params = set(g.used_params)
+        self.width_hints = self._apply_width_hints(os.environ.get("RTP_WIDTH_HINTS", DEFAULT_WIDTH_HINTS if batch == 8 else ""))
+
+    def _apply_width_hints(self, spec):
+        """spec: "tag-prefix=workgroups;..." (e.g. "conv:s3.b0=192;wgrad:s4.b0=208"): the LDS-tiled launches whose tag starts with a
+        prefix run on that many workgroups instead of one per CU (include/rtp.h: rtp_tiled_width_hint), leaving CUs to the other
+        lanes' dependent chains while they run.  Keyed by the launch's output buffer; results do not change."""
+        lib = getattr(self.be, "lib", None)
+        if not spec or lib is None or not hasattr(lib, "rtp_tiled_width_hint"):
+            return []
+        import ctypes as C
+        rules = [(k.strip(), int(v)) for k, v in (item.split("=") for item in spec.split(";") if "=" in item)]
+        done = []
+        for L in list(self.fwd) + list(self.bwd):
+            for pre, wgs in rules:
+                if L.tag.startswith(pre) and L.writes:
+                    lib.rtp_tiled_width_hint(C.c_void_p(L.writes[0]), wgs)
+                    done.append((L.tag, wgs))
+                    break
+        return done
+
+    def _account_merged(self, done, *families):
+        """The merged-in launches' algorithmic FLOPs / bytes join the family their shared launch is timed under (bench.py roofline)."""
+        g = self.graph
+        for ta, tb in done:
+            self.merged.append((ta, tb))
+            fl, nb = g.cost.get(tb, (0, 0))
+            for fam in families:
+                if fam:
+                    g.flops[fam] += fl
+                    g.alg_bytes[fam] += nb
 
     # ------------------------------------------------------------------ data in (plumbing copies)
     def load_input(self, rdr_tensor):

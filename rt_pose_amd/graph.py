@@ -168,6 +168,7 @@ class Graph:
         self.flops = {"conv_fwd": 0, "conv_dgrad": 0, "wgrad": 0, "conv_tiled": 0, "conv_generic": 0,
                       "wgrad_tiled": 0, "wgrad_generic": 0, "conv_tiled_full": 0, "conv_tiled_full_bwd": 0}
         # algorithmic HBM bytes (fused minimum, SURVEY 8d: every operand tensor of a launch read or written once) per family
+        self.cost = {}   # launch tag -> (algorithmic FLOPs, bytes) of the tiled conv / data-gradient launches (engine: shared launches)
         self.alg_bytes = {"conv_tiled": 0, "conv_generic": 0, "wgrad_tiled": 0, "wgrad_generic": 0, "conv_tiled_full": 0,
                           "conv_tiled_full_bwd": 0}
 
@@ -695,6 +696,7 @@ class ConvOp:
             2 * g.n * self.y.vox * self.y.c if self.residual is not None else 0)
         g.alg_bytes["conv_tiled" if self.tiled_fwd else "conv_generic"] += self.bytes_fwd
         # the tiled kernel at its dominant geometry (csrc/conv_tiled.hip: 32 output channels, >= 2^20 voxels per launch)
+        g.cost["conv:" + self.name] = (self.alg_flops, self.bytes_fwd)
         self.full_fwd = self.tiled_fwd and ge.co == 32 and g.n * self.y.vox >= (1 << 20)
         if self.full_fwd:
             g.flops["conv_tiled_full"] += self.alg_flops
@@ -914,6 +916,7 @@ class ConvOp:
         # read gy + x (+ the other contributions), write dx
         nb = 2 * g.n * (gy.vox * co32 + x.vox * ge.ci * (2 + len(terms)))
         g.alg_bytes["conv_tiled"] += nb
+        g.cost["dgrad:" + self.name] = (self.alg_flops, nb)
         if g.n * x.vox >= (1 << 20):
             g.flops["conv_tiled_full"] += self.alg_flops
             g.alg_bytes["conv_tiled_full"] += nb

@@ -217,6 +217,94 @@ def hoist_tagged(launches, pattern, before):
     return [launches[k] for k in out]
 
 
+def merge_launches(launches, backend, pairs):
+    """Horizontal fusion (include/rtp.h: rtp_multi_*): independent launches of one LDS-tiled kernel variant become ONE launch.
+
+    pairs: (tag_a, tag_b) candidates, tried in order.  Launch b (a side lane's: the level-1 branch of an HRNet stage) joins launch a
+    (the main lane's full-resolution launch of the same position) on a's lane; the merged launch reads and writes what both did.
+    A pair is accepted if (1) neither launch depends on the other -- directly or through other launches, merged ones included --
+    and (2) the backend can build the shared launch (same kernel variant, eight samples, tiled geometry: HipBackend.multi).
+    The list is then re-sorted topologically over the read-after-write / write-after-read / write-after-write relations of the
+    ORIGINAL order (earliest original position first among the ready launches), so every dependency of the original list holds in
+    the new one by construction.  -> (new list, [(tag_a, tag_b), ...] merged)."""
+    if not hasattr(backend, "multi") or not pairs:
+        return launches, []
+    dbg = (lambda *a: print("[merge]", *a)) if os.environ.get("RTP_MERGE_DEBUG") else (lambda *a: None)
+    n = len(launches)
+    preds = _order_preds(launches)
+    by_tag = {}
+    for i, L in enumerate(launches):
+        by_tag.setdefault(L.tag, []).append(i)
+    node_of = list(range(n))            # launch index -> its node (the smaller index of a merged pair)
+    fns, merged = {}, []
+
+    def topo():
+        """Stable topological order of the nodes, or None if merging made a cycle."""
+        members = {}
+        for i in range(n):
+            members.setdefault(node_of[i], []).append(i)
+        indeg = {v: 0 for v in members}
+        succ = {v: set() for v in members}
+        for i in range(n):
+            for j in preds[i]:
+                a, b = node_of[j], node_of[i]
+                if a != b and b not in succ[a]:
+                    succ[a].add(b)
+                    indeg[b] += 1
+                elif a == b and i != j:
+                    return None         # the two launches of a pair depend on each other
+        import heapq
+        ready = [v for v in members if indeg[v] == 0]
+        heapq.heapify(ready)
+        order = []
+        while ready:
+            v = heapq.heappop(ready)
+            order.append(v)
+            for w in succ[v]:
+                indeg[w] -= 1
+                if indeg[w] == 0:
+                    heapq.heappush(ready, w)
+        return (order, members) if len(order) == len(members) else None
+
+    for ta, tb in pairs:
+        if len(by_tag.get(ta, ())) != 1 or len(by_tag.get(tb, ())) != 1:
+            dbg("tags not found once:", ta, tb)
+            continue
+        ia, ib = by_tag[ta][0], by_tag[tb][0]
+        if node_of[ia] != ia or node_of[ib] != ib:
+            continue
+        keep = node_of[ib]
+        node_of[ib] = ia
+        if topo() is None:
+            dbg("dependent launches (directly or through others):", ta, tb)
+            node_of[ib] = keep
+            continue
+        f = backend.multi([launches[ia].fn, launches[ib].fn])
+        if f is None:
+            dbg("the backend cannot share a launch for", ta, tb)
+            node_of[ib] = keep
+            continue
+        fns[ia] = f
+        merged.append((ta, tb))
+    if not merged:
+        return launches, []
+    order, members = topo()
+    new = []
+    for v in order:
+        if len(members[v]) == 1:
+            new.append(launches[v])
+            continue
+        a, b = launches[members[v][0]], launches[members[v][1]]
+        if members[v][0] != v:
+            a, b = b, a
+        m = Launch.__new__(Launch)
+        m.fn, m.lane, m.tag = fns[v], a.lane, a.tag + "+" + b.tag.split(":", 1)[-1]
+        m.reads = tuple(dict.fromkeys(a.reads + b.reads))
+        m.writes = tuple(dict.fromkeys(a.writes + b.writes))
+        new.append(m)
+    return new, merged
+
+
 class LanePlan:
     """A launch list bound to a backend, replayable on one stream or on one stream per lane."""
 

@@ -5,6 +5,8 @@ path produce (stride 2, 1x1x1, depth-1 volumes, channel-padded heads, channel-sl
 Tolerances: bf16 outputs -- norm-wise 4e-3 (one bf16 ulp is 2^-8 relative; fp32 accumulation order differs);
 fp32 outputs -- norm-wise 2e-4.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -12,6 +14,17 @@ import torch
 from rt_pose_amd.graph import Geom, View, pad_to
 from tests.emu_backend import EmuBackend
 from tests.util import rel_err
+
+# RTP_CLAIM=1 (tests/test_gpu_claim.py runs this file that way): bricks are claimed from counters, so WHICH workgroup's partial (slab,
+# Q / subset-sum table) a brick lands in changes from launch to launch -- the partials' SUMS, all the plan consumes, do not
+CLAIMED = os.environ.get("RTP_CLAIM", "0") not in ("", "0")
+
+
+def same_partials(a, b, dim=1):
+    """Bit-equal per-workgroup partials under the static deal; equal sums over the partial axis under dynamic claiming."""
+    if not CLAIMED:
+        return torch.equal(a, b)
+    return rel_err(a.sum(dim).float().cpu(), b.sum(dim).float().cpu()) < 1e-5
 
 pytestmark = pytest.mark.gpu
 
@@ -784,7 +797,7 @@ def test_fused_backward_chain(hip, case):
         slab2 = hip.alloc((n, S, 27, co32, ci), "f32")
         hip.wgrad(gyg, xg, geom, S, slab2)(hip.stream())
         torch.cuda.synchronize()
-        assert torch.equal(slab2, slab.g)
+        assert same_partials(slab2, slab.g)
         # coefficients
         cs_split = 3
         clsp = Pair(hip, torch.zeros(n, cs_split, 64, co32))
@@ -870,8 +883,8 @@ def test_fused_backward_chain(hip, case):
             tg.fill_(float("nan"))   # every workgroup must write its whole table
             hip.wgrad_q(gyg, xg, geom, S, slab3, wd.g, qp3, tg)(hip.stream())
             torch.cuda.synchronize()
-            assert torch.equal(slab3, slab.g) and torch.equal(qp3, qp.g), "the subset sums do not disturb the slabs"
-            assert prev is None or torch.equal(prev, tg), "subset sums are reproducible bit for bit"
+            assert same_partials(slab3, slab.g) and same_partials(qp3, qp.g), "the subset sums do not disturb the slabs"
+            assert prev is None or same_partials(prev, tg), "subset sums are reproducible bit for bit"
             prev = tg.clone()
         EMU.wgrad_q(gyc, xc, geom, Sc, torch.zeros_like(slab_e), wd.c, torch.zeros_like(qp_e), tg_e)(None)
         assert rel_err(tg.sum(1).cpu(), tg_e.sum(1)) < 1e-5, "inclusive subset sums of gy"
@@ -1104,6 +1117,69 @@ def test_bias_gradient_from_weight_gradient_subset_sums(hip):
     hip.class_sums(gg, 3, hip.alloc((n, 3, 64, 32), "f32"), cs)(s)
     hip.tail([("wgrad_fold", gp2, S, cs, None, None, None, 1, geom, 32, co_real, dw2, db2, 0, None)])(s)
     torch.cuda.synchronize()
-    assert torch.equal(gp1, gp2) and torch.equal(dw1, dw2)
+    assert same_partials(gp1, gp2) and (torch.equal(dw1, dw2) if not CLAIMED else rel_err(dw1.cpu(), dw2.cpu()) < 1e-5)
     want = gt.float().reshape(-1, 32)[:, :co_real].sum(0)
     assert rel_err(db1.cpu(), want) < F32 * 5 and rel_err(db2.cpu(), want) < F32 * 5
+
+
+# ------------------------------------------------------------------------------------------------ shared launches (rtp_multi_*)
+def test_two_convs_and_two_weight_gradients_in_one_launch(hip):
+    """HipBackend.multi: a 'full-resolution' and a 'level-1' problem (eight samples each, the same kernel variant) as ONE launch --
+    conv + GroupNorm-fold prologue + residual + ReLU + statistics epilogue, and the weight-gradient kernel.  Every problem must
+    produce exactly what it produces alone (outputs bit for bit; the per-workgroup partials as sums: a problem runs on fewer
+    workgroups per sample inside the shared launch), the untouched partial slots must stay zero, and launches that cannot share a
+    kernel must be refused (None) without side effects."""
+    n, ci, co = 8, 32, 32
+    probs = []
+    for k, dims in enumerate(((8, 64, 128), (4, 32, 64))):   # 256 and 32 bricks per sample: 28 + 4 workgroups per XCD
+        d, h, w = dims
+        geom = Geom(n, d, h, w, d, h, w, ci, co, 3, 1, 1)
+        xp, xc, xg = views(hip, rnd((n, d, h, w, ci), 100 + k, relu=True), n, d, h, w)
+        rp, rc, rg = views(hip, rnd((n, d, h, w, co), 110 + k), n, d, h, w)
+        W = Pair(hip, rnd((co, ci, 3, 3, 3), 120 + k, torch.float32, scale=0.05))
+        gamma, beta = Pair(hip, rnd((ci,), 130 + k, torch.float32) * 0.2 + 1.0), Pair(hip, rnd((ci,), 140 + k, torch.float32) * 0.2)
+        xv = xp.c.float().reshape(n, -1, ci)
+        st = Pair(hip, torch.stack([xv.sum(1), (xv * xv).sum(1)], -1)[:, None].contiguous())       # one statistics partial per sample
+        wt = Pair(hip, torch.zeros(27, co, ci))
+        hip.tail([("pack_wt", W.g, co, co, ci, 27, wt.g)])(hip.stream())
+        S = hip.conv_stats_nsplit(xg, geom, False)
+        assert S > 0
+        ys, sos, mrs = [], [], []
+        for rep in range(2):   # [0]: alone, [1]: inside the shared launch
+            ys.append(views(hip, torch.zeros(n, d, h, w, co, dtype=torch.bfloat16), n, d, h, w))
+            sos.append(hip.alloc((n, S, co, 2), "f32"))
+            mrs.append(hip.alloc((n, 8, 2), "f32"))
+        def mk(r, xg=xg, wt=wt, gamma=gamma, beta=beta, st=st, mrs=mrs, rg=rg, ys=ys, geom=geom, sos=sos):   # (bound now, not at call time)
+            return hip.conv_gn_fused(xg, wt.g, None, gamma.g, beta.g, st.g, 1, 8, 1e-5, co, mrs[r], rg, ys[r][2], geom, True, sos[r])
+        # weight gradient of the same geometry (gy = the residual tensor, any bf16 tensor will do)
+        Sw = hip.wgrad_nsplit(geom)
+        slabs = [hip.alloc((n, Sw, 27, co, ci), "f32") for _ in range(2)]
+        def mkw(r, rg=rg, xg=xg, geom=geom, Sw=Sw, slabs=slabs):
+            return hip.wgrad(rg, xg, geom, Sw, slabs[r])
+        probs.append(dict(mk=mk, mkw=mkw, ys=ys, sos=sos, mrs=mrs, slabs=slabs, S=S, Sw=Sw))
+    s = hip.stream()
+    for pr in probs:
+        pr["mk"](0)(s)
+        pr["mkw"](0)(s)
+    both = hip.multi([pr["mk"](1) for pr in probs])
+    bothw = hip.multi([pr["mkw"](1) for pr in probs])
+    assert both is not None and bothw is not None, "two eight-sample launches of one variant must be mergeable"
+    for _ in range(2):      # replays
+        both(s)
+        bothw(s)
+    torch.cuda.synchronize()
+    for k, pr in enumerate(probs):
+        assert torch.equal(pr["ys"][0][0].g, pr["ys"][1][0].g), "conv output of problem %d" % k
+        assert torch.equal(pr["mrs"][0], pr["mrs"][1])
+        assert rel_err(pr["sos"][1].sum(1).cpu(), pr["sos"][0].sum(1).cpu()) < 1e-5, "statistics of problem %d" % k
+        assert rel_err(pr["slabs"][1].sum(1).cpu(), pr["slabs"][0].sum(1).cpu()) < 1e-5, "weight gradient of problem %d" % k
+    # the level-1 problem ran on fewer workgroups than its buffers have slots: the upper slots were never touched
+    small = probs[1]
+    used = int((small["sos"][1].abs().sum((0, 2, 3)) > 0).sum())
+    assert 0 < used < small["S"] and float(small["sos"][1][:, used:].abs().max()) == 0.0, (used, small["S"], small["sos"][1].abs().sum((0, 2, 3)).tolist())
+    assert int((small["slabs"][1].abs().sum((0, 2, 3, 4)) > 0).sum()) < small["Sw"]
+    # different variants (with / without the residual) cannot share a kernel: refused, and nothing was launched or left open
+    odd = hip.multi([probs[0]["mk"](1), probs[0]["mkw"](1)])
+    assert odd is None
+    again = hip.multi([pr["mk"](1) for pr in probs])
+    assert again is not None

@@ -97,3 +97,77 @@ def test_hr3d_plan_hazards_are_covered():
     assert 0 < nf < len(eng.fwd) and 0 < nb < len(eng.bwd)     # far fewer events than launches
     # every launch declares what it writes (a launch with no write set could never be ordered)
     assert all(L.writes for L in eng.fwd + eng.bwd)
+
+
+def test_merge_launches_keeps_every_dependency():
+    """lanes.merge_launches (horizontal fusion of independent launches): a side-lane launch joins its main-lane twin, the list is
+    re-sorted so that every dependency of the original order still holds (the transition conv that feeds the side launch moves in
+    front of the merged launch), launches that depend on each other are never merged, and a backend that refuses leaves the list alone."""
+    from rt_pose_amd.lanes import Launch, merge_launches, _order_preds
+
+    class T:
+        def __init__(self, i):
+            self.i = i
+
+        def data_ptr(self):
+            return self.i
+
+        def numel(self):
+            return 1
+
+        def element_size(self):
+            return 1
+
+    class BE:
+        def __init__(self, refuse=()):
+            self.refuse, self.asked = set(refuse), []
+
+        def multi(self, fns):
+            names = tuple(f.__name__ for f in fns)
+            self.asked.append(names)
+            if names in self.refuse:
+                return None
+            return lambda s: [f(s) for f in fns]
+
+    t = [T(i) for i in range(10)]
+    ran = []
+
+    def mk(name):
+        def f(s):
+            ran.append(name)
+        f.__name__ = name
+        return f
+
+    def build():
+        return [Launch(mk("a1"), 0, [t[0]], [t[1]], "conv:a1"), Launch(mk("a2"), 0, [t[1]], [t[2]], "conv:a2"),
+                Launch(mk("t"), 1, [t[0]], [t[3]], "conv:t"), Launch(mk("b1"), 1, [t[3]], [t[4]], "conv:b1"),
+                Launch(mk("b2"), 1, [t[4]], [t[5]], "conv:b2"), Launch(mk("f"), 0, [t[2], t[5]], [t[6]], "fuse")]
+
+    L = build()
+    new, merged = merge_launches(L, BE(), [("conv:a1", "conv:b1"), ("conv:a2", "conv:b2"), ("conv:a1", "conv:a2"), ("conv:x", "conv:b1")])
+    assert merged == [("conv:a1", "conv:b1"), ("conv:a2", "conv:b2")]
+    assert [x.tag for x in new] == ["conv:t", "conv:a1+b1", "conv:a2+b2", "fuse"]
+    assert all(x.lane == 0 for x in new[1:3]) and set(new[1].reads) == {0, 3} and set(new[1].writes) == {1, 4}
+    for x in new:
+        x.fn(None)
+    assert ran == ["t", "a1", "b1", "a2", "b2", "f"]
+    # dependent launches (a2 reads what a1 writes) are refused even when the backend would take them
+    be = BE()
+    new2, merged2 = merge_launches(build(), be, [("conv:a1", "conv:a2")])
+    assert merged2 == [] and [x.tag for x in new2] == [x.tag for x in build()] and be.asked == []
+    # ... and so is a pair that would close a cycle THROUGH other launches: t feeds b1, a2 depends on a1 -> (t, a2)? independent: fine;
+    # (a1, b2) with (a2, b1) already merged would need a1 < a2 = b1 < b2 = a1
+    new3, merged3 = merge_launches(build(), BE(), [("conv:a2", "conv:b1"), ("conv:a1", "conv:b2")])
+    assert merged3 == [("conv:a2", "conv:b1")]
+    preds = _order_preds(build())
+    where = {}
+    for k, x in enumerate(new3):
+        for name in x.tag.replace("conv:", "").split("+"):
+            where[name] = k
+    names = ["a1", "a2", "t", "b1", "b2", "fuse"]
+    for i, ps in enumerate(preds):
+        for j in ps:
+            assert where[names[j]] <= where[names[i]]
+    # a backend that cannot build the shared launch: nothing changes
+    new4, merged4 = merge_launches(build(), BE(refuse={("a1", "b1")}), [("conv:a1", "conv:b1")])
+    assert merged4 == [] and [x.tag for x in new4] == [x.tag for x in build()]
