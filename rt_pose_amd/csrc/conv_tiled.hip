@@ -98,6 +98,9 @@ struct TiledParams {
   int* claim; int ranges, total_wgs, nbig, ubig, usmall;
   // freerun: the two teams synchronise only WITHIN themselves (LDS-counter barriers over their four waves) and drift freely
   // against each other, instead of swapping roles at workgroup barriers; prio: wave priority of a team's MFMA phase.
+  // Free-running is the default (RTP_TILED_FREERUN=0: lock-step): it takes 25 % of the kernel's cycles away, of which the chip's
+  // power management hands back a third (2.01 -> 1.80 GHz under the denser MFMA stream); beside the width hints of the default
+  // plan the hr3d step gains 1.3 % (5.72 -> 5.65 ms, two same-box pairs), alone 0 ... 1.7 %.
   int freerun, prio;
   // Per-workgroup partial outputs (statistics, totals) go to slot n * part_stride + wg: part_stride = workgroups per sample of a
   // plain launch; a launch that shares the grid with other problems (conv_tiled_multi_kernel) runs on fewer workgroups per sample
@@ -1163,7 +1166,7 @@ int rtp_conv_tiled_try(const RtpAct* x, const void* wf, int w_per_sample, const 
     const int len = p.tiles_per_sample / p.ranges, teams = 2 * wgs / p.ranges;
     p.nbig = (int)((long)len * bigpct / 100 / p.ubig) / teams * teams;
   }
-  static const int freerun = getenv("RTP_TILED_FREERUN") ? atoi(getenv("RTP_TILED_FREERUN")) : 0;
+  static const int freerun = getenv("RTP_TILED_FREERUN") ? atoi(getenv("RTP_TILED_FREERUN")) : 1;
   static const int prio = getenv("RTP_TILED_PRIO") ? atoi(getenv("RTP_TILED_PRIO")) : 0;
   p.freerun = freerun; p.prio = prio;
   p.nextra = 0; p.mask = 0; p.tot_out = nullptr;

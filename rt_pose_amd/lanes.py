@@ -348,17 +348,17 @@ class LanePlan:
         for l in side:
             streams[l].wait_event(self._start)
         waits, record, lane_of = self.waits, self.record, self.lane_of
-        trace = getattr(self, "trace", None)   # tools/main_lane_trace.py: (start, end) timing events around every launch of lane 0
+        trace = getattr(self, "trace", None)   # tools/main_lane_trace.py, tools/lane_timeline.py: {launch index: (start, end) timing events}
         for i, L in enumerate(self.launches):
             lane = lane_of[i]
             st = streams[lane]
             for j in waits[i]:
                 st.wait_event(ev[j])
-            if trace is not None and lane == 0:
+            if trace is not None and i in trace:
                 trace[i][0].record(st)
             if skip is None or not skip[i]:
                 L.fn(ptrs[lane])
-            if trace is not None and lane == 0:
+            if trace is not None and i in trace:
                 trace[i][1].record(st)
             if record[i]:
                 ev[i].record(st)
