@@ -1120,6 +1120,12 @@ def test_bias_gradient_from_weight_gradient_subset_sums(hip):
     assert same_partials(gp1, gp2) and (torch.equal(dw1, dw2) if not CLAIMED else rel_err(dw1.cpu(), dw2.cpu()) < 1e-5)
     want = gt.float().reshape(-1, 32)[:, :co_real].sum(0)
     assert rel_err(db1.cpu(), want) < F32 * 5 and rel_err(db2.cpu(), want) < F32 * 5
+    # ... and the folded weight gradient is the slabs' sum, which is the emulation's
+    tot = gp1.sum((0, 1))[:, :co_real, :].permute(1, 2, 0).reshape(co_real, 32, 3, 3, 3)
+    assert rel_err(dw1.cpu(), tot.cpu()) < 1e-5
+    gpe = torch.zeros(n, 2, 27, 32, 32)
+    EMU.wgrad(gc, xc, geom, 2, gpe)(None)
+    assert rel_err(dw1.cpu(), gpe.sum((0, 1))[:, :co_real, :].permute(1, 2, 0).reshape(co_real, 32, 3, 3, 3)) < F32 * 5
 
 
 # ------------------------------------------------------------------------------------------------ shared launches (rtp_multi_*)

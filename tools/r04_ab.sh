@@ -5,7 +5,7 @@ tag=$1; shift
 i=0
 for envs in "$@"; do
   out=gpurun_out/${tag}_$i.json
-  env $envs timeout 600 python3 bench.py --steps 30 --warmup 8 --no-cpu-baseline --no-torch-gpu --no-lidar --no-dcn --no-forward --no-other-models > $out 2> gpurun_out/${tag}_$i.err
+  env $envs timeout 150 python3 bench.py --steps 30 --warmup 8 --no-cpu-baseline --no-torch-gpu --no-lidar --no-dcn --no-forward --no-other-models > $out 2> gpurun_out/${tag}_$i.err
   python3 - "$envs" $out <<'PY'
 import json, sys
 try:

@@ -12,6 +12,7 @@ done
 timeout 900 tools/pmc_tiled.sh > gpurun_out/${tag}_pmc_tiled.txt 2>&1; tail -5 gpurun_out/${tag}_pmc_tiled.txt
 timeout 900 tools/pmc_step.sh > gpurun_out/${tag}_pmc_step_traffic.txt 2>&1; tail -3 gpurun_out/${tag}_pmc_step_traffic.txt
 timeout 600 python3 tools/main_lane_trace.py hr3d > gpurun_out/${tag}_main_lane_trace.txt 2>&1
+timeout 600 python3 tools/lane_timeline.py hr3d > gpurun_out/${tag}_lane_timeline.txt 2>&1
 timeout 600 python3 tools/plan_times.py --convs --order --top 30 > gpurun_out/${tag}_plan_times.txt 2>&1
 RTP_LIB=rt_pose_amd/lib/librtp_hip_prof.so timeout 300 python3 tools/tiled_prof.py > gpurun_out/${tag}_tiled_prof.txt 2>&1
 RTP_LIB=rt_pose_amd/lib/librtp_hip_wgtprof.so timeout 300 python3 tools/wgt_prof.py > gpurun_out/${tag}_wgt_prof.txt 2>&1
