@@ -360,7 +360,7 @@ extern "C" int rtp_grad_combine_cls_lazy(const RtpTerm* terms, int nterms, const
 // ------------------------------------------------------------------------------------------------
 // rtp_fuse_sum : trilinear align_corners=True, PyTorch index rule (upsample_trilinear3d)
 // ------------------------------------------------------------------------------------------------
-struct FuseTerm { const bf16_t* t; int cs, co, d, h, w; float sz, sy, sx; int same; };  // s*: align_corners scale (I-1)/(O-1), computed in fp32 like ATen
+struct FuseTerm { const bf16_t* t; int cs, co, d, h, w; float sz, sy, sx; int same; int span; };  // span: source voxels an FX-output run touches (rows kernel)  // s*: align_corners scale (I-1)/(O-1), computed in fp32 like ATen
 struct FuseParams {
   FuseTerm terms[RTP_MAX_TERMS]; int nterms;
   const float* bias; bf16_t* out; int o_cs, o_co;
@@ -463,6 +463,54 @@ __global__ __launch_bounds__(256) void fuse_sum_kernel(FuseParams p) {
 // (the point-per-thread kernel above is bound by L1/TA traffic: 26 gathers per output for a 4-branch fuse row).
 #define FX 4
 #define FSPAN 5
+// One up-sampled term of a run of FX outputs (fuse_sum_rows_kernel): the 2x2 (z, y) corner rows blended into SPAN source columns,
+// the FX outputs interpolated from them.  The kernel is VALU-bound on these terms (~100 vector instructions per source column).
+template <int SPAN>
+__device__ __forceinline__ void fuse_up_term(const FuseParams& p, const FuseTerm& t, int n, int z, int y, int xs, int ck, float (&acc)[FX][8]) {
+  int z0, z1, y0, y1, xb, xdummy;
+  float lz0, lz1, ly0, ly1, ldum0, ldum1;
+  src_index(z, t.d, p.d, t.sz, z0, z1, lz0, lz1);
+  src_index(y, t.h, p.h, t.sy, y0, y1, ly0, ly1);
+  src_index(xs, t.w, p.w, t.sx, xb, xdummy, ldum0, ldum1);
+  const long base = (long)n * t.d * t.h * t.w;
+  float row[SPAN][8];
+#pragma unroll
+  for (int q = 0; q < SPAN; ++q)
+#pragma unroll
+    for (int c = 0; c < 8; ++c) row[q][c] = 0.f;
+  int qo[SPAN];  // clamped source offsets: columns past the row end carry zero weight below, so any valid address does
+#pragma unroll
+  for (int q = 0; q < SPAN; ++q) qo[q] = ((xb + q < t.w) ? q : t.w - 1 - xb) * t.cs;
+#pragma unroll
+  for (int cz = 0; cz < 2; ++cz)
+#pragma unroll
+    for (int cy = 0; cy < 2; ++cy) {
+      const float wgt = (cz ? lz1 : lz0) * (cy ? ly1 : ly0);
+      const bf16_t* src = t.t + (base + ((long)(cz ? z1 : z0) * t.h + (cy ? y1 : y0)) * t.w + xb) * t.cs + t.co + ck * 8;
+      bf16x8 tv[SPAN];
+#pragma unroll
+      for (int q = 0; q < SPAN; ++q) tv[q] = ld_bf16x8(src + qo[q]);
+#pragma unroll
+      for (int q = 0; q < SPAN; ++q)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) row[q][c] += wgt * bf2f(tv[q][c]);
+    }
+#pragma unroll
+  for (int j = 0; j < FX; ++j) {
+    int x0, x1;
+    float lx0, lx1;
+    src_index(xs + j, t.w, p.w, t.sx, x0, x1, lx0, lx1);
+    x0 -= xb;
+    x1 -= xb;
+#pragma unroll
+    for (int q = 0; q < SPAN; ++q) {
+      const float wq = (q == x0 ? lx0 : 0.f) + (q == x1 ? lx1 : 0.f);
+#pragma unroll
+      for (int c = 0; c < 8; ++c) acc[j][c] += wq * row[q][c];
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void fuse_sum_rows_kernel(FuseParams p) {
   const int cpv = p.c >> 3, runs = p.w / FX;
   const bool per_sample = p.stat_out != nullptr;   // grid (stat_blocks, n): a block stays inside one sample
@@ -513,47 +561,13 @@ __global__ __launch_bounds__(256) void fuse_sum_rows_kernel(FuseParams p) {
           for (int c = 0; c < 8; ++c) acc[j][c] += bf2f(tv[c]);
         }
       } else {
-        int z0, z1, y0, y1, xb, xdummy;
-        float lz0, lz1, ly0, ly1, ldum0, ldum1;
-        src_index(z, t.d, p.d, t.sz, z0, z1, lz0, lz1);
-        src_index(y, t.h, p.h, t.sy, y0, y1, ly0, ly1);
-        src_index(xs, t.w, p.w, t.sx, xb, xdummy, ldum0, ldum1);
-        const long base = (long)n * t.d * t.h * t.w;
-        float row[FSPAN][8];
-#pragma unroll
-        for (int q = 0; q < FSPAN; ++q)
-#pragma unroll
-          for (int c = 0; c < 8; ++c) row[q][c] = 0.f;
-        int qo[FSPAN];  // clamped source offsets: columns past the row end carry zero weight below, so any valid address does
-#pragma unroll
-        for (int q = 0; q < FSPAN; ++q) qo[q] = ((xb + q < t.w) ? q : t.w - 1 - xb) * t.cs;
-#pragma unroll
-        for (int cz = 0; cz < 2; ++cz)
-#pragma unroll
-          for (int cy = 0; cy < 2; ++cy) {
-            const float wgt = (cz ? lz1 : lz0) * (cy ? ly1 : ly0);
-            const bf16_t* src = t.t + (base + ((long)(cz ? z1 : z0) * t.h + (cy ? y1 : y0)) * t.w + xb) * t.cs + t.co + ck * 8;
-            bf16x8 tv[FSPAN];
-#pragma unroll
-            for (int q = 0; q < FSPAN; ++q) tv[q] = ld_bf16x8(src + qo[q]);
-#pragma unroll
-            for (int q = 0; q < FSPAN; ++q)
-#pragma unroll
-              for (int c = 0; c < 8; ++c) row[q][c] += wgt * bf2f(tv[q][c]);
-          }
-#pragma unroll
-        for (int j = 0; j < FX; ++j) {
-          int x0, x1;
-          float lx0, lx1;
-          src_index(xs + j, t.w, p.w, t.sx, x0, x1, lx0, lx1);
-          x0 -= xb;
-          x1 -= xb;
-#pragma unroll
-          for (int q = 0; q < FSPAN; ++q) {
-            const float wq = (q == x0 ? lx0 : 0.f) + (q == x1 ? lx1 : 0.f);
-#pragma unroll
-            for (int c = 0; c < 8; ++c) acc[j][c] += wq * row[q][c];
-          }
+        // the first t.span source columns of a run can carry weight (launch-uniform per term: 4 / 3 / 2 for the x2 / x4 / x8 branches,
+        // computed by the host with this kernel's own index rule): one straight-line body per span
+        switch (t.span) {
+          case 2: fuse_up_term<2>(p, t, n, z, y, xs, ck, acc); break;
+          case 3: fuse_up_term<3>(p, t, n, z, y, xs, ck, acc); break;
+          case 4: fuse_up_term<4>(p, t, n, z, y, xs, ck, acc); break;
+          default: fuse_up_term<FSPAN>(p, t, n, z, y, xs, ck, acc); break;
         }
       }
     }
@@ -585,11 +599,13 @@ __global__ __launch_bounds__(256) void fuse_sum_rows_kernel(FuseParams p) {
 }
 
 // can every up-sampled term's FX-output run be served from FSPAN source voxels?
-static bool fuse_rows_ok(const FuseParams& p) {
+static bool fuse_rows_ok(FuseParams& p) {   // (also fills every up-sampled term's span)
   if (p.w % FX) return false;
   for (int k = 0; k < p.nterms; ++k) {
-    const FuseTerm& t = p.terms[k];
+    FuseTerm& t = p.terms[k];
+    t.span = FSPAN;
     if (t.same) continue;
+    int span = 2;
     if (t.w == p.w || p.w < 2) return false;  // same width but another depth/height: not a shape of this path
     const float scale = t.sx;
     for (int xs = 0; xs < p.w; xs += FX) {    // exact check with the kernel's own index rule
@@ -597,7 +613,9 @@ static bool fuse_rows_ok(const FuseParams& p) {
       int hi = (int)(scale * (float)(xs + FX - 1));
       hi += (hi < t.w - 1) ? 1 : 0;
       if (hi - lo >= FSPAN) return false;
+      if (hi - lo + 1 > span) span = hi - lo + 1;
     }
+    t.span = span;
   }
   return true;
 }
@@ -634,7 +652,7 @@ extern "C" int rtp_fuse_sum_stats(const RtpTerm* terms, int nterms, const float*
     if (terms[k].t.c != p.c || (terms[k].t.cs % 8) || (terms[k].t.co % 8)) return RTP_ERR_ALIGN;
     p.terms[k] = FuseTerm{(const bf16_t*)terms[k].t.ptr, terms[k].t.cs, terms[k].t.co, terms[k].d, terms[k].h, terms[k].w,
                           ac_scale(terms[k].d, d), ac_scale(terms[k].h, h), ac_scale(terms[k].w, w),
-                          terms[k].d == d && terms[k].h == h && terms[k].w == w};
+                          terms[k].d == d && terms[k].h == h && terms[k].w == w, FSPAN};
   }
   p.bias = bias; p.out = (bf16_t*)out->ptr; p.o_cs = out->cs; p.o_co = out->co;
   p.n = n; p.d = d; p.h = h; p.w = w; p.relu = relu;
