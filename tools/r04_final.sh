@@ -4,10 +4,10 @@
 export TMPDIR=/tmp
 tag=r04
 timeout 900 tools/gpu_prof.sh ${tag}f
-for k in single lanes; do
+for k in single lanes; do   # (32 = 2 warm-up + 3 segments x 10 steps)
   db=$(find gpurun_out/prof_${tag}f_$k -name '*results.db' | head -1)
-  python3 tools/prof_db.py stats $db 12 "Round 4 (final build) -- per-kernel device time of the default train step, $k" > gpurun_out/${tag}_step_kernel_stats_$k.md 2>&1
-  python3 tools/prof_db.py tiled $db 12 >> gpurun_out/${tag}_step_kernel_stats_$k.md 2>&1
+  python3 tools/prof_db.py stats $db 32 "Round 4 (final build) -- per-kernel device time of the default train step, $k" > gpurun_out/${tag}_step_kernel_stats_$k.md 2>&1
+  python3 tools/prof_db.py tiled $db 32 >> gpurun_out/${tag}_step_kernel_stats_$k.md 2>&1
 done
 timeout 900 tools/pmc_tiled.sh > gpurun_out/${tag}_pmc_tiled.txt 2>&1; tail -5 gpurun_out/${tag}_pmc_tiled.txt
 timeout 900 tools/pmc_step.sh > gpurun_out/${tag}_pmc_step_traffic.txt 2>&1; tail -3 gpurun_out/${tag}_pmc_step_traffic.txt
