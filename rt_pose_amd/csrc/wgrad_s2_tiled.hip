@@ -12,6 +12,7 @@
 // rtp_wgrad_fold like every other slab -- no atomics, fixed summation order.
 #include <stdlib.h>
 
+#include "rtp_claim.h"
 #include "rtp_common.h"
 #include "rtp_prof.h"
 
@@ -37,6 +38,7 @@ struct WgS2Params {
   float* gp; int slab_rows, slab_cols;
   int N, D, H, W, Do, Ho, Wo;
   int tiles_y, tiles_x, bricks_per_sample, wgs_per_sample;
+  int part_stride;   // slab slots per sample (>= wgs_per_sample: a width-hinted launch runs on fewer workgroups and leaves the upper slots zero)
 };
 
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4_w2;
@@ -191,7 +193,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(512, 512), amdgpu_waves_pe
   }
   // ---- one fp32 slab window per workgroup; D[row = co][col = ci]: lane holds rows 4q..4q+3, column lane & 15
   const int q = lane >> 4, ii = lane & 15;
-  float* out = p.gp + ((long)n * p.wgs_per_sample + wg) * 27 * p.slab_rows * p.slab_cols;
+  float* out = p.gp + ((long)n * p.part_stride + wg) * 27 * p.slab_rows * p.slab_cols;
 #pragma unroll
   for (int t = 0; t < 7; ++t) {
     const int tap = tw + 4 * t;
@@ -257,14 +259,18 @@ int rtp_wgrad_s2_try(const RtpAct* gy, const RtpAct* x, const RtpConvGeom* g, in
   p.N = g->n; p.D = g->di; p.H = g->hi; p.W = g->wi; p.Do = g->dov; p.Ho = g->ho; p.Wo = g->wo;
   p.tiles_y = p.Ho / W2_OY; p.tiles_x = (p.Wo + W2_OX - 1) / W2_OX;
   p.bricks_per_sample = p.Do * p.tiles_y * p.tiles_x;
-  p.wgs_per_sample = nsplit;
+  p.wgs_per_sample = nsplit; p.part_stride = nsplit;
+  if (const int hint = rtp_tiled_width_for(gp)) {   // (rtp_claim.h: per-launch width hints; CUs left to the other lanes)
+    const int hw = hint / g->n;
+    if (hw >= 1 && hw < nsplit) p.wgs_per_sample = hw;
+  }
   const size_t shm = sizeof(bf16_t) * (size_t)W2_RING * W2_SLOT;
   RtpProfScope prof(RTP_FAM_WGRAD_TILED, s);
   static bool attr[RTP_MAX_DEVICES] = {};
   if (rtp_once_per_device(attr)) {
     (void)hipFuncSetAttribute((const void*)wgrad_s2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
   }
-  hipLaunchKernelGGL(wgrad_s2_kernel, dim3(p.N * nsplit), dim3(512), shm, s, p);
+  hipLaunchKernelGGL(wgrad_s2_kernel, dim3(p.N * p.wgs_per_sample), dim3(512), shm, s, p);
   RTP_CHECK_LAUNCH();
   return RTP_OK;
 }
