@@ -113,7 +113,10 @@ class PoseEngine:
             lidar = (g.pack("lidar", self.lidar_in, lidar_channels, dims), lidar_channels)
         self.outs = net.build_head(g, self.feats, list(self.heads), lidar=lidar)
         self.fwd = list(g.forward_list())
-        if os.environ.get("RTP_FWD_ROW0_FIRST", "0") == "1":   # A/B: the main lane's fuse-row feeders ahead of the other rows' chains
+        # the main lane's fuse-row feeders (the 1x1x1 convs of row 0) ahead of the other rows' chains on their FIFO lanes: neutral on hr3d
+        # (5.608 -> 5.595 ms, the wait moves from fuse:s3.row0 to fuse:s4.row0), -0.6 % on the configs whose stage 4 keeps every row
+        # (hr3d_one_hm_doppler 10.43 -> 10.36); RTP_FWD_ROW0_FIRST=0: creation order
+        if os.environ.get("RTP_FWD_ROW0_FIRST", "1") == "1":
             from .lanes import main_row_first
             self.fwd = main_row_first(self.fwd)
         # Horizontal fusion (lanes.merge_launches, RTP_MERGE=1): the level-1 branch's convs of a stage join the full-resolution convs
