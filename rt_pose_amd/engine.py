@@ -195,17 +195,20 @@ class PoseEngine:
         prefix run on that many workgroups instead of one per CU (include/rtp.h: rtp_tiled_width_hint), leaving CUs to the other
         lanes' dependent chains while they run.  Keyed by the launch's output buffer; results do not change."""
         lib = getattr(self.be, "lib", None)
-        if not spec or lib is None or not hasattr(lib, "rtp_tiled_width_hint"):
+        if lib is None or not hasattr(lib, "rtp_tiled_width_hint"):
             return []
         import ctypes as C
-        rules = [(k.strip(), int(v)) for k, v in (item.split("=") for item in spec.split(";") if "=" in item)]
+        rules = [(k.strip(), int(v)) for k, v in (item.split("=") for item in (spec or "").split(";") if "=" in item)]
         done = []
         for L in list(self.fwd) + list(self.bwd):
-            for pre, wgs in rules:
-                if L.tag.startswith(pre) and L.writes:
-                    lib.rtp_tiled_width_hint(C.c_void_p(L.writes[0]), wgs)
-                    done.append((L.tag, wgs))
-                    break
+            if not L.writes:
+                continue
+            # the table is keyed by address and outlives the plans that filled it: every output of THIS plan is set or cleared, so a
+            # hint left behind by an earlier engine whose buffer lived at the same address never reaches a launch of this one
+            wgs = next((w for pre, w in rules if L.tag.startswith(pre)), 0)
+            lib.rtp_tiled_width_hint(C.c_void_p(L.writes[0]), wgs)
+            if wgs:
+                done.append((L.tag, wgs))
         return done
 
     def _account_merged(self, done, *families):

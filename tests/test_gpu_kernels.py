@@ -1189,3 +1189,60 @@ def test_two_convs_and_two_weight_gradients_in_one_launch(hip):
     assert odd is None
     again = hip.multi([pr["mk"](1) for pr in probs])
     assert again is not None
+
+
+# ------------------------------------------------------------------------------------------------ per-launch width hints
+def test_width_hints_change_no_result(hip):
+    """rtp_tiled_width_hint (include/rtp.h): a hinted LDS-tiled launch runs on fewer workgroups -- conv output bit for bit, the
+    per-workgroup partials (statistics, weight-gradient slabs: stride 1 and stride 2) as sums, the partial slots of the workgroups
+    that did not run stay zero, and removing the hint restores the full-width launch exactly."""
+    import ctypes as C
+    n, ci, co = 8, 32, 32
+    d, h, w = 8, 64, 128      # 256 bricks per sample: full-width launches (32 workgroups per sample)
+    geom = Geom(n, d, h, w, d, h, w, ci, co, 3, 1, 1)
+    xp, xc, xg = views(hip, rnd((n, d, h, w, ci), 700, relu=True), n, d, h, w)
+    rp, rc, rg = views(hip, rnd((n, d, h, w, co), 701), n, d, h, w)
+    Wt = Pair(hip, rnd((co, ci, 3, 3, 3), 702, torch.float32, scale=0.05))
+    gamma, beta = Pair(hip, rnd((ci,), 703, torch.float32) * 0.2 + 1.0), Pair(hip, rnd((ci,), 704, torch.float32) * 0.2)
+    xv = xp.c.float().reshape(n, -1, ci)
+    st = Pair(hip, torch.stack([xv.sum(1), (xv * xv).sum(1)], -1)[:, None].contiguous())
+    wt = Pair(hip, torch.zeros(27, co, ci))
+    hip.tail([("pack_wt", Wt.g, co, co, ci, 27, wt.g)])(hip.stream())
+    S, Sw = hip.conv_stats_nsplit(xg, geom, False), hip.wgrad_nsplit(geom)
+    assert S >= 16 and Sw >= 16
+    # stride 2: [n, 16, 64, 128] -> [n, 8, 32, 64]
+    g2 = Geom(n, d * 2, h, w, d, h // 2, w // 2, ci, co, 3, 2, 1)
+    x2p, x2c, x2g = views(hip, rnd((n, d * 2, h, w, ci), 705, relu=True), n, d * 2, h, w)
+    gy2p, gy2c, gy2g = views(hip, rnd((n, d, h // 2, w // 2, co), 706), n, d, h // 2, w // 2)
+    S2 = hip.wgrad_nsplit(g2)
+    assert S2 >= 16
+    s = hip.stream()
+    hint = hip.lib.rtp_tiled_width_hint
+
+    def once(total_wgs):
+        y = views(hip, torch.zeros(n, d, h, w, co, dtype=torch.bfloat16), n, d, h, w)
+        so, mr = hip.alloc((n, S, co, 2), "f32"), hip.alloc((n, 8, 2), "f32")
+        slab, slab2 = hip.alloc((n, Sw, 27, co, ci), "f32"), hip.alloc((n, S2, 27, co, ci), "f32")
+        keys = (y[2].buf.data_ptr(), slab.data_ptr(), slab2.data_ptr())
+        for k in keys:
+            assert hint(C.c_void_p(k), total_wgs) == 0
+        hip.conv_gn_fused(xg, wt.g, None, gamma.g, beta.g, st.g, 1, 8, 1e-5, co, mr, rg, y[2], geom, True, so)(s)
+        hip.wgrad(rg, xg, geom, Sw, slab)(s)
+        hip.wgrad(gy2g, x2g, g2, S2, slab2)(s)
+        torch.cuda.synchronize()
+        for k in keys:
+            hint(C.c_void_p(k), 0)
+        return y[0].g.clone(), so, mr, slab, slab2
+
+    full = once(0)
+    for total in (192, 64):
+        got = once(total)
+        per = total // n
+        assert torch.equal(got[0], full[0]) and torch.equal(got[2], full[2]), "conv output / group statistics under a %d-workgroup hint" % total
+        for k, slots in ((1, S), (3, Sw), (4, S2)):
+            a, b = got[k].flatten(2), full[k].flatten(2)
+            assert rel_err(a.sum(1).cpu(), b.sum(1).cpu()) < 1e-5, (total, k)
+            used = int((a.abs().sum((0, 2)) > 0).sum())
+            assert used <= min(per, slots) and float(a[:, min(per, slots):].abs().max() if per < slots else 0.0) == 0.0, (total, k, used)
+    again = once(0)
+    assert all(torch.equal(u, v) for u, v in zip(again, full)), "hint removed: the full-width launch, bit for bit"

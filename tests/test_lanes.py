@@ -171,3 +171,48 @@ def test_merge_launches_keeps_every_dependency():
     # a backend that cannot build the shared launch: nothing changes
     new4, merged4 = merge_launches(build(), BE(refuse={("a1", "b1")}), [("conv:a1", "conv:b1")])
     assert merged4 == [] and [x.tag for x in new4] == [x.tag for x in build()]
+
+
+def test_width_hint_rules_reach_the_right_launches():
+    """PoseEngine._apply_width_hints: first matching tag prefix wins, every other output of the plan is CLEARED (the C-side table is
+    keyed by address and outlives plans), launches without outputs are left alone."""
+    from rt_pose_amd.engine import PoseEngine, DEFAULT_WIDTH_HINTS
+
+    class Lib:
+        def __init__(self):
+            self.calls = []
+
+        def rtp_tiled_width_hint(self, key, wgs):
+            self.calls.append((key.value, wgs))
+            return 0
+
+    class Be:
+        lib = Lib()
+
+    class L:
+        def __init__(self, tag, writes):
+            self.tag, self.writes = tag, writes
+
+    eng = PoseEngine.__new__(PoseEngine)
+    eng.be = Be()
+    eng.fwd = [L("conv:s3.b0.c2", (11,)), L("conv:s3.b1.c2", (12,)), L("fuse:s3.row0", (13,)), L("stats", ())]
+    eng.bwd = [L("wgrad:s3.b0.c2", (21, 22)), L("dgrad:s3.b0.c3", (23,)), L("dgrad:s3.b0.c2", (24,))]
+    done = eng._apply_width_hints("conv:s3.b0=192;wgrad:s3.b0=176;dgrad:s3.b0.c3=208;conv:s3=64")
+    assert done == [("conv:s3.b0.c2", 192), ("conv:s3.b1.c2", 64), ("wgrad:s3.b0.c2", 176), ("dgrad:s3.b0.c3", 208)]
+    assert Be.lib.calls == [(11, 192), (12, 64), (13, 0), (21, 176), (23, 208), (24, 0)]
+    Be.lib.calls.clear()
+    assert eng._apply_width_hints("") == [] and [w for _, w in Be.lib.calls] == [0] * 6     # switched off: everything cleared
+    # the shipped default names launches that exist in the hr3d plan
+    pre = [r.split("=")[0] for r in DEFAULT_WIDTH_HINTS.split(";")]
+    from tests.emu_backend import EmuBackend
+    from rt_pose_amd import configs
+    from rt_pose_amd.engine import FlatParams
+    from rt_pose_amd.trainer import init_state_dict
+    be = EmuBackend()
+    s = configs.spec("hr3d")
+    shapes = configs.param_shapes("hr3d")
+    flat = FlatParams(shapes, be.alloc)
+    flat.load_state_dict(init_state_dict(shapes, 0))
+    real = PoseEngine(be, flat.values, s["arch"], s["final_fuse"], s["heads"], s["weight"], s["code_weights"], 1, (8, 16, 32), train=True, pgrads=flat.grads)
+    tags = [x.tag for x in real.fwd + real.bwd]
+    assert all(any(t.startswith(p) for t in tags) for p in pre), [p for p in pre if not any(t.startswith(p) for t in tags)]
