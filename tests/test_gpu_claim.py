@@ -48,6 +48,16 @@ def test_kernel_parity_suite_with_claimed_bricks():
     assert " passed" in r.stdout
 
 
+@pytest.mark.timeout(1800)
+def test_kernel_parity_suite_with_lock_step_teams():
+    """conv_tiled's two teams free-run by default (csrc/conv_tiled.hip: TiledParams::freerun); RTP_TILED_FREERUN=0 is the lock-step
+    schedule of rounds 2-3, kept as a switch -- and kept correct: the conv part of the kernel suite under it."""
+    r = _run([sys.executable, "-m", "pytest", "tests/test_gpu_kernels.py", "-x", "-q", "-k", "conv or fused or dgrad or one_launch or width"],
+             {"RTP_TILED_FREERUN": "0"})
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+    assert " passed" in r.stdout
+
+
 @pytest.mark.timeout(900)
 def test_train_step_claimed_equals_static(tmp_path):
     import torch
