@@ -1056,7 +1056,7 @@ __global__ __launch_bounds__(512, 2) void conv_tiled_kernel(TiledParams p) {
 // the host exactly as for a plain launch, teams_per_sample = 2 x its share), split[j] = first workgroup of problem j within an XCD.
 #define RTP_MULTI_MAX 4
 struct TiledMulti { const TiledParams* jobs; int njobs; int split[RTP_MULTI_MAX + 1]; };
-template <int NT, bool HAS_BTAB, int AUX, bool STAT, int FUSEX = 0>
+template <int NT, bool HAS_BTAB, int AUX, bool STAT, int FUSEX = 0, bool GEN = false>
 __global__ __launch_bounds__(512, 2) void conv_tiled_multi_kernel(TiledMulti m) {
   const int xcd = (int)(blockIdx.x % 8), l = (int)(blockIdx.x / 8);   // grid = 8 x workgroups per XCD; sample = XCD
   int j = 0;
@@ -1064,7 +1064,7 @@ __global__ __launch_bounds__(512, 2) void conv_tiled_multi_kernel(TiledMulti m) 
   for (int k = 1; k < RTP_MULTI_MAX; ++k) j += (k < m.njobs && l >= m.split[k]) ? 1 : 0;
   j = __builtin_amdgcn_readfirstlane(j);
   const TiledParams p = m.jobs[j];   // (uniform address: scalar loads)
-  conv_tiled_body<NT, HAS_BTAB, AUX, STAT, FUSEX, false>(p, xcd, l - m.split[j]);
+  conv_tiled_body<NT, HAS_BTAB, AUX, STAT, FUSEX, GEN>(p, xcd, l - m.split[j]);
 }
 
 static bool tiled_geometry_ok(const RtpAct* x, const RtpConvGeom* g, int transposed, int* Co_out) {
@@ -1208,12 +1208,16 @@ int rtp_conv_tiled_try(const RtpAct* x, const void* wf, int w_per_sample, const 
   const size_t shm = sizeof(bf16_t) * (27 * (size_t)Co * 32 + 2 * (size_t)HALO_VOX * 32) + 27 * (size_t)Co * sizeof(float) + 64;
   if (std::vector<RtpMultiJob>* cap = rtp_multi_capture()) {   // recorded for a shared launch (rtp_multi.h), not issued
     const int aux_c = stat_x ? 2 : (res ? 1 : 0);
-    if (nt != 2 || acc32 || y_fp32 || slice) return RTP_ERR_UNSUPPORTED;
+    // (besides the 32-channel variants: the head towers' last convs -- <= 16 output channels, class-bias table, fp32 output)
+    const bool head_last = nt == 1 && !acc32 && y_fp32 && !slice && !fuse && (btab || fold) && aux_c == 0 && !stat_out;
+    if (!head_last && (nt != 2 || acc32 || y_fp32 || slice)) return RTP_ERR_UNSUPPORTED;
     RtpMultiJob job;
     job.kind = RTP_MULTI_CONV_TILED;
-    job.variant = fuse ? (100 + p.nextra) : (((btab || fold) ? 1 : 0) * 8 + aux_c * 2 + (stat_out ? 1 : 0));
+    job.variant = head_last ? 200 : fuse ? (100 + p.nextra) : (((btab || fold) ? 1 : 0) * 8 + aux_c * 2 + (stat_out ? 1 : 0));
     job.tiles_per_sample = p.tiles_per_sample; job.n = p.N; job.slots_per_sample = p.part_stride; job.shm = shm;
-    job.fam = transposed ? RTP_FAM_CONV_TILED_FULL_BWD : RTP_FAM_CONV_TILED_FULL;
+    // (the family the problem is timed under when launched alone, below)
+    job.fam = (Co == 32 && (long)p.N * p.D * p.H * p.W >= (1L << 20)) ? (transposed ? RTP_FAM_CONV_TILED_FULL_BWD : RTP_FAM_CONV_TILED_FULL)
+                                                                        : RTP_FAM_CONV_TILED;
     p.claim = nullptr; p.ranges = 1;   // the static deal inside a shared launch
     job.params.assign((const char*)&p, (const char*)&p + sizeof(p));
     cap->push_back(job);
@@ -1332,6 +1336,7 @@ MKern conv_multi_kernel_for(int variant) {
     case 101: return conv_tiled_multi_kernel<2, false, 2, false, 2>;
     case 102: return conv_tiled_multi_kernel<2, false, 2, false, 3>;
     case 103: return conv_tiled_multi_kernel<2, false, 2, false, 4>;
+    case 200: return conv_tiled_multi_kernel<1, true, 0, false, 0, true>;
     default: return nullptr;
   }
 }

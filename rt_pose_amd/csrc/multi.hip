@@ -4,6 +4,8 @@
 #include <mutex>
 
 #include "rtp_common.h"
+#include <stdio.h>
+#include <stdlib.h>
 #include "rtp_multi.h"
 #include "rtp_prof.h"
 
@@ -35,6 +37,9 @@ extern "C" int rtp_multi_end(int* handle_out) {
   const int nj = (int)jobs.size();
   if (nj < 2 || nj > 4) return RTP_ERR_UNSUPPORTED;
   long total = 0;
+  if (getenv("RTP_MERGE_DEBUG"))
+    for (const RtpMultiJob& j : jobs)
+      fprintf(stderr, "[multi] job kind %d variant %d n %d shm %zu tiles %d slots %d\n", j.kind, j.variant, j.n, (size_t)j.shm, j.tiles_per_sample, j.slots_per_sample);
   for (const RtpMultiJob& j : jobs) {
     if (j.kind != jobs[0].kind || j.variant != jobs[0].variant || j.n != 8 || j.shm != jobs[0].shm || j.tiles_per_sample < 1) return RTP_ERR_UNSUPPORTED;
     total += j.tiles_per_sample;

@@ -131,6 +131,18 @@ class PoseEngine:
             pairs = [("conv:s%d.b0.%s" % (st, c), "conv:s%d.b1.%s" % (st, c)) for st in (2, 3, 4) for c in ("c2", "c3")]
             self.fwd, done = merge_launches(self.fwd, be, pairs)
             self._account_merged(done, "conv_tiled_full", None)
+        # The two head towers (hm, reg) are independent chains of full-resolution launches on the main lane: they run pairwise in ONE
+        # launch, each problem on half of every XCD's workgroups (lanes.merge_launches -> HipBackend.multi -> rtp_multi_*).  Alone a
+        # full-resolution tiled kernel is limited by fixed costs, power and HBM rather than by CUs (91 us on 128 workgroups against 78
+        # on 256), so two of them side by side finish well before two in a row: hr3d 5.56 -> 5.48 ms per step (-1.4 %, two same-box
+        # pairs) with five pairs merged -- conv .0 / .2, dgrad .2, wgrad .0 / .2; dgrad:head.reg.0 adds dgrad:head.hm.0's result in
+        # its epilogue and stays behind it.  (Unlike RTP_MERGE above this moves nothing ONTO the main lane.)  RTP_MERGE_HEAD=0: off.
+        self._merge_head = os.environ.get("RTP_MERGE_HEAD", "1") == "1" and hasattr(be, "multi") and batch == 8
+        self.merged_head = []
+        if self._merge_head:
+            from .lanes import merge_launches
+            self.fwd, done = merge_launches(self.fwd, be, [("conv:head.reg.0", "conv:head.hm.0"), ("conv:head.reg.2", "conv:head.hm.2")])
+            self.merged_head = list(done)   # (both launches of a pair belong to the same kernel family: nothing to re-account)
         self.fwd_plan = LanePlan(be, self.fwd, LANE_MAP)
         self.bwd_plan = None
         self.use_lanes = True      # False: replay everything on the caller's stream in list order
@@ -186,6 +198,14 @@ class PoseEngine:
                 pairs = [("%s:s%d.b0.%s" % (k, st, c), "%s:s%d.b1.%s" % (k, st, c)) for st in (4, 3, 2) for c in ("c3", "c2") for k in kinds]
                 self.bwd, done = merge_launches(self.bwd, be, pairs)
                 self._account_merged([d for d in done if d[0].startswith("dgrad:")], "conv_tiled_full", "conv_tiled_full_bwd")
+            if self._merge_head:
+                from .lanes import merge_launches
+                self.bwd, done = merge_launches(self.bwd, be, [("dgrad:head.hm.2", "dgrad:head.reg.2"), ("dgrad:head.hm.0", "dgrad:head.reg.0"),
+                                                               ("wgrad:head.hm.2", "wgrad:head.reg.2"), ("wgrad:head.hm.0", "wgrad:head.reg.0")]
+                                                if os.environ.get("RTP_MERGE_HEAD_WG4", "0") != "1" else
+                                                [("dgrad:head.hm.2", "dgrad:head.reg.2"),
+                                                 ("wgrad:head.hm.2", "wgrad:head.reg.2", "wgrad:head.hm.0", "wgrad:head.reg.0")])
+                self.merged_head += list(done)
             self.bwd_plan = LanePlan(be, self.bwd, LANE_MAP)
         self.live_params = set(g.used_params)
         self.width_hints = self._apply_width_hints(os.environ.get("RTP_WIDTH_HINTS", DEFAULT_WIDTH_HINTS if batch == 8 else ""))

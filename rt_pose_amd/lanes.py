@@ -220,8 +220,9 @@ def hoist_tagged(launches, pattern, before):
 def merge_launches(launches, backend, pairs):
     """Horizontal fusion (include/rtp.h: rtp_multi_*): independent launches of one LDS-tiled kernel variant become ONE launch.
 
-    pairs: (tag_a, tag_b) candidates, tried in order.  Launch b (a side lane's: the level-1 branch of an HRNet stage) joins launch a
-    (the main lane's full-resolution launch of the same position) on a's lane; the merged launch reads and writes what both did.
+    pairs: (tag_a, tag_b[, tag_c[, tag_d]]) candidates, tried in order.  Launches b, c, d (e.g. a side lane's: the level-1 branch of an
+    HRNet stage) join launch a (the main lane's full-resolution launch of the same position) on a's lane; the merged launch reads and
+    writes what all of them did.
     A pair is accepted if (1) neither launch depends on the other -- directly or through other launches, merged ones included --
     and (2) the backend can build the shared launch (same kernel variant, eight samples, tiled geometry: HipBackend.multi).
     The list is then re-sorted topologically over the read-after-write / write-after-read / write-after-write relations of the
@@ -266,26 +267,30 @@ def merge_launches(launches, backend, pairs):
                     heapq.heappush(ready, w)
         return (order, members) if len(order) == len(members) else None
 
-    for ta, tb in pairs:
-        if len(by_tag.get(ta, ())) != 1 or len(by_tag.get(tb, ())) != 1:
-            dbg("tags not found once:", ta, tb)
+    for group in pairs:     # (tag_a, tag_b[, tag_c[, tag_d]]): everything joins the first launch
+        if any(len(by_tag.get(t, ())) != 1 for t in group):
+            dbg("tags not found once:", *group)
             continue
-        ia, ib = by_tag[ta][0], by_tag[tb][0]
-        if node_of[ia] != ia or node_of[ib] != ib:
+        idx = [by_tag[t][0] for t in group]
+        if any(node_of[i] != i for i in idx):
             continue
-        keep = node_of[ib]
-        node_of[ib] = ia
+        ia = idx[0]
+        keep = [node_of[i] for i in idx]
+        for i in idx[1:]:
+            node_of[i] = ia
         if topo() is None:
-            dbg("dependent launches (directly or through others):", ta, tb)
-            node_of[ib] = keep
+            dbg("dependent launches (directly or through others):", *group)
+            for i, k in zip(idx, keep):
+                node_of[i] = k
             continue
-        f = backend.multi([launches[ia].fn, launches[ib].fn])
+        f = backend.multi([launches[i].fn for i in idx])
         if f is None:
-            dbg("the backend cannot share a launch for", ta, tb)
-            node_of[ib] = keep
+            dbg("the backend cannot share a launch for", *group)
+            for i, k in zip(idx, keep):
+                node_of[i] = k
             continue
         fns[ia] = f
-        merged.append((ta, tb))
+        merged.append(tuple(group))
     if not merged:
         return launches, []
     order, members = topo()
@@ -294,13 +299,12 @@ def merge_launches(launches, backend, pairs):
         if len(members[v]) == 1:
             new.append(launches[v])
             continue
-        a, b = launches[members[v][0]], launches[members[v][1]]
-        if members[v][0] != v:
-            a, b = b, a
+        mem = [launches[v]] + [launches[i] for i in members[v] if i != v]
         m = Launch.__new__(Launch)
-        m.fn, m.lane, m.tag = fns[v], a.lane, a.tag + "+" + b.tag.split(":", 1)[-1]
-        m.reads = tuple(dict.fromkeys(a.reads + b.reads))
-        m.writes = tuple(dict.fromkeys(a.writes + b.writes))
+        m.fn, m.lane = fns[v], mem[0].lane
+        m.tag = mem[0].tag + "".join("+" + x.tag.split(":", 1)[-1] for x in mem[1:])
+        m.reads = tuple(dict.fromkeys(k for x in mem for k in x.reads))
+        m.writes = tuple(dict.fromkeys(k for x in mem for k in x.writes))
         new.append(m)
     return new, merged
 
