@@ -1246,3 +1246,30 @@ def test_width_hints_change_no_result(hip):
             assert used <= min(per, slots) and float(a[:, min(per, slots):].abs().max() if per < slots else 0.0) == 0.0, (total, k, used)
     again = once(0)
     assert all(torch.equal(u, v) for u, v in zip(again, full)), "hint removed: the full-width launch, bit for bit"
+
+
+def test_head_last_convs_in_one_launch(hip):
+    """The head towers' last convs (<= 16 output channels, class-bias table, fp32 output: conv_tiled variant 200) as ONE shared
+    launch -- what the default plan does with conv:head.reg.2 + conv:head.hm.2 -- against the same two convs launched alone."""
+    n, ci, d, h, w = 8, 32, 8, 64, 128
+    outs, mk = [], []
+    for k, co_real in enumerate((15, 3)):
+        co = pad_to(co_real, 16)
+        geom = Geom(n, d, h, w, d, h, w, ci, co, 3, 1, 1)
+        xp, xc, xg = views(hip, rnd((n, d, h, w, ci), 800 + k, relu=True), n, d, h, w)
+        wf = Pair(hip, rnd((1, 27, co, ci), 810 + k, scale=0.05))
+        bt = Pair(hip, rnd((1, 64, co), 820 + k, torch.float32))
+        ys = [views(hip, torch.zeros(n, d, h, w, co, dtype=torch.float32), n, d, h, w) for _ in range(2)]
+        outs.append(ys)
+        mk.append(lambda r, xg=xg, wf=wf, bt=bt, ys=ys, geom=geom: hip.conv(xg, wf.g, False, bt.g, None, ys[r][2], geom, False, False, True))
+    s = hip.stream()
+    for f in mk:
+        f(0)(s)
+    both = hip.multi([f(1) for f in mk])
+    assert both is not None, "the two last convs of the head towers must share a launch"
+    both(s)
+    both(s)
+    torch.cuda.synchronize()
+    for k, ys in enumerate(outs):
+        assert float(ys[0][0].g.abs().max()) > 0
+        assert torch.equal(ys[0][0].g, ys[1][0].g), "problem %d" % k
