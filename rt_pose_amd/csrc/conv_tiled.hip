@@ -1367,7 +1367,7 @@ int rtp_conv_tiled_multi_finish(std::vector<RtpMultiJob>& jobs, const int* share
 
 int rtp_conv_tiled_multi_launch(void* launcher, hipStream_t s) {
   ConvMultiLauncher* L = (ConvMultiLauncher*)launcher;
-  hipLaunchKernelGGL(L->kern, dim3(256), dim3(512), L->shm, s, L->m);
+  hipLaunchKernelGGL(L->kern, dim3(8 * L->m.split[L->m.njobs]), dim3(512), L->shm, s, L->m);
   RTP_CHECK_LAUNCH();
   return RTP_OK;
 }

@@ -45,7 +45,9 @@ extern "C" int rtp_multi_end(int* handle_out) {
     total += j.tiles_per_sample;
   }
   // shares of an XCD's 32 workgroups: proportional to the bricks, at least one each, largest remainders first
-  const int WG = 32;
+  // workgroups per XCD the shared launch is dealt over (experiments: RTP_MULTI_WGS_PER_XCD < 32 leaves CUs to the other lanes)
+  static const int wg_env = getenv("RTP_MULTI_WGS_PER_XCD") ? atoi(getenv("RTP_MULTI_WGS_PER_XCD")) : 32;
+  const int WG = wg_env < nj ? nj : (wg_env > 32 ? 32 : wg_env);
   int share[4] = {0, 0, 0, 0}, used = 0;
   double frac[4];
   for (int k = 0; k < nj; ++k) {

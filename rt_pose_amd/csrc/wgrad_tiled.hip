@@ -665,7 +665,7 @@ int rtp_wgrad_tiled_multi_finish(std::vector<RtpMultiJob>& jobs, const int* shar
 
 int rtp_wgrad_tiled_multi_launch(void* launcher, hipStream_t s) {
   WgMultiLauncher* L = (WgMultiLauncher*)launcher;
-  hipLaunchKernelGGL(wgrad_tiled_multi_kernel, dim3(256), dim3(WG_THREADS), L->shm, s, L->m);
+  hipLaunchKernelGGL(wgrad_tiled_multi_kernel, dim3(8 * L->m.split[L->m.njobs]), dim3(WG_THREADS), L->shm, s, L->m);
   RTP_CHECK_LAUNCH();
   return RTP_OK;
 }
