@@ -322,6 +322,12 @@ long rtp_upsample_bwd_scratch_floats(int n, int c, int d, int h, int w, int dl, 
 
 /* layer1.conv1 when Cin == 1 (common.py:111-113): y[v][c] = x[v]*w[c] + b[c]; x fp32 [n][vox]. */
 int rtp_stem_fwd(const float* x, const float* w, const float* b, const RtpAct* y, int n, long vox, void* stream);
+/* ... that also leaves the statistics the first GroupNorm (hr_util/common.py:57, applied to this output by layer1.conv2) needs:
+ * stat_out [n][nsplit][c][2] = per-block partial (sum y, sum y^2) of the STORED bf16 values, nsplit = rtp_stem_stats_nsplit(n, c, vox)
+ * (0: not offered for this channel count) -- what rtp_chan_stats computes in a read pass of its own. */
+int rtp_stem_stats_nsplit(int n, int c, long vox);
+int rtp_stem_fwd_stats(const float* x, const float* w, const float* b, const RtpAct* y, int n, long vox, float* stat_out, int nsplit,
+                       void* stream);
 /* dw[c] (+)= sum x*g, db[c] (+)= sum g ; scratch fp32 [nblk][c][2] with nblk = rtp_stem_bwd_blocks(). */
 int rtp_stem_bwd(const float* x, const RtpAct* gy, int n, long vox, float* scratch, float* dw, float* db,
                  int accumulate, void* stream);

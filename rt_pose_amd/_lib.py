@@ -104,6 +104,8 @@ PROTOTYPES = {
     "rtp_upsample_bwd": [_A, _I, _I, _I, _A, _I, _I, _I, _I, _P, _P],
     "rtp_upsample_bwd_scratch_floats": [_I] * 8,
     "rtp_stem_fwd": [_P, _P, _P, _A, _I, _L, _P],
+    "rtp_stem_stats_nsplit": [_I, _I, _L],
+    "rtp_stem_fwd_stats": [_P, _P, _P, _A, _I, _L, _P, _I, _P],
     "rtp_stem_bwd": [_P, _A, _I, _L, _P, _P, _P, _I, _P],
     "rtp_stem_bwd_blocks": [],
     "rtp_pack_ncdhw": [_P, _A, _I, _I, _L, _P],

@@ -388,6 +388,16 @@ class HipBackend:
         keep = (x, w, b, y)
         return lambda s: check(fn(*args, s), "rtp_stem_fwd") or keep and None
 
+    def stem_stats_nsplit(self, n, c, vox):
+        return self.lib.rtp_stem_stats_nsplit(n, c, vox)
+
+    def stem_fwd_stats(self, x, w, b, y, stats, nsplit):
+        """rtp_stem_fwd_stats: the stem with the statistics of its (stored) output as an epilogue, [n, nsplit, c, 2]."""
+        fn = self.lib.rtp_stem_fwd_stats
+        args = (_ptr(x), _ptr(w), _ptr(b), _act(y), y.n, y.vox, _ptr(stats), nsplit)
+        keep = (x, w, b, y, stats)
+        return lambda s: check(fn(*args, s), "rtp_stem_fwd_stats") or keep and None
+
     def stem_bwd(self, x, gy, scratch, dw, db, acc):
         fn = self.lib.rtp_stem_bwd
         args = (_ptr(x), _act(gy), gy.n, gy.vox, _ptr(scratch), _ptr(dw), _ptr(db), int(acc))

@@ -372,9 +372,9 @@ struct FuseParams {
 
 // statistics of a thread's items -> one partial per block.  Every item of a thread has the same 8-channel chunk (the index
 // stride is a multiple of 256 and c / 8 divides 256), threads tid = chunk (mod c / 8) own the same channels.
-__device__ __forceinline__ void fuse_stats_flush(const FuseParams& p, int n, const float (&sy)[8], const float (&sq)[8]) {
+__device__ __forceinline__ void stats_flush(float* stat_out, int stat_blocks, int c, int n, const float (&sy)[8], const float (&sq)[8]) {
   __shared__ float red[256][17];
-  const int tid = threadIdx.x, cpv = p.c >> 3;
+  const int tid = threadIdx.x, cpv = c >> 3;
 #pragma unroll
   for (int j = 0; j < 8; ++j) { red[tid][j] = sy[j]; red[tid][8 + j] = sq[j]; }
   __syncthreads();
@@ -382,8 +382,11 @@ __device__ __forceinline__ void fuse_stats_flush(const FuseParams& p, int n, con
     const int ck = t >> 4, j = t & 15;
     float a = 0.f;
     for (int m = ck; m < 256; m += cpv) a += red[m][j];   // fixed order
-    p.stat_out[(((long)n * p.stat_blocks + blockIdx.x) * p.c + ck * 8 + (j & 7)) * 2 + (j >> 3)] = a;
+    stat_out[(((long)n * stat_blocks + blockIdx.x) * c + ck * 8 + (j & 7)) * 2 + (j >> 3)] = a;
   }
+}
+__device__ __forceinline__ void fuse_stats_flush(const FuseParams& p, int n, const float (&sy)[8], const float (&sq)[8]) {
+  stats_flush(p.stat_out, p.stat_blocks, p.c, n, sy, sq);
 }
 
 __host__ __device__ __forceinline__ float ac_scale(int I, int O) { return (O > 1) ? (float)(I - 1) / (float)(O - 1) : 0.f; }
@@ -932,6 +935,52 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* x, const flo
     for (int j = 0; j < 8; ++j) o[j] = f2bf(xv * w[ck * 8 + j] + b[ck * 8 + j]);
     st_bf16x8(y + vv * y_cs + y_co + ck * 8, o);
   }
+}
+
+// ... with the per-channel statistics (sum y, sum y^2 of the STORED values) the first GroupNorm wants, one partial per block:
+// grid (nsplit, n), a block stays inside one sample -- the read pass of rtp_chan_stats over the 84-MB stem output is gone.
+__global__ __launch_bounds__(256) void stem_fwd_stats_kernel(const float* x, const float* w, const float* b, bf16_t* y, int y_cs, int y_co,
+                                                             int c, long vox, float* stat_out, int stat_blocks) {
+  const int cpv = c >> 3, n = blockIdx.y;
+  const long total = vox * cpv;
+  float sy[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, sq[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const int ck = (int)(threadIdx.x % cpv);      // the same chunk for every item of a thread (the stride is a multiple of 256, cpv | 256)
+  float wr[8], br[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { wr[j] = w[ck * 8 + j]; br[j] = b[ck * 8 + j]; }
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long vv = (long)n * vox + i / cpv;
+    const float xv = x[vv];
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      o[j] = f2bf(xv * wr[j] + br[j]);
+      const float r = bf2f(o[j]);
+      sy[j] += r; sq[j] += r * r;
+    }
+    st_bf16x8(y + vv * y_cs + y_co + ck * 8, o);
+  }
+  stats_flush(stat_out, stat_blocks, c, n, sy, sq);
+}
+
+extern "C" int rtp_stem_stats_nsplit(int n, int c, long vox) {
+  if (c < 8 || c % 8 || 256 % (c / 8) || n < 1) return 0;
+  long s = (vox * (c / 8) + 1023) / 1024;   // ~4 items per thread
+  const long want = (2048 + n - 1) / n;
+  if (s > want) s = want;
+  if (s > 128) s = 128;
+  return (int)(s < 1 ? 1 : s);
+}
+
+extern "C" int rtp_stem_fwd_stats(const float* x, const float* w, const float* b, const RtpAct* y, int n, long vox, float* stat_out,
+                                  int nsplit, void* stream) {
+  if (!x || !w || !b || !y || !stat_out || nsplit < 1 || y->c % 8 || (y->cs % 8) || (y->co % 8) || 256 % (y->c / 8)) return RTP_ERR_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  RtpProfScope prof(RTP_FAM_POINTWISE, s);
+  hipLaunchKernelGGL(stem_fwd_stats_kernel, dim3(nsplit, n), dim3(256), 0, s, x, w, b, (bf16_t*)y->ptr, y->cs, y->co, y->c, vox, stat_out,
+                     nsplit);
+  RTP_CHECK_LAUNCH();
+  return RTP_OK;
 }
 
 extern "C" int rtp_stem_fwd(const float* x, const float* w, const float* b, const RtpAct* y, int n, long vox,

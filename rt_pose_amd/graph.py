@@ -297,7 +297,14 @@ class Graph:
         op = StemOp(self, x_f32, y, wname, bname)
         y.producer = op
         self._add_op(op)
-        self.emit_fwd(self.be.stem_fwd(x_f32, w, b, y), self.lane_of(y), [x_f32], [y], "stem:" + name)
+        import os
+        S = self.be.stem_stats_nsplit(self.n, y.c, y.vox) if (hasattr(self.be, "stem_fwd_stats") and not os.environ.get("RTP_NO_STEM_STATS")) else 0
+        if S > 0:   # the statistics the block's first GroupNorm needs, as the stem's epilogue: no rtp_chan_stats pass over its output
+            y.stats_split = S
+            y.stats = self.be.alloc((self.n, S, y.c, 2), "f32")
+            self.emit_fwd(self.be.stem_fwd_stats(x_f32, w, b, y, y.stats, S), self.lane_of(y), [x_f32], [y, y.stats], "stem:" + name)
+        else:
+            self.emit_fwd(self.be.stem_fwd(x_f32, w, b, y), self.lane_of(y), [x_f32], [y], "stem:" + name)
         return y
 
     def pack(self, name, x_f32, c, dims):

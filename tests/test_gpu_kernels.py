@@ -649,6 +649,24 @@ def test_stem_and_pack(hip):
     yp, yc, yg = views(hip, torch.zeros(n, d, h, w, 32, dtype=torch.bfloat16), n, d, h, w)
     run(hip, EMU.stem_fwd(x.c, wt.c, b.c, yc), hip.stem_fwd(x.g, wt.g, b.g, yg))
     check(yp, BF, "stem_fwd")
+    # the same stem with the statistics of its stored output as an epilogue (rtp_stem_fwd_stats): output bit for bit, statistics = a
+    # read pass over that output (rtp_chan_stats) up to the summation order
+    for nn, dims2 in ((n, (d, h, w)), (3, (6, 10, 20))):
+        d2, h2, w2 = dims2
+        x2 = Pair(hip, torch.relu(rnd((nn, 1, d2, h2, w2), 45, torch.float32)))
+        ya = views(hip, torch.zeros(nn, d2, h2, w2, 32, dtype=torch.bfloat16), nn, d2, h2, w2)
+        yb = views(hip, torch.zeros(nn, d2, h2, w2, 32, dtype=torch.bfloat16), nn, d2, h2, w2)
+        S = hip.stem_stats_nsplit(nn, 32, d2 * h2 * w2)
+        assert S > 0
+        st = hip.alloc((nn, S, 32, 2), "f32")
+        st.fill_(float("nan"))     # every partial must be written
+        ref = hip.alloc((nn, 3, 32, 2), "f32")
+        hip.stem_fwd(x2.g, wt.g, b.g, ya[2])(hip.stream())
+        hip.stem_fwd_stats(x2.g, wt.g, b.g, yb[2], st, S)(hip.stream())
+        hip.chan_stats(yb[2], None, 3, ref)(hip.stream())
+        torch.cuda.synchronize()
+        assert torch.equal(ya[0].g, yb[0].g)
+        assert rel_err(st.sum(1).cpu(), ref.sum(1).cpu()) < F32
     _, gc, gg = views(hip, rnd((n, d, h, w, 32), 43), n, d, h, w)
     dw, db = Pair(hip, torch.zeros(32, 1, 1, 1, 1)), Pair(hip, torch.zeros(32))
     sc = hip.alloc((hip.stem_bwd_blocks(), 32, 2), "f32")
