@@ -252,7 +252,7 @@ def test_fused_stride2_data_gradient_route(monkeypatch):
 def test_launch_list_reorderings_keep_dependencies_and_results(monkeypatch):
     """lanes.main_row_first / lanes.hoist_tagged permute a launch list only inside the read/write relations of the original
     order (checked here with an independent walk), refuse a permutation that would break one, and the plan computes the same
-    losses and gradients with the forward list re-ordered (RTP_FWD_ROW0_FIRST=1) and with the backward hoist switched off."""
+    losses and gradients with the forward list in creation order (RTP_FWD_ROW0_FIRST=0) and with the backward hoist switched off."""
     from rt_pose_amd.lanes import Launch, _order_preds, hoist_tagged, main_row_first
 
     def respects(orig, new):
@@ -260,9 +260,12 @@ def test_launch_list_reorderings_keep_dependencies_and_results(monkeypatch):
         preds = _order_preds(orig)
         return len(new) == len(orig) and all(pos[id(orig[q])] < pos[id(orig[k])] for k in range(len(orig)) for q in preds[k])
 
+    monkeypatch.setenv("RTP_FWD_ROW0_FIRST", "0")      # creation order (the engine applies main_row_first itself by default)
     eng, flat, sd, ex, _ = make("hr3d", exact=True)
+    monkeypatch.delenv("RTP_FWD_ROW0_FIRST")
     fwd2 = main_row_first(eng.fwd)
     assert [L.tag for L in fwd2] != [L.tag for L in eng.fwd] and respects(eng.fwd, fwd2)
+    assert [L.tag for L in make("hr3d", exact=True)[0].fwd] == [L.tag for L in fwd2], "the default forward list is the re-ordered one"
     tags = [L.tag for L in fwd2]
     assert tags.index("conv:s3.f01") < tags.index("fuse:s3.row0") < tags.index("conv:s3.f20.0")
     # a hoist across a true dependency is refused: b reads what a writes
@@ -284,7 +287,7 @@ def test_launch_list_reorderings_keep_dependencies_and_results(monkeypatch):
         return e.losses()["loss"].clone(), {k: v.clone() for k, v in f.grads.items()}
 
     l0, g0 = run({})
-    for env in ({"RTP_FWD_ROW0_FIRST": "1"}, {"RTP_BWD_F10_FIRST": "0"}):
+    for env in ({"RTP_FWD_ROW0_FIRST": "0"}, {"RTP_BWD_F10_FIRST": "0"}):
         l1, g1 = run(env)
         assert torch.equal(l0, l1), env
         assert all(torch.equal(g0[k], g1[k]) for k in g0), env
