@@ -19,7 +19,7 @@ import torch
 
 from . import net
 from .graph import Graph, View, pad_to
-from .lanes import LanePlan, LANE_MAP
+from .lanes import LanePlan, LANE_MAP, LANE_MAP_4
 
 
 def one_cycle(step, total_step, lr_max, moms=(0.95, 0.85), div_factor=10.0, pct_start=0.4):
@@ -143,7 +143,12 @@ class PoseEngine:
             from .lanes import merge_launches
             self.fwd, done = merge_launches(self.fwd, be, [("conv:head.reg.0", "conv:head.hm.0"), ("conv:head.reg.2", "conv:head.hm.2")])
             self.merged_head = list(done)   # (both launches of a pair belong to the same kernel family: nothing to re-account)
-        self.fwd_plan = LanePlan(be, self.fwd, LANE_MAP)
+        # lanes -> streams (lanes.py): four streams where the full-resolution weight-gradient lane is (nearly) empty, i.e. no channel-
+        # sliced head whose weight gradients stay there; one stream per lane otherwise
+        from .graph import SplitConvOp, CoSplitConvOp
+        sliced_head = any(isinstance(op, (SplitConvOp, CoSplitConvOp)) for op in g.ops)
+        self.lane_map = LANE_MAP if ("RTP_LANES" in os.environ or sliced_head or batch != 8) else LANE_MAP_4
+        self.fwd_plan = LanePlan(be, self.fwd, self.lane_map)
         self.bwd_plan = None
         self.use_lanes = True      # False: replay everything on the caller's stream in list order
         d, h, w = dims
@@ -206,7 +211,7 @@ class PoseEngine:
                                                 [("dgrad:head.hm.2", "dgrad:head.reg.2"),
                                                  ("wgrad:head.hm.2", "wgrad:head.reg.2", "wgrad:head.hm.0", "wgrad:head.reg.0")])
                 self.merged_head += list(done)
-            self.bwd_plan = LanePlan(be, self.bwd, LANE_MAP)
+            self.bwd_plan = LanePlan(be, self.bwd, self.lane_map)
         self.live_params = set(g.used_params)
         self.width_hints = self._apply_width_hints(os.environ.get("RTP_WIDTH_HINTS", DEFAULT_WIDTH_HINTS if batch == 8 else ""))
 

@@ -17,6 +17,14 @@ NLANES = 6
 import os
 LANE_MAP = [int(v) for v in os.environ.get("RTP_LANES", "0,1,2,3,4,5").split(",")]
 assert len(LANE_MAP) == NLANES and all(0 <= v < NLANES for v in LANE_MAP)
+# FOUR streams -- as many as HIP has hardware queues (rt_pose_amd.pin_hw_queues), so that no two streams share a queue and run each
+# other's launches in submission order: the lowest level's lane shares a stream with the lower levels' weight gradients, the full-
+# resolution weight-gradient lane (what is left of it once the head towers' launches are deferred onto the main lane: the stem's)
+# with the level-2 lane.  Measured (round 4, hr3d, B = 8, width hints in place): 5.50 -> 5.38 ms per step (-2.2 %, three same-box
+# triples; "0,1,2,3,3,3" 5.40, "0,1,2,0,3,3" 5.43, "0,1,2,3,2,3" 5.55, "0,1,2,2,3,1" 5.59); hr3d_dcn 11.51 -> 11.47.  The configs whose
+# heads are channel-sliced keep their weight gradients on that lane and lose with it (hr3d_one_hm_doppler 10.23 -> 10.34): they stay
+# on one stream per lane (engine.PoseEngine picks; RTP_LANES overrides both).
+LANE_MAP_4 = [0, 1, 2, 2, 3, 3]
 
 
 BUF_BYTES = {}   # data_ptr -> bytes of every buffer a launch names (tools/plan_times.py prices launches with it)
@@ -317,6 +325,7 @@ class LanePlan:
         self.launches = [x if isinstance(x, Launch) else Launch(x) for x in launches]
         if os.environ.get("RTP_REORDER", "0") == "1":
             self.launches = reorder_critical_path(self.launches)
+        self.lane_map = lane_map
         self.lane_of = [lane_map[L.lane] if lane_map is not None else L.lane for L in self.launches]
         self.lanes_used = sorted(set(self.lane_of))
         self.waits, self.record = plan_waits(self.launches, NLANES, self.lane_of)

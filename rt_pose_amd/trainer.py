@@ -121,7 +121,7 @@ class DataParallelTrainer:
     def _install_early_bucket(self):
         """Split the flat gradient buffer at the first parameter the early tail flush finalises and queue that suffix's all-reduce
         as a launch of the backward list, right behind the flush (same lane: stream order makes it wait for exactly that flush)."""
-        from .lanes import LANE_MAP, LanePlan, Launch, L_WG_LOW
+        from .lanes import LanePlan, Launch, L_WG_LOW
         eng, g = self.engine, self.engine.graph
         # the flush is looked up by identity AFTER every re-ordering of the list (engine.py hoists launches by tag): its creation
         # index (g.early_tail_index) is a position in Graph.bwd, not in eng.bwd
@@ -151,7 +151,7 @@ class DataParallelTrainer:
             else:
                 self._ar_pending = dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
         eng.bwd.insert(idx + 1, Launch(kick, L_WG_LOW, grads, grads, "allreduce:early"))
-        eng.bwd_plan = LanePlan(self.be, eng.bwd, LANE_MAP)
+        eng.bwd_plan = LanePlan(self.be, eng.bwd, eng.bwd_plan.lane_map)   # (the map the plan it replaces was built with)
 
     # ------------------------------------------------------------------ one step
     def _on_stream(self):
