@@ -216,3 +216,29 @@ def test_width_hint_rules_reach_the_right_launches():
     real = PoseEngine(be, flat.values, s["arch"], s["final_fuse"], s["heads"], s["weight"], s["code_weights"], 1, (8, 16, 32), train=True, pgrads=flat.grads)
     tags = [x.tag for x in real.fwd + real.bwd]
     assert all(any(t.startswith(p) for t in tags) for p in pre), [p for p in pre if not any(t.startswith(p) for t in tags)]
+
+
+def test_four_stream_map_is_chosen_where_it_pays_and_orders_every_hazard():
+    """PoseEngine picks lanes.LANE_MAP_4 (four streams = four hardware queues) for eight-sample plans without channel-sliced heads and
+    one stream per lane otherwise; the waits derived under the four-stream map still order every read/write hazard of both lists."""
+    from tests.emu_backend import EmuBackend
+    from rt_pose_amd import configs
+    from rt_pose_amd.engine import PoseEngine, FlatParams
+    from rt_pose_amd.trainer import init_state_dict
+
+    def build(name, batch):
+        be = EmuBackend()
+        s = configs.spec(name)
+        shapes = configs.param_shapes(name)
+        flat = FlatParams(shapes, be.alloc)
+        flat.load_state_dict(init_state_dict(shapes, 0))
+        return PoseEngine(be, flat.values, s["arch"], s["final_fuse"], s["heads"], s["weight"], s["code_weights"], batch, (4, 8, 16),
+                          train=True, pgrads=flat.grads)
+
+    eng = build("hr3d", 8)
+    assert eng.lane_map == lanes.LANE_MAP_4 and eng.fwd_plan.lane_map == lanes.LANE_MAP_4 and eng.bwd_plan.lane_map == lanes.LANE_MAP_4
+    assert len(set(eng.bwd_plan.lane_of)) <= 4
+    _check(eng.fwd, eng.fwd_plan.lane_of)
+    _check(eng.bwd, eng.bwd_plan.lane_of)
+    assert build("hr3d", 2).lane_map == lanes.LANE_MAP
+    assert build("hr3d_one_hm_doppler", 8).lane_map == lanes.LANE_MAP
