@@ -512,13 +512,20 @@ const char* rtp_version(void);
  *   rtp_conv_dgrad_fused / rtp_wgrad* on the tiled kernels -- they validate and RECORD instead of launching>;  rtp_multi_end(&h);
  *   then rtp_multi_launch(h, stream) per step.  Results and buffers are those of the separate launches (a problem merely runs on
  *   its share of every XCD's workgroups).  rtp_multi_end returns RTP_ERR_UNSUPPORTED when the recorded launches cannot share one
- *   (different kernels or variants, batch != 8, a generic-kernel geometry): the caller keeps the separate launches. */
+ *   (different kernels or variants, batch != 8, a generic-kernel geometry): the caller keeps the separate launches.
+ *   The default plan uses it for the two head towers (center_head.py:66-109: hm and reg are independent chains of the same convs):
+ *   conv .0 / .2, data gradient .2 and both weight gradients run pairwise in one launch (-1.4 % on the hr3d step). */
 int rtp_multi_begin(void);
 int rtp_multi_end(int* handle_out);
 int rtp_multi_abort(void);
 int rtp_multi_launch(int handle, void* stream);
 /* Width hint: the LDS-tiled launch whose output buffer starts at `key` (conv / data gradient: y->ptr + 2 * y->co bytes; weight
- * gradient: the slab buffer) runs on total_wgs workgroups instead of one per CU; 0 removes the hint.  Results do not change. */
+ * gradient, stride 1 or 2: the slab buffer) runs on total_wgs workgroups instead of one per CU; 0 removes the hint.  The launch's
+ * tensor output is bit-identical; its per-workgroup partial buffers (statistics, slabs, Q / subset-sum partials) keep their size, the
+ * slots of the workgroups that do not run stay untouched (zero), and the partials sum to the same totals up to summation order.
+ * The table is keyed by address and persists until overwritten: a plan sets or clears the entry of EVERY output it owns
+ * (rt_pose_amd/engine.py).  Why: a main-lane launch that leaves a quarter of the CUs alone costs itself 5 % and lets the other
+ * lanes' dependent chains run beside it (-3.8 % on the hr3d step). */
 int rtp_tiled_width_hint(const void* key, int total_wgs);
 /* Dynamic work claiming of the persistent LDS-tiled kernels (csrc/rtp_claim.h): 32-bit words of the per-GPU counter pool handed
  * out so far on the current device (every launch owns a slot keyed by its output pointer); -1 on error.  the claiming is opt-in: RTP_CLAIM=1
