@@ -242,3 +242,60 @@ def test_four_stream_map_is_chosen_where_it_pays_and_orders_every_hazard():
     _check(eng.bwd, eng.bwd_plan.lane_of)
     assert build("hr3d", 2).lane_map == lanes.LANE_MAP
     assert build("hr3d_one_hm_doppler", 8).lane_map == lanes.LANE_MAP
+
+
+def test_merge_launches_groups_of_three_and_four():
+    """merge_launches with more than two launches per group (the head towers' four weight gradients, RTP_MERGE_HEAD_WG4): everything
+    joins the group's first launch, reads / writes are the union, a group with one dependent member is refused as a whole."""
+    from rt_pose_amd.lanes import Launch, merge_launches, _order_preds
+
+    class T:
+        def __init__(self, i):
+            self.i = i
+
+        def data_ptr(self):
+            return self.i
+
+        def numel(self):
+            return 1
+
+        def element_size(self):
+            return 1
+
+    class BE:
+        def __init__(self):
+            self.asked = []
+
+        def multi(self, fns):
+            self.asked.append(tuple(f.__name__ for f in fns))
+            return lambda s: [f(s) for f in fns]
+
+    t = [T(i) for i in range(12)]
+    ran = []
+
+    def mk(name):
+        def f(s):
+            ran.append(name)
+        f.__name__ = name
+        return f
+
+    def build():   # four independent weight gradients w0..w3 of one producer p, a consumer c of all, and d that depends on w0
+        return [Launch(mk("p"), 0, [t[0]], [t[1]], "p"), Launch(mk("w0"), 0, [t[1]], [t[2]], "wgrad:w0"), Launch(mk("d"), 0, [t[2]], [t[6]], "wgrad:d"),
+                Launch(mk("w1"), 3, [t[1]], [t[3]], "wgrad:w1"), Launch(mk("w2"), 3, [t[1]], [t[4]], "wgrad:w2"), Launch(mk("w3"), 4, [t[1]], [t[5]], "wgrad:w3"),
+                Launch(mk("c"), 0, [t[2], t[3], t[4], t[5], t[6]], [t[7]], "tail")]
+
+    be = BE()
+    new, merged = merge_launches(build(), be, [("wgrad:w0", "wgrad:w1", "wgrad:w2", "wgrad:w3")])
+    assert merged == [("wgrad:w0", "wgrad:w1", "wgrad:w2", "wgrad:w3")] and be.asked == [("w0", "w1", "w2", "w3")]
+    assert [x.tag for x in new] == ["p", "wgrad:w0+w1+w2+w3", "wgrad:d", "tail"]
+    m = new[1]
+    assert m.lane == 0 and set(m.reads) == {1} and set(m.writes) == {2, 3, 4, 5}
+    for x in new:
+        x.fn(None)
+    assert ran == ["p", "w0", "w1", "w2", "w3", "d", "c"]
+    # a group with a member that depends on another member (d reads what w0 writes) is refused as a whole, smaller groups still go
+    be = BE()
+    new2, merged2 = merge_launches(build(), be, [("wgrad:w0", "wgrad:w1", "wgrad:d"), ("wgrad:w1", "wgrad:w2", "wgrad:w3")])
+    assert merged2 == [("wgrad:w1", "wgrad:w2", "wgrad:w3")] and be.asked == [("w1", "w2", "w3")]
+    assert [x.tag for x in new2] == ["p", "wgrad:w0", "wgrad:d", "wgrad:w1+w2+w3", "tail"]
+    assert all(x.lane == 3 for x in new2 if x.tag.startswith("wgrad:w1"))
