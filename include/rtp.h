@@ -49,6 +49,15 @@ typedef struct RtpConvGeom {
   int pad;        /* 0 (ks=1) or 1 (ks=3) */
   int w_ci_total; /* the fp32 weight tensor is [co][w_ci_total][ks^3]; this conv uses input channels   */
   int w_ci_off;   /* [w_ci_off, w_ci_off+ci_real) of it (0,0 = the whole tensor; final_conv chunks)   */
+  int wgs;        /* launch width of the persistent LDS-tiled kernels: 0 = their own choice (one workgroup per CU); > 0 = at most
+                   * this many workgroups in all (wgs / n per sample, at least one).  The launch's tensor output is bit-identical;
+                   * its per-workgroup partial buffers (statistics, slabs, Q / subset-sum partials) keep the size the query
+                   * functions (rtp_conv_stats_nsplit, rtp_wgrad_nsplit) report for the geometry, the slots of the workgroups
+                   * that do not run are NOT written -- the caller zeroes those buffers once and always launches with the same
+                   * width -- and the partials sum to the same totals up to summation order.  Why: a main-stream launch that
+                   * leaves a quarter of the CUs alone costs itself 5 % and lets other streams' dependent chains run beside it
+                   * (-3.8 % on the hr3d step).  Kernels other than conv_tiled / wgrad_tiled /
+                   * wgrad_s2_tiled ignore the field. */
 } RtpConvGeom;
 
 /* ---------------------------------------------------------------- A. convolution family --- */
@@ -507,30 +516,25 @@ int rtp_prof_collect(int family, float* total_ms, int* launches); /* synchronise
 const char* rtp_version(void);
 /* Several independent launches of ONE LDS-tiled kernel variant as one launch (csrc/rtp_multi.h; round 4).  HRNet's branches run the
  * same block structure side by side: the full-resolution conv of a stage and the level-1 conv of the same position are launches
- * of the same kernel on eight samples each, and alone the small one occupies every CU for a ninth of the work.
+ * of the same kernel on the same samples, and alone the small one occupies every CU for a ninth of the work.
  *   rtp_multi_begin();  <call the ordinary entry points of the launches to merge: rtp_conv_gn_fused / rtp_conv_igemm* /
- *   rtp_conv_dgrad_fused / rtp_wgrad* on the tiled kernels -- they validate and RECORD instead of launching>;  rtp_multi_end(&h);
- *   then rtp_multi_launch(h, stream) per step.  Results and buffers are those of the separate launches (a problem merely runs on
- *   its share of every XCD's workgroups).  rtp_multi_end returns RTP_ERR_UNSUPPORTED when the recorded launches cannot share one
- *   (different kernels or variants, batch != 8, a generic-kernel geometry): the caller keeps the separate launches.
+ *   rtp_conv_dgrad_fused / rtp_wgrad* on the tiled kernels -- they validate and RECORD instead of launching>;
+ *   rtp_multi_end(dev_params, rtp_multi_param_bytes(), &h);  then rtp_multi_launch(h, stream) per step;  rtp_multi_free(h) at the end.
+ *   dev_params: device memory of rtp_multi_param_bytes() bytes that the CALLER owns and keeps alive until rtp_multi_free (the
+ *   library allocates nothing; the blocks are uploaded inside rtp_multi_end with a synchronous copy).
+ *   Results and buffers are those of the separate launches (a problem merely runs on its share of every sample's 256 / n
+ *   workgroups).  rtp_multi_end returns RTP_ERR_UNSUPPORTED when the recorded launches cannot share one (different kernels or
+ *   variants, different sample counts n or an n that does not divide 256, a generic-kernel geometry, fewer than 2 or more than 4
+ *   launches): the caller keeps the separate launches.  A capture left open by a failed caller is discarded by the next
+ *   rtp_multi_begin on that thread.  rtp_multi_launch returns RTP_ERR_UNSUPPORTED on another device than the handle's.
  *   The default plan uses it for the two head towers (center_head.py:66-109: hm and reg are independent chains of the same convs):
  *   conv .0 / .2, data gradient .2 and both weight gradients run pairwise in one launch (-1.4 % on the hr3d step). */
 int rtp_multi_begin(void);
-int rtp_multi_end(int* handle_out);
+long rtp_multi_param_bytes(void);
+int rtp_multi_end(void* dev_params, long dev_bytes, int* handle_out);
 int rtp_multi_abort(void);
 int rtp_multi_launch(int handle, void* stream);
-/* Width hint: the LDS-tiled launch whose output buffer starts at `key` (conv / data gradient: y->ptr + 2 * y->co bytes; weight
- * gradient, stride 1 or 2: the slab buffer) runs on total_wgs workgroups instead of one per CU; 0 removes the hint.  The launch's
- * tensor output is bit-identical; its per-workgroup partial buffers (statistics, slabs, Q / subset-sum partials) keep their size, the
- * slots of the workgroups that do not run stay untouched (zero), and the partials sum to the same totals up to summation order.
- * The table is keyed by address and persists until overwritten: a plan sets or clears the entry of EVERY output it owns
- * (rt_pose_amd/engine.py).  Why: a main-lane launch that leaves a quarter of the CUs alone costs itself 5 % and lets the other
- * lanes' dependent chains run beside it (-3.8 % on the hr3d step). */
-int rtp_tiled_width_hint(const void* key, int total_wgs);
-/* Dynamic work claiming of the persistent LDS-tiled kernels (csrc/rtp_claim.h): 32-bit words of the per-GPU counter pool handed
- * out so far on the current device (every launch owns a slot keyed by its output pointer); -1 on error.  the claiming is opt-in: RTP_CLAIM=1
- * (environment, read once); the default is the static deal of bricks to workgroups. */
-int rtp_claim_slots_in_use(void);
+int rtp_multi_free(int handle);
 
 #ifdef __cplusplus
 }

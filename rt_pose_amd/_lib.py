@@ -28,7 +28,7 @@ class RtpAct(C.Structure):
 class RtpConvGeom(C.Structure):
     _fields_ = [("n", C.c_int), ("di", C.c_int), ("hi", C.c_int), ("wi", C.c_int), ("dov", C.c_int), ("ho", C.c_int),
                 ("wo", C.c_int), ("ci", C.c_int), ("co", C.c_int), ("ks", C.c_int), ("stride", C.c_int),
-                ("pad", C.c_int), ("w_ci_total", C.c_int), ("w_ci_off", C.c_int)]
+                ("pad", C.c_int), ("w_ci_total", C.c_int), ("w_ci_off", C.c_int), ("wgs", C.c_int)]
 
 
 class RtpGnBwd(C.Structure):
@@ -141,11 +141,10 @@ PROTOTYPES = {
     "rtp_prof_enable": [_I, _I],
     "rtp_prof_collect": [_I, C.POINTER(_F), C.POINTER(_I)],
     "rtp_version": [],
-    "rtp_claim_slots_in_use": [],
-    "rtp_tiled_width_hint": [_P, _I],
-    "rtp_multi_begin": [], "rtp_multi_end": [C.POINTER(_I)], "rtp_multi_abort": [], "rtp_multi_launch": [_I, _P],
+    "rtp_multi_begin": [], "rtp_multi_param_bytes": [], "rtp_multi_end": [_P, _L, C.POINTER(_I)], "rtp_multi_abort": [],
+    "rtp_multi_launch": [_I, _P], "rtp_multi_free": [_I],
 }
-_RESTYPE = {"rtp_version": C.c_char_p, "rtp_dcn_workspace_bytes": C.c_long, "rtp_voxelize_workspace_bytes": C.c_long,
+_RESTYPE = {"rtp_version": C.c_char_p, "rtp_multi_param_bytes": C.c_long, "rtp_dcn_workspace_bytes": C.c_long, "rtp_voxelize_workspace_bytes": C.c_long,
             "rtp_upsample_bwd_scratch_floats": C.c_long}
 
 _lib = None

@@ -27,7 +27,25 @@ def _act(v):
 
 def _geom(g):
     return RtpConvGeom(g.n, g.di, g.hi, g.wi, g.do, g.ho, g.wo, g.ci, g.co, g.ks, g.stride, g.pad, g.w_ci_total,
-                       g.w_ci_off)
+                       g.w_ci_off, getattr(g, "wgs", 0))
+
+
+class _MultiLaunch:
+    """A shared launch (rtp_multi_*): callable like every other launch closure; owns the handle and its device parameter block."""
+
+    def __init__(self, lib, handle, params, fns):
+        self.lib, self.handle, self.params, self.fns = lib, handle, params, fns
+
+    def __call__(self, s):
+        check(self.lib.rtp_multi_launch(self.handle, s), "rtp_multi_launch")
+
+    def __del__(self):
+        try:
+            if self.handle >= 0:
+                self.lib.rtp_multi_free(self.handle)
+                self.handle = -1
+        except Exception:   # interpreter shutdown: the library may be gone already
+            pass
 
 
 class HipBackend:
@@ -98,22 +116,25 @@ class HipBackend:
         return lambda s: check(fn(*args, s), "rtp_pack_dgrad_w") or keep and None
 
     def multi(self, fns):
-        """fns: launch closures of this backend that each issue ONE stride-1 LDS-tiled kernel launch of the same variant on eight
+        """fns: launch closures of this backend that each issue ONE stride-1 LDS-tiled kernel launch of the same variant on the same
         samples (conv_gn_fused / conv / conv_dgrad_fused, or wgrad / wgrad_q / wgrad_tg).  -> ONE closure that issues them as a
-        shared launch (include/rtp.h: rtp_multi_*), or None when they cannot share one (the callers keep the separate launches)."""
+        shared launch (include/rtp.h: rtp_multi_*), or None when they cannot share one (the callers keep the separate launches).
+        The handle and its device parameter block live as long as the returned closure (released by _MultiLaunch.__del__)."""
         lib = self.lib
         check(lib.rtp_multi_begin(), "rtp_multi_begin")
         try:
             for f in fns:
                 f(None)          # recorded by the entry points, not launched
-        except _lib.RtpError:
+        except BaseException as e:   # whatever a closure raises: the capture must not stay open on this thread
             lib.rtp_multi_abort()
-            return None
+            if isinstance(e, _lib.RtpError):
+                return None
+            raise
+        params = torch.zeros(int(lib.rtp_multi_param_bytes()), dtype=torch.uint8, device=self.device)
         h = C.c_int(-1)
-        if lib.rtp_multi_end(C.byref(h)) != 0 or h.value < 0:
+        if lib.rtp_multi_end(_ptr(params), params.numel(), C.byref(h)) != 0 or h.value < 0:
             return None
-        hv, keep = h.value, tuple(fns)
-        return lambda s: check(lib.rtp_multi_launch(hv, s), "rtp_multi_launch") or keep and None
+        return _MultiLaunch(lib, h.value, params, tuple(fns))
 
     def conv_tiled_ok(self, x, geom, transposed):
         return bool(self.lib.rtp_conv_tiled_ok(_act(x), _geom(geom), int(transposed)))

@@ -21,7 +21,6 @@
 #include <stdlib.h>
 #include <string.h>
 
-#include "rtp_claim.h"
 #include "rtp_common.h"
 #include "rtp_multi.h"
 #include "rtp_prof.h"
@@ -88,20 +87,11 @@ struct TiledParams {
   int x_cs, x_co;          // x may be a 32-channel slice of a wider tensor (channel stride / first channel)
   const float* acc32; int a_cs;  // optional fp32 partial result [N][vox][a_cs] added before bias / ReLU (input-channel split)
   int dbg;  // timing experiments only (RTP_TILED_DBG): bit0 = skip the MFMA loop, bit1 = skip staging, bit2 = skip epilogue
-  // Dynamic brick claiming (rtp_claim.h).  claim != null: a team takes UNITS of `unit` consecutive bricks (z fastest) from the
-  // counters claim[n * ranges + r]; a sample's bricks are cut into `ranges` contiguous ranges (one per XCD that serves the sample:
-  // neighbouring bricks keep meeting in one L2), a team starts in its home range and moves on to the others when it is empty.
-  // claim == null: the static deal (contiguous, balanced runs per team).
-  // A range's bricks are cut into units handed out by INDEX (the counter counts units): the first `nbig` units have `ubig` bricks,
-  // the rest `usmall` -- big units first keep the staging cheap (inside a unit a brick stages one z-plane pair instead of two),
-  // the small ones at the end keep the workgroups' finishing times within a brick or two of each other.
-  int* claim; int ranges, total_wgs, nbig, ubig, usmall;
-  // freerun: the two teams synchronise only WITHIN themselves (LDS-counter barriers over their four waves) and drift freely
-  // against each other, instead of swapping roles at workgroup barriers; prio: wave priority of a team's MFMA phase.
-  // Free-running is the default (RTP_TILED_FREERUN=0: lock-step): it takes 25 % of the kernel's cycles away, of which the chip's
-  // power management hands back a third (2.01 -> 1.80 GHz under the denser MFMA stream); beside the width hints of the default
-  // plan the hr3d step gains 1.3 % (5.72 -> 5.65 ms, two same-box pairs), alone 0 ... 1.7 %.
-  int freerun, prio;
+  // The two teams synchronise only WITHIN themselves (LDS-counter barriers over their four waves) and drift freely against each
+  // other (round 4; the lock-step schedule of rounds 2-3 -- roles swapped at a workgroup barrier per phase -- measured 25 % more
+  // cycles and 1.3 % on the step, profiles/r04_tiled_prof.txt, and is gone, as is the opt-in dynamic brick claiming that lost its
+  // A/B there).  prio: wave priority of a team's MFMA phase (experiments).
+  int prio;
   // Per-workgroup partial outputs (statistics, totals) go to slot n * part_stride + wg: part_stride = workgroups per sample of a
   // plain launch; a launch that shares the grid with other problems (conv_tiled_multi_kernel) runs on fewer workgroups per sample
   // than the buffers were sized for and leaves the upper slots untouched (they are zero: nothing else writes them).
@@ -206,11 +196,7 @@ __device__ __forceinline__ void conv_tiled_body(const TiledParams& p, const int 
   const int team_id = wg_in_sample * 2 + team;  // team index within the sample
   const int v = lane & 15, q = lane >> 4;
   const int wz = tw >> 1, wx = tw & 1;
-  // dynamic brick claiming (below, "work distribution")
-  const bool dyn = p.claim != nullptr;                                          // kernel-uniform
-  const bool claimer = tw == 0 && lane == 0;                                    // the one lane per team that talks to the counters
-  int rng = dyn ? (wg_in_sample * p.ranges) / wgs_per_sample : 0;   // claimer's current range (home range first)
-  int nfail = 0;   // ranges this claimer has found empty
+  const bool claimer = tw == 0 && lane == 0;                                    // the one lane per team that publishes the team's run of bricks
 
   if (p.fw) {   // kernel-uniform: GroupNorm fold in the prologue (both teams' brick regions are scratch until the phase loop)
     float* scr = reinterpret_cast<float*>(lds + 27 * NT * 16 * 32);
@@ -470,74 +456,28 @@ __device__ __forceinline__ void conv_tiled_body(const TiledParams& p, const int 
     if (tid < 256) bL[192 + tid] = 0.f;   // per-wave running totals [8 waves][32]
   }
   PROF_T(pk1);
-  // ---- work distribution.  A team works through UNITS of consecutive bricks (z fastest) of its sample.  Static deal (p.claim
-  // null): one unit per team, its balanced contiguous run.  Dynamic (rtp_claim.h): units of 4 then 2 bricks taken from the sample's
-  // counters, so a workgroup that starts late -- its CU was still busy with another stream's kernel -- takes fewer bricks
-  // instead of stretching the launch.  One lane per team (the CLAIMER) talks to the counters; the team's other waves learn the
-  // next unit from LDS after the phase barrier.  ctl[2 * team + {0, 1}] = next unit (first brick or -1, end);
-  // ctl[4 + 2 * (phase & 3) + team] = "this team has nothing left" as of the end of that phase.
+  // ---- work distribution: a static deal.  A team works through ONE contiguous, balanced run of its sample's bricks (z fastest:
+  // consecutive bricks share two of their four haloed z-planes).  ctl[2 * team + {0, 1}] = the run [first, end) (first = -1: none);
+  // ctl[12 + team] = the team's barrier counter.
   int* ctl = reinterpret_cast<int*>(bL + 27 * p.Co);
-  auto range_lo = [&](int r) { return (int)((long)r * p.tiles_per_sample / p.ranges); };
-  // claimer only: turn a unit index of range `rng` into the team's next unit.  A team's FIRST unit of its home range is its own
-  // (index = the team's number within the range, drawn = false: no counter involved -- 64 teams asking one address at kernel start
-  // cost the last of them 5 us); every later one is drawn from the range's counter (index = teams of the range + the counter's
-  // answer).  While the current range is exhausted the claimer moves on through the others, cyclically from its home range
-  // (only at the tail of a launch: one atomic round trip per further range).
-  auto claim_finish = [&](int u, bool drawn) {
-    int s0 = -1, s1 = 0;
-    const int teams_r = p.teams_per_sample / p.ranges;
-    for (;;) {
-      const int lo = range_lo(rng), len = range_lo(rng + 1) - lo;
-      const int units = p.nbig + (len - p.nbig * p.ubig + p.usmall - 1) / p.usmall;
-      // (every team of the sample ends with exactly one failed draw on every range's counter)
-      if (drawn) rtp_claim_reset_if_last(p.claim + n * p.ranges + rng, u, units > teams_r ? units - teams_r : 0, p.teams_per_sample);
-      const int idx = drawn ? teams_r + u : u;
-      const int b = idx < p.nbig ? idx * p.ubig : p.nbig * p.ubig + (idx - p.nbig) * p.usmall;
-      if (b < len) {
-        const int e = b + (idx < p.nbig ? p.ubig : p.usmall);
-        s0 = lo + b; s1 = lo + (e < len ? e : len);
-        break;
-      }
-      if (drawn) {
-        if (++nfail >= p.ranges) break;   // (ranges are visited cyclically from the home range: a failed one is never asked again)
-        rng = rng + 1 == p.ranges ? 0 : rng + 1;
-      }
-      u = rtp_claim_take(p.claim + n * p.ranges + rng, 1);   // (after a missing own unit: this range's counter, which fails as well)
-      drawn = true;
-    }
-    ctl[2 * team] = s0;
-    ctl[2 * team + 1] = s1;
-  };
   if (claimer) {
-    if (dyn) {
-      claim_finish(team_id - rng * (p.teams_per_sample / p.ranges), false);
-    } else {   // contiguous, balanced runs of bricks per team: consecutive bricks share two of their four haloed z-planes
-      // (32-bit: team index x bricks of a sample stays far below 2^31 -- rtp_conv_tiled_try checks -- and a 64-bit division is
-      // ~150 instructions on this chip)
-      const int t_begin = (int)((unsigned)team_id * (unsigned)p.tiles_per_sample / (unsigned)p.teams_per_sample);
-      const int t_end = (int)((unsigned)(team_id + 1) * (unsigned)p.tiles_per_sample / (unsigned)p.teams_per_sample);
-      ctl[2 * team] = t_end > t_begin ? t_begin : -1;
-      ctl[2 * team + 1] = t_end;
-    }
+    // (32-bit: team index x bricks of a sample stays far below 2^31 -- rtp_conv_tiled_try checks -- and a 64-bit division is
+    // ~150 instructions on this chip)
+    const int t_begin = (int)((unsigned)team_id * (unsigned)p.tiles_per_sample / (unsigned)p.teams_per_sample);
+    const int t_end = (int)((unsigned)(team_id + 1) * (unsigned)p.tiles_per_sample / (unsigned)p.teams_per_sample);
+    ctl[2 * team] = t_end > t_begin ? t_begin : -1;
+    ctl[2 * team + 1] = t_end;
   }
-  if (tid < 10) ctl[4 + tid] = 0;   // flags, and the two team-barrier counters ctl[12 + team]
-  __syncthreads();   // weights, tables and the first units are in place for both teams
+  if (tid < 2) ctl[12 + tid] = 0;   // the two team-barrier counters
+  __syncthreads();   // weights, tables and the teams' runs are in place for both teams
   int both_done = 0;
-  const bool fr = p.freerun != 0;   // kernel-uniform
   unsigned* tcnt = reinterpret_cast<unsigned*>(ctl + 12 + team);
   unsigned tbar = 0;
-  // Lock-step: the teams swap roles at a workgroup barrier per phase and leave together, one phase after both have reported
-  // "nothing left".  Free-running: a team barrier per phase; a team leaves after a load phase that staged nothing (its pending
-  // epilogue has run there).
+  // A team barrier per phase; a team leaves after a load phase that staged nothing (its pending epilogue has run there).
 #define PHASE_SYNC() do { \
-    if (fr) { \
-      if (loading && !staged) both_done = 1; \
-      tbar += 4; team_sync(tcnt, tbar, lane); \
-    } else { \
-      if (claimer) ctl[4 + 2 * (phase & 3) + team] = (finished && !pend && !staged) ? 1 : 0; \
-      both_done = __builtin_amdgcn_readfirstlane(fl[0] & fl[1]); \
-      __syncthreads(); \
-    } } while (0)
+    if (loading && !staged) both_done = 1; \
+    tbar += 4; team_sync(tcnt, tbar, lane); \
+  } while (0)
   const long vox_n = (long)n * p.D * p.H * p.W;
   // Staging descriptors (brick-independent, computed once): element offset of each of this thread's 13 sixteen-byte
   // items relative to the brick origin, its swizzled LDS slot, and six "on the low/high face of the halo" bits.
@@ -648,13 +588,9 @@ __device__ __forceinline__ void conv_tiled_body(const TiledParams& p, const int 
   long long prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   PROF_T(pk2);
 #endif
-  // Every compute phase of a team is followed by a load phase of the same team (its epilogue runs there).  The loop ends one
-  // phase after both teams have reported "nothing left": the flags are read a phase late so that the LDS read's latency sits
-  // under the phase's own work instead of in front of it.
+  // Every compute phase of a team is followed by a load phase of the same team (its epilogue runs there).
   for (int phase = 0; !both_done; ++phase) {
-    const bool loading = ((phase + (fr ? 0 : team)) & 1) == 0;  // team-uniform (=> wave-uniform)
-    typedef int i32x2 __attribute__((ext_vector_type(2)));
-    const i32x2 fl = (!fr && phase > 0) ? *reinterpret_cast<const volatile i32x2*>(ctl + 4 + 2 * ((phase - 1) & 3)) : i32x2{0, 0};
+    const bool loading = (phase & 1) == 0;  // team-uniform (=> wave-uniform)
     PROF_T(pt0);
     if (loading) {
       bf16x8 exr[NEX > 0 ? NEX : 1][TY];
@@ -894,11 +830,7 @@ __device__ __forceinline__ void conv_tiled_body(const TiledParams& p, const int 
       staged = false;
       const int z0 = c_tz * TZ, y0 = c_ty * TY, x0 = c_tx * TX;
       if (++c_tz == p.tiles_z) { c_tz = 0; if (++c_tx == p.tiles_x) { c_tx = 0; ++c_ty; } }
-      // the unit's last brick: the claimer asks for the next unit NOW -- the counter's answer travels under this phase's MFMAs
-      // and is published (LDS) at its end, for the team's next load phase
-      const bool unit_ends = ++u_cur == u_end;
-      int take = 0;
-      if (unit_ends && claimer && dyn) take = rtp_claim_take(p.claim + n * p.ranges + rng, 1);
+      const bool unit_ends = ++u_cur == u_end;   // the run's last brick: "no further brick" is published (LDS) at this phase's end
       const bool live = x0 + wx * 16 < p.W;  // wave-uniform: otherwise this wave's 16-voxel column is padding (never the claimer's: wx = 0).
                                              // No early `continue`: every extra path through the loop body costs register copies where
                                              // the paths meet (32 accumulator + 16 residual registers were being shuffled per phase).
@@ -966,10 +898,7 @@ __device__ __forceinline__ void conv_tiled_body(const TiledParams& p, const int 
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt) acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(idf[nt], pre_r8[t], acc[t][nt], 0, 0, 0);
       }
-      if (unit_ends && claimer) {
-        if (dyn) claim_finish(take, true);
-        else ctl[2 * team] = -1;
-      }
+      if (unit_ends && claimer) ctl[2 * team] = -1;
 #ifdef RTP_TILED_PROF
       __builtin_amdgcn_s_waitcnt(0);   // (MFMA results are not covered by a counter: the delta below is issue time)
       PROF_T(pc2);
@@ -999,7 +928,7 @@ __device__ __forceinline__ void conv_tiled_body(const TiledParams& p, const int 
   }
 #endif
 #undef PHASE_SYNC
-  if (fr) __syncthreads();   // both teams done before the workgroup-wide reductions below
+  __syncthreads();   // both teams done before the workgroup-wide reductions below
   if constexpr (FUSE) {
     if (p.tot_out && tid < 32) {   // (the phase loop ends with a barrier)
       float a = 0.f;
@@ -1054,17 +983,20 @@ __global__ __launch_bounds__(512, 2) void conv_tiled_kernel(TiledParams p) {
 // serialised.  Here the eight samples keep their XCDs and each XCD's 32 workgroups are split between the problems in proportion to
 // their bricks (28 + 4 for full resolution + level 1: 11.4 and 12 bricks per team).  jobs[j] = the problem's parameters (built by
 // the host exactly as for a plain launch, teams_per_sample = 2 x its share), split[j] = first workgroup of problem j within an XCD.
-#define RTP_MULTI_MAX 4
 struct TiledMulti { const TiledParams* jobs; int njobs; int split[RTP_MULTI_MAX + 1]; };
 template <int NT, bool HAS_BTAB, int AUX, bool STAT, int FUSEX = 0, bool GEN = false>
 __global__ __launch_bounds__(512, 2) void conv_tiled_multi_kernel(TiledMulti m) {
-  const int xcd = (int)(blockIdx.x % 8), l = (int)(blockIdx.x / 8);   // grid = 8 x workgroups per XCD; sample = XCD
+  // grid = samples x workgroups per sample; the XCD-aware order of the plain kernel (every XCD one contiguous run of logical
+  // workgroups), cut into samples: n = 8 -> sample = XCD, n = 16 -> two samples per XCD, n = 4 -> a sample on two XCDs
+  const int per = m.split[m.njobs];
+  const int bid = (gridDim.x % 8 == 0) ? (int)(blockIdx.x % 8) * (int)(gridDim.x / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
+  const int n = bid / per, l = bid - n * per;
   int j = 0;
 #pragma unroll
   for (int k = 1; k < RTP_MULTI_MAX; ++k) j += (k < m.njobs && l >= m.split[k]) ? 1 : 0;
   j = __builtin_amdgcn_readfirstlane(j);
   const TiledParams p = m.jobs[j];   // (uniform address: scalar loads)
-  conv_tiled_body<NT, HAS_BTAB, AUX, STAT, FUSEX, GEN>(p, xcd, l - m.split[j]);
+  conv_tiled_body<NT, HAS_BTAB, AUX, STAT, FUSEX, GEN>(p, n, l - m.split[j]);
 }
 
 static bool tiled_geometry_ok(const RtpAct* x, const RtpConvGeom* g, int transposed, int* Co_out) {
@@ -1140,35 +1072,16 @@ int rtp_conv_tiled_try(const RtpAct* x, const void* wf, int w_per_sample, const 
   p.tiles_per_sample = (p.D / TZ) * p.tiles_y * p.tiles_x;
   int wgs = tiled_wgs_per_sample(g);
   p.part_stride = wgs;   // (the partial buffers are sized for the un-hinted launch)
-  if (const int hint = rtp_tiled_width_for((const char*)y->ptr + 2 * (size_t)y->co)) {   // fewer workgroups: CUs left to other lanes
-    const int hw = hint / g->n;
+  if (g->wgs > 0) {   // RtpConvGeom::wgs: the caller wants the launch on fewer workgroups (CUs left to other streams)
+    const int hw = g->wgs / g->n;
     if (hw >= 1 && hw < wgs) wgs = hw;
   }
   p.teams_per_sample = wgs * 2;
   if ((long)p.tiles_per_sample * (p.teams_per_sample + 1) >= (1L << 31)) return RTP_ERR_SHAPE;
   static const int dbg = getenv("RTP_TILED_DBG") ? atoi(getenv("RTP_TILED_DBG")) : 0;
   p.dbg = dbg;
-  // dynamic brick claiming (rtp_claim.h; RTP_CLAIM=1 switches it on; default: the static deal, RTP_TILED_UNIT: bricks per claim)
-  p.claim = nullptr; p.ranges = 1; p.total_wgs = p.N * wgs; p.nbig = 0; p.ubig = 4; p.usmall = 2;
-  if (rtp_claim_enabled()) {
-    // one range per XCD that serves a sample (the kernel's workgroup permutation gives XCD k the k-th eighth of the grid)
-    int ranges = 1;
-    const int grid = p.N * wgs;
-    if (grid % 8 == 0 && p.N < 8 && 8 % p.N == 0 && wgs % (8 / p.N) == 0 && p.tiles_per_sample >= 8 * (8 / p.N)) ranges = 8 / p.N;
-    p.claim = rtp_claim_slot((const char*)y->ptr + 2 * (size_t)y->co, p.N * ranges);
-    p.ranges = p.claim ? ranges : 1;
-    // unit schedule of a range (RTP_TILED_UBIG / RTP_TILED_USMALL / RTP_TILED_BIGPCT: experiments): ~80 % of its bricks in big
-    // units, a whole number of them per team, the rest in small ones
-    static const int ubig = getenv("RTP_TILED_UBIG") ? atoi(getenv("RTP_TILED_UBIG")) : 4;
-    static const int usmall = getenv("RTP_TILED_USMALL") ? atoi(getenv("RTP_TILED_USMALL")) : 2;
-    static const int bigpct = getenv("RTP_TILED_BIGPCT") ? atoi(getenv("RTP_TILED_BIGPCT")) : 80;
-    p.ubig = ubig < 1 ? 1 : ubig; p.usmall = usmall < 1 ? 1 : usmall;
-    const int len = p.tiles_per_sample / p.ranges, teams = 2 * wgs / p.ranges;
-    p.nbig = (int)((long)len * bigpct / 100 / p.ubig) / teams * teams;
-  }
-  static const int freerun = getenv("RTP_TILED_FREERUN") ? atoi(getenv("RTP_TILED_FREERUN")) : 1;
   static const int prio = getenv("RTP_TILED_PRIO") ? atoi(getenv("RTP_TILED_PRIO")) : 0;
-  p.freerun = freerun; p.prio = prio;
+  p.prio = prio;
   p.nextra = 0; p.mask = 0; p.tot_out = nullptr;
   p.qpart = nullptr; p.q_nsplit = 0; p.gn_p = p.gn_mr = p.gn_gamma = nullptr; p.gn_groups = 1; p.gn_m = 1.f; p.coef_out = nullptr;
   p.tg = nullptr; p.csum_out = nullptr;
@@ -1218,7 +1131,6 @@ int rtp_conv_tiled_try(const RtpAct* x, const void* wf, int w_per_sample, const 
     // (the family the problem is timed under when launched alone, below)
     job.fam = (Co == 32 && (long)p.N * p.D * p.H * p.W >= (1L << 20)) ? (transposed ? RTP_FAM_CONV_TILED_FULL_BWD : RTP_FAM_CONV_TILED_FULL)
                                                                         : RTP_FAM_CONV_TILED;
-    p.claim = nullptr; p.ranges = 1;   // the static deal inside a shared launch
     job.params.assign((const char*)&p, (const char*)&p + sizeof(p));
     cap->push_back(job);
     return RTP_OK;
@@ -1318,7 +1230,7 @@ extern "C" int rtp_conv_dgrad_fused_ok(const RtpAct* gy, const RtpConvGeom* g) {
 
 // ---- shared launches (rtp_multi.h)
 namespace {
-struct ConvMultiLauncher { void (*kern)(TiledMulti); TiledMulti m; size_t shm; };
+struct ConvMultiLauncher { void (*kern)(TiledMulti); TiledMulti m; size_t shm; int n; };
 using MKern = void (*)(TiledMulti);
 MKern conv_multi_kernel_for(int variant) {
   switch (variant) {
@@ -1349,13 +1261,12 @@ int rtp_conv_tiled_multi_finish(std::vector<RtpMultiJob>& jobs, const int* share
   std::vector<TiledParams> host(jobs.size());
   ConvMultiLauncher* L = new ConvMultiLauncher();
   L->kern = k; L->shm = jobs[0].shm;
-  L->m.jobs = (const TiledParams*)dev_params; L->m.njobs = (int)jobs.size();
+  L->m.jobs = (const TiledParams*)dev_params; L->m.njobs = (int)jobs.size(); L->n = jobs[0].n;
   int at = 0;
   for (size_t j = 0; j < jobs.size(); ++j) {
     if (jobs[j].params.size() != sizeof(TiledParams)) { delete L; return RTP_ERR_SHAPE; }
     memcpy(&host[j], jobs[j].params.data(), sizeof(TiledParams));
     host[j].teams_per_sample = 2 * share[j];   // (part_stride keeps the slots the problem's partial buffers were sized for)
-    host[j].total_wgs = 8 * share[j];
     L->m.split[j] = at;
     at += share[j];
   }
@@ -1367,7 +1278,9 @@ int rtp_conv_tiled_multi_finish(std::vector<RtpMultiJob>& jobs, const int* share
 
 int rtp_conv_tiled_multi_launch(void* launcher, hipStream_t s) {
   ConvMultiLauncher* L = (ConvMultiLauncher*)launcher;
-  hipLaunchKernelGGL(L->kern, dim3(8 * L->m.split[L->m.njobs]), dim3(512), L->shm, s, L->m);
+  hipLaunchKernelGGL(L->kern, dim3(L->n * L->m.split[L->m.njobs]), dim3(512), L->shm, s, L->m);
   RTP_CHECK_LAUNCH();
   return RTP_OK;
 }
+
+void rtp_conv_tiled_multi_drop(void* launcher) { delete (ConvMultiLauncher*)launcher; }

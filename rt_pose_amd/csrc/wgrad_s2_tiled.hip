@@ -12,7 +12,6 @@
 // rtp_wgrad_fold like every other slab -- no atomics, fixed summation order.
 #include <stdlib.h>
 
-#include "rtp_claim.h"
 #include "rtp_common.h"
 #include "rtp_prof.h"
 
@@ -260,8 +259,8 @@ int rtp_wgrad_s2_try(const RtpAct* gy, const RtpAct* x, const RtpConvGeom* g, in
   p.tiles_y = p.Ho / W2_OY; p.tiles_x = (p.Wo + W2_OX - 1) / W2_OX;
   p.bricks_per_sample = p.Do * p.tiles_y * p.tiles_x;
   p.wgs_per_sample = nsplit; p.part_stride = nsplit;
-  if (const int hint = rtp_tiled_width_for(gp)) {   // (rtp_claim.h: per-launch width hints; CUs left to the other lanes)
-    const int hw = hint / g->n;
+  if (g->wgs > 0) {   // RtpConvGeom::wgs: fewer workgroups than slabs (the upper slabs stay zero): CUs left to other streams
+    const int hw = g->wgs / g->n;
     if (hw >= 1 && hw < nsplit) p.wgs_per_sample = hw;
   }
   const size_t shm = sizeof(bf16_t) * (size_t)W2_RING * W2_SLOT;

@@ -13,7 +13,6 @@
 
 #include <string.h>
 
-#include "rtp_claim.h"
 #include "rtp_common.h"
 #include "rtp_multi.h"
 #include "rtp_prof.h"
@@ -68,12 +67,6 @@ struct WgTiledParams {
   // dense [27][32][32] for a 32 -> 32 layer; for a wider conv run as (output slice, input slice) launches every launch fills
   // its window of the SAME [27][Co][Ci] slabs, which rtp_wgrad_fold then reads like the generic kernel's
   int slab_rows, slab_cols;
-  // Dynamic brick claiming (rtp_claim.h).  claim != null: a workgroup's first brick is fixed (its index within its home range), every
-  // further one is taken from the counters claim[n * ranges + r] -- a sample's bricks are cut into `ranges` contiguous ranges, one per
-  // XCD that serves the sample; a workgroup moves on to the other ranges when its own is empty.  claim == null: the static deal.
-  // Claims are UNITS of `unit` consecutive bricks (1 or 2), by index: the counter's answer is asked for at a unit's first brick and
-  // needed only after its last one.
-  int* claim; int ranges, total_wgs, unit;
   // per-workgroup outputs (slab, Q partial, subset sums) go to slot n * part_stride + wg: the workgroups per sample of a plain
   // launch; in a shared launch (wgrad_tiled_multi_kernel) a problem runs on fewer and leaves the upper slots untouched (zero)
   int part_stride;
@@ -194,19 +187,11 @@ __device__ __forceinline__ void wgrad_tiled_body(const WgTiledParams& p, const i
   const int ttid = tid - WG_NCW * 64;                                   // loader thread index 0 .. 255
   const long vox_n = (long)n * p.D * p.H * p.W;
   constexpr int BUF = (HALO_VOX + BRICK_VOX) * 32;  // elements per staged brick (x halo + gy)
-  // ---- which bricks: iteration k of the workgroup works on brick tile_k.  Static deal: a contiguous run, z fastest (L2 reuse of
-  // shared z-planes).  Dynamic: the first brick is the workgroup's own, the others are claimed one at a time, an iteration ahead
-  // (the counter's answer travels under the staging of the current brick); ctl[k & 3] = tile_k, published by the claimer (first
-  // loader thread) before the barrier that ends iteration k - 1.
-  const bool dyn = p.claim != nullptr;
+  // ---- which bricks: iteration k of the workgroup works on brick tile_k of its contiguous run (static deal, z fastest: L2 reuse of
+  // shared z-planes); ctl[k & 3] = tile_k, published by the first loader thread before the barrier that ends iteration k - 1.
   int* ctl = reinterpret_cast<int*>(lds + 2 * BUF);
-  const int wgs_r = p.wgs_per_sample / p.ranges;       // workgroups per home range (dyn: ranges divides the workgroups)
-  int rng = dyn ? wg / wgs_r : 0;
-  auto range_lo = [&](int r) { return (int)((long)r * p.tiles_per_sample / p.ranges); };
-  // the workgroup's first unit: its own (index within the home range) / static: its whole run
-  const int t_begin = dyn ? range_lo(rng) + p.unit * (wg - rng * wgs_r) : (int)((long)wg * p.tiles_per_sample / p.wgs_per_sample);
-  const int t_lim = dyn ? range_lo(rng + 1) : (int)((long)(wg + 1) * p.tiles_per_sample / p.wgs_per_sample);
-  const int t_end = dyn ? (t_begin + p.unit < t_lim ? t_begin + p.unit : t_lim) : t_lim;
+  const int t_begin = (int)((long)wg * p.tiles_per_sample / p.wgs_per_sample);
+  const int t_end = (int)((long)(wg + 1) * p.tiles_per_sample / p.wgs_per_sample);
   const int first = t_begin < t_end ? t_begin : WG_NONE;
 
   if (loader) {
@@ -257,13 +242,10 @@ __device__ __forceinline__ void wgrad_tiled_body(const WgTiledParams& p, const i
       if (ttid == 0) *tcnt = 0;
     }
     int prev_tile = WG_NONE;
-    int c_end = t_end, take = 0, nfail = 0;   // claimer (first loader thread): end of the current unit, the outstanding answer for the next one
-    bool c_first = true;
     for (int k = 0;; ++k) {
       const int tile = k == 0 ? first : __builtin_amdgcn_readfirstlane(ctl[k & 3]);
       const bool have = tile < WG_NONE;
       WPROF_T(l0);
-      if (dyn && have && ttid == 0 && c_first) take = rtp_claim_take(p.claim + n * p.ranges + rng, 1);   // the NEXT unit: asked for now
       if (have) {
         bf16_t* xL = lds + (k & 1) * BUF;
         const int tz = tile % p.tiles_z, tx = (tile / p.tiles_z) % p.tiles_x, ty = tile / (p.tiles_z * p.tiles_x);  // z fastest
@@ -328,27 +310,7 @@ __device__ __forceinline__ void wgrad_tiled_body(const WgTiledParams& p, const i
           }
         }
       }
-      if (ttid == 0 && have) {   // publish brick k + 1
-        int nxt = WG_NONE;
-        if (tile + 1 < c_end) {
-          nxt = tile + 1;
-          c_first = false;
-        } else if (dyn) {   // the unit is done: the next one, from the answer asked for at its first brick
-          int u = take;
-          for (;;) {   // home range empty: the other ranges (cyclically, each at most once), one round trip each
-            const int lo = range_lo(rng), len = range_lo(rng + 1) - lo, b = p.unit * (wgs_r + u);
-            // (every workgroup of the sample ends with exactly one failed take on every range's counter; the first wgs_r units
-            // of a range are never asked for)
-            rtp_claim_reset_if_last(p.claim + n * p.ranges + rng, u, (len + p.unit - 1) / p.unit - wgs_r, p.wgs_per_sample);
-            if (b < len) { nxt = lo + b; c_end = lo + (b + p.unit < len ? b + p.unit : len); break; }
-            if (++nfail >= p.ranges) break;
-            rng = rng + 1 == p.ranges ? 0 : rng + 1;
-            u = rtp_claim_take(p.claim + n * p.ranges + rng, 1);
-          }
-          c_first = true;
-        }
-        ctl[(k + 1) & 3] = nxt;
-      }
+      if (ttid == 0 && have) ctl[(k + 1) & 3] = tile + 1 < t_end ? tile + 1 : WG_NONE;   // publish brick k + 1
       prev_tile = tile;
       WPROF_T(l2);
       WPROF_ADD(5, l1, l2);
@@ -519,19 +481,20 @@ void wgrad_tiled_kernel(WgTiledParams p) {
   wgrad_tiled_body(p, n, bid - n * p.wgs_per_sample);
 }
 
-// Several weight gradients in one launch (rtp_multi.h, conv_tiled.hip's conv_tiled_multi_kernel): sample = XCD, every XCD's 32
-// workgroups split between the problems in proportion to their bricks.
-#define RTP_MULTI_MAX 4
+// Several weight gradients in one launch (rtp_multi.h, conv_tiled.hip's conv_tiled_multi_kernel): every sample's 256 / n workgroups
+// (n = 8: an XCD's 32) split between the problems in proportion to their bricks.
 struct WgMulti { const WgTiledParams* jobs; int njobs; int split[RTP_MULTI_MAX + 1]; };
 __global__ __attribute__((amdgpu_flat_work_group_size(WG_THREADS, WG_THREADS), amdgpu_waves_per_eu(WG_THREADS / 256, WG_THREADS / 256)))
 void wgrad_tiled_multi_kernel(WgMulti m) {
-  const int xcd = (int)(blockIdx.x % 8), l = (int)(blockIdx.x / 8);
+  const int per = m.split[m.njobs];   // workgroups per sample
+  const int bid = (gridDim.x % 8 == 0) ? (int)(blockIdx.x % 8) * (int)(gridDim.x / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
+  const int n = bid / per, l = bid - n * per;
   int j = 0;
 #pragma unroll
   for (int k = 1; k < RTP_MULTI_MAX; ++k) j += (k < m.njobs && l >= m.split[k]) ? 1 : 0;
   j = __builtin_amdgcn_readfirstlane(j);
   const WgTiledParams p = m.jobs[j];
-  wgrad_tiled_body(p, xcd, l - m.split[j]);
+  wgrad_tiled_body(p, n, l - m.split[j]);
 }
 
 // 32 -> <=32 channels: one launch.  Cin = 32 K, Cout = 32 J (K * J > 1, the feat64 backbone's layers): K x J launches, each
@@ -594,24 +557,13 @@ int rtp_wgrad_tiled_try(const RtpAct* gy, const RtpAct* x, const RtpConvGeom* g,
   p.tiles_y = p.H / TY; p.tiles_x = (p.W + TX - 1) / TX; p.tiles_z = p.D / TZ;
   p.tiles_per_sample = (p.D / TZ) * p.tiles_y * p.tiles_x;
   p.wgs_per_sample = nsplit; p.part_stride = nsplit;
-  if (const int hint = rtp_tiled_width_for(gp)) {   // fewer workgroups than slabs (the upper slabs stay zero): CUs left to other lanes
-    const int hw = hint / g->n;
+  if (g->wgs > 0) {   // RtpConvGeom::wgs: fewer workgroups than slabs (the upper slabs stay zero): CUs left to other streams
+    const int hw = g->wgs / g->n;
     if (hw >= 1 && hw < nsplit) p.wgs_per_sample = hw;
   }
   static const int dbg = getenv("RTP_TILED_DBG") ? atoi(getenv("RTP_TILED_DBG")) : 0;
   p.dbg = dbg;
   p.wd = (const bf16_t*)wd; p.qpart = wd ? qpart : nullptr; p.tg = tg;
-  // dynamic brick claiming (rtp_claim.h; RTP_CLAIM=1 switches it on; default: the static deal)
-  p.claim = nullptr; p.ranges = 1; p.total_wgs = p.N * nsplit; p.unit = 1;
-  if (rtp_claim_enabled()) {
-    int ranges = 1;
-    const int grid = p.N * nsplit;
-    if (grid % 8 == 0 && p.N < 8 && 8 % p.N == 0 && nsplit % (8 / p.N) == 0 && p.tiles_per_sample >= 8 * (8 / p.N)) ranges = 8 / p.N;
-    p.claim = rtp_claim_slot(gp, p.N * ranges);
-    p.ranges = p.claim ? ranges : 1;
-    static const int unit = getenv("RTP_WGRAD_UNIT") ? atoi(getenv("RTP_WGRAD_UNIT")) : 2;
-    p.unit = (unit >= 2 && p.tiles_per_sample / p.ranges >= 4 * (nsplit / p.ranges)) ? 2 : 1;
-  }
   const size_t shm_base = sizeof(bf16_t) * 2 * (size_t)(HALO_VOX + BRICK_VOX) * 32 + 32;
   const size_t shm = shm_base + (tg ? 4 * 27 * 32 * sizeof(float) + 16 : 0);
   if (std::vector<RtpMultiJob>* cap = rtp_multi_capture()) {   // recorded for a shared launch (rtp_multi.h), not issued
@@ -620,7 +572,6 @@ int rtp_wgrad_tiled_try(const RtpAct* gy, const RtpAct* x, const RtpConvGeom* g,
     job.variant = tg ? 1 : 0;   // (the subset-sum tables change the LDS size)
     job.tiles_per_sample = p.tiles_per_sample; job.n = p.N; job.slots_per_sample = nsplit; job.shm = shm;
     job.fam = RTP_FAM_WGRAD_TILED;
-    p.claim = nullptr; p.ranges = 1; p.unit = 1;
     job.params.assign((const char*)&p, (const char*)&p + sizeof(p));
     cap->push_back(job);
     return RTP_OK;
@@ -638,7 +589,7 @@ int rtp_wgrad_tiled_try(const RtpAct* gy, const RtpAct* x, const RtpConvGeom* g,
 
 // ---- shared launches (rtp_multi.h)
 namespace {
-struct WgMultiLauncher { WgMulti m; size_t shm; };
+struct WgMultiLauncher { WgMulti m; size_t shm; int n; };
 }
 
 int rtp_wgrad_tiled_multi_finish(std::vector<RtpMultiJob>& jobs, const int* share, void* dev_params, void** launcher) {
@@ -647,13 +598,12 @@ int rtp_wgrad_tiled_multi_finish(std::vector<RtpMultiJob>& jobs, const int* shar
   std::vector<WgTiledParams> host(jobs.size());
   WgMultiLauncher* L = new WgMultiLauncher();
   L->shm = jobs[0].shm;
-  L->m.jobs = (const WgTiledParams*)dev_params; L->m.njobs = (int)jobs.size();
+  L->m.jobs = (const WgTiledParams*)dev_params; L->m.njobs = (int)jobs.size(); L->n = jobs[0].n;
   int at = 0;
   for (size_t j = 0; j < jobs.size(); ++j) {
     if (jobs[j].params.size() != sizeof(WgTiledParams)) { delete L; return RTP_ERR_SHAPE; }
     memcpy(&host[j], jobs[j].params.data(), sizeof(WgTiledParams));
     host[j].wgs_per_sample = share[j];   // (part_stride keeps the slots the slab / partial buffers were sized for)
-    host[j].total_wgs = 8 * share[j];
     L->m.split[j] = at;
     at += share[j];
   }
@@ -665,7 +615,9 @@ int rtp_wgrad_tiled_multi_finish(std::vector<RtpMultiJob>& jobs, const int* shar
 
 int rtp_wgrad_tiled_multi_launch(void* launcher, hipStream_t s) {
   WgMultiLauncher* L = (WgMultiLauncher*)launcher;
-  hipLaunchKernelGGL(wgrad_tiled_multi_kernel, dim3(8 * L->m.split[L->m.njobs]), dim3(WG_THREADS), L->shm, s, L->m);
+  hipLaunchKernelGGL(wgrad_tiled_multi_kernel, dim3(L->n * L->m.split[L->m.njobs]), dim3(WG_THREADS), L->shm, s, L->m);
   RTP_CHECK_LAUNCH();
   return RTP_OK;
 }
+
+void rtp_wgrad_tiled_multi_drop(void* launcher) { delete (WgMultiLauncher*)launcher; }

@@ -85,9 +85,15 @@ class FlatParams:
 # 91 us against 78 on 256), so leaving 64 CUs free costs them 5 % and lets the chains run BESIDE them: 5.77-5.88 -> 5.62-5.66 ms per
 # step (-2.5 ... -3.5 %, five same-box pairs).  Forward convs and weight gradients of the full-resolution branch in stages 2-4, the
 # conv3 data gradients of stages 3-4; data gradients elsewhere, 208 / 176 / 160 workgroups, the head and layer1: no better or worse.
-# Results do not change (include/rtp.h: rtp_tiled_width_hint).  RTP_WIDTH_HINTS="" switches them off, any other value replaces them.
+# Results do not change (include/rtp.h: RtpConvGeom::wgs).  RTP_WIDTH_HINTS="" switches them off, any other value replaces them.
+# The width is an explicit field of each launch's geometry, fixed when the plan is built (graph.Graph.with_width).
 DEFAULT_WIDTH_HINTS = ";".join(["conv:s%d.b0=192" % s for s in (2, 3, 4)] + ["wgrad:s%d.b0=192" % s for s in (2, 3, 4)]
                                + ["dgrad:s4.b0.c3=192", "dgrad:s3.b0.c3=192"])
+
+
+def parse_width_hints(spec):
+    """"tag-prefix=workgroups;..." (e.g. "conv:s3.b0=192;wgrad:s4.b0=208") -> [(prefix, workgroups)] in order (first match wins)."""
+    return [(k.strip(), int(v)) for k, v in (item.split("=") for item in (spec or "").split(";") if "=" in item) if int(v) > 0]
 
 
 class PoseEngine:
@@ -101,7 +107,9 @@ class PoseEngine:
         self.loss_weight = float(loss_weight)
         cin = net.ARCH_TABLES[arch]["inplanes"]
         be = backend
-        g = self.graph = Graph(be, batch, params, train=train, pgrads=pgrads)
+        # width hints: measured at B = 8 (the bench workload); for other batch sizes set RTP_WIDTH_HINTS explicitly
+        rules = parse_width_hints(os.environ.get("RTP_WIDTH_HINTS", DEFAULT_WIDTH_HINTS if batch == 8 else ""))
+        g = self.graph = Graph(be, batch, params, train=train, pgrads=pgrads, width_rules=rules)
         g.early_flush = bool(early_flush)   # two gradient buckets (trainer): one early flush of the deferred tail
         self.x_in = g.input_f32("rdr", cin, dims)
         self.feats = net.build_hrnet3d(g, self.x_in, arch, dims, final_fuse)
@@ -119,25 +127,16 @@ class PoseEngine:
         if os.environ.get("RTP_FWD_ROW0_FIRST", "1") == "1":
             from .lanes import main_row_first
             self.fwd = main_row_first(self.fwd)
-        # Horizontal fusion (lanes.merge_launches, RTP_MERGE=1): the level-1 branch's convs of a stage join the full-resolution convs
-        # of the same position in ONE launch -- alone they occupy every CU for a ninth of the work.  Measured (hr3d, B = 8): the merged
-        # launches cost 83-89 us against 72 + 27 separately and the serial kernel total drops, but in LANE mode the step gets 0.7-1 %
-        # SLOWER (5.77 -> 5.81-5.83 ms): the main lane is the critical path, and work moved onto it from a side lane lengthens it by
-        # more than the side lane's (largely hidden) launches cost.  Off by default; the one-stream replay is where it pays.
-        self.merged = []
-        self._merge = os.environ.get("RTP_MERGE", "0") == "1" and hasattr(be, "multi") and batch == 8
-        if self._merge:
-            from .lanes import merge_launches
-            pairs = [("conv:s%d.b0.%s" % (st, c), "conv:s%d.b1.%s" % (st, c)) for st in (2, 3, 4) for c in ("c2", "c3")]
-            self.fwd, done = merge_launches(self.fwd, be, pairs)
-            self._account_merged(done, "conv_tiled_full", None)
+        self.merged = []   # (tag_a, tag_b) whose algorithmic cost was re-accounted to a's kernel family (none in the default plan)
         # The two head towers (hm, reg) are independent chains of full-resolution launches on the main lane: they run pairwise in ONE
         # launch, each problem on half of every XCD's workgroups (lanes.merge_launches -> HipBackend.multi -> rtp_multi_*).  Alone a
         # full-resolution tiled kernel is limited by fixed costs, power and HBM rather than by CUs (91 us on 128 workgroups against 78
         # on 256), so two of them side by side finish well before two in a row: hr3d 5.56 -> 5.48 ms per step (-1.4 %, two same-box
         # pairs) with five pairs merged -- conv .0 / .2, dgrad .2, wgrad .0 / .2; dgrad:head.reg.0 adds dgrad:head.hm.0's result in
-        # its epilogue and stays behind it.  (Unlike RTP_MERGE above this moves nothing ONTO the main lane.)  RTP_MERGE_HEAD=0: off.
-        self._merge_head = os.environ.get("RTP_MERGE_HEAD", "1") == "1" and hasattr(be, "multi") and batch == 8
+        # its epilogue and stays behind it.  (Merging a side lane's level-1 convs INTO the main lane's full-resolution launches of the same
+        # position -- round 4's RTP_MERGE -- measured 0.7-1 % slower in lane mode: work moved onto the critical path; removed.)
+        # Any batch whose samples tile the chip's 256 workgroups (rtp_multi_end: n divides 256).  RTP_MERGE_HEAD=0: off.
+        self._merge_head = os.environ.get("RTP_MERGE_HEAD", "1") == "1" and hasattr(be, "multi") and 256 % batch == 0
         self.merged_head = []
         if self._merge_head:
             from .lanes import merge_launches
@@ -197,44 +196,14 @@ class PoseEngine:
                 # the level-2 lane's chain had arrived (-1 % on the step; RTP_BWD_F10_FIRST=0: creation order)
                 from .lanes import hoist_tagged
                 self.bwd = hoist_tagged(self.bwd, r":s3\.f10\.0$", r":s3\.(row2|f2)")
-            if self._merge:
-                from .lanes import merge_launches
-                kinds = ("wgrad", "dgrad") if not os.environ.get("RTP_NO_MERGE_WGRAD") else ("dgrad",)
-                pairs = [("%s:s%d.b0.%s" % (k, st, c), "%s:s%d.b1.%s" % (k, st, c)) for st in (4, 3, 2) for c in ("c3", "c2") for k in kinds]
-                self.bwd, done = merge_launches(self.bwd, be, pairs)
-                self._account_merged([d for d in done if d[0].startswith("dgrad:")], "conv_tiled_full", "conv_tiled_full_bwd")
             if self._merge_head:
                 from .lanes import merge_launches
                 self.bwd, done = merge_launches(self.bwd, be, [("dgrad:head.hm.2", "dgrad:head.reg.2"), ("dgrad:head.hm.0", "dgrad:head.reg.0"),
-                                                               ("wgrad:head.hm.2", "wgrad:head.reg.2"), ("wgrad:head.hm.0", "wgrad:head.reg.0")]
-                                                if os.environ.get("RTP_MERGE_HEAD_WG4", "0") != "1" else
-                                                [("dgrad:head.hm.2", "dgrad:head.reg.2"),
-                                                 ("wgrad:head.hm.2", "wgrad:head.reg.2", "wgrad:head.hm.0", "wgrad:head.reg.0")])
+                                                               ("wgrad:head.hm.2", "wgrad:head.reg.2"), ("wgrad:head.hm.0", "wgrad:head.reg.0")])
                 self.merged_head += list(done)
             self.bwd_plan = LanePlan(be, self.bwd, self.lane_map)
         self.live_params = set(g.used_params)
-        self.width_hints = self._apply_width_hints(os.environ.get("RTP_WIDTH_HINTS", DEFAULT_WIDTH_HINTS if batch == 8 else ""))
-
-    def _apply_width_hints(self, spec):
-        """spec: "tag-prefix=workgroups;..." (e.g. "conv:s3.b0=192;wgrad:s4.b0=208"): the LDS-tiled launches whose tag starts with a
-        prefix run on that many workgroups instead of one per CU (include/rtp.h: rtp_tiled_width_hint), leaving CUs to the other
-        lanes' dependent chains while they run.  Keyed by the launch's output buffer; results do not change."""
-        lib = getattr(self.be, "lib", None)
-        if lib is None or not hasattr(lib, "rtp_tiled_width_hint"):
-            return []
-        import ctypes as C
-        rules = [(k.strip(), int(v)) for k, v in (item.split("=") for item in (spec or "").split(";") if "=" in item)]
-        done = []
-        for L in list(self.fwd) + list(self.bwd):
-            if not L.writes:
-                continue
-            # the table is keyed by address and outlives the plans that filled it: every output of THIS plan is set or cleared, so a
-            # hint left behind by an earlier engine whose buffer lived at the same address never reaches a launch of this one
-            wgs = next((w for pre, w in rules if L.tag.startswith(pre)), 0)
-            lib.rtp_tiled_width_hint(C.c_void_p(L.writes[0]), wgs)
-            if wgs:
-                done.append((L.tag, wgs))
-        return done
+        self.width_hints = list(g.widths_applied)   # [(tag, workgroups)] the rules reached
 
     def _account_merged(self, done, *families):
         """The merged-in launches' algorithmic FLOPs / bytes join the family their shared launch is timed under (bench.py roofline)."""

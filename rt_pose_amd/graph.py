@@ -21,7 +21,7 @@ emulation of each kernel to check this file's plan logic without a GPU).  Every 
 closure f(stream) so argument marshalling happens once, at build time.
 """
 import os
-from dataclasses import dataclass, field
+from dataclasses import dataclass, field, replace
 from typing import List, Optional
 
 from .lanes import Launch, L_FULL, L_MID, L_LOW, L_LOW3, L_WG, L_WG_LOW
@@ -51,6 +51,7 @@ class Geom:
     pad: int
     w_ci_total: int = 0
     w_ci_off: int = 0
+    wgs: int = 0     # launch width of the LDS-tiled kernels (include/rtp.h RtpConvGeom::wgs): 0 = one workgroup per CU
 
 
 class View:
@@ -126,11 +127,15 @@ def wgrad_split(vox):
 
 
 class Graph:
-    def __init__(self, backend, n, params, train=True, pgrads=None):
+    def __init__(self, backend, n, params, train=True, pgrads=None, width_rules=()):
         """params: dict name -> fp32 tensor (reference state_dict names/shapes).
         pgrads: optional dict name -> fp32 tensor the backward plan writes parameter gradients into
-        (views of a flat buffer); allocated per parameter when absent."""
+        (views of a flat buffer); allocated per parameter when absent.
+        width_rules: [(launch-tag prefix, workgroups)]: the LDS-tiled launches whose tag starts with a prefix run on that many
+        workgroups (first match wins) -- an explicit field of the launch's geometry (Geom.wgs -> RtpConvGeom::wgs)."""
         self.be, self.n, self.params, self.train = backend, n, params, train
+        self.width_rules = [(str(k), int(v)) for k, v in width_rules]
+        self.widths_applied = []   # (tag, workgroups) of the launches a rule reached
         self._pgrads_ext = pgrads
         self.fwd: List = []
         self.bwd: List = []
@@ -141,9 +146,8 @@ class Graph:
         self.bytes = 0
         self.tail_a, self.tail_b = [], []   # deferred optimiser-only items (emit_tail)
         import os
-        # folds per flush: earlier, smaller flushes on the weight-gradient lane measured the same as one flush at the end
-        # (1 158-1 170 frames/s for 12 / 20 / all), so the default is a single flush; RTP_TAIL_BATCH for experiments
-        self.tail_batch = int(os.environ.get("RTP_TAIL_BATCH", "1000000"))
+        # (folds are flushed once, at the end of the sweep: earlier, smaller flushes on the weight-gradient lane measured the same,
+        # 1 158-1 170 frames/s for 12 / 20 / all in round 1)
         self._defer_wg = [int(v) for v in os.environ.get("RTP_DEFER_WG", "3").split(",") if v.strip() != ""]
         self._defer_keep = int(os.environ.get("RTP_DEFER_KEEP", "4"))
         # at most this many launches move (the two 32-channel head towers of hr3d: 8; the wide heads of the one-heat-map configs
@@ -173,6 +177,14 @@ class Graph:
                           "conv_tiled_full_bwd": 0}
 
     # ------------------------------------------------------------------ helpers
+    def with_width(self, geom, tag):
+        """`geom` for the launch tagged `tag`: a copy carrying the launch width of the first matching rule, or geom itself."""
+        wgs = next((w for pre, w in self.width_rules if tag.startswith(pre)), 0)
+        if not wgs:
+            return geom
+        self.widths_applied.append((tag, wgs))
+        return replace(geom, wgs=wgs)
+
     def _add_op(self, op):
         op.group = self.group
         self.ops.append(op)
@@ -569,8 +581,6 @@ class Graph:
             if gy is None:
                 continue
             op.emit_backward(gy)
-            if len(self.tail_b) >= self.tail_batch:   # optional early flush on the weight-gradient lane
-                self.emit_tail(L_WG_LOW)
         self.emit_tail(L_FULL)
 
     def emit_tail(self, lane=L_FULL):
@@ -674,13 +684,14 @@ class ConvOp:
             self.wt = be.alloc((ntap, ge.co, ge.ci), "f32")   # tap-major fp32 copy of the master, made by the step's opening launch
             g.head.append(("pack_wt", w, self.co_real, ge.co, ge.ci, ntap, self.wt))
             g.emit_fwd(be.conv_gn_fused(self.x, self.wt, bias, gamma, beta, stats, self.x.stats_split, self.groups, GN_EPS, self.co_real,
-                                        self.mr, self.residual, self.y, ge, self.relu, self.y.stats if fstats else None),
+                                        self.mr, self.residual, self.y, g.with_width(ge, "conv:" + self.name), self.relu,
+                                        self.y.stats if fstats else None),
                        lane, [self.x, self.wt, stats, self.residual], [self.y, self.mr, self.y.stats if fstats else None],
                        "conv:" + self.name)
         else:
             kw = dict(ws=g.slice_ws(lane, g.n * self.y.vox * 32)) if self.sliced_fwd else {}
-            g.emit_fwd(be.conv(self.x, self.wf, nw > 1, self.btab, self.residual, self.y, ge, self.relu, False,
-                               self.out_fp32, fstats, **kw),
+            g.emit_fwd(be.conv(self.x, self.wf, nw > 1, self.btab, self.residual, self.y, g.with_width(ge, "conv:" + self.name), self.relu,
+                               False, self.out_fp32, fstats, **kw),
                        lane, [self.x, self.wf, self.btab, self.residual, kw.get("ws")],
                        [self.y, self.y.stats if fstats else None, kw.get("ws")], "conv:" + self.name)
         self.alg_flops = 2 * g.n * ge.do * ge.ho * ge.wo * self.co_real * self.ci_real * ntap
@@ -730,7 +741,8 @@ class ConvOp:
             pq = be.alloc((g.n, S or x.stats_split, ge.ci, 2), "f32") if self.gn else None
             lane = g.lane_of(self.y)   # a stride-2 conv's data gradient runs with the LOWER-resolution group
             kw = dict(ws=g.slice_ws(lane, g.n * x.vox * 32)) if self.sliced_bwd else {}
-            g.emit_bwd(be.conv(gy, wd, False, None, None, dxh, ge, False, True, False, (x, pq) if S else None, **kw),
+            g.emit_bwd(be.conv(gy, wd, False, None, None, dxh, g.with_width(ge, "dgrad:" + self.name), False, True, False,
+                               (x, pq) if S else None, **kw),
                        lane, [gy, wd, x if S else None, kw.get("ws")], [dxh, pq if S else None, kw.get("ws")], "dgrad:" + self.name)
             g.flops["conv_dgrad"] += self.alg_flops
             if self.sliced_bwd:
@@ -775,10 +787,11 @@ class ConvOp:
         # a conv with bias and without GroupNorm on the tiled weight-gradient kernel: its loader waves sum gy as a by-product (tg),
         # the bias gradient is read off those sums in the tail -- no class-sum pass over gy (the head towers: 84 MB each)
         tg = self._bias_tg(S) if self.tiled_wgrad else None
+        gw = g.with_width(ge, "wgrad:" + self.name)
         if tg is not None:
-            g.emit_bwd(be.wgrad_tg(gy, x, ge, S, gp, tg), wl, [gy, x], [gp, tg], "wgrad:" + self.name)
+            g.emit_bwd(be.wgrad_tg(gy, x, gw, S, gp, tg), wl, [gy, x], [gp, tg], "wgrad:" + self.name)
         else:
-            g.emit_bwd(be.wgrad(gy, x, ge, S, gp), wl, [gy, x], [gp], "wgrad:" + self.name)
+            g.emit_bwd(be.wgrad(gy, x, gw, S, gp), wl, [gy, x], [gp], "wgrad:" + self.name)
         g.flops["wgrad"] += self.alg_flops
         g.flops["wgrad_tiled" if self.tiled_wgrad else "wgrad_generic"] += self.alg_flops
         g.alg_bytes["wgrad_tiled" if self.tiled_wgrad else "wgrad_generic"] += 2 * g.n * (gy.vox * co32 + x.vox * ge.ci) + (
@@ -855,11 +868,12 @@ class ConvOp:
         # ---- weight gradient (for a GroupNorm conv it now precedes the data gradient: its slabs give Q)
         gp = be.alloc((g.n, S, ntap, co32, ge.ci), "f32")
         coeff = gnq = None
+        gw, gd = g.with_width(ge, "wgrad:" + self.name), g.with_width(ge, "dgrad:" + self.name)
         if self.gn and ge.stride == 2:
             # the generic weight-gradient kernel's slabs, contracted with the weights by a small launch; P in the data gradient's
             # prologue from gy's boundary-class sums
             qpart = be.alloc((g.n, S, ge.ci), "f32")
-            g.emit_bwd(be.wgrad(gy, x, ge, S, gp), lane, [gy, x], [gp], "wgrad:" + self.name)
+            g.emit_bwd(be.wgrad(gy, x, gw, S, gp), lane, [gy, x], [gp], "wgrad:" + self.name)
             g.emit_bwd(be.qpart_from_slabs(gp, g.n, S, ntap, co32, ge.ci, self.wd, qpart), lane, [gp, self.wd], [qpart],
                        "qslab:" + self.name)
             coeff = be.alloc((g.n * ge.ci * 5,), "f32")
@@ -868,7 +882,7 @@ class ConvOp:
             g.tail_a.append(("gn_param", coeff, g.n, self.ci_real, g.pgrad[self.gn[0]], g.pgrad[self.gn[1]], 0))
         elif self.gn:
             qpart = be.alloc((g.n, S, ge.ci), "f32")
-            g.emit_bwd(be.wgrad_q(gy, x, ge, S, gp, self.wd, qpart, tg), lane, [gy, x, self.wd], [gp, qpart, tg], "wgrad:" + self.name)
+            g.emit_bwd(be.wgrad_q(gy, x, gw, S, gp, self.wd, qpart, tg), lane, [gy, x, self.wd], [gp, qpart, tg], "wgrad:" + self.name)
             coeff = be.alloc((g.n * ge.ci * 5,), "f32")
             if own_kernel:
                 g.emit_bwd(be.gn_bwd_coeffs_cls(qpart, S, csum, 1, None, self.wd, self.mr, g.params[self.gn[0]], ge,
@@ -884,9 +898,9 @@ class ConvOp:
                            gamma=g.params[self.gn[0]], groups=self.groups, coeff_out=coeff)
             g.tail_a.append(("gn_param", coeff, g.n, self.ci_real, g.pgrad[self.gn[0]], g.pgrad[self.gn[1]], 0))
         elif btg is not None:
-            g.emit_bwd(be.wgrad_tg(gy, x, ge, S, gp, btg), wl, [gy, x], [gp, btg], "wgrad:" + self.name)
+            g.emit_bwd(be.wgrad_tg(gy, x, gw, S, gp, btg), wl, [gy, x], [gp, btg], "wgrad:" + self.name)
         else:
-            g.emit_bwd(be.wgrad(gy, x, ge, S, gp), wl, [gy, x], [gp], "wgrad:" + self.name)
+            g.emit_bwd(be.wgrad(gy, x, gw, S, gp), wl, [gy, x], [gp], "wgrad:" + self.name)
         g.flops["wgrad"] += self.alg_flops
         g.flops["wgrad_tiled" if self.tiled_wgrad else "wgrad_generic"] += self.alg_flops
         g.alg_bytes["wgrad_tiled" if self.tiled_wgrad else "wgrad_generic"] += 2 * g.n * (gy.vox * co32 + x.vox * ge.ci) + (
@@ -912,10 +926,10 @@ class ConvOp:
                 x.grad_tot = (ts, tot)
         if gnq is not None:
             reads += [gnq["qpart"], gnq["p"], gnq["tg"], gnq.get("csum"), self.mr]
-            g.emit_bwd(be.conv_dgrad_fused(gy, self.wd, x, None, terms, x.relu, dx, ge, tot, gnq), lane, reads,
+            g.emit_bwd(be.conv_dgrad_fused(gy, self.wd, x, None, terms, x.relu, dx, gd, tot, gnq), lane, reads,
                        [dx_buf, tot, coeff, gnq["csum_out"]], "dgrad:" + self.name)
         else:
-            g.emit_bwd(be.conv_dgrad_fused(gy, self.wd, x, coeff, terms, x.relu, dx, ge, tot), lane, reads, [dx_buf, tot],
+            g.emit_bwd(be.conv_dgrad_fused(gy, self.wd, x, coeff, terms, x.relu, dx, gd, tot), lane, reads, [dx_buf, tot],
                        "dgrad:" + self.name)
         x.grad, x.final, x.contribs = dx, True, []
         g.flops["conv_dgrad"] += self.alg_flops

@@ -108,42 +108,6 @@ def plan_waits(launches, nlanes=NLANES, lane_of=None):
     return waits, record
 
 
-def reorder_critical_path(launches):
-    """A topological re-ordering of a launch list that issues the launches on the LONGEST dependency chain first.
-
-    Every lane is a FIFO stream that runs its launches in list order, so a launch that is ready early can sit behind one that
-    waits for another lane (head-of-line blocking): e.g. the level-1 lane's 1x1x1 conv that feeds the main lane's fuse row,
-    created after -- hence queued behind -- a stride-2 conv that waits for the main lane's newest tensor.  The dependency edges
-    are the read-after-write / write-after-read / write-after-write relations of the ORIGINAL order (the same ones plan_waits
-    turns into event waits), so any topological order of them computes the same values; among the launches whose predecessors
-    have all been issued, the one with the largest bottom level (its own estimated duration + the longest chain behind it) goes
-    next.  Durations are estimated from the bytes of the buffers a launch names (3 TB/s) plus 4 us."""
-    n = len(launches)
-    preds = _order_preds(launches)
-    succs = [[] for _ in range(n)]
-    for i in range(n):
-        for j in preds[i]:
-            succs[j].append(i)
-    cost = [4e-6 + sum(BUF_BYTES.get(k, 0) for k in set(L.reads) | set(L.writes)) / 3e12 for L in launches]
-    blevel = [0.0] * n
-    for i in range(n - 1, -1, -1):
-        blevel[i] = cost[i] + max((blevel[j] for j in succs[i]), default=0.0)
-    import heapq
-    indeg = [len(p) for p in preds]
-    heap = [(-blevel[i], i) for i in range(n) if indeg[i] == 0]
-    heapq.heapify(heap)
-    order = []
-    while heap:
-        _, i = heapq.heappop(heap)
-        order.append(i)
-        for j in succs[i]:
-            indeg[j] -= 1
-            if indeg[j] == 0:
-                heapq.heappush(heap, (-blevel[j], j))
-    assert len(order) == n
-    return [launches[i] for i in order]
-
-
 def _order_preds(launches):
     """Read-after-write / write-after-read / write-after-write predecessors of every launch in the list's own order."""
     last_w, readers = {}, {}
@@ -323,8 +287,6 @@ class LanePlan:
     def __init__(self, backend, launches, lane_map=None):
         self.be = backend
         self.launches = [x if isinstance(x, Launch) else Launch(x) for x in launches]
-        if os.environ.get("RTP_REORDER", "0") == "1":
-            self.launches = reorder_critical_path(self.launches)
         self.lane_map = lane_map
         self.lane_of = [lane_map[L.lane] if lane_map is not None else L.lane for L in self.launches]
         self.lanes_used = sorted(set(self.lane_of))

@@ -74,8 +74,12 @@ class _TapMajor:
 class EmuBackend:
     name = "emu"
 
-    def __init__(self, exact=False, fast=False, noise=0.0, seed=0):
-        """exact=True keeps every 'bf16' buffer in fp32: isolates plan-logic errors from rounding.
+    def __init__(self, exact=False, fast=False, noise=0.0, seed=0, device="cpu"):
+        """device: where the emulation's buffers and arithmetic live.  "cpu" (default) or a GPU ("cuda:0"): the emulated plan is
+        plain torch ops, so at the dataset-native shape the -m gpu tests run it on the device with torch's own kernels (minutes on
+        the host's cores, seconds there).  The caller runs the plan inside `with be.on_device():` so that the temporaries the
+        closures create (torch.zeros / torch.tensor / torch.arange ...) land on the same device as the buffers.
+        exact=True keeps every 'bf16' buffer in fp32: isolates plan-logic errors from rounding.
         fast=True: the weight-gradient emulation puts the whole correlation into slab 0 (one pass per sample instead of one
         per slab; the slabs' sum -- all the plan consumes -- is the same) for native-shape comparisons.
         noise > 0: a model of ANOTHER SUMMATION ORDER.  Every fp32 value is multiplied by (1 + noise * N(0, 1)) right before it is
@@ -86,17 +90,22 @@ class EmuBackend:
         self.exact = exact
         self.fast = fast
         self.noise = float(noise)
-        self._gen = torch.Generator().manual_seed(seed) if noise else None
+        self.device = torch.device(device)
+        self._gen = torch.Generator(device=self.device).manual_seed(seed) if noise else None
+
+    def on_device(self):
+        """Context manager: torch factory calls default to this backend's device (a no-op for "cpu")."""
+        return torch.device(self.device)
 
     def _store(self, v, val):
         if self.noise and v.buf.dtype == torch.bfloat16:
-            val = val * (1.0 + self.noise * torch.randn(val.shape, generator=self._gen, dtype=val.dtype))
+            val = val * (1.0 + self.noise * torch.randn(val.shape, generator=self._gen, dtype=val.dtype, device=val.device))
         _store(v, val)
 
     def alloc(self, shape, dtype):
         if self.exact and dtype == "bf16":
             dtype = "f32"
-        return torch.zeros(shape, dtype=_DT[dtype])
+        return torch.zeros(shape, dtype=_DT[dtype], device=self.device)
 
     def stream(self):
         return None
@@ -704,7 +713,7 @@ class EmuBackend:
 
     # ---------------------------------------------------------------- head
     def focal_scratch(self, n):
-        return torch.zeros(2)
+        return torch.zeros(2, device=self.device)
 
     def focal_loss(self, logits, target, ind, mask, cat, ncls, gscale, scratch, out_loss, ghm, write_pad=True):
         @torch.enable_grad()
@@ -746,7 +755,7 @@ class EmuBackend:
         return run
 
     def decode_scratch(self, n, ncls):
-        return torch.zeros(1)
+        return torch.zeros(1, device=self.device)
 
     def decode(self, hm, reg, ncls, nreg, scale_xyz, origin_xyz, scratch, out):
         def run(s):

@@ -174,34 +174,24 @@ def test_merge_launches_keeps_every_dependency():
 
 
 def test_width_hint_rules_reach_the_right_launches():
-    """PoseEngine._apply_width_hints: first matching tag prefix wins, every other output of the plan is CLEARED (the C-side table is
-    keyed by address and outlives plans), launches without outputs are left alone."""
-    from rt_pose_amd.engine import PoseEngine, DEFAULT_WIDTH_HINTS
+    """Width rules are resolved when the plan is built (graph.Graph.with_width): first matching tag prefix wins, the width travels
+    as an explicit field of that launch's geometry (Geom.wgs -> RtpConvGeom::wgs), every other launch keeps wgs = 0 -- no table on
+    the C side that could outlive the plan."""
+    from rt_pose_amd.engine import PoseEngine, DEFAULT_WIDTH_HINTS, parse_width_hints
+    from rt_pose_amd.graph import Graph, Geom
 
-    class Lib:
-        def __init__(self):
-            self.calls = []
-
-        def rtp_tiled_width_hint(self, key, wgs):
-            self.calls.append((key.value, wgs))
-            return 0
-
-    class Be:
-        lib = Lib()
-
-    class L:
-        def __init__(self, tag, writes):
-            self.tag, self.writes = tag, writes
-
-    eng = PoseEngine.__new__(PoseEngine)
-    eng.be = Be()
-    eng.fwd = [L("conv:s3.b0.c2", (11,)), L("conv:s3.b1.c2", (12,)), L("fuse:s3.row0", (13,)), L("stats", ())]
-    eng.bwd = [L("wgrad:s3.b0.c2", (21, 22)), L("dgrad:s3.b0.c3", (23,)), L("dgrad:s3.b0.c2", (24,))]
-    done = eng._apply_width_hints("conv:s3.b0=192;wgrad:s3.b0=176;dgrad:s3.b0.c3=208;conv:s3=64")
-    assert done == [("conv:s3.b0.c2", 192), ("conv:s3.b1.c2", 64), ("wgrad:s3.b0.c2", 176), ("dgrad:s3.b0.c3", 208)]
-    assert Be.lib.calls == [(11, 192), (12, 64), (13, 0), (21, 176), (23, 208), (24, 0)]
-    Be.lib.calls.clear()
-    assert eng._apply_width_hints("") == [] and [w for _, w in Be.lib.calls] == [0] * 6     # switched off: everything cleared
+    rules = parse_width_hints("conv:s3.b0=192;wgrad:s3.b0=176;dgrad:s3.b0.c3=208;conv:s3=64;conv:s4=0")
+    assert rules == [("conv:s3.b0", 192), ("wgrad:s3.b0", 176), ("dgrad:s3.b0.c3", 208), ("conv:s3", 64)]
+    g = Graph.__new__(Graph)
+    g.width_rules, g.widths_applied = rules, []
+    ge = Geom(8, 16, 64, 160, 16, 64, 160, 32, 32, 3, 1, 1)
+    got = {t: g.with_width(ge, t).wgs for t in ("conv:s3.b0.c2", "conv:s3.b1.c2", "fuse:s3.row0", "wgrad:s3.b0.c2", "dgrad:s3.b0.c3",
+                                                "dgrad:s3.b0.c2")}
+    assert got == {"conv:s3.b0.c2": 192, "conv:s3.b1.c2": 64, "fuse:s3.row0": 0, "wgrad:s3.b0.c2": 176, "dgrad:s3.b0.c3": 208,
+                   "dgrad:s3.b0.c2": 0}
+    assert ge.wgs == 0 and g.with_width(ge, "fuse:s3.row0") is ge, "the shared geometry object is never modified"
+    assert g.widths_applied == [("conv:s3.b0.c2", 192), ("conv:s3.b1.c2", 64), ("wgrad:s3.b0.c2", 176), ("dgrad:s3.b0.c3", 208)]
+    assert parse_width_hints("") == [] and parse_width_hints(None) == []
     # the shipped default names launches that exist in the hr3d plan
     pre = [r.split("=")[0] for r in DEFAULT_WIDTH_HINTS.split(";")]
     from tests.emu_backend import EmuBackend
@@ -213,9 +203,11 @@ def test_width_hint_rules_reach_the_right_launches():
     shapes = configs.param_shapes("hr3d")
     flat = FlatParams(shapes, be.alloc)
     flat.load_state_dict(init_state_dict(shapes, 0))
-    real = PoseEngine(be, flat.values, s["arch"], s["final_fuse"], s["heads"], s["weight"], s["code_weights"], 1, (8, 16, 32), train=True, pgrads=flat.grads)
+    real = PoseEngine(be, flat.values, s["arch"], s["final_fuse"], s["heads"], s["weight"], s["code_weights"], 8, (4, 8, 16), train=True, pgrads=flat.grads)
     tags = [x.tag for x in real.fwd + real.bwd]
     assert all(any(t.startswith(p) for t in tags) for p in pre), [p for p in pre if not any(t.startswith(p) for t in tags)]
+    # ... and the eight-sample plan (the bench's batch) carries them: every rule reached at least one launch
+    assert real.width_hints and all(any(t.startswith(p) for t, _ in real.width_hints) for p in pre)
 
 
 def test_four_stream_map_is_chosen_where_it_pays_and_orders_every_hazard():
