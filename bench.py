@@ -496,6 +496,28 @@ def main():
                 "final_loss": round(float(otr.losses()["loss"]), 5)}
             del otr
             torch.cuda.empty_cache()
+    # The headline model at other frames-per-GPU counts (the reference's own hr3d batch is 16 per GPU, configs/cruw_pose/hr3d.py:7): the
+    # same plan rules (four-stream lane map, width hints, shared head launches) for every batch; 3 warm-up + 10 timed steps each
+    if world == 1 and not args.no_other_models and args.model == "hr3d" and args.batch == 8:
+        line["other_batches"] = {}
+        for ob in (4, 16):
+            otr = DataParallelTrainer("hr3d", ob, configs.NATIVE_DIMS, total_steps=100, device=dev, use_graph=False, backend=tr.be,
+                                      stream=tr.stream)
+            otr.load(synth.make_batch(ob, spec["cin"], configs.NATIVE_DIMS, seed=1234, one_hm=False))
+            for _ in range(3):
+                otr.step()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(10):
+                otr.step()
+            torch.cuda.synchronize()
+            el_o = time.perf_counter() - t1
+            line["other_batches"][str(ob)] = {"value": round(ob * 10 / el_o, 2), "unit": "frames/s", "ms_per_step": round(1e2 * el_o, 3),
+                                              "steps": 10, "frames_per_gpu": ob,
+                                              "mfma_frac_whole_step": round(ob * 10 / el_o * train_flops_per_frame / (PEAK_BF16_TFLOPS * 1e12), 4),
+                                              "final_loss": round(float(otr.losses()["loss"]), 5)}
+            del otr
+            torch.cuda.empty_cache()
     # BASELINE config 4, op level (the reference's DCN head cannot run on its own 5-D feature): DCNv1 3x3,
     # deformable_groups 4, im2col_step 64 on the level-0 feature with Z folded into the batch, [B*16, 32, 64, 160] fp32
     if world == 1 and not args.no_dcn:

@@ -107,8 +107,9 @@ class PoseEngine:
         self.loss_weight = float(loss_weight)
         cin = net.ARCH_TABLES[arch]["inplanes"]
         be = backend
-        # width hints: measured at B = 8 (the bench workload); for other batch sizes set RTP_WIDTH_HINTS explicitly
-        rules = parse_width_hints(os.environ.get("RTP_WIDTH_HINTS", DEFAULT_WIDTH_HINTS if batch == 8 else ""))
+        # width hints: a launch's wgs / batch workgroups per sample, whatever the batch.  Measured (round 5, same box, hr3d, four-stream
+        # map): B = 8 5.44 -> 5.26 ms per step, B = 16 9.44 -> 9.28 (1 694 -> 1 723 frames/s), B = 4 3.69 -> 3.56 (1 083 -> 1 123)
+        rules = parse_width_hints(os.environ.get("RTP_WIDTH_HINTS", DEFAULT_WIDTH_HINTS))
         g = self.graph = Graph(be, batch, params, train=train, pgrads=pgrads, width_rules=rules)
         g.early_flush = bool(early_flush)   # two gradient buckets (trainer): one early flush of the deferred tail
         self.x_in = g.input_f32("rdr", cin, dims)
@@ -146,7 +147,8 @@ class PoseEngine:
         # sliced head whose weight gradients stay there; one stream per lane otherwise
         from .graph import SplitConvOp, CoSplitConvOp
         sliced_head = any(isinstance(op, (SplitConvOp, CoSplitConvOp)) for op in g.ops)
-        self.lane_map = LANE_MAP if ("RTP_LANES" in os.environ or sliced_head or batch != 8) else LANE_MAP_4
+        # (any batch: B = 4 / 16 measured like B = 8 -- 3.83 -> 3.69 and 9.51 -> 9.44 ms per step for the map alone, round 5)
+        self.lane_map = LANE_MAP if ("RTP_LANES" in os.environ or sliced_head) else LANE_MAP_4
         self.fwd_plan = LanePlan(be, self.fwd, self.lane_map)
         self.bwd_plan = None
         self.use_lanes = True      # False: replay everything on the caller's stream in list order

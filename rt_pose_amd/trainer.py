@@ -98,7 +98,7 @@ class DataParallelTrainer:
             # hipStreamEndCapture crashes (ROCm 7.2) on a capture that forks into all six lane streams; three streams
             # capture and replay fine, so graph mode folds the lanes: {full}, {mid, low, lowest}, {weight gradients}
             from .lanes import LanePlan
-            gmap = [0, 1, 1, 2, 2, 1]
+            gmap = [int(v) for v in os.environ.get("RTP_GRAPH_LANES", "0,1,1,2,2,1").split(",")]   # (A/B: "0,1,2,2,3,3" = lanes.LANE_MAP_4)
             self.engine.fwd_plan = LanePlan(self.be, self.engine.fwd, gmap)
             self.engine.bwd_plan = LanePlan(self.be, self.engine.bwd, gmap)
         # All work of a step goes to ONE explicit (non-default) HIP stream: a graph launched on the legacy NULL stream

@@ -14,6 +14,8 @@ sys.path.insert(0, ROOT)
 def main():
     rank, world, port, out, buckets = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], int(sys.argv[5])
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from rt_pose_amd import pin_hw_queues
+    pin_hw_queues()   # before torch selects a device: GPU_MAX_HW_QUEUES is read when HIP initialises (set_device does that)
     import torch
     import torch.distributed as dist
     from rt_pose_amd import synth

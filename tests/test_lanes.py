@@ -211,8 +211,9 @@ def test_width_hint_rules_reach_the_right_launches():
 
 
 def test_four_stream_map_is_chosen_where_it_pays_and_orders_every_hazard():
-    """PoseEngine picks lanes.LANE_MAP_4 (four streams = four hardware queues) for eight-sample plans without channel-sliced heads and
-    one stream per lane otherwise; the waits derived under the four-stream map still order every read/write hazard of both lists."""
+    """PoseEngine picks lanes.LANE_MAP_4 (four streams = four hardware queues) for plans without channel-sliced heads -- any batch:
+    B = 4 / 8 / 16 measured, round 5 -- and one stream per lane otherwise; the waits derived under the four-stream map still order
+    every read/write hazard of both lists, and the default width rules reach the same launches whatever the batch."""
     from tests.emu_backend import EmuBackend
     from rt_pose_amd import configs
     from rt_pose_amd.engine import PoseEngine, FlatParams
@@ -232,7 +233,11 @@ def test_four_stream_map_is_chosen_where_it_pays_and_orders_every_hazard():
     assert len(set(eng.bwd_plan.lane_of)) <= 4
     _check(eng.fwd, eng.fwd_plan.lane_of)
     _check(eng.bwd, eng.bwd_plan.lane_of)
-    assert build("hr3d", 2).lane_map == lanes.LANE_MAP
+    for b in (2, 4, 16):
+        other = build("hr3d", b)
+        assert other.lane_map == lanes.LANE_MAP_4
+        assert [t for t, _ in other.width_hints] == [t for t, _ in eng.width_hints] and other.width_hints
+        _check(other.bwd, other.bwd_plan.lane_of)
     assert build("hr3d_one_hm_doppler", 8).lane_map == lanes.LANE_MAP
 
 
