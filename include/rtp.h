@@ -536,6 +536,16 @@ int rtp_multi_abort(void);
 int rtp_multi_launch(int handle, void* stream);
 int rtp_multi_free(int handle);
 
+/* Ordering events between streams of ONE device (the lane plan's cross-lane dependencies, rt_pose_amd/lanes.py).  system_fence = 0:
+ * hipEventDisableTiming | hipEventDisableSystemFence -- recording the event does not write back and invalidate the caches for the
+ * host (what an ordinary event does after every kernel it follows); a kernel on another stream of the same device that waits for
+ * it is ordered behind the producer by the dispatch packets' own agent-scope release / acquire.  Do NOT use such an event to make
+ * device memory visible to the host or to another GPU.  system_fence = 1: an ordinary event (A/B).  Handles are hipEvent_t. */
+int rtp_event_create(void** ev_out, int system_fence);
+int rtp_event_destroy(void* ev);
+int rtp_event_record(void* ev, void* stream);
+int rtp_stream_wait_event(void* stream, void* ev);
+
 #ifdef __cplusplus
 }
 #endif

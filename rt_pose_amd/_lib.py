@@ -141,6 +141,7 @@ PROTOTYPES = {
     "rtp_prof_enable": [_I, _I],
     "rtp_prof_collect": [_I, C.POINTER(_F), C.POINTER(_I)],
     "rtp_version": [],
+    "rtp_event_create": [C.POINTER(_P), _I], "rtp_event_destroy": [_P], "rtp_event_record": [_P, _P], "rtp_stream_wait_event": [_P, _P],
     "rtp_multi_begin": [], "rtp_multi_param_bytes": [], "rtp_multi_end": [_P, _L, C.POINTER(_I)], "rtp_multi_abort": [],
     "rtp_multi_launch": [_I, _P], "rtp_multi_free": [_I],
 }

@@ -48,6 +48,31 @@ class _MultiLaunch:
             pass
 
 
+class _LaneEvent:
+    """hipEvent_t behind the C ABI (rtp_event_*): record(stream handle) / wait(stream handle), both c_void_p stream pointers."""
+    __slots__ = ("lib", "h")
+
+    def __init__(self, lib, system_fence):
+        self.lib = lib
+        h = C.c_void_p()
+        check(lib.rtp_event_create(C.byref(h), int(system_fence)), "rtp_event_create")
+        self.h = h
+
+    def record(self, stream_ptr):
+        check(self.lib.rtp_event_record(self.h, stream_ptr), "rtp_event_record")
+
+    def wait(self, stream_ptr):
+        check(self.lib.rtp_stream_wait_event(stream_ptr, self.h), "rtp_stream_wait_event")
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.lib.rtp_event_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
 class HipBackend:
     name = "hip"
 
@@ -88,9 +113,11 @@ class HipBackend:
         streams = [cur] + self._lanes[:n - 1]
         return streams, [C.c_void_p(st.cuda_stream) for st in streams]
 
-    @staticmethod
-    def new_event():
-        return torch.cuda.Event()
+    def new_event(self):
+        """An ordering event of the lane plan: device-scope (csrc/lane_events.hip: no system-scope cache writeback / invalidate when
+        it is recorded); RTP_EVENT_FENCE=1: ordinary events with the system fence (A/B)."""
+        import os
+        return _LaneEvent(self.lib, os.environ.get("RTP_EVENT_FENCE", "0") == "1")
 
     def stem_bwd_blocks(self):
         return self.lib.rtp_stem_bwd_blocks()

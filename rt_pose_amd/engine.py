@@ -111,7 +111,8 @@ class PoseEngine:
         # map): B = 8 5.44 -> 5.26 ms per step, B = 16 9.44 -> 9.28 (1 694 -> 1 723 frames/s), B = 4 3.69 -> 3.56 (1 083 -> 1 123)
         rules = parse_width_hints(os.environ.get("RTP_WIDTH_HINTS", DEFAULT_WIDTH_HINTS))
         g = self.graph = Graph(be, batch, params, train=train, pgrads=pgrads, width_rules=rules)
-        g.early_flush = bool(early_flush)   # two gradient buckets (trainer): one early flush of the deferred tail
+        # two gradient buckets (trainer): one early flush of the deferred tail; RTP_EARLY_TAIL=1: the same flush in single-bucket mode (A/B)
+        g.early_flush = bool(early_flush) or os.environ.get("RTP_EARLY_TAIL", "0") == "1"
         self.x_in = g.input_f32("rdr", cin, dims)
         self.feats = net.build_hrnet3d(g, self.x_in, arch, dims, final_fuse)
         # two-stream fusion (BASELINE config 5): the dense LiDAR voxel grid [B, C_l, Z, Y, X] fp32 enters beside the radar feature
@@ -198,6 +199,11 @@ class PoseEngine:
                 # the level-2 lane's chain had arrived (-1 % on the step; RTP_BWD_F10_FIRST=0: creation order)
                 from .lanes import hoist_tagged
                 self.bwd = hoist_tagged(self.bwd, r":s3\.f10\.0$", r":s3\.(row2|f2)")
+            if os.environ.get("RTP_BWD_SINK_WG", "1") == "1" and self.lane_map is LANE_MAP_4:
+                # the lower levels' weight gradients behind the other launches of their stage (they share a stream with the level-3
+                # chain under the four-stream map: lanes.sink_lane_in_segments); RTP_BWD_SINK_WG=0: creation order
+                from .lanes import sink_lane_in_segments, L_WG_LOW
+                self.bwd = sink_lane_in_segments(self.bwd, L_WG_LOW, r"^combine:s\d\.b0\.c3$")
             if self._merge_head:
                 from .lanes import merge_launches
                 self.bwd, done = merge_launches(self.bwd, be, [("dgrad:head.hm.2", "dgrad:head.reg.2"), ("dgrad:head.hm.0", "dgrad:head.reg.0"),

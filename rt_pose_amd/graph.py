@@ -149,7 +149,7 @@ class Graph:
         # (folds are flushed once, at the end of the sweep: earlier, smaller flushes on the weight-gradient lane measured the same,
         # 1 158-1 170 frames/s for 12 / 20 / all in round 1)
         self._defer_wg = [int(v) for v in os.environ.get("RTP_DEFER_WG", "3").split(",") if v.strip() != ""]
-        self._defer_keep = int(os.environ.get("RTP_DEFER_KEEP", "4"))
+        self._defer_keep = int(os.environ.get("RTP_DEFER_KEEP", "0"))   # (round 5: 0 -- all of them in front of the SECOND fan-in, where the main lane waits longest: 5.22 -> 5.17 ms, two same-box pairs; was 4)
         # at most this many launches move (the two 32-channel head towers of hr3d: 8; the wide heads of the one-heat-map configs
         # queue 20+ launches there, more than the waits absorb: measured 11.20 ms/step without the move, 11.45 with all of it)
         self._defer_max, self._ndeferred = int(os.environ.get("RTP_DEFER_MAX", "8")), 0

@@ -189,6 +189,34 @@ def hoist_tagged(launches, pattern, before):
     return [launches[k] for k in out]
 
 
+def sink_lane_in_segments(launches, lane, boundary):
+    """Backward list: inside every segment (the list is cut in front of each launch whose tag matches `boundary`: the main lane's
+    fan-in passes, one per stage) the launches of `lane` -- the lower levels' weight-gradient chains, whose results only the deferred
+    tail reads -- are issued AFTER the segment's other launches (both groups keep their order).
+
+    Why: under the four-stream map that lane shares a stream with the level-3 lane, and a stream runs its launches in list order.  In
+    creation order every weight gradient sits right behind its data gradient, so stage 4's level-3 chain (combine -> dgrad -> combine
+    -> dgrad ... -> dgrad:t3, the head of the dependency chain the MAIN lane waits for in front of its stage-3 fan-in) queued behind
+    weight gradients that were themselves waiting for other lanes' tensors (round 5 timeline: combine:s4.b3.c3 started 240 us after
+    its inputs were ready).  The dependency relations of the original order are checked; the list is returned unchanged if the
+    permutation would break one."""
+    import re
+    cuts = [i for i, L in enumerate(launches) if re.search(boundary, L.tag)]
+    out, lo = [], 0
+    for hi in cuts + [len(launches)]:
+        seg = list(range(lo, hi))
+        out += [i for i in seg if launches[i].lane != lane] + [i for i in seg if launches[i].lane == lane]
+        lo = hi
+    if out == list(range(len(launches))):
+        return launches
+    preds = _order_preds(launches)
+    where = {k: p for p, k in enumerate(out)}
+    for k in range(len(launches)):
+        if any(where[q] > where[k] for q in preds[k]):
+            return launches
+    return [launches[k] for k in out]
+
+
 def merge_launches(launches, backend, pairs):
     """Horizontal fusion (include/rtp.h: rtp_multi_*): independent launches of one LDS-tiled kernel variant become ONE launch.
 
@@ -317,26 +345,27 @@ class LanePlan:
             self._start = be.new_event()
             self._ends = [be.new_event() for _ in range(NLANES)]
         ev = self._events
-        main = streams[0]
         side = [l for l in self.lanes_used if l != 0]
-        self._start.record(main)
+        # the backend's ordering events take stream HANDLES: record(ptr) / wait(ptr) (HipBackend: device-scope HIP events behind the
+        # C ABI, csrc/lane_events.hip)
+        self._start.record(ptrs[0])
         for l in side:
-            streams[l].wait_event(self._start)
+            self._start.wait(ptrs[l])
         waits, record, lane_of = self.waits, self.record, self.lane_of
         trace = getattr(self, "trace", None)   # tools/main_lane_trace.py, tools/lane_timeline.py: {launch index: (start, end) timing events}
         for i, L in enumerate(self.launches):
             lane = lane_of[i]
-            st = streams[lane]
+            sp = ptrs[lane]
             for j in waits[i]:
-                st.wait_event(ev[j])
+                ev[j].wait(sp)
             if trace is not None and i in trace:
-                trace[i][0].record(st)
+                trace[i][0].record(streams[lane])
             if skip is None or not skip[i]:
-                L.fn(ptrs[lane])
+                L.fn(sp)
             if trace is not None and i in trace:
-                trace[i][1].record(st)
+                trace[i][1].record(streams[lane])
             if record[i]:
-                ev[i].record(st)
+                ev[i].record(sp)
         for l in side:
-            self._ends[l].record(streams[l])
-            main.wait_event(self._ends[l])
+            self._ends[l].record(ptrs[l])
+            self._ends[l].wait(ptrs[0])
