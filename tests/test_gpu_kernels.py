@@ -999,6 +999,117 @@ def test_fused_stride2_data_gradient(hip, case):
     assert rel_err(tot.sum(1).cpu(), dxg.buf.float().reshape(n, -1, ci).sum(1).cpu()) < F32
 
 
+@pytest.mark.parametrize("dims", [(2, 4, 16), (4, 6, 32)])
+def test_stride2_accumulating_data_gradient_and_coefficient_only_terms(hip, dims):
+    """rtp_dgrad_s2_acc (out = prev + rstd * gamma * dxhat, statistics of the un-rounded dxhat) chained over two stride-2 GroupNorm
+    consumers of one tensor, then rtp_grad_combine_cls_lazy with the chain's last link as a plain term and two COEFFICIENT-ONLY terms
+    (t.ptr = NULL): against the emulation of the same chain, and against the plan it replaces -- one dxhat tensor + one full GroupNorm
+    term per consumer -- which computes the same gradient up to where the bf16 roundings sit."""
+    n, ci, co, groups = 2, 32, 32, 8
+    do, ho, wo = dims
+    d, h, w = 2 * do, 2 * ho, 2 * wo
+    geom = Geom(n, d, h, w, do, ho, wo, ci, co, 3, 2, 1)
+    xp, xc, xg = views(hip, rnd((n, d, h, w, ci), 950, relu=True), n, d, h, w)
+    g0p, g0c, g0g = views(hip, rnd((n, d, h, w, ci), 951), n, d, h, w)                      # the fuse row's direct contribution
+    gam = [Pair(hip, rnd((ci,), 960 + k, torch.float32) * 0.2 + 1.0) for k in range(2)]
+    mr = [Pair(hip, torch.stack([rnd((n, groups), 962 + k, torch.float32) * 0.1, rnd((n, groups), 964 + k, torch.float32).abs() + 0.5], -1).contiguous())
+          for k in range(2)]
+    gys = [views(hip, rnd((n, do, ho, wo, co), 970 + k), n, do, ho, wo) for k in range(2)]
+    wds = [Pair(hip, rnd((27, ci, co), 980 + k, scale=0.05)) for k in range(2)]
+    assert hip.conv_dgrad_fused_ok(gys[0][2], geom)
+    S = hip.conv_stats_nsplit(gys[0][2], geom, True)
+    s = hip.stream()
+    res = {}
+    for tag, be, sel in (("hip", hip, 2), ("emu", EMU, 1)):
+        dev = (lambda t: t.g) if tag == "hip" else (lambda t: t.c)
+        alloc = be.alloc
+        prev, cfs, pqs = None, [], []
+        for k in range(2):
+            out = alloc((n, d, h, w, ci), "bf16")
+            outv = View(out, n, d, h, w, ci, 0, ci)
+            pq = alloc((n, S if tag == "hip" else 3, ci, 2), "f32")
+            be.dgrad_s2_acc(gys[k][sel], dev(wds[k]), (xg, xc)[tag == "emu"], prev, dev(mr[k]), dev(gam[k]), groups, outv, geom, pq)(s if tag == "hip" else None)
+            prev = outv
+            pqs.append(pq)
+            cfs.append(alloc((n * ci * 5,), "f32"))
+        if tag == "hip":
+            torch.cuda.synchronize()
+        res[tag] = (prev, pqs, cfs)
+    # statistics and the accumulated tensor, link by link
+    for k in range(2):
+        assert rel_err(res["hip"][1][k].sum(1).cpu(), res["emu"][1][k].sum(1)) < F32 * 5, "statistics of link %d" % k
+    assert rel_err(res["hip"][0].buf.float().cpu(), res["emu"][0].buf.float()) < BF, "accumulated A * dxhat chain"
+    # the fan-in pass: plain chain + plain row term + two coefficient-only terms, lazy coefficients from the statistics
+    from rt_pose_amd.graph import LazyCoeff
+
+    class G:   # (LazyCoeff only needs .be for materialise, which this test never calls)
+        pass
+
+    outs = {}
+    for tag, be in (("hip", hip), ("emu", EMU)):
+        prev, pqs, cfs = res[tag]
+        x_, g0_ = (xg, g0g) if tag == "hip" else (xc, g0c)
+        lz = [LazyCoeff(G(), "t%d" % k, 0, pqs[k], pqs[k].shape[1], (mr[k].g if tag == "hip" else mr[k].c), (gam[k].g if tag == "hip" else gam[k].c),
+                        n, ci, groups, d * h * w, cfs[k]) for k in range(2)]
+        o = be.alloc((n, d, h, w, ci), "bf16")
+        ov = View(o, n, d, h, w, ci, 0, ci)
+        nsplit = 4
+        scratch = be.alloc((n, nsplit, 64, ci), "f32")
+        be.grad_combine([(prev, None), (g0_, None), (None, lz[0]), (None, lz[1])], x_, x_, ov, (nsplit, scratch))(s if tag == "hip" else None)
+        outs[tag] = (o, scratch, cfs)
+    torch.cuda.synchronize()
+    assert rel_err(outs["hip"][0].float().cpu(), outs["emu"][0].float()) < BF, "fan-in result"
+    for k in range(2):
+        assert rel_err(outs["hip"][2][k].cpu(), outs["emu"][2][k]) < 5e-3, "lazy coefficients of term %d" % k
+    assert rel_err(outs["hip"][1].sum(1).cpu(), outs["emu"][1].sum(1)) < 5e-3, "class sums of the result"
+    # ... and the plan it replaces: dxhat per consumer (stored bf16, statistics of the stored values) + full GroupNorm terms
+    terms, keep = [(g0g, None)], []
+    for k in range(2):
+        dxh = hip.alloc((n, d, h, w, ci), "bf16")
+        dxv = View(dxh, n, d, h, w, ci, 0, ci)
+        pq = hip.alloc((n, S, ci, 2), "f32")
+        hip.conv(gys[k][2], wds[k].g, False, None, None, dxv, geom, False, True, False, (xg, pq))(s)
+        cf = hip.alloc((n * ci * 5,), "f32")
+        terms.append((dxv, LazyCoeff(G(), "u%d" % k, 0, pq, S, mr[k].g, gam[k].g, n, ci, groups, d * h * w, cf)))
+        keep += [dxh, pq, cf]
+    old = hip.alloc((n, d, h, w, ci), "bf16")
+    hip.grad_combine(terms, xg, xg, View(old, n, d, h, w, ci, 0, ci), (4, hip.alloc((n, 4, 64, ci), "f32")))(s)
+    torch.cuda.synchronize()
+    assert rel_err(outs["hip"][0].float().cpu(), old.float().cpu()) < 3 * BF, "same gradient as one dxhat tensor per consumer"
+
+
+@pytest.mark.parametrize("nterms", [0, 1])
+@pytest.mark.parametrize("dims", [(4, 8, 32), (2, 12, 48)])
+def test_fused_data_gradient_second_masked_output(hip, dims, nterms):
+    """rtp_conv_dgrad_fused with mask2 / dx2 (conv_tiled variants FUSEX 5 / 6): the first output is what the launch writes without
+    the second one, bit for bit; the second is exactly the first under the other tensor's ReLU mask; both equal the emulation's.
+    The plan's use: dgrad:head.reg.0 writes the gradient of fuse row 0 AND of the block output below it (no combine:s4.b0.c3)."""
+    n, ci, co = 2, 32, 32
+    d, h, w = dims
+    geom = Geom(n, d, h, w, d, h, w, ci, co, 3, 1, 1)
+    gp_, gyc, gyg = views(hip, rnd((n, d, h, w, co), 900), n, d, h, w)
+    xp, xc, xg = views(hip, rnd((n, d, h, w, ci), 901, relu=True), n, d, h, w)
+    mp, mc, mg = views(hip, rnd((n, d, h, w, ci), 902, relu=True), n, d, h, w)       # the other tensor (post-ReLU: ~half zeros)
+    ep, ec, eg = views(hip, rnd((n, d, h, w, ci), 903), n, d, h, w)
+    wd = Pair(hip, rnd((27, ci, co), 904, scale=0.05))
+    terms_c, terms_g = ([(ec, None)], [(eg, None)]) if nterms else ([], [])
+    outs = [views(hip, torch.zeros(n, d, h, w, ci, dtype=torch.bfloat16), n, d, h, w) for _ in range(3)]   # dx alone, dx, dx2
+    s = hip.stream()
+    hip.conv_dgrad_fused(gyg, wd.g, xg, None, terms_g, True, outs[0][2], geom)(s)
+    hip.conv_dgrad_fused(gyg, wd.g, xg, None, terms_g, True, outs[1][2], geom, second=(mg, outs[2][2]))(s)
+    EMU.conv_dgrad_fused(gyc, wd.c, xc, None, terms_c, True, outs[1][1], geom, second=(mc, outs[2][1]))(None)
+    torch.cuda.synchronize()
+    a, b, c2 = outs[0][0].g, outs[1][0].g, outs[2][0].g
+    assert torch.equal(a, b), "the first output does not change"
+    assert torch.equal(c2, torch.where(mp.g > 0, b, torch.zeros((), dtype=b.dtype, device=b.device))), "second output = first under the mask"
+    assert rel_err(b.float().cpu(), outs[1][0].c.float()) < BF and rel_err(c2.float().cpu(), outs[2][0].c.float()) < BF
+    assert float(c2.abs().max()) > 0
+    # shapes the variants do not cover are refused, not silently ignored
+    two = [(eg, None), (eg, None)]
+    with pytest.raises(Exception):
+        hip.conv_dgrad_fused(gyg, wd.g, xg, None, two, True, outs[1][2], geom, second=(mg, outs[2][2]))(s)
+
+
 @pytest.mark.parametrize("case", [
     # n, dims, ci, co, per-sample weights + class bias (GroupNorm fold output), residual, relu
     (2, (4, 8, 32), 64, 64, True, True, True), (1, (2, 8, 48), 128, 64, True, False, False),
