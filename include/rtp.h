@@ -49,15 +49,16 @@ typedef struct RtpConvGeom {
   int pad;        /* 0 (ks=1) or 1 (ks=3) */
   int w_ci_total; /* the fp32 weight tensor is [co][w_ci_total][ks^3]; this conv uses input channels   */
   int w_ci_off;   /* [w_ci_off, w_ci_off+ci_real) of it (0,0 = the whole tensor; final_conv chunks)   */
-  int wgs;        /* launch width of the persistent LDS-tiled kernels: 0 = their own choice (one workgroup per CU); > 0 = at most
-                   * this many workgroups in all (wgs / n per sample, at least one).  The launch's tensor output is bit-identical;
-                   * its per-workgroup partial buffers (statistics, slabs, Q / subset-sum partials) keep the size the query
-                   * functions (rtp_conv_stats_nsplit, rtp_wgrad_nsplit) report for the geometry, the slots of the workgroups
-                   * that do not run are NOT written -- the caller zeroes those buffers once and always launches with the same
-                   * width -- and the partials sum to the same totals up to summation order.  Why: a main-stream launch that
-                   * leaves a quarter of the CUs alone costs itself 5 % and lets other streams' dependent chains run beside it
-                   * (-3.8 % on the hr3d step).  Kernels other than conv_tiled / wgrad_tiled /
-                   * wgrad_s2_tiled ignore the field. */
+  int wgs;        /* launch width of the persistent LDS-tiled kernels: 0 = their own choice (one workgroup per CU; 64 / 128 for the
+                   * small launches of the lower levels); > 0 = this many workgroups in all (wgs / n per sample, at least one, at most
+                   * 256 in all and one per brick).  The launch's tensor output is bit-identical.  The width is also the number of
+                   * per-workgroup partial slots (statistics, slabs, Q / subset-sum partials): the query functions
+                   * (rtp_conv_stats_nsplit, rtp_wgrad_nsplit) report the count FOR THE GEOMETRY THEY ARE GIVEN, wgs included, and a
+                   * launch writes every slot -- size the buffers from a query with the same geometry object the launch gets.  The
+                   * partials sum to the same totals up to summation order.  Why narrower: a main-stream launch that leaves a quarter
+                   * of the CUs alone costs itself 5 % and lets other streams' dependent chains run beside it (DESIGN.md 8, round 4:
+                   * -3.8 % on the hr3d step); why wider: a side chain's launches while the main stream waits for them (round 5).
+                   * Kernels other than conv_tiled / wgrad_tiled / wgrad_s2_tiled ignore the field. */
 } RtpConvGeom;
 
 /* ---------------------------------------------------------------- A. convolution family --- */
@@ -276,26 +277,12 @@ typedef struct RtpGnBwd {
  * input dims = 2 x output dims, Ho % 2 == 0, Wo % 16 == 0; gn then carries csum instead of tg); others return
  * RTP_ERR_UNSUPPORTED (use rtp_conv_igemm + rtp_grad_combine).
  * tot_out (optional): per-channel sums of the stored dx, one fp32 partial per workgroup
- * [n][rtp_conv_stats_nsplit(gy, g, 1)][32], which rtp_class_sums_boundary completes to per-boundary-class sums.
- * mask2 / dx2 (both or neither; stride 1, nterms <= 1): a SECOND output dx2 = [mask2 > 0] * dx (the stored, rounded values of dx
- * under another tensor's ReLU mask).  x = row 0 of a HighResolutionModule fuse block = relu(x0 + up-sampled terms) (hr3d.py:
- * 213-228): when that row is x0's only consumer, [x0 > 0] * dx IS the gradient of x0 -- written here (mask2 = x0) beside dx instead of
- * by a fan-in pass over both full-resolution tensors. */
+ * [n][rtp_conv_stats_nsplit(gy, g, 1)][32], which rtp_class_sums_boundary completes to per-boundary-class sums. */
 int rtp_conv_dgrad_fused(const RtpAct* gy, const void* wd, const RtpAct* x, const float* coeff, const RtpGnBwd* gn /*host*/,
                          const RtpTerm* terms /*host*/, int nterms, int mask, const RtpAct* dx, const RtpConvGeom* g,
-                         float* tot_out, const RtpAct* mask2, const RtpAct* dx2, void* stream);
+                         float* tot_out, void* stream);
 
 int rtp_conv_dgrad_fused_ok(const RtpAct* gy, const RtpConvGeom* g);
-
-/* Data gradient of a GroupNorm 3x3x3 STRIDE-2 conv (32 -> <= 32 channels, the geometries of csrc/dgrad_s2_tiled.hip) with an
- * ACCUMULATING output:  out = (prev ? prev : 0) + rstd[n][group(c)] * gamma[c] * dxhat  -- the A * dxhat part of this conv's
- * GroupNorm-backward term, known before the launch from mr (rtp_fold_fwd) and gamma; stat_out [n][rtp_conv_stats_nsplit(gy, g, 1)]
- * [32][2] = (P, Q) = (sum dxhat, sum dxhat * x) of the un-rounded dxhat, from which rtp_grad_combine_cls_lazy computes the B * x + C
- * part: pass the term there with t.ptr = NULL (coefficient-only) and `out` of the chain's last link as a plain term.  The tensor
- * several stride-2 convs read (a HighResolutionModule block output, hr3d.py:162-197) then costs the fan-in pass ONE gradient
- * tensor instead of one per consumer.  RTP_ERR_UNSUPPORTED for other geometries. */
-int rtp_dgrad_s2_acc(const RtpAct* gy, const void* wd, const RtpAct* x, const RtpAct* prev, const float* mr, const float* gamma,
-                     int groups, const RtpAct* out, const RtpConvGeom* g, float* stat_out, void* stream);
 
 /* GroupNorm -> Conv3d(3x3x3, stride 1, 32 -> 16|32 channels) -> [+ residual] -> [ReLU] in ONE launch: the fold of the
  * input's GroupNorm into per-sample weights and the boundary-class bias table (rtp_fold_fwd) happens in the prologue of

@@ -77,11 +77,10 @@ PROTOTYPES = {
     "rtp_zero_f32": [_P, _L, _P],
     "rtp_qpart_from_slabs": [_P, _I, _I, _I, _I, _I, _P, _P, _P],
     "rtp_gn_bwd_coeffs_cls": [_P, _I, _P, _I, _P, _P, _P, _P, _G, _I, _I, _I, _P, _P],
-    "rtp_conv_dgrad_fused": [_A, _P, _A, _P, _P, _T, _I, _I, _A, _G, _P, _A, _A, _P],
+    "rtp_conv_dgrad_fused": [_A, _P, _A, _P, _P, _T, _I, _I, _A, _G, _P, _P],
     "rtp_conv_gn_fused": [_A, _P, _A, _A, _G, _I, _P, _P],
     "rtp_gn_bwd_p": [_P, _I, _P, _P, _G, _I, _I, _P, _P],
     "rtp_conv_dgrad_fused_ok": [_A, _G],
-    "rtp_dgrad_s2_acc": [_A, _P, _A, _A, _P, _P, _I, _A, _G, _P, _P],
     "rtp_class_sums_boundary": [_A, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P],
     "rtp_class_sums_p": [_A, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P, _G, _I, _I, _P, _P, _P],
     "rtp_class_sums": [_A, _I, _I, _I, _I, _I, _P, _P, _P],

@@ -266,13 +266,10 @@ class HipBackend:
         keep = (cls_part, csum_out, wd, p_out)
         return lambda s: check(fn(*args, s), "rtp_gn_bwd_p") or keep and None
 
-    masked_second_output_ok = True   # conv_dgrad_fused(second=...): rtp_conv_dgrad_fused's mask2 / dx2
-
-    def conv_dgrad_fused(self, gy, wd, x, coeff, terms, mask, dx, geom, tot_out=None, gn=None, second=None):
+    def conv_dgrad_fused(self, gy, wd, x, coeff, terms, mask, dx, geom, tot_out=None, gn=None):
         """rtp_conv_dgrad_fused: terms = [(View, coeff | None)] contributions of x's other consumers (<= 3);
         tot_out fp32 [n][conv_stats_nsplit(gy, geom, True)][32]: per-channel totals of the stored dx;
-        gn = dict(qpart, q_nsplit, p, mr, gamma, groups, coeff_out): coefficients computed in the kernel (coeff is None);
-        second = (mask2 View, dx2 View): also dx2 = [mask2 > 0] * dx (stride 1, at most one term)."""
+        gn = dict(qpart, q_nsplit, p, mr, gamma, groups, coeff_out): coefficients computed in the kernel (coeff is None)."""
         fn, g = self.lib.rtp_conv_dgrad_fused, _geom(geom)
         arr = self._terms(terms, False) if terms else None
         gs = None
@@ -281,16 +278,9 @@ class HipBackend:
             gs = _lib.RtpGnBwd(dp("qpart"), gn["q_nsplit"], dp("p"), dp("tg"), dp("csum_out"), dp("csum"), dp("mr"), dp("gamma"),
                                gn["groups"], dp("coeff_out"))
         args = (_act(gy), _ptr(wd), _act(x), _ptr(coeff), C.byref(gs) if gs is not None else None, arr, len(terms), int(mask),
-                _act(dx), g, _ptr(tot_out), _act(second[0]) if second else None, _act(second[1]) if second else None)
-        keep = (gy, wd, x, coeff, terms, dx, arr, tot_out, gn, gs, second)
+                _act(dx), g, _ptr(tot_out))
+        keep = (gy, wd, x, coeff, terms, dx, arr, tot_out, gn, gs)
         return lambda s: check(fn(*args, s), "rtp_conv_dgrad_fused") or keep and None
-
-    def dgrad_s2_acc(self, gy, wd, x, prev, mr, gamma, groups, out, geom, pq):
-        """rtp_dgrad_s2_acc: out = (prev or 0) + rstd * gamma * dxhat of a GroupNorm stride-2 conv; pq = (P, Q) partials of dxhat."""
-        fn, g = self.lib.rtp_dgrad_s2_acc, _geom(geom)
-        args = (_act(gy), _ptr(wd), _act(x), _act(prev), _ptr(mr), _ptr(gamma), int(groups), _act(out), g, _ptr(pq))
-        keep = (gy, wd, x, prev, mr, gamma, out, pq)
-        return lambda s: check(fn(*args, s), "rtp_dgrad_s2_acc") or keep and None
 
     def class_sums_p(self, gy, nsplit, scratch, tot_part, tot_nsplit, csum_out, wd, geom, ci_real, co_real, p_out):
         """rtp_class_sums_p: class sums (boundary-only when tot_part is given) + P of the GroupNorm backward, one launch."""
@@ -387,9 +377,9 @@ class HipBackend:
         for i, t in enumerate(terms):
             v, coeff = t if isinstance(t, tuple) else (t, None)
             coeff = getattr(coeff, "tensor", coeff)   # graph.LazyCoeff: the buffer the coefficients live in
-            arr[i].t = _act(v) if v is not None else RtpAct(None, 0, 0, 0)   # (None: a coefficient-only GroupNorm term, B * x + C)
+            arr[i].t = _act(v)
             arr[i].coeff = coeff.data_ptr() if coeff is not None else None
-            arr[i].d, arr[i].h, arr[i].w = (v.d, v.h, v.w) if (with_dims and v is not None) else (0, 0, 0)
+            arr[i].d, arr[i].h, arr[i].w = (v.d, v.h, v.w) if with_dims else (0, 0, 0)
         return arr
 
     def grad_combine(self, terms, x, relu_src, out, cls=None):

@@ -104,11 +104,6 @@ struct TiledParams {
   const float* coef[4];
   const bf16_t* ex[3]; int ex_cs[3], ex_co[3];
   int nextra, mask;
-  // FUSE, optional second output (variants FUSEX 5 / 6): y2 = [m2 > 0] * y, the stored (rounded) values of y under the ReLU mask of
-  // ANOTHER tensor.  HighResolutionModule row 0 = relu(x0 + up-sampled terms) (hr3d.py:213-228): the gradient of the block output
-  // x0, when the row is x0's only consumer, is [x0 > 0] * (gradient of the row) -- written here beside the row's gradient instead
-  // of by a fan-in pass of its own over both full-resolution tensors (combine:s4.b0.c3 under final_fuse = 'top').
-  const bf16_t* m2; int m2_cs, m2_co; bf16_t* y2; int y2_cs, y2_co;
   float* tot_out;   // FUSE, optional: per-channel sums of the stored output, one partial per workgroup [N][wgs][32]
   // FUSE, optional: this conv's GroupNorm-backward coefficients are computed HERE (every workgroup, in its prologue) instead
   // of by a kernel of their own between the weight gradient and this launch: Q = sum of the slab contractions qpart
@@ -180,10 +175,7 @@ template <int NT, bool HAS_BTAB, int AUX, bool STAT, int FUSEX = 0, bool GEN = f
 __device__ __forceinline__ void conv_tiled_body(const TiledParams& p, const int n, const int wg_in_sample) {
   constexpr bool FUSE = FUSEX > 0;
   static_assert(!(FUSE && GEN), "the fused data-gradient epilogue is bf16 in / bf16 out");
-  // FUSEX 5 / 6: the fused epilogue with 0 / 1 extra terms AND a second, masked output (M2): y2 = [m2 > 0] * y, the gradient of the
-  // tensor m2 whose only consumer is the same-resolution term of the fuse row whose gradient y is (TiledParams::m2)
-  constexpr bool M2 = FUSEX >= 5;
-  constexpr int NEX = FUSE ? (M2 ? FUSEX - 5 : FUSEX - 1) : 0;
+  constexpr int NEX = FUSE ? FUSEX - 1 : 0;
   static_assert(!FUSE || (NT == 2 && !HAS_BTAB && AUX == 2 && !STAT), "fused data-gradient epilogue: 32 channels, x in the AUX slot");
   extern __shared__ __attribute__((aligned(16))) bf16_t lds[];
   PROF_T(pk0);
@@ -549,7 +541,6 @@ __device__ __forceinline__ void conv_tiled_body(const TiledParams& p, const int 
   const unsigned res_lane_b = 2u * (unsigned)(v * p.r_cs + c0);
   const unsigned y_lane_b = ((GEN && p.y_fp32) ? 4u : 2u) * (unsigned)(v * p.y_cs + c0);
   const unsigned a_lane_b = 4u * (unsigned)(v * p.a_cs + c0);
-  const unsigned m2_lane_b = M2 ? 2u * (unsigned)(v * p.m2_cs + c0) : 0u, y2_lane_b = M2 ? 2u * (unsigned)(v * p.y2_cs + c0) : 0u;
   unsigned ex_lane_b[NEX > 0 ? NEX : 1];
 #pragma unroll
   for (int e = 0; e < (NEX > 0 ? NEX : 1); ++e) ex_lane_b[e] = NEX > 0 ? 2u * (unsigned)(v * p.ex_cs[e] + c0) : 0u;
@@ -603,15 +594,6 @@ __device__ __forceinline__ void conv_tiled_body(const TiledParams& p, const int 
     PROF_T(pt0);
     if (loading) {
       bf16x8 exr[NEX > 0 ? NEX : 1][TY];
-      bf16x8 m2r[M2 ? TY : 1];
-      if constexpr (M2) {   // the second output's mask rows, requested with the other operands of the pending brick
-        if (pend) {
-#pragma unroll
-          for (int t = 0; t < TY; ++t)
-            m2r[t] = ld_bf16x8(reinterpret_cast<const bf16_t*>(
-                reinterpret_cast<const char*>(p.m2 + (vox_n + ((long)e_oz * p.H + (e_y0 + t)) * p.W + e_xb) * p.m2_cs + p.m2_co) + m2_lane_b));
-        }
-      }
       if constexpr (NEX > 0) {
         // the other consumers' terms of the pending brick: requested first, so they arrive under the DMA issue below
         if (pend) {
@@ -740,12 +722,6 @@ __device__ __forceinline__ void conv_tiled_body(const TiledParams& p, const int 
               if constexpr (FUSE) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) tsum[j] += bf2f(o[j]);   // totals of the stored (rounded) values
-              }
-              if constexpr (M2) {
-                bf16x8 o2;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) o2[j] = bf2f(m2r[t][j]) > 0.f ? o[j] : (bf16_t)0.0f;
-                st_bf16x8_nt(reinterpret_cast<bf16_t*>(reinterpret_cast<char*>(p.y2 + rs * p.y2_cs + p.y2_co) + y2_lane_b), o2);
               }
               if constexpr (STAT) {
 #pragma unroll
@@ -1045,6 +1021,10 @@ static int tiled_wgs_per_sample(const RtpConvGeom* g) {
   // step: -0.7 ... -2.3 % depending on the box for 128, another -0.5 % for 64 beside the width hints; RTP_TILED_WGS_SMALL, 0 = as the large ones)
   static const int small_wgs = getenv("RTP_TILED_WGS_SMALL") ? atoi(getenv("RTP_TILED_WGS_SMALL")) : 64;
   int wgs = ((small_wgs > 0 && (long)tiles * g->n < 2048) ? small_wgs : total_wgs) / g->n;  // workgroups per sample: one workgroup per CU when N divides 256
+  // RtpConvGeom::wgs: the caller's launch width (narrower: CUs left to other streams; wider than the narrow default of a small
+  // launch: a side chain the main stream is waiting for) -- also the number of per-workgroup partial slots, so queries and launches
+  // of one geometry object agree by construction
+  if (g->wgs > 0) wgs = (g->wgs > 256 ? 256 : g->wgs) / g->n;
   if (wgs < 1) wgs = 1;
   if (wgs * 2 > tiles) wgs = (tiles + 1) / 2;
   // small volumes: a workgroup pays ~6 us of fixed cost (55 KB of weights, pipeline ramp) whatever it computes; with fewer than
@@ -1065,8 +1045,7 @@ int rtp_conv_tiled_stat_slots(const RtpAct* x, const RtpConvGeom* g, int transpo
 struct S2Fuse { const float* coef[4]; const RtpAct* ex[3]; int nextra, mask; float* tot_out; const RtpGnBwd* gn; };   // dgrad_s2_tiled.hip
 int rtp_dgrad_s2_try(const RtpAct* gy, const void* wd, const RtpAct* dx, const RtpConvGeom* g, const RtpAct* stat_x, float* stat_out,
                      const S2Fuse* fuse, hipStream_t s);
-struct TiledFuse { const float* coef[4]; const RtpAct* ex[3]; int nextra, mask; float* tot_out; const RtpGnBwd* gn;
-                   const RtpAct* m2; const RtpAct* y2; };   // m2 / y2: optional second, masked output (TiledParams::m2)
+struct TiledFuse { const float* coef[4]; const RtpAct* ex[3]; int nextra, mask; float* tot_out; const RtpGnBwd* gn; };
 struct TiledSlice { long w_sample_stride; int w_tap_stride, w_row_stride, bt_cs, st_cs; };
 
 int rtp_conv_tiled_try(const RtpAct* x, const void* wf, int w_per_sample, const float* btab, const RtpAct* res,
@@ -1096,11 +1075,7 @@ int rtp_conv_tiled_try(const RtpAct* x, const void* wf, int w_per_sample, const 
   p.tiles_y = p.H / TY; p.tiles_x = (p.W + TX - 1) / TX; p.tiles_z = p.D / TZ;
   p.tiles_per_sample = (p.D / TZ) * p.tiles_y * p.tiles_x;
   int wgs = tiled_wgs_per_sample(g);
-  p.part_stride = wgs;   // (the partial buffers are sized for the un-hinted launch)
-  if (g->wgs > 0) {   // RtpConvGeom::wgs: the caller wants the launch on fewer workgroups (CUs left to other streams)
-    const int hw = g->wgs / g->n;
-    if (hw >= 1 && hw < wgs) wgs = hw;
-  }
+  p.part_stride = wgs;   // (one partial slot per workgroup: rtp_conv_stats_nsplit reports the same count for this geometry)
   p.teams_per_sample = wgs * 2;
   if ((long)p.tiles_per_sample * (p.teams_per_sample + 1) >= (1L << 31)) return RTP_ERR_SHAPE;
   static const int dbg = getenv("RTP_TILED_DBG") ? atoi(getenv("RTP_TILED_DBG")) : 0;
@@ -1124,16 +1099,8 @@ int rtp_conv_tiled_try(const RtpAct* x, const void* wf, int w_per_sample, const 
   }
   for (int e = 0; e < 4; ++e) p.coef[e] = nullptr;
   for (int e = 0; e < 3; ++e) { p.ex[e] = nullptr; p.ex_cs[e] = p.ex_co[e] = 0; }
-  p.m2 = nullptr; p.y2 = nullptr; p.m2_cs = p.m2_co = p.y2_cs = p.y2_co = 0;
   if (fuse) {
     if (fuse->nextra < 0 || fuse->nextra > 3) return RTP_ERR_SHAPE;
-    if ((fuse->m2 != nullptr) != (fuse->y2 != nullptr)) return RTP_ERR_SHAPE;
-    if (fuse->m2) {
-      if (fuse->nextra > 1) return RTP_ERR_UNSUPPORTED;   // (variants FUSEX 5 / 6: at most one extra term beside the second output)
-      if (fuse->m2->c < 32 || fuse->y2->c < 32 || (fuse->m2->cs % 8) || (fuse->m2->co % 8) || (fuse->y2->cs % 8) || (fuse->y2->co % 8)) return RTP_ERR_ALIGN;
-      p.m2 = (const bf16_t*)fuse->m2->ptr; p.m2_cs = fuse->m2->cs; p.m2_co = fuse->m2->co;
-      p.y2 = (bf16_t*)fuse->y2->ptr; p.y2_cs = fuse->y2->cs; p.y2_co = fuse->y2->co;
-    }
     p.nextra = fuse->nextra; p.mask = fuse->mask; p.tot_out = fuse->tot_out;
     p.coef[0] = fuse->coef[0];
     if (fuse->gn) {
@@ -1159,7 +1126,7 @@ int rtp_conv_tiled_try(const RtpAct* x, const void* wf, int w_per_sample, const 
     if (!head_last && (nt != 2 || acc32 || y_fp32 || slice)) return RTP_ERR_UNSUPPORTED;
     RtpMultiJob job;
     job.kind = RTP_MULTI_CONV_TILED;
-    job.variant = head_last ? 200 : fuse ? ((p.m2 ? 110 : 100) + p.nextra) : (((btab || fold) ? 1 : 0) * 8 + aux_c * 2 + (stat_out ? 1 : 0));
+    job.variant = head_last ? 200 : fuse ? (100 + p.nextra) : (((btab || fold) ? 1 : 0) * 8 + aux_c * 2 + (stat_out ? 1 : 0));
     job.tiles_per_sample = p.tiles_per_sample; job.n = p.N; job.slots_per_sample = p.part_stride; job.shm = shm;
     // (the family the problem is timed under when launched alone, below)
     job.fam = (Co == 32 && (long)p.N * p.D * p.H * p.W >= (1L << 20)) ? (transposed ? RTP_FAM_CONV_TILED_FULL_BWD : RTP_FAM_CONV_TILED_FULL)
@@ -1193,16 +1160,15 @@ int rtp_conv_tiled_try(const RtpAct* x, const void* wf, int w_per_sample, const 
   }
   const int aux = stat_x ? 2 : (res ? 1 : 0);
   if (fuse) {
-    static const Kern ftab[6] = {conv_tiled_kernel<2, false, 2, false, 1>, conv_tiled_kernel<2, false, 2, false, 2>,
-                                 conv_tiled_kernel<2, false, 2, false, 3>, conv_tiled_kernel<2, false, 2, false, 4>,
-                                 conv_tiled_kernel<2, false, 2, false, 5>, conv_tiled_kernel<2, false, 2, false, 6>};
+    static const Kern ftab[4] = {conv_tiled_kernel<2, false, 2, false, 1>, conv_tiled_kernel<2, false, 2, false, 2>,
+                                 conv_tiled_kernel<2, false, 2, false, 3>, conv_tiled_kernel<2, false, 2, false, 4>};
     static bool fattr[RTP_MAX_DEVICES] = {};
     if (rtp_once_per_device(fattr)) {
-      for (int e = 0; e < 6; ++e)
+      for (int e = 0; e < 4; ++e)
         (void)hipFuncSetAttribute((const void*)ftab[e], hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)(sizeof(bf16_t) * (27 * (size_t)32 * 32 + 2 * (size_t)HALO_VOX * 32) + 27 * 32 * sizeof(float) + 64));
     }
-    hipLaunchKernelGGL(ftab[p.m2 ? 4 + p.nextra : p.nextra], dim3(p.N * wgs), dim3(512), shm, s, p);
+    hipLaunchKernelGGL(ftab[p.nextra], dim3(p.N * wgs), dim3(512), shm, s, p);
     RTP_CHECK_LAUNCH();
     return RTP_OK;
   }
@@ -1230,15 +1196,14 @@ extern "C" int rtp_conv_gn_fused(const RtpAct* x, const RtpGnFold* f, const RtpA
 // Only the LDS-tiled kernel's geometries (rtp_conv_tiled_ok(gy, g, 1)).
 extern "C" int rtp_conv_dgrad_fused(const RtpAct* gy, const void* wd, const RtpAct* x, const float* coeff, const RtpGnBwd* gn,
                                     const RtpTerm* terms /*host*/, int nterms, int mask, const RtpAct* dx,
-                                    const RtpConvGeom* g, float* tot_out, const RtpAct* mask2, const RtpAct* dx2, void* stream) {
+                                    const RtpConvGeom* g, float* tot_out, void* stream) {
   if (!gy || !wd || !x || !dx || !g || nterms < 0 || nterms > 3 || (nterms && !terms)) return RTP_ERR_SHAPE;
-  if ((mask2 != nullptr) != (dx2 != nullptr)) return RTP_ERR_SHAPE;
   if (coeff && gn) return RTP_ERR_SHAPE;
   if ((gy->co % 8) || (gy->cs % 8) || (dx->co % 8) || (dx->cs % 8) || (x->co % 8) || (x->cs % 8)) return RTP_ERR_ALIGN;
   if (x->c < 32 || dx->c < 32) return RTP_ERR_SHAPE;
   if (gn && gn->groups != 8 && gn->groups != 1) return RTP_ERR_UNSUPPORTED;
   if (g->stride == 2) {   // the parity-class kernel (dgrad_s2_tiled.hip)
-    if (rtp_multi_capture() || mask2) return RTP_ERR_UNSUPPORTED;
+    if (rtp_multi_capture()) return RTP_ERR_UNSUPPORTED;
     S2Fuse f2;
     f2.nextra = nterms; f2.mask = mask; f2.tot_out = tot_out; f2.gn = gn;
     f2.coef[0] = coeff;
@@ -1247,7 +1212,7 @@ extern "C" int rtp_conv_dgrad_fused(const RtpAct* gy, const void* wd, const RtpA
     return rc2 > 0 ? RTP_ERR_UNSUPPORTED : rc2;
   }
   TiledFuse f;
-  f.nextra = nterms; f.mask = mask; f.tot_out = tot_out; f.gn = gn; f.m2 = mask2; f.y2 = dx2;
+  f.nextra = nterms; f.mask = mask; f.tot_out = tot_out; f.gn = gn;
   f.coef[0] = coeff;
   for (int e = 0; e < 3; ++e) { f.ex[e] = e < nterms ? &terms[e].t : nullptr; f.coef[1 + e] = e < nterms ? terms[e].coeff : nullptr; }
   const int rc = rtp_conv_tiled_try(gy, wd, 0, nullptr, nullptr, dx, g, 0, 1, 0, x, nullptr, nullptr, 0, (hipStream_t)stream, &f, nullptr, nullptr);
@@ -1283,8 +1248,6 @@ MKern conv_multi_kernel_for(int variant) {
     case 101: return conv_tiled_multi_kernel<2, false, 2, false, 2>;
     case 102: return conv_tiled_multi_kernel<2, false, 2, false, 3>;
     case 103: return conv_tiled_multi_kernel<2, false, 2, false, 4>;
-    case 110: return conv_tiled_multi_kernel<2, false, 2, false, 5>;
-    case 111: return conv_tiled_multi_kernel<2, false, 2, false, 6>;
     case 200: return conv_tiled_multi_kernel<1, true, 0, false, 0, true>;
     default: return nullptr;
   }

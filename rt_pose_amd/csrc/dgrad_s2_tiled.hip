@@ -41,11 +41,6 @@ struct S2Params {
   float* tot_out;
   const float* qpart; int q_nsplit; const float* csum; const float* gn_mr; const float* gn_gamma; int gn_groups;
   float gn_m; float* coef_out;
-  // MODE 0, optional ACCUMULATING output (rtp_dgrad_s2_acc): dx = prev + A * dxhat with A[n][c] = rstd[n][group(c)] * gamma[c], the
-  // part of this conv's GroupNorm backward that is known before the launch (the B * x + C part needs the statistics this launch
-  // produces: it is applied by the fan-in pass, which then reads ONE accumulated tensor instead of one dxhat per consumer);
-  // the statistics (P, Q) are those of the un-rounded dxhat, which is never stored.  prev may be null (first link of the chain).
-  const bf16_t* prev; int pv_cs, pv_co; const float* acc_mr; const float* acc_gamma; int acc_groups;
 };
 
 __device__ __forceinline__ int swz2(int chunk, int xi) { return ((chunk + 2 * (xi >> 2)) & 3) << 3; }  // bf16 elements
@@ -162,14 +157,6 @@ __global__ __launch_bounds__(256, 2) void dgrad_s2_kernel(S2Params p) {
     }
     bL[192 + tid] = 0.f;   // per-wave running totals [4 waves][32] (+ slack)
     __syncthreads();
-  } else {
-    if (p.acc_gamma) {   // kernel-uniform: the scale table of the accumulating output, behind the statistics reduction's 256 floats
-      if (tid < 32) {
-        const int cg = 32 / p.acc_groups;
-        bL[320 + tid] = p.acc_mr[((long)n * p.acc_groups + tid / cg) * 2 + 1] * p.acc_gamma[tid];
-      }
-      __syncthreads();
-    }
   }
 
   const long vox_g = (long)n * p.Do * p.Ho * p.Wo;
@@ -230,7 +217,7 @@ __global__ __launch_bounds__(256, 2) void dgrad_s2_kernel(S2Params p) {
     tile_org(t_begin + k, mz0, my0, mx0);
     const unsigned g_base = lds0 + 2u * (unsigned)(27 * 32 * 32 + (k & 1) * GVOX * 32);
     // 4 groups per wave: (class, y row); the x / extra operands of all four are requested up front
-    bf16x8 xr[4], exr[NEX > 0 ? NEX : 1][4], pvr[FUSE ? 1 : 4];
+    bf16x8 xr[4], exr[NEX > 0 ? NEX : 1][4];
     long vo[4];
 #pragma unroll
     for (int gi = 0; gi < 4; ++gi) {
@@ -241,18 +228,6 @@ __global__ __launch_bounds__(256, 2) void dgrad_s2_kernel(S2Params p) {
       if (p.x) xr[gi] = ld_bf16x8(p.x + vo[gi] * p.x_cs + p.x_co + c0);
 #pragma unroll
       for (int e = 0; e < NEX; ++e) exr[e][gi] = ld_bf16x8(p.ex[e] + vo[gi] * p.ex_cs[e] + p.ex_co[e] + c0);
-      if constexpr (!FUSE) {
-        pvr[gi] = zero_bf16x8();
-        if (p.prev) pvr[gi] = ld_bf16x8(p.prev + vo[gi] * p.pv_cs + p.pv_co + c0);
-      }
-    }
-    float sa[8];
-    if constexpr (!FUSE) {
-      if (p.acc_gamma) {
-        const f32x4 s0 = *reinterpret_cast<const f32x4*>(bL + 320 + c0), s1 = *reinterpret_cast<const f32x4*>(bL + 324 + c0);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { sa[j] = s0[j]; sa[4 + j] = s1[j]; }
-      }
     }
     float ka[8], kb[8], kc[8], ke[NEX > 0 ? NEX : 1][8];
     if constexpr (FUSE) {
@@ -309,18 +284,6 @@ __global__ __launch_bounds__(256, 2) void dgrad_s2_kernel(S2Params p) {
           for (int j = 0; j < 8; ++j) ev[j] = aux[j] > 0.f ? ev[j] : 0.f;
         }
       }
-      bool acc_mode = false;
-      if constexpr (!FUSE) {
-        if (p.acc_gamma) {   // statistics of dxhat itself, then the accumulating output
-          acc_mode = true;
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            st_p[j] += ev[j];
-            st_q[j] += ev[j] * aux[j];
-            ev[j] = sa[j] * ev[j] + bf2f(pvr[gi][j]);
-          }
-        }
-      }
       bf16x8 o;
 #pragma unroll
       for (int j = 0; j < 8; ++j) o[j] = f2bf(ev[j]);
@@ -329,7 +292,7 @@ __global__ __launch_bounds__(256, 2) void dgrad_s2_kernel(S2Params p) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) tsum[j] += bf2f(o[j]);
       } else {
-        if (p.stat_out && !acc_mode) {
+        if (p.stat_out) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
             const float rr = bf2f(o[j]);
@@ -418,12 +381,11 @@ int rtp_dgrad_s2_stat_slots(const RtpAct* gy, const RtpConvGeom* g) { return s2_
 
 struct TiledFuse;   // conv_tiled.hip
 struct S2Fuse { const float* coef[4]; const RtpAct* ex[3]; int nextra, mask; float* tot_out; const RtpGnBwd* gn; };
-struct S2Acc { const RtpAct* prev; const float* mr; const float* gamma; int groups; };
 
 // +1: not this kernel's geometry; RTP_OK / negative otherwise.  stat_x: the conv's input when statistics or the fused epilogue
 // are requested.
-static int s2_launch(const RtpAct* gy, const void* wd, const RtpAct* dx, const RtpConvGeom* g, const RtpAct* stat_x, float* stat_out,
-                     const S2Fuse* fuse, hipStream_t s, const S2Acc* acc) {
+int rtp_dgrad_s2_try(const RtpAct* gy, const void* wd, const RtpAct* dx, const RtpConvGeom* g, const RtpAct* stat_x, float* stat_out,
+                     const S2Fuse* fuse, hipStream_t s) {
   if (!s2_geometry_ok(gy, g)) return 1;
   if ((dx->cs % 8) || (dx->co % 8) || dx->c < 32 || gy->c < 32) return RTP_ERR_ALIGN;
   if (stat_out && !stat_x) return RTP_ERR_SHAPE;
@@ -459,13 +421,6 @@ static int s2_launch(const RtpAct* gy, const void* wd, const RtpAct* dx, const R
       p.coef_out = q->coeff_out;
     }
   }
-  if (acc) {
-    if (fuse || !stat_x || !stat_out || !acc->mr || !acc->gamma || acc->groups < 1 || 32 % acc->groups) return RTP_ERR_SHAPE;
-    if (acc->prev && (acc->prev->c < 32 || (acc->prev->cs % 8) || (acc->prev->co % 8))) return RTP_ERR_ALIGN;
-    p.prev = acc->prev ? (const bf16_t*)acc->prev->ptr : nullptr;
-    p.pv_cs = acc->prev ? acc->prev->cs : 0; p.pv_co = acc->prev ? acc->prev->co : 0;
-    p.acc_mr = acc->mr; p.acc_gamma = acc->gamma; p.acc_groups = acc->groups;
-  }
   const size_t shm = sizeof(bf16_t) * (27 * 32 * 32 + 2 * GVOX * 32) + 864 * sizeof(float);
   using Kern = void (*)(S2Params);
   static const Kern tab[5] = {dgrad_s2_kernel<0>, dgrad_s2_kernel<1>, dgrad_s2_kernel<2>, dgrad_s2_kernel<3>, dgrad_s2_kernel<4>};
@@ -477,21 +432,4 @@ static int s2_launch(const RtpAct* gy, const void* wd, const RtpAct* dx, const R
   hipLaunchKernelGGL(tab[mode], dim3(p.N * p.wgs_per_sample), dim3(256), shm, s, p);
   RTP_CHECK_LAUNCH();
   return RTP_OK;
-}
-
-int rtp_dgrad_s2_try(const RtpAct* gy, const void* wd, const RtpAct* dx, const RtpConvGeom* g, const RtpAct* stat_x, float* stat_out,
-                     const S2Fuse* fuse, hipStream_t s) {
-  return s2_launch(gy, wd, dx, g, stat_x, stat_out, fuse, s, nullptr);
-}
-
-// Accumulating data gradient of a GroupNorm stride-2 conv (see S2Params::prev): out = (prev ? prev : 0) + rstd * gamma * dxhat,
-// stat_out [n][rtp_conv_stats_nsplit(gy, g, 1)][32][2] = (sum dxhat, sum dxhat * x) of the un-rounded dxhat.  Only the geometries of
-// this file's kernel (RTP_ERR_UNSUPPORTED otherwise: use rtp_conv_igemm_stats + a GN term of rtp_grad_combine).
-extern "C" int rtp_dgrad_s2_acc(const RtpAct* gy, const void* wd, const RtpAct* x, const RtpAct* prev, const float* mr,
-                                const float* gamma, int groups, const RtpAct* out, const RtpConvGeom* g, float* stat_out,
-                                void* stream) {
-  if (!gy || !wd || !x || !mr || !gamma || !out || !g || !stat_out) return RTP_ERR_SHAPE;
-  S2Acc a{prev, mr, gamma, groups};
-  const int rc = s2_launch(gy, wd, out, g, x, stat_out, nullptr, (hipStream_t)stream, &a);
-  return rc > 0 ? RTP_ERR_UNSUPPORTED : rc;
 }

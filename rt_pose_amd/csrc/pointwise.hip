@@ -37,8 +37,7 @@ __device__ __forceinline__ void combine_items(const CombParams& p, const long (&
     if (!live[u]) continue;
 #pragma unroll
     for (int k = 0; k < RTP_MAX_TERMS; ++k)
-      if (k < p.nterms) tv[u][k] = p.terms[k].t ? ld_bf16x8(p.terms[k].t + vv[u] * p.terms[k].cs + p.terms[k].co + chunk * 8)
-                                                : zero_bf16x8();   // coefficient-only term: B * x + C (its A * dxhat sits in another term)
+      if (k < p.nterms) tv[u][k] = ld_bf16x8(p.terms[k].t + vv[u] * p.terms[k].cs + p.terms[k].co + chunk * 8);
     if (need_x) xv[u] = ld_bf16x8(p.x + vv[u] * p.x_cs + p.x_co + chunk * 8);
     if (p.relu && !(same_rx && need_x)) rv[u] = ld_bf16x8(p.relu + vv[u] * p.r_cs + p.r_co + chunk * 8);
   }
@@ -310,10 +309,7 @@ static int comb_params(CombParams& p, const RtpTerm* terms, int nterms, const Rt
   if (p.c % 8 || (out->cs % 8) || (out->co % 8)) return RTP_ERR_ALIGN;
   bool need_x = false;
   for (int k = 0; k < nterms; ++k) {
-    // t.ptr == NULL with coefficients: a COEFFICIENT-ONLY GroupNorm term, B * x + C -- its A * dxhat was accumulated into another
-    // term's tensor by the data gradient that produced it (rtp_dgrad_s2_acc)
-    if (!terms[k].t.ptr && !terms[k].coeff) return RTP_ERR_SHAPE;
-    if (terms[k].t.ptr && (terms[k].t.c != p.c || (terms[k].t.cs % 8) || (terms[k].t.co % 8))) return RTP_ERR_ALIGN;
+    if (terms[k].t.c != p.c || (terms[k].t.cs % 8) || (terms[k].t.co % 8)) return RTP_ERR_ALIGN;
     p.terms[k] = CombTerm{(const bf16_t*)terms[k].t.ptr, terms[k].t.cs, terms[k].t.co, terms[k].coeff, nullptr, 0, nullptr, nullptr, 1, nullptr};
     need_x |= terms[k].coeff != nullptr;
   }

@@ -224,7 +224,7 @@ static bool w2_geometry_ok(const RtpConvGeom* g) {
 
 static int w2_wgs(const RtpConvGeom* g) {
   const int bricks = g->dov * (g->ho / W2_OY) * ((g->wo + W2_OX - 1) / W2_OX);
-  int wgs = 256 / g->n;
+  int wgs = (g->wgs > 0 ? (g->wgs > 256 ? 256 : g->wgs) : 256) / g->n;   // RtpConvGeom::wgs: launch width = number of slabs
   if (wgs < 1) wgs = 1;
   if (wgs > bricks) wgs = bricks;
   return wgs;
@@ -259,10 +259,6 @@ int rtp_wgrad_s2_try(const RtpAct* gy, const RtpAct* x, const RtpConvGeom* g, in
   p.tiles_y = p.Ho / W2_OY; p.tiles_x = (p.Wo + W2_OX - 1) / W2_OX;
   p.bricks_per_sample = p.Do * p.tiles_y * p.tiles_x;
   p.wgs_per_sample = nsplit; p.part_stride = nsplit;
-  if (g->wgs > 0) {   // RtpConvGeom::wgs: fewer workgroups than slabs (the upper slabs stay zero): CUs left to other streams
-    const int hw = g->wgs / g->n;
-    if (hw >= 1 && hw < nsplit) p.wgs_per_sample = hw;
-  }
   const size_t shm = sizeof(bf16_t) * (size_t)W2_RING * W2_SLOT;
   RtpProfScope prof(RTP_FAM_WGRAD_TILED, s);
   static bool attr[RTP_MAX_DEVICES] = {};

@@ -514,6 +514,7 @@ static int wg_tiled_wgs(const RtpConvGeom* g) {
   static const int total_wgs = getenv("RTP_WGRAD_TILED_WGS") ? atoi(getenv("RTP_WGRAD_TILED_WGS")) : 256;  // experiments: fewer slabs / CUs left to other streams
   static const int small_wgs = getenv("RTP_WGRAD_WGS_SMALL") ? atoi(getenv("RTP_WGRAD_WGS_SMALL")) : 128;   // (conv_tiled.hip: narrow launches for the lower levels)
   int wgs = ((small_wgs > 0 && (long)tiles * g->n < 2048) ? small_wgs : total_wgs) / g->n;
+  if (g->wgs > 0) wgs = (g->wgs > 256 ? 256 : g->wgs) / g->n;   // RtpConvGeom::wgs: launch width = number of slabs (conv_tiled.hip)
   if (wgs < 1) wgs = 1;
   if (wgs > tiles) wgs = tiles;
   return wgs;
@@ -557,10 +558,6 @@ int rtp_wgrad_tiled_try(const RtpAct* gy, const RtpAct* x, const RtpConvGeom* g,
   p.tiles_y = p.H / TY; p.tiles_x = (p.W + TX - 1) / TX; p.tiles_z = p.D / TZ;
   p.tiles_per_sample = (p.D / TZ) * p.tiles_y * p.tiles_x;
   p.wgs_per_sample = nsplit; p.part_stride = nsplit;
-  if (g->wgs > 0) {   // RtpConvGeom::wgs: fewer workgroups than slabs (the upper slabs stay zero): CUs left to other streams
-    const int hw = g->wgs / g->n;
-    if (hw >= 1 && hw < nsplit) p.wgs_per_sample = hw;
-  }
   static const int dbg = getenv("RTP_TILED_DBG") ? atoi(getenv("RTP_TILED_DBG")) : 0;
   p.dbg = dbg;
   p.wd = (const bf16_t*)wd; p.qpart = wd ? qpart : nullptr; p.tg = tg;

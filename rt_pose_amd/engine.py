@@ -112,7 +112,7 @@ class PoseEngine:
         rules = parse_width_hints(os.environ.get("RTP_WIDTH_HINTS", DEFAULT_WIDTH_HINTS))
         g = self.graph = Graph(be, batch, params, train=train, pgrads=pgrads, width_rules=rules)
         # two gradient buckets (trainer): one early flush of the deferred tail; RTP_EARLY_TAIL=1: the same flush in single-bucket mode (A/B)
-        g.early_flush = bool(early_flush) or os.environ.get("RTP_EARLY_TAIL", "0") in ("1", "2")
+        g.early_flush = bool(early_flush) or os.environ.get("RTP_EARLY_TAIL", "0") == "1"
         self.x_in = g.input_f32("rdr", cin, dims)
         self.feats = net.build_hrnet3d(g, self.x_in, arch, dims, final_fuse)
         # two-stream fusion (BASELINE config 5): the dense LiDAR voxel grid [B, C_l, Z, Y, X] fp32 enters beside the radar feature

@@ -179,11 +179,16 @@ class Graph:
     # ------------------------------------------------------------------ helpers
     def with_width(self, geom, tag):
         """`geom` for the launch tagged `tag`: a copy carrying the launch width of the first matching rule, or geom itself."""
+        cache = self.__dict__.setdefault("_width_cache", {})
+        if tag in cache:   # (one geometry object per launch tag: the slot-count queries and the launch itself must see the same width)
+            return cache[tag]
         wgs = next((w for pre, w in self.width_rules if tag.startswith(pre)), 0)
-        if not wgs:
-            return geom
-        self.widths_applied.append((tag, wgs))
-        return replace(geom, wgs=wgs)
+        out = geom
+        if wgs:
+            self.widths_applied.append((tag, wgs))
+            out = replace(geom, wgs=wgs)
+        cache[tag] = out
+        return out
 
     def _add_op(self, op):
         op.group = self.group
@@ -217,10 +222,6 @@ class Graph:
                 chunks.append(rev[j:k])
                 j = k
             chunks = list(reversed(chunks))                         # lowest resolution first: row 2, row 1, row 0
-            if os.environ.get("RTP_ROW_ORDER", "1") == "2" and len(chunks) >= 3:   # A/B: row 1, then the lower rows, row 0 last
-                k1 = next((k for k, ch in enumerate(chunks) if ch[0].group[1] == 1), None)
-                if k1 is not None:
-                    chunks.insert(0, chunks.pop(k1))
             for ch in chunks:
                 out.extend(ch)
             i = j
@@ -458,7 +459,7 @@ class Graph:
         if len(t.contribs) == 1 and t.contribs[0][1] is None and not t.relu:
             t.grad = t.contribs[0][0]
             return t.grad
-        c = next(v for v, _ in t.contribs if v is not None).c
+        c = t.contribs[0][0].c
         gbuf = self.be.alloc((self.n, t.d, t.h, t.w, c), "bf16")
         t.grad = View(gbuf, self.n, t.d, t.h, t.w, c, 0, c)
         need_x = any(cf is not None for _, cf in t.contribs)
@@ -564,20 +565,15 @@ class Graph:
         self.first_consumer = {}
         self.fused_dgrad = not os.environ.get("RTP_NO_FUSED_DGRAD") and hasattr(self.be, "conv_dgrad_fused")
         order = self.sweep_order()
-        self.n_consumers = {}
         for op in order:   # ("first consumer" = the consumer the sweep reaches LAST: its contribution completes the tensor's gradient)
             for t in op.inputs():
                 self.first_consumer[id(t)] = op
-                self.n_consumers[id(t)] = self.n_consumers.get(id(t), 0) + 1
         # (the move of the weight-gradient lane onto the main lane pays for the two 32-channel towers of hr3d; the wide heads of
         # the one-heat-map configs -- slice ops -- queue more work there than the waits absorb: 11.3 vs 11.5 ms/step, so not by default)
         if "RTP_DEFER_WG" not in os.environ and any(isinstance(op, (SplitConvOp, CoSplitConvOp)) for op in self.ops):
             self._defer_wg = []
         for op in order:
-            # (where: two gradient buckets / RTP_EARLY_TAIL=1 -- when the sweep leaves stage 3; RTP_EARLY_TAIL=2 -- when it reaches layer1,
-            # so that only layer1's slabs are left for the flush at the very end of the main lane)
-            late = os.environ.get("RTP_EARLY_TAIL", "0") == "2"
-            if self.early_flush and self.early_tail_index is None and op.y.name.startswith(("l1.",) if late else ("l1.", "t1", "s2.")):
+            if self.early_flush and self.early_tail_index is None and op.y.name.startswith(("l1.", "t1", "s2.")):
                 # (coefficients a later fan-in pass would have computed in its prologue are needed by the GroupNorm parameter
                 # sums of this flush: their launches are emitted now)
                 for it in self.tail_a:
@@ -685,7 +681,8 @@ class ConvOp:
         # LDS-tiled kernels, the partial sums carried in an fp32 workspace (rtp_conv_igemm_ws)
         self.sliced_fwd = (not self.fold_fused) and hasattr(be, "conv_sliced_ok") and be.conv_sliced_ok(self.x, ge, False)
         skw = dict(ws=True) if self.sliced_fwd else {}
-        S = 0 if (self.out_fp32 or ge.co != self.y.c or not self.want_stats) else be.conv_stats_nsplit(self.x, ge, False, **skw)
+        S = 0 if (self.out_fp32 or ge.co != self.y.c or not self.want_stats) else be.conv_stats_nsplit(
+            self.x, g.with_width(ge, "conv:" + self.name), False, **skw)
         if S > 0:
             self.y.stats_split = S
             self.y.stats = be.alloc((g.n, S, self.y.c, 2), "f32")
@@ -742,20 +739,12 @@ class ConvOp:
             cok = pad_to(ge.co, 32)
             assert gy.c >= cok, (self.name, gy.c, cok)
             wd = self.wd
-            # A GroupNorm stride-2 conv that reads a block output whose gradient is completed by a fan-in pass (its last contribution
-            # comes from the fuse row, not from a fusable conv): the A * dxhat part of its term is ACCUMULATED onto the chain of the
-            # tensor's earlier stride-2 consumers (rtp_dgrad_s2_acc), the B * x + C part stays a coefficient-only term -- the fan-in
-            # pass reads one gradient tensor instead of one per consumer (RTP_S2_ACC=0: a dxhat tensor per consumer, A/B)
-            if (self.s2_bwd and self.gn and x.needs_grad and ge.ci == 32 and self.ci_real == 32 and x.c == 32 and x.cs == 32 and x.co == 0
-                    and hasattr(be, "dgrad_s2_acc") and isinstance(g.first_consumer.get(id(x)), FuseOp)
-                    and os.environ.get("RTP_S2_ACC", "1") == "1"):
-                return self._emit_backward_s2_acc(gy)
             dxh_buf = be.alloc((g.n, x.d, x.h, x.w, ge.ci), "bf16")
             dxh = View(dxh_buf, g.n, x.d, x.h, x.w, ge.ci, 0, ge.ci)
             # GroupNorm backward needs P = sum dxhat and Q = sum dxhat*x per (sample, channel): the tiled kernel
             # accumulates them in its epilogue, otherwise a chan_stats pass over (dxhat, x) follows
             self.sliced_bwd = hasattr(be, "conv_sliced_ok") and be.conv_sliced_ok(gy, ge, True)
-            S = be.conv_stats_nsplit(gy, ge, True, **(dict(ws=True) if self.sliced_bwd else {})) if self.gn else 0
+            S = be.conv_stats_nsplit(gy, g.with_width(ge, "dgrad:" + self.name), True, **(dict(ws=True) if self.sliced_bwd else {})) if self.gn else 0
             pq = be.alloc((g.n, S or x.stats_split, ge.ci, 2), "f32") if self.gn else None
             lane = g.lane_of(self.y)   # a stride-2 conv's data gradient runs with the LOWER-resolution group
             kw = dict(ws=g.slice_ws(lane, g.n * x.vox * 32)) if self.sliced_bwd else {}
@@ -797,7 +786,8 @@ class ConvOp:
     def _emit_wgrad_unfused(self, gy: View):
         g, be, ge, x = self.g, self.g.be, self.geom, self.x
         # ---- weight gradient
-        S = be.wgrad_nsplit(ge) if (x.cs % 32 == 0 and x.co % 8 == 0 and gy.cs % 32 == 0 and (ge.ci > 32 or (x.cs == 32 and x.co == 0))) else 0
+        S = be.wgrad_nsplit(g.with_width(ge, "wgrad:" + self.name)) if (x.cs % 32 == 0 and x.co % 8 == 0 and gy.cs % 32 == 0
+                                                                        and (ge.ci > 32 or (x.cs == 32 and x.co == 0))) else 0
         self.tiled_wgrad = S > 0
         S = S or wgrad_split(gy.vox)
         co32 = pad_to(ge.co, 32)
@@ -825,33 +815,6 @@ class ConvOp:
                          g.params[self.gn[1]] if self.gn else None, self.groups, ge, self.ci_real,
                          self.co_real, g.pgrad[self.wname], g.pgrad[self.bname] if self.bname else None, 0, tg))
 
-    def _emit_backward_s2_acc(self, gy: View):
-        """emit_backward of a GroupNorm stride-2 conv on the accumulating data gradient (see the call site), then its weight gradient."""
-        g, be, ge, x = self.g, self.g.be, self.geom, self.x
-        lane = g.lane_of(self.y)
-        prev = getattr(x, "acc", None)
-        out_buf = be.alloc((g.n, x.d, x.h, x.w, 32), "bf16")
-        out = View(out_buf, g.n, x.d, x.h, x.w, 32, 0, 32)
-        S = be.conv_stats_nsplit(gy, ge, True)
-        assert S > 0, self.name
-        pq = be.alloc((g.n, S, 32, 2), "f32")
-        gamma = g.params[self.gn[0]]
-        g.emit_bwd(be.dgrad_s2_acc(gy, self.wd, x, prev, self.mr, gamma, self.groups, out, g.with_width(ge, "dgrad:" + self.name), pq),
-                   lane, [gy, self.wd, x, prev, self.mr], [out_buf, pq], "dgrad:" + self.name)
-        g.flops["conv_dgrad"] += self.alg_flops
-        g.flops["conv_tiled"] += self.alg_flops
-        g.alg_bytes["conv_tiled"] += 2 * g.n * (gy.vox * pad_to(ge.co, 32) + x.vox * 32 * (3 if prev is not None else 2))
-        coeff = be.alloc((g.n * 32 * 5,), "f32")
-        lz = LazyCoeff(g, self.name, lane, pq, S, self.mr, gamma, g.n, 32, self.groups, x.vox, coeff)
-        g._lazy_by_coeff[coeff.data_ptr()] = lz
-        g.tail_a.append(("gn_param", coeff, g.n, 32, g.pgrad[self.gn[0]], g.pgrad[self.gn[1]], 0))
-        if prev is not None:   # the chain's newest link replaces the previous one as the tensor's plain gradient term
-            x.contribs = [(v, cf) for v, cf in x.contribs if v is not prev]
-        x.contribs.append((out, None))
-        x.contribs.append((None, lz))      # coefficient-only: B * x + C
-        x.acc = out
-        self._emit_wgrad_unfused(gy)
-
     def _bias_tg(self, S):
         """Subset-sum buffer for rtp_wgrad_tg when this conv qualifies (bias, no GroupNorm, 32 -> <= 32 channels, stride 1, tiled)."""
         g, be, ge = self.g, self.g.be, self.geom
@@ -877,11 +840,11 @@ class ConvOp:
             return False
         if self.gn and (self.ci_real != 32 or ge.ci != self.ci_real):   # the fused prologue's GroupNorm algebra is 32 real channels
             return False
-        if len(x.contribs) > 3 or any(v is None or v.c < 32 or (cf is not None and v.c != 32) for v, cf in x.contribs):
+        if len(x.contribs) > 3 or any(v.c < 32 or (cf is not None and v.c != 32) for v, cf in x.contribs):
             return False
         if ge.stride == 2:   # Q from the generic weight-gradient kernel's slabs (rtp_qpart_from_slabs), P from gy's class sums
             return gy.c == 32 and hasattr(be, "qpart_from_slabs") and be.conv_dgrad_fused_ok(gy, ge)
-        if self.gn and not (be.wgrad_nsplit(ge) > 0 and gy.c == 32 and pad_to(ge.co, 32) == 32):
+        if self.gn and not (be.wgrad_nsplit(g.with_width(ge, "wgrad:" + self.name)) > 0 and gy.c == 32 and pad_to(ge.co, 32) == 32):
             return False   # Q comes from the tiled weight-gradient kernel's slabs
         return be.conv_tiled_ok(gy, ge, True)
 
@@ -904,11 +867,11 @@ class ConvOp:
         if ge.stride == 2:
             csum = g.class_sums_for(self.y, gy, wl, self.name, early=True) if (self.gn or self.bname) else None
         elif from_wgrad:
-            tg = be.alloc((g.n, be.wgrad_nsplit(ge), 27, 32), "f32")   # one partial table per weight-gradient slab
+            tg = be.alloc((g.n, be.wgrad_nsplit(g.with_width(ge, "wgrad:" + self.name)), 27, 32), "f32")   # one partial table per weight-gradient slab
             csum = be.alloc((g.n, 64, gy.c), "f32")
         elif self.gn and not own_kernel and hasattr(be, "class_sums_p"):
             csum, pbuf = g.class_sums_and_p(self.y, gy, wl, self.name, self.wd, ge, self.ci_real, self.co_real)
-        S = be.wgrad_nsplit(ge) if x.cs == 32 and x.co == 0 else 0
+        S = be.wgrad_nsplit(g.with_width(ge, "wgrad:" + self.name)) if x.cs == 32 and x.co == 0 else 0
         self.tiled_wgrad = S > 0
         S = S or wgrad_split(gy.vox)
         btg = self._bias_tg(S) if (self.tiled_wgrad and not self.gn and ge.stride == 1) else None
@@ -969,37 +932,22 @@ class ConvOp:
                            and not os.environ.get("RTP_GNCOEF_KERNEL") and not os.environ.get("RTP_CLS_KERNELS"))
         if (isinstance(prod, (ConvOp, SplitConvOp)) and (prod.gn or prod.bname) and hasattr(be, "class_sums_boundary")
                 and not prod_from_wgrad):
-            ts = be.conv_stats_nsplit(gy, ge, True)
+            ts = be.conv_stats_nsplit(gy, g.with_width(ge, "dgrad:" + self.name), True)
             if ts > 0:
                 tot = be.alloc((g.n, ts, 32), "f32")
                 x.grad_tot = (ts, tot)
-        # x = a fuse row whose same-resolution term t (the block output, through its own ReLU) has no other consumer: the gradient of
-        # t is [t > 0] * dx -- a second output of this launch (rtp_conv_dgrad_fused mask2 / dx2) instead of a fan-in pass over both
-        # full-resolution tensors (hr3d: combine:s4.b0.c3, 76 us on the main lane; RTP_NO_MASKED_OUT=1: the pass, A/B)
-        second, dx2_buf = None, None
-        if (isinstance(prod, FuseOp) and ge.stride == 1 and len(terms) <= 1 and getattr(be, "masked_second_output_ok", False)
-                and not os.environ.get("RTP_NO_MASKED_OUT")):
-            same = [t for t in prod.terms if t.dims == x.dims]
-            if (len(same) == 1 and same[0].needs_grad and same[0].relu and g.n_consumers.get(id(same[0]), 0) == 1 and not same[0].contribs
-                    and same[0].c == 32 and same[0].cs == 32 and same[0].co == 0 and x.c == 32):
-                t2 = same[0]
-                dx2_buf = be.alloc((g.n, t2.d, t2.h, t2.w, 32), "bf16")
-                t2.premasked = View(dx2_buf, g.n, t2.d, t2.h, t2.w, 32, 0, 32)
-                second = (t2, t2.premasked)
-                reads.append(t2)
-        kw2 = dict(second=second) if second is not None else {}
         if gnq is not None:
             reads += [gnq["qpart"], gnq["p"], gnq["tg"], gnq.get("csum"), self.mr]
-            g.emit_bwd(be.conv_dgrad_fused(gy, self.wd, x, None, terms, x.relu, dx, gd, tot, gnq, **kw2), lane, reads,
-                       [dx_buf, tot, coeff, gnq["csum_out"], dx2_buf], "dgrad:" + self.name)
+            g.emit_bwd(be.conv_dgrad_fused(gy, self.wd, x, None, terms, x.relu, dx, gd, tot, gnq), lane, reads,
+                       [dx_buf, tot, coeff, gnq["csum_out"]], "dgrad:" + self.name)
         else:
-            g.emit_bwd(be.conv_dgrad_fused(gy, self.wd, x, coeff, terms, x.relu, dx, gd, tot, **kw2), lane, reads, [dx_buf, tot, dx2_buf],
+            g.emit_bwd(be.conv_dgrad_fused(gy, self.wd, x, coeff, terms, x.relu, dx, gd, tot), lane, reads, [dx_buf, tot],
                        "dgrad:" + self.name)
         x.grad, x.final, x.contribs = dx, True, []
         g.flops["conv_dgrad"] += self.alg_flops
         g.flops["conv_tiled"] += self.alg_flops
         # read gy + x (+ the other contributions), write dx
-        nb = 2 * g.n * (gy.vox * co32 + x.vox * ge.ci * (2 + len(terms) + (2 if second is not None else 0)))
+        nb = 2 * g.n * (gy.vox * co32 + x.vox * ge.ci * (2 + len(terms)))
         g.alg_bytes["conv_tiled"] += nb
         g.cost["dgrad:" + self.name] = (self.alg_flops, nb)
         if g.n * x.vox >= (1 << 20):
@@ -1249,10 +1197,7 @@ class FuseOp:
             if not t.needs_grad:
                 continue
             if t.dims == self.y.dims:
-                if getattr(t, "premasked", None) is not None and gy is self.y.grad and not t.contribs:
-                    t.grad, t.final = t.premasked, True   # written, under t's ReLU mask, by the launch that finished gy (second output)
-                else:
-                    t.contribs.append((gy, None))
+                t.contribs.append((gy, None))
             else:
                 glow_buf = be.alloc((g.n, t.d, t.h, t.w, t.c), "bf16")
                 glow = View(glow_buf, g.n, t.d, t.h, t.w, t.c, 0, t.c)

@@ -500,12 +500,9 @@ class EmuBackend:
             p_out.copy_(torch.einsum("tic,ntc->ni", wd.float(), CS)[:, :ci_real])
         return run
 
-    masked_second_output_ok = True
-
-    def conv_dgrad_fused(self, gy, wd, x, coeff, terms, mask, dx, geom, tot_out=None, gn=None, second=None):
+    def conv_dgrad_fused(self, gy, wd, x, coeff, terms, mask, dx, geom, tot_out=None, gn=None):
         """rtp_conv_dgrad_fused: dx = [x > 0] * (A*convT(gy; wd) + B*x + C + sum terms), one rounding.
-        gn: the coefficients are computed here from Q (slab contractions) and P, and written to gn['coeff_out'].
-        second = (mask2, dx2): dx2 = [mask2 > 0] * (the stored dx)."""
+        gn: the coefficients are computed here from Q (slab contractions) and P, and written to gn['coeff_out']."""
         def run(s):
             g = geom
             nonlocal coeff
@@ -570,34 +567,9 @@ class EmuBackend:
             if mask:
                 acc = torch.where(xv > 0, acc, torch.zeros(()))
             self._store(dx, acc)
-            if second is not None:
-                m2, dx2 = second
-                _store(dx2, torch.where(_sl(m2)[..., :c] > 0, _sl(dx)[..., :c], torch.zeros(())))
             if tot_out is not None:   # totals of the stored (rounded) values, everything in partial 0
                 tot_out.zero_()
                 tot_out.view(g.n, -1, tot_out.shape[-1])[:, 0, :c] = _sl(dx)[..., :c].reshape(g.n, -1, c).sum(1)
-        return run
-
-    def dgrad_s2_acc(self, gy, wd, x, prev, mr, gamma, groups, out, geom, pq):
-        """rtp_dgrad_s2_acc: out = (prev or 0) + rstd * gamma * dxhat, one rounding; pq = (P, Q) of the un-rounded dxhat (partial 0)."""
-        def run(s):
-            g, k = geom, geom.ks
-            cok = (g.co + 31) // 32 * 32
-            xin = _ncdhw(gy.buf[..., gy.co:gy.co + cok].float())
-            wt = wd.float().reshape(k, k, k, g.ci, cok).permute(4, 3, 0, 1, 2)
-            op = [i - ((o - 1) * g.stride - 2 * g.pad + k) for i, o in zip((g.di, g.hi, g.wi), (g.do, g.ho, g.wo))]
-            dxh = _ndhwc(F.conv_transpose3d(xin, wt, None, g.stride, g.pad, output_padding=tuple(op)))
-            c = dxh.shape[-1]
-            xv = _sl(x)[..., :c]
-            pq.zero_()
-            pq[:, 0, :c, 0] = dxh.reshape(g.n, -1, c).sum(1)
-            pq[:, 0, :c, 1] = (dxh * xv).reshape(g.n, -1, c).sum(1)
-            cg = c // groups
-            a = mr[:, :, 1].repeat_interleave(cg, 1) * gamma.detach().float()   # [n, c]
-            acc = a.view(g.n, 1, 1, 1, c) * dxh
-            if prev is not None:
-                acc = acc + _sl(prev)[..., :c]
-            self._store(out, acc)
         return run
 
     def dcn_adapt(self, x, off_act, koff, w_ad, y, dg=4):
@@ -664,9 +636,7 @@ class EmuBackend:
                     acc += _sl(v)
                 else:
                     c = cf[:out.n * out.c * 3].view(out.n, 1, 1, 1, out.c, 3)
-                    if v is not None:
-                        acc += c[..., 0] * _sl(v)
-                    acc += c[..., 1] * _sl(x)[..., :out.c] + c[..., 2]   # (v None: a coefficient-only term)
+                    acc += c[..., 0] * _sl(v) + c[..., 1] * _sl(x)[..., :out.c] + c[..., 2]
             if relu_src is not None:
                 acc = torch.where(_sl(relu_src)[..., :out.c] > 0, acc, torch.zeros(()))
             self._store(out, acc)

@@ -999,117 +999,6 @@ def test_fused_stride2_data_gradient(hip, case):
     assert rel_err(tot.sum(1).cpu(), dxg.buf.float().reshape(n, -1, ci).sum(1).cpu()) < F32
 
 
-@pytest.mark.parametrize("dims", [(2, 4, 16), (4, 6, 32)])
-def test_stride2_accumulating_data_gradient_and_coefficient_only_terms(hip, dims):
-    """rtp_dgrad_s2_acc (out = prev + rstd * gamma * dxhat, statistics of the un-rounded dxhat) chained over two stride-2 GroupNorm
-    consumers of one tensor, then rtp_grad_combine_cls_lazy with the chain's last link as a plain term and two COEFFICIENT-ONLY terms
-    (t.ptr = NULL): against the emulation of the same chain, and against the plan it replaces -- one dxhat tensor + one full GroupNorm
-    term per consumer -- which computes the same gradient up to where the bf16 roundings sit."""
-    n, ci, co, groups = 2, 32, 32, 8
-    do, ho, wo = dims
-    d, h, w = 2 * do, 2 * ho, 2 * wo
-    geom = Geom(n, d, h, w, do, ho, wo, ci, co, 3, 2, 1)
-    xp, xc, xg = views(hip, rnd((n, d, h, w, ci), 950, relu=True), n, d, h, w)
-    g0p, g0c, g0g = views(hip, rnd((n, d, h, w, ci), 951), n, d, h, w)                      # the fuse row's direct contribution
-    gam = [Pair(hip, rnd((ci,), 960 + k, torch.float32) * 0.2 + 1.0) for k in range(2)]
-    mr = [Pair(hip, torch.stack([rnd((n, groups), 962 + k, torch.float32) * 0.1, rnd((n, groups), 964 + k, torch.float32).abs() + 0.5], -1).contiguous())
-          for k in range(2)]
-    gys = [views(hip, rnd((n, do, ho, wo, co), 970 + k), n, do, ho, wo) for k in range(2)]
-    wds = [Pair(hip, rnd((27, ci, co), 980 + k, scale=0.05)) for k in range(2)]
-    assert hip.conv_dgrad_fused_ok(gys[0][2], geom)
-    S = hip.conv_stats_nsplit(gys[0][2], geom, True)
-    s = hip.stream()
-    res = {}
-    for tag, be, sel in (("hip", hip, 2), ("emu", EMU, 1)):
-        dev = (lambda t: t.g) if tag == "hip" else (lambda t: t.c)
-        alloc = be.alloc
-        prev, cfs, pqs = None, [], []
-        for k in range(2):
-            out = alloc((n, d, h, w, ci), "bf16")
-            outv = View(out, n, d, h, w, ci, 0, ci)
-            pq = alloc((n, S if tag == "hip" else 3, ci, 2), "f32")
-            be.dgrad_s2_acc(gys[k][sel], dev(wds[k]), (xg, xc)[tag == "emu"], prev, dev(mr[k]), dev(gam[k]), groups, outv, geom, pq)(s if tag == "hip" else None)
-            prev = outv
-            pqs.append(pq)
-            cfs.append(alloc((n * ci * 5,), "f32"))
-        if tag == "hip":
-            torch.cuda.synchronize()
-        res[tag] = (prev, pqs, cfs)
-    # statistics and the accumulated tensor, link by link
-    for k in range(2):
-        assert rel_err(res["hip"][1][k].sum(1).cpu(), res["emu"][1][k].sum(1)) < F32 * 5, "statistics of link %d" % k
-    assert rel_err(res["hip"][0].buf.float().cpu(), res["emu"][0].buf.float()) < BF, "accumulated A * dxhat chain"
-    # the fan-in pass: plain chain + plain row term + two coefficient-only terms, lazy coefficients from the statistics
-    from rt_pose_amd.graph import LazyCoeff
-
-    class G:   # (LazyCoeff only needs .be for materialise, which this test never calls)
-        pass
-
-    outs = {}
-    for tag, be in (("hip", hip), ("emu", EMU)):
-        prev, pqs, cfs = res[tag]
-        x_, g0_ = (xg, g0g) if tag == "hip" else (xc, g0c)
-        lz = [LazyCoeff(G(), "t%d" % k, 0, pqs[k], pqs[k].shape[1], (mr[k].g if tag == "hip" else mr[k].c), (gam[k].g if tag == "hip" else gam[k].c),
-                        n, ci, groups, d * h * w, cfs[k]) for k in range(2)]
-        o = be.alloc((n, d, h, w, ci), "bf16")
-        ov = View(o, n, d, h, w, ci, 0, ci)
-        nsplit = 4
-        scratch = be.alloc((n, nsplit, 64, ci), "f32")
-        be.grad_combine([(prev, None), (g0_, None), (None, lz[0]), (None, lz[1])], x_, x_, ov, (nsplit, scratch))(s if tag == "hip" else None)
-        outs[tag] = (o, scratch, cfs)
-    torch.cuda.synchronize()
-    assert rel_err(outs["hip"][0].float().cpu(), outs["emu"][0].float()) < BF, "fan-in result"
-    for k in range(2):
-        assert rel_err(outs["hip"][2][k].cpu(), outs["emu"][2][k]) < 5e-3, "lazy coefficients of term %d" % k
-    assert rel_err(outs["hip"][1].sum(1).cpu(), outs["emu"][1].sum(1)) < 5e-3, "class sums of the result"
-    # ... and the plan it replaces: dxhat per consumer (stored bf16, statistics of the stored values) + full GroupNorm terms
-    terms, keep = [(g0g, None)], []
-    for k in range(2):
-        dxh = hip.alloc((n, d, h, w, ci), "bf16")
-        dxv = View(dxh, n, d, h, w, ci, 0, ci)
-        pq = hip.alloc((n, S, ci, 2), "f32")
-        hip.conv(gys[k][2], wds[k].g, False, None, None, dxv, geom, False, True, False, (xg, pq))(s)
-        cf = hip.alloc((n * ci * 5,), "f32")
-        terms.append((dxv, LazyCoeff(G(), "u%d" % k, 0, pq, S, mr[k].g, gam[k].g, n, ci, groups, d * h * w, cf)))
-        keep += [dxh, pq, cf]
-    old = hip.alloc((n, d, h, w, ci), "bf16")
-    hip.grad_combine(terms, xg, xg, View(old, n, d, h, w, ci, 0, ci), (4, hip.alloc((n, 4, 64, ci), "f32")))(s)
-    torch.cuda.synchronize()
-    assert rel_err(outs["hip"][0].float().cpu(), old.float().cpu()) < 3 * BF, "same gradient as one dxhat tensor per consumer"
-
-
-@pytest.mark.parametrize("nterms", [0, 1])
-@pytest.mark.parametrize("dims", [(4, 8, 32), (2, 12, 48)])
-def test_fused_data_gradient_second_masked_output(hip, dims, nterms):
-    """rtp_conv_dgrad_fused with mask2 / dx2 (conv_tiled variants FUSEX 5 / 6): the first output is what the launch writes without
-    the second one, bit for bit; the second is exactly the first under the other tensor's ReLU mask; both equal the emulation's.
-    The plan's use: dgrad:head.reg.0 writes the gradient of fuse row 0 AND of the block output below it (no combine:s4.b0.c3)."""
-    n, ci, co = 2, 32, 32
-    d, h, w = dims
-    geom = Geom(n, d, h, w, d, h, w, ci, co, 3, 1, 1)
-    gp_, gyc, gyg = views(hip, rnd((n, d, h, w, co), 900), n, d, h, w)
-    xp, xc, xg = views(hip, rnd((n, d, h, w, ci), 901, relu=True), n, d, h, w)
-    mp, mc, mg = views(hip, rnd((n, d, h, w, ci), 902, relu=True), n, d, h, w)       # the other tensor (post-ReLU: ~half zeros)
-    ep, ec, eg = views(hip, rnd((n, d, h, w, ci), 903), n, d, h, w)
-    wd = Pair(hip, rnd((27, ci, co), 904, scale=0.05))
-    terms_c, terms_g = ([(ec, None)], [(eg, None)]) if nterms else ([], [])
-    outs = [views(hip, torch.zeros(n, d, h, w, ci, dtype=torch.bfloat16), n, d, h, w) for _ in range(3)]   # dx alone, dx, dx2
-    s = hip.stream()
-    hip.conv_dgrad_fused(gyg, wd.g, xg, None, terms_g, True, outs[0][2], geom)(s)
-    hip.conv_dgrad_fused(gyg, wd.g, xg, None, terms_g, True, outs[1][2], geom, second=(mg, outs[2][2]))(s)
-    EMU.conv_dgrad_fused(gyc, wd.c, xc, None, terms_c, True, outs[1][1], geom, second=(mc, outs[2][1]))(None)
-    torch.cuda.synchronize()
-    a, b, c2 = outs[0][0].g, outs[1][0].g, outs[2][0].g
-    assert torch.equal(a, b), "the first output does not change"
-    assert torch.equal(c2, torch.where(mp.g > 0, b, torch.zeros((), dtype=b.dtype, device=b.device))), "second output = first under the mask"
-    assert rel_err(b.float().cpu(), outs[1][0].c.float()) < BF and rel_err(c2.float().cpu(), outs[2][0].c.float()) < BF
-    assert float(c2.abs().max()) > 0
-    # shapes the variants do not cover are refused, not silently ignored
-    two = [(eg, None), (eg, None)]
-    with pytest.raises(Exception):
-        hip.conv_dgrad_fused(gyg, wd.g, xg, None, two, True, outs[1][2], geom, second=(mg, outs[2][2]))(s)
-
-
 @pytest.mark.parametrize("case", [
     # n, dims, ci, co, per-sample weights + class bias (GroupNorm fold output), residual, relu
     (2, (4, 8, 32), 64, 64, True, True, True), (1, (2, 8, 48), 128, 64, True, False, False),
@@ -1261,7 +1150,8 @@ def test_two_convs_and_two_weight_gradients_in_one_launch(hip, n):
     kernel must be refused (None) without side effects."""
     ci, co = 32, 32
     probs = []
-    for k, dims in enumerate(((8, 64, 128), (4, 32, 64))):   # 256 and 32 bricks per sample: n = 8: 28 + 4 workgroups per XCD
+    # 256 and 32 bricks per sample (n = 8: 28 + 4 workgroups per XCD); n = 4: 512 bricks, so that the launch still counts as a large one
+    for k, dims in enumerate((((8, 64, 128) if n >= 8 else (16, 64, 128)), (4, 32, 64))):
         d, h, w = dims
         geom = Geom(n, d, h, w, d, h, w, ci, co, 3, 1, 1)
         xp, xc, xg = views(hip, rnd((n, d, h, w, ci), 100 + k, relu=True), n, d, h, w)
@@ -1317,55 +1207,68 @@ def test_two_convs_and_two_weight_gradients_in_one_launch(hip, n):
 
 # ------------------------------------------------------------------------------------------------ per-launch width hints
 def test_width_hints_change_no_result(hip):
-    """RtpConvGeom::wgs (include/rtp.h): an LDS-tiled launch told to run on fewer workgroups -- conv output bit for bit, the
-    per-workgroup partials (statistics, weight-gradient slabs: stride 1 and stride 2) as sums, the partial slots of the workgroups
-    that did not run stay zero, and wgs = 0 afterwards is the full-width launch exactly (the width is a parameter of the launch:
-    nothing of it outlives the call)."""
+    """RtpConvGeom::wgs (include/rtp.h): an LDS-tiled launch told to run on another number of workgroups -- narrower than one per CU,
+    or wider than the narrow default of a small launch -- gives the conv output bit for bit and the per-workgroup partials
+    (statistics, weight-gradient slabs: stride 1 and stride 2) as sums; the slot-count queries report the width they are given, every
+    reported slot is written, and wgs = 0 afterwards is the default launch exactly (the width is a parameter of the launch: nothing of
+    it outlives the call)."""
     from dataclasses import replace
     n, ci, co = 8, 32, 32
-    d, h, w = 8, 64, 128      # 256 bricks per sample: full-width launches (32 workgroups per sample)
-    geom = Geom(n, d, h, w, d, h, w, ci, co, 3, 1, 1)
-    xp, xc, xg = views(hip, rnd((n, d, h, w, ci), 700, relu=True), n, d, h, w)
-    rp, rc, rg = views(hip, rnd((n, d, h, w, co), 701), n, d, h, w)
+
+    def problem(d, h, w, seed):
+        geom = Geom(n, d, h, w, d, h, w, ci, co, 3, 1, 1)
+        xp, xc, xg = views(hip, rnd((n, d, h, w, ci), seed, relu=True), n, d, h, w)
+        rp, rc, rg = views(hip, rnd((n, d, h, w, co), seed + 1), n, d, h, w)
+        xv = xp.c.float().reshape(n, -1, ci)
+        st = Pair(hip, torch.stack([xv.sum(1), (xv * xv).sum(1)], -1)[:, None].contiguous())
+        # stride 2 beside it: [n, 2d, h, w] -> [n, d, h/2, w/2]
+        g2 = Geom(n, d * 2, h, w, d, h // 2, w // 2, ci, co, 3, 2, 1)
+        x2p, x2c, x2g = views(hip, rnd((n, d * 2, h, w, ci), seed + 2, relu=True), n, d * 2, h, w)
+        gy2p, gy2c, gy2g = views(hip, rnd((n, d, h // 2, w // 2, co), seed + 3), n, d, h // 2, w // 2)
+        return dict(geom=geom, g2=g2, xg=xg, rg=rg, st=st, x2g=x2g, gy2g=gy2g, dims=(d, h, w))
+
     Wt = Pair(hip, rnd((co, ci, 3, 3, 3), 702, torch.float32, scale=0.05))
     gamma, beta = Pair(hip, rnd((ci,), 703, torch.float32) * 0.2 + 1.0), Pair(hip, rnd((ci,), 704, torch.float32) * 0.2)
-    xv = xp.c.float().reshape(n, -1, ci)
-    st = Pair(hip, torch.stack([xv.sum(1), (xv * xv).sum(1)], -1)[:, None].contiguous())
     wt = Pair(hip, torch.zeros(27, co, ci))
     hip.tail([("pack_wt", Wt.g, co, co, ci, 27, wt.g)])(hip.stream())
-    S, Sw = hip.conv_stats_nsplit(xg, geom, False), hip.wgrad_nsplit(geom)
-    assert S >= 16 and Sw >= 16
-    # stride 2: [n, 16, 64, 128] -> [n, 8, 32, 64]
-    g2 = Geom(n, d * 2, h, w, d, h // 2, w // 2, ci, co, 3, 2, 1)
-    x2p, x2c, x2g = views(hip, rnd((n, d * 2, h, w, ci), 705, relu=True), n, d * 2, h, w)
-    gy2p, gy2c, gy2g = views(hip, rnd((n, d, h // 2, w // 2, co), 706), n, d, h // 2, w // 2)
-    S2 = hip.wgrad_nsplit(g2)
-    assert S2 >= 16
     s = hip.stream()
 
-    def once(total_wgs):
+    def once(pr, total_wgs):
+        d, h, w = pr["dims"]
+        gw, g2w = replace(pr["geom"], wgs=total_wgs), replace(pr["g2"], wgs=total_wgs)
+        S, Sw, S2 = hip.conv_stats_nsplit(pr["xg"], gw, False), hip.wgrad_nsplit(gw), hip.wgrad_nsplit(g2w)
         y = views(hip, torch.zeros(n, d, h, w, co, dtype=torch.bfloat16), n, d, h, w)
         so, mr = hip.alloc((n, S, co, 2), "f32"), hip.alloc((n, 8, 2), "f32")
         slab, slab2 = hip.alloc((n, Sw, 27, co, ci), "f32"), hip.alloc((n, S2, 27, co, ci), "f32")
-        gw, g2w = replace(geom, wgs=total_wgs), replace(g2, wgs=total_wgs)
-        hip.conv_gn_fused(xg, wt.g, None, gamma.g, beta.g, st.g, 1, 8, 1e-5, co, mr, rg, y[2], gw, True, so)(s)
-        hip.wgrad(rg, xg, gw, Sw, slab)(s)
-        hip.wgrad(gy2g, x2g, g2w, S2, slab2)(s)
+        hip.conv_gn_fused(pr["xg"], wt.g, None, gamma.g, beta.g, pr["st"].g, 1, 8, 1e-5, co, mr, pr["rg"], y[2], gw, True, so)(s)
+        hip.wgrad(pr["rg"], pr["xg"], gw, Sw, slab)(s)
+        hip.wgrad(pr["gy2g"], pr["x2g"], g2w, S2, slab2)(s)
         torch.cuda.synchronize()
-        return y[0].g.clone(), so, mr, slab, slab2
+        return (y[0].g.clone(), so, mr, slab, slab2), (S, Sw, S2)
 
-    full = once(0)
+    # a large launch (256 bricks per sample: one workgroup per CU by default), narrowed
+    big = problem(8, 64, 128, 700)
+    full, slots0 = once(big, 0)
+    assert slots0[0] == 32 and slots0[1] == 32
     for total in (192, 64):
-        got = once(total)
+        got, slots = once(big, total)
         per = total // n
-        assert torch.equal(got[0], full[0]) and torch.equal(got[2], full[2]), "conv output / group statistics under a %d-workgroup hint" % total
-        for k, slots in ((1, S), (3, Sw), (4, S2)):
+        assert slots == (per, per, min(per, slots0[2])), (total, slots)
+        assert torch.equal(got[0], full[0]) and torch.equal(got[2], full[2]), "conv output / group statistics on %d workgroups" % total
+        for k in (1, 3, 4):
             a, b = got[k].flatten(2), full[k].flatten(2)
             assert rel_err(a.sum(1).cpu(), b.sum(1).cpu()) < 1e-5, (total, k)
-            used = int((a.abs().sum((0, 2)) > 0).sum())
-            assert used <= min(per, slots) and float(a[:, min(per, slots):].abs().max() if per < slots else 0.0) == 0.0, (total, k, used)
-    again = once(0)
-    assert all(torch.equal(u, v) for u, v in zip(again, full)), "wgs = 0 again: the full-width launch, bit for bit"
+            assert int((a.abs().sum((0, 2)) > 0).sum()) == a.shape[1], "every reported slot is written (%d workgroups, buffer %d)" % (total, k)
+    again, _ = once(big, 0)
+    assert all(torch.equal(u, v) for u, v in zip(again, full)), "wgs = 0 again: the default launch, bit for bit"
+    # a small launch (32 bricks per sample: narrow by default -- 64 / 128 workgroups in all), widened
+    small = problem(4, 32, 64, 710)
+    base, sl0 = once(small, 0)
+    wide, sl1 = once(small, 128)
+    assert sl0[0] == 8 and sl1[0] == 16 and sl1[1] >= sl0[1], (sl0, sl1)
+    assert torch.equal(wide[0], base[0]) and torch.equal(wide[2], base[2])
+    for k in (1, 3, 4):
+        assert rel_err(wide[k].flatten(2).sum(1).cpu(), base[k].flatten(2).sum(1).cpu()) < 1e-5, k
 
 
 @pytest.mark.parametrize("n", [8, 4, 16])
