@@ -533,18 +533,38 @@ def main():
         line["torch_gpu_baseline"] = torch_gpu_baseline(args.model, args.batch)
     # MPJPE proxy: an ARTEFACT of tests/keypoint_agreement.py (run on an MI355X with the oracle as the checker, which this
     # process may only use for cpu_baseline) -- quoted with its file name, not measured by this run
-    for kname in ("r04_keypoint_agreement.json", "r03_keypoint_agreement.json", "r02_keypoint_agreement.json"):
+    for kname in ("r05_keypoint_agreement_%s.json" % ("hr3d" if args.model == "hr3d" else "doppler"), "r03_keypoint_agreement.json"):
         kj = os.path.join(ROOT, "profiles", kname)
         if world == 1 and os.path.exists(kj):
             try:
                 with open(kj) as f:
                     ka = json.load(f)
+                ka.pop("per_seed", None)
                 line["keypoint_agreement_artefact"] = dict(ka, source="profiles/" + kname)
             except Exception:
                 pass
             break
+    # ... and its round-5 companions (artefacts as well, quoted by file name): the same comparison for the Doppler configuration, and
+    # the TRAJECTORY check (tests/trajectory_check.py: the same seeds trained by the HIP bf16 step and by the oracle's fp32 step at
+    # reduced dims, each model decoding the same held-out frames with its own forward)
+    if world == 1:
+        extra = {}
+        for key, kname in (("keypoint_agreement_doppler", "r05_keypoint_agreement_doppler.json"),
+                           ("trajectory_hr3d", "r05_trajectory_hr3d.json"), ("trajectory_doppler", "r05_trajectory_doppler.json")):
+            kj = os.path.join(ROOT, "profiles", kname)
+            if os.path.exists(kj):
+                try:
+                    with open(kj) as f:
+                        ka = json.load(f)
+                    extra[key] = dict({k: ka[k] for k in ("model", "dims", "train_steps", "seeds", "frames", "mpjpe_cm", "abs_mpjpe_cm",
+                                                          "argmax_agreement", "argmax_within_1_voxel", "worst_seed_abs_mpjpe_delta_cm") if k in ka},
+                                      source="profiles/" + kname)
+                except Exception:
+                    pass
+        if extra:
+            line["numerics_artefacts"] = extra
     # whole-step HBM traffic from the separate PMC passes (tools/pmc_step.sh), against the fused-minimum algorithmic bytes
-    pj = next((q for q in (os.path.join(ROOT, "profiles", f) for f in ("r04_pmc_step_traffic.json", "r03_pmc_step_traffic.json")) if os.path.exists(q)),
+    pj = next((q for q in (os.path.join(ROOT, "profiles", f) for f in ("r05_pmc_step_traffic.json", "r04_pmc_step_traffic.json", "r03_pmc_step_traffic.json")) if os.path.exists(q)),
               os.path.join(ROOT, "profiles", "r03_pmc_step_traffic.json"))
     if world == 1 and "roofline" in line and os.path.exists(pj) and args.model == "hr3d" and args.batch == 8:
         try:

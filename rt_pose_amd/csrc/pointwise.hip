@@ -603,152 +603,6 @@ __global__ __launch_bounds__(256) void fuse_sum_rows_kernel(FuseParams p) {
   if (per_sample) fuse_stats_flush(p, blockIdx.y, sy, sq);
 }
 
-// Row-in-LDS variant (round 5): a workgroup owns whole output x-rows (n, z, y).  Per row and up-sampled term the 2 x 2 (z, y) corner
-// rows of the source are blended ONCE into an fp32 row of the term's own width in LDS (4 sixteen-byte loads + 32 FMAs per source
-// voxel and 8-channel chunk -- for the x2 / x4 / x8 branches of a full-resolution row that is 1 / 2 / 4 / 8 of the outputs), then every
-// output interpolates its two x neighbours from LDS (4 ds_read_b128 + 16 FMAs per term).  The rows kernel above re-blends the source
-// columns of every 4-output run (4 x span gathers + span x 4 x 8 FMAs with mostly-zero weights) and is VALU-bound: 53 us for a
-// full-resolution row with three up-sampled terms against 30 us of HBM time.  Same index rule, same rounding points; the fp32
-// summation order of an output differs (terms are added in list order, up-sampled ones as lx0 * R[x0] + lx1 * R[x1]).
-#define FL_MAX_UP 5
-struct FuseLdsPlan { int nup; int up[FL_MAX_UP]; int off[FL_MAX_UP + 1]; int nsame; int same[RTP_MAX_TERMS]; };   // off: float offsets of the terms' LDS rows
-#define FL_ITEMS 3   // output items (x, 8-channel chunk) per thread and row at most: W * c / 8 <= 768
-
-__global__ __launch_bounds__(256) void fuse_sum_lds_kernel(FuseParams p, FuseLdsPlan pl) {
-  extern __shared__ __attribute__((aligned(16))) float frow[];   // [2 buffers][sum of w_s * c]
-  const int tid = threadIdx.x, c = p.c, cpv = c >> 3, chunk = tid % cpv;
-  const bool per_sample = p.stat_out != nullptr;   // grid (stat_blocks, n): a block stays inside one sample
-  const int rows_n = p.d * p.h;
-  const long rows_all = per_sample ? rows_n : (long)p.n * rows_n;
-  const int nb = gridDim.x;
-  const long r_lo = rows_all * blockIdx.x / nb, r_hi = rows_all * (blockIdx.x + 1) / nb;
-  const int items = p.w * cpv;
-  float sy[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, sq[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  float bias8[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) bias8[j] = p.bias ? p.bias[chunk * 8 + j] : 0.f;
-  const int rowf = pl.off[pl.nup];   // floats of one buffer
-  int buf = 0;
-  for (long r = r_lo; r < r_hi; ++r, buf ^= 1) {
-    const int n = per_sample ? (int)blockIdx.y : (int)(r / rows_n);
-    const int zy = (int)(r - (per_sample ? 0 : (long)n * rows_n));
-    const int z = zy / p.h, y = zy - z * p.h;
-    const long vrow = (((long)n * p.d + z) * p.h + y) * p.w;
-    // the same-resolution terms are this kernel's HBM traffic: requested first, consumed after the blend phase
-    bf16x8 pre[2][FL_ITEMS];
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      if (q < pl.nsame) {
-        const FuseTerm& t = p.terms[pl.same[q]];
-#pragma unroll
-        for (int k = 0; k < FL_ITEMS; ++k) {
-          const int i = tid + k * 256;
-          pre[q][k] = i < items ? ld_bf16x8(t.t + (vrow + i / cpv) * t.cs + t.co + chunk * 8) : zero_bf16x8();
-        }
-      }
-    }
-    // ---- phase 1: blended source rows -> LDS
-    float* fb = frow + buf * rowf;
-    for (int u = 0; u < pl.nup; ++u) {
-      const FuseTerm& t = p.terms[pl.up[u]];
-      int z0, z1, y0, y1;
-      float lz0, lz1, ly0, ly1;
-      src_index(z, t.d, p.d, t.sz, z0, z1, lz0, lz1);
-      src_index(y, t.h, p.h, t.sy, y0, y1, ly0, ly1);
-      const long base = (long)n * t.d * t.h * t.w;
-      const bf16_t* r00 = t.t + (base + ((long)z0 * t.h + y0) * t.w) * t.cs + t.co + chunk * 8;
-      const bf16_t* r01 = t.t + (base + ((long)z0 * t.h + y1) * t.w) * t.cs + t.co + chunk * 8;
-      const bf16_t* r10 = t.t + (base + ((long)z1 * t.h + y0) * t.w) * t.cs + t.co + chunk * 8;
-      const bf16_t* r11 = t.t + (base + ((long)z1 * t.h + y1) * t.w) * t.cs + t.co + chunk * 8;
-      const float w00 = lz0 * ly0, w01 = lz0 * ly1, w10 = lz1 * ly0, w11 = lz1 * ly1;
-      float* dst = fb + pl.off[u];
-      for (int i = tid; i < t.w * cpv; i += 256) {
-        const int xs = i / cpv;
-        const long o = (long)xs * t.cs;
-        const bf16x8 a = ld_bf16x8(r00 + o), b = ld_bf16x8(r01 + o), cc = ld_bf16x8(r10 + o), dd = ld_bf16x8(r11 + o);
-        float v8[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {   // (the corner order of fuse_sum_kernel: z0y0, z0y1, z1y0, z1y1)
-          float v = w00 * bf2f(a[j]);
-          v += w01 * bf2f(b[j]);
-          v += w10 * bf2f(cc[j]);
-          v += w11 * bf2f(dd[j]);
-          v8[j] = v;
-        }
-        float* q = dst + xs * c + chunk * 8;
-        *reinterpret_cast<f32x4*>(q) = f32x4{v8[0], v8[1], v8[2], v8[3]};
-        *reinterpret_cast<f32x4*>(q + 4) = f32x4{v8[4], v8[5], v8[6], v8[7]};
-      }
-    }
-    __syncthreads();   // (one barrier per row: the next row blends into the other buffer)
-    // ---- phase 2: outputs
-#pragma unroll
-    for (int k = 0; k < FL_ITEMS; ++k) {
-      const int i = tid + k * 256;
-      if (i >= items) break;
-      const int x = i / cpv;
-      float acc[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) acc[j] = bias8[j];
-      for (int q = 2; q < pl.nsame; ++q) {   // (beyond the two prefetched ones: none on this path's shapes)
-        const FuseTerm& t = p.terms[pl.same[q]];
-        const bf16x8 tv = ld_bf16x8(t.t + (vrow + x) * t.cs + t.co + chunk * 8);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] += bf2f(tv[j]);
-      }
-      for (int u = 0; u < pl.nup; ++u) {
-        const FuseTerm& t = p.terms[pl.up[u]];
-        int x0, x1;
-        float lx0, lx1;
-        src_index(x, t.w, p.w, t.sx, x0, x1, lx0, lx1);
-        const float* q0 = fb + pl.off[u] + x0 * c + chunk * 8;
-        const float* q1 = fb + pl.off[u] + x1 * c + chunk * 8;
-        const f32x4 a0 = *reinterpret_cast<const f32x4*>(q0), a1 = *reinterpret_cast<const f32x4*>(q0 + 4);
-        const f32x4 b0 = *reinterpret_cast<const f32x4*>(q1), b1 = *reinterpret_cast<const f32x4*>(q1 + 4);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          acc[j] += lx0 * a0[j] + lx1 * b0[j];
-          acc[4 + j] += lx0 * a1[j] + lx1 * b1[j];
-        }
-      }
-#pragma unroll
-      for (int q = 0; q < 2; ++q)
-        if (q < pl.nsame) {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) acc[j] += bf2f(pre[q][k][j]);
-        }
-      bf16x8 o;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) o[j] = f2bf(p.relu ? (acc[j] > 0.f ? acc[j] : 0.f) : acc[j]);
-      st_bf16x8(p.out + (vrow + x) * p.o_cs + p.o_co + chunk * 8, o);
-      if (per_sample) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { const float rr = bf2f(o[j]); sy[j] += rr; sq[j] += rr * rr; }
-      }
-    }
-  }
-  if (per_sample) fuse_stats_flush(p, blockIdx.y, sy, sq);
-}
-
-// the row-in-LDS kernel's plan for this launch, or false (other shapes: the kernels above)
-static bool fuse_lds_plan(const FuseParams& p, FuseLdsPlan& pl, size_t* lds_bytes) {
-  static const bool off = getenv("RTP_FUSE_ROWS_OLD") != nullptr;   // A/B: the rows kernel
-  if (off || p.c < 8 || p.c % 8 || 256 % (p.c / 8) || (long)p.w * (p.c / 8) > 256L * FL_ITEMS) return false;
-  pl.nup = pl.nsame = 0;
-  pl.off[0] = 0;
-  for (int k = 0; k < p.nterms; ++k) {
-    const FuseTerm& t = p.terms[k];
-    if (t.same) { pl.same[pl.nsame++] = k; continue; }
-    if (pl.nup == FL_MAX_UP) return false;
-    pl.up[pl.nup] = k;
-    pl.off[pl.nup + 1] = pl.off[pl.nup] + t.w * p.c;
-    ++pl.nup;
-  }
-  if (pl.nup == 0) return false;   // nothing to blend: the point kernel is a plain streaming sum
-  *lds_bytes = 2 * (size_t)pl.off[pl.nup] * sizeof(float);
-  return *lds_bytes <= 64 * 1024;
-}
-
 // can every up-sampled term's FX-output run be served from FSPAN source voxels?
 static bool fuse_rows_ok(FuseParams& p) {   // (also fills every up-sampled term's span)
   if (p.w % FX) return false;
@@ -811,14 +665,7 @@ extern "C" int rtp_fuse_sum_stats(const RtpTerm* terms, int nterms, const float*
   RtpProfScope prof(RTP_FAM_POINTWISE, s);
   const dim3 grid_rows = stat_out ? dim3(nsplit, n) : dim3(grid_for((long)n * d * h * (w / FX) * (p.c / 8)));
   const dim3 grid_pts = stat_out ? dim3(nsplit, n) : dim3(grid_for((long)n * d * h * w * (p.c / 8)));
-  FuseLdsPlan pl;
-  size_t lds_bytes = 0;
-  if (fuse_lds_plan(p, pl, &lds_bytes)) {
-    // per-sample statistics: the caller's block count (blocks own contiguous row ranges of a sample); otherwise ~4 workgroups per CU
-    const long rows = (long)n * d * h;
-    const dim3 grid = stat_out ? dim3(nsplit, n) : dim3((unsigned)(rows < 1024 ? rows : 1024));
-    hipLaunchKernelGGL(fuse_sum_lds_kernel, grid, dim3(256), lds_bytes, s, p, pl);
-  } else if (fuse_rows_ok(p))
+  if (fuse_rows_ok(p))
     hipLaunchKernelGGL(fuse_sum_rows_kernel, grid_rows, dim3(256), 0, s, p);
   else
     hipLaunchKernelGGL(fuse_sum_kernel, grid_pts, dim3(256), 0, s, p);

@@ -1277,7 +1277,7 @@ def test_head_last_convs_in_one_launch(hip, n):
     launch -- what the default plan does with conv:head.reg.2 + conv:head.hm.2 -- against the same two convs launched alone.
     n = 8: a sample per XCD; n = 4 / 16 (round 5: any sample count that divides the chip's 256 workgroups): a sample on two XCDs /
     two samples per XCD."""
-    ci, d, h, w = 32, 8, 64, 128 if n <= 8 else 64
+    ci, d, h, w = 32, (16 if n < 8 else 8), 64, (128 if n <= 8 else 64)   # (n = 4: 512 bricks per sample -- still a "large" launch)
     outs, mk = [], []
     for k, co_real in enumerate((15, 3)):
         co = pad_to(co_real, 16)
