@@ -333,6 +333,10 @@ int rtp_dgrad_s2_stat_slots(const RtpAct* gy, const RtpConvGeom* g);
 int rtp_dgrad_s2_try(const RtpAct* gy, const void* wd, const RtpAct* dx, const RtpConvGeom* g, const RtpAct* stat_x, float* stat_out,
                      const S2Fuse* fuse, hipStream_t s);
 int rtp_conv_tiled_stat_slots(const RtpAct* x, const RtpConvGeom* g, int transposed);
+// conv64_tiled.hip: the 64 -> 64-channel stride-1 layers as ONE launch (weights in the waves' registers, no fp32 workspace)
+int rtp_conv64_try(const RtpAct* x, const void* wf, int w_per_sample, const float* btab, const RtpAct* res, const RtpAct* y,
+                   const RtpConvGeom* g, int relu, int transposed, int y_fp32, const RtpAct* stat_x, float* stat_out, int wgs,
+                   hipStream_t s);
 // ---- wide 3x3x3 stride-1 convs (Cin = 32 K, Cout = 32 J, K * J > 1) as K x J launches of the LDS-tiled 32 -> 32 kernel
 // (the 64- and 128-channel layers of the feat64 backbone, hrnet3D_config.py:149-177): output slice j is the sum over the
 // input slices k of a 32 x 32 window of the SAME weight image (fold output [n][27][Co][Ci] / data-gradient packing
@@ -376,6 +380,11 @@ static int conv_sliced(const RtpAct* x, const void* wf, int w_per_sample, const 
   const int Ci = 32 * K, Co = 32 * J;
   if (x->c < Ci || y->c < Co || (res && res->c < Co) || (stat_x && stat_x->c < Co)) return RTP_ERR_SHAPE;
   if (stat_out && y_fp32) return RTP_ERR_UNSUPPORTED;
+  if (K == 2 && J == 2 && g->stride == 1) {   // the native 64 -> 64 kernel: same partial slots, the workspace stays untouched
+    const int rc = rtp_conv64_try(x, wf, w_per_sample, btab, res, y, g, relu, transposed, y_fp32, stat_x, stat_out,
+                                  sliced_stat_slots(x, g, transposed), s);
+    if (rc <= 0) return rc;
+  }
   TiledSlice sl;
   // forward: wf [n][27][Co][Ci] (rows = output channels); transposed: wd [27][conv ci = Co here][cok = Ci here]
   sl.w_row_stride = Ci; sl.w_tap_stride = Co * Ci; sl.w_sample_stride = 27L * Co * Ci; sl.bt_cs = Co; sl.st_cs = Co;

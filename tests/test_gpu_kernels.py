@@ -1004,6 +1004,9 @@ def test_fused_stride2_data_gradient(hip, case):
     (2, (4, 8, 32), 64, 64, True, True, True), (1, (2, 8, 48), 128, 64, True, False, False),
     (2, (2, 4, 16), 64, 128, False, True, True), (3, (4, 8, 80), 128, 128, True, False, True),
     (2, (4, 8, 32), 32, 64, True, False, True), (1, (2, 4, 32), 64, 32, False, True, False),
+    # 64 -> 64: ONE launch of csrc/conv64_tiled.hip (weights in registers, no workspace traffic)
+    (1, (2, 8, 48), 64, 64, False, False, False), (3, (4, 8, 80), 64, 64, True, True, True), (8, (4, 16, 64), 64, 64, True, False, True),
+    (2, (2, 4, 16), 64, 64, True, True, False),
 ])
 def test_wide_convs_as_channel_slices_of_the_tiled_kernel(hip, case):
     """rtp_conv_igemm_ws / rtp_wgrad on Cin = 32 K, Cout = 32 J (the feat64 backbone's 64- and 128-channel layers,
