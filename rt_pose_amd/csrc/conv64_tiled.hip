@@ -128,6 +128,8 @@ __global__ __launch_bounds__(512, 2) void conv64_kernel(C64Params p) {
     for (int zo = 0; zo < C64_TZ; ++zo)
 #pragma unroll
       for (int yo = 0; yo < C64_TY; ++yo) acc[zo][yo] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // (issue order left to the compiler: with two MFMA waves per SIMD its read-then-use order measured 281 us at the native shape,
+    // an explicit one-group-ahead software pipeline with sched_group_barrier 319)
     const unsigned char* bufp = lds + buf * C64_BRICK_B;
 #pragma unroll
     for (int dx = 0; dx < 3; ++dx) {
@@ -227,7 +229,7 @@ __global__ __launch_bounds__(512, 2) void conv64_kernel(C64Params p) {
   }
 }
 
-static bool c64_geometry_ok(const RtpAct* x, const RtpAct* y, const RtpConvGeom* g, int transposed) {
+static bool c64_geometry_ok(const RtpAct* x, const RtpConvGeom* g, int transposed) {
   static const bool disabled = getenv("RTP_CONV64") && atoi(getenv("RTP_CONV64")) == 0;
   if (disabled) return false;
   if (g->ks != 3 || g->stride != 1 || g->pad != 1) return false;
@@ -235,22 +237,34 @@ static bool c64_geometry_ok(const RtpAct* x, const RtpAct* y, const RtpConvGeom*
   const int Co = transposed ? g->ci : g->co;
   if (Ci != 64 || Co != 64) return false;
   if (g->di % C64_TZ || g->hi % C64_TY || g->wi % C64_TX) return false;
-  if (x->c < 64 || y->c < 64 || (x->cs % 8) || (x->co % 8) || (y->cs % 4) || (y->co % 4)) return false;
+  if (x->c < 64 || (x->cs % 8) || (x->co % 8)) return false;
   return true;
 }
 
-/* 1 if rtp_conv64_try has a kernel for this conv (forward: x -> y, transposed: gy -> dx). */
-int rtp_conv64_ok(const RtpAct* x, const RtpAct* y, const RtpConvGeom* g, int transposed) {
-  return (x && y && g && c64_geometry_ok(x, y, g, transposed)) ? 1 : 0;
+/* Workgroups per sample of the launch rtp_conv64_try makes for this conv = statistics partials per sample it writes (0: not this
+ * kernel's geometry).  One workgroup per CU when the batch divides 256 (half of them for the level-1 tensors), RtpConvGeom::wgs
+ * (include/rtp.h) narrower or wider. */
+int rtp_conv64_wgs(const RtpAct* x, const RtpConvGeom* g, int transposed) {
+  if (!x || !g || !c64_geometry_ok(x, g, transposed)) return 0;
+  const int tiles = (g->di / C64_TZ) * (g->hi / C64_TY) * (g->wi / C64_TX);
+  // the level-1 tensors (fewer than 4096 bricks in all) on half the chip: phase config, same box, 256 / 128 / 64 workgroups:
+  // 27.88-27.90 / 27.84-27.85 / 28.04-28.11 ms per step (alone the launch takes 43 / ~60 / 130 us: the side lanes want the CUs)
+  static const int small_wgs = getenv("RTP_CONV64_WGS_SMALL") ? atoi(getenv("RTP_CONV64_WGS_SMALL")) : 128;
+  int wgs = (g->wgs > 0 ? (g->wgs > 256 ? 256 : g->wgs) : ((long)tiles * g->n < 4096 ? small_wgs : 256)) / g->n;
+  if (wgs < 1) wgs = 1;
+  if (wgs > tiles) wgs = tiles;
+  return wgs;
 }
 
-/* The conv as ONE launch of conv64_kernel on `wgs` workgroups per sample (= the statistics partials per sample the caller's
- * stat_out holds: [n][wgs][64][2]).  RTP_OK, +1 if the geometry / options are not this kernel's, or a negative error. */
+/* The conv as ONE launch of conv64_kernel on `wgs` = rtp_conv64_wgs(x, g, transposed) workgroups per sample (= the statistics
+ * partials per sample the caller's stat_out holds: [n][wgs][64][2]).  RTP_OK, +1 if the geometry / options are not this kernel's, or a negative error. */
 int rtp_conv64_try(const RtpAct* x, const void* wf, int w_per_sample, const float* btab, const RtpAct* res, const RtpAct* y,
                    const RtpConvGeom* g, int relu, int transposed, int y_fp32, const RtpAct* stat_x, float* stat_out, int wgs,
                    hipStream_t s) {
   if (!x || !y || !g || !wf) return RTP_ERR_SHAPE;
-  if (!c64_geometry_ok(x, y, g, transposed) || y_fp32 || (stat_x && res) || wgs < 1) return 1;
+  if (!c64_geometry_ok(x, g, transposed) || y_fp32 || (stat_x && res) || wgs < 1) return 1;
+  if (y->c < 64) return RTP_ERR_SHAPE;
+  if ((y->cs % 4) || (y->co % 4)) return RTP_ERR_ALIGN;
   if (rtp_multi_capture()) return RTP_ERR_UNSUPPORTED;
   const RtpAct* aux = stat_x ? stat_x : res;
   if (aux && (aux->c < 64 || (aux->cs % 4) || (aux->co % 4))) return RTP_ERR_ALIGN;

@@ -337,6 +337,7 @@ int rtp_conv_tiled_stat_slots(const RtpAct* x, const RtpConvGeom* g, int transpo
 int rtp_conv64_try(const RtpAct* x, const void* wf, int w_per_sample, const float* btab, const RtpAct* res, const RtpAct* y,
                    const RtpConvGeom* g, int relu, int transposed, int y_fp32, const RtpAct* stat_x, float* stat_out, int wgs,
                    hipStream_t s);
+int rtp_conv64_wgs(const RtpAct* x, const RtpConvGeom* g, int transposed);
 // ---- wide 3x3x3 stride-1 convs (Cin = 32 K, Cout = 32 J, K * J > 1) as K x J launches of the LDS-tiled 32 -> 32 kernel
 // (the 64- and 128-channel layers of the feat64 backbone, hrnet3D_config.py:149-177): output slice j is the sum over the
 // input slices k of a 32 x 32 window of the SAME weight image (fold output [n][27][Co][Ci] / data-gradient packing
@@ -356,6 +357,10 @@ static int sliced_stat_slots(const RtpAct* x, const RtpConvGeom* g, int transpos
   const int Ci = transposed ? (g->co + 31) / 32 * 32 : g->ci, Co = transposed ? g->ci : g->co;
   if (Ci % 32 || Co % 32 || Ci * Co <= 32 * 32 || Ci > 256 || Co > 256) return 0;
   if (!transposed && (g->co % 32)) return 0;
+  {   // 64 -> 64, stride 1: ONE launch of conv64_tiled.hip with its own width (the slice chain below only without that kernel)
+    const int w64 = rtp_conv64_wgs(x, g, transposed);
+    if (w64 > 0) return w64;
+  }
   RtpConvGeom gs; int K, J;
   slice_geom(g, transposed, &gs, &K, &J);
   RtpAct xs = *x; xs.c = 32;
@@ -380,10 +385,10 @@ static int conv_sliced(const RtpAct* x, const void* wf, int w_per_sample, const 
   const int Ci = 32 * K, Co = 32 * J;
   if (x->c < Ci || y->c < Co || (res && res->c < Co) || (stat_x && stat_x->c < Co)) return RTP_ERR_SHAPE;
   if (stat_out && y_fp32) return RTP_ERR_UNSUPPORTED;
-  if (K == 2 && J == 2 && g->stride == 1) {   // the native 64 -> 64 kernel: same partial slots, the workspace stays untouched
-    const int rc = rtp_conv64_try(x, wf, w_per_sample, btab, res, y, g, relu, transposed, y_fp32, stat_x, stat_out,
-                                  sliced_stat_slots(x, g, transposed), s);
+  if (const int w64 = rtp_conv64_wgs(x, g, transposed)) {   // the native 64 -> 64 kernel; the workspace stays untouched
+    const int rc = rtp_conv64_try(x, wf, w_per_sample, btab, res, y, g, relu, transposed, y_fp32, stat_x, stat_out, w64, s);
     if (rc <= 0) return rc;
+    if (stat_out) return RTP_ERR_UNSUPPORTED;   // (the slice chain would write another number of partials)
   }
   TiledSlice sl;
   // forward: wf [n][27][Co][Ci] (rows = output channels); transposed: wd [27][conv ci = Co here][cok = Ci here]
