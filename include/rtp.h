@@ -114,6 +114,33 @@ int rtp_conv_igemm_stats(const RtpAct* x, const void* wf, int w_per_sample, cons
  * rtp_conv_igemm_ws: rtp_conv_igemm / rtp_conv_igemm_stats (stat_x / stat_out may be NULL) with ws = n * (output voxels) * 32
  * floats of scratch; geometries that are not sliced ignore ws.  rtp_conv_stats_nsplit gives the partial count either way. */
 int rtp_conv_sliced_ok(const RtpAct* x, const RtpConvGeom* g, int transposed);
+
+/* --- 64-channel-wide stride-1 3x3x3 convolution in 32-channel BLOCKS (csrc/conv64_tiled.hip; round 5).
+ * The kernel behind the 64 -> 64 layers of rtp_conv_igemm_ws, with every operand addressed per 32-channel half, so that two
+ * 32-channel layers can share one launch -- SepHead's two towers over a 128- / 256-channel feature (center_head.py:86-93):
+ *   forward          x[k] = input-channel halves of ONE 64-channel slice of the feature, w[h][k] = tower h's weights for that slice,
+ *                    y[h] = tower h's output, btab[h] = its class-bias table; a feature wider than 64 channels is a CHAIN of calls
+ *                    over its slices through `acc` (fp32 [n][voxels][64]): acc_out on all but the last (raw sums, nothing else is
+ *                    written), acc_in on all but the first;
+ *   data gradient    transposed = 1 (taps flipped): x[k] = the gradient of tower k's output, w[h][k] = tower k's data-gradient
+ *                    weights for input channels 32 h .. 32 h + 31 of the slice, y[h] = those 32 channels of the feature's gradient --
+ *                    the SUM over both towers, one tensor instead of two for the fan-in pass.
+ * Weight block w[h][k]: [sample | 1][27 taps][32 rows = output channels of half h][32 columns = input channels of half k] with the
+ * given element strides (w_tap_stride between taps, w_row_stride between rows, w_sample_stride between samples when w_per_sample).
+ * btab[h]: [sample | 1][64 classes][bt_cs] or NULL; res[h]: residual added before the ReLU (both or neither).  Pointers carry the
+ * channel offsets (x, w: 16-byte aligned; y, res: 8-byte).  Geometry: ks 3, stride 1, pad 1, D % 2 == 0, H % 4 == 0, W % 16 == 0;
+ * g->ci / g->co are not read; g->wgs as everywhere (0: one workgroup per CU).  No allocation, no statistics. */
+typedef struct RtpConv64 {
+  const void* x[2]; int x_cs[2];
+  const void* w[2][2]; int w_row_stride, w_tap_stride; long w_sample_stride; int w_per_sample;
+  const float* btab[2]; int bt_cs;
+  const void* res[2]; int r_cs[2];
+  void* y[2]; int y_cs[2];
+  float* acc; int acc_in, acc_out;
+  int relu, transposed;
+} RtpConv64;
+int rtp_conv64_blocks(const RtpConv64* c, const RtpConvGeom* g, void* stream);
+
 int rtp_conv_stats_nsplit_ws(const RtpAct* x, const RtpConvGeom* g, int transposed);   /* partial count of rtp_conv_igemm_ws */
 int rtp_conv_igemm_ws(const RtpAct* x, const void* wf, int w_per_sample, const float* btab, const RtpAct* res,
                       const RtpAct* y, const RtpConvGeom* g, int relu, int transposed, int y_fp32,

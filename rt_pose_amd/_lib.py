@@ -41,6 +41,18 @@ class RtpGnFold(C.Structure):
                 ("nsplit", C.c_int), ("groups", C.c_int), ("co_real", C.c_int), ("eps", C.c_float), ("mr", C.c_void_p)]
 
 
+class RtpConv64(C.Structure):
+    """include/rtp.h: operands of rtp_conv64_blocks, per 32-channel half."""
+    _fields_ = [("x", C.c_void_p * 2), ("x_cs", C.c_int * 2),
+                ("w", (C.c_void_p * 2) * 2), ("w_row_stride", C.c_int), ("w_tap_stride", C.c_int), ("w_sample_stride", C.c_long),
+                ("w_per_sample", C.c_int),
+                ("btab", C.c_void_p * 2), ("bt_cs", C.c_int),
+                ("res", C.c_void_p * 2), ("r_cs", C.c_int * 2),
+                ("y", C.c_void_p * 2), ("y_cs", C.c_int * 2),
+                ("acc", C.c_void_p), ("acc_in", C.c_int), ("acc_out", C.c_int),
+                ("relu", C.c_int), ("transposed", C.c_int)]
+
+
 class RtpGnLazy(C.Structure):
     _fields_ = [("pq", C.c_void_p), ("nsplit", C.c_int), ("mr", C.c_void_p), ("gamma", C.c_void_p), ("groups", C.c_int)]
 
@@ -66,6 +78,7 @@ PROTOTYPES = {
     "rtp_conv_igemm_stats": [_A, _P, _I, _P, _A, _A, _G, _I, _I, _I, _A, _P, _P],
     "rtp_conv_stats_nsplit": [_A, _G, _I],
     "rtp_conv_sliced_ok": [_A, _G, _I],
+    "rtp_conv64_blocks": [_P, _G, _P],
     "rtp_conv_stats_nsplit_ws": [_A, _G, _I],
     "rtp_conv_igemm_ws": [_A, _P, _I, _P, _A, _A, _G, _I, _I, _I, _A, _P, _P, _P],
     "rtp_conv_igemm_acc": [_A, _P, _I, _P, _A, _A, _G, _I, _I, _I, _P, _I, _P],

@@ -211,6 +211,36 @@ class HipBackend:
         keep = (x, wt, bias, gamma, beta, stats, mr, res, y, stat_out, fs)
         return lambda s: check(fn(*args, s), "rtp_conv_gn_fused") or keep and None
 
+    def conv64_blocks(self, xs, wblocks, w_row_stride, w_tap_stride, btabs, bt_cs, ress, ys, geom, relu, transposed,
+                      acc=None, acc_in=False, acc_out=False):
+        """rtp_conv64_blocks (include/rtp.h): a 64-wide stride-1 3x3x3 conv whose operands are given per 32-channel half.
+        xs / ys / ress: pairs of Views (the 32 channels at .co; ys None with acc_out, ress None: no residual);
+        wblocks[h][k] = (bf16 tensor, element offset) of the weight block [27][32 rows of output half h][32 columns of input half k];
+        btabs = pair of (fp32 tensor, element offset) or None; acc: fp32 [n, voxels, 64] partial sums of a chain over slices."""
+        c = _lib.RtpConv64()
+        keep = [xs, wblocks, btabs, ress, ys, acc]
+        for h in range(2):
+            c.x[h] = xs[h].buf.data_ptr() + 2 * xs[h].co
+            c.x_cs[h] = xs[h].cs
+            for k in range(2):
+                t, off = wblocks[h][k]
+                c.w[h][k] = t.data_ptr() + 2 * off
+            if btabs is not None:
+                t, off = btabs[h]
+                c.btab[h] = t.data_ptr() + 4 * off
+            if ress is not None:
+                c.res[h] = ress[h].buf.data_ptr() + 2 * ress[h].co
+                c.r_cs[h] = ress[h].cs
+            if ys is not None:
+                c.y[h] = ys[h].buf.data_ptr() + 2 * ys[h].co
+                c.y_cs[h] = ys[h].cs
+        c.w_row_stride, c.w_tap_stride, c.w_sample_stride, c.w_per_sample = int(w_row_stride), int(w_tap_stride), 0, 0
+        c.bt_cs = int(bt_cs)
+        c.acc = acc.data_ptr() if acc is not None else None
+        c.acc_in, c.acc_out, c.relu, c.transposed = int(acc_in), int(acc_out), int(relu), int(transposed)
+        fn, g = self.lib.rtp_conv64_blocks, _geom(geom)
+        return lambda s: check(fn(C.byref(c), g, s), "rtp_conv64_blocks") or keep and None
+
     def conv_stats_nsplit(self, x, geom, transposed, ws=False):
         """ws: the conv will be launched with a slice workspace (conv(..., ws=...))."""
         fn = self.lib.rtp_conv_stats_nsplit_ws if ws else self.lib.rtp_conv_stats_nsplit

@@ -42,10 +42,21 @@
 
 __device__ __attribute__((aligned(16))) bf16_t g_zero_line_c64[8];
 
+// Every operand is addressed in 32-channel BLOCKS, so that one kernel serves a plain 64 -> 64 layer (blocks = windows of one tensor /
+// one weight image) and a PAIR of 32-channel layers that share the launch (rtp_conv64_blocks: the two head towers' first convs,
+// center_head.py:86-93 -- forward: two weight images and two outputs over one input; data gradient: two output gradients and two
+// weight images into one input gradient).
 struct C64Params {
-  const bf16_t* x; const bf16_t* w; const float* btab; const bf16_t* aux; bf16_t* y; float* stat_out;
+  const bf16_t* x[2]; int x_cs[2];             // input-channel halves (channel offset folded into the pointer)
+  const bf16_t* w[2][2];                       // weight blocks [output half][input half]: 32 rows x 32 columns per tap
+  int w_row_stride, w_tap_stride; long w_sample_stride;
+  const float* bt[2]; int bt_cs;               // class-bias tables by output half: [sample | 1][64 classes][bt_cs]
+  const bf16_t* aux[2]; int a_cs[2];           // residual / second statistics operand by output half
+  bf16_t* y[2]; int y_cs[2];                   // output halves
+  float* stat_out;                             // [n][wgs][64][2]
+  float* acc;                                  // fp32 partial sums [n][voxels][64] of a chain over input-channel slices
+  int acc_in, acc_out;                         // add them in the epilogue / write them INSTEAD of the finished output
   int N, D, H, W;
-  int x_cs, x_co, y_cs, y_co, a_cs, a_co;
   int relu, flip, w_per_sample;
   int aux_mode;                 // 0 none, 1 residual (added), 2 second operand of the statistics (sum y * aux instead of sum y^2)
   int wgs_per_sample, tiles_x, tiles_y, tiles_per_sample;
@@ -57,6 +68,8 @@ __device__ __forceinline__ void c64_dma16(const bf16_t* src, unsigned lds_wave_b
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" : : "s"(m0v), "v"(src) : "memory", "m0");
 }
 
+// ACC: the launch is a link of a chain over input-channel slices (fp32 partial sums in and / or out)
+template <bool ACC>
 __global__ __launch_bounds__(512, 2) void conv64_kernel(C64Params p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -72,12 +85,12 @@ __global__ __launch_bounds__(512, 2) void conv64_kernel(C64Params p) {
   unsigned char* xch = lds + 2 * C64_BRICK_B;
   float* red = reinterpret_cast<float*>(lds + 2 * C64_BRICK_B + C64_XCH_B);
 
-  // ---- this wave's share of the weight image, into registers (rows = this launch's output channels, 64 input channels per row)
+  // ---- this wave's share of the weights, into registers: rows (ct & 1) * 16 .. + 15 of block [ct >> 1][kh]
   bf16x8 wreg[27];
   {
-    const bf16_t* wsrc = p.w + (p.w_per_sample ? (long)n * 27 * 64 * 64 : 0) + (ct * 16 + v) * 64 + kh * 32 + q * 8;
+    const bf16_t* wsrc = (ct >> 1 ? (kh ? p.w[1][1] : p.w[1][0]) : (kh ? p.w[0][1] : p.w[0][0])) + (p.w_per_sample ? (long)n * p.w_sample_stride : 0) + ((ct & 1) * 16 + v) * p.w_row_stride + q * 8;
 #pragma unroll
-    for (int t = 0; t < 27; ++t) wreg[t] = ld_bf16x8(wsrc + (p.flip ? 26 - t : t) * (64 * 64));
+    for (int t = 0; t < 27; ++t) wreg[t] = ld_bf16x8(wsrc + (p.flip ? 26 - t : t) * p.w_tap_stride);
   }
   // ---- staging descriptors (brick independent): this thread's pieces of a brick
   int s_rel[C64_ROUNDS], s_pk[C64_ROUNDS];
@@ -88,21 +101,23 @@ __global__ __launch_bounds__(512, 2) void conv64_kernel(C64Params p) {
     const int hx = hv % C64_HX, hy = (hv / C64_HX) % C64_HY, hz = hv / (C64_HX * C64_HY);
     const int ck = (cp - 2 * (hx >> 1)) & 7;   // the logical chunk whose rotated position is cp
     s_pk[k] = (hz == 0) | ((hz == C64_HZ - 1) << 1) | ((hy == 0) << 2) | ((hy == C64_HY - 1) << 3) | ((hx == 0) << 4) |
-              ((hx == C64_HX - 1) << 5);
-    s_rel[k] = ((hz * p.H + hy) * p.W + hx) * p.x_cs + ck * 8;
+              ((hx == C64_HX - 1) << 5) | ((ck >> 2) << 6);   // bit 6: which input half the piece comes from
+    s_rel[k] = ((hz * p.H + hy) * p.W + hx) * ((ck >> 2) ? p.x_cs[1] : p.x_cs[0]) + (ck & 3) * 8;
   }
   const long vox_n = (long)n * p.D * p.H * p.W;
-  const bf16_t* xn = p.x + vox_n * p.x_cs + p.x_co;
+  const bf16_t* xn0 = p.x[0] + vox_n * p.x_cs[0];
+  const bf16_t* xn1 = p.x[1] + vox_n * p.x_cs[1];
   auto stage = [&](int t, int buf) {   // workgroup-uniform arguments
     const int tx = t % p.tiles_x, ty = (t / p.tiles_x) % p.tiles_y, tz = t / (p.tiles_x * p.tiles_y);
     const int z0 = tz * C64_TZ, y0 = ty * C64_TY, x0 = tx * C64_TX;
     const int tflg = (z0 == 0) | ((z0 + C64_TZ == p.D) << 1) | ((y0 == 0) << 2) | ((y0 + C64_TY == p.H) << 3) | ((x0 == 0) << 4) |
                      ((x0 + C64_TX == p.W) << 5);
-    const int org = (((z0 - 1) * p.H + (y0 - 1)) * p.W + (x0 - 1)) * p.x_cs;
+    const int orgv = ((z0 - 1) * p.H + (y0 - 1)) * p.W + (x0 - 1);
+    const int org0 = orgv * p.x_cs[0], org1 = orgv * p.x_cs[1];
 #pragma unroll
     for (int k = 0; k < C64_ROUNDS; ++k) {
       if (k * 512 + (tid & ~63) < C64_ITEMS) {   // wave-uniform (3456 = 54 waves' worth)
-        const bf16_t* src = (s_pk[k] & tflg) ? g_zero_line_c64 : xn + org + s_rel[k];
+        const bf16_t* src = (s_pk[k] & tflg) ? g_zero_line_c64 : ((s_pk[k] & 64) ? xn1 + org1 : xn0 + org0) + s_rel[k];
         c64_dma16(src, lds0 + buf * C64_BRICK_B + (k * 512 + (tid & ~63)) * 16);
       }
     }
@@ -115,6 +130,12 @@ __global__ __launch_bounds__(512, 2) void conv64_kernel(C64Params p) {
     boff[dx] = hx * 128 + (((kh * 4 + q) + 2 * (hx >> 1)) & 7) * 16;
   }
   const int c0 = ct * 16 + q * 4;   // the four output channels this lane's accumulator elements stand for
+  const int oh = ct >> 1, cl = c0 & 31;   // ... = channels cl .. cl + 3 of output half oh
+  const bf16_t* const auxp = (oh ? p.aux[1] : p.aux[0]) + cl;
+  const float* const btb = oh ? p.bt[1] : p.bt[0];
+  const float* const btp = btb ? btb + (long)(p.w_per_sample ? n : 0) * 64 * p.bt_cs + cl : nullptr;
+  bf16_t* const yp = (oh ? p.y[1] : p.y[0]) + cl;
+  const int a_cs = oh ? p.a_cs[1] : p.a_cs[0], y_cs = oh ? p.y_cs[1] : p.y_cs[0];
   float st_s[4] = {0.f, 0.f, 0.f, 0.f}, st_q[4] = {0.f, 0.f, 0.f, 0.f};
 
   stage(t_begin, 0);
@@ -166,17 +187,35 @@ __global__ __launch_bounds__(512, 2) void conv64_kernel(C64Params p) {
       const int z0 = tz * C64_TZ, y0 = ty * C64_TY, x = tx * C64_TX + v;
       bf16x4 av[C64_TZ][C64_TY];
       f32x4 bv[C64_TZ][C64_TY];
+      if (ACC && p.acc_out) {   // a link of a chain over input-channel slices: raw fp32 sums, nothing else
+#pragma unroll
+        for (int zo = 0; zo < C64_TZ; ++zo)
+#pragma unroll
+          for (int yo = 0; yo < C64_TY; ++yo) {
+            const f32x4 o = *reinterpret_cast<const f32x4*>(xch + ((ct * 8 + zo * C64_TY + yo) * 64 + lane) * 16);
+            const long vo = vox_n + ((long)(z0 + zo) * p.H + (y0 + yo)) * p.W + x;
+            f32x4 r = acc[zo][yo] + o;
+            if (p.acc_in) r += *reinterpret_cast<const f32x4*>(p.acc + vo * 64 + c0);
+            *reinterpret_cast<f32x4*>(p.acc + vo * 64 + c0) = r;
+          }
+        continue;
+      }
 #pragma unroll
       for (int zo = 0; zo < C64_TZ; ++zo)
 #pragma unroll
         for (int yo = 0; yo < C64_TY; ++yo) {
           const long vo = vox_n + ((long)(z0 + zo) * p.H + (y0 + yo)) * p.W + x;
-          if (p.aux_mode) av[zo][yo] = *reinterpret_cast<const bf16x4*>(p.aux + vo * p.a_cs + p.a_co + c0);
-          if (p.btab) {
+          if (p.aux_mode) av[zo][yo] = *reinterpret_cast<const bf16x4*>(auxp + vo * a_cs);
+          if (btp) {
             const int cls = vox_class(z0 + zo, y0 + yo, x, p.D, p.H, p.W);
-            bv[zo][yo] = *reinterpret_cast<const f32x4*>(p.btab + ((long)(p.w_per_sample ? n : 0) * 64 + cls) * 64 + c0);
+            bv[zo][yo] = *reinterpret_cast<const f32x4*>(btp + cls * p.bt_cs);
+          }
+          if (ACC && p.acc_in) {
+            const f32x4 a4 = *reinterpret_cast<const f32x4*>(p.acc + vo * 64 + c0);
+            bv[zo][yo] = btp ? bv[zo][yo] + a4 : a4;
           }
         }
+      const bool has_b = btp != nullptr || (ACC && p.acc_in);
 #pragma unroll
       for (int zo = 0; zo < C64_TZ; ++zo)
 #pragma unroll
@@ -187,14 +226,14 @@ __global__ __launch_bounds__(512, 2) void conv64_kernel(C64Params p) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             val[j] = acc[zo][yo][j] + o[j];
-            if (p.btab) val[j] += bv[zo][yo][j];
+            if (has_b) val[j] += bv[zo][yo][j];
             if (p.aux_mode == 1) val[j] += bf2f(av[zo][yo][j]);
             if (p.relu) val[j] = val[j] > 0.f ? val[j] : 0.f;
           }
           bf16x4 ob;
 #pragma unroll
           for (int j = 0; j < 4; ++j) ob[j] = f2bf(val[j]);
-          *reinterpret_cast<bf16x4*>(p.y + vo * p.y_cs + p.y_co + c0) = ob;
+          *reinterpret_cast<bf16x4*>(yp + vo * y_cs) = ob;
           if (p.stat_out) {   // of the STORED values, as a read-back pass would see them
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -256,8 +295,29 @@ int rtp_conv64_wgs(const RtpAct* x, const RtpConvGeom* g, int transposed) {
   return wgs;
 }
 
+static int c64_launch(C64Params& p, const RtpConvGeom* g, int wgs, hipStream_t s) {
+  p.N = g->n; p.D = g->di; p.H = g->hi; p.W = g->wi;
+  p.tiles_x = p.W / C64_TX; p.tiles_y = p.H / C64_TY;
+  p.tiles_per_sample = (p.D / C64_TZ) * p.tiles_y * p.tiles_x;
+  if (wgs < 1 || wgs > p.tiles_per_sample) return RTP_ERR_SHAPE;
+  p.wgs_per_sample = wgs;
+  const long vox = (long)p.D * p.H * p.W;
+  if (vox * p.x_cs[0] >= (1L << 31) || vox * p.x_cs[1] >= (1L << 31) || (long)p.tiles_per_sample * (wgs + 1) >= (1L << 31)) return RTP_ERR_SHAPE;
+  static bool attr_done[RTP_MAX_DEVICES] = {};
+  if (rtp_once_per_device(attr_done)) {
+    (void)hipFuncSetAttribute((const void*)conv64_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, C64_LDS_B);
+    (void)hipFuncSetAttribute((const void*)conv64_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, C64_LDS_B);
+  }
+  RtpProfScope prof(RTP_FAM_CONV_TILED, s);
+  if (p.acc_in || p.acc_out) hipLaunchKernelGGL(conv64_kernel<true>, dim3(p.N * wgs), dim3(512), C64_LDS_B, s, p);
+  else hipLaunchKernelGGL(conv64_kernel<false>, dim3(p.N * wgs), dim3(512), C64_LDS_B, s, p);
+  RTP_CHECK_LAUNCH();
+  return RTP_OK;
+}
+
 /* The conv as ONE launch of conv64_kernel on `wgs` = rtp_conv64_wgs(x, g, transposed) workgroups per sample (= the statistics
- * partials per sample the caller's stat_out holds: [n][wgs][64][2]).  RTP_OK, +1 if the geometry / options are not this kernel's, or a negative error. */
+ * partials per sample the caller's stat_out holds: [n][wgs][64][2]).  RTP_OK, +1 if the geometry / options are not this kernel's,
+ * or a negative error.  wf: [sample | 1][27][64][64] (rows = this launch's output channels). */
 int rtp_conv64_try(const RtpAct* x, const void* wf, int w_per_sample, const float* btab, const RtpAct* res, const RtpAct* y,
                    const RtpConvGeom* g, int relu, int transposed, int y_fp32, const RtpAct* stat_x, float* stat_out, int wgs,
                    hipStream_t s) {
@@ -270,22 +330,53 @@ int rtp_conv64_try(const RtpAct* x, const void* wf, int w_per_sample, const floa
   if (aux && (aux->c < 64 || (aux->cs % 4) || (aux->co % 4))) return RTP_ERR_ALIGN;
   if (stat_x && !stat_out) return RTP_ERR_SHAPE;
   C64Params p;
-  p.x = (const bf16_t*)x->ptr; p.w = (const bf16_t*)wf; p.btab = btab; p.aux = aux ? (const bf16_t*)aux->ptr : nullptr;
-  p.y = (bf16_t*)y->ptr; p.stat_out = stat_out;
-  p.N = g->n; p.D = g->di; p.H = g->hi; p.W = g->wi;
-  p.x_cs = x->cs; p.x_co = x->co; p.y_cs = y->cs; p.y_co = y->co; p.a_cs = aux ? aux->cs : 0; p.a_co = aux ? aux->co : 0;
+  for (int h = 0; h < 2; ++h) {
+    p.x[h] = (const bf16_t*)x->ptr + x->co + 32 * h; p.x_cs[h] = x->cs;
+    p.y[h] = (bf16_t*)y->ptr + y->co + 32 * h; p.y_cs[h] = y->cs;
+    p.aux[h] = aux ? (const bf16_t*)aux->ptr + aux->co + 32 * h : nullptr; p.a_cs[h] = aux ? aux->cs : 0;
+    p.bt[h] = btab ? btab + 32 * h : nullptr;
+    for (int k = 0; k < 2; ++k) p.w[h][k] = (const bf16_t*)wf + (32 * h) * 64 + 32 * k;
+  }
+  p.bt_cs = 64; p.w_row_stride = 64; p.w_tap_stride = 64 * 64; p.w_sample_stride = 27L * 64 * 64;
+  p.stat_out = stat_out; p.acc = nullptr; p.acc_in = p.acc_out = 0;
   p.relu = relu; p.flip = transposed; p.w_per_sample = w_per_sample;
   p.aux_mode = stat_x ? 2 : (res ? 1 : 0);
-  p.tiles_x = p.W / C64_TX; p.tiles_y = p.H / C64_TY;
-  p.tiles_per_sample = (p.D / C64_TZ) * p.tiles_y * p.tiles_x;
-  if (wgs > p.tiles_per_sample) return 1;   // (never at the shapes of the path: the slice kernels' bricks are twice as long)
-  p.wgs_per_sample = wgs;
-  if ((long)p.D * p.H * p.W * x->cs >= (1L << 31) || (long)p.tiles_per_sample * (wgs + 1) >= (1L << 31)) return RTP_ERR_SHAPE;
-  static bool attr_done[RTP_MAX_DEVICES] = {};
-  if (rtp_once_per_device(attr_done))
-    (void)hipFuncSetAttribute((const void*)conv64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, C64_LDS_B);
-  RtpProfScope prof(RTP_FAM_CONV_TILED, s);
-  hipLaunchKernelGGL(conv64_kernel, dim3(p.N * wgs), dim3(512), C64_LDS_B, s, p);
-  RTP_CHECK_LAUNCH();
-  return RTP_OK;
+  return c64_launch(p, g, wgs, s);
+}
+
+/* include/rtp.h: rtp_conv64_blocks */
+extern "C" int rtp_conv64_blocks(const RtpConv64* c, const RtpConvGeom* g, void* stream) {
+  if (!c || !g) return RTP_ERR_SHAPE;
+  if (g->ks != 3 || g->stride != 1 || g->pad != 1 || g->di % C64_TZ || g->hi % C64_TY || g->wi % C64_TX || g->n < 1) return RTP_ERR_UNSUPPORTED;
+  if (rtp_multi_capture()) return RTP_ERR_UNSUPPORTED;
+  C64Params p;
+  for (int h = 0; h < 2; ++h) {
+    if (!c->x[h] || (c->x_cs[h] % 8) || ((uintptr_t)c->x[h] % 16)) return RTP_ERR_ALIGN;
+    p.x[h] = (const bf16_t*)c->x[h]; p.x_cs[h] = c->x_cs[h];
+    if (c->acc_out) { p.y[h] = nullptr; p.y_cs[h] = 0; }
+    else {
+      if (!c->y[h] || (c->y_cs[h] % 4) || ((uintptr_t)c->y[h] % 8)) return RTP_ERR_ALIGN;
+      p.y[h] = (bf16_t*)c->y[h]; p.y_cs[h] = c->y_cs[h];
+    }
+    if (c->res[h] && ((c->r_cs[h] % 4) || ((uintptr_t)c->res[h] % 8))) return RTP_ERR_ALIGN;
+    p.aux[h] = (const bf16_t*)c->res[h]; p.a_cs[h] = c->r_cs[h];
+    p.bt[h] = c->btab[h];
+    for (int k = 0; k < 2; ++k) {
+      if (!c->w[h][k] || ((uintptr_t)c->w[h][k] % 16)) return RTP_ERR_ALIGN;
+      p.w[h][k] = (const bf16_t*)c->w[h][k];
+    }
+  }
+  if ((c->res[0] == nullptr) != (c->res[1] == nullptr)) return RTP_ERR_SHAPE;
+  if ((c->w_row_stride % 8) || (c->w_tap_stride % 8) || (c->w_sample_stride % 8) || c->w_row_stride < 32) return RTP_ERR_ALIGN;
+  if ((c->acc_in || c->acc_out) && (!c->acc || ((uintptr_t)c->acc % 16))) return RTP_ERR_SHAPE;
+  if ((c->btab[0] || c->btab[1]) && (c->bt_cs < 32 || (c->bt_cs % 4))) return RTP_ERR_ALIGN;
+  p.bt_cs = c->bt_cs; p.w_row_stride = c->w_row_stride; p.w_tap_stride = c->w_tap_stride; p.w_sample_stride = c->w_sample_stride;
+  p.stat_out = nullptr; p.acc = c->acc; p.acc_in = c->acc_in; p.acc_out = c->acc_out;
+  p.relu = c->relu; p.flip = c->transposed; p.w_per_sample = c->w_per_sample;
+  p.aux_mode = c->res[0] ? 1 : 0;
+  int wgs = (g->wgs > 0 ? (g->wgs > 256 ? 256 : g->wgs) : 256) / g->n;
+  const int tiles = (g->di / C64_TZ) * (g->hi / C64_TY) * (g->wi / C64_TX);
+  if (wgs < 1) wgs = 1;
+  if (wgs > tiles) wgs = tiles;
+  return c64_launch(p, g, wgs, (hipStream_t)stream);
 }

@@ -1302,3 +1302,54 @@ def test_head_last_convs_in_one_launch(hip, n):
     for k, ys in enumerate(outs):
         assert float(ys[0][0].g.abs().max()) > 0
         assert torch.equal(ys[0][0].g, ys[1][0].g), "problem %d" % k
+
+
+@pytest.mark.parametrize("case", [(2, (4, 8, 32), 128), (1, (2, 4, 16), 64), (8, (2, 8, 32), 256)])
+def test_conv64_blocks_two_towers_in_one_launch(hip, case):
+    """rtp_conv64_blocks (csrc/conv64_tiled.hip): SepHead's two towers' first convs, Conv3d(C, 32, 3x3x3, bias) + ReLU each
+    (center_head.py:86-93), as ONE 64-wide launch per 64-channel slice of the feature -- chained through fp32 partial sums for
+    C = 128 / 256 -- and their data gradients as one launch per 64 input channels that writes the SUM over both towers; against
+    torch's conv3d / autograd in fp32 on the same bf16-representable operands."""
+    import torch.nn.functional as F
+    n, dims, C = case
+    d, h, w = dims
+    geom = Geom(n, d, h, w, d, h, w, 64, 64, 3, 1, 1)
+    x = rnd((n, d, h, w, C), 700, relu=True)
+    W = [rnd((32, C, 3, 3, 3), 701 + t, torch.float32, 0.05).to(torch.bfloat16).float() for t in range(2)]
+    b = [rnd((32,), 703 + t, torch.float32) for t in range(2)]
+    dev = hip.device
+    xg = x.to(dev)
+    K = C // 32
+    wf = [[W[t][:, 32 * k:32 * k + 32].reshape(32, 32, 27).permute(2, 0, 1).contiguous().to(torch.bfloat16).to(dev) for k in range(K)]
+          for t in range(2)]                                                        # [tower][slice]: [27][32 co][32 ci]
+    wd = [[W[t][:, 32 * k:32 * k + 32].reshape(32, 32, 27).permute(2, 1, 0).contiguous().to(torch.bfloat16).to(dev) for k in range(K)]
+          for t in range(2)]                                                        # [27][32 ci][32 co]
+    bt = [b[t][None].expand(64, 32).contiguous().to(dev) for t in range(2)]
+    y = [torch.zeros(n, d, h, w, 32, dtype=torch.bfloat16, device=dev) for _ in range(2)]
+    yv = [View(t, n, d, h, w, 32, 0, 32) for t in y]
+    acc = hip.alloc((n, d * h * w, 64), "f32")
+    s = hip.stream()
+    M = C // 64
+    for m in range(M):
+        xs = [View(xg, n, d, h, w, C, 64 * m + 32 * k, 32) for k in range(2)]
+        blocks = [[(wf[t][2 * m + k], 0) for k in range(2)] for t in range(2)]
+        last = m == M - 1
+        hip.conv64_blocks(xs, blocks, 32, 1024, [(bt[0], 0), (bt[1], 0)] if last else None, 32, None, yv if last else None, geom,
+                          last, False, acc if M > 1 else None, m > 0, not last)(s)
+    torch.cuda.synchronize()
+    xr = x.float().permute(0, 4, 1, 2, 3).contiguous().requires_grad_(True)
+    want = [F.relu(F.conv3d(xr, W[t], b[t], padding=1)) for t in range(2)]
+    for t in range(2):
+        assert rel_err(y[t].float().cpu().permute(0, 4, 1, 2, 3), want[t]) < BF, "tower %d forward %r" % (t, case)
+    # data gradients: one tensor for both towers
+    gy = [rnd((n, d, h, w, 32), 710 + t) for t in range(2)]
+    gyg = [View(t.to(dev), n, d, h, w, 32, 0, 32) for t in gy]
+    dx = torch.zeros(n, d, h, w, C, dtype=torch.bfloat16, device=dev)
+    for j in range(C // 64):
+        blocks = [[(wd[t][2 * j + hh], 0) for t in range(2)] for hh in range(2)]   # [output half = slice 2j + hh][input half = tower]
+        ys = [View(dx, n, d, h, w, C, 64 * j + 32 * hh, 32) for hh in range(2)]
+        hip.conv64_blocks(gyg, blocks, 32, 1024, None, 32, None, ys, geom, False, True)(s)
+    torch.cuda.synchronize()
+    lin = sum((F.conv3d(xr, W[t], None, padding=1) * gy[t].float().permute(0, 4, 1, 2, 3)).sum() for t in range(2))
+    lin.backward()
+    assert rel_err(dx.float().cpu().permute(0, 4, 1, 2, 3), xr.grad) < BF, "data gradient of both towers %r" % (case,)
