@@ -376,6 +376,36 @@ class Graph:
         op.emit_forward()
         return y
 
+    def conv_pair(self, names, x: Act, wnames, bnames, relu=True):
+        """Two Conv3d(C, 32, 3x3x3, bias) [+ ReLU] over the SAME wide feature x -- SepHead's towers for the 128- / 256-channel features
+        of the one-heat-map configs (center_head.py:86-93) -- sharing their launches: forward and data gradient run 64 wide on
+        csrc/conv64_tiled.hip (one launch per 64-channel slice of x instead of two per 32-channel slice), and x receives ONE gradient
+        tensor, the sum over both towers.  -> [Act, Act], or None when the pair cannot share (the caller then builds them one by one)."""
+        import os
+        be = self.be
+        if not hasattr(be, "conv64_blocks") or os.environ.get("RTP_PAIR_HEADS", "1") == "0":
+            return None
+        ws = [self.param(n) for n in wnames]
+        ci_real = ws[0].shape[1]
+        if (len(names) != 2 or any(tuple(w.shape) != (32, ci_real, 3, 3, 3) for w in ws) or ci_real % 64 or x.c != ci_real or x.co != 0
+                or x.cs != ci_real or not all(bnames)):
+            return None
+        gs = Geom(self.n, x.d, x.h, x.w, x.d, x.h, x.w, 32, 32, 3, 1, 1, ci_real, 0)
+        if not be.conv_tiled_ok(View(x.buf, x.n, x.d, x.h, x.w, x.cs, 0, 32), gs, False):
+            return None
+        ops = []
+        for name, wn, bn in zip(names, wnames, bnames):
+            y = self.act(name, 32, x.dims, c=32, relu=relu)
+            op = SplitConvOp(self, name, x, y, gs, wn, bn, relu, ci_real, 32)
+            y.producer = op
+            self._add_op(op)
+            op.emit_forward(launches=False)
+            ops.append(op)
+        a, b = ops
+        a.partner, b.partner, a._pair_first, b._pair_first = b, a, True, False
+        a.emit_pair_forward()
+        return [a.y, b.y]
+
     def conv_cat(self, name, xs: List[Act], reals, wname, bname=None, relu=False):
         """Conv3d(sum(reals), Cout in {16, 32}, 3x3x3, bias) [+ ReLU] over the channel concatenation of `xs` without building
         it: every source (<= 32 real channels, padded to 32) is one input-channel slice of a SplitConvOp -- the two-stream
@@ -587,6 +617,9 @@ class Graph:
             if gy is None:
                 continue
             op.emit_backward(gy)
+        for op in order:
+            if getattr(op, "partner", None) is not None and op.x.needs_grad:
+                assert (op._pair_gy is None) == (op.partner._pair_gy is None), "paired head towers: one has a gradient, the other not"
         self.emit_tail(L_FULL)
 
     def emit_tail(self, lane=L_FULL):
@@ -971,6 +1004,10 @@ class SplitConvOp:
         # slices of one wide tensor (Graph.conv_cat); None: the K = Cin / 32 slices of x
         self.sources = sources
         self.K = len(sources) if sources else ci_real // 32
+        # partner: the OTHER head tower's first conv over the same feature (Graph.conv_pair): the two run as ONE 64-wide launch per
+        # 64-channel slice of the feature (rtp_conv64_blocks), forward and data gradient; the weight gradients stay per tower
+        self.partner = None
+        self._pair_gy = None
 
     def inputs(self):
         return [s[0] for s in self.sources] if self.sources else [self.x]
@@ -990,7 +1027,8 @@ class SplitConvOp:
         x = self.x
         return View(x.buf, x.n, x.d, x.h, x.w, x.cs, 32 * k, 32)
 
-    def emit_forward(self):
+    def emit_forward(self, launches=True):
+        """launches=False: the weight images only (the launches come from emit_pair_forward)."""
         g, be, gs = self.g, self.g.be, self.gs
         w = g.param(self.wname)
         bias = g.param(self.bname) if self.bname else None
@@ -998,8 +1036,10 @@ class SplitConvOp:
         need_dgrad = g.train and any(a.needs_grad for a in self.inputs())
         self.wf, self.wd, self.btab = [], [], None
         lane = g.lane_of(self.y)
-        acc = be.alloc((g.n, self.y.vox, gs.co), "f32")
-        accv = View(acc.view(g.n, self.y.d, self.y.h, self.y.w, gs.co), g.n, self.y.d, self.y.h, self.y.w, gs.co, 0, gs.co)
+        acc = accv = None
+        if launches:
+            acc = be.alloc((g.n, self.y.vox, gs.co), "f32")
+            accv = View(acc.view(g.n, self.y.d, self.y.h, self.y.w, gs.co), g.n, self.y.d, self.y.h, self.y.w, gs.co, 0, gs.co)
         for k in range(self.K):
             last = k == self.K - 1
             gk = self.slice_geom(k)
@@ -1012,6 +1052,8 @@ class SplitConvOp:
                 self.btab = bt
             g.head.append(("fold_fwd", w, bias if bt is not None else None, None, None, None, 0, 1, GN_EPS, gk, self.slice_real(k),
                            self.co_real, wf, bt, None, wd))
+            if not launches:
+                continue
             g.emit_fwd(be.conv(self.x_slice(k), wf, False, bt, None, self.y if last else accv, gk, self.relu and last, False,
                                not last, None, (acc, gs.co) if k > 0 else None),
                        lane, [self.inputs()[k] if self.sources else self.x, wf, bt, acc if k > 0 else None],
@@ -1021,17 +1063,61 @@ class SplitConvOp:
         g.flops["conv_tiled"] += self.alg_flops
         nb = 2 * g.n * (self.x.vox * (32 * self.K if self.sources else self.ci_real) + self.y.vox * self.y.c)
         g.alg_bytes["conv_tiled"] += nb
-        self.full = gs.co == 32 and g.n * self.y.vox >= (1 << 20)   # the profiling family of these launches (conv_tiled.hip)
+        self.full = launches and gs.co == 32 and g.n * self.y.vox >= (1 << 20)   # the profiling family of these launches (conv_tiled.hip)
         if self.full:
             g.flops["conv_tiled_full"] += self.alg_flops
             g.alg_bytes["conv_tiled_full"] += nb
+
+    def emit_pair_forward(self):
+        """Both towers (self, self.partner) as ONE launch per 64-channel slice of the feature: tower h = output half h, the partial
+        sums of a feature wider than 64 channels travel through one fp32 buffer [n][voxels][64]."""
+        g, be, gs, a, b, x = self.g, self.g.be, self.gs, self, self.partner, self.x
+        lane = g.lane_of(a.y)
+        M = self.K // 2
+        acc = be.alloc((g.n, a.y.vox, 64), "f32") if M > 1 else None
+        g64 = g.with_width(Geom(gs.n, gs.di, gs.hi, gs.wi, gs.do, gs.ho, gs.wo, 64, 64, 3, 1, 1), "conv:%s+%s" % (a.name, b.name))
+        ys = [View(t.y.buf, g.n, t.y.d, t.y.h, t.y.w, t.y.cs, 0, 32) for t in (a, b)]
+        for m in range(M):
+            last = m == M - 1
+            xs = [View(x.buf, x.n, x.d, x.h, x.w, x.cs, 64 * m + 32 * k, 32) for k in range(2)]
+            blocks = [[(t.wf[2 * m + k], 0) for k in range(2)] for t in (a, b)]
+            bts = [(a.btab, 0), (b.btab, 0)] if (last and a.btab is not None) else None
+            g.emit_fwd(be.conv64_blocks(xs, blocks, 32, gs.co * 32, bts, gs.co, None, ys if last else None, g64, a.relu and last, False,
+                                        acc, m > 0, not last),
+                       lane, [x, acc if m > 0 else None] + [t.wf[2 * m + k] for t in (a, b) for k in range(2)] + ([a.btab, b.btab] if bts else []),
+                       [a.y, b.y] if last else [acc], "conv:%s+%s.%d" % (a.name, b.name, m))
+
+    def _emit_pair_dgrad(self, gys):
+        """The data gradients of both towers as ONE launch per 64 input channels, summed: input half t = tower t's output gradient."""
+        g, be, gs, a, b, x = self.g, self.g.be, self.gs, self, self.partner, self.x
+        lane = g.lane_of(a.y)
+        towers = (a, b) if a._pair_first else (b, a)   # creation order: the order the forward used
+        gv = [View(gys[id(t)].buf, g.n, x.d, x.h, x.w, gys[id(t)].cs, gys[id(t)].co, 32) for t in towers]
+        dxb = be.alloc((g.n, x.d, x.h, x.w, self.ci_real), "bf16")
+        g64 = g.with_width(Geom(gs.n, gs.di, gs.hi, gs.wi, gs.do, gs.ho, gs.wo, 64, 64, 3, 1, 1), "dgrad:%s+%s" % (towers[0].name, towers[1].name))
+        for j in range(self.K // 2):
+            blocks = [[(t.wd[2 * j + hh], 0) for t in towers] for hh in range(2)]
+            ys = [View(dxb, g.n, x.d, x.h, x.w, self.ci_real, 64 * j + 32 * hh, 32) for hh in range(2)]
+            g.emit_bwd(be.conv64_blocks(gv, blocks, 32, 32 * 32, None, 32, None, ys, g64, False, True), lane,
+                       [gys[id(t)] for t in towers] + [t.wd[2 * j + hh] for t in towers for hh in range(2)], [dxb],
+                       "dgrad:%s+%s.%d" % (towers[0].name, towers[1].name, j))
+        x.contribs.append((View(dxb, g.n, x.d, x.h, x.w, self.ci_real, 0, self.ci_real), None))
+        for t in towers:
+            g.flops["conv_dgrad"] += t.alg_flops
+            g.flops["conv_tiled"] += t.alg_flops
+            g.alg_bytes["conv_tiled"] += 2 * g.n * (x.vox * 32 + x.vox * self.ci_real // 2)
 
     def emit_backward(self, gy: View):
         g, be, gs, x = self.g, self.g.be, self.gs, self.x
         co32 = pad_to(gs.co, 32)
         assert gy.c >= co32, (self.name, gy.c, co32)
         lane = g.lane_of(self.y)
-        if self.sources:   # separate tensors: a data gradient per source that wants one
+        if self.partner is not None and x.needs_grad:
+            # the tower the sweep reaches second emits the shared data-gradient launches; each tower its own weight gradients
+            self._pair_gy = gy
+            if self.partner._pair_gy is not None:
+                self._emit_pair_dgrad({id(self): gy, id(self.partner): self.partner._pair_gy})
+        elif self.sources:   # separate tensors: a data gradient per source that wants one
             for k, (a, _real, _off) in enumerate(self.sources):
                 if not a.needs_grad:
                     continue

@@ -126,9 +126,20 @@ def build_head(g: Graph, feats, heads, prefix="pose_head", lidar=None):
         adapt = {"hm": g.dcn_adapt("adapt.cls", feats, prefix + ".tasks.0.feature_adapt_cls"),
                  "reg": g.dcn_adapt("adapt.reg", feats, prefix + ".tasks.0.feature_adapt_reg")}
     src = feats
+    # the two towers' first convs over a 128- / 256-channel feature: one 64-wide launch per 64-channel slice (Graph.conv_pair)
+    paired = {}
+    hl = list(heads)
+    if lidar is None and not adapt and len(hl) == 2:
+        ps = ["%s.tasks.0.%s" % (prefix, name) for name in hl]
+        ts = g.conv_pair(["head.%s.0" % name for name in hl], src, [p + ".0.weight" for p in ps], [p + ".0.bias" for p in ps], relu=True)
+        if ts is not None:
+            paired = dict(zip(hl, ts))
     for name in heads:
         p = "%s.tasks.0.%s" % (prefix, name)
         feats = adapt.get(name, src)
+        if name in paired:
+            out[name] = g.conv("head.%s.2" % name, paired[name], p + ".2.weight", bname=p + ".2.bias", out_fp32=True)
+            continue
         if lidar is not None:
             t = g.conv_cat("head.%s.0" % name, [feats, lidar[0]], [feats.c_real, lidar[1]], p + ".0.weight", bname=p + ".0.bias",
                            relu=True)

@@ -259,6 +259,40 @@ class EmuBackend:
                 so[:, 0, :, 1] = (yv * other).sum(1)
         return run
 
+    def conv64_blocks(self, xs, wblocks, w_row_stride, w_tap_stride, btabs, bt_cs, ress, ys, geom, relu, transposed,
+                      acc=None, acc_in=False, acc_out=False):
+        """rtp_conv64_blocks: a 64 -> 64 stride-1 3x3x3 conv assembled from 32-channel blocks (include/rtp.h)."""
+        def run(s):
+            g = geom
+            xin = _ncdhw(torch.cat([_sl(v)[..., :32] for v in xs], -1))          # [n, 64, d, h, w]
+            W = torch.zeros(64, 64, 27, device=xin.device)
+            for hh in range(2):
+                for k in range(2):
+                    t, off = wblocks[hh][k]
+                    blk = torch.as_strided(t.reshape(-1), (27, 32, 32), (w_tap_stride, w_row_stride, 1), off).float()
+                    W[32 * hh:32 * hh + 32, 32 * k:32 * k + 32] = blk.permute(1, 2, 0)
+            if transposed:   # out[v] = sum_tau W[tau] . in[v - (tau - 1)]
+                W = W.flip(2)
+            out = _ndhwc(F.conv3d(xin, W.view(64, 64, 3, 3, 3), None, 1, 1))
+            if acc_in:
+                out = out + acc.view(g.n, g.di, g.hi, g.wi, 64)
+            if acc_out:
+                acc.view(g.n, g.di, g.hi, g.wi, 64).copy_(out)
+                return
+            if btabs is not None:
+                cls = _classes(g.di, g.hi, g.wi)
+                for hh in range(2):
+                    t, off = btabs[hh]
+                    bt = torch.as_strided(t.reshape(-1), (64, 32), (bt_cs, 1), off).float()
+                    out[..., 32 * hh:32 * hh + 32] += bt[cls]
+            if ress is not None:
+                out = out + torch.cat([_sl(v)[..., :32] for v in ress], -1)
+            if relu:
+                out = out.clamp_min(0)
+            for hh in range(2):
+                self._store(ys[hh], out[..., 32 * hh:32 * hh + 32])
+        return run
+
     def wgrad(self, gy, x, geom, nsplit, gp):
         def run(s):
             g = geom

@@ -291,3 +291,28 @@ def test_launch_list_reorderings_keep_dependencies_and_results(monkeypatch):
         l1, g1 = run(env)
         assert torch.equal(l0, l1), env
         assert all(torch.equal(g0[k], g1[k]) for k in g0), env
+
+
+def test_head_towers_over_a_wide_feature_share_their_launches(monkeypatch):
+    """Graph.conv_pair: SepHead's two first convs over the 128-channel feature of the one-heat-map configs (center_head.py:86-93)
+    run 64 wide -- one launch per 64-channel slice forward, one per 64 input channels for the data gradient, which writes the SUM
+    over both towers -- and give what the per-tower slice route (RTP_PAIR_HEADS=0) gives."""
+    def grads(paired):
+        monkeypatch.setenv("RTP_PAIR_HEADS", "1" if paired else "0")
+        eng, flat, sd, ex, _ = make("hr3d_one_hm_doppler", exact=True)
+        eng.load_input(ex["rdr"]["rdr_tensor"])
+        eng.load_targets(ex["rdr"])
+        eng.run_forward()
+        eng.run_loss_backward()
+        return [L.tag for L in eng.fwd + eng.bwd], {k: v.clone() for k, v in flat.grads.items()}, eng.losses()
+    tags, g1, l1 = grads(True)
+    assert [t for t in tags if t.startswith("conv:head.reg.0")] == ["conv:head.reg.0+head.hm.0.0", "conv:head.reg.0+head.hm.0.1"]
+    assert [t for t in tags if t.startswith("dgrad:head.reg.0")] == ["dgrad:head.reg.0+head.hm.0.0", "dgrad:head.reg.0+head.hm.0.1"]
+    assert not any(t.startswith(("conv:head.hm.0", "dgrad:head.hm.0")) for t in tags)
+    assert sum(t.startswith("wgrad:head.reg.0.") for t in tags) == 4 and sum(t.startswith("wgrad:head.hm.0.") for t in tags) == 4
+    assert "combine:final.sum" not in tags, "one gradient tensor for the feature: no fan-in pass"
+    tags0, g0, l0 = grads(False)
+    assert sum(t.startswith("conv:head.reg.0.") for t in tags0) == 4 and "combine:final.sum" in tags0
+    assert abs(float(l1["loss"]) - float(l0["loss"])) < 1e-5 * abs(float(l0["loss"]))
+    for k in g0:
+        assert rel_err(g1[k], g0[k]) < 1e-4, k
