@@ -120,8 +120,8 @@ int rtp_conv_sliced_ok(const RtpAct* x, const RtpConvGeom* g, int transposed);
  * 32-channel layers can share one launch -- SepHead's two towers over a 128- / 256-channel feature (center_head.py:86-93):
  *   forward          x[k] = input-channel halves of ONE 64-channel slice of the feature, w[h][k] = tower h's weights for that slice,
  *                    y[h] = tower h's output, btab[h] = its class-bias table; a feature wider than 64 channels is a CHAIN of calls
- *                    over its slices through `acc` (fp32 [n][voxels][64]): acc_out on all but the last (raw sums, nothing else is
- *                    written), acc_in on all but the first;
+ *                    over its slices through `acc` (n * voxels * 64 floats, in a layout private to the chain: the links must share geometry and
+ *                    g->wgs): acc_out on all but the last (raw sums, nothing else is written), acc_in on all but the first;
  *   data gradient    transposed = 1 (taps flipped): x[k] = the gradient of tower k's output, w[h][k] = tower k's data-gradient
  *                    weights for input channels 32 h .. 32 h + 31 of the slice, y[h] = those 32 channels of the feature's gradient --
  *                    the SUM over both towers, one tensor instead of two for the fan-in pass.

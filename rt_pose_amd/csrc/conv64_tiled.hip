@@ -54,7 +54,7 @@ struct C64Params {
   const bf16_t* aux[2]; int a_cs[2];           // residual / second statistics operand by output half
   bf16_t* y[2]; int y_cs[2];                   // output halves
   float* stat_out;                             // [n][wgs][64][2]
-  float* acc;                                  // fp32 partial sums [n][voxels][64] of a chain over input-channel slices
+  float* acc;                                  // fp32 partial sums (n * voxels * 64 floats) of a chain over input-channel slices
   int acc_in, acc_out;                         // add them in the epilogue / write them INSTEAD of the finished output
   int N, D, H, W;
   int relu, flip, w_per_sample;
@@ -187,16 +187,19 @@ __global__ __launch_bounds__(512, 2) void conv64_kernel(C64Params p) {
       const int z0 = tz * C64_TZ, y0 = ty * C64_TY, x = tx * C64_TX + v;
       bf16x4 av[C64_TZ][C64_TY];
       f32x4 bv[C64_TZ][C64_TY];
+      // The partial sums of a chain are private to its links (same geometry, same width, hence the same bricks on the same waves):
+      // they are kept in the ACCUMULATORS' layout [sample][brick][channel tile][voxel tile][lane] x 16 B -- every access is one
+      // contiguous kilobyte per wave (in voxel-major order a lane's four channels are a 16-byte piece of a 256-byte row).
+      f32x4* const accp = ACC ? reinterpret_cast<f32x4*>(p.acc) + (((long)n * p.tiles_per_sample + t) * 4 + ct) * (8 * 64) + lane : nullptr;
       if (ACC && p.acc_out) {   // a link of a chain over input-channel slices: raw fp32 sums, nothing else
 #pragma unroll
         for (int zo = 0; zo < C64_TZ; ++zo)
 #pragma unroll
           for (int yo = 0; yo < C64_TY; ++yo) {
             const f32x4 o = *reinterpret_cast<const f32x4*>(xch + ((ct * 8 + zo * C64_TY + yo) * 64 + lane) * 16);
-            const long vo = vox_n + ((long)(z0 + zo) * p.H + (y0 + yo)) * p.W + x;
             f32x4 r = acc[zo][yo] + o;
-            if (p.acc_in) r += *reinterpret_cast<const f32x4*>(p.acc + vo * 64 + c0);
-            *reinterpret_cast<f32x4*>(p.acc + vo * 64 + c0) = r;
+            if (p.acc_in) r += accp[(zo * C64_TY + yo) * 64];
+            accp[(zo * C64_TY + yo) * 64] = r;
           }
         continue;
       }
@@ -211,7 +214,7 @@ __global__ __launch_bounds__(512, 2) void conv64_kernel(C64Params p) {
             bv[zo][yo] = *reinterpret_cast<const f32x4*>(btp + cls * p.bt_cs);
           }
           if (ACC && p.acc_in) {
-            const f32x4 a4 = *reinterpret_cast<const f32x4*>(p.acc + vo * 64 + c0);
+            const f32x4 a4 = accp[(zo * C64_TY + yo) * 64];
             bv[zo][yo] = btp ? bv[zo][yo] + a4 : a4;
           }
         }

@@ -274,7 +274,7 @@ class EmuBackend:
             if transposed:   # out[v] = sum_tau W[tau] . in[v - (tau - 1)]
                 W = W.flip(2)
             out = _ndhwc(F.conv3d(xin, W.view(64, 64, 3, 3, 3), None, 1, 1))
-            if acc_in:
+            if acc_in:   # (the layout of the partial sums is private to the chain)
                 out = out + acc.view(g.n, g.di, g.hi, g.wi, 64)
             if acc_out:
                 acc.view(g.n, g.di, g.hi, g.wi, 64).copy_(out)
