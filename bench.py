@@ -468,11 +468,12 @@ def main():
                             "hbm_view": {"achieved": round(best[3], 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                                          "frac": round(best[3] / PEAK_HBM_GBPS, 4)},
                             "families": detail}
-    # The other shipped configs (configs/cruw_pose/hr3d_one_hm_doppler*.py), driver-timed in the same run: 3 warm-up + 10 timed
-    # train steps each at the same 8 frames per GPU (their plans are built beside the headline model's)
+    # The other shipped configs (configs/cruw_pose/hr3d_one_hm_doppler*.py) and the DCN-head variant of the headline model (BASELINE
+    # config 4), driver-timed in the same run: 3 warm-up + 10 timed train steps each at the same 8 frames per GPU (their plans are
+    # built beside the headline model's)
     if world == 1 and not args.no_other_models and args.model == "hr3d":
         line["other_models"] = {}
-        for oname in ("hr3d_one_hm_doppler", "hr3d_one_hm_doppler_phase"):
+        for oname in ("hr3d_one_hm_doppler", "hr3d_one_hm_doppler_phase", "hr3d_dcn"):
             ospec = configs.spec(oname)
             # (same backend object and step stream as the headline model: the lanes keep their streams / hardware queues)
             otr = DataParallelTrainer(oname, args.batch, configs.NATIVE_DIMS, total_steps=100, device=dev, use_graph=False,

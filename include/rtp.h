@@ -380,6 +380,18 @@ int rtp_unpack_ncdhw_f32(const float* x, int x_cs, int x_co, float* y, int n, in
  * det3d/models/pose_heads/center_head.py:59-62; backward: grad_input of the two paths summed). */
 int rtp_pack_ncdhw_ex(const float* x, const float* x2, const RtpAct* y, int n, int c, long vox, int relu, void* stream);
 
+/* --- Deformable convolution forward on the plan's layout (csrc/dcn_cl.hip; round 5): the deformable half of FeatureAdaption
+ * (center_head.py:24-62) per (frame, z) slice without the hand-off to the fp32 NCHW operator of section D.
+ *   x   bf16 channels-last [n_img][h][w][>= 32]   (n_img = frames * Z: the 5-D feature with Z folded into the batch)
+ *   off fp32 channels-last [n_img][h][w][>= 72]   (RtpAct over floats: 4 deformable groups x 9 taps x (dh, dw), the order of
+ *                                                  deform_conv_cuda_kernel.cu:190-243)
+ *   w   fp32 [32][32][3][3] (DeformConv.weight, no bias);  y bf16 channels-last [n_img][h][w][>= 32], ReLU when relu != 0.
+ * DCNv1, 3x3, stride 1, padding 1, dilation 1, 32 -> 32 channels, 4 deformable groups; h * w a multiple of 16.  Sampling rule and
+ * per-corner bounds as the section-D operator; the samples and the weights enter the product as bf16 (fp32 accumulation), like the
+ * operands of every other conv of the plan -- rtp_deform_conv_forward keeps fp32 operands.  No allocation. */
+int rtp_dcn_cl_forward(const RtpAct* x, const RtpAct* off, const float* w, const RtpAct* y, int n_img, int h, int w_, int relu,
+                       void* stream);
+
 /* ---------------------------------------------------------------- C. head: loss / decode / optimiser --- */
 
 /* FastFocalLoss forward+backward (centernet_loss.py:34-54, center_head.py:240-242).

@@ -79,6 +79,7 @@ PROTOTYPES = {
     "rtp_conv_stats_nsplit": [_A, _G, _I],
     "rtp_conv_sliced_ok": [_A, _G, _I],
     "rtp_conv64_blocks": [_P, _G, _P],
+    "rtp_dcn_cl_forward": [_A, _A, _P, _A, _I, _I, _I, _I, _P],
     "rtp_conv_stats_nsplit_ws": [_A, _G, _I],
     "rtp_conv_igemm_ws": [_A, _P, _I, _P, _A, _A, _G, _I, _I, _I, _A, _P, _P, _P],
     "rtp_conv_igemm_acc": [_A, _P, _I, _P, _A, _A, _G, _I, _I, _I, _P, _I, _P],

@@ -6,6 +6,7 @@ There is deliberately no CPU path here: constructing the backend without a GPU o
 raises.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -495,6 +496,15 @@ class HipBackend:
         return lambda s: check(fn(*args, s), "rtp_unpack_ncdhw") or keep and None
 
     # -------------------------------------------------------------- deformable feature adaption (BASELINE config 4)
+    def dcn_cl_forward(self, x, off_act, w_ad, y, relu=True):
+        """rtp_dcn_cl_forward: y = [relu] DeformConv3x3_dg4(x, off) per (frame, z) slice on the plan's layout (x, y bf16 channels-last
+        Views, off_act an fp32 channels-last View with >= 72 channels, w_ad fp32 [32, 32, 3, 3])."""
+        fn = self.lib.rtp_dcn_cl_forward
+        oa = RtpAct(off_act.buf.data_ptr(), off_act.cs, off_act.co, off_act.c)
+        args = (_act(x), oa, _ptr(w_ad), _act(y), x.n * x.d, x.h, x.w, int(relu))
+        keep = (x, off_act, w_ad, y)
+        return lambda s: check(fn(*args, s), "rtp_dcn_cl_forward") or keep and None
+
     def dcn_adapt(self, x, off_act, koff, w_ad, y, dg=4):
         """The deformable half of FeatureAdaption (center_head.py:24-62) on a 5-D feature with Z folded into the batch:
         y = relu(DeformConv3x3(x2, offset)) for x2 = [N*D, C, H, W].  The offsets are an activation of the plan (the 1x1
@@ -512,10 +522,24 @@ class HipBackend:
         ws3 = f32(max(1, lib.rtp_dcn_workspace_bytes(step, C, H, W, C, 3, 3, H, W) // 4))
         xa, ya = _act(x), _act(y)
         keep = [x, y, off_act, w_ad, xf, off, yf, ws3]
+        # forward on the plan's own layout (rtp_dcn_cl_forward: four 16-byte corner loads per sample instead of sixteen planar ones,
+        # no unpack / transpose / pack passes); the backward operator still wants fp32 planes and unpacks them itself then.
+        # RTP_DCN_CL=0: the fp32 NCHW operator for the forward too
+        cl = (os.environ.get("RTP_DCN_CL", "1") != "0" and C == 32 and dg == 4 and koff == 72 and vox % 16 == 0
+              and x.cs % 8 == 0 and x.co % 8 == 0)
+        oa = RtpAct(off_act.buf.data_ptr(), off_act.cs, off_act.co, off_act.c)
 
-        def fwd(s):
+        state = {"prepared": False}   # True: the plan runs `prep` as a launch of its own (beside the forward) before the backward
+
+        def unpack_inputs(s):
             check(lib.rtp_unpack_ncdhw(xa, _ptr(xf), N, C, vox, s), "rtp_unpack_ncdhw")
             check(lib.rtp_unpack_ncdhw_f32(_ptr(off_act.buf), off_act.cs, off_act.co, _ptr(off), N, koff, vox, s), "rtp_unpack_ncdhw_f32")
+
+        def fwd(s):
+            if cl:
+                check(lib.rtp_dcn_cl_forward(xa, oa, _ptr(w_ad), ya, N, H, W, 1, s), "rtp_dcn_cl_forward")
+                return keep and None
+            unpack_inputs(s)
             check(lib.rtp_deform_conv_forward(_ptr(xf), _ptr(w_ad), _ptr(off), _ptr(yf), _ptr(ws3), N, C, H, W, C, 3, 3, 1, 1, 1, 1,
                                               1, 1, 1, dg, step, s), "rtp_deform_conv_forward")
             check(lib.rtp_pack_ncdhw_ex(_ptr(yf), None, ya, N, C, vox, 1, s), "rtp_pack_ncdhw_ex")
@@ -530,6 +554,8 @@ class HipBackend:
             def bwd(s):
                 # the plan owns the three gradient buffers: the overwriting entry (no zero fills; the reference's wrapper
                 # allocates zeros and accumulates, deform_conv.py:75-76, 86)
+                if cl and not state["prepared"]:
+                    unpack_inputs(s)
                 check(lib.rtp_unpack_ncdhw(gya, _ptr(gyf), N, C, vox, s), "rtp_unpack_ncdhw")
                 check(lib.rtp_deform_conv_backward_overwrite(_ptr(xf), _ptr(off), _ptr(gyf), _ptr(gi), _ptr(goff), _ptr(w_ad),
                                                              _ptr(gw_ad), _ptr(ws3), N, C, H, W, C, 3, 3, 1, 1, 1, 1, 1, 1, 1, dg,
@@ -539,6 +565,16 @@ class HipBackend:
                 check(lib.rtp_pack_ncdhw_ex(_ptr(goff), None, goa, N, koff, vox, 0, s), "rtp_pack_ncdhw_ex")
                 return keepb and None
             return bwd
+
+        if cl:
+            def prep(s):
+                unpack_inputs(s)
+                return keep and None
+
+            def use_prep():
+                state["prepared"] = True
+                return prep
+            make_backward.prep = use_prep   # the backward operator's fp32 planes as a launch the plan places where it likes
         return fwd, make_backward
 
     # -------------------------------------------------------------- head: loss / decode / optimiser

@@ -464,6 +464,10 @@ class Graph:
         # both on the main lane, A/B)
         op.lane = L_MID if (name.endswith(".reg") and not os.environ.get("RTP_DCN_ONE_LANE")) else self.lane_of(y)
         self.emit_fwd(op.fwd_fn, op.lane, [x, off, w_ad], [y], "dcn:" + name)
+        if self.train and hasattr(op.make_bwd, "prep") and not os.environ.get("RTP_DCN_PREP_IN_BWD"):
+            # the forward runs on the plan's layout (rtp_dcn_cl_forward); the fp32 planes the BACKWARD operator reads are unpacked by a
+            # launch of their own on a lane that idles while the head runs, instead of in front of the backward operator
+            self.emit_fwd(op.make_bwd.prep(), L_WG_LOW, [x, off], [], "dcnprep:" + name)
         return y
 
     def forward_list(self):

@@ -403,3 +403,46 @@ def test_small_fixed_case_on_the_gpu(mode, monkeypatch):
     def dcn(x, off, w):
         return deform_conv(x.cuda(), off.cuda(), w.cuda(), 1, 0, 1, 1, 1, 1).cpu()
     run_known_answer(dcn)
+
+
+@pytest.mark.parametrize("case", [
+    # frames, z, h, w, offset sigma (pixels), relu
+    (1, 2, 8, 16, 0.5, True), (2, 3, 16, 32, 1.5, False), (1, 1, 4, 4, 0.0, True), (2, 2, 12, 20, 6.0, True),   # 6 px: samples leave the image
+    (1, 4, 64, 160, 0.7, True),                                                                                    # the native slice shape
+])
+def test_dcn_forward_on_the_plans_layout(case):
+    """rtp_dcn_cl_forward (csrc/dcn_cl.hip): bf16 channels-last feature + fp32 channels-last offsets -> bf16 channels-last output, the
+    deformable half of FeatureAdaption (center_head.py:24-62) without the hand-off to the fp32 NCHW operator -- against the oracle
+    (oracle/dcn_ref.py, parity unpinned) on the same bf16-representable feature and weights, and against the section-D operator on
+    the device.  Tolerance: the samples are rounded to bf16 before the product (one more bf16 rounding than the operator's output
+    rounding): norm-wise 6e-3."""
+    from oracle import dcn_ref
+    from rt_pose_amd.backend import HipBackend
+    from rt_pose_amd.graph import View
+    from tests.util import rel_err
+    hip = HipBackend("cuda:0")
+    nf, z, h, w, sigma, relu = case
+    g = torch.Generator().manual_seed(99)
+    x = (torch.randn(nf, z, h, w, 32, generator=g)).to(torch.bfloat16)
+    off = torch.randn(nf, z, h, w, 80, generator=g) * sigma          # 72 used of an 80-channel row
+    wt = (torch.randn(32, 32, 3, 3, generator=g) * 0.1).to(torch.bfloat16).float()
+    dev = hip.device
+    xg, og, wg = x.to(dev), off.to(dev), wt.to(dev)
+    y = torch.zeros(nf, z, h, w, 32, dtype=torch.bfloat16, device=dev)
+    hip.dcn_cl_forward(View(xg, nf, z, h, w, 32, 0, 32), View(og, nf, z, h, w, 80, 0, 72), wg, View(y, nf, z, h, w, 32, 0, 32), relu)(hip.stream())
+    torch.cuda.synchronize()
+    x2 = x.float().permute(0, 1, 4, 2, 3).reshape(nf * z, 32, h, w)
+    o2 = off[..., :72].permute(0, 1, 4, 2, 3).reshape(nf * z, 72, h, w).contiguous()
+    want = dcn_ref.deform_conv2d(x2, o2, wt, 1, 1, 1, 1, 4)
+    if relu:
+        want = torch.relu(want)
+    got = y.float().cpu().permute(0, 1, 4, 2, 3).reshape(nf * z, 32, h, w)
+    assert torch.isfinite(got).all()
+    assert rel_err(got, want) < 6e-3, (case, rel_err(got, want))
+    # the fp32 NCHW operator on the same inputs
+    from rt_pose_amd import deform_conv_cuda as dcc
+    out = torch.zeros(nf * z, 32, h, w, device=dev)
+    cols, ones = torch.zeros(1, device=dev), torch.zeros(1, device=dev)
+    dcc.deform_conv_forward_cuda(x2.to(dev).contiguous(), wg, o2.to(dev), out, cols, ones, 3, 3, 1, 1, 1, 1, 1, 1, 1, 4, min(64, nf * z))
+    ref = torch.relu(out) if relu else out
+    assert rel_err(got, ref.cpu()) < 6e-3
