@@ -18,6 +18,11 @@
 //     per brick orders everything (brick buffers, exchange area);
 //   * the LDS image rotates the 16-B chunk index by 2 * (x >> 1) (mod 8) -- with 128 B per voxel two voxels share a 256-B bank row,
 //     and the rotation makes every ds_read_b128 lane group hit 16 distinct 16-B slots for each of the three x shifts.
+//   * W need not be a multiple of the brick: the last brick column's lanes beyond the volume stage zeros and store nothing (the
+//     level-2 / level-3 tensors of the native shape have 40 and 20 columns);
+//   * (the GroupNorm fold in this kernel's prologue, as conv_tiled.hip has it, was built and measured: 5.100-5.111 ms per hr3d step
+//     against 5.087-5.104 with the fold launch in front -- every workgroup folding its sample's 442 KB of fp32 weights costs what the
+//     launch saves; removed)
 // Results: the same arithmetic as the slice chain up to fp32 summation order (one accumulator chain per input-channel half).
 // Measured (B = 8, [16, 64, 160]): forward 281 us, data gradient 267 us = 1.03 / 1.09 PFLOP/s (the slice chain: 441 / 432 us);
 // level 1 ([8, 32, 80]) 43 us on the whole chip (tools/microbench_conv64.py).
@@ -103,7 +108,7 @@ __global__ __launch_bounds__(512, 2) void conv64_kernel(C64Params p) {
     const int hx = hv % C64_HX, hy = (hv / C64_HX) % C64_HY, hz = hv / (C64_HX * C64_HY);
     const int ck = (cp - 2 * (hx >> 1)) & 7;   // the logical chunk whose rotated position is cp
     s_pk[k] = (hz == 0) | ((hz == C64_HZ - 1) << 1) | ((hy == 0) << 2) | ((hy == C64_HY - 1) << 3) | ((hx == 0) << 4) |
-              ((hx == C64_HX - 1) << 5) | ((ck >> 2) << 6);   // bit 6: which input half the piece comes from
+              ((ck >> 2) << 6) | (hx << 8);   // bit 6: which input half the piece comes from; bits 8-12: the haloed x index
     s_rel[k] = ((hz * p.H + hy) * p.W + hx) * ((ck >> 2) ? p.x_cs[1] : p.x_cs[0]) + (ck & 3) * 8;
   }
   const long vox_n = (long)n * p.D * p.H * p.W;
@@ -112,14 +117,15 @@ __global__ __launch_bounds__(512, 2) void conv64_kernel(C64Params p) {
   auto stage = [&](int t, int buf) {   // workgroup-uniform arguments
     const int tx = t % p.tiles_x, ty = (t / p.tiles_x) % p.tiles_y, tz = t / (p.tiles_x * p.tiles_y);
     const int z0 = tz * C64_TZ, y0 = ty * C64_TY, x0 = tx * C64_TX;
-    const int tflg = (z0 == 0) | ((z0 + C64_TZ == p.D) << 1) | ((y0 == 0) << 2) | ((y0 + C64_TY == p.H) << 3) | ((x0 == 0) << 4) |
-                     ((x0 + C64_TX == p.W) << 5);
+    const int tflg = (z0 == 0) | ((z0 + C64_TZ == p.D) << 1) | ((y0 == 0) << 2) | ((y0 + C64_TY == p.H) << 3) | ((x0 == 0) << 4);
+    const int xlim = (p.W - x0 + 1) << 8;   // a haloed x index >= this lies beyond the volume (W need not be a multiple of the brick)
     const int orgv = ((z0 - 1) * p.H + (y0 - 1)) * p.W + (x0 - 1);
     const int org0 = orgv * p.x_cs[0], org1 = orgv * p.x_cs[1];
 #pragma unroll
     for (int k = 0; k < C64_ROUNDS; ++k) {
       if (k * 512 + (tid & ~63) < C64_ITEMS) {   // wave-uniform (3456 = 54 waves' worth)
-        const bf16_t* src = (s_pk[k] & tflg) ? g_zero_line_c64 : ((s_pk[k] & 64) ? xn1 + org1 : xn0 + org0) + s_rel[k];
+        const bool oob = (s_pk[k] & tflg & 0x1f) || (s_pk[k] & 0x1f00) >= xlim;
+        const bf16_t* src = oob ? g_zero_line_c64 : ((s_pk[k] & 64) ? xn1 + org1 : xn0 + org0) + s_rel[k];
         c64_dma16(src, lds0 + buf * C64_BRICK_B + (k * 512 + (tid & ~63)) * 16);
       }
     }
@@ -187,6 +193,7 @@ __global__ __launch_bounds__(512, 2) void conv64_kernel(C64Params p) {
     if (epi) {
       const int tx = t % p.tiles_x, ty = (t / p.tiles_x) % p.tiles_y, tz = t / (p.tiles_x * p.tiles_y);
       const int z0 = tz * C64_TZ, y0 = ty * C64_TY, x = tx * C64_TX + v;
+      const bool inw = x < p.W;   // (the last brick column of a ragged W: its lanes beyond the volume load and store nothing)
       bf16x4 av[C64_TZ][C64_TY];
       f32x4 bv[C64_TZ][C64_TY];
       // The partial sums of a chain are private to its links (same geometry, same width, hence the same bricks on the same waves):
@@ -210,8 +217,8 @@ __global__ __launch_bounds__(512, 2) void conv64_kernel(C64Params p) {
 #pragma unroll
         for (int yo = 0; yo < C64_TY; ++yo) {
           const long vo = vox_n + ((long)(z0 + zo) * p.H + (y0 + yo)) * p.W + x;
-          if (p.aux_mode) av[zo][yo] = *reinterpret_cast<const bf16x4*>(auxp + vo * a_cs);
-          if (btp) {
+          if (p.aux_mode) av[zo][yo] = inw ? *reinterpret_cast<const bf16x4*>(auxp + vo * a_cs) : bf16x4{(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+          if (btp && inw) {
             const int cls = vox_class(z0 + zo, y0 + yo, x, p.D, p.H, p.W);
             bv[zo][yo] = *reinterpret_cast<const f32x4*>(btp + cls * p.bt_cs);
           }
@@ -238,8 +245,8 @@ __global__ __launch_bounds__(512, 2) void conv64_kernel(C64Params p) {
           bf16x4 ob;
 #pragma unroll
           for (int j = 0; j < 4; ++j) ob[j] = f2bf(val[j]);
-          *reinterpret_cast<bf16x4*>(yp + vo * y_cs) = ob;
-          if (p.stat_out) {   // of the STORED values, as a read-back pass would see them
+          if (inw) *reinterpret_cast<bf16x4*>(yp + vo * y_cs) = ob;
+          if (p.stat_out && inw) {   // of the STORED values, as a read-back pass would see them
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
               const float r = bf2f(ob[j]);
@@ -280,7 +287,7 @@ static bool c64_geometry_ok(const RtpAct* x, const RtpConvGeom* g, int transpose
   const int Ci = transposed ? (g->co + 31) / 32 * 32 : g->ci;
   const int Co = transposed ? g->ci : g->co;
   if (Ci != 64 || Co != 64) return false;
-  if (g->di % C64_TZ || g->hi % C64_TY || g->wi % C64_TX) return false;
+  if (g->di % C64_TZ || g->hi % C64_TY || g->wi < 1) return false;   // (any W: the last brick column may be partly outside)
   if (x->c < 64 || (x->cs % 8) || (x->co % 8)) return false;
   return true;
 }
@@ -290,7 +297,7 @@ static bool c64_geometry_ok(const RtpAct* x, const RtpConvGeom* g, int transpose
  * (include/rtp.h) narrower or wider. */
 int rtp_conv64_wgs(const RtpAct* x, const RtpConvGeom* g, int transposed) {
   if (!x || !g || !c64_geometry_ok(x, g, transposed)) return 0;
-  const int tiles = (g->di / C64_TZ) * (g->hi / C64_TY) * (g->wi / C64_TX);
+  const int tiles = (g->di / C64_TZ) * (g->hi / C64_TY) * ((g->wi + C64_TX - 1) / C64_TX);
   // the level-1 tensors (fewer than 4096 bricks in all) on half the chip: phase config, same box, 256 / 128 / 64 workgroups:
   // 27.88-27.90 / 27.84-27.85 / 28.04-28.11 ms per step (alone the launch takes 43 / ~60 / 130 us: the side lanes want the CUs)
   static const int small_wgs = getenv("RTP_CONV64_WGS_SMALL") ? atoi(getenv("RTP_CONV64_WGS_SMALL")) : 128;
@@ -302,7 +309,7 @@ int rtp_conv64_wgs(const RtpAct* x, const RtpConvGeom* g, int transposed) {
 
 static int c64_launch(C64Params& p, const RtpConvGeom* g, int wgs, hipStream_t s) {
   p.N = g->n; p.D = g->di; p.H = g->hi; p.W = g->wi;
-  p.tiles_x = p.W / C64_TX; p.tiles_y = p.H / C64_TY;
+  p.tiles_x = (p.W + C64_TX - 1) / C64_TX; p.tiles_y = p.H / C64_TY;
   p.tiles_per_sample = (p.D / C64_TZ) * p.tiles_y * p.tiles_x;
   if (wgs < 1 || wgs > p.tiles_per_sample) return RTP_ERR_SHAPE;
   p.wgs_per_sample = wgs;
@@ -352,7 +359,7 @@ int rtp_conv64_try(const RtpAct* x, const void* wf, int w_per_sample, const floa
 /* include/rtp.h: rtp_conv64_blocks */
 extern "C" int rtp_conv64_blocks(const RtpConv64* c, const RtpConvGeom* g, void* stream) {
   if (!c || !g) return RTP_ERR_SHAPE;
-  if (g->ks != 3 || g->stride != 1 || g->pad != 1 || g->di % C64_TZ || g->hi % C64_TY || g->wi % C64_TX || g->n < 1) return RTP_ERR_UNSUPPORTED;
+  if (g->ks != 3 || g->stride != 1 || g->pad != 1 || g->di % C64_TZ || g->hi % C64_TY || g->wi < 1 || g->n < 1) return RTP_ERR_UNSUPPORTED;
   if (rtp_multi_capture()) return RTP_ERR_UNSUPPORTED;
   C64Params p;
   for (int h = 0; h < 2; ++h) {
@@ -380,7 +387,7 @@ extern "C" int rtp_conv64_blocks(const RtpConv64* c, const RtpConvGeom* g, void*
   p.relu = c->relu; p.flip = c->transposed; p.w_per_sample = c->w_per_sample;
   p.aux_mode = c->res[0] ? 1 : 0;
   int wgs = (g->wgs > 0 ? (g->wgs > 256 ? 256 : g->wgs) : 256) / g->n;
-  const int tiles = (g->di / C64_TZ) * (g->hi / C64_TY) * (g->wi / C64_TX);
+  const int tiles = (g->di / C64_TZ) * (g->hi / C64_TY) * ((g->wi + C64_TX - 1) / C64_TX);
   if (wgs < 1) wgs = 1;
   if (wgs > tiles) wgs = tiles;
   return c64_launch(p, g, wgs, (hipStream_t)stream);

@@ -429,6 +429,10 @@ extern "C" int rtp_conv_stats_nsplit(const RtpAct* x, const RtpConvGeom* g, int 
   if (!x || !g) return 0;
   const int tiled = rtp_conv_tiled_stat_slots(x, g, transposed);
   if (tiled > 0) return tiled;
+  {   // 64 -> 64, stride 1: conv64_tiled.hip (needs no workspace: rtp_conv_igemm_stats and rtp_conv_gn_fused take it too)
+    const int w64 = rtp_conv64_wgs(x, g, transposed);
+    if (w64 > 0) return w64;
+  }
   if (!transposed) {
     const int s2 = rtp_conv_s2_fwd_stat_slots(x, g);
     if (s2 > 0) return s2;
@@ -509,6 +513,13 @@ static int conv_dispatch(const RtpAct* x, const void* wf, int w_per_sample, cons
     if (rc <= 0) return rc;  // handled (or failed) by the LDS-tiled kernel
   }
   if (rtp_multi_capture()) return RTP_ERR_UNSUPPORTED;   // only the stride-1 LDS-tiled kernel can be recorded for a shared launch
+  if (!acc32) {
+    if (const int w64 = rtp_conv64_wgs(x, g, transposed)) {   // 64 -> 64, stride 1: one launch of conv64_tiled.hip
+      const int rc = rtp_conv64_try(x, wf, w_per_sample, btab, res, y, g, relu, transposed, y_fp32, stat_x, stat_out, w64, (hipStream_t)stream);
+      if (rc <= 0) return rc;
+      if (stat_out) return RTP_ERR_UNSUPPORTED;   // (the generic kernel would write another number of partials)
+    }
+  }
   if (!transposed && g->stride == 2 && !stat_x) {
     const int rc = rtp_conv_s2_fwd_try(x, wf, w_per_sample, btab, res, y, g, relu, y_fp32, stat_out, acc32, acc_cs, (hipStream_t)stream, nullptr);
     if (rc <= 0) return rc;
