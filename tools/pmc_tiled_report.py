@@ -11,6 +11,8 @@ import sys
 out = sys.argv[1]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KERNELS = {"conv_tiled_full": "conv_tiled_kernel<2, true, 1, false", "wgrad_tiled": "wgrad_tiled_kernel"}
+if os.environ.get("PMC_KERNELS"):   # "name=substring of the kernel name;..." (tools/pmc_conv64.sh)
+    KERNELS = dict(it.split("=", 1) for it in os.environ["PMC_KERNELS"].split(";") if "=" in it)
 agg = {k: collections.defaultdict(list) for k in KERNELS}
 dur = {k: collections.defaultdict(list) for k in KERNELS}
 for tag in ("f", "w", "s1", "s2", "g"):
@@ -58,7 +60,7 @@ if os.path.exists(out + "/unprofiled.txt"):
 import time
 tj = {"recorded": time.strftime("%Y-%m-%dT%H:%M:%SZ", time.gmtime()), "source": "tools/pmc_tiled.sh (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over tools/microbench_tiled.py full, B=8 [8,16,64,160,32])",
       "bytes_per_launch": {k: v["hbm_bytes_per_launch"] for k, v in res.items() if "hbm_bytes_per_launch" in v}, "detail": res}
-if tj["bytes_per_launch"]:
+if tj["bytes_per_launch"] and not os.environ.get("PMC_KERNELS"):
     with open(os.path.join(ROOT, "gpurun_out", "pmc_traffic.json"), "w") as f:
         json.dump(tj, f, indent=1)
     print("wrote gpurun_out/pmc_traffic.json (copy to profiles/)")
