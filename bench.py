@@ -414,6 +414,7 @@ def main():
                 "  of which forward": (_lib.FAM_CONV_TILED_FULL, g.flops["conv_tiled_full"] - fb_f, g.alg_bytes["conv_tiled_full"] - fb_b),
                 "  of which data gradient": (_lib.FAM_CONV_TILED_FULL_BWD, fb_f, fb_b),
                 "conv_tiled other geometries (level 1, 16-channel outputs)": (_lib.FAM_CONV_TILED, rest_f, rest_b),
+                "conv64_kernel 64-wide 3x3x3 (64->64 layers, paired head towers; fwd+dgrad)": (_lib.FAM_CONV64, g.flops["conv64"], g.alg_bytes["conv64"]),
                 "conv_igemm generic (fwd+dgrad)": (_lib.FAM_CONV, g.flops["conv_generic"], g.alg_bytes["conv_generic"]),
                 "wgrad_tiled (32ch 3x3x3)": (_lib.FAM_WGRAD_TILED, g.flops["wgrad_tiled"], g.alg_bytes["wgrad_tiled"]),
                 "wgrad generic": (_lib.FAM_WGRAD, g.flops["wgrad_generic"], g.alg_bytes["wgrad_generic"])}

@@ -12,7 +12,7 @@ RTP_MAX_TERMS = 6
 
 # kernel families for rtp_prof_* (csrc/rtp_prof.h)
 (FAM_CONV, FAM_CONV_TILED, FAM_WGRAD, FAM_POINTWISE, FAM_NORM, FAM_LOSS, FAM_OPTIM, FAM_DCN, FAM_WGRAD_TILED, FAM_CONV_TILED_FULL,
- FAM_CONV_TILED_FULL_BWD) = range(11)
+ FAM_CONV_TILED_FULL_BWD, FAM_CONV64) = range(12)
 
 _ERR = {-1: "RTP_ERR_SHAPE", -2: "RTP_ERR_UNSUPPORTED", -3: "RTP_ERR_LAUNCH", -4: "RTP_ERR_ALIGN"}
 

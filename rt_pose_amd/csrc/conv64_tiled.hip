@@ -298,6 +298,10 @@ static bool c64_geometry_ok(const RtpAct* x, const RtpConvGeom* g, int transpose
 int rtp_conv64_wgs(const RtpAct* x, const RtpConvGeom* g, int transposed) {
   if (!x || !g || !c64_geometry_ok(x, g, transposed)) return 0;
   const int tiles = (g->di / C64_TZ) * (g->hi / C64_TY) * ((g->wi + C64_TX - 1) / C64_TX);
+  // a launch of this kernel costs ~16 us whatever it computes (512-thread workgroups, 27 weight fragments per lane, a staged brick
+  // before the first MFMA): below 64 bricks in all -- the level-3 tensors of the native shape, [2, 8, 20] x 8 samples = 32 bricks,
+  // 16.7 us here against 12.1 on the generic kernel -- the conv stays there (level 2, 192 bricks: 23.7 against 28.5)
+  if ((long)tiles * g->n < 64) return 0;
   // the level-1 tensors (fewer than 4096 bricks in all) on half the chip: phase config, same box, 256 / 128 / 64 workgroups:
   // 27.88-27.90 / 27.84-27.85 / 28.04-28.11 ms per step (alone the launch takes 43 / ~60 / 130 us: the side lanes want the CUs)
   static const int small_wgs = getenv("RTP_CONV64_WGS_SMALL") ? atoi(getenv("RTP_CONV64_WGS_SMALL")) : 128;
@@ -320,7 +324,7 @@ static int c64_launch(C64Params& p, const RtpConvGeom* g, int wgs, hipStream_t s
     (void)hipFuncSetAttribute((const void*)conv64_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, C64_LDS_B);
     (void)hipFuncSetAttribute((const void*)conv64_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, C64_LDS_B);
   }
-  RtpProfScope prof(RTP_FAM_CONV_TILED, s);
+  RtpProfScope prof(RTP_FAM_CONV64, s);
   if (p.acc_in || p.acc_out) hipLaunchKernelGGL(conv64_kernel<true>, dim3(p.N * wgs), dim3(512), C64_LDS_B, s, p);
   else hipLaunchKernelGGL(conv64_kernel<false>, dim3(p.N * wgs), dim3(512), C64_LDS_B, s, p);
   RTP_CHECK_LAUNCH();

@@ -14,7 +14,8 @@ enum RtpFamily {
   RTP_FAM_WGRAD_TILED = 8,
   RTP_FAM_CONV_TILED_FULL = 9,  // the LDS-tiled conv at its dominant geometry: 32 -> 32 channels, >= 2^20 output voxels per launch
   RTP_FAM_CONV_TILED_FULL_BWD = 10,  // ... its data-gradient launches (flipped taps; the fused variants carry the fan-in / GroupNorm-backward epilogue)
-  RTP_FAM_COUNT = 11
+  RTP_FAM_CONV64 = 11,  // csrc/conv64_tiled.hip: the 64-wide stride-1 kernel (64 -> 64 layers, paired head towers)
+  RTP_FAM_COUNT = 12
 };
 
 void rtp_prof_begin(int fam, hipStream_t s);

@@ -169,11 +169,11 @@ class Graph:
         self.group = None          # (block, row) tag the ops created from now on carry (net.build_backbone: fuse rows)
         self.full_vox = None       # voxels of the first (full-resolution) activation: lanes are assigned by resolution
         # algorithmic FLOPs (2*MACs of real channels) per kernel family, per replay of the lists
-        self.flops = {"conv_fwd": 0, "conv_dgrad": 0, "wgrad": 0, "conv_tiled": 0, "conv_generic": 0,
+        self.flops = {"conv_fwd": 0, "conv_dgrad": 0, "wgrad": 0, "conv_tiled": 0, "conv_generic": 0, "conv64": 0,
                       "wgrad_tiled": 0, "wgrad_generic": 0, "conv_tiled_full": 0, "conv_tiled_full_bwd": 0}
         # algorithmic HBM bytes (fused minimum, SURVEY 8d: every operand tensor of a launch read or written once) per family
         self.cost = {}   # launch tag -> (algorithmic FLOPs, bytes) of the tiled conv / data-gradient launches (engine: shared launches)
-        self.alg_bytes = {"conv_tiled": 0, "conv_generic": 0, "wgrad_tiled": 0, "wgrad_generic": 0, "conv_tiled_full": 0,
+        self.alg_bytes = {"conv_tiled": 0, "conv_generic": 0, "conv64": 0, "wgrad_tiled": 0, "wgrad_generic": 0, "conv_tiled_full": 0,
                           "conv_tiled_full_bwd": 0}
 
     # ------------------------------------------------------------------ helpers
@@ -752,11 +752,14 @@ class ConvOp:
         self.s2_bwd = (ge.ks == 3 and ge.stride == 2 and ge.ci == 32 and pad_to(ge.co, 32) == 32 and ge.di == 2 * ge.do
                        and ge.hi == 2 * ge.ho and ge.wi == 2 * ge.wo and ge.ho % 2 == 0 and ge.wo % 16 == 0
                        and not __import__("os").environ.get("RTP_DISABLE_S2_TILED"))
-        g.flops["conv_tiled" if self.tiled_fwd else "conv_generic"] += self.alg_flops
+        # (the 64 -> 64 stride-1 layers the sliced route hands to csrc/conv64_tiled.hip are a kernel family of their own)
+        self.c64 = ge.ks == 3 and ge.stride == 1 and ge.ci == 64 and ge.co == 64
+        fam_f = "conv64" if (self.sliced_fwd and self.c64) else "conv_tiled" if self.tiled_fwd else "conv_generic"
+        g.flops[fam_f] += self.alg_flops
         esz = 4 if self.out_fp32 else 2
         self.bytes_fwd = 2 * g.n * self.x.vox * ge.ci + esz * g.n * self.y.vox * self.y.c + (
             2 * g.n * self.y.vox * self.y.c if self.residual is not None else 0)
-        g.alg_bytes["conv_tiled" if self.tiled_fwd else "conv_generic"] += self.bytes_fwd
+        g.alg_bytes[fam_f] += self.bytes_fwd
         # the tiled kernel at its dominant geometry (csrc/conv_tiled.hip: 32 output channels, >= 2^20 voxels per launch)
         g.cost["conv:" + self.name] = (self.alg_flops, self.bytes_fwd)
         self.full_fwd = self.tiled_fwd and ge.co == 32 and g.n * self.y.vox >= (1 << 20)
@@ -791,10 +794,11 @@ class ConvOp:
             g.flops["conv_dgrad"] += self.alg_flops
             if self.sliced_bwd:
                 self.tiled_bwd = True
-            g.flops["conv_tiled" if (self.tiled_bwd or self.s2_bwd) else "conv_generic"] += self.alg_flops
+            fam_b = "conv64" if (self.sliced_bwd and self.c64) else "conv_tiled" if (self.tiled_bwd or self.s2_bwd) else "conv_generic"
+            g.flops[fam_b] += self.alg_flops
             # data gradient: read gy, write dxhat, (GroupNorm: read x for Q)
             nb = 2 * g.n * (gy.vox * pad_to(ge.co, 32) + x.vox * ge.ci * (2 if self.gn else 1))
-            g.alg_bytes["conv_tiled" if (self.tiled_bwd or self.s2_bwd) else "conv_generic"] += nb
+            g.alg_bytes[fam_b] += nb
             if self.tiled_bwd and ge.ci == 32 and g.n * x.vox >= (1 << 20):   # transposed: the kernel's Cout is the conv's Cin
                 g.flops["conv_tiled_full"] += self.alg_flops
                 g.alg_bytes["conv_tiled_full"] += nb
@@ -1064,9 +1068,9 @@ class SplitConvOp:
                        [self.y if last else acc], "conv:%s.%d" % (self.name, k))
         self.alg_flops = 2 * g.n * gs.do * gs.ho * gs.wo * self.co_real * self.ci_real * ntap
         g.flops["conv_fwd"] += self.alg_flops
-        g.flops["conv_tiled"] += self.alg_flops
+        g.flops["conv_tiled" if launches else "conv64"] += self.alg_flops   # (no launches of its own: paired on the 64-wide kernel)
         nb = 2 * g.n * (self.x.vox * (32 * self.K if self.sources else self.ci_real) + self.y.vox * self.y.c)
-        g.alg_bytes["conv_tiled"] += nb
+        g.alg_bytes["conv_tiled" if launches else "conv64"] += nb
         self.full = launches and gs.co == 32 and g.n * self.y.vox >= (1 << 20)   # the profiling family of these launches (conv_tiled.hip)
         if self.full:
             g.flops["conv_tiled_full"] += self.alg_flops
@@ -1108,8 +1112,8 @@ class SplitConvOp:
         x.contribs.append((View(dxb, g.n, x.d, x.h, x.w, self.ci_real, 0, self.ci_real), None))
         for t in towers:
             g.flops["conv_dgrad"] += t.alg_flops
-            g.flops["conv_tiled"] += t.alg_flops
-            g.alg_bytes["conv_tiled"] += 2 * g.n * (x.vox * 32 + x.vox * self.ci_real // 2)
+            g.flops["conv64"] += t.alg_flops
+            g.alg_bytes["conv64"] += 2 * g.n * (x.vox * 32 + x.vox * self.ci_real // 2)
 
     def emit_backward(self, gy: View):
         g, be, gs, x = self.g, self.g.be, self.gs, self.x

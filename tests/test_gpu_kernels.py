@@ -1008,7 +1008,9 @@ def test_fused_stride2_data_gradient(hip, case):
     (1, (2, 8, 48), 64, 64, False, False, False), (3, (4, 8, 80), 64, 64, True, True, True), (8, (4, 16, 64), 64, 64, True, False, True),
     (2, (2, 4, 16), 64, 64, True, True, False),
     # ... ragged W (the level-2 / level-3 tensors of the native shape: 40 and 20 columns; the last brick column partly outside)
-    (2, (4, 16, 40), 64, 64, True, True, True), (8, (2, 8, 20), 64, 64, True, False, True), (1, (2, 4, 7), 64, 64, False, True, False),
+    # (launches of fewer than 64 bricks stay on the slice / generic kernels: the cases are sized to reach the 64-wide kernel)
+    (8, (4, 16, 40), 64, 64, True, True, True), (16, (2, 8, 20), 64, 64, True, False, True), (64, (2, 4, 7), 64, 64, False, True, False),
+    (8, (4, 8, 48), 64, 64, True, True, True),
 ])
 def test_wide_convs_as_channel_slices_of_the_tiled_kernel(hip, case):
     """rtp_conv_igemm_ws / rtp_wgrad on Cin = 32 K, Cout = 32 J (the feat64 backbone's 64- and 128-channel layers,

@@ -14,7 +14,7 @@ def t(f, it=100):
     for _ in range(it): f(s)
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / it * 1e6
 n, c = 8, 64
-for (d, h, w) in (((16, 64, 160),) if 'full' in sys.argv else ((16, 64, 160), (8, 32, 80))):   # full: the native shape only (PMC passes)
+for (d, h, w) in (((16, 64, 160),) if 'full' in sys.argv else ((16, 64, 160), (8, 32, 80), (4, 16, 40), (2, 8, 20))):   # full: the native shape only (PMC passes)
     g = Geom(n, d, h, w, d, h, w, c, c, 3, 1, 1)
     x = View(mk((n, d, h, w, c)), n, d, h, w, c, 0, c)
     y = View(mk((n, d, h, w, c)), n, d, h, w, c, 0, c)
