@@ -19,7 +19,8 @@
 //   * the LDS image rotates the 16-B chunk index by 2 * (x >> 1) (mod 8) -- with 128 B per voxel two voxels share a 256-B bank row,
 //     and the rotation makes every ds_read_b128 lane group hit 16 distinct 16-B slots for each of the three x shifts.
 //   * W need not be a multiple of the brick: the last brick column's lanes beyond the volume stage zeros and store nothing (the
-//     level-2 / level-3 tensors of the native shape have 40 and 20 columns);
+//     level-2 tensors of the native shape have 40 columns; level 3 -- 20 columns, 32 bricks in all -- stays on the generic kernel:
+//     rtp_conv64_wgs);
 //   * (the GroupNorm fold in this kernel's prologue, as conv_tiled.hip has it, was built and measured: 5.100-5.111 ms per hr3d step
 //     against 5.087-5.104 with the fold launch in front -- every workgroup folding its sample's 442 KB of fp32 weights costs what the
 //     launch saves; removed)
