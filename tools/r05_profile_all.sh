@@ -4,8 +4,8 @@
 python __graft_entry__.py --smoke 2>&1 | tail -2 > gpurun_out/r05_smoke.txt
 python bench.py > gpurun_out/r05_bench_default.json 2> gpurun_out/r05_bench_default.err
 tools/gpu_prof.sh r05 > gpurun_out/r05_gpu_prof.log 2>&1
-python tools/prof_db.py stats $(ls gpurun_out/prof_r05_lanes/*/run_results.db | head -1) 32 'Round 5 -- per-kernel device time of the default train step, lanes' > gpurun_out/r05_step_kernel_stats_lanes.md 2>&1
-python tools/prof_db.py stats $(ls gpurun_out/prof_r05_single/*/run_results.db | head -1) 32 'Round 5 -- per-kernel device time of the default train step, single stream' > gpurun_out/r05_step_kernel_stats_single_stream.md 2>&1
+python tools/prof_db.py stats $(ls gpurun_out/prof_r05_lanes/run_results.db gpurun_out/prof_r05_lanes/*/run_results.db 2>/dev/null | head -1) 32 'Round 5 -- per-kernel device time of the default train step, lanes' > gpurun_out/r05_step_kernel_stats_lanes.md 2>&1
+python tools/prof_db.py stats $(ls gpurun_out/prof_r05_single/run_results.db gpurun_out/prof_r05_single/*/run_results.db 2>/dev/null | head -1) 32 'Round 5 -- per-kernel device time of the default train step, single stream' > gpurun_out/r05_step_kernel_stats_single_stream.md 2>&1
 tools/pmc_tiled.sh > gpurun_out/r05_pmc_tiled.txt 2>&1
 tools/pmc_step.sh > gpurun_out/r05_pmc_step_traffic.txt 2>&1
 python tools/plan_times.py > gpurun_out/r05_plan_times.txt 2>&1
