@@ -290,18 +290,36 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # a rank that stops making progress names its own line on stderr and exits (its peers then fail in the collective instead
+        # of waiting for it): re-armed at every phase below, so the limit is per phase, not for the whole run
+        import datetime
+        import faulthandler
+        hang_s = float(os.environ.get("RTP_HANG_DUMP_S", "600"))
+
+        def watchdog(phase):
+            faulthandler.cancel_dump_traceback_later()
+            if phase is not None and hang_s > 0:
+                sys.stderr.write("[bench rank %d] %s\n" % (rank, phase))
+                sys.stderr.flush()
+                faulthandler.dump_traceback_later(hang_s, exit=True)
+        watchdog("rendezvous")
+        pg_timeout = datetime.timedelta(seconds=max(60.0, hang_s))
         # RTP_BENCH_ONE_DEVICE=1 (test rigs with a single GPU): every rank on cuda:0 over gloo -- exercises this file's N > 1
         # control flow (barriers, max over ranks, rank-0 JSON) where RCCL cannot run; the numbers mean nothing
         if os.environ.get("RTP_BENCH_ONE_DEVICE"):
             local = 0
             torch.cuda.set_device(0)
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=pg_timeout)
         else:
             torch.cuda.set_device(local)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local), timeout=pg_timeout)
     else:
         torch.cuda.set_device(0)
+
+        def watchdog(phase):
+            pass
     dev = "cuda:%d" % local
+    watchdog("building the trainer")
 
     from rt_pose_amd import _lib, configs, synth
     from rt_pose_amd.trainer import DataParallelTrainer
@@ -320,6 +338,7 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    watchdog("warm-up")
     for _ in range(args.warmup):
         tr.step()
     # THREE consecutive timed segments of exactly --steps steps each, every one bracketed by barrier + synchronize on both sides; the
@@ -327,6 +346,7 @@ def main():
     # lists all three.  Multi-rank: a segment's time is the slowest rank's.
     seg_s, seg_rank_ms = [], []
     for _seg in range(3):
+        watchdog("timed segment %d" % _seg)
         barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
@@ -371,6 +391,7 @@ def main():
     # BASELINE config 2, reported beside the metric: forward + key-point decode only (the same plan's forward list; in
     # training mode it also writes the statistics the backward needs), same batch, timed after the train steps
     if not args.no_forward:
+        watchdog("forward-only leg")
         from rt_pose_amd.engine import PoseEngine
         inf = PoseEngine(tr.be, tr.flat.values, spec["arch"], spec["final_fuse"], spec["heads"], spec["weight"],
                          spec["code_weights"], args.batch, configs.NATIVE_DIMS, train=False, test_cfg=configs.test_cfg())
@@ -583,7 +604,9 @@ def main():
     if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:
+        watchdog("shutdown")
         dist.destroy_process_group()
+        watchdog(None)
 
 
 if __name__ == "__main__":

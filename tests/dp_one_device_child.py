@@ -2,7 +2,7 @@
 over gloo with DEVICE tensors (a 1-GPU box cannot run RCCL between ranks).  Everything the multi-rank product path does beyond the
 collective's transport runs for real: rank-sharded batches, the flat fp32 gradient buffer, `ar_buckets` 1 / 2 (the early bucket is
 kicked from inside the backward launch list under torch.cuda.ExternalStream), grad_scale = 1 / world inside the optimiser kernels.
-    python tests/dp_one_device_child.py <rank> <world> <port> <out dir> <buckets>
+    RANK=r WORLD_SIZE=n MASTER_ADDR=127.0.0.1 MASTER_PORT=p python tests/dp_one_device_child.py <out dir> <buckets>
 """
 import os
 import sys
@@ -12,8 +12,11 @@ sys.path.insert(0, ROOT)
 
 
 def main():
-    rank, world, port, out, buckets = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], int(sys.argv[5])
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    out, buckets = sys.argv[1], int(sys.argv[2])
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])   # MASTER_ADDR / MASTER_PORT come with them (run_ranks)
+    import datetime
+    import faulthandler
+    faulthandler.dump_traceback_later(float(os.environ.get("RTP_HANG_DUMP_S", "180")), exit=True)   # a stuck rank names its line
     from rt_pose_amd import pin_hw_queues
     pin_hw_queues()   # before torch selects a device: GPU_MAX_HW_QUEUES is read when HIP initialises (set_device does that)
     import torch
@@ -22,7 +25,7 @@ def main():
     from rt_pose_amd.trainer import DataParallelTrainer
     from tests.test_gpu_dp_one_device import B, DIMS, STEPS
     torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=180))
     tr = DataParallelTrainer("hr3d", B, DIMS, total_steps=10, device="cuda:0", rank=rank, world_size=world, use_graph=False, seed=0,
                              ar_buckets=buckets)
     assert tr.be.name == "hip" and tr.ar_buckets == buckets, (tr.be.name, tr.ar_buckets)

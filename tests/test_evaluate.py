@@ -39,3 +39,26 @@ def test_prediction_file_layout_and_mpjpe(tmp_path):
     assert np.isclose(res["results"]["ABS_MPJPE"], np.mean([v[1] for v in per_seq.values()]))
     assert res["results"]["ABS_MPJPE"] > res["results"]["MPJPE"] + 100      # the 0.3 m shift only shows in the absolute error
     assert res["seq_results"]["ALL"] == res["results"] and "PJPE_14" in res["results"]
+
+
+def test_evaluate_against_the_reference_evaluation():
+    """tests/golden/eval_golden.json: CRUW_POSE_Dataset.evaluation (cruw_pose.py:277-311) + eval_util.PJPE / ABS_PJPE called unbound
+    on a seeded label file and detections dict (gen_golden_eval.py).  Every entry of the reference's `res` -- totals, per sequence,
+    per joint, the 'ALL' row -- to 1e-9 relative (fp64 numpy on both sides)."""
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "eval_golden.json")) as f:
+        z = json.load(f)
+    import copy
+    dets0, gt0 = copy.deepcopy(z["detections"]), copy.deepcopy(z["gt"])
+    res = E.evaluate(z["detections"], z["gt"], z["seq_id_to_name"])
+    want = z["reference_result"]
+    assert set(res) == set(want) and set(res["seq_results"]) == set(want["seq_results"])
+    assert set(res["results"]) == set(want["results"]) and len(want["results"]) == 32
+    for k, v in want["results"].items():
+        assert np.isclose(res["results"][k], v, rtol=1e-9, atol=0), k
+    for seq, d in want["seq_results"].items():
+        assert set(res["seq_results"][seq]) == set(d), seq
+        for k, v in d.items():
+            assert np.isclose(res["seq_results"][seq][k], v, rtol=1e-9, atol=0), (seq, k)
+    # the inputs were not modified (the reference's PJPE shifts its arguments in place; evaluate() must not)
+    assert z["detections"] == dets0 and z["gt"] == gt0

@@ -1,45 +1,34 @@
-"""bench.py's N > 1 control flow on ONE GPU (VERDICT r4 item 9; reference launch: tools/train.py:93-126, one process per GPU).
+"""bench.py's N > 1 control flow on ONE GPU (reference launch: tools/train.py:93-126, one process per GPU).
 
 The driver launches `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`; on a 1-GPU box RCCL cannot run, so
 the two ranks are started here as two fresh child processes (subprocess from a fresh interpreter -- never exec'd from a process that
 touched the GPU) with RTP_BENCH_ONE_DEVICE=1: both on cuda:0, gloo as the process group.  What is checked is the file's own
 multi-rank logic, the part no other test reaches: rendezvous from RANK / WORLD_SIZE / MASTER_*, barrier-bracketed segments, the
 all_gather of every rank's clock and the MAX over ranks, and rank 0 -- only rank 0 -- printing ONE JSON line with the collective
-object filled in.  The numbers themselves mean nothing (two processes share one GPU)."""
+object filled in.  The numbers themselves mean nothing (two processes share one GPU).
+
+Hang-proofing: the children write to FILES (two PIPEs drained one after the other deadlock as soon as the
+second child is chatty), both are polled against ONE deadline, on expiry BOTH are killed and the failure carries both ranks'
+tails; bench.py itself arms faulthandler.dump_traceback_later when WORLD_SIZE > 1, so a stuck rank names its own line first.
+tests/conftest.py runs every multi-process test after the parity tests."""
 import json
 import os
-import socket
-import subprocess
 import sys
 
 import pytest
+
+from tests.util import run_ranks
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
-
-
 @pytest.mark.timeout(600)
-def test_bench_two_ranks_on_one_gpu_prints_one_line_with_the_collective():
-    world, port = 2, _free_port()
+def test_bench_two_ranks_on_one_gpu_prints_one_line_with_the_collective(tmp_path):
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-other-models",
            "--no-dcn", "--no-lidar", "--no-torch-gpu", "--no-cpu-baseline"]
-    procs = []
-    for r in range(world):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   RTP_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-        procs.append(subprocess.Popen(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
-    outs = [p.communicate(timeout=540) for p in procs]
-    for r, p in enumerate(procs):
-        assert p.returncode == 0, "rank %d failed:\n%s" % (r, outs[r][1][-3000:])
-    lines = [[ln for ln in o.splitlines() if ln.startswith("{")] for o, _ in outs]
+    _, outs, _ = run_ranks(cmd, 2, str(tmp_path), {"RTP_BENCH_ONE_DEVICE": "1"})
+    lines = [[ln for ln in o.splitlines() if ln.startswith("{")] for o in outs]
     assert len(lines[0]) == 1 and len(lines[1]) == 0, "exactly one JSON line, from rank 0"
     d = json.loads(lines[0][0])
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1

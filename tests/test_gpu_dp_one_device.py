@@ -11,8 +11,6 @@ by hand (reference: det3d/torchie/apis/train.py:284-291 DDP wrap, det3d/core/uti
 The children are started with subprocess from a fresh interpreter -- never forked from, or exec'd by, a process that has touched
 the GPU."""
 import os
-import socket
-import subprocess
 import sys
 
 import pytest
@@ -23,28 +21,17 @@ DIMS, B, STEPS = (8, 16, 32), 2, 3
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
-
-
-@pytest.mark.timeout(900)
+@pytest.mark.timeout(600)
 @pytest.mark.parametrize("buckets", [1, 2])
 def test_two_ranks_on_one_gpu_match_manual_sum(tmp_path, buckets):
     from rt_pose_amd import configs, synth
     from rt_pose_amd.engine import one_cycle
     from rt_pose_amd.trainer import DataParallelTrainer
-    world, port = 2, _free_port()
-    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
-    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dp_one_device_child.py"), str(r), str(world), str(port),
-                               str(tmp_path), str(buckets)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-             for r in range(world)]
-    outs = [p.communicate(timeout=800)[0] for p in procs]
-    for r, p in enumerate(procs):
-        assert p.returncode == 0, "rank %d failed:\n%s" % (r, outs[r][-3000:])
+    from tests.util import run_ranks
+    world = 2
+    # (files for the children's output, one deadline for both, both killed on expiry: tests/util.py)
+    run_ranks([sys.executable, os.path.join(ROOT, "tests", "dp_one_device_child.py"), str(tmp_path), str(buckets)], world, str(tmp_path),
+              {"PYTHONPATH": ROOT + os.pathsep + os.environ.get("PYTHONPATH", "")})
     r0, r1 = [torch.load(os.path.join(tmp_path, "rank%d.pt" % r)) for r in range(world)]
     assert torch.equal(r0["p"], r1["p"]), "replicas diverged"
     assert all(torch.equal(a, b) for a, b in zip(r0["g"], r1["g"])), "all-reduced gradients differ between ranks"

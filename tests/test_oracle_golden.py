@@ -127,3 +127,26 @@ def test_one_cycle_and_adam_rule():
         opt.step()
         mine.step(3e-4, 0.9, max_norm=1e9)
     np.testing.assert_allclose(p.detach().numpy(), q.detach().numpy(), rtol=1e-6, atol=1e-7)
+
+
+def test_train_step_rule_against_the_reference_optimiser():
+    """Row T pinned by import, not by formula: tests/golden/optim_golden.npz was captured from the reference's OWN OptimWrapper
+    (fastai_optim.py:121-175, true_wd) around torch.optim.Adam + OneCycle (learning_schedules_fastai.py:53-95) + clip_grad_norm_(35),
+    driven in the trainer's order (gen_golden_optim.py).  O.one_cycle and O.AdamTrueWD must reproduce lr, momentum and every
+    parameter after each of the 7 steps (both cosine phases, one clipped step, parameters that never get a gradient)."""
+    import os
+    import numpy as np
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "optim_golden.npz"))
+    names, total = [str(n) for n in z["names"]], int(z["total_steps"])
+    params = [torch.tensor(z["init/" + k]).requires_grad_(True) for k in names]
+    opt = O.AdamTrueWD(params)
+    for step in range(len(z["lr"])):
+        lr, b1 = O.one_cycle(step, total, 1e-3)
+        assert abs(lr - float(z["lr"][step])) < 1e-15 and abs(b1 - float(z["mom"][step])) < 1e-15, (step, lr, b1)
+        for k, p in zip(names, params):
+            key = "grad/%d/%s" % (step, k)
+            p.grad = torch.tensor(z[key]) if key in z.files else None
+        norm = opt.step(lr, b1)
+        assert abs(norm - float(z["grad_norm"][step])) < 1e-4 * float(z["grad_norm"][step])
+        for k, p in zip(names, params):
+            np.testing.assert_allclose(p.detach().numpy(), z["after/%d/%s" % (step, k)], rtol=2e-6, atol=2e-7, err_msg="%d %s" % (step, k))

@@ -1,6 +1,15 @@
 """Shared helpers for the parity tests."""
+import os
+import socket
+import subprocess
+import time
+
 import numpy as np
+import pytest
 import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DEADLINE_S = float(os.environ.get("RTP_TWO_RANK_DEADLINE_S", "240"))
 
 
 def sample_index(numel, nsample=8192):
@@ -49,3 +58,52 @@ def check_golden_like_emulation(golden, key, got, emu, slack=1.5):
     assert float(np.abs(d_h).max()) <= slack * float(np.abs(d_e).max()) + 4 * rms_e, (key, "per element", float(np.abs(d_h).max()), float(np.abs(d_e).max()), rms_e)
     assert float(np.abs(a - e).max()) <= 8 * rms_e, (key, "kernels vs emulated plan", float(np.abs(a - e).max()), rms_e)
     return rms_h, rms_e
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def run_ranks(cmd, world, tmp_path, extra_env=None, deadline_s=DEADLINE_S):
+    """Start `world` fresh children of `cmd` (RANK / WORLD_SIZE / MASTER_* in the env, output to files), wait for all of them against
+    one deadline; returns (return codes, stdout texts, stderr texts).  On expiry every child still alive is killed."""
+    port = _free_port()
+    procs, files = [], []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY="0", RTP_HANG_DUMP_S=str(int(deadline_s * 0.75)))
+        env.update(extra_env or {})
+        fo, fe = open(os.path.join(tmp_path, "rank%d.out" % r), "w+"), open(os.path.join(tmp_path, "rank%d.err" % r), "w+")
+        files.append((fo, fe))
+        procs.append(subprocess.Popen(cmd, env=env, cwd=ROOT, stdout=fo, stderr=fe, stdin=subprocess.DEVNULL, text=True))
+    end = time.monotonic() + deadline_s
+    try:
+        while time.monotonic() < end and any(p.poll() is None for p in procs):
+            if any(p.poll() not in (None, 0) for p in procs):   # one rank died: its peer would wait for the collective's own timeout
+                time.sleep(2.0)
+                break
+            time.sleep(0.2)
+    finally:
+        timed_out = [r for r, p in enumerate(procs) if p.poll() is None]
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        for p in procs:
+            p.wait()
+
+    def text(f):
+        f.flush()
+        f.seek(0)
+        t = f.read()
+        f.close()
+        return t
+    outs, errs = [text(fo) for fo, _ in files], [text(fe) for _, fe in files]
+    if timed_out or any(p.returncode != 0 for p in procs):
+        tails = "\n".join("---- rank %d: rc %s%s\n[stdout]\n%s\n[stderr]\n%s" % (r, p.returncode, " (killed at the deadline)" if r in timed_out else "",
+                                                                                 outs[r][-1500:], errs[r][-4000:]) for r, p in enumerate(procs))
+        pytest.fail("ranks %s still running after %.0f s / non-zero exit\n%s" % (timed_out, deadline_s, tails), pytrace=False)
+    return [p.returncode for p in procs], outs, errs
