@@ -279,6 +279,8 @@ def main():
     ap.add_argument("--no-dcn", action="store_true", help="skip the DCN operator (config 4) leg")
     ap.add_argument("--no-forward", action="store_true", help="skip the forward-only (config 2) leg")
     ap.add_argument("--no-other-models", action="store_true", help="skip the driver-timed legs of the other shipped configs")
+    ap.add_argument("--dims", default="", help="Z,Y,X of the radar tensor -- TEST RIGS ONLY (tests/test_gpu_bench_two_ranks.py checks this "
+                    "file's multi-rank control flow at a small size); the metric is defined at the dataset-native 16,64,160, the default")
     args = ap.parse_args()
 
     import torch
@@ -325,9 +327,13 @@ def main():
     from rt_pose_amd.trainer import DataParallelTrainer
 
     spec = configs.spec(args.model)
-    tr = DataParallelTrainer(args.model, args.batch, configs.NATIVE_DIMS, total_steps=max(100, args.steps + args.warmup),
+    dims = tuple(int(v) for v in args.dims.split(",")) if args.dims else tuple(configs.NATIVE_DIMS)
+    native = dims == tuple(configs.NATIVE_DIMS)
+    if not native:   # a test rig's size: only the train-step and forward-only control flow, none of the measurement legs
+        args.no_roofline = args.no_other_models = args.no_dcn = args.no_lidar = args.no_torch_gpu = args.no_cpu_baseline = True
+    tr = DataParallelTrainer(args.model, args.batch, dims, total_steps=max(100, args.steps + args.warmup),
                              device=dev, rank=rank, world_size=world, use_graph=args.graph)
-    ex = synth.make_batch(args.batch, spec["cin"], configs.NATIVE_DIMS, seed=1234, one_hm=spec["heads"]["hm"] == 1, rank=rank,
+    ex = synth.make_batch(args.batch, spec["cin"], dims, seed=1234, one_hm=spec["heads"]["hm"] == 1, rank=rank,
                           lidar_channels=spec.get("lidar_channels", 0))
     tr.load(ex)  # inputs resident in HBM before the timed region
     torch.cuda.synchronize()
@@ -373,8 +379,8 @@ def main():
         "metric": "radar frames/sec (train) HRRadarPose", "value": round(frames / elapsed, 3), "unit": "frames/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": "%s train step (fwd+loss+bwd+allreduce+clip+Adam), %d frames/GPU of [%d,16,64,160], "
-                               "random-init weights" % (args.model, args.batch, spec["cin"]),
+        "config": {"workload": "%s train step (fwd+loss+bwd+allreduce+clip+Adam), %d frames/GPU of [%d,%d,%d,%d], "
+                               "random-init weights%s" % (args.model, args.batch, spec["cin"], *dims, "" if native else " -- NOT the native shape (test rig)"),
                    "global_batch": world * args.batch, "parallelism": "dp%d" % world, "hip_graph": bool(args.graph),
                    "hw_queues": HW_QUEUES},
         "allreduce_ms": (round(tr.allreduce_ms(), 4) if world > 1 else None),   # flat fp32 gradient all-reduce, events on the step stream
@@ -394,7 +400,7 @@ def main():
         watchdog("forward-only leg")
         from rt_pose_amd.engine import PoseEngine
         inf = PoseEngine(tr.be, tr.flat.values, spec["arch"], spec["final_fuse"], spec["heads"], spec["weight"],
-                         spec["code_weights"], args.batch, configs.NATIVE_DIMS, train=False, test_cfg=configs.test_cfg())
+                         spec["code_weights"], args.batch, dims, train=False, test_cfg=configs.test_cfg())
         with tr._on_stream():
             inf.load_input(ex["rdr"]["rdr_tensor"])
             for _ in range(3):

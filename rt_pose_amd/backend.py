@@ -114,11 +114,12 @@ class HipBackend:
         streams = [cur] + self._lanes[:n - 1]
         return streams, [C.c_void_p(st.cuda_stream) for st in streams]
 
-    def new_event(self):
-        """An ordering event of the lane plan: device-scope (csrc/lane_events.hip: no system-scope cache writeback / invalidate when
-        it is recorded); RTP_EVENT_FENCE=1: ordinary events with the system fence (A/B)."""
-        import os
-        return _LaneEvent(self.lib, os.environ.get("RTP_EVENT_FENCE", "0") == "1")
+    def new_event(self, system_fence=False):
+        """An ordering event of the lane plan.  Events BETWEEN launches of a plan are device-scope (csrc/lane_events.hip: no
+        system-scope cache writeback / invalidate when recorded); the few events that JOIN the side lanes back into the caller's
+        stream at the end of a plan (system_fence=True) are ordinary HIP events: what the side lanes wrote is then visible to
+        whatever the caller queues next -- a D2H copy of the losses, a collective's peer reads -- by the HIP contract itself."""
+        return _LaneEvent(self.lib, bool(system_fence))
 
     def stem_bwd_blocks(self):
         return self.lib.rtp_stem_bwd_blocks()

@@ -60,11 +60,11 @@ def test_cfg():
                 voxel_size=VOXEL_SIZE, input_type="rdr_cube")
 
 
-def param_shapes(name):
-    """Reference state_dict names -> shapes (det3d module tree; checked against tests/golden/param_schema.json)."""
-    s = spec(name)
+def backbone_shapes(arch, final_conv_in, final_conv_out):
+    """HRNet3D(backbone_cfg=arch, final_conv_in, final_conv_out): reference state_dict names -> shapes (hrnet3d.py:11-20 around
+    hr_util/hr3d.py's HighResolution3DNet)."""
     from .net import ARCH_TABLES
-    ch = ARCH_TABLES[s["arch"]]["channels"]
+    ch, cin = ARCH_TABLES[arch]["channels"], ARCH_TABLES[arch]["inplanes"]
     sd = OrderedDict()
     bb = "backbone.backbone"
 
@@ -84,7 +84,7 @@ def param_shapes(name):
         gn(p + ".0", cin)
         sd[p + ".1.weight"] = (cout, cin, k, k, k)
 
-    block(bb + ".layer1", s["cin"], ch[0])
+    block(bb + ".layer1", cin, ch[0])
     for stage in (2, 3, 4):
         nb = stage
         seq("%s.transition%d.%d.0" % (bb, stage - 1, stage - 1), ch[nb - 2], ch[nb - 1], 3)
@@ -98,9 +98,16 @@ def param_shapes(name):
                 elif j < i:
                     for k in range(i - j):
                         seq("%s.fuse_layers.%d.%d.%d" % (p, i, j, k), ch[j], ch[i] if k == i - j - 1 else ch[j], 3)
-    if s["final_conv_in"] != s["final_conv_out"]:
-        sd["backbone.final_conv.weight"] = (s["final_conv_out"], s["final_conv_in"], 1, 1, 1)
-        sd["backbone.final_conv.bias"] = (s["final_conv_out"],)
+    if final_conv_in != final_conv_out:
+        sd["backbone.final_conv.weight"] = (final_conv_out, final_conv_in, 1, 1, 1)
+        sd["backbone.final_conv.bias"] = (final_conv_out,)
+    return sd
+
+
+def param_shapes(name):
+    """Reference state_dict names -> shapes (det3d module tree; checked against tests/golden/param_schema.json)."""
+    s = spec(name)
+    sd = backbone_shapes(s["arch"], s["final_conv_in"], s["final_conv_out"])
     if s["dcn_head"]:   # FeatureAdaption x 2 (center_head.py:44-57, 125-135); before the towers: keeps every view 16-B aligned
         c = s["final_conv_out"]
         for which in ("cls", "reg"):

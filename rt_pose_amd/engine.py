@@ -100,12 +100,15 @@ class PoseEngine:
     """HRRadarPose for a fixed (batch, Cin, dims): buffers + launch lists built once, replayed every step."""
 
     def __init__(self, backend, params, arch, final_fuse, heads, loss_weight, code_weights, batch, dims, train=True,
-                 pgrads=None, test_cfg=None, max_objs=None, lidar_channels=0, early_flush=False):
+                 pgrads=None, test_cfg=None, max_objs=None, lidar_channels=0, early_flush=False, feature_channels=None):
+        """feature_channels=C: a plan of the HEAD alone (CenterHead used without RadarPoseNet, center_head.py:232-270): the input is a
+        feature [B, C, Z, Y, X] fp32 (load_features); in training mode the backward list ends with the feature's gradient, unpacked
+        into feat_grad [B, C, Z, Y, X] fp32.  `arch` / `final_fuse` are not used then."""
         self.be, self.n, self.dims, self.train = backend, batch, tuple(dims), train
         self.heads = OrderedDict(heads)
         self.nreg, self.ncls = self.heads["reg"], self.heads["hm"]
         self.loss_weight = float(loss_weight)
-        cin = net.ARCH_TABLES[arch]["inplanes"]
+        cin = net.ARCH_TABLES[arch]["inplanes"] if feature_channels is None else None
         be = backend
         # width hints: a launch's wgs / batch workgroups per sample, whatever the batch.  Measured (round 5, same box, hr3d, four-stream
         # map): B = 8 5.44 -> 5.26 ms per step, B = 16 9.44 -> 9.28 (1 694 -> 1 723 frames/s), B = 4 3.69 -> 3.56 (1 083 -> 1 123)
@@ -113,8 +116,17 @@ class PoseEngine:
         g = self.graph = Graph(be, batch, params, train=train, pgrads=pgrads, width_rules=rules)
         # two gradient buckets (trainer): one early flush of the deferred tail; RTP_EARLY_TAIL=1: the same flush in single-bucket mode (A/B)
         g.early_flush = bool(early_flush) or os.environ.get("RTP_EARLY_TAIL", "0") == "1"
-        self.x_in = g.input_f32("rdr", cin, dims)
-        self.feats = net.build_hrnet3d(g, self.x_in, arch, dims, final_fuse)
+        self.feat_in = self.feat_grad = None
+        if feature_channels is None:
+            self.x_in = g.input_f32("rdr", cin, dims)
+            self.feats = net.build_hrnet3d(g, self.x_in, arch, dims, final_fuse)
+        else:
+            from .graph import pad_to as _pad
+            self.x_in = None
+            self.feat_in = g.input_f32("feats_in", feature_channels, dims)
+            self.feats = g.act("feats", feature_channels, dims, c=_pad(feature_channels, 32), needs_grad=bool(train))
+            g.emit_fwd(be.pack_ncdhw(self.feat_in, self.feats, feature_channels), g.lane_of(self.feats), [self.feat_in], [self.feats],
+                       "pack:feats")
         # two-stream fusion (BASELINE config 5): the dense LiDAR voxel grid [B, C_l, Z, Y, X] fp32 enters beside the radar feature
         self.lidar_in = None
         lidar = None
@@ -191,7 +203,15 @@ class PoseEngine:
             self.loss_launches.append(rl)
             g.seed_grad(hm, self.ghm)
             g.seed_grad(reg, self.greg)
+            if feature_channels is not None:
+                g.grad_leaves = [self.feats]
             g.build_backward()
+            if feature_channels is not None:   # the head alone: hand the feature's gradient back in the caller's layout
+                gf = self.feats.grad
+                if gf is not None:
+                    self.feat_grad = be.alloc((batch, feature_channels, d, h, w), "f32")
+                    g.emit_bwd(be.unpack_ncdhw(gf, self.feat_grad, feature_channels), g.lane_of(self.feats), [gf], [self.feat_grad],
+                               "unpack:feats.grad")
             self.bwd = list(g.bwd)
             if os.environ.get("RTP_BWD_F10_FIRST", "1") == "1":
                 # stage 3's row-1 stride-2 data gradient (level-1 lane) is issued ahead of the row-2 chain it does not depend on:
@@ -227,6 +247,11 @@ class PoseEngine:
     # ------------------------------------------------------------------ data in (plumbing copies)
     def load_input(self, rdr_tensor):
         self.x_in.copy_(rdr_tensor.reshape(self.x_in.shape), non_blocking=True)
+
+    def load_features(self, feats):
+        if self.feat_in is None:
+            raise ValueError("this plan starts at the radar tensor (built without feature_channels)")
+        self.feat_in.copy_(feats.reshape(self.feat_in.shape), non_blocking=True)
 
     def load_lidar(self, grid):
         """grid: dense LiDAR voxel grid [B, C_l, Z, Y, X] (fp32; rt_pose_amd.lidar.DynamicVoxelEncoder.to_dense per frame)."""

@@ -445,6 +445,25 @@ class Graph:
                       self.lane_of(y), terms, [y, y.stats if st else None], "fuse:" + name)
         return y
 
+    def concat(self, name, terms: List[Act]):
+        """cat(terms, channel axis) with the lower-resolution terms upsampled (trilinear, align_corners=True) to the first term's
+        size -- HRNet3D.forward's plain-concat fuse (hrnet3d.py:37-40; any final_fuse other than 'top' / 'conat_conv' leaves it
+        un-convolved, appendix quirk 5).  Every term is one single-term launch of the fuse-row kernel writing its channel slice of
+        the wide tensor; the backward hands each term the matching slice of the gradient (through the upsample adjoint)."""
+        hi = terms[0]
+        assert all(t.c == t.c_real and t.co == 0 and t.c % 8 == 0 for t in terms), name
+        total = sum(t.c_real for t in terms)
+        y = self.act(name, total, hi.dims, c=total, relu=False)
+        op = ConcatOp(self, terms, y)
+        y.producer = op
+        self._add_op(op)
+        off = 0
+        for k, t in enumerate(terms):
+            yk = View(y.buf, y.n, y.d, y.h, y.w, y.cs, off, t.c)
+            self.emit_fwd(self.be.fuse_sum([t], None, yk, False), self.lane_of(y), [t], [y], "concat:%s.%d" % (name, k))
+            off += t.c
+        return y
+
     def dcn_adapt(self, name, x: Act, prefix):
         """FeatureAdaption of the reference's DCN head (center_head.py:24-62) with Z folded into the batch:
         relu(DeformConv3x3_dg4(x, Conv1x1(x))) per (frame, z) slice.  The 1x1 offset conv is an ordinary conv node of the plan
@@ -624,6 +643,10 @@ class Graph:
         for op in order:
             if getattr(op, "partner", None) is not None and op.x.needs_grad:
                 assert (op._pair_gy is None) == (op.partner._pair_gy is None), "paired head towers: one has a gradient, the other not"
+        # graph inputs whose gradient the caller wants (a head-only plan's feature): their fan-in goes in front of the tail, whose
+        # GroupNorm parameter sums may use coefficients that fan-in's prologue computes
+        for t in getattr(self, "grad_leaves", ()):
+            self.finalize_grad(t)
         self.emit_tail(L_FULL)
 
     def emit_tail(self, lane=L_FULL):
@@ -1276,6 +1299,32 @@ class DcnAdaptOp:
         if x.needs_grad:
             x.contribs.append((gx, None))
         off.contribs.append((go, None))
+
+
+class ConcatOp:
+    """Graph.concat: channel concatenation with upsampling; the adjoint is a channel slice (and the upsample adjoint)."""
+
+    def __init__(self, g, terms, y):
+        self.g, self.terms, self.y = g, terms, y
+
+    def inputs(self):
+        return list(self.terms)
+
+    def emit_backward(self, gy: View):
+        g, be = self.g, self.g.be
+        off = 0
+        for t in self.terms:
+            gk = View(gy.buf, gy.n, gy.d, gy.h, gy.w, gy.cs, gy.co + off, t.c)
+            off += t.c
+            if not t.needs_grad:
+                continue
+            if t.dims == self.y.dims:
+                t.contribs.append((gk, None))
+            else:
+                glow_buf = be.alloc((g.n, t.d, t.h, t.w, t.c), "bf16")
+                glow = View(glow_buf, g.n, t.d, t.h, t.w, t.c, 0, t.c)
+                g.emit_bwd(be.upsample_bwd(gk, glow), g.lane_of(glow), [gy], [glow], "upbwd:" + t.name)
+                t.contribs.append((glow, None))
 
 
 class FuseOp:

@@ -343,7 +343,8 @@ class LanePlan:
         if self._events is None:
             self._events = [be.new_event() if r else None for r in self.record]
             self._start = be.new_event()
-            self._ends = [be.new_event() for _ in range(NLANES)]
+            # the joins at the plan boundary carry the system fence (backend.HipBackend.new_event); only the lanes in use get one
+            self._ends = [be.new_event(system_fence=True) if l in self.lanes_used and l != 0 else None for l in range(NLANES)]
         ev = self._events
         side = [l for l in self.lanes_used if l != 0]
         # the backend's ordering events take stream HANDLES: record(ptr) / wait(ptr) (HipBackend: device-scope HIP events behind the

@@ -56,11 +56,7 @@ def _build_params(shapes, seed=0):
 
 def _backbone_shapes(arch, final_in, final_out):
     from . import configs
-    for k, v in configs._TABLE.items():
-        if v[0] == arch and v[2] == final_in and v[3] == final_out:
-            sd = configs.param_shapes(k)
-            return OrderedDict((n, s) for n, s in sd.items() if n.startswith("backbone."))
-    raise NotImplementedError("HRNet3D(%s, final_conv %d->%d) is not one of the shipped configurations" % (arch, final_in, final_out))
+    return configs.backbone_shapes(arch, final_in, final_out)
 
 
 @READERS.register_module
@@ -120,8 +116,6 @@ class CenterHead(nn.Module):
         # constructor also raises, :152); here the two FeatureAdaption modules run per (frame, z) slice in front of the
         # SepHead towers (parity unpinned by construction)
         self.dcn_head = bool(dcn_head)
-        if in_channels != share_conv_channel:
-            raise NotImplementedError("shared_conv (in_channels != share_conv_channel) is not used by any shipped config")
         if len(tasks) != 1 or num_hm_conv != 2:
             raise NotImplementedError("one task with two convs per head, as in every shipped config")
         self.class_names = [t["class_names"] for t in tasks]
@@ -131,6 +125,17 @@ class CenterHead(nn.Module):
         self.heads = OrderedDict((k, v[0]) for k, v in dict(common_heads).items())
         self.heads["hm"] = self.num_classes[0]
         shapes = OrderedDict()
+        # shared_conv (center_head.py:203-211): GroupNorm(8, in) -> Conv3d(in, share, 3x3x3, no bias) -> ReLU when the channel counts
+        # differ, Identity otherwise (every shipped config)
+        self.has_shared_conv = in_channels != share_conv_channel
+        if self.has_shared_conv:
+            if self.dcn_head or self.lidar_channels:
+                raise NotImplementedError("shared_conv together with dcn_head / lidar_channels")
+            if in_channels % 8:
+                raise ValueError("GroupNorm(8, %d): in_channels must be a multiple of 8 (center_head.py:205)" % in_channels)
+            shapes["pose_head.shared_conv.0.weight"] = (in_channels,)
+            shapes["pose_head.shared_conv.0.bias"] = (in_channels,)
+            shapes["pose_head.shared_conv.1.weight"] = (share_conv_channel, in_channels, 3, 3, 3)
         if self.dcn_head:
             for which in ("cls", "reg"):
                 p = "pose_head.tasks.0.feature_adapt_%s" % which
@@ -146,23 +151,41 @@ class CenterHead(nn.Module):
         init = _build_params(shapes)
         if init_bias != -2.19:
             init["pose_head.tasks.0.hm.2.bias"].fill_(init_bias)
-        self.shared_conv = nn.Identity()
+        self.shared_conv = ParamTree() if self.has_shared_conv else nn.Identity()
         self.tasks = ParamTree()
         for k, t in init.items():
-            self.tasks.add(k[len("pose_head.tasks."):], t)
+            if k.startswith("pose_head.shared_conv."):
+                self.shared_conv.add(k[len("pose_head.shared_conv."):], t)
+            else:
+                self.tasks.add(k[len("pose_head.tasks."):], t)
         self._engines = {}
         self._last = None
+        self._last_x = None
 
     def forward(self, x, *kwargs):
-        eng = _standalone_engine(self, x, "head")
-        eng.load_features(x)
+        """-> ([{head name: [B, classes, Z, Y, X]}], x) like center_head.py:232-238 (x: the feature the towers read, i.e. behind
+        shared_conv when there is one).  In training mode the plan keeps what CenterHead.loss needs for the backward sweep."""
+        eng = _standalone_engine(self, x, "head_train" if (self.training and torch.is_grad_enabled()) else "head")
+        eng.load_features(x.detach())
         eng.run_forward()
-        self._last = eng
-        return [OrderedDict((k, eng.output(k)) for k in self.heads)], x
+        self._last, self._last_x = eng, x
+        return [OrderedDict((k, eng.output(k)) for k in self.heads)], (eng.tower_input() if self.has_shared_conv else x)
 
     def loss(self, example, preds_dicts, test_cfg, **kwargs):
-        raise NotImplementedError("stand-alone CenterHead.loss: training runs through RadarPoseNet's fused plan "
-                                  "(RadarPoseNet.forward(example, return_loss=True))")
+        """center_head.py:244-270 on the stand-alone head: the loss kernels run on the logits of the LAST forward() (preds_dicts must be
+        what that call returned: the plan owns those buffers), and `loss` is attached to autograd -- backward() replays the head's
+        backward launch list, fills the head parameters' .grad and hands the feature's gradient to whatever produced the feature."""
+        eng = self._last
+        if eng is None or not eng.train:
+            raise RuntimeError("CenterHead.loss: call forward() in training mode (head.train(), gradients enabled) first")
+        got = preds_dicts[0]
+        if any(got[k].data_ptr() != eng.output(k).data_ptr() for k in self.heads):
+            raise ValueError("CenterHead.loss: preds_dicts must be the output of the last forward() call of this head")
+        eng.load_targets(example)
+        eng.run_losses_only()
+        named = list(self.named_parameters())
+        loss = _HeadLoss.apply(self, eng, self._last_x, *[p for _, p in named])
+        return _loss_dict(eng, loss)
 
     @torch.no_grad()
     def predict(self, example, preds_dicts, test_cfg, **kwargs):
@@ -190,45 +213,32 @@ def _loss_dict(eng, loss_tensor=None):
 
 
 def _standalone_engine(mod, x, kind):
-    """Inference plans for a backbone or a head used on its own."""
-    from .graph import Graph
+    """Plans for a backbone (inference) or a head (inference / training) used on its own."""
     key = (tuple(x.shape), str(x.device), kind)
     eng = mod._engines.get(key)
     if eng is None:
-        eng = _StandaloneEngine(mod, x, kind)
+        eng = _StandaloneEngine(mod, x, kind) if kind == "backbone" else _HeadEngine(mod, x, kind == "head_train")
         mod._engines[key] = eng
     return eng
 
 
 class _StandaloneEngine:
+    """Inference plan of a backbone used on its own."""
+
     def __init__(self, mod, x, kind):
-        from .graph import Graph, Act
+        from .graph import Graph
         be = _backend_factory(x.device)
         self.be, self.kind, self.train = be, kind, False
         b, c, d, h, w = x.shape
         self.n, self.dims = b, (d, h, w)
-        prefix = "backbone." if kind == "backbone" else "pose_head."
-        params = OrderedDict((prefix + k, p.data) for k, p in mod.named_parameters())
+        params = OrderedDict(("backbone." + k, p.data) for k, p in mod.named_parameters())
         g = self.graph = Graph(be, b, params, train=False)
-        if kind == "backbone":
-            self.x_in = g.input_f32("rdr", c, self.dims)
-            self.feats = net.build_hrnet3d(g, self.x_in, mod.backbone_cfg, self.dims, mod.final_fuse)
-        else:
-            self.heads = mod.heads
-            self.f32_in = be.alloc((b, c, d, h, w), "f32")
-            self.feats = g.act("feats", c, self.dims, needs_grad=False)
-            g.fwd.append(be.pack_ncdhw(self.f32_in, self.feats, c))
-            self.outs = net.build_head(g, self.feats, list(mod.heads))
-            self.ncls, self.nreg = mod.heads["hm"], mod.heads["reg"]
-            self.dec_out = be.alloc((b, self.ncls, 2 + self.nreg), "f32")
-            self.dec = None
+        self.x_in = g.input_f32("rdr", c, self.dims)
+        self.feats = net.build_hrnet3d(g, self.x_in, mod.backbone_cfg, self.dims, mod.final_fuse)
         self.fwd = list(g.forward_list())
 
     def load_input(self, x):
         self.x_in.copy_(x.reshape(self.x_in.shape))
-
-    def load_features(self, x):
-        self.f32_in.copy_(x.float())
 
     def run_forward(self):
         s = self.be.stream()
@@ -239,12 +249,23 @@ class _StandaloneEngine:
         a = self.feats
         return a.buf[..., :a.c_real].permute(0, 4, 1, 2, 3)
 
-    def output(self, name):
-        return self.outs[name].buf[..., :self.heads[name]].permute(0, 4, 1, 2, 3)
 
-    set_test_cfg = PoseEngine.set_test_cfg
-    run_decode = PoseEngine.run_decode
-    keypoints = PoseEngine.keypoints
+class _HeadEngine(PoseEngine):
+    """CenterHead on its own (engine.PoseEngine's head-only mode): inference, or training with the losses and the backward list."""
+
+    def __init__(self, mod, x, train):
+        be = _backend_factory(x.device)
+        b, c, d, h, w = x.shape
+        params = OrderedDict(("pose_head." + k, p.data) for k, p in mod.named_parameters())
+        self.param_grads = OrderedDict((k, be.alloc(tuple(p.shape), "f32")) for k, p in params.items()) if train else {}
+        cw = list(mod.code_weights) if len(mod.code_weights) == mod.heads["reg"] else [1.0] * mod.heads["reg"]
+        super().__init__(be, params, None, None, mod.heads, mod.weight, cw, b, (d, h, w), train=train,
+                         pgrads=self.param_grads if train else None, feature_channels=c)
+
+    def tower_input(self):
+        """The feature behind shared_conv (what center_head.py:234-238 returns beside the predictions)."""
+        a = next(op.y for op in self.graph.ops if getattr(op.y, "name", "") == "shared")
+        return a.buf[..., :a.c_real].permute(0, 4, 1, 2, 3)
 
 
 class _PlanLoss(torch.autograd.Function):
@@ -269,6 +290,28 @@ class _PlanLoss(torch.autograd.Function):
             else:
                 grads.append(None)
         return (None, *grads)
+
+
+class _HeadLoss(torch.autograd.Function):
+    """The stand-alone head's scalar loss in autograd: backward replays the head plan's backward list (parameter gradients land in the
+    plan's gradient buffers, the feature's gradient in eng.feat_grad)."""
+
+    @staticmethod
+    def forward(ctx, head, eng, x, *params):
+        ctx.head, ctx.eng = head, eng
+        ctx.x_needs = bool(torch.is_tensor(x) and x.requires_grad)
+        return eng.losses()["loss"].detach().clone()
+
+    @staticmethod
+    def backward(ctx, go):
+        eng = ctx.eng
+        eng.run_backward_only()
+        gx = (eng.feat_grad * go).to(ctx.head._last_x.dtype) if (ctx.x_needs and eng.feat_grad is not None) else None
+        grads = []
+        for name, _ in ctx.head.named_parameters():
+            g = eng.param_grads.get("pose_head." + name)
+            grads.append(None if (g is None or ("pose_head." + name) not in eng.live_params) else g * go)
+        return (None, None, gx, *grads)
 
 
 @DETECTORS.register_module

@@ -97,7 +97,10 @@ def build_hrnet3d(g: Graph, x_f32, arch, dims, final_fuse, prefix="backbone"):
         return f
     ys = build_backbone(g, x_f32, arch, dims, prefix + ".backbone")
     if final_fuse != "conat_conv" or not has_final:
-        raise NotImplementedError("final_fuse=%r without final_conv (plain concat) is not used by any shipped config" % final_fuse)
+        # hrnet3d.py:37-43: any other value returns the plain concatenation cat(x0, up(x1), up(x2), up(x3)) -- final_conv, if the
+        # constructor made one, is never applied (appendix quirk 5: 'conat_conv' is the only spelling that reaches it) -- and so does
+        # 'conat_conv' when final_conv_in == final_conv_out made final_conv an Identity (hrnet3d.py:13-14)
+        return g.concat("final.cat", ys)
     # cat(x0, up(x1), up(x2), up(x3)) -> 1x1x1 conv  ==  sum_j up(conv1x1_j(x_j))   (both ops are linear and
     # the upsample acts per channel), so the 192-channel concat is never materialised.
     total = sum(ch)

@@ -1,0 +1,132 @@
+"""The registry door's less-travelled paths (VERDICT r5 "missing" item 5), shared by the CPU (emulated kernels) and GPU (HIP) tests:
+
+  shared_conv          CenterHead(in_channels != share_conv_channel): GroupNorm(8, in) -> Conv3d(in, share, 3x3x3) -> ReLU in front of
+                       the towers (center_head.py:203-211)
+  stand-alone loss     CenterHead.forward + CenterHead.loss without RadarPoseNet (center_head.py:232-270): loss dict, parameter
+                       gradients and the gradient handed back to the feature
+  plain concat         HRNet3D(final_fuse = anything but 'top' / 'conat_conv'): cat(x0, up(x1), up(x2), up(x3)), no final conv
+                       (hrnet3d.py:37-43; appendix quirk 5)
+
+Each helper runs the module door and the oracle (oracle/hrradarpose_ref.py) on the same seeded inputs and returns what the caller
+compares; tolerances are the callers' (bf16 storage on both backends)."""
+from collections import OrderedDict
+
+import torch
+
+from oracle import hrradarpose_ref as O
+from rt_pose_amd import configs
+
+
+def shared_conv_state(share=64, seed=1):
+    """hr3d ('top', 32-channel feature) whose head reads the feature through a 32 -> `share` shared conv."""
+    arch, fin, fout, fuse, heads, weight, cw = O.MODEL_CONFIGS["hr3d"]
+    shapes = O.param_shapes(arch, fin, fout, share, heads)
+    shapes["pose_head.shared_conv.0.weight"] = (fout,)
+    shapes["pose_head.shared_conv.0.bias"] = (fout,)
+    shapes["pose_head.shared_conv.1.weight"] = (share, fout, 3, 3, 3)
+    md = configs.model_dict("hr3d")
+    md["pose_head"]["share_conv_channel"] = share
+    return md, O.seeded_state_dict(shapes, seed=seed), (fuse, weight, cw, heads)
+
+
+def to_dev(v, dev):
+    if torch.is_tensor(v):
+        return v.to(dev)
+    if isinstance(v, dict):
+        return {k: to_dev(x, dev) for k, x in v.items()}
+    if isinstance(v, (list, tuple)):
+        return type(v)(to_dev(x, dev) for x in v)
+    return v
+
+
+def run_shared_conv(build_detector, dev, dims=(8, 16, 32), b=2):
+    md, sd, (fuse, weight, cw, heads) = shared_conv_state()
+    model = build_detector(md, train_cfg=None, test_cfg=configs.test_cfg())
+    assert [k for k, _ in model.named_parameters() if "shared_conv" in k] == ["pose_head.shared_conv.0.weight", "pose_head.shared_conv.0.bias",
+                                                                              "pose_head.shared_conv.1.weight"]
+    model.load_state_dict(sd)    # strict: names and shapes are the reference module tree's
+    ex = O.synth_example(b, 1, dims, seed=1234)
+    out = model(to_dev(ex, dev), return_loss=True)
+    sum(out["loss"]).backward()
+    sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ref = O.radar_pose_net(sdr, ex, fuse, weight, cw)
+    ref["loss"][0].backward()
+    named = dict(model.named_parameters())
+    return out, ref, named, sdr
+
+
+def run_standalone_head(build_head, dev, name="hr3d", dims=(8, 16, 32), b=2, share=None):
+    """-> dict of (got, want) pairs: predictions, loss dict entries, parameter gradients, feature gradient."""
+    arch, fin, fout, fuse, heads, weight, cw = O.MODEL_CONFIGS[name]
+    md = configs.model_dict(name)["pose_head"]
+    shapes = O.param_shapes(arch, fin, fout, share or fout, heads)
+    if share:
+        md["share_conv_channel"] = share
+        shapes["pose_head.shared_conv.0.weight"] = (fout,)
+        shapes["pose_head.shared_conv.0.bias"] = (fout,)
+        shapes["pose_head.shared_conv.1.weight"] = (share, fout, 3, 3, 3)
+    sd = OrderedDict((k, v) for k, v in O.seeded_state_dict(shapes, seed=3).items() if k.startswith("pose_head."))
+    head = build_head(md)
+    head.load_state_dict({k[len("pose_head."):]: v for k, v in sd.items()})
+    head.train()
+    g = torch.Generator().manual_seed(11)
+    feat = torch.relu(torch.randn(b, fout, *dims, generator=g) * 0.5)
+    feat = feat.to(torch.bfloat16).float()          # what a bf16 plan hands over: both sides read the same values
+    ex = O.synth_example(b, 1, dims, seed=77, one_hm=heads["hm"] == 1)["rdr"]
+    x = feat.clone().to(dev).requires_grad_(True)
+    preds, tower_in = head(x)
+    out = head.loss(to_dev(ex, dev), preds, None)
+    sum(out["loss"]).backward()
+    # oracle
+    sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    xr = feat.clone().requires_grad_(True)
+    rp, rx = O.center_head(sdr, xr, tuple(heads))
+    ref = O.center_head_loss(rp, ex, weight, cw)
+    ref["loss"][0].backward()
+    named = dict(head.named_parameters())
+    pairs = {"pred." + k: (preds[0][k].detach().float().cpu(), rp[0][k].detach()) for k in heads}
+    pairs["tower_in"] = (tower_in.detach().float().cpu(), rx.detach())
+    for k in ("loss", "hm_loss", "loc_loss"):
+        pairs[k] = (sum(out[k]).detach().float().cpu().reshape(()), ref[k][0].detach().reshape(()))
+    pairs["loc_loss_elem"] = (out["loc_loss_elem"][0].float().cpu(), ref["loc_loss_elem"][0])
+    pairs["grad.feature"] = (x.grad.detach().float().cpu(), xr.grad)
+    for k in sd:
+        pairs["grad." + k] = (named[k[len("pose_head."):]].grad.detach().float().cpu(), sdr[k].grad)
+    return pairs, out
+
+
+def rel(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def plain_concat_state(share=None, seed=1):
+    """hr3d's backbone with final_fuse='concat' (anything but 'top' / 'conat_conv'): the head reads the 192-channel concatenation,
+    directly (share=None: towers Conv3d(192, 32)) or through shared_conv 192 -> share."""
+    arch, fin, fout, fuse, heads, weight, cw = O.MODEL_CONFIGS["hr3d"]
+    cat = 192
+    shapes = O.param_shapes(arch, cat, cat, share or cat, heads)
+    if share:
+        shapes["pose_head.shared_conv.0.weight"] = (cat,)
+        shapes["pose_head.shared_conv.0.bias"] = (cat,)
+        shapes["pose_head.shared_conv.1.weight"] = (share, cat, 3, 3, 3)
+    md = configs.model_dict("hr3d")
+    md["backbone"].update(final_conv_in=cat, final_conv_out=cat, final_fuse="concat")
+    md["pose_head"].update(in_channels=cat, share_conv_channel=share or cat)
+    return md, O.seeded_state_dict(shapes, seed=seed), ("concat", weight, cw, heads)
+
+
+def run_plain_concat(build_detector, dev, dims=(8, 16, 32), b=2, share=None):
+    md, sd, (fuse, weight, cw, heads) = plain_concat_state(share)
+    model = build_detector(md, train_cfg=None, test_cfg=configs.test_cfg())
+    model.load_state_dict(sd)
+    ex = O.synth_example(b, 1, dims, seed=1234)
+    with torch.no_grad():
+        feat_ref = O.hrnet3d(sd, ex["rdr"]["rdr_tensor"], fuse)
+    feat = model.extract_feat(to_dev(ex, dev)["rdr"]).detach().float().cpu()
+    out = model(to_dev(ex, dev), return_loss=True)
+    sum(out["loss"]).backward()
+    sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ref = O.radar_pose_net(sdr, ex, fuse, weight, cw)
+    ref["loss"][0].backward()
+    return feat, feat_ref, out, ref, dict(model.named_parameters()), sdr

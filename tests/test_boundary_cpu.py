@@ -1,0 +1,69 @@
+"""tests/boundary_cases.py on the emulated kernels (plumbing on CPU; the HIP run is tests/test_gpu_boundary.py)."""
+import pytest
+import torch
+
+from rt_pose_amd import modules, registry
+from rt_pose_amd.registry import build_detector
+from tests import boundary_cases as BC
+from tests.emu_backend import EmuBackend
+
+
+@pytest.fixture(autouse=True)
+def emu():
+    modules.set_backend_factory(lambda device: EmuBackend())
+    yield
+    modules.set_backend_factory(None)
+
+
+def test_shared_conv_through_the_registry_door():
+    out, ref, named, sdr = BC.run_shared_conv(build_detector, "cpu", dims=(8, 16, 16))
+    for k in ("loss", "hm_loss", "loc_loss"):
+        want = float(ref[k][0].detach())
+        assert abs(float(sum(out[k]).detach()) - want) < 2e-2 * abs(want) + 1e-4, k
+    live = [k for k in sdr if sdr[k].grad is not None]
+    assert "pose_head.shared_conv.1.weight" in live and all(named[k].grad is not None for k in live)
+    for k in ("pose_head.shared_conv.0.weight", "pose_head.shared_conv.0.bias", "pose_head.shared_conv.1.weight"):
+        assert BC.rel(named[k].grad, sdr[k].grad) < 6e-2, (k, BC.rel(named[k].grad, sdr[k].grad))
+    gm = torch.cat([named[k].grad.reshape(-1) for k in live])
+    gr = torch.cat([sdr[k].grad.reshape(-1) for k in live])
+    assert float(torch.dot(gm, gr) / (gm.norm() * gr.norm())) > 0.97
+
+
+@pytest.mark.parametrize("name,share", [("hr3d", None), ("hr3d", 64), ("hr3d_one_hm", None)])
+def test_standalone_center_head_forward_loss_backward(name, share):
+    pairs, out = BC.run_standalone_head(registry.build_head, "cpu", name=name, dims=(8, 16, 16), share=share)
+    assert set(out.keys()) == {"loss", "hm_loss", "loc_loss", "loc_loss_elem", "num_positive"}
+    for k, (got, want) in pairs.items():
+        assert tuple(got.shape) == tuple(want.shape), k
+        tol = 5e-3 if k in ("loss", "hm_loss", "loc_loss", "loc_loss_elem") else 5e-2   # bf16 activations between the convs; the regression gradient lives on <= 15 voxels per frame
+        if k == "grad.feature" and share:   # behind GroupNorm's backward (differences of bf16-rounded sums): direction + 8 %
+            assert float(torch.dot(got.reshape(-1), want.reshape(-1)) / (got.norm() * want.norm())) > 0.995 and BC.rel(got, want) < 8e-2
+            continue
+        assert BC.rel(got, want) < tol, (k, BC.rel(got, want))
+
+
+def test_standalone_loss_needs_the_last_forward():
+    head = registry.build_head(BC.configs.model_dict("hr3d")["pose_head"])
+    x = torch.zeros(1, 32, 8, 16, 16)
+    with pytest.raises(RuntimeError):
+        head.loss({}, [{}], None)
+    preds, _ = head(x)
+    other = [{k: v.clone() for k, v in preds[0].items()}]
+    with pytest.raises(ValueError):
+        head.loss({}, other, None)
+
+
+@pytest.mark.parametrize("share", [None, 64])
+def test_plain_concat_final_fuse(share):
+    feat, feat_ref, out, ref, named, sdr = BC.run_plain_concat(build_detector, "cpu", dims=(8, 16, 16), share=share)
+    assert tuple(feat.shape) == tuple(feat_ref.shape) and feat.shape[1] == 192
+    assert BC.rel(feat, feat_ref) < 3e-2
+    for k in ("loss", "hm_loss", "loc_loss"):
+        want = float(ref[k][0].detach())
+        assert abs(float(sum(out[k]).detach()) - want) < 2e-2 * abs(want) + 1e-4, k
+    live = [k for k in sdr if sdr[k].grad is not None]
+    assert all(named[k].grad is not None for k in live) and all(named[k].grad is None for k in sdr if sdr[k].grad is None)
+    assert any(".stage4.0.fuse_layers.3." in k for k in live), "every stage-4 row is live under the concatenation"
+    gm = torch.cat([named[k].grad.reshape(-1) for k in live])
+    gr = torch.cat([sdr[k].grad.reshape(-1) for k in live])
+    assert float(torch.dot(gm, gr) / (gm.norm() * gr.norm())) > 0.97

@@ -1,0 +1,53 @@
+"""tests/boundary_cases.py on the HIP kernels (VERDICT r5 "missing" item 5): shared_conv, stand-alone CenterHead.loss, plain-concat
+final_fuse -- the module door against the oracle on the same seeded inputs.  Tolerances: bf16 activations between convs (5e-3 per
+conv norm-wise, tests/test_gpu_kernels_vs_oracle.py) compound over the model; losses 2 %, gradients by direction + norm."""
+import pytest
+import torch
+
+from rt_pose_amd import registry
+from rt_pose_amd.registry import build_detector
+from tests import boundary_cases as BC
+
+pytestmark = pytest.mark.gpu
+
+
+def _check_model(out, ref, named, sdr, cos_min=0.97):
+    for k in ("loss", "hm_loss", "loc_loss"):
+        want = float(ref[k][0].detach())
+        assert abs(float(sum(out[k]).detach().float().sum()) - want) < 2e-2 * abs(want) + 1e-4, k
+    live = [k for k in sdr if sdr[k].grad is not None]
+    assert all(named[k].grad is not None for k in live) and all(named[k].grad is None for k in sdr if sdr[k].grad is None)
+    gm = torch.cat([named[k].grad.detach().float().cpu().reshape(-1) for k in live])
+    gr = torch.cat([sdr[k].grad.reshape(-1) for k in live])
+    assert float(torch.dot(gm, gr) / (gm.norm() * gr.norm())) > cos_min
+    assert abs(float(gm.norm() / gr.norm()) - 1) < 0.05
+    return live
+
+
+def test_shared_conv_through_the_registry_door():
+    out, ref, named, sdr = BC.run_shared_conv(build_detector, "cuda:0")
+    live = _check_model(out, ref, named, sdr)
+    for k in ("pose_head.shared_conv.0.weight", "pose_head.shared_conv.0.bias", "pose_head.shared_conv.1.weight"):
+        assert k in live and BC.rel(named[k].grad.detach().float().cpu(), sdr[k].grad) < 6e-2, (k, BC.rel(named[k].grad.detach().float().cpu(), sdr[k].grad))
+
+
+@pytest.mark.parametrize("name,share", [("hr3d", None), ("hr3d", 64), ("hr3d_one_hm", None)])
+def test_standalone_center_head_forward_loss_backward(name, share):
+    pairs, out = BC.run_standalone_head(registry.build_head, "cuda:0", name=name, share=share)
+    assert set(out.keys()) == {"loss", "hm_loss", "loc_loss", "loc_loss_elem", "num_positive"}
+    for k, (got, want) in pairs.items():
+        assert tuple(got.shape) == tuple(want.shape), k
+        if k == "grad.feature" and share:   # behind GroupNorm's backward (differences of bf16-rounded sums): direction + 8 %
+            assert float(torch.dot(got.reshape(-1), want.reshape(-1)) / (got.norm() * want.norm())) > 0.995 and BC.rel(got, want) < 8e-2
+            continue
+        tol = 5e-3 if k in ("loss", "hm_loss", "loc_loss", "loc_loss_elem") else 5e-2
+        assert BC.rel(got, want) < tol, (k, BC.rel(got, want))
+
+
+@pytest.mark.parametrize("share", [None, 64])
+def test_plain_concat_final_fuse(share):
+    feat, feat_ref, out, ref, named, sdr = BC.run_plain_concat(build_detector, "cuda:0", share=share)
+    assert tuple(feat.shape) == tuple(feat_ref.shape) and feat.shape[1] == 192
+    assert BC.rel(feat, feat_ref) < 3e-2
+    live = _check_model(out, ref, named, sdr)
+    assert any(".stage4.0.fuse_layers.3." in k for k in live), "every stage-4 row is live under the concatenation"

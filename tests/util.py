@@ -9,7 +9,8 @@ import pytest
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-DEADLINE_S = float(os.environ.get("RTP_TWO_RANK_DEADLINE_S", "240"))
+DEADLINE_S = float(os.environ.get("RTP_TWO_RANK_DEADLINE_S", "120"))   # (a two-rank test takes 4-8 s)
+_RETRIES_LEFT = [1]   # per pytest session: the driver's window for the whole -m gpu run is finite
 
 
 def sample_index(numel, nsample=8192):
@@ -68,16 +69,36 @@ def _free_port():
     return p
 
 
-def run_ranks(cmd, world, tmp_path, extra_env=None, deadline_s=DEADLINE_S):
+def run_ranks(cmd, world, tmp_path, extra_env=None, deadline_s=DEADLINE_S, attempts=2):
     """Start `world` fresh children of `cmd` (RANK / WORLD_SIZE / MASTER_* in the env, output to files), wait for all of them against
-    one deadline; returns (return codes, stdout texts, stderr texts).  On expiry every child still alive is killed."""
+    one deadline; returns (return codes, stdout texts, stderr texts).  On expiry every child still alive is killed.  A rank that
+    EXITS non-zero fails the test at once; a deadline expiry (two processes sharing one GPU is a test rig, not the product's
+    one-process-per-GPU layout) is retried on a fresh port -- once per pytest session -- with a warning carrying the first attempt's
+    tails."""
+    import warnings
+    for attempt in range(attempts):
+        codes, outs, errs, timed_out = _run_ranks_once(cmd, world, os.path.join(tmp_path, "attempt%d" % attempt), extra_env, deadline_s)
+        if not timed_out and all(c == 0 for c in codes):
+            return codes, outs, errs
+        tails = "\n".join("---- rank %d: rc %s%s\n[stdout]\n%s\n[stderr]\n%s" % (r, codes[r], " (killed at the deadline)" if r in timed_out else "",
+                                                                                   outs[r][-1500:], errs[r][-4000:]) for r in range(world))
+        msg = "attempt %d: ranks %s still running after %.0f s / exit codes %s\n%s" % (attempt, timed_out, deadline_s, codes, tails)
+        crashed = any(c != 0 for r, c in enumerate(codes) if r not in timed_out)
+        if crashed or attempt == attempts - 1 or _RETRIES_LEFT[0] <= 0:
+            pytest.fail(msg, pytrace=False)
+        _RETRIES_LEFT[0] -= 1
+        warnings.warn("two-rank rig: " + msg)
+
+
+def _run_ranks_once(cmd, world, out_dir, extra_env, deadline_s):
+    os.makedirs(out_dir, exist_ok=True)
     port = _free_port()
     procs, files = [], []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    HSA_ENABLE_IPC_MODE_LEGACY="0", RTP_HANG_DUMP_S=str(int(deadline_s * 0.75)))
         env.update(extra_env or {})
-        fo, fe = open(os.path.join(tmp_path, "rank%d.out" % r), "w+"), open(os.path.join(tmp_path, "rank%d.err" % r), "w+")
+        fo, fe = open(os.path.join(out_dir, "rank%d.out" % r), "w+"), open(os.path.join(out_dir, "rank%d.err" % r), "w+")
         files.append((fo, fe))
         procs.append(subprocess.Popen(cmd, env=env, cwd=ROOT, stdout=fo, stderr=fe, stdin=subprocess.DEVNULL, text=True))
     end = time.monotonic() + deadline_s
@@ -102,8 +123,4 @@ def run_ranks(cmd, world, tmp_path, extra_env=None, deadline_s=DEADLINE_S):
         f.close()
         return t
     outs, errs = [text(fo) for fo, _ in files], [text(fe) for _, fe in files]
-    if timed_out or any(p.returncode != 0 for p in procs):
-        tails = "\n".join("---- rank %d: rc %s%s\n[stdout]\n%s\n[stderr]\n%s" % (r, p.returncode, " (killed at the deadline)" if r in timed_out else "",
-                                                                                 outs[r][-1500:], errs[r][-4000:]) for r, p in enumerate(procs))
-        pytest.fail("ranks %s still running after %.0f s / non-zero exit\n%s" % (timed_out, deadline_s, tails), pytrace=False)
-    return [p.returncode for p in procs], outs, errs
+    return [p.returncode for p in procs], outs, errs, timed_out
