@@ -69,7 +69,7 @@ extern "C" int rtp_chan_stats(const RtpAct* a, const RtpAct* b, int n, long vox,
                               void* stream) {
   if (!a || !out || nsplit < 1) return RTP_ERR_SHAPE;
   const int c = a->c;
-  if (c % 8 || c > 256 || (256 % (c / 8))) return RTP_ERR_UNSUPPORTED;
+  if (c % 8 || c > 256) return RTP_ERR_UNSUPPORTED;   // (256 % (c / 8) != 0, e.g. 192 channels: the last threads of a block idle)
   if ((a->cs % 8) || (a->co % 8) || (b && ((b->cs % 8) || (b->co % 8) || b->c != c))) return RTP_ERR_ALIGN;
   hipStream_t s = (hipStream_t)stream;
   RtpProfScope prof(RTP_FAM_NORM, s);

@@ -217,6 +217,10 @@ def _standalone_engine(mod, x, kind):
     key = (tuple(x.shape), str(x.device), kind)
     eng = mod._engines.get(key)
     if eng is None:
+        off = [k for k, p in mod.named_parameters() if p.device != x.device]
+        if off:   # (the kernels would read host pointers: fail here, not in a GPU memory fault)
+            raise RuntimeError("%s: parameters (%s, ...) are on %s but the input is on %s -- move the module first (module.to(%r))"
+                               % (type(mod).__name__, off[0], next(mod.parameters()).device, x.device, str(x.device)))
         eng = _StandaloneEngine(mod, x, kind) if kind == "backbone" else _HeadEngine(mod, x, kind == "head_train")
         mod._engines[key] = eng
     return eng

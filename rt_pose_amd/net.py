@@ -100,6 +100,11 @@ def build_hrnet3d(g: Graph, x_f32, arch, dims, final_fuse, prefix="backbone"):
         # hrnet3d.py:37-43: any other value returns the plain concatenation cat(x0, up(x1), up(x2), up(x3)) -- final_conv, if the
         # constructor made one, is never applied (appendix quirk 5: 'conat_conv' is the only spelling that reaches it) -- and so does
         # 'conat_conv' when final_conv_in == final_conv_out made final_conv an Identity (hrnet3d.py:13-14)
+        if (prefix.replace("backbone", "pose_head") + ".shared_conv.1.weight") in g.params and sum(ch) not in (32, 64, 128, 256):
+            # GroupNorm(8, 192) -> Conv3d(192, share): the fold kernels' weight images come 32 / 64 / 128 / 256 input channels wide
+            # (rtp_wgrad_fold reads whole 1-KB rows).  The concatenation itself and towers that read it directly are built.
+            raise NotImplementedError("shared_conv over the %d-channel plain concatenation (final_fuse=%r): not built; use "
+                                      "in_channels == share_conv_channel, or final_fuse='conat_conv'" % (sum(ch), final_fuse))
         return g.concat("final.cat", ys)
     # cat(x0, up(x1), up(x2), up(x3)) -> 1x1x1 conv  ==  sum_j up(conv1x1_j(x_j))   (both ops are linear and
     # the upsample acts per channel), so the 192-channel concat is never materialised.

@@ -68,7 +68,7 @@ def run_standalone_head(build_head, dev, name="hr3d", dims=(8, 16, 32), b=2, sha
     sd = OrderedDict((k, v) for k, v in O.seeded_state_dict(shapes, seed=3).items() if k.startswith("pose_head."))
     head = build_head(md)
     head.load_state_dict({k[len("pose_head."):]: v for k, v in sd.items()})
-    head.train()
+    head.to(dev).train()
     g = torch.Generator().manual_seed(11)
     feat = torch.relu(torch.randn(b, fout, *dims, generator=g) * 0.5)
     feat = feat.to(torch.bfloat16).float()          # what a bf16 plan hands over: both sides read the same values

@@ -53,7 +53,14 @@ def test_standalone_loss_needs_the_last_forward():
         head.loss({}, other, None)
 
 
-@pytest.mark.parametrize("share", [None, 64])
+def test_plain_concat_behind_a_shared_conv_is_refused_by_name():
+    md, sd, _ = BC.plain_concat_state(share=64)
+    model = build_detector(md, train_cfg=None, test_cfg=BC.configs.test_cfg())
+    with pytest.raises(NotImplementedError, match="shared_conv over the 192-channel plain concatenation"):
+        model(BC.O.synth_example(1, 1, (8, 16, 16), seed=1), return_loss=False)
+
+
+@pytest.mark.parametrize("share", [None])
 def test_plain_concat_final_fuse(share):
     feat, feat_ref, out, ref, named, sdr = BC.run_plain_concat(build_detector, "cpu", dims=(8, 16, 16), share=share)
     assert tuple(feat.shape) == tuple(feat_ref.shape) and feat.shape[1] == 192
@@ -67,3 +74,9 @@ def test_plain_concat_final_fuse(share):
     gm = torch.cat([named[k].grad.reshape(-1) for k in live])
     gr = torch.cat([sdr[k].grad.reshape(-1) for k in live])
     assert float(torch.dot(gm, gr) / (gm.norm() * gr.norm())) > 0.97
+
+
+def test_standalone_module_on_another_device_than_its_input_is_refused():
+    head = registry.build_head(BC.configs.model_dict("hr3d")["pose_head"])
+    with pytest.raises(RuntimeError, match="move the module first"):
+        head(torch.zeros(1, 32, 8, 16, 16, device="meta"))

@@ -44,7 +44,7 @@ def test_standalone_center_head_forward_loss_backward(name, share):
         assert BC.rel(got, want) < tol, (k, BC.rel(got, want))
 
 
-@pytest.mark.parametrize("share", [None, 64])
+@pytest.mark.parametrize("share", [None])
 def test_plain_concat_final_fuse(share):
     feat, feat_ref, out, ref, named, sdr = BC.run_plain_concat(build_detector, "cuda:0", share=share)
     assert tuple(feat.shape) == tuple(feat_ref.shape) and feat.shape[1] == 192
