@@ -58,7 +58,8 @@ typedef struct RtpConvGeom {
                    * partials sum to the same totals up to summation order.  Why narrower: a main-stream launch that leaves a quarter
                    * of the CUs alone costs itself 5 % and lets other streams' dependent chains run beside it (DESIGN.md 8, round 4:
                    * -3.8 % on the hr3d step); why wider: a side chain's launches while the main stream waits for them (round 5).
-                   * Kernels other than conv_tiled / wgrad_tiled / wgrad_s2_tiled ignore the field. */
+                   * Honoured by conv_tiled / wgrad_tiled / wgrad_s2_tiled and by the 64-wide kernel (conv64_tiled.hip: rtp_conv_igemm_ws on
+                   * 64 -> 64 layers -- its statistics slot count follows it -- and rtp_conv64_blocks); other kernels ignore the field. */
 } RtpConvGeom;
 
 /* ---------------------------------------------------------------- A. convolution family --- */
@@ -565,8 +566,10 @@ const char* rtp_version(void);
  *   Results and buffers are those of the separate launches (a problem merely runs on its share of every sample's 256 / n
  *   workgroups).  rtp_multi_end returns RTP_ERR_UNSUPPORTED when the recorded launches cannot share one (different kernels or
  *   variants, different sample counts n or an n that does not divide 256, a generic-kernel geometry, fewer than 2 or more than 4
- *   launches): the caller keeps the separate launches.  A capture left open by a failed caller is discarded by the next
- *   rtp_multi_begin on that thread.  rtp_multi_launch returns RTP_ERR_UNSUPPORTED on another device than the handle's.
+ *   launches): the caller keeps the separate launches.  An EMPTY capture left open on the thread is replaced by the next
+ *   rtp_multi_begin; one with recorded launches (a nested begin, or a caller that failed without rtp_multi_abort) is discarded and
+ *   that begin returns RTP_ERR_UNSUPPORTED -- no mixed set is ever merged.  rtp_multi_launch returns RTP_ERR_UNSUPPORTED on another
+ *   device than the handle's.  rtp_multi_free: no launch of the handle may still be in flight.
  *   The default plan uses it for the two head towers (center_head.py:66-109: hm and reg are independent chains of the same convs):
  *   conv .0 / .2, data gradient .2 and both weight gradients run pairwise in one launch (-1.4 % on the hr3d step). */
 int rtp_multi_begin(void);

@@ -43,6 +43,9 @@ class _MultiLaunch:
     def __del__(self):
         try:
             if self.handle >= 0:
+                # rtp_multi_free requires that no launch of the handle is in flight (include/rtp.h): wait for the device first
+                if torch.cuda.is_available():
+                    torch.cuda.synchronize(self.params.device)
                 self.lib.rtp_multi_free(self.handle)
                 self.handle = -1
         except Exception:   # interpreter shutdown: the library may be gone already
@@ -97,20 +100,10 @@ class HipBackend:
     def lane_streams(self, n):
         cur = torch.cuda.current_stream(self.device)
         if len(getattr(self, "_lanes", ())) < n - 1:
-            import os
-            # stream priority per side lane (0 = default, -1 = high); RTP_LANE_PRIORITIES="p1,p2,..." for experiments
-            pr = [int(v) for v in os.environ.get("RTP_LANE_PRIORITIES", "").split(",") if v.strip() != ""]
             # HIP deals streams onto GPU_MAX_HW_QUEUES (4) hardware queues in creation order, and which lanes share a queue decides
-            # how their kernels interleave with the main lane's persistent ones (measured: 4 queues 6.1 ms/step, 3: 6.4, 5+: 9.0).
-            # Experiment knobs: RTP_DUMMY_STREAMS=k creates k unused streams first (shifts the deal), RTP_LANE_ORDER="3,1,2,5,4"
-            # creates the side lanes' streams in that order.
-            self._dummies = [torch.cuda.Stream(self.device) for _ in range(int(os.environ.get("RTP_DUMMY_STREAMS", "0")))]
-            order = [int(v) for v in os.environ.get("RTP_LANE_ORDER", "").split(",") if v.strip() != ""] or list(range(1, n))
-            assert sorted(order) == list(range(1, n)), "RTP_LANE_ORDER must be a permutation of 1..%d" % (n - 1)
-            made = {}
-            for lane in order:
-                made[lane] = torch.cuda.Stream(self.device, priority=(pr[lane - 1] if lane - 1 < len(pr) else 0))
-            self._lanes = [made[i] for i in range(1, n)]
+            # how their kernels interleave with the main lane's persistent ones (measured: 4 queues 6.1 ms/step, 3: 6.4, 5+: 9.0;
+            # side lanes at default priority, the step stream high: the other combinations measured 3-8 % slower)
+            self._lanes = [torch.cuda.Stream(self.device) for _ in range(1, n)]
         streams = [cur] + self._lanes[:n - 1]
         return streams, [C.c_void_p(st.cuda_stream) for st in streams]
 
@@ -525,8 +518,9 @@ class HipBackend:
         keep = [x, y, off_act, w_ad, xf, off, yf, ws3]
         # forward on the plan's own layout (rtp_dcn_cl_forward: four 16-byte corner loads per sample instead of sixteen planar ones,
         # no unpack / transpose / pack passes); the backward operator still wants fp32 planes and unpacks them itself then.
-        # RTP_DCN_CL=0: the fp32 NCHW operator for the forward too
-        cl = (os.environ.get("RTP_DCN_CL", "1") != "0" and C == 32 and dg == 4 and koff == 72 and vox % 16 == 0
+        # PlanOptions.dcn_cl = 0: the fp32 NCHW operator for the forward too
+        from .options import PlanOptions
+        cl = (PlanOptions.from_env().dcn_cl and C == 32 and dg == 4 and koff == 72 and vox % 16 == 0
               and x.cs % 8 == 0 and x.co % 8 == 0)
         oa = RtpAct(off_act.buf.data_ptr(), off_act.cs, off_act.co, off_act.c)
 
@@ -576,6 +570,7 @@ class HipBackend:
                 state["prepared"] = True
                 return prep
             make_backward.prep = use_prep   # the backward operator's fp32 planes as a launch the plan places where it likes
+        make_backward.planes = (xf, off)    # what `prep` writes and the backward operator reads: the plan tracks them as buffers
         return fwd, make_backward
 
     # -------------------------------------------------------------- head: loss / decode / optimiser

@@ -305,7 +305,7 @@ int rtp_conv64_wgs(const RtpAct* x, const RtpConvGeom* g, int transposed) {
   if ((long)tiles * g->n < 64) return 0;
   // the level-1 tensors (fewer than 4096 bricks in all) on half the chip: phase config, same box, 256 / 128 / 64 workgroups:
   // 27.88-27.90 / 27.84-27.85 / 28.04-28.11 ms per step (alone the launch takes 43 / ~60 / 130 us: the side lanes want the CUs)
-  static const int small_wgs = getenv("RTP_CONV64_WGS_SMALL") ? atoi(getenv("RTP_CONV64_WGS_SMALL")) : 128;
+  static const int small_wgs = 128;
   int wgs = (g->wgs > 0 ? (g->wgs > 256 ? 256 : g->wgs) : ((long)tiles * g->n < 4096 ? small_wgs : 256)) / g->n;
   if (wgs < 1) wgs = 1;
   if (wgs > tiles) wgs = tiles;
@@ -364,7 +364,10 @@ int rtp_conv64_try(const RtpAct* x, const void* wf, int w_per_sample, const floa
 /* include/rtp.h: rtp_conv64_blocks */
 extern "C" int rtp_conv64_blocks(const RtpConv64* c, const RtpConvGeom* g, void* stream) {
   if (!c || !g) return RTP_ERR_SHAPE;
-  if (g->ks != 3 || g->stride != 1 || g->pad != 1 || g->di % C64_TZ || g->hi % C64_TY || g->wi < 1 || g->n < 1) return RTP_ERR_UNSUPPORTED;
+  // W % 16 == 0 as documented: the chain's fp32 partial sums live in BRICK layout (tiles * 8 192 floats per sample), which only
+  // for full brick columns equals the documented n * voxels * 64 floats -- a ragged W would write past a buffer of that size
+  if (g->ks != 3 || g->stride != 1 || g->pad != 1 || g->di % C64_TZ || g->hi % C64_TY || g->wi < C64_TX || g->wi % C64_TX || g->n < 1)
+    return RTP_ERR_UNSUPPORTED;
   if (rtp_multi_capture()) return RTP_ERR_UNSUPPORTED;
   C64Params p;
   for (int h = 0; h < 2; ++h) {

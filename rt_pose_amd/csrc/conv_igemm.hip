@@ -318,7 +318,7 @@ int rtp_conv_s2_fwd_try(const RtpAct* x, const void* wf, int w_per_sample, const
 
 // tile shape of the generic kernel for a problem: (cout tiles per wave, voxel tiles per wave, blocks per sample)
 static void igemm_shape(int N, int Vo, int Co, int* nt, int* mt, int* bps) {
-  static const int force_mt = getenv("RTP_IGEMM_MT") ? atoi(getenv("RTP_IGEMM_MT")) : 0;  // experiments: 1 or 4
+  static const int force_mt = 0;
   *nt = (Co % 32 == 0) ? 2 : 1;
   // 64 voxels per wave amortise the weight fragments; small (low-resolution) problems instead take 16 voxels per wave
   // so that they still spread over the chip (they are latency-, not throughput-bound)
@@ -351,7 +351,7 @@ static void slice_geom(const RtpConvGeom* g, int transposed, RtpConvGeom* gs, in
 }
 
 static int sliced_stat_slots(const RtpAct* x, const RtpConvGeom* g, int transposed) {
-  static const bool disabled = getenv("RTP_DISABLE_SLICED") != nullptr || getenv("RTP_DISABLE_TILED") != nullptr;
+  static const bool disabled = getenv("RTP_DISABLE_TILED") != nullptr;
   if (disabled || !x || !g) return 0;
   if (g->ks != 3 || g->pad != 1 || (g->stride != 1 && !(g->stride == 2 && !transposed))) return 0;
   const int Ci = transposed ? (g->co + 31) / 32 * 32 : g->ci, Co = transposed ? g->ci : g->co;

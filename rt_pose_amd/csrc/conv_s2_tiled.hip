@@ -252,7 +252,7 @@ __global__ __launch_bounds__(512, 2) void conv_s2_fwd_kernel(S2FwdParams p) {
 }
 
 static bool s2f_geometry_ok(const RtpAct* x, const RtpConvGeom* g) {
-  static const bool disabled = getenv("RTP_DISABLE_S2_FWD") != nullptr || getenv("RTP_DISABLE_TILED") != nullptr;
+  static const bool disabled = getenv("RTP_DISABLE_TILED") != nullptr;
   if (disabled || !x || !g) return false;
   if (g->ks != 3 || g->stride != 2 || g->pad != 1 || g->ci != 32 || g->co != 32) return false;
   if (g->di != 2 * g->dov || g->hi != 2 * g->ho || g->wi != 2 * g->wo) return false;

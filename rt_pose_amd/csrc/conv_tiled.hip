@@ -1014,12 +1014,12 @@ static bool tiled_geometry_ok(const RtpAct* x, const RtpConvGeom* g, int transpo
 
 static int tiled_wgs_per_sample(const RtpConvGeom* g) {
   const int tiles = (g->di / TZ) * (g->hi / TY) * ((g->wi + TX - 1) / TX);
-  static const int total_wgs = getenv("RTP_TILED_WGS") ? atoi(getenv("RTP_TILED_WGS")) : 256;  // experiments: leave CUs to other streams
+  static const int total_wgs = 256;   // (a launch's own width: RtpConvGeom::wgs)
   // launches of the lower levels (fewer than 2048 bricks in all: the level-1 tensors at the native shape) are kept NARROW -- 64
   // workgroups with four times the bricks each: the 55 KB of weights (and the GroupNorm fold) a workgroup pays before its first brick
   // are amortised over 6 bricks per team instead of 1.5, and they fit on the CUs the hinted main-lane launches leave free (hr3d B = 8
   // step: -0.7 ... -2.3 % depending on the box for 128, another -0.5 % for 64 beside the width hints; RTP_TILED_WGS_SMALL, 0 = as the large ones)
-  static const int small_wgs = getenv("RTP_TILED_WGS_SMALL") ? atoi(getenv("RTP_TILED_WGS_SMALL")) : 64;
+  static const int small_wgs = 64;
   int wgs = ((small_wgs > 0 && (long)tiles * g->n < 2048) ? small_wgs : total_wgs) / g->n;  // workgroups per sample: one workgroup per CU when N divides 256
   // RtpConvGeom::wgs: the caller's launch width (narrower: CUs left to other streams; wider than the narrow default of a small
   // launch: a side chain the main stream is waiting for) -- also the number of per-workgroup partial slots, so queries and launches
@@ -1029,7 +1029,7 @@ static int tiled_wgs_per_sample(const RtpConvGeom* g) {
   if (wgs * 2 > tiles) wgs = (tiles + 1) / 2;
   // small volumes: a workgroup pays ~6 us of fixed cost (55 KB of weights, pipeline ramp) whatever it computes; with fewer than
   // `minb` bricks per team that dominates (experiment knob; 0 = off)
-  static const int minb = getenv("RTP_TILED_MIN_BRICKS") ? atoi(getenv("RTP_TILED_MIN_BRICKS")) : 0;
+  static const int minb = 0;
   if (minb > 0 && wgs * 2 * minb > tiles) { wgs = tiles / (2 * minb); if (wgs < 1) wgs = 1; }
   return wgs;
 }
@@ -1078,9 +1078,13 @@ int rtp_conv_tiled_try(const RtpAct* x, const void* wf, int w_per_sample, const 
   p.part_stride = wgs;   // (one partial slot per workgroup: rtp_conv_stats_nsplit reports the same count for this geometry)
   p.teams_per_sample = wgs * 2;
   if ((long)p.tiles_per_sample * (p.teams_per_sample + 1) >= (1L << 31)) return RTP_ERR_SHAPE;
-  static const int dbg = getenv("RTP_TILED_DBG") ? atoi(getenv("RTP_TILED_DBG")) : 0;
+  #ifdef RTP_TILED_DBGFLAGS
+  static const int dbg = getenv("RTP_TILED_DBG") ? atoi(getenv("RTP_TILED_DBG")) : 0;   // (phase-skipping experiment builds only)
+#else
+  static const int dbg = 0;
+#endif
   p.dbg = dbg;
-  static const int prio = getenv("RTP_TILED_PRIO") ? atoi(getenv("RTP_TILED_PRIO")) : 0;
+  static const int prio = 0;
   p.prio = prio;
   p.nextra = 0; p.mask = 0; p.tot_out = nullptr;
   p.qpart = nullptr; p.q_nsplit = 0; p.gn_p = p.gn_mr = p.gn_gamma = nullptr; p.gn_groups = 1; p.gn_m = 1.f; p.coef_out = nullptr;

@@ -714,8 +714,7 @@ __global__ __launch_bounds__(64) void dcn_gradw_mfma_kernel(const float* go, con
 // dispatchers: true when the MFMA kernel took the GEMM
 static bool dcn_colgrad_mfma(hipStream_t s, const float* w, const float* go, float* cols, int cog, int c_base, int cg,
                              const DcnGeom& g, long N) {
-  const char* e = getenv("RTP_DCN_VALU_GEMM");
-  if ((e && atoi(e)) || cog > 64) return false;
+  if (cog > 64) return false;
   const int ck = cg * g.kh * g.kw;
   const int kp = (cog + 1) / 2;
   const int kpt = kp <= 8 ? 8 : kp <= 16 ? 16 : 32;
@@ -731,8 +730,7 @@ static bool dcn_colgrad_mfma(hipStream_t s, const float* w, const float* go, flo
 
 static bool dcn_gradw_mfma(hipStream_t s, const float* go, const float* cols, float* gw, int cog, int ck, int co_total,
                            int P, long N, float scale) {
-  const char* e = getenv("RTP_DCN_VALU_GEMM");
-  if ((e && atoi(e)) || cog > 32 || P % 64) return false;
+  if (cog > 32 || P % 64) return false;
   const long units = N / 64;
   int upw = (int)((units + 1023) / 1024);  // ~1024 waves: one per SIMD
   if (upw < 1) upw = 1;
@@ -1324,8 +1322,7 @@ static DcnWin dcn_win_plan(const DcnGeom& g, int cop) {
   if (wn.halo < 0) wn.halo = 0;
   const int rows = (DCN_FWD_THREADS + g.wo - 2) / g.wo + 1;  // output rows a tile of consecutive positions can touch
   wn.wr = (rows - 1) * g.sh + (g.kh - 1) * g.dh + 2 + 2 * wn.halo;
-  const char* pe = getenv("RTP_DCN_NOPAD");
-  wn.wrs = ((g.w & 3) == 0 && g.w + 4 <= 4 * DCN_FWD_THREADS && !(pe && atoi(pe))) ? g.w + 4 : 0;
+  wn.wrs = ((g.w & 3) == 0 && g.w + 4 <= 4 * DCN_FWD_THREADS) ? g.w + 4 : 0;
   wn.ws = wn.wrs ? wn.wr * wn.wrs + 4 : wn.wr * g.w;
   wn.ws = (wn.ws + 31) / 32 * 32;
   if (wn.ws % 64 == 0) wn.ws += 32;  // channel cq+1 (upper half-wave) 32 banks away from channel cq
@@ -1592,8 +1589,6 @@ __global__ __launch_bounds__(256, 2) void dcn_gradw_fused_kernel(const float* x,
 }
 
 static bool dcn_gradw_fused_ok(const DcnGeom& g) {
-  const char* e = getenv("RTP_DCN_NO_FUSED_GRADW");
-  if (e && atoi(e)) return false;
   return g.group == 1 && g.dg == 4 && g.c == 32 && g.kh == 3 && g.kw == 3 && g.co <= 32 && (g.ho * g.wo) % 64 == 0 && g.w >= 2;
 }
 
@@ -2190,8 +2185,7 @@ static int dcn_backward_fused(const float* input, const float* offset, const flo
     ok = ok && hipFuncSetAttribute((const void*)dcn_bwd_fused_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
     if (!ok) { attr[rtp_device_index()] = false; return RTP_ERR_LAUNCH; }
   }
-  const char* se = getenv("RTP_DCN_SPLIT_GW");   // weight gradient by dcn_gradw_fused_kernel (its own gather pass)
-  const bool split = gradWeight && se && atoi(se) && dcn_gradw_fused_ok(g);
+  const bool split = false;   // (weight gradient by dcn_gradw_fused_kernel, a gather pass of its own: measured slower, round 3)
   float* gwk = split ? nullptr : gradWeight;
   const char* fe = getenv("RTP_DCN_FP32_MFMA");  // the two products on the fp32 matrix instruction (exact products, 3x the cycles)
   const bool x3 = !(fe && atoi(fe));

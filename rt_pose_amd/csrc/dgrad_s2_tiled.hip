@@ -358,7 +358,7 @@ __global__ __launch_bounds__(256, 2) void dgrad_s2_kernel(S2Params p) {
 }
 
 static bool s2_geometry_ok(const RtpAct* gy, const RtpConvGeom* g) {
-  static const bool disabled = getenv("RTP_DISABLE_S2_TILED") != nullptr || getenv("RTP_DISABLE_TILED") != nullptr;
+  static const bool disabled = getenv("RTP_DISABLE_TILED") != nullptr;
   if (disabled) return false;
   if (g->ks != 3 || g->stride != 2 || g->pad != 1 || g->ci != 32 || (g->co + 31) / 32 * 32 != 32) return false;
   if (g->di != 2 * g->dov || g->hi != 2 * g->ho || g->wi != 2 * g->wo) return false;
@@ -369,7 +369,7 @@ static bool s2_geometry_ok(const RtpAct* gy, const RtpConvGeom* g) {
 
 static int s2_wgs_per_sample(const RtpConvGeom* g) {
   const int tiles = g->dov * (g->ho / 2) * (g->wo / 16);
-  static const int total_wgs = getenv("RTP_S2_WGS") ? atoi(getenv("RTP_S2_WGS")) : 512;
+  static const int total_wgs = 512;
   int wgs = total_wgs / g->n;
   if (wgs < 1) wgs = 1;
   if (wgs > tiles) wgs = tiles;

@@ -24,7 +24,17 @@ std::vector<RtpMultiJob>* rtp_multi_capture() { return t_capture; }
 
 // A capture left open on this thread (a caller that failed between begin and end without calling rtp_multi_abort) is dropped, not
 // inherited: otherwise every later tiled entry point on the thread would record instead of launching and still return RTP_OK.
+// ... unless it has recorded jobs.  That is either a nested / re-entrant begin (a closure that itself builds a shared launch) or a
+// caller that failed after recording: in both cases the open capture is DISCARDED and this begin fails with RTP_ERR_UNSUPPORTED --
+// nothing is merged from a mixed set, the nested caller sees an error, the outer rtp_multi_end then fails with RTP_ERR_SHAPE (no
+// capture), and the next begin on the thread starts clean.
 extern "C" int rtp_multi_begin(void) {
+  if (t_capture && !t_capture->empty()) {
+    if (getenv("RTP_MERGE_DEBUG")) fprintf(stderr, "[multi] begin inside an open capture with %zu recorded jobs: both dropped\n", t_capture->size());
+    delete t_capture;
+    t_capture = nullptr;
+    return RTP_ERR_UNSUPPORTED;
+  }
   if (t_capture) { delete t_capture; t_capture = nullptr; }
   t_capture = new std::vector<RtpMultiJob>();
   return RTP_OK;
@@ -61,7 +71,7 @@ extern "C" int rtp_multi_end(void* dev_params, long dev_bytes, int* handle_out) 
   }
   // shares of a sample's 256 / n workgroups (n = 8: one XCD's 32): proportional to the bricks, at least one each, largest
   // remainders first.  (experiments: RTP_MULTI_WGS_PER_XCD < 32 leaves CUs to the other lanes)
-  static const int wg_env = getenv("RTP_MULTI_WGS_PER_XCD") ? atoi(getenv("RTP_MULTI_WGS_PER_XCD")) : 32;
+  static const int wg_env = 32;
   const int per_xcd = wg_env > 32 ? 32 : (wg_env < 1 ? 1 : wg_env);
   const int WG = 8 * per_xcd / n;
   if (WG < nj) return RTP_ERR_UNSUPPORTED;

@@ -344,7 +344,7 @@ static int fill_fold_fwd(FoldParams& p, const float* w, const float* bias, const
   p.wf = (bf16_t*)wf; p.btab = wf ? btab : nullptr; p.mr = wf ? mr : nullptr;
   p.wd = (bf16_t*)wd; p.cok = (g->co + 31) / 32 * 32;
   p.cos = fold_cos(ci_real, p.ntap);
-  static const int dbg = getenv("RTP_FOLD_DBG") ? atoi(getenv("RTP_FOLD_DBG")) : 0;
+  static const int dbg = 0;
   p.dbg = dbg;
   if (p.ci_pad % 8) return RTP_ERR_UNSUPPORTED;
   if (fold_shm(p) > 60 * 1024) return RTP_ERR_UNSUPPORTED;

@@ -283,7 +283,7 @@ extern "C" int rtp_wgrad(const RtpAct* gy, const RtpAct* x, const RtpConvGeom* g
   p.vps = rtp_div_up(rtp_div_up(p.Vo, nsplit), WG_VB) * WG_VB;
   hipStream_t s = (hipStream_t)stream;
   RtpProfScope prof(RTP_FAM_WGRAD, s);
-  static const bool no_1x1 = getenv("RTP_DISABLE_WGRAD_1X1") != nullptr;
+  static const bool no_1x1 = false;
   if (!no_1x1 && p.ks == 1 && p.stride == 1 && p.pad == 0 && (p.co32 / 32) * p.citiles <= 16) {
     const size_t shm = sizeof(bf16_t) * (size_t)(p.co32 / 32 + p.citiles) * W1_VB * 32;
     static bool attr[RTP_MAX_DEVICES] = {};

@@ -208,7 +208,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(512, 512), amdgpu_waves_pe
 }
 
 static bool w2_geometry_ok(const RtpConvGeom* g) {
-  static const bool disabled = getenv("RTP_DISABLE_S2_WGRAD") != nullptr || getenv("RTP_DISABLE_TILED") != nullptr;
+  static const bool disabled = getenv("RTP_DISABLE_TILED") != nullptr;
   if (disabled || !g) return false;
   if (g->ks != 3 || g->stride != 2 || g->pad != 1) return false;
   if (g->di != 2 * g->dov || g->hi != 2 * g->ho || g->wi != 2 * g->wo) return false;
@@ -216,7 +216,7 @@ static bool w2_geometry_ok(const RtpConvGeom* g) {
   const int co32 = (g->co + 31) / 32 * 32;
   if (g->ci % 32 || g->ci > 256 || co32 > 256) return false;
   if (g->ci * co32 > 32 * 32) {   // channel slices: every launch streams x again; only for volumes that fill the chip
-    static const bool no_slices = getenv("RTP_DISABLE_SLICED") != nullptr;
+    static const bool no_slices = false;
     if (no_slices || g->co % 32 || (g->ci > 32 && (long)g->n * g->dov * g->ho * g->wo < 65536)) return false;
   }
   return true;

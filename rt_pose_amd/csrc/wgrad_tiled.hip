@@ -501,7 +501,7 @@ void wgrad_tiled_multi_kernel(WgMulti m) {
 // filling its 32 x 32 window of the [27][Co][Ci] slabs.
 static bool wg_tiled_applicable(const RtpConvGeom* g) {
   static const bool disabled = getenv("RTP_DISABLE_TILED") != nullptr;
-  static const bool no_slices = getenv("RTP_DISABLE_SLICED") != nullptr;
+  static const bool no_slices = false;
   if (disabled) return false;
   const int co32 = (g->co + 31) / 32 * 32;
   if (!(g->ks == 3 && g->stride == 1 && g->pad == 1 && g->di % TZ == 0 && g->hi % TY == 0 && g->wi % 16 == 0)) return false;
@@ -511,8 +511,8 @@ static bool wg_tiled_applicable(const RtpConvGeom* g) {
 
 static int wg_tiled_wgs(const RtpConvGeom* g) {
   const int tiles = (g->di / TZ) * (g->hi / TY) * ((g->wi + TX - 1) / TX);
-  static const int total_wgs = getenv("RTP_WGRAD_TILED_WGS") ? atoi(getenv("RTP_WGRAD_TILED_WGS")) : 256;  // experiments: fewer slabs / CUs left to other streams
-  static const int small_wgs = getenv("RTP_WGRAD_WGS_SMALL") ? atoi(getenv("RTP_WGRAD_WGS_SMALL")) : 128;   // (conv_tiled.hip: narrow launches for the lower levels)
+  static const int total_wgs = 256;   // (a launch's own width: RtpConvGeom::wgs)
+  static const int small_wgs = 128;   // (conv_tiled.hip: narrow launches for the lower levels)
   int wgs = ((small_wgs > 0 && (long)tiles * g->n < 2048) ? small_wgs : total_wgs) / g->n;
   if (g->wgs > 0) wgs = (g->wgs > 256 ? 256 : g->wgs) / g->n;   // RtpConvGeom::wgs: launch width = number of slabs (conv_tiled.hip)
   if (wgs < 1) wgs = 1;
@@ -558,7 +558,11 @@ int rtp_wgrad_tiled_try(const RtpAct* gy, const RtpAct* x, const RtpConvGeom* g,
   p.tiles_y = p.H / TY; p.tiles_x = (p.W + TX - 1) / TX; p.tiles_z = p.D / TZ;
   p.tiles_per_sample = (p.D / TZ) * p.tiles_y * p.tiles_x;
   p.wgs_per_sample = nsplit; p.part_stride = nsplit;
-  static const int dbg = getenv("RTP_TILED_DBG") ? atoi(getenv("RTP_TILED_DBG")) : 0;
+  #ifdef RTP_TILED_DBGFLAGS
+  static const int dbg = getenv("RTP_TILED_DBG") ? atoi(getenv("RTP_TILED_DBG")) : 0;   // (phase-skipping experiment builds only)
+#else
+  static const int dbg = 0;
+#endif
   p.dbg = dbg;
   p.wd = (const bf16_t*)wd; p.qpart = wd ? qpart : nullptr; p.tg = tg;
   const size_t shm_base = sizeof(bf16_t) * 2 * (size_t)(HALO_VOX + BRICK_VOX) * 32 + 32;

@@ -49,6 +49,19 @@ def _check(x, *others):
             raise NotImplementedError("rt_pose_amd.dcn: floating-point tensors only (got %s)" % t.dtype)
 
 
+def _conv_out(size, kernel, stride, padding, dilation):
+    """Output extent of one convolution axis."""
+    return (size + 2 * padding - dilation * (kernel - 1) - 1) // stride + 1
+
+
+def _uniform_fan_in_(weight, in_channels, kernel_size):
+    """U(-1/sqrt(fan), 1/sqrt(fan)) with fan = in_channels * prod(kernel) -- the reference's initialisation of both DeformConv and
+    ModulatedDeformConv weights (deform_conv.py:221-227, 355-363; note: in_channels, not in_channels / groups)."""
+    bound = 1.0 / math.sqrt(in_channels * math.prod(kernel_size))
+    with torch.no_grad():
+        weight.uniform_(-bound, bound)
+
+
 def _f32(t):
     """The kernels compute in fp32; half / bfloat16 / double tensors (the reference dispatches fp64/fp32/fp16,
     deform_conv_cuda_kernel.cu:259) are converted around the call and results returned in the caller's dtype."""
@@ -124,15 +137,13 @@ class DeformConvFunction(Function):
 
     @staticmethod
     def _output_size(input, weight, padding, dilation, stride):
-        channels = weight.size(0)
-        output_size = (input.size(0), channels)
-        for d in range(input.dim() - 2):
-            in_size = input.size(d + 2)
-            kernel = dilation[d] * (weight.size(d + 2) - 1) + 1
-            output_size += ((in_size + (2 * padding[d]) - kernel) // stride[d] + 1,)
-        if not all(map(lambda s: s > 0, output_size)):
-            raise ValueError("convolution input is too small (output would be {})".format("x".join(map(str, output_size))))
-        return output_size
+        """(N, Cout, Ho, Wo) of the convolution (deform_conv.py:97-112); ValueError when a spatial size would not be positive."""
+        spatial = tuple(_conv_out(input.shape[2 + i], weight.shape[2 + i], stride[i], padding[i], dilation[i])
+                        for i in range(input.dim() - 2))
+        if min(spatial, default=1) <= 0:
+            raise ValueError("convolution input is too small (output would be %s)"
+                             % "x".join(str(v) for v in (input.shape[0], weight.shape[0]) + spatial))
+        return (input.shape[0], weight.shape[0]) + spatial
 
 
 class ModulatedDeformConvFunction(Function):
@@ -190,12 +201,9 @@ class ModulatedDeformConvFunction(Function):
 
     @staticmethod
     def _infer_shape(ctx, input, weight):
-        n, channels_out = input.size(0), weight.size(0)
-        height, width = input.shape[2:4]
-        kernel_h, kernel_w = weight.shape[2:4]
-        height_out = (height + 2 * ctx.padding - (ctx.dilation * (kernel_h - 1) + 1)) // ctx.stride + 1
-        width_out = (width + 2 * ctx.padding - (ctx.dilation * (kernel_w - 1) + 1)) // ctx.stride + 1
-        return n, channels_out, height_out, width_out
+        """(N, Cout, Ho, Wo) for the scalar stride / padding / dilation this function takes (deform_conv.py:176-189)."""
+        ho, wo = (_conv_out(input.shape[2 + i], weight.shape[2 + i], ctx.stride, ctx.padding, ctx.dilation) for i in (0, 1))
+        return input.shape[0], weight.shape[0], ho, wo
 
 
 deform_conv = DeformConvFunction.apply
@@ -218,22 +226,18 @@ class DeformConv(nn.Module):
         self.reset_parameters()
 
     def reset_parameters(self):
-        n = self.in_channels
-        for k in self.kernel_size:
-            n *= k
-        stdv = 1.0 / math.sqrt(n)
-        self.weight.data.uniform_(-stdv, stdv)
+        _uniform_fan_in_(self.weight, self.in_channels, self.kernel_size)
 
     def forward(self, x, offset):
-        input_pad = x.size(2) < self.kernel_size[0] or x.size(3) < self.kernel_size[1]
-        if input_pad:  # deform_conv.py:230-238
-            pad_h = max(self.kernel_size[0] - x.size(2), 0)
-            pad_w = max(self.kernel_size[1] - x.size(3), 0)
-            x = F.pad(x, (0, pad_w, 0, pad_h), "constant", 0).contiguous()
-            offset = F.pad(offset, (0, pad_w, 0, pad_h), "constant", 0).contiguous()
+        # an input smaller than the kernel is zero-padded up to it (bottom / right), the offsets likewise, and the output cropped
+        # back by the same amounts (deform_conv.py:230-247)
+        grow = [max(k - s, 0) for k, s in zip(self.kernel_size, x.shape[2:4])]
+        if any(grow):
+            x = F.pad(x, (0, grow[1], 0, grow[0])).contiguous()
+            offset = F.pad(offset, (0, grow[1], 0, grow[0])).contiguous()
         out = deform_conv(x, offset, self.weight, self.stride, self.padding, self.dilation, self.groups, self.deformable_groups)
-        if input_pad:
-            out = out[:, :, :out.size(2) - pad_h, :out.size(3) - pad_w].contiguous()
+        if any(grow):
+            out = out[:, :, :out.shape[2] - grow[0], :out.shape[3] - grow[1]].contiguous()
         return out
 
 
@@ -248,8 +252,8 @@ class DeformConvPack(DeformConv):
         self.conv_offset.bias.data.zero_()
 
     def forward(self, x):
-        offset = self.conv_offset(x)
-        return deform_conv(x, offset, self.weight, self.stride, self.padding, self.dilation, self.groups, self.deformable_groups)
+        return deform_conv(x, self.conv_offset(x), self.weight, self.stride, self.padding, self.dilation, self.groups,
+                           self.deformable_groups)
 
     def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
         """Checkpoints written before version 2 name the offset conv '<name>_offset.*' instead of '<name>.conv_offset.*'
@@ -277,13 +281,12 @@ class ModulatedDeformConv(nn.Module):
             self.bias = nn.Parameter(torch.Tensor(out_channels))
         else:
             self.register_parameter("bias", None)
-        n = self.in_channels
-        for k in self.kernel_size:
-            n *= k
-        stdv = 1.0 / math.sqrt(n)
-        self.weight.data.uniform_(-stdv, stdv)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        _uniform_fan_in_(self.weight, self.in_channels, self.kernel_size)
         if self.bias is not None:
-            self.bias.data.zero_()
+            nn.init.zeros_(self.bias)
 
     def forward(self, x, offset, mask):
         return modulated_deform_conv(x, offset, mask, self.weight, self.bias, self.stride, self.padding, self.dilation,
@@ -301,12 +304,12 @@ class ModulatedDeformConvPack(ModulatedDeformConv):
         self.conv_offset.bias.data.zero_()
 
     def forward(self, x):
-        out = self.conv_offset(x)
-        o1, o2, mask = torch.chunk(out, 3, dim=1)
-        offset = torch.cat((o1, o2), dim=1)
-        mask = torch.sigmoid(mask)
-        return modulated_deform_conv(x, offset, mask, self.weight, self.bias, self.stride, self.padding, self.dilation,
-                                     self.groups, self.deformable_groups)
+        # conv_offset's 3 * dg * kh * kw channels: the first two thirds are the offsets (in place, the channel order the operator
+        # expects), the last third the modulation logits (deform_conv.py:409-416)
+        raw = self.conv_offset(x)
+        k = 2 * raw.shape[1] // 3
+        return modulated_deform_conv(x, raw[:, :k].contiguous(), raw[:, k:].sigmoid(), self.weight, self.bias, self.stride,
+                                     self.padding, self.dilation, self.groups, self.deformable_groups)
 
     def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
         """Checkpoints written before version 2 name the offset conv '<name>_offset.*' instead of '<name>.conv_offset.*'

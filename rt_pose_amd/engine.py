@@ -85,7 +85,7 @@ class FlatParams:
 # 91 us against 78 on 256), so leaving 64 CUs free costs them 5 % and lets the chains run BESIDE them: 5.77-5.88 -> 5.62-5.66 ms per
 # step (-2.5 ... -3.5 %, five same-box pairs).  Forward convs and weight gradients of the full-resolution branch in stages 2-4, the
 # conv3 data gradients of stages 3-4; data gradients elsewhere, 208 / 176 / 160 workgroups, the head and layer1: no better or worse.
-# Results do not change (include/rtp.h: RtpConvGeom::wgs).  RTP_WIDTH_HINTS="" switches them off, any other value replaces them.
+# Results do not change (include/rtp.h: RtpConvGeom::wgs).  PlanOptions.width_hints = "" switches them off, any other value replaces them.
 # The width is an explicit field of each launch's geometry, fixed when the plan is built (graph.Graph.with_width).
 DEFAULT_WIDTH_HINTS = ";".join(["conv:s%d.b0=192" % s for s in (2, 3, 4)] + ["wgrad:s%d.b0=192" % s for s in (2, 3, 4)]
                                + ["dgrad:s4.b0.c3=192", "dgrad:s3.b0.c3=192"])
@@ -93,14 +93,15 @@ DEFAULT_WIDTH_HINTS = ";".join(["conv:s%d.b0=192" % s for s in (2, 3, 4)] + ["wg
 
 def parse_width_hints(spec):
     """"tag-prefix=workgroups;..." (e.g. "conv:s3.b0=192;wgrad:s4.b0=208") -> [(prefix, workgroups)] in order (first match wins)."""
-    return [(k.strip(), int(v)) for k, v in (item.split("=") for item in (spec or "").split(";") if "=" in item) if int(v) > 0]
+    items = (spec or "").replace(",", ";").split(";")   # (',' inside RTP_PLAN, whose own separator is ';')
+    return [(k.strip(), int(v)) for k, v in (item.rsplit("=", 1) for item in items if "=" in item) if int(v) > 0]
 
 
 class PoseEngine:
     """HRRadarPose for a fixed (batch, Cin, dims): buffers + launch lists built once, replayed every step."""
 
     def __init__(self, backend, params, arch, final_fuse, heads, loss_weight, code_weights, batch, dims, train=True,
-                 pgrads=None, test_cfg=None, max_objs=None, lidar_channels=0, early_flush=False, feature_channels=None):
+                 pgrads=None, test_cfg=None, max_objs=None, lidar_channels=0, early_flush=False, feature_channels=None, options=None):
         """feature_channels=C: a plan of the HEAD alone (CenterHead used without RadarPoseNet, center_head.py:232-270): the input is a
         feature [B, C, Z, Y, X] fp32 (load_features); in training mode the backward list ends with the feature's gradient, unpacked
         into feat_grad [B, C, Z, Y, X] fp32.  `arch` / `final_fuse` are not used then."""
@@ -112,10 +113,11 @@ class PoseEngine:
         be = backend
         # width hints: a launch's wgs / batch workgroups per sample, whatever the batch.  Measured (round 5, same box, hr3d, four-stream
         # map): B = 8 5.44 -> 5.26 ms per step, B = 16 9.44 -> 9.28 (1 694 -> 1 723 frames/s), B = 4 3.69 -> 3.56 (1 083 -> 1 123)
-        rules = parse_width_hints(os.environ.get("RTP_WIDTH_HINTS", DEFAULT_WIDTH_HINTS))
-        g = self.graph = Graph(be, batch, params, train=train, pgrads=pgrads, width_rules=rules)
-        # two gradient buckets (trainer): one early flush of the deferred tail; RTP_EARLY_TAIL=1: the same flush in single-bucket mode (A/B)
-        g.early_flush = bool(early_flush) or os.environ.get("RTP_EARLY_TAIL", "0") == "1"
+        from .options import PlanOptions
+        opt = self.options = options if options is not None else PlanOptions.from_env()
+        rules = parse_width_hints(DEFAULT_WIDTH_HINTS if opt.width_hints is None else opt.width_hints)
+        g = self.graph = Graph(be, batch, params, train=train, pgrads=pgrads, width_rules=rules, options=opt)
+        g.early_flush = bool(early_flush)   # two gradient buckets (trainer): one early flush of the deferred tail
         self.feat_in = self.feat_grad = None
         if feature_channels is None:
             self.x_in = g.input_f32("rdr", cin, dims)
@@ -137,8 +139,8 @@ class PoseEngine:
         self.fwd = list(g.forward_list())
         # the main lane's fuse-row feeders (the 1x1x1 convs of row 0) ahead of the other rows' chains on their FIFO lanes: neutral on hr3d
         # (5.608 -> 5.595 ms, the wait moves from fuse:s3.row0 to fuse:s4.row0), -0.6 % on the configs whose stage 4 keeps every row
-        # (hr3d_one_hm_doppler 10.43 -> 10.36); RTP_FWD_ROW0_FIRST=0: creation order
-        if os.environ.get("RTP_FWD_ROW0_FIRST", "1") == "1":
+        # (hr3d_one_hm_doppler 10.43 -> 10.36); options.fwd_row0_first = 0: creation order
+        if opt.fwd_row0_first:
             from .lanes import main_row_first
             self.fwd = main_row_first(self.fwd)
         self.merged = []   # (tag_a, tag_b) whose algorithmic cost was re-accounted to a's kernel family (none in the default plan)
@@ -149,8 +151,8 @@ class PoseEngine:
         # pairs) with five pairs merged -- conv .0 / .2, dgrad .2, wgrad .0 / .2; dgrad:head.reg.0 adds dgrad:head.hm.0's result in
         # its epilogue and stays behind it.  (Merging a side lane's level-1 convs INTO the main lane's full-resolution launches of the same
         # position -- round 4's RTP_MERGE -- measured 0.7-1 % slower in lane mode: work moved onto the critical path; removed.)
-        # Any batch whose samples tile the chip's 256 workgroups (rtp_multi_end: n divides 256).  RTP_MERGE_HEAD=0: off.
-        self._merge_head = os.environ.get("RTP_MERGE_HEAD", "1") == "1" and hasattr(be, "multi") and 256 % batch == 0
+        # Any batch whose samples tile the chip's 256 workgroups (rtp_multi_end: n divides 256).  options.merge_head = 0: off.
+        self._merge_head = bool(opt.merge_head) and hasattr(be, "multi") and 256 % batch == 0
         self.merged_head = []
         if self._merge_head:
             from .lanes import merge_launches
@@ -161,7 +163,7 @@ class PoseEngine:
         from .graph import SplitConvOp, CoSplitConvOp
         sliced_head = any(isinstance(op, (SplitConvOp, CoSplitConvOp)) for op in g.ops)
         # (any batch: B = 4 / 16 measured like B = 8 -- 3.83 -> 3.69 and 9.51 -> 9.44 ms per step for the map alone, round 5)
-        self.lane_map = LANE_MAP if ("RTP_LANES" in os.environ or sliced_head) else LANE_MAP_4
+        self.lane_map = opt.int_list("lanes") if opt.lanes is not None else (LANE_MAP if sliced_head else LANE_MAP_4)
         self.fwd_plan = LanePlan(be, self.fwd, self.lane_map)
         self.bwd_plan = None
         self.use_lanes = True      # False: replay everything on the caller's stream in list order
@@ -197,9 +199,8 @@ class PoseEngine:
             # loss kernel clears the voxels it wrote last time (state: reg_prev; the buffer starts zeroed, nothing else writes it)
             self.reg_prev = be.alloc((batch, self.m), "i64")
             self.reg_prev.fill_(-1)
-            dense = bool(os.environ.get("RTP_REG_DENSE"))   # A/B: zero fill every step
             rl = be.reg_loss(reg, self.tgt_pose, self.tgt_ind, self.tgt_mask, self.code_w, self.nreg, self.loss_weight,
-                             self.loss_reg, self.greg, None if dense else self.reg_prev)
+                             self.loss_reg, self.greg, self.reg_prev)
             self.loss_launches.append(rl)
             g.seed_grad(hm, self.ghm)
             g.seed_grad(reg, self.greg)
@@ -213,15 +214,15 @@ class PoseEngine:
                     g.emit_bwd(be.unpack_ncdhw(gf, self.feat_grad, feature_channels), g.lane_of(self.feats), [gf], [self.feat_grad],
                                "unpack:feats.grad")
             self.bwd = list(g.bwd)
-            if os.environ.get("RTP_BWD_F10_FIRST", "1") == "1":
+            if opt.bwd_f10_first:
                 # stage 3's row-1 stride-2 data gradient (level-1 lane) is issued ahead of the row-2 chain it does not depend on:
                 # the main lane's fan-in `combine:s3.b0.c3` waits for both, and the level-1 lane used to start this one only after
-                # the level-2 lane's chain had arrived (-1 % on the step; RTP_BWD_F10_FIRST=0: creation order)
+                # the level-2 lane's chain had arrived (-1 % on the step; options.bwd_f10_first = 0: creation order)
                 from .lanes import hoist_tagged
                 self.bwd = hoist_tagged(self.bwd, r":s3\.f10\.0$", r":s3\.(row2|f2)")
-            if os.environ.get("RTP_BWD_SINK_WG", "1") == "1" and self.lane_map is LANE_MAP_4:
+            if opt.bwd_sink_wg and self.lane_map is LANE_MAP_4:
                 # the lower levels' weight gradients behind the other launches of their stage (they share a stream with the level-3
-                # chain under the four-stream map: lanes.sink_lane_in_segments); RTP_BWD_SINK_WG=0: creation order
+                # chain under the four-stream map: lanes.sink_lane_in_segments); options.bwd_sink_wg = 0: creation order
                 from .lanes import sink_lane_in_segments, L_WG_LOW
                 self.bwd = sink_lane_in_segments(self.bwd, L_WG_LOW, r"^combine:s\d\.b0\.c3$")
             if self._merge_head:

@@ -127,7 +127,7 @@ def wgrad_split(vox):
 
 
 class Graph:
-    def __init__(self, backend, n, params, train=True, pgrads=None, width_rules=()):
+    def __init__(self, backend, n, params, train=True, pgrads=None, width_rules=(), options=None):
         """params: dict name -> fp32 tensor (reference state_dict names/shapes).
         pgrads: optional dict name -> fp32 tensor the backward plan writes parameter gradients into
         (views of a flat buffer); allocated per parameter when absent.
@@ -145,17 +145,19 @@ class Graph:
         self.used_params = []      # creation order
         self.bytes = 0
         self.tail_a, self.tail_b = [], []   # deferred optimiser-only items (emit_tail)
-        import os
+        from .options import PlanOptions
+        self.opt = options if options is not None else PlanOptions.from_env()
         # (folds are flushed once, at the end of the sweep: earlier, smaller flushes on the weight-gradient lane measured the same,
         # 1 158-1 170 frames/s for 12 / 20 / all in round 1)
-        self._defer_wg = [int(v) for v in os.environ.get("RTP_DEFER_WG", "3").split(",") if v.strip() != ""]
-        self._defer_keep = int(os.environ.get("RTP_DEFER_KEEP", "0"))   # (round 5: 0 -- all of them in front of the SECOND fan-in, where the main lane waits longest: 5.22 -> 5.17 ms, two same-box pairs; was 4)
+        # Launches of these lanes (default: the full-resolution weight-gradient lane) are queued onto the MAIN lane in front of its
+        # fan-ins; all of them in front of the SECOND fan-in, where the main lane waits longest (round 5: 5.22 -> 5.17 ms)
+        self._defer_wg = self.opt.int_list("defer_wg")
+        self._defer_keep = 0
         # at most this many launches move (the two 32-channel head towers of hr3d: 8; the wide heads of the one-heat-map configs
         # queue 20+ launches there, more than the waits absorb: measured 11.20 ms/step without the move, 11.45 with all of it)
-        self._defer_max, self._ndeferred = int(os.environ.get("RTP_DEFER_MAX", "8")), 0
-        self._defer_tags = tuple(v for v in os.environ.get("RTP_DEFER_TAGS", "").split(",") if v)
+        self._defer_max, self._ndeferred = 8, 0
         # (the stem's weight gradient is the sweep's last launch: nothing left to wait for, it stays beside the tail on its lane)
-        self._defer_skip = set(v for v in os.environ.get("RTP_DEFER_SKIP", "stem_bwd").split(",") if v)
+        self._defer_skip = {"stem_bwd"}
         self._deferred = []
         self.head, self._head_emitted = [], False   # activation-independent weight packing (forward_list)
         self._lazy_by_coeff = {}   # coefficient tensor -> its LazyCoeff (an early tail flush has to materialise pending ones)
@@ -201,11 +203,11 @@ class Graph:
         level-1 lane queues row 0's up-sampling adjoint -- which waits for the main lane's newest gradient -- in FRONT of the
         stride-2 data gradients of rows 1 and 2, whose inputs are long finished and whose outputs the main lane needs next
         (head-of-line blocking at every stage boundary).  Rows of a block only meet at the branch outputs they all contribute
-        to, so any row order is a valid reverse-topological order.  RTP_ROW_ORDER=0 restores plain reverse creation order."""
+        to, so any row order is a valid reverse-topological order."""
         rev = list(reversed(self.ops))
-        # (RTP_FUSED_S2, the A/B route where a row's stride-2 data gradient absorbs the fan-in of the branch-0 output, needs that
-        # conv to be the last contributor: plain reverse creation order)
-        if os.environ.get("RTP_ROW_ORDER", "1") == "0" or os.environ.get("RTP_FUSED_S2"):
+        # (options.fused_s2, the A/B route where a row's stride-2 data gradient absorbs the fan-in of the branch-0 output, needs
+        # that conv to be the last contributor: plain reverse creation order)
+        if self.opt.fused_s2:
             return rev
         out, i = [], 0
         while i < len(rev):
@@ -252,8 +254,7 @@ class Graph:
         # only time-share the CUs and stretch the critical chain -- but are queued and issued ON the main lane where it is about
         # to wait for the side lanes anyway: in front of the second fan-in of a full-resolution block output (RTP_DEFER_WG="3"
         # default, "" = off; only lanes whose results nothing but the tail reads may be listed: measured 6.30 -> 6.22 ms/step)
-        if (((self._defer_wg and lane in self._defer_wg) or (self._defer_tags and tag.startswith(self._defer_tags)))
-                and tag not in self._defer_skip and self._ndeferred < self._defer_max):
+        if self._defer_wg and lane in self._defer_wg and tag not in self._defer_skip and self._ndeferred < self._defer_max:
             self._ndeferred += 1
             self._deferred.append(Launch(fn, L_FULL, reads, writes, tag))
             return
@@ -315,8 +316,7 @@ class Graph:
         op = StemOp(self, x_f32, y, wname, bname)
         y.producer = op
         self._add_op(op)
-        import os
-        S = self.be.stem_stats_nsplit(self.n, y.c, y.vox) if (hasattr(self.be, "stem_fwd_stats") and not os.environ.get("RTP_NO_STEM_STATS")) else 0
+        S = self.be.stem_stats_nsplit(self.n, y.c, y.vox) if hasattr(self.be, "stem_fwd_stats") else 0
         if S > 0:   # the statistics the block's first GroupNorm needs, as the stem's epilogue: no rtp_chan_stats pass over its output
             y.stats_split = S
             y.stats = self.be.alloc((self.n, S, y.c, 2), "f32")
@@ -381,9 +381,8 @@ class Graph:
         of the one-heat-map configs (center_head.py:86-93) -- sharing their launches: forward and data gradient run 64 wide on
         csrc/conv64_tiled.hip (one launch per 64-channel slice of x instead of two per 32-channel slice), and x receives ONE gradient
         tensor, the sum over both towers.  -> [Act, Act], or None when the pair cannot share (the caller then builds them one by one)."""
-        import os
         be = self.be
-        if not hasattr(be, "conv64_blocks") or os.environ.get("RTP_PAIR_HEADS", "1") == "0":
+        if not hasattr(be, "conv64_blocks") or not self.opt.pair_heads:
             return None
         ws = [self.param(n) for n in wnames]
         ci_real = ws[0].shape[1]
@@ -434,8 +433,7 @@ class Graph:
         y.producer = op
         self._add_op(op)
         # a fuse row feeds GroupNorm convs of the next stage: it emits the statistics of what it stores (no chan_stats pass)
-        S = self.be.fuse_stats_nsplit(y) if (want_stats and hasattr(self.be, "fuse_stats_nsplit")
-                                            and not os.environ.get("RTP_NO_FUSE_STATS")) else 0
+        S = self.be.fuse_stats_nsplit(y) if (want_stats and hasattr(self.be, "fuse_stats_nsplit") and self.opt.fuse_stats) else 0
         st = None
         if S > 0:
             y.stats_split = S
@@ -479,14 +477,15 @@ class Graph:
         self._add_op(op)
         op.fwd_fn, op.make_bwd = self.be.dcn_adapt(x, off, off.c_real, w_ad, y)
         # The two feature adaptions (heat-map / regression) are independent and their operator's kernels are ordinary grids, not
-        # chip-filling persistent ones: the regression one runs on the level-1 lane beside the heat-map one's (RTP_DCN_ONE_LANE=1:
-        # both on the main lane, A/B)
-        op.lane = L_MID if (name.endswith(".reg") and not os.environ.get("RTP_DCN_ONE_LANE")) else self.lane_of(y)
+        # chip-filling persistent ones: the regression one runs on the level-1 lane beside the heat-map one's
+        op.lane = L_MID if name.endswith(".reg") else self.lane_of(y)
         self.emit_fwd(op.fwd_fn, op.lane, [x, off, w_ad], [y], "dcn:" + name)
-        if self.train and hasattr(op.make_bwd, "prep") and not os.environ.get("RTP_DCN_PREP_IN_BWD"):
+        if self.train and hasattr(op.make_bwd, "prep"):
             # the forward runs on the plan's layout (rtp_dcn_cl_forward); the fp32 planes the BACKWARD operator reads are unpacked by a
             # launch of their own on a lane that idles while the head runs, instead of in front of the backward operator
-            self.emit_fwd(op.make_bwd.prep(), L_WG_LOW, [x, off], [], "dcnprep:" + name)
+            # (the planes are plan-tracked buffers: written here, read by the backward operator's launch -- the lane planner and
+            # the reorder passes see the dependency instead of relying on the forward plan's final join)
+            self.emit_fwd(op.make_bwd.prep(), L_WG_LOW, [x, off], list(getattr(op.make_bwd, "planes", ())), "dcnprep:" + name)
         return y
 
     def forward_list(self):
@@ -525,7 +524,7 @@ class Graph:
                 chunk = [(t.grad, None)] + chunk
             last = not terms
             cls = None
-            can_lazy = hasattr(self.be, "grad_combine_lazy_ok") and not os.environ.get("RTP_NO_LAZY_COEF")
+            can_lazy = hasattr(self.be, "grad_combine_lazy_ok") and bool(self.opt.lazy_coef)
             pending = can_lazy and any(isinstance(cf, LazyCoeff) and not cf.done for _, cf in chunk)
             # the class-sum variant of the combine also when nobody wants the sums but a term's coefficients are still to be
             # computed: its prologue does that (per-sample blocks), which is cheaper than a coefficient launch in the chain
@@ -589,26 +588,6 @@ class Graph:
                 self.tail_a.append(("class_reduce", scratch, split, self.n, gy.c, csum))
         return csum
 
-    def class_sums_and_p(self, y: Act, gy: View, lane, name, wd, geom, ci_real, co_real):
-        """class_sums_for(early=True) plus P = sum dxhat of the GroupNorm backward of the conv whose output gradient gy is, as
-        ONE launch on `lane`: -> (csum [n][64][c], P [n][ci])."""
-        be = self.be
-        csum = be.alloc((self.n, 64, gy.c), "f32")
-        pbuf = be.alloc((self.n, geom.ci), "f32")
-        if y.grad is gy and y.grad_cls is not None:      # partials from the grad_combine pass: reduce + P
-            split, scratch = y.grad_cls
-            self.emit_bwd(be.gn_bwd_p(scratch, split, csum, wd, geom, ci_real, co_real, pbuf), lane, [scratch, wd], [csum, pbuf],
-                          "clsp:" + name)
-            return csum, pbuf
-        tot, tsplit = None, 0
-        if y.grad is gy and y.grad_tot is not None:      # totals from the fused data gradient: boundary-only scan
-            tsplit, tot = y.grad_tot
-        split = min(32, cls_split(gy.d, gy.h))
-        scratch = be.alloc((self.n, split, 64, gy.c), "f32")
-        self.emit_bwd(be.class_sums_p(gy, split, scratch, tot, tsplit, csum, wd, geom, ci_real, co_real, pbuf), lane,
-                      [gy, tot, wd], [scratch, csum, pbuf], ("clsbp:" if tot is not None else "clsp:") + name)
-        return csum, pbuf
-
     def build_backward(self):
         assert self.train
         import os
@@ -616,14 +595,14 @@ class Graph:
         # if that consumer is a conv whose data gradient runs on the LDS-tiled kernel, its epilogue absorbs the fan-in
         # (all other contributions + GroupNorm backward + ReLU mask) and writes the finished gradient (ConvOp.emit_backward).
         self.first_consumer = {}
-        self.fused_dgrad = not os.environ.get("RTP_NO_FUSED_DGRAD") and hasattr(self.be, "conv_dgrad_fused")
+        self.fused_dgrad = hasattr(self.be, "conv_dgrad_fused")
         order = self.sweep_order()
         for op in order:   # ("first consumer" = the consumer the sweep reaches LAST: its contribution completes the tensor's gradient)
             for t in op.inputs():
                 self.first_consumer[id(t)] = op
         # (the move of the weight-gradient lane onto the main lane pays for the two 32-channel towers of hr3d; the wide heads of
         # the one-heat-map configs -- slice ops -- queue more work there than the waits absorb: 11.3 vs 11.5 ms/step, so not by default)
-        if "RTP_DEFER_WG" not in os.environ and any(isinstance(op, (SplitConvOp, CoSplitConvOp)) for op in self.ops):
+        if self.opt.defer_wg == "3" and any(isinstance(op, (SplitConvOp, CoSplitConvOp)) for op in self.ops):   # (the default only)
             self._defer_wg = []
         for op in order:
             if self.early_flush and self.early_tail_index is None and op.y.name.startswith(("l1.", "t1", "s2.")):
@@ -656,7 +635,7 @@ class Graph:
         a, b = self.tail_a, self.tail_b
         self.tail_a, self.tail_b = [], []
         stages = [a, b]
-        if os.environ.get("RTP_NO_TAIL"):   # A/B: one launch per item, like a per-layer plan
+        if self.opt.no_tail:   # A/B: one launch per item, like a per-layer plan
             stages = [[it] for it in a] + [[it] for it in b]
         for items in stages:
             if not items:
@@ -708,11 +687,11 @@ class ConvOp:
             nw = 1
         self.groups = GROUPS if self.ci_real >= GROUPS else 1
         # A GroupNorm conv on the LDS-tiled kernel folds the norm in the kernel's own prologue (rtp_conv_gn_fused): no fold launch
-        # between two convs of a chain, no per-sample weight / bias-table buffers (RTP_NO_FUSED_FOLD: the separate launch, A/B)
+        # between two convs of a chain, no per-sample weight / bias-table buffers (options.fused_fold = 0: the separate launch, A/B)
         self.fold_fused = bool(self.gn and not self.out_fp32 and ge.ks == 3 and ge.stride == 1 and ge.pad == 1 and ge.ci == 32
                                and self.ci_real == 32 and ge.co in (16, 32) and self.x.cs == 32 and self.x.co == 0
                                and ge.di % 2 == 0 and ge.hi % 4 == 0 and ge.wi % 16 == 0 and not ge.w_ci_total
-                               and hasattr(be, "conv_gn_fused") and not __import__("os").environ.get("RTP_NO_FUSED_FOLD"))
+                               and hasattr(be, "conv_gn_fused") and bool(g.opt.fused_fold))
         self.wf = None if self.fold_fused else be.alloc((nw, ntap, ge.co, ge.ci), "bf16")
         need_btab = (bool(self.gn) or bias is not None) and not self.fold_fused
         self.btab = be.alloc((nw, 64, ge.co), "f32") if need_btab else None
@@ -774,7 +753,7 @@ class ConvOp:
         # the output's size
         self.s2_bwd = (ge.ks == 3 and ge.stride == 2 and ge.ci == 32 and pad_to(ge.co, 32) == 32 and ge.di == 2 * ge.do
                        and ge.hi == 2 * ge.ho and ge.wi == 2 * ge.wo and ge.ho % 2 == 0 and ge.wo % 16 == 0
-                       and not __import__("os").environ.get("RTP_DISABLE_S2_TILED"))
+)
         # (the 64 -> 64 stride-1 layers the sliced route hands to csrc/conv64_tiled.hip are a kernel family of their own)
         self.c64 = ge.ks == 3 and ge.stride == 1 and ge.ci == 64 and ge.co == 64
         fam_f = "conv64" if (self.sliced_fwd and self.c64) else "conv_tiled" if self.tiled_fwd else "conv_generic"
@@ -883,7 +862,7 @@ class ConvOp:
         """Subset-sum buffer for rtp_wgrad_tg when this conv qualifies (bias, no GroupNorm, 32 -> <= 32 channels, stride 1, tiled)."""
         g, be, ge = self.g, self.g.be, self.geom
         if (self.gn or not self.bname or not hasattr(be, "wgrad_tg") or ge.ci != 32 or pad_to(ge.co, 32) != 32 or ge.stride != 1
-                or ge.ks != 3 or self.x.cs != 32 or self.x.co != 0 or os.environ.get("RTP_NO_BIAS_TG")):
+                or ge.ks != 3 or self.x.cs != 32 or self.x.co != 0):
             return None
         return be.alloc((g.n, S, 27, 32), "f32")
 
@@ -897,7 +876,7 @@ class ConvOp:
         # sums) is built and tested but OFF by default: measured 6.41 ms/step against 6.31 with the same kernel writing dxhat +
         # statistics and the fan-in pass kept (the slab contraction and the early class sums cost more than the two passes
         # they remove), and P inherits the LDS-atomic order of the class-sum scan (1e-6 instead of 1e-9 run to run).
-        s2 = self.s2_bwd and bool(__import__("os").environ.get("RTP_FUSED_S2"))
+        s2 = self.s2_bwd and bool(g.opt.fused_s2)
         if not (g.fused_dgrad and (self.tiled_bwd or s2) and x.needs_grad and g.first_consumer.get(id(x)) is self):
             return False
         if self.residual is x or x.c != 32 or x.cs != 32 or x.co != 0 or gy.c < 32:
@@ -921,25 +900,23 @@ class ConvOp:
         co32 = pad_to(ge.co, 32)
         assert gy.c == co32, (self.name, gy.c, co32)
         ntap = ge.ks ** 3
-        # ---- per-boundary-class sums of gy: bias / un-fold need them, and now P does too
-        import os
-        own_kernel = bool(os.environ.get("RTP_GNCOEF_KERNEL"))   # A/B: coefficients by a kernel of their own on the main chain
-        # default: the weight-gradient kernel's loader waves sum gy over the volume / faces / edges / corners (tg), from which
-        # the data gradient's prologue derives P and the class sums -- no pass over gy, no launch between the two kernels
-        from_wgrad = bool(self.gn) and not own_kernel and not os.environ.get("RTP_CLS_KERNELS") and ge.stride == 1
-        csum = pbuf = tg = None
+        # ---- per-boundary-class sums of gy: bias / un-fold need them, and now P does too.
+        # A stride-1 GroupNorm conv: the weight-gradient kernel's loader waves sum gy over the volume / faces / edges / corners
+        # (tg), from which the data gradient's prologue derives P and the class sums -- no pass over gy, no launch between the
+        # two kernels.  (Rounds 2-3 kept two intermediate routes for A/B -- coefficients by a kernel of their own, class sums + P by
+        # a scan kernel -- both slower on the main chain; removed in round 6 with their switches.)
+        from_wgrad = bool(self.gn) and ge.stride == 1
+        csum = tg = None
         if ge.stride == 2:
             csum = g.class_sums_for(self.y, gy, wl, self.name, early=True) if (self.gn or self.bname) else None
         elif from_wgrad:
             tg = be.alloc((g.n, be.wgrad_nsplit(g.with_width(ge, "wgrad:" + self.name)), 27, 32), "f32")   # one partial table per weight-gradient slab
             csum = be.alloc((g.n, 64, gy.c), "f32")
-        elif self.gn and not own_kernel and hasattr(be, "class_sums_p"):
-            csum, pbuf = g.class_sums_and_p(self.y, gy, wl, self.name, self.wd, ge, self.ci_real, self.co_real)
         S = be.wgrad_nsplit(g.with_width(ge, "wgrad:" + self.name)) if x.cs == 32 and x.co == 0 else 0
         self.tiled_wgrad = S > 0
         S = S or wgrad_split(gy.vox)
         btg = self._bias_tg(S) if (self.tiled_wgrad and not self.gn and ge.stride == 1) else None
-        if csum is None and pbuf is None and tg is None and (self.gn or self.bname) and btg is None:
+        if csum is None and tg is None and (self.gn or self.bname) and btg is None:
             csum = g.class_sums_for(self.y, gy, wl, self.name, early=bool(self.gn))
         # ---- weight gradient (for a GroupNorm conv it now precedes the data gradient: its slabs give Q)
         gp = be.alloc((g.n, S, ntap, co32, ge.ci), "f32")
@@ -960,18 +937,9 @@ class ConvOp:
             qpart = be.alloc((g.n, S, ge.ci), "f32")
             g.emit_bwd(be.wgrad_q(gy, x, gw, S, gp, self.wd, qpart, tg), lane, [gy, x, self.wd], [gp, qpart, tg], "wgrad:" + self.name)
             coeff = be.alloc((g.n * ge.ci * 5,), "f32")
-            if own_kernel:
-                g.emit_bwd(be.gn_bwd_coeffs_cls(qpart, S, csum, 1, None, self.wd, self.mr, g.params[self.gn[0]], ge,
-                                                self.ci_real, self.co_real, self.groups, coeff),
-                           lane, [qpart, csum, self.wd, self.mr], [coeff], "gncoef:" + self.name)
-            else:
-                # P beside the weight gradient (side lane); Q and the coefficients in the data gradient's own prologue
-                if pbuf is None and tg is None:
-                    pbuf = be.alloc((g.n, ge.ci), "f32")
-                    g.emit_bwd(be.gn_bwd_p(csum, 1, None, self.wd, ge, self.ci_real, self.co_real, pbuf), wl, [csum, self.wd], [pbuf],
-                               "gnp:" + self.name)
-                gnq = dict(qpart=qpart, q_nsplit=S, p=pbuf, tg=tg, csum_out=csum if tg is not None else None, mr=self.mr,
-                           gamma=g.params[self.gn[0]], groups=self.groups, coeff_out=coeff)
+            # Q, P (from tg) and the coefficients in the data gradient's own prologue
+            gnq = dict(qpart=qpart, q_nsplit=S, p=None, tg=tg, csum_out=csum, mr=self.mr,
+                       gamma=g.params[self.gn[0]], groups=self.groups, coeff_out=coeff)
             g.tail_a.append(("gn_param", coeff, g.n, self.ci_real, g.pgrad[self.gn[0]], g.pgrad[self.gn[1]], 0))
         elif btg is not None:
             g.emit_bwd(be.wgrad_tg(gy, x, gw, S, gp, btg), wl, [gy, x], [gp, btg], "wgrad:" + self.name)
@@ -991,9 +959,7 @@ class ConvOp:
         reads = [gy, self.wd, x, coeff] + [v for v, _ in terms] + [cf for _, cf in terms]
         # x's producer will want the per-boundary-class sums of this gradient: emit the per-channel totals here
         tot, prod = None, x.producer
-        import os
-        prod_from_wgrad = (isinstance(prod, ConvOp) and prod.gn and prod.tiled_bwd and g.fused_dgrad
-                           and not os.environ.get("RTP_GNCOEF_KERNEL") and not os.environ.get("RTP_CLS_KERNELS"))
+        prod_from_wgrad = isinstance(prod, ConvOp) and prod.gn and prod.tiled_bwd and g.fused_dgrad
         if (isinstance(prod, (ConvOp, SplitConvOp)) and (prod.gn or prod.bname) and hasattr(be, "class_sums_boundary")
                 and not prod_from_wgrad):
             ts = be.conv_stats_nsplit(gy, g.with_width(ge, "dgrad:" + self.name), True)
@@ -1294,8 +1260,8 @@ class DcnAdaptOp:
         go_buf = g.be.alloc((g.n, x.d, x.h, x.w, oc), "bf16")
         go = View(go_buf, g.n, x.d, x.h, x.w, oc, 0, oc)
         gw = g.pgrad[self.prefix + ".conv_adaption.weight"]
-        g.emit_bwd(self.make_bwd(gy, gx, go, gw), getattr(self, "lane", g.lane_of(self.y)), [gy, x, off], [gx_buf, go_buf, gw],
-                   "dcn_bwd:" + self.name)
+        g.emit_bwd(self.make_bwd(gy, gx, go, gw), getattr(self, "lane", g.lane_of(self.y)),
+                   [gy, x, off] + list(getattr(self.make_bwd, "planes", ())), [gx_buf, go_buf, gw], "dcn_bwd:" + self.name)
         if x.needs_grad:
             x.contribs.append((gx, None))
         off.contribs.append((go, None))

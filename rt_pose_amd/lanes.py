@@ -13,10 +13,9 @@ serial order (vector clocks keep only the waits not already implied by stream or
 L_FULL, L_MID, L_LOW, L_WG, L_WG_LOW, L_LOW3 = 0, 1, 2, 3, 4, 5
 NLANES = 6
 # Lanes -> streams.  Measured on MI355X (hr3d, B=8, ms/step) with the main stream at high priority: one stream 8.9;
-# "0,1,1,2,2" 7.1; one stream per lane "0,1,2,3,4" 6.96 (default).  RTP_LANES overrides for experiments.
+# "0,1,1,2,2" 7.1; one stream per lane "0,1,2,3,4" 6.96.  PlanOptions.lanes overrides for experiments.
 import os
-LANE_MAP = [int(v) for v in os.environ.get("RTP_LANES", "0,1,2,3,4,5").split(",")]
-assert len(LANE_MAP) == NLANES and all(0 <= v < NLANES for v in LANE_MAP)
+LANE_MAP = [0, 1, 2, 3, 4, 5]
 # FOUR streams -- as many as HIP has hardware queues (rt_pose_amd.pin_hw_queues), so that no two streams share a queue and run each
 # other's launches in submission order: the lowest level's lane shares a stream with the lower levels' weight gradients, the full-
 # resolution weight-gradient lane (what is left of it once the head towers' launches are deferred onto the main lane: the stem's)
@@ -56,11 +55,6 @@ def plan_waits(launches, nlanes=NLANES, lane_of=None):
     """-> (waits, record): waits[i] = indices of earlier launches (on other lanes) launch i must wait for;
     record[j] = launch j's completion needs an event.  lane_of: optional list overriding each launch's lane."""
     lane_of = lane_of if lane_of is not None else [L.lane for L in launches]
-    # Gating (RTP_GATE="1,2,5"): a launch of lane 0 also waits for every launch of the gated lanes that precedes it in list order.
-    # The persistent full-resolution kernels own every CU while they run, so a side lane's chain of small kernels otherwise
-    # advances about one launch per big-kernel boundary; gated, the side chains run (concurrently with each other) in the
-    # window before the next big launch instead.
-    gated = [int(v) for v in os.environ.get("RTP_GATE", "").split(",") if v.strip() != ""]
     last_on = {}
     last_w, readers = {}, {}
     clock = [[-1] * nlanes for _ in range(nlanes)]  # clock[l][m]: newest launch on lane m known finished before lane l's next
@@ -78,10 +72,6 @@ def plan_waits(launches, nlanes=NLANES, lane_of=None):
                 deps.add(j)
             deps.update(readers.get(k, ()))
         lane = lane_of[i]
-        if lane == 0:
-            for m in gated:
-                if m in last_on:
-                    deps.add(last_on[m])
         last_on[lane] = i
         vc = clock[lane]
         need = {}
@@ -320,11 +310,6 @@ class LanePlan:
         self.lanes_used = sorted(set(self.lane_of))
         self.waits, self.record = plan_waits(self.launches, NLANES, self.lane_of)
         self._events = None
-        # Timing experiment only (results are wrong): RTP_EXP_SKIP="prefix,prefix" skips the launches whose tag starts with a
-        # prefix from the fourth replay on -- the step time then shows what removing that family could gain at most.
-        pre = [v for v in os.environ.get("RTP_EXP_SKIP", "").split(",") if v]
-        self._skip = [bool(pre) and any(L.tag.startswith(v) for v in pre) for L in self.launches]
-        self._replays = 0
 
     def __len__(self):
         return len(self.launches)
@@ -332,12 +317,9 @@ class LanePlan:
     def run(self, stream_ptr, multi=True):
         """stream_ptr: the caller's (main) stream handle.  multi=False replays everything on it in list order."""
         be = self.be
-        self._replays += 1
-        skip = self._skip if self._replays > 3 else None
         if not multi or len(self.lanes_used) <= 1 or not hasattr(be, "lane_streams"):
-            for i, L in enumerate(self.launches):
-                if skip is None or not skip[i]:
-                    L.fn(stream_ptr)
+            for L in self.launches:
+                L.fn(stream_ptr)
             return
         streams, ptrs = be.lane_streams(NLANES)    # [current, side...], their handles
         if self._events is None:
@@ -361,8 +343,7 @@ class LanePlan:
                 ev[j].wait(sp)
             if trace is not None and i in trace:
                 trace[i][0].record(streams[lane])
-            if skip is None or not skip[i]:
-                L.fn(sp)
+            L.fn(sp)
             if trace is not None and i in trace:
                 trace[i][1].record(streams[lane])
             if record[i]:

@@ -62,7 +62,7 @@ def init_state_dict(shapes, seed=0):
 class DataParallelTrainer:
     def __init__(self, name="hr3d", batch_per_gpu=8, dims=configs.NATIVE_DIMS, total_steps=1000, lr_max=None,
                  device="cuda:0", rank=0, world_size=1, use_graph=True, seed=0, backend=None, process_group=None, ar_buckets=None,
-                 stream=None):
+                 stream=None, options=None):
         self.spec = s = configs.spec(name)
         self.name, self.rank, self.world = name, rank, world_size
         if backend is None and str(device).startswith("cuda"):
@@ -72,19 +72,21 @@ class DataParallelTrainer:
         self.shapes = configs.param_shapes(name)
         self.flat = FlatParams(self.shapes, self.be.alloc)
         self.flat.load_state_dict(init_state_dict(self.shapes, seed))
-        # Gradient all-reduce in ONE bucket (the whole flat buffer after the backward sweep) or in TWO (RTP_AR_BUCKETS=2 / ar_buckets=2,
+        from .options import PlanOptions
+        opt = self.options = options if options is not None else PlanOptions.from_env()
+        # Gradient all-reduce in ONE bucket (the whole flat buffer after the backward sweep) or in TWO (options.ar_buckets / ar_buckets=2,
         # multi-rank eager mode only): the reference's DDP overlaps bucketed all-reduces with the tail of backward
         # (det3d/torchie/apis/train.py:284-291); here the deferred tail is flushed once early (graph.Graph.early_flush) so that
         # the gradients of transition2 .. pose_head -- a contiguous suffix of the flat buffer -- are reduced on the process
         # group's stream while stage 2 / layer 1 are still being swept.  One bucket stays the default (A/B: `allreduce_buckets`
         # in the bench line); with 8-33 MB of gradients per step the collective is a few percent of the step either way.
         if ar_buckets is None:
-            ar_buckets = int(os.environ.get("RTP_AR_BUCKETS", "1"))
+            ar_buckets = int(opt.ar_buckets)
         self.ar_buckets = 2 if (ar_buckets == 2 and world_size > 1 and not (use_graph and self.be.name == "hip")) else 1
         self.engine = PoseEngine(self.be, self.flat.values, s["arch"], s["final_fuse"], s["heads"], s["weight"],
                                  s["code_weights"], batch_per_gpu, dims, train=True, pgrads=self.flat.grads,
                                  test_cfg=configs.test_cfg(), lidar_channels=s.get("lidar_channels", 0),
-                                 early_flush=self.ar_buckets == 2)
+                                 early_flush=self.ar_buckets == 2, options=opt)
         self._ar_pending = None
         if self.ar_buckets == 2:
             self._install_early_bucket()
@@ -94,18 +96,18 @@ class DataParallelTrainer:
         self.pg = process_group
         self.use_graph = use_graph and self.be.name == "hip"
         self._graph = None
-        if self.use_graph and "RTP_LANES" not in os.environ:
+        if self.use_graph and opt.lanes is None:
             # hipStreamEndCapture crashes (ROCm 7.2) on a capture that forks into all six lane streams; three streams
             # capture and replay fine, so graph mode folds the lanes: {full}, {mid, low, lowest}, {weight gradients}
             from .lanes import LanePlan
-            gmap = [int(v) for v in os.environ.get("RTP_GRAPH_LANES", "0,1,1,2,2,1").split(",")]   # (A/B: "0,1,2,2,3,3" = lanes.LANE_MAP_4)
+            gmap = opt.int_list("graph_lanes")   # (A/B: "0,1,2,2,3,3" = lanes.LANE_MAP_4)
             self.engine.fwd_plan = LanePlan(self.be, self.engine.fwd, gmap)
             self.engine.bwd_plan = LanePlan(self.be, self.engine.bwd, gmap)
         # All work of a step goes to ONE explicit (non-default) HIP stream: a graph launched on the legacy NULL stream
         # was observed NOT to be ordered against the optimiser kernels queued behind it on ROCm 7.x.
         # High priority: this stream carries the full-resolution chain, the critical path of the lane plan (side lanes
         # keep the default priority, so their small kernels fill in around it instead of delaying it).
-        prio = int(os.environ.get("RTP_MAIN_PRIORITY", "-1"))
+        prio = -1
         # (stream: reuse another trainer's step stream.  A second set of streams lands on the four hardware queues in a different
         # pattern -- which lanes share a queue decides how the persistent kernels time-share the CUs: measured 12.6 instead of
         # 10.8 ms/step for a second model built on streams of its own in the same process)

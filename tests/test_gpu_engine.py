@@ -204,22 +204,23 @@ def test_graph_replay_equals_eager_lane_mode(tmp_path):
     assert rel_err(p1, p0) < 1e-4
 
 
-@pytest.mark.parametrize("env", [{"RTP_DEFER_WG": ""}, {"RTP_NO_LAZY_COEF": "1"}, {"RTP_NO_FUSE_STATS": "1", "RTP_NO_FUSED_FOLD": "1"}])
-def test_schedule_and_fusion_switches_do_not_change_the_result(hip, env, monkeypatch):
-    """The plan-level choices of round 2 only move work between launches or change where a launch is issued: the weight-gradient
-    lane on the main lane (RTP_DEFER_WG), GroupNorm-backward coefficients in the combine's prologue (RTP_NO_LAZY_COEF),
-    statistics from the fuse rows and the fold inside the tiled conv (RTP_NO_FUSE_STATS, RTP_NO_FUSED_FOLD).  One train step
+@pytest.mark.parametrize("env", [{"defer_wg": ""}, {"lazy_coef": 0}, {"fuse_stats": 0, "fused_fold": 0}])
+def test_schedule_and_fusion_switches_do_not_change_the_result(hip, env):
+    """The plan-level choices of round 2 only move work between launches or change where a launch is issued (rt_pose_amd.options.
+    PlanOptions): the weight-gradient lane on the main lane (defer_wg), GroupNorm-backward coefficients in the combine's prologue
+    (lazy_coef), statistics from the fuse rows and the fold inside the tiled conv (fuse_stats, fused_fold).  One train step
     with each switch flipped must give the default plan's loss and parameter gradients up to summation-order noise."""
+    from rt_pose_amd.options import PlanOptions
     name, dims, batch = "hr3d", (8, 16, 32), 2
     arch, fin, fout, fuse, heads, weight, cw = O.MODEL_CONFIGS[name]
     shapes = O.param_shapes(arch, fin, fout, fout, heads)
     sd = O.seeded_state_dict(shapes, seed=1)
     ex = O.synth_example(batch, 1, dims, seed=1234)
 
-    def one():
+    def one(options=None):
         flat = FlatParams(shapes, hip.alloc)
         flat.load_state_dict(sd)
-        eng = PoseEngine(hip, flat.values, arch, fuse, heads, weight, cw, batch, dims, pgrads=flat.grads)
+        eng = PoseEngine(hip, flat.values, arch, fuse, heads, weight, cw, batch, dims, pgrads=flat.grads, options=options)
         eng.load_input(ex["rdr"]["rdr_tensor"])
         eng.load_targets(ex["rdr"])
         eng.run_forward()
@@ -228,15 +229,13 @@ def test_schedule_and_fusion_switches_do_not_change_the_result(hip, env, monkeyp
         return float(eng.losses()["loss"]), flat.g.detach().float().cpu().clone(), [L.tag for L in eng.bwd], [L.tag for L in eng.fwd]
 
     l0, g0, bwd0, fwd0 = one()
-    for k, v in env.items():
-        monkeypatch.setenv(k, v)
-    l1, g1, bwd1, fwd1 = one()
+    l1, g1, bwd1, fwd1 = one(PlanOptions(**env))
     assert (bwd0, fwd0) != (bwd1, fwd1), "the switch changes the launch lists"
     # forward switches re-round a few folded weights / class-bias sums: two bf16 evaluations of one plan.  Measured against the
     # oracle's fp32 loss 36.4926 on this input: round 3 36.5615 / 36.5524 (default / un-fused fold), round 4 36.5047 / 36.6357 --
     # each within 0.4 % of fp32, up to 0.36 % from each other; backward-only switches agree to 1e-5 below
-    assert abs(l0 - l1) <= (8e-3 if "RTP_NO_FUSED_FOLD" in env else 2e-3) * abs(l0), (l0, l1)
-    if "RTP_DEFER_WG" in env or "RTP_NO_LAZY_COEF" in env:      # backward-only: same operands, same arithmetic
+    assert abs(l0 - l1) <= (8e-3 if "fused_fold" in env else 2e-3) * abs(l0), (l0, l1)
+    if "defer_wg" in env or "lazy_coef" in env:      # backward-only: same operands, same arithmetic
         assert rel_err(g1, g0) < 1e-5, rel_err(g1, g0)
     else:   # forward statistics summed in another order: a few folded weights move by a bf16 ulp, ReLU masks of single voxels
             # flip -- the same gate as two bf16 evaluations of one plan elsewhere in this file

@@ -1361,3 +1361,24 @@ def test_conv64_blocks_two_towers_in_one_launch(hip, case):
     lin = sum((F.conv3d(xr, W[t], None, padding=1) * gy[t].float().permute(0, 4, 1, 2, 3)).sum() for t in range(2))
     lin.backward()
     assert rel_err(dx.float().cpu().permute(0, 4, 1, 2, 3), xr.grad) < BF, "data gradient of both towers %r" % (case,)
+
+
+def test_conv64_blocks_refuses_a_ragged_width(hip):
+    """include/rtp.h documents W % 16 == 0 for rtp_conv64_blocks: the chain's fp32 partial sums are in brick layout, so W = 40 (three
+    brick columns = 48 voxel columns) would write past an `acc` of the documented n * voxels * 64 floats.  The entry
+    point returns RTP_ERR_UNSUPPORTED before anything is launched."""
+    from rt_pose_amd._lib import RtpError
+    n, d, h, w, C = 1, 2, 4, 40, 64
+    geom = Geom(n, d, h, w, d, h, w, 64, 64, 3, 1, 1)
+    dev = hip.device
+    xg = torch.zeros(n, d, h, w, C, dtype=torch.bfloat16, device=dev)
+    wf = torch.zeros(27, 32, 32, dtype=torch.bfloat16, device=dev)
+    y = [torch.zeros(n, d, h, w, 32, dtype=torch.bfloat16, device=dev) for _ in range(2)]
+    xs = [View(xg, n, d, h, w, C, 32 * k, 32) for k in range(2)]
+    yv = [View(t, n, d, h, w, 32, 0, 32) for t in y]
+    acc = hip.alloc((n, d * h * w, 64), "f32")
+    blocks = [[(wf, 0) for _ in range(2)] for _ in range(2)]
+    for kw in (dict(), dict(acc=acc, acc_in=False, acc_out=True)):
+        with pytest.raises(RtpError, match="UNSUPPORTED"):
+            hip.conv64_blocks(xs, blocks, 32, 1024, None, 32, None, None if kw else yv, geom, False, False, **kw)(hip.stream())
+    torch.cuda.synchronize()

@@ -252,14 +252,18 @@ def far_targets(sd, ex, fuse, nreg, seed=77):
     return ex
 
 
-@pytest.mark.parametrize("name,b,far", [("hr3d", 8, False), ("hr3d_one_hm_doppler", 8, False),
+@pytest.mark.parametrize("name,b,far", [("hr3d", 8, False), ("hr3d_one_hm", 8, False),
+                                        pytest.param("hr3d_one_hm_doppler", 8, False, marks=pytest.mark.slow),
                                         pytest.param("hr3d_one_hm_doppler", 8, True, marks=pytest.mark.slow),
-                                        ("hr3d_one_hm", 8, False), ("hr3d_one_hm_doppler_phase", 2, False),
+                                        ("hr3d_one_hm_doppler_phase", 2, False),
                                         pytest.param("hr3d_one_hm_doppler_phase", 2, True, marks=pytest.mark.slow)])
 def test_native_b8_train_step_per_tensor(hip, name, b, far):
     """The bench's own workload (B = 8 frames of [Cin,16,64,160]; the 64-channel phase configuration at B = 2): loss dict vs the
     oracle (2 %), every live parameter tensor's gradient vs the oracle's fp32 autograd AND vs the emulated bf16 plan, worst five
-    reported.  far: regression targets away from the L1 ties (far_targets) -- the tight gates of hr3d then apply."""
+    reported.  far: regression targets away from the L1 ties (far_targets) -- the tight gates of hr3d then apply.
+    hr3d_one_hm_doppler at B = 8 runs by default in test_one_heat_map_gate_is_summation_order_spread, whose gates are DERIVED per
+    tensor from the spread measured in the same run (the phase configuration there with RTP_SLOW=1); here the Doppler configurations
+    keep the coarse fixed guards of GATES (phase at B = 2 by default, the others with RTP_SLOW=1)."""
     arch, fin, fout, fuse, heads, weight, cw = O.MODEL_CONFIGS[name]
     spec = configs.spec(name)
     shapes = O.param_shapes(arch, fin, fout, fout, heads)
@@ -383,8 +387,9 @@ def _plan_grads(be, name, sd, ex, b, max_objs=None):
 SUM_ORDER_NOISE = 5e-7   # relative fp32 noise that stands for another summation order of a ~10^3-term fp32 dot product (~sqrt(864) * 2^-24 / 3)
 
 
-@pytest.mark.parametrize("poses", [1, pytest.param(8, marks=pytest.mark.slow)])
-def test_one_heat_map_gate_is_summation_order_spread(hip, poses):
+@pytest.mark.parametrize("name,b,poses", [("hr3d_one_hm_doppler", 8, 1), pytest.param("hr3d_one_hm_doppler_phase", 2, 1, marks=pytest.mark.slow),
+                                          pytest.param("hr3d_one_hm_doppler", 8, 8, marks=pytest.mark.slow)])
+def test_one_heat_map_gate_is_summation_order_spread(hip, name, b, poses):
     """hr3d_one_hm_doppler, B = 8: is the 15-20 % worst-tensor distance between the HIP kernels and the emulated plan "summation
     order only"?  Measured instead of asserted by hand: the emulated plan is run TWICE with fp32 noise of
     another summation order in front of every bf16 rounding (EmuBackend(noise=...), two seeds).  Two correct implementations of one
@@ -394,8 +399,14 @@ def test_one_heat_map_gate_is_summation_order_spread(hip, poses):
     batch, the reference's max_poses > 1 layout) -- round 3 blamed the ONE supervised voxel for the wide spread; the measurement
     says otherwise: with eight the emulation differs from itself by almost as much (the sensitivity belongs to this configuration's
     dense 32-channel input path, layer1 / stage2 tensors), and the kernels stay inside that spread either way.
-    Measured (round 4): poses 1: emu-emu worst 0.1765 / median 0.0169, HIP-emu 0.1774 / 0.0181, the same five tensors on top."""
-    name, b = "hr3d_one_hm_doppler", 8
+    Measured (round 4): poses 1: emu-emu worst 0.1765 / median 0.0169, HIP-emu 0.1774 / 0.0181, the same five tensors on top.
+    Round 6: (a) the gate is PER TENSOR -- tensor k of the HIP plan may be as far from its nearest emulation as
+    2 x the largest distance between any two of THREE emulations on that same tensor (+ 1 %); a mis-scaled small tensor, which a fixed
+    35 % bound lets through, is far outside its own spread.  Three samples estimate a tensor's spread coarsely, so up to 2 % of the
+    tensors may exceed their own bound as long as none exceeds 1.5 x the worst spread of all.  (b) "it is rounding noise" as a test:
+    the same plan with every bf16 buffer kept in fp32 (EmuBackend(exact=True): same fold / un-fold algebra, same launch list) lands
+    on the oracle -- the worst tensor within 2 % of the norm and at least 8 x closer than the bf16 emulations are -- so what
+    separates the bf16 plan from the oracle is the rounding of stored activations, not the plan."""
     arch, fin, fout, fuse, heads, weight, cw = O.MODEL_CONFIGS[name]
     spec = configs.spec(name)
     sd = O.seeded_state_dict(O.param_shapes(arch, fin, fout, fout, heads), seed=1)
@@ -411,28 +422,35 @@ def test_one_heat_map_gate_is_summation_order_spread(hip, poses):
         assert abs(float(losses[k].sum()) - want) < 2e-2 * abs(want) + 1e-4, (k, float(losses[k].sum()), want)
     assert float(losses["num_positive"]) == float(ref["num_positive"][0]) == b * poses
     got = OrderedDict((k, flat.grads[k].detach().float().cpu()) for k in live)
+    dead = [k for k in sd if rgrad[k] is None]
+    assert all(float(flat.grads[k].abs().max()) == 0 for k in dead)
+    del eng, flat
+    torch.cuda.empty_cache()
     orc = OrderedDict((k, rgrad[k]) for k in live)
-    emu = []
-    for seed in (11, 22):   # (the emulated plan = torch ops on the device: seconds instead of the ~125 s per run on the host's cores)
-        be = EmuBackend(fast=True, noise=SUM_ORDER_NOISE, seed=seed, device=DEV)
+
+    def emulate(**kw):   # (the emulated plan = torch ops on the device: seconds instead of minutes on the host's cores)
+        be = EmuBackend(fast=True, device=DEV, **kw)
         with be.on_device():
             e2, fl = _plan_grads(be, name, sd, ex, b, max_objs=mo)
-        emu.append(OrderedDict((k, fl.grads[k].detach().float().cpu()) for k in live))
+        g = OrderedDict((k, fl.grads[k].detach().float().cpu()) for k in live)
         del e2, fl
         torch.cuda.empty_cache()
-    r_ee = tensor_report(emu[0], emu[1], live)
+        return g
+    emu = [emulate(noise=SUM_ORDER_NOISE, seed=seed) for seed in (11, 22, 33)]
+    pairs = [(0, 1), (0, 2), (1, 2)]
+    r_ee = [tensor_report(emu[i], emu[j], live) for i, j in pairs]
     r_he = [tensor_report(got, e, live) for e in emu]
     r_ho, r_eo = tensor_report(got, orc, live), [tensor_report(e, orc, live) for e in emu]
-    top = max(r[2] for r in r_ee)
+    top = max(r[2] for r in r_ee[0])
     sig = lambda rows: [r for r in rows if r[5] > GATE_ABS * top]          # tensors that are not tiny-norm
     worst = lambda rows: max(r[3] for r in sig(rows))
     med = lambda rows: float(np.median([r[3] for r in rows]))
-    worst_ee, med_ee = worst(r_ee), med(r_ee)
+    worst_ee, med_ee = max(worst(rows) for rows in r_ee), max(med(rows) for rows in r_ee)
     worst_he, med_he = max(worst(rows) for rows in r_he), max(med(rows) for rows in r_he)
     worst_ho, worst_eo = worst(r_ho), max(worst(rows) for rows in r_eo)
     fmt = "   %-62s n=%-7d |g|=%.3e rel=%.4f cos=%.5f"
-    print("\n[%d pose(s) per frame] emulation (seed 11) vs emulation (seed 22), noise %.0e -- worst 5:\n%s"
-          % (poses, SUM_ORDER_NOISE, "\n".join(fmt % r[:5] for r in r_ee[:5])))
+    print("\n[%s B=%d, %d pose(s) per frame] emulation (seed 11) vs emulation (seed 22), noise %.0e -- worst 5:\n%s"
+          % (name, b, poses, SUM_ORDER_NOISE, "\n".join(fmt % r[:5] for r in r_ee[0][:5])))
     print("HIP vs emulation (seed 11) -- worst 5:\n%s" % "\n".join(fmt % r[:5] for r in r_he[0][:5]))
     print("HIP vs oracle -- worst 3:\n%s" % "\n".join(fmt % r[:5] for r in r_ho[:3]))
     print("worst tensor: emu-emu %.4f  hip-emu %.4f  emu-oracle %.4f  hip-oracle %.4f ; median: emu-emu %.4f  hip-emu %.4f"
@@ -441,3 +459,21 @@ def test_one_heat_map_gate_is_summation_order_spread(hip, poses):
                                               worst_he, worst_ee)
     assert med_he <= 1.5 * med_ee + 0.005, (med_he, med_ee)
     assert worst_ho <= 1.5 * worst_eo + 0.01, (worst_ho, worst_eo)
+    # ---- (a) per tensor: HIP-to-nearest-emulation against that tensor's own emulation-to-emulation spread
+    spread = {k: max(next(r[3] for r in rows if r[0] == k) for rows in r_ee) for k in live}
+    tiny = {r[0] for r in r_he[0] if min(next(q[5] for q in rows if q[0] == r[0]) for rows in r_he) <= GATE_ABS * top}
+    dist = {k: min(next(r[3] for r in rows if r[0] == k) for rows in r_he) for k in live}
+    over = sorted(((dist[k] / (2.0 * spread[k] + 0.01), k, dist[k], spread[k]) for k in live if k not in tiny and dist[k] > 2.0 * spread[k] + 0.01),
+                  reverse=True)
+    print("per-tensor gate (2 x own spread + 1 %%): %d of %d tensors over it%s"
+          % (len(over), len(live), "".join("\n   %-62s hip-emu %.4f  own spread %.4f" % (k, d, sp) for _, k, d, sp in over[:5])))
+    assert len(over) <= max(1, len(live) // 50), over[:5]
+    assert all(d <= 1.5 * worst_ee + 0.01 for _, _, d, _ in over), over[:5]
+    # ---- (b) the same plan with fp32 storage: the spread collapses, i.e. it IS the rounding of the stored activations
+    exact = emulate(exact=True)
+    r_xo = tensor_report(exact, orc, live)
+    worst_xo, med_xo = max(r[3] for r in r_xo), med(r_xo)   # (every tensor: nothing is "tiny" by absolute error here)
+    print("fp32-storage plan vs oracle: worst %.5f median %.6f (bf16 emulations vs oracle: worst %.4f)\n%s"
+          % (worst_xo, med_xo, worst_eo, "\n".join(fmt % r[:5] for r in r_xo[:3])))
+    assert worst_xo <= 0.02 and worst_xo * 8 <= worst_eo, (worst_xo, worst_eo)
+    assert med_xo <= 2e-3, med_xo

@@ -86,7 +86,7 @@ def test_hr3d_plan_hazards_are_covered():
     eng = PoseEngine(be, flat.values, s["arch"], s["final_fuse"], s["heads"], s["weight"], s["code_weights"], 1,
                      (8, 16, 32), train=True, pgrads=flat.grads)
     assert {L.lane for L in eng.fwd} >= {lanes.L_FULL, lanes.L_MID, lanes.L_LOW}
-    # (the full-resolution weight-gradient lane L_WG is issued on the main lane by default: graph.Graph.emit_bwd, RTP_DEFER_WG)
+    # (the full-resolution weight-gradient lane L_WG is issued on the main lane by default: graph.Graph.emit_bwd, PlanOptions.defer_wg)
     assert {L.lane for L in eng.bwd} >= {lanes.L_FULL, lanes.L_MID, lanes.L_LOW, lanes.L_WG_LOW}
     assert any(L.tag.startswith("wgrad:head.") and L.lane == lanes.L_FULL for L in eng.bwd)
     nf, nb = _check(eng.fwd), _check(eng.bwd)
@@ -242,7 +242,7 @@ def test_four_stream_map_is_chosen_where_it_pays_and_orders_every_hazard():
 
 
 def test_merge_launches_groups_of_three_and_four():
-    """merge_launches with more than two launches per group (the head towers' four weight gradients, RTP_MERGE_HEAD_WG4): everything
+    """merge_launches with more than two launches per group (the head towers' four weight gradients, a four-launch group): everything
     joins the group's first launch, reads / writes are the union, a group with one dependent member is refused as a whole."""
     from rt_pose_amd.lanes import Launch, merge_launches, _order_preds
 

@@ -131,14 +131,14 @@ def test_flat_params_runs():
 
 
 def test_no_tail_switch_keeps_every_deferred_item(monkeypatch):
-    """RTP_NO_TAIL (the per-item A/B switch of DESIGN 8d) must emit one launch per deferred item, not drop them:
+    """PlanOptions.no_tail (the per-item A/B switch, RTP_PLAN="no_tail") must emit one launch per deferred item, not drop them:
     parameter gradients are identical with and without it."""
     grads = {}
     for flag in (None, "1"):
         if flag:
-            monkeypatch.setenv("RTP_NO_TAIL", flag)
+            monkeypatch.setenv("RTP_PLAN", "no_tail")
         else:
-            monkeypatch.delenv("RTP_NO_TAIL", raising=False)
+            monkeypatch.delenv("RTP_PLAN", raising=False)
         eng, flat, sd, ex, _ = make("hr3d", exact=True)
         eng.load_input(ex["rdr"]["rdr_tensor"])
         eng.load_targets(ex["rdr"])
@@ -221,7 +221,7 @@ def test_lidar_fusion_head_matches_oracle_concat():
 
 
 def test_fused_stride2_data_gradient_route(monkeypatch):
-    monkeypatch.setenv("RTP_FUSED_S2", "1")   # built and tested, off by default (graph.ConvOp._fusable)
+    monkeypatch.setenv("RTP_PLAN", "fused_s2=1")   # built and tested, off by default (graph.ConvOp._fusable)
     """Volumes wide enough for the stride-2 parity-class kernel (Wo % 16 == 0): the first conv of a fuse chain from branch 0
     is the last gradient contribution to the branch-0 output and writes its finished gradient (weight gradient -> slab
     contraction -> data gradient); gradients still equal the oracle's."""
@@ -252,7 +252,7 @@ def test_fused_stride2_data_gradient_route(monkeypatch):
 def test_launch_list_reorderings_keep_dependencies_and_results(monkeypatch):
     """lanes.main_row_first / lanes.hoist_tagged permute a launch list only inside the read/write relations of the original
     order (checked here with an independent walk), refuse a permutation that would break one, and the plan computes the same
-    losses and gradients with the forward list in creation order (RTP_FWD_ROW0_FIRST=0) and with the backward hoist switched off."""
+    losses and gradients with the forward list in creation order (PlanOptions.fwd_row0_first = 0) and with the backward hoist switched off."""
     from rt_pose_amd.lanes import Launch, _order_preds, hoist_tagged, main_row_first
 
     def respects(orig, new):
@@ -260,9 +260,9 @@ def test_launch_list_reorderings_keep_dependencies_and_results(monkeypatch):
         preds = _order_preds(orig)
         return len(new) == len(orig) and all(pos[id(orig[q])] < pos[id(orig[k])] for k in range(len(orig)) for q in preds[k])
 
-    monkeypatch.setenv("RTP_FWD_ROW0_FIRST", "0")      # creation order (the engine applies main_row_first itself by default)
+    monkeypatch.setenv("RTP_PLAN", "fwd_row0_first=0")      # creation order (the engine applies main_row_first itself by default)
     eng, flat, sd, ex, _ = make("hr3d", exact=True)
-    monkeypatch.delenv("RTP_FWD_ROW0_FIRST")
+    monkeypatch.delenv("RTP_PLAN")
     fwd2 = main_row_first(eng.fwd)
     assert [L.tag for L in fwd2] != [L.tag for L in eng.fwd] and respects(eng.fwd, fwd2)
     assert [L.tag for L in make("hr3d", exact=True)[0].fwd] == [L.tag for L in fwd2], "the default forward list is the re-ordered one"
@@ -274,20 +274,19 @@ def test_launch_list_reorderings_keep_dependencies_and_results(monkeypatch):
     assert hoist_tagged([a, c, b], r"r:b", r"w:a") == [a, c, b]
     assert [L.tag for L in hoist_tagged([a, c, b], r"r:b", r"o:c")] == ["w:a", "r:b", "o:c"]
 
-    def run(env):
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
+    def run(plan):
+        if plan:
+            monkeypatch.setenv("RTP_PLAN", plan)
         e, f, _, x, _ = make("hr3d", exact=True)
         e.load_input(x["rdr"]["rdr_tensor"])
         e.load_targets(x["rdr"])
         e.run_forward()
         e.run_loss_backward()
-        for k in env:
-            monkeypatch.delenv(k)
+        monkeypatch.delenv("RTP_PLAN", raising=False)
         return e.losses()["loss"].clone(), {k: v.clone() for k, v in f.grads.items()}
 
-    l0, g0 = run({})
-    for env in ({"RTP_FWD_ROW0_FIRST": "0"}, {"RTP_BWD_F10_FIRST": "0"}):
+    l0, g0 = run("")
+    for env in ("fwd_row0_first=0", "bwd_f10_first=0"):
         l1, g1 = run(env)
         assert torch.equal(l0, l1), env
         assert all(torch.equal(g0[k], g1[k]) for k in g0), env
@@ -296,9 +295,9 @@ def test_launch_list_reorderings_keep_dependencies_and_results(monkeypatch):
 def test_head_towers_over_a_wide_feature_share_their_launches(monkeypatch):
     """Graph.conv_pair: SepHead's two first convs over the 128-channel feature of the one-heat-map configs (center_head.py:86-93)
     run 64 wide -- one launch per 64-channel slice forward, one per 64 input channels for the data gradient, which writes the SUM
-    over both towers -- and give what the per-tower slice route (RTP_PAIR_HEADS=0) gives."""
+    over both towers -- and give what the per-tower slice route (PlanOptions.pair_heads = 0) gives."""
     def grads(paired):
-        monkeypatch.setenv("RTP_PAIR_HEADS", "1" if paired else "0")
+        monkeypatch.setenv("RTP_PLAN", "pair_heads=%d" % int(paired))
         eng, flat, sd, ex, _ = make("hr3d_one_hm_doppler", exact=True)
         eng.load_input(ex["rdr"]["rdr_tensor"])
         eng.load_targets(ex["rdr"])
