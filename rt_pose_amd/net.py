@@ -53,36 +53,48 @@ def build_backbone(g: Graph, x_f32, arch, dims, prefix="backbone.backbone", live
     ys = [_resblock(g, p, t0, "l1")]
     for stage in (2, 3, 4):
         nb = stage
-        sp = "%s.stage%d.0" % (prefix, stage)
-        # Creation order = launch order, and the backward sweep runs it in reverse: the existing branches' blocks are created
-        # BEFORE the transition conv, so that a branch block's first conv -- whose data gradient runs on the LDS-tiled kernel --
-        # is the last gradient contribution to the previous stage's output and can absorb the others (graph.ConvOp._fusable)
-        xs = [_resblock(g, "%s.branches.%d.0" % (sp, i), ys[i], "s%d.b%d" % (stage, i)) for i in range(nb - 1)]
-        new = _seq(g, "%s.transition%d.%d.0" % (prefix, stage - 1, stage - 1), ys[-1], "t%d" % (stage - 1), 3, 2, True)
-        xs.append(_resblock(g, "%s.branches.%d.0" % (sp, nb - 1), new, "s%d.b%d" % (stage, nb - 1)))
         rows = nb if (stage < 4 or live_rows_last is None) else live_rows_last
-        # rows are CREATED last-to-first: the stride-2 conv that starts a lower row's chain from branch 0 then precedes row 0's
-        # fuse node, i.e. it is the first-created consumer of the branch-0 output and its (tiled) data gradient can absorb the
-        # other gradient contributions to that full-resolution tensor (graph.ConvOp._fusable)
-        ys = [None] * rows
-        for i in reversed(range(rows)):
-            g.group = ("fuse%d" % stage, i)   # (graph.Graph.build_backward may sweep a fuse block's rows in another order)
-            terms = []
-            for j in range(nb):
-                if j == i:
-                    terms.append(xs[j])
-                elif j > i:
-                    terms.append(_seq(g, "%s.fuse_layers.%d.%d" % (sp, i, j), xs[j], "s%d.f%d%d" % (stage, i, j), 1, 1, False,
-                                      want_stats=False))   # feeds only the fuse sum
-                else:
-                    t = xs[j]
-                    for k in range(i - j):
-                        t = _seq(g, "%s.fuse_layers.%d.%d.%d" % (sp, i, j, k), t, "s%d.f%d%d.%d" % (stage, i, j, k), 3, 2,
-                                 relu=(k != i - j - 1), want_stats=(k != i - j - 1))
-                    terms.append(t)
-            ys[i] = g.fuse("s%d.row%d" % (stage, i), terms, relu=True, want_stats=stage < 4)   # (stage-4 rows feed no GroupNorm)
-        g.group = None
+        tp = "%s.transition%d.%d.0" % (prefix, stage - 1, stage - 1)
+        last = ys[-1]
+        ys = hr_module(g, "%s.stage%d.0" % (prefix, stage), stage, ys, lambda: _seq(g, tp, last, "t%d" % (stage - 1), 3, 2, True), rows)
     return ys
+
+
+def hr_module(g: Graph, sp, stage, ys, new_branch, rows=None):
+    """One HighResolutionModule (hr3d.py:205-229) of `stage` branches: ys = the stage's inputs for the existing branches,
+    new_branch() -> the input of the new lowest branch (the transition conv of HighResolution3DNet.forward, hr3d.py:386,394; called
+    after the existing branches' blocks are created).  -> the `rows` first fuse rows (default: all)."""
+    nb = stage
+    ch = [y.c_real for y in ys]
+    # Creation order = launch order, and the backward sweep runs it in reverse: the existing branches' blocks are created
+    # BEFORE the transition conv, so that a branch block's first conv -- whose data gradient runs on the LDS-tiled kernel --
+    # is the last gradient contribution to the previous stage's output and can absorb the others (graph.ConvOp._fusable)
+    xs = [_resblock(g, "%s.branches.%d.0" % (sp, i), ys[i], "s%d.b%d" % (stage, i)) for i in range(nb - 1)]
+    new = new_branch()
+    xs.append(_resblock(g, "%s.branches.%d.0" % (sp, nb - 1), new, "s%d.b%d" % (stage, nb - 1)))
+    rows = nb if rows is None else rows
+    # rows are CREATED last-to-first: the stride-2 conv that starts a lower row's chain from branch 0 then precedes row 0's
+    # fuse node, i.e. it is the first-created consumer of the branch-0 output and its (tiled) data gradient can absorb the
+    # other gradient contributions to that full-resolution tensor (graph.ConvOp._fusable)
+    out = [None] * rows
+    for i in reversed(range(rows)):
+        g.group = ("fuse%d" % stage, i)   # (graph.Graph.build_backward may sweep a fuse block's rows in another order)
+        terms = []
+        for j in range(nb):
+            if j == i:
+                terms.append(xs[j])
+            elif j > i:
+                terms.append(_seq(g, "%s.fuse_layers.%d.%d" % (sp, i, j), xs[j], "s%d.f%d%d" % (stage, i, j), 1, 1, False,
+                                  want_stats=False))   # feeds only the fuse sum
+            else:
+                t = xs[j]
+                for k in range(i - j):
+                    t = _seq(g, "%s.fuse_layers.%d.%d.%d" % (sp, i, j, k), t, "s%d.f%d%d.%d" % (stage, i, j, k), 3, 2,
+                             relu=(k != i - j - 1), want_stats=(k != i - j - 1))
+                terms.append(t)
+        out[i] = g.fuse("s%d.row%d" % (stage, i), terms, relu=True, want_stats=stage < 4)   # (stage-4 rows feed no GroupNorm)
+    g.group = None
+    return out
 
 
 def build_hrnet3d(g: Graph, x_f32, arch, dims, final_fuse, prefix="backbone"):
@@ -106,8 +118,14 @@ def build_hrnet3d(g: Graph, x_f32, arch, dims, final_fuse, prefix="backbone"):
             raise NotImplementedError("shared_conv over the %d-channel plain concatenation (final_fuse=%r): not built; use "
                                       "in_channels == share_conv_channel, or final_fuse='conat_conv'" % (sum(ch), final_fuse))
         return g.concat("final.cat", ys)
-    # cat(x0, up(x1), up(x2), up(x3)) -> 1x1x1 conv  ==  sum_j up(conv1x1_j(x_j))   (both ops are linear and
-    # the upsample acts per channel), so the 192-channel concat is never materialised.
+    return final_concat_conv(g, ys, prefix)
+
+
+def final_concat_conv(g: Graph, ys, prefix="backbone"):
+    """HRNet3D.forward's 'conat_conv' fuse (hrnet3d.py:37-42): cat(x0, up(x1), up(x2), up(x3)) -> final_conv 1x1x1 (with bias)
+    ==  sum_j up(conv1x1_j(x_j))  -- both ops are linear and the upsample acts per channel -- so the 192-channel concatenation is
+    never materialised: one 1x1x1 conv per branch over its column block of the weight, then one fuse row."""
+    ch = [y.c_real for y in ys]
     total = sum(ch)
     off, terms = 0, []
     for j, y in enumerate(ys):
