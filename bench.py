@@ -593,8 +593,8 @@ def main():
         if extra:
             line["numerics_artefacts"] = extra
     # whole-step HBM traffic from the separate PMC passes (tools/pmc_step.sh), against the fused-minimum algorithmic bytes
-    pj = next((q for q in (os.path.join(ROOT, "profiles", f) for f in ("r05_pmc_step_traffic.json", "r04_pmc_step_traffic.json", "r03_pmc_step_traffic.json")) if os.path.exists(q)),
-              os.path.join(ROOT, "profiles", "r03_pmc_step_traffic.json"))
+    pj = next((q for q in (os.path.join(ROOT, "profiles", f) for f in ("r06_pmc_step_traffic.json", "r05_pmc_step_traffic.json", "r04_pmc_step_traffic.json")) if os.path.exists(q)),
+              os.path.join(ROOT, "profiles", "r06_pmc_step_traffic.json"))
     if world == 1 and "roofline" in line and os.path.exists(pj) and args.model == "hr3d" and args.batch == 8:
         try:
             with open(pj) as f:
