@@ -313,7 +313,8 @@ def abs_pjpe(pred, gt):
 
 
 # ----------------------------------------------------------------------------
-# train-step rule (restated by formula; the reference file is un-importable on py3.10)
+# train-step rule -- restated from the formulas; pinned (round 6) against steps captured from the reference's own OptimWrapper + OneCycle
+# (tests/golden/gen_golden_optim.py, tests/test_oracle_golden.py::test_train_step_rule_against_the_reference_optimiser)
 #   torchie/apis/train.py:157-174, solver/fastai_optim.py:121-175,
 #   solver/learning_schedules_fastai.py:53-95, trainer/hooks/optimizer.py:14-24
 # ----------------------------------------------------------------------------
