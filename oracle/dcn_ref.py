@@ -5,7 +5,10 @@ and its CUDA sources (det3d/ops/dcn/src/*.cu, THC headers, nvcc) cannot be built
 file restates the published algorithm from the reference's own kernels and is held only by property tests
 (tests/test_dcn_oracle.py: zero offsets == F.conv2d, integer offsets == shifted conv, out-of-window taps == 0,
 mask == 1 reduces v2 to v1, fp64 gradcheck) and a small fixed case whose expected values this file itself produced
-(tests/golden/dcn_known_answer.json -- not an external pin; see its provenance).
+(tests/golden/dcn_known_answer.json -- not an external pin; see its provenance).  Round 6 adds a second opinion that shares no
+code with this file: the same operator written on ATen's F.grid_sample (bilinear, zeros padding, align_corners) agrees in values and
+in every gradient to 1e-10 (tests/test_dcn_oracle.py::test_dcn_ref_agrees_with_an_independent_grid_sample_formulation) -- a
+cross-check by a third party's sampler, still not a pin by the reference.
 
 Restated from det3d/ops/dcn/src/deform_conv_cuda_kernel.cu:
   bilinear sample with per-corner bounds ................. :85-115  (dmcn_im2col_bilinear :467-495)

@@ -94,3 +94,59 @@ def run_known_answer(dcn):
 
 def test_small_fixed_case_regression():
     run_known_answer(lambda x, off, w: deform_conv2d(x, off, w, 1, 0, 1, 1, 1))
+
+
+def _deform_conv2d_via_grid_sample(x, offset, weight, stride, padding, dilation, groups, dg, mask=None):
+    """The same operator written a second, independent way: every (deformable group, tap) is ONE call of ATen's
+    F.grid_sample(mode='bilinear', padding_mode='zeros', align_corners=True) at the positions  base + tap * dilation + offset
+    -- ATen's bilinear sampler treats each out-of-image corner as zero, which is the per-corner rule of
+    deform_conv_cuda_kernel.cu:85-115 -- followed by an einsum with the weights.  No code shared with oracle/dcn_ref.py."""
+    B, C, H, W = x.shape
+    co, cig, kh, kw = weight.shape
+    Ho = (H + 2 * padding - (dilation * (kh - 1) + 1)) // stride + 1
+    Wo = (W + 2 * padding - (dilation * (kw - 1) + 1)) // stride + 1
+    cpg = C // dg
+    ys = (torch.arange(Ho, dtype=x.dtype) * stride - padding).view(1, Ho, 1)
+    xs = (torch.arange(Wo, dtype=x.dtype) * stride - padding).view(1, 1, Wo)
+    cols = x.new_zeros(B, C, kh * kw, Ho, Wo)
+    for g in range(dg):
+        for i in range(kh):
+            for j in range(kw):
+                k = i * kw + j
+                oh = offset[:, (g * kh * kw + k) * 2]
+                ow = offset[:, (g * kh * kw + k) * 2 + 1]
+                py, px = ys + i * dilation + oh, xs + j * dilation + ow            # [B, Ho, Wo] pixel coordinates
+                grid = torch.stack([2 * px / max(W - 1, 1) - 1, 2 * py / max(H - 1, 1) - 1], dim=-1)   # (x, y) in [-1, 1], align_corners
+                v = F.grid_sample(x[:, g * cpg:(g + 1) * cpg], grid, mode="bilinear", padding_mode="zeros", align_corners=True)
+                if mask is not None:
+                    v = v * mask[:, g * kh * kw + k].unsqueeze(1)
+                cols[:, g * cpg:(g + 1) * cpg, k] = v
+    cols = cols.view(B, groups, C // groups, kh * kw, Ho, Wo)
+    w = weight.view(groups, co // groups, cig, kh * kw)
+    return torch.einsum("bgckhw,gock->bgohw", cols, w).reshape(B, co, Ho, Wo)
+
+
+@pytest.mark.parametrize("stride,padding,dilation,groups,dg,modulated", [(1, 1, 1, 1, 4, False), (2, 1, 1, 1, 2, False), (1, 2, 2, 2, 2, True),
+                                                                          (1, 1, 1, 1, 1, True)])
+def test_dcn_ref_agrees_with_an_independent_grid_sample_formulation(stride, padding, dilation, groups, dg, modulated):
+    """A second opinion on the unpinned oracle (the reference ships no vectors and its CUDA does not build here): ATen's own bilinear
+    sampler, a different code path by different authors, gives the same forward values and the same gradients with respect to input,
+    offsets, mask and weights -- offsets up to +-2.5 px so that samples leave the image on every side."""
+    torch.manual_seed(3)
+    B, C, H, W, co, k = 2, 8, 7, 9, 6, 3
+    x = torch.randn(B, C, H, W, dtype=torch.float64, requires_grad=True)
+    Ho = (H + 2 * padding - (dilation * (k - 1) + 1)) // stride + 1
+    Wo = (W + 2 * padding - (dilation * (k - 1) + 1)) // stride + 1
+    off = (torch.randn(B, dg * 2 * k * k, Ho, Wo, dtype=torch.float64) * 1.3).requires_grad_(True)
+    msk = torch.rand(B, dg * k * k, Ho, Wo, dtype=torch.float64).requires_grad_(True) if modulated else None
+    wt = torch.randn(co, C // groups, k, k, dtype=torch.float64, requires_grad=True)
+    a = deform_conv2d(x, off, wt, stride, padding, dilation, groups, dg, mask=msk)
+    b = _deform_conv2d_via_grid_sample(x, off, wt, stride, padding, dilation, groups, dg, mask=msk)
+    assert a.shape == b.shape and torch.allclose(a, b, rtol=1e-10, atol=1e-10), float((a - b).abs().max())
+    gy = torch.randn_like(a)
+    wrt = [t for t in (x, off, wt, msk) if t is not None]
+    ga = torch.autograd.grad(a, wrt, gy, retain_graph=True)
+    gb = torch.autograd.grad(b, wrt, gy)
+    for u, v, name in zip(ga, gb, ("input", "offset", "weight", "mask")):
+        # offsets that land exactly on an integer coordinate have a one-sided derivative: none do with random fp64 offsets
+        assert torch.allclose(u, v, rtol=1e-8, atol=1e-9), (name, float((u - v).abs().max()))
