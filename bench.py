@@ -497,6 +497,42 @@ def main():
                             "hbm_view": {"achieved": round(best[3], 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                                          "frac": round(best[3] / PEAK_HBM_GBPS, 4)},
                             "families": detail}
+        # ... and the same family at FULL WIDTH: the plan's width hints give the main lane's launches 192 of 256 workgroups so that the
+        # side lanes' chains run beside them -- in the single-stream timing above nothing runs beside them, so the hints
+        # only cost.  A second plan built without hints, same kernels, same events, 3 single-stream steps: what the kernel does with
+        # the chip to itself.  Reported beside `frac` (which stays the figure of the plan as shipped).
+        try:
+            from rt_pose_amd.options import PlanOptions
+            opt = PlanOptions.from_env()
+            opt.width_hints = ""
+            ftr = DataParallelTrainer(args.model, args.batch, dims, total_steps=100, device=dev, use_graph=False, backend=be,
+                                      stream=tr.stream, options=opt)
+            ftr.load(ex)
+            ftr.engine.use_lanes = False
+            for _ in range(2):
+                ftr.step()
+            torch.cuda.synchronize()
+            fw = (_lib.FAM_CONV_TILED_FULL, _lib.FAM_CONV_TILED_FULL_BWD)
+            for fam in fw:
+                be.prof_collect(fam)          # (drop what the warm-up steps recorded)
+                be.prof_enable(fam, True)
+            for _ in range(3):
+                ftr.step()
+            torch.cuda.synchronize()
+            parts = [be.prof_collect(f) for f in fw]
+            for fam in fw:
+                be.prof_enable(fam, False)
+            ms, cnt = sum(p_[0] for p_ in parts), sum(p_[1] for p_ in parts)
+            fg = ftr.engine.graph
+            if cnt:
+                tf = fg.flops["conv_tiled_full"] * 3 / (ms * 1e-3) / 1e12
+                line["roofline"]["full_width"] = {"what": "the same launches from a plan WITHOUT width hints (256 workgroups), single stream",
+                                                  "avg_us_per_launch": round(1e3 * ms / cnt, 2), "tflops": round(tf, 2),
+                                                  "frac": round(tf / PEAK_BF16_TFLOPS, 4)}
+            del ftr
+            torch.cuda.empty_cache()
+        except Exception as e:   # informational
+            line["roofline"]["full_width"] = {"error": repr(e)[:200]}
     # The other shipped configs (configs/cruw_pose/hr3d_one_hm_doppler*.py) and the DCN-head variant of the headline model (BASELINE
     # config 4), driver-timed in the same run: 3 warm-up + 10 timed train steps each at the same 8 frames per GPU (their plans are
     # built beside the headline model's)
