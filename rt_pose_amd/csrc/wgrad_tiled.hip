@@ -40,8 +40,8 @@
 //   one 16 x 16 tile per wave for all 27 taps, every haloed x fragment read once (640 reads per brick and workgroup, 160 per
 //     wave): the right shape on paper, but hipcc's register allocator lets the 27 accumulator tiles rotate through the file
 //     (three-address MFMA: the result lands in the dying operand's registers) and pays 54 copies + 20 spills per brick; with the
-//     accumulator tied by inline assembly it splits every tile's live range instead (310 copies).  Kept as
-//     tools/ubench/wgrad_tile_per_wave_attempt.hip.txt for a round with a hand-scheduled loop.
+//     accumulator tied by inline assembly it splits every tile's live range instead (310 copies).  The attempt's
+//     source is in the repository history (round 4, tools/ubench/) for a round with a hand-scheduled loop.
 #ifndef WG_NCW
 #define WG_NCW 4
 #endif
