@@ -20,7 +20,7 @@ def pytest_configure(config):
 GPU_ORDER_FIRST = ["test_gpu_engine.py", "test_gpu_kernels_vs_oracle.py", "test_gpu_modules_vs_oracle.py", "test_gpu_optimizer_golden.py", "test_gpu_native.py",
                    "test_gpu_dcn.py", "test_gpu_dcn_binding.py", "test_gpu_dcn_head.py", "test_gpu_input_pipeline.py",
                    "test_gpu_lidar.py", "test_gpu_lidar_fusion.py", "test_gpu_boundary.py"]
-GPU_ORDER_LAST = ["test_gpu_kernels.py", "test_gpu_rccl.py", "test_gpu_dp_one_device.py", "test_gpu_bench_two_ranks.py"]
+GPU_ORDER_LAST = ["test_gpu_kernels.py", "test_gpu_bench_contract.py", "test_gpu_rccl.py", "test_gpu_dp_one_device.py", "test_gpu_bench_two_ranks.py"]
 
 
 def _order_key(item):
