@@ -62,3 +62,17 @@ def test_evaluate_against_the_reference_evaluation():
             assert np.isclose(res["seq_results"][seq][k], v, rtol=1e-9, atol=0), (seq, k)
     # the inputs were not modified (the reference's PJPE shifts its arguments in place; evaluate() must not)
     assert z["detections"] == dets0 and z["gt"] == gt0
+
+
+def test_prediction_file_is_byte_identical_to_the_reference_save_pred(tmp_path):
+    """tests/golden/eval_golden.json["reference_prediction_file"]: the text tools/test.py's own save_pred (:41-63) wrote for the same
+    detections and sequence table (gen_golden_eval.py runs the function as the reference wrote it).  E.save_pred must produce the same
+    path below the root and the same bytes -- sequence order by name, frame order by int(frame), json indent 2."""
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "eval_golden.json")) as f:
+        z = json.load(f)
+    ref = z["reference_prediction_file"]
+    path = E.save_pred(z["detections"], str(tmp_path), ref["checkpoint_name"], ref["dataset_split"], z["seq_id_to_name"])
+    assert os.path.relpath(path, str(tmp_path)) == ref["relative_path"]
+    with open(path) as f:
+        assert f.read() == ref["text"]
