@@ -148,3 +148,63 @@ def test_mpjpe_matches_reference_vectors(golden):
     m = float(np.mean(golden["pjpe.rel"])) * 1000
     assert res["seq_results"]["s1"]["MPJPE"] == pytest.approx(m / 2) and res["seq_results"]["s2"]["MPJPE"] == pytest.approx(m)
     assert res["results"]["MPJPE"] == pytest.approx(0.75 * m)
+
+
+def test_registry_behaves_like_the_reference_registry_class():
+    """Differential test against the reference's own det3d/utils/registry.py (loaded at file level; it imports nothing but inspect
+    and det3d.torchie.is_str): the same operations on both Registry classes give the same results and the same exception TYPES --
+    registration (decorator without parens), duplicate, non-class, lookup, build_from_cfg with default_args, unknown type, non-dict
+    cfg, non-str / non-class type."""
+    import importlib.util
+    import sys
+    import types
+    ref_path = "/root/reference/det3d/utils/registry.py"
+    if not os.path.exists(ref_path):
+        pytest.skip("needs /root/reference (authoring container)")
+    before = dict(sys.modules)
+    try:
+        tor = types.ModuleType("det3d.torchie")
+        tor.is_str = lambda x: isinstance(x, str)
+        pkg = types.ModuleType("det3d")
+        pkg.__path__ = []
+        pkg.torchie = tor
+        sys.modules.update({"det3d": pkg, "det3d.torchie": tor})
+        spec = importlib.util.spec_from_file_location("ref_registry", ref_path)
+        ref = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(ref)
+    finally:
+        for k in list(sys.modules):
+            if k not in before:
+                del sys.modules[k]
+        sys.modules.update(before)
+
+    def script(Reg, build):
+        out = []
+
+        def attempt(f):
+            try:
+                out.append(("ok", f()))
+            except Exception as e:   # noqa: BLE001 -- the exception TYPE is the observable
+                out.append(("raise", type(e).__name__))
+        reg = Reg("thing")
+
+        class A:
+            def __init__(self, x=1, y=2):
+                self.x, self.y = x, y
+
+        attempt(lambda: reg.register_module(A) is A)
+        attempt(lambda: reg.register_module(A))                                   # duplicate
+        attempt(lambda: reg._register_module(lambda: 0))                          # not a class
+        attempt(lambda: (reg.get("A") is A, reg.get("B")))
+        attempt(lambda: reg.name)
+        attempt(lambda: sorted(reg.module_dict))
+        attempt(lambda: (lambda o: (o.x, o.y))(build(dict(type="A", x=5), reg, dict(y=7, x=9))))
+        attempt(lambda: build(dict(type=A), reg).x)
+        attempt(lambda: build(dict(type="Nope"), reg))
+        attempt(lambda: build(["type"], reg))
+        attempt(lambda: build(dict(x=1), reg))
+        attempt(lambda: build(dict(type=3), reg))
+        attempt(lambda: build(dict(type="A"), reg, default_args=[1]))
+        return out
+
+    assert script(Registry, build_from_cfg) == script(ref.Registry, ref.build_from_cfg)
